@@ -1,0 +1,145 @@
+"""ctypes front-end of the plain-C oracle (TEST INFRASTRUCTURE ONLY).
+
+Independent restatement of the parameter-block layout and of the map from packed
+gradients back to the reference's ``state_dict`` names; cites the same reference lines as
+``pi_oracle_impl.h``.  Never imported by ``percnn_amd``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libpi_oracle.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        _LIB = ctypes.CDLL(so)
+    return _LIB
+
+
+def star_taps(w_laplace: np.ndarray):
+    """Extract (centre, taps[ndim][4]) from a dense [1,1,5,5(,5)] stencil; assert star support."""
+    w = np.asarray(w_laplace)
+    ndim = w.ndim - 2
+    w = w.reshape(w.shape[2:])
+    c = (2,) * ndim
+    taps = np.zeros((3, 4), dtype=w.dtype)
+    mask = np.zeros_like(w, dtype=bool)
+    mask[c] = True
+    for ax in range(ndim):
+        for i, off in enumerate((-2, -1, 1, 2)):
+            idx = list(c)
+            idx[ax] += off
+            taps[ax, i] = w[tuple(idx)]
+            mask[tuple(idx)] = True
+    assert np.all(w[~mask] == 0), "stencil is not star-shaped"
+    return w[c], taps
+
+
+def pack_params(sd: dict, dt: float, coef_u: float, coef_v: float, dtype) -> np.ndarray:
+    """state_dict-like {name: ndarray} -> parameter block P (layout in pi_oracle_impl.h)."""
+    hc = sd["Wh1_u.weight"].shape[0]
+    P = np.zeros(16 + 2 * (10 * hc + 1), dtype=dtype)
+    P[0], P[1], P[2] = dt, coef_u, coef_v
+    c, taps = star_taps(sd["W_laplace.weight"])
+    P[3] = c
+    P[4:16] = taps.reshape(-1)
+    for s, name in enumerate("uv"):
+        base = 16 + s * (10 * hc + 1)
+        for k in (1, 2, 3):
+            w = np.asarray(sd[f"Wh{k}_{name}.weight"]).reshape(hc, 2)
+            b = np.asarray(sd[f"Wh{k}_{name}.bias"]).reshape(hc)
+            for j in range(hc):
+                P[base + 10 * j + 3 * (k - 1) + 0] = w[j, 0]
+                P[base + 10 * j + 3 * (k - 1) + 1] = w[j, 1]
+                P[base + 10 * j + 3 * (k - 1) + 2] = b[j]
+        w4 = np.asarray(sd[f"Wh4_{name}.weight"]).reshape(hc)
+        for j in range(hc):
+            P[base + 10 * j + 9] = w4[j]
+        P[base + 10 * hc] = np.asarray(sd[f"Wh4_{name}.bias"]).reshape(())
+    return P
+
+
+def unpack_grads(pg: np.ndarray, hc: int, ndim: int) -> dict:
+    """packed gradient block -> {reference parameter name: ndarray}; 'coef_u','coef_v' are the
+    gradients w.r.t. the diffusion coefficients (chain through sigmoid is the caller's)."""
+    out = {"coef_u": pg[1], "coef_v": pg[2]}
+    one = (1,) * ndim
+    for s, name in enumerate("uv"):
+        base = 16 + s * (10 * hc + 1)
+        blk = pg[base:base + 10 * hc].reshape(hc, 10)
+        for k in (1, 2, 3):
+            out[f"Wh{k}_{name}.weight"] = blk[:, 3 * (k - 1):3 * (k - 1) + 2].reshape((hc, 2) + one).copy()
+            out[f"Wh{k}_{name}.bias"] = blk[:, 3 * (k - 1) + 2].copy()
+        out[f"Wh4_{name}.weight"] = blk[:, 9].reshape((1, hc) + one).copy()
+        out[f"Wh4_{name}.bias"] = pg[base + 10 * hc].reshape(1).copy()
+    return out
+
+
+def _ct(dtype):
+    return (ctypes.c_float, "f32") if np.dtype(dtype) == np.float32 else (ctypes.c_double, "f64")
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def _shape(S):
+    return (ctypes.c_long * len(S))(*S)
+
+
+def step_fwd(h: np.ndarray, P: np.ndarray, hc: int) -> np.ndarray:
+    """h: [2,*S] -> next state [2,*S]."""
+    ct, suf = _ct(h.dtype)
+    h = np.ascontiguousarray(h)
+    out = np.empty_like(h)
+    S = h.shape[1:]
+    getattr(lib(), "pi_oracle_step_fwd_" + suf)(_ptr(h, ct), _ptr(out, ct), _ptr(P, ct), hc, len(S), _shape(S))
+    return out
+
+
+def step_bwd(h, G, inj, P, hc):
+    """-> (Gprev [2,*S], pg double[len(P)])"""
+    ct, suf = _ct(h.dtype)
+    h, G = np.ascontiguousarray(h), np.ascontiguousarray(G)
+    S = h.shape[1:]
+    Gp = np.empty_like(h)
+    pg = np.zeros(P.shape[0], dtype=np.float64)
+    injp = _ptr(np.ascontiguousarray(inj), ct) if inj is not None else None
+    getattr(lib(), "pi_oracle_step_bwd_" + suf)(_ptr(h, ct), _ptr(G, ct), injp, _ptr(Gp, ct),
+                                                _ptr(pg, ctypes.c_double), _ptr(P, ct), hc, len(S), _shape(S))
+    return Gp, pg
+
+
+def rollout_fwd(h0: np.ndarray, P: np.ndarray, hc: int, T: int) -> np.ndarray:
+    """h0: [2,*S] -> traj [T+1,2,*S]"""
+    ct, suf = _ct(h0.dtype)
+    S = h0.shape[1:]
+    traj = np.empty((T + 1,) + h0.shape, dtype=h0.dtype)
+    traj[0] = h0
+    getattr(lib(), "pi_oracle_rollout_fwd_" + suf)(_ptr(traj, ct), _ptr(P, ct), hc, len(S), _shape(S), T)
+    return traj
+
+
+def rollout_bwd(traj: np.ndarray, gtraj: np.ndarray, P: np.ndarray, hc: int):
+    """-> (dL/dh0 [2,*S], pg double[len(P)])"""
+    ct, suf = _ct(traj.dtype)
+    T = traj.shape[0] - 1
+    S = traj.shape[2:]
+    traj, gtraj = np.ascontiguousarray(traj), np.ascontiguousarray(gtraj)
+    g0 = np.empty(traj.shape[1:], dtype=traj.dtype)
+    work = np.empty((2,) + traj.shape[1:], dtype=traj.dtype)
+    pg = np.zeros(P.shape[0], dtype=np.float64)
+    getattr(lib(), "pi_oracle_rollout_bwd_" + suf)(_ptr(traj, ct), _ptr(gtraj, ct), _ptr(g0, ct),
+                                                   _ptr(pg, ctypes.c_double), _ptr(work, ct), _ptr(P, ct),
+                                                   hc, len(S), _shape(S), T)
+    return g0, pg

@@ -1,0 +1,149 @@
+/* Plain-C restatement of one Pi-block step and its adjoint.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Included twice by pi_oracle.c with REAL = float / double and SUF = f32 / f64.
+ *
+ * What it restates (paths relative to /root/reference):
+ *   periodic pad           DataDrivenModeling/2d_gs_rd/train_2drd.py:108-109, 3d_gs_rd/train_3drd.py:125-127
+ *   Laplacian conv         train_2drd.py:115-116 (W_laplace, weights pre-scaled by 1/dx^2 at :66)
+ *   1x1 branches + product train_2drd.py:115-116 (Wh1*Wh2*Wh3 -> Wh4)
+ *   Euler update           train_2drd.py:117-119;  lambda-omega twin percnn_LO_eqn.py:98-112
+ *   backward               implicit autograd of the above (train_2drd.py:407)
+ *
+ * Parameter block P (array of REAL) -- the same layout the product's C-ABI documents in
+ * include/percnn_pi.h (restated here independently):
+ *   P[0]=dt  P[1]=coef_u  P[2]=coef_v  P[3]=centre tap
+ *   P[4+4*ax+i]: tap of spatial axis ax (0 = slowest) at offset {-2,-1,+1,+2}[i]   (12 slots)
+ *   P[16 + s*(10*hc+1) + 10*j + {0..9}] = {w1u,w1v,b1, w2u,w2v,b2, w3u,w3v,b3, w4} of hidden j, species s
+ *   P[16 + s*(10*hc+1) + 10*hc]         = b4 of species s
+ * Gradient block pg (double) uses the same indexing (slots 0 and 3..15 stay untouched).
+ */
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+#define FN(name) CAT(name, SUF)
+
+static inline long FN(wrap_)(long i, long n) { i %= n; return i < 0 ? i + n : i; }
+
+/* star stencil applied at point (z,y,x); flip = +1 forward (cross-correlation), -1 adjoint */
+static REAL FN(star_)(const REAL *f, const REAL *P, int ndim, const long *S, const long *idx, int flip)
+{
+    static const int offs[4] = {-2, -1, 1, 2};
+    long str[3], lin = 0;
+    long acc = 1;
+    for (int a = ndim - 1; a >= 0; --a) { str[a] = acc; acc *= S[a]; }
+    for (int a = 0; a < ndim; ++a) lin += idx[a] * str[a];
+    REAL lap = P[3] * f[lin];
+    for (int a = 0; a < ndim; ++a)
+        for (int i = 0; i < 4; ++i) {
+            long j = FN(wrap_)(idx[a] + flip * offs[i], S[a]);
+            lap = FMA(P[4 + 4 * a + i], f[lin + (j - idx[a]) * str[a]], lap);
+        }
+    return lap;
+}
+
+void FN(pi_oracle_step_fwd_)(const REAL *h, REAL *out, const REAL *P, int hc, int ndim, const long *S)
+{
+    long n = 1;
+    for (int a = 0; a < ndim; ++a) n *= S[a];
+    const REAL dt = P[0];
+    long idx[3] = {0, 0, 0};
+    for (long p = 0; p < n; ++p) {
+        long r = p;
+        for (int a = ndim - 1; a >= 0; --a) { idx[a] = r % S[a]; r /= S[a]; }
+        const REAL u = h[p], v = h[n + p];
+        for (int s = 0; s < 2; ++s) {
+            const REAL *W = P + 16 + s * (10 * hc + 1);
+            REAL lap = FN(star_)(h + s * n, P, ndim, S, idx, +1);
+            REAL rr = W[10 * hc];
+            for (int j = 0; j < hc; ++j) {
+                const REAL *w = W + 10 * j;
+                REAL a1 = FMA(w[0], u, FMA(w[1], v, w[2]));
+                REAL a2 = FMA(w[3], u, FMA(w[4], v, w[5]));
+                REAL a3 = FMA(w[6], u, FMA(w[7], v, w[8]));
+                rr = FMA(w[9], (a1 * a2) * a3, rr);
+            }
+            REAL res = P[1 + s] * lap + rr;
+            REAL t = res * dt;
+            out[s * n + p] = h[s * n + p] + t;
+        }
+    }
+}
+
+/* Adjoint of one step.  G = dL/d(next state) [2][n]; inj (nullable) = dL/d(out_{t-1}) added at the end;
+ * Gprev = dL/d(prev state); pg accumulates parameter gradients (double). */
+void FN(pi_oracle_step_bwd_)(const REAL *h, const REAL *G, const REAL *inj, REAL *Gprev, double *pg,
+                             const REAL *P, int hc, int ndim, const long *S)
+{
+    long n = 1;
+    for (int a = 0; a < ndim; ++a) n *= S[a];
+    const REAL dt = P[0];
+    long idx[3] = {0, 0, 0};
+    for (long p = 0; p < n; ++p) {
+        long r = p;
+        for (int a = ndim - 1; a >= 0; --a) { idx[a] = r % S[a]; r /= S[a]; }
+        const REAL u = h[p], v = h[n + p];
+        REAL du = 0, dv = 0;
+        REAL dl[2];
+        for (int s = 0; s < 2; ++s) {
+            const REAL *W = P + 16 + s * (10 * hc + 1);
+            double *gW = pg + 16 + s * (10 * hc + 1);
+            REAL lg = FN(star_)(G + s * n, P, ndim, S, idx, -1);
+            dl[s] = lg * dt;
+            pg[1 + s] += (double)(dl[s] * h[s * n + p]);
+            const REAL gr = G[s * n + p] * dt;
+            gW[10 * hc] += (double)gr;
+            for (int j = 0; j < hc; ++j) {
+                const REAL *w = W + 10 * j;
+                double *g = gW + 10 * j;
+                REAL a1 = FMA(w[0], u, FMA(w[1], v, w[2]));
+                REAL a2 = FMA(w[3], u, FMA(w[4], v, w[5]));
+                REAL a3 = FMA(w[6], u, FMA(w[7], v, w[8]));
+                REAL p12 = a1 * a2;
+                REAL gw = gr * w[9];
+                REAL q1 = gw * (a2 * a3), q2 = gw * (a1 * a3), q3 = gw * p12;
+                g[9] += (double)(gr * (p12 * a3));
+                g[0] += (double)(q1 * u); g[1] += (double)(q1 * v); g[2] += (double)q1;
+                g[3] += (double)(q2 * u); g[4] += (double)(q2 * v); g[5] += (double)q2;
+                g[6] += (double)(q3 * u); g[7] += (double)(q3 * v); g[8] += (double)q3;
+                du = FMA(q1, w[0], FMA(q2, w[3], FMA(q3, w[6], du)));
+                dv = FMA(q1, w[1], FMA(q2, w[4], FMA(q3, w[7], dv)));
+            }
+        }
+        REAL tu = P[1] * dl[0] + du;
+        REAL tv = P[2] * dl[1] + dv;
+        REAL gu = G[p] + tu, gv = G[n + p] + tv;
+        if (inj) { gu += inj[p]; gv += inj[n + p]; }
+        Gprev[p] = gu;
+        Gprev[n + p] = gv;
+    }
+}
+
+/* traj: [T+1][2][n], frame 0 filled by the caller (2dgs:162-190 rollout loop) */
+void FN(pi_oracle_rollout_fwd_)(REAL *traj, const REAL *P, int hc, int ndim, const long *S, int T)
+{
+    long n = 1;
+    for (int a = 0; a < ndim; ++a) n *= S[a];
+    for (int t = 0; t < T; ++t)
+        FN(pi_oracle_step_fwd_)(traj + (long)t * 2 * n, traj + (long)(t + 1) * 2 * n, P, hc, ndim, S);
+}
+
+/* gtraj: dL/dtraj [T+1][2][n]; g0 out = dL/dh0 [2][n]; work: 2 x [2][n] scratch */
+void FN(pi_oracle_rollout_bwd_)(const REAL *traj, const REAL *gtraj, REAL *g0, double *pg, REAL *work,
+                                const REAL *P, int hc, int ndim, const long *S, int T)
+{
+    long n = 1;
+    for (int a = 0; a < ndim; ++a) n *= S[a];
+    REAL *A = work, *B = work + 2 * n;
+    for (long i = 0; i < 2 * n; ++i) A[i] = gtraj[(long)T * 2 * n + i];
+    for (int t = T; t >= 1; --t) {
+        REAL *dst = (t == 1) ? g0 : B;
+        FN(pi_oracle_step_bwd_)(traj + (long)(t - 1) * 2 * n, A, gtraj + (long)(t - 1) * 2 * n, dst, pg,
+                                P, hc, ndim, S);
+        if (t > 1) { REAL *tmp = A; A = B; B = tmp; }
+    }
+    if (T == 0) for (long i = 0; i < 2 * n; ++i) g0[i] = A[i];
+}
+
+#undef FN
+#undef CAT
+#undef CAT_

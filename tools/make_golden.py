@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the REAL reference scripts (build container only).
+
+    python tools/make_golden.py            # all small cases  -> tests/golden/*.npz
+    python tools/make_golden.py --big      # + 512^2 x1000 and 128^3 x500 statistics (minutes)
+
+The reference lives read-only at /root/reference and never travels to the GPU box; only
+the data written here (inputs + expected outputs) is committed.  Every case also asserts
+that ``oracle/restatement.py`` reproduces the reference BIT-FOR-BIT on the same inputs and
+weights, which is what pins the oracle.
+
+Each reference script is imported in its own subprocess: importing ``lo`` flips the global
+default dtype to float64 (lo:12) and every script sets CUDA_VISIBLE_DEVICES at import.
+The scripts hard-call ``.cuda()`` (2dgs:150,261,268): the harness shims ``.cuda`` to a no-op
+before import -- the reference files themselves are not modified or copied.
+"""
+import argparse
+import importlib.util
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+SCRIPTS = {
+    "gs2d": "DataDrivenModeling/2d_gs_rd/train_2drd.py",
+    "gs3d": "DataDrivenModeling/3d_gs_rd/train_3drd.py",
+    "lo2d": "ForwardSimulationOfPDEs/2d_lambda_omega/percnn_LO_eqn.py",
+}
+CKPT = {
+    "gs2d": "DataDrivenModeling/2d_gs_rd/model/checkpoint.pt",
+    "gs3d": "DataDrivenModeling/3d_gs_rd/model/checkpoint.pt",
+    "lo2d": "ForwardSimulationOfPDEs/2d_lambda_omega/model/rcnn_pde.pt",
+}
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference(case):
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import matplotlib
+    matplotlib.use("Agg")
+    path = os.path.join(REF, SCRIPTS[case])
+    spec = importlib.util.spec_from_file_location("ref_" + case, path)
+    mod = importlib.util.module_from_spec(spec)
+    cwd = os.getcwd()
+    os.chdir(os.path.dirname(path))
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        os.chdir(cwd)
+    return mod
+
+
+def ref_cell(mod, case):
+    if case == "gs2d":
+        return mod.RCNNCell(2, 8, 5)
+    if case == "gs3d":
+        return mod.RCNNCell(2, 2, 5)
+    return mod.RCNNCell(input_kernel_size=1, input_stride=1, input_padding=0)
+
+
+def oracle_cell(case):
+    from oracle import restatement as R
+    return {"gs2d": R.gs2d_cell, "gs3d": R.gs3d_cell, "lo2d": R.lo2d_cell}[case]()
+
+
+def ckpt_cell_state(case):
+    sd = torch.load(os.path.join(REF, CKPT[case]), map_location="cpu", weights_only=False)
+    if "model_state_dict" in sd:
+        sd = sd["model_state_dict"]
+    out = {}
+    for k, v in sd.items():
+        for pre in ("crnn_cell.", "rcnn_cell."):
+            if k.startswith(pre):
+                out[k[len(pre):]] = v
+    return out, sd
+
+
+def initial_state(case, shape):
+    from oracle import restatement as R
+    if case == "lo2d":
+        assert shape[0] == shape[1]
+        return R.lo_initial_state(shape[0])
+    return R.gs_initial_state(shape, seed=0)
+
+
+def run_traj(cell, h0, steps):
+    outs = [h0]
+    h = h0
+    for _ in range(steps):
+        h, _ = cell(h)
+        outs.append(h)
+    return torch.cat(tuple(outs), dim=0)
+
+
+def data_loss(traj, stride_t, ndim):
+    sl = (slice(0, -1, stride_t), slice(None)) + (slice(None, None, 4),) * ndim   # cf. 2dgs:397
+    return ((traj[sl] - 0.5) ** 2).mean()
+
+
+def grads_of(loss, cell, h0):
+    names = [n for n, p in cell.named_parameters() if p.requires_grad]
+    params = [p for n, p in cell.named_parameters() if p.requires_grad]
+    g = torch.autograd.grad(loss, params + [h0], retain_graph=True, allow_unused=True)
+    return {n: gi for n, gi in zip(names, g[:-1])}, g[-1]
+
+
+def small_case(case, mod, tag, state, shape, steps, keep_t, stride_t):
+    """One fixture: reference vs restatement (bit-equal) + saved vectors."""
+    ndim = len(shape)
+    rc, oc = ref_cell(mod, case), oracle_cell(case)
+    if state is not None:
+        rc.load_state_dict(state)
+    oc.load_state_dict(rc.state_dict())
+    assert sorted(rc.state_dict().keys()) == sorted(oc.state_dict().keys())
+    h0r = initial_state(case, shape).requires_grad_(True)
+    h0o = h0r.detach().clone().requires_grad_(True)
+    tr, to = run_traj(rc, h0r, steps), run_traj(oc, h0o, steps)
+    assert torch.equal(tr, to), f"{case}/{tag}: restatement forward differs from reference"
+    rec = {"h0": h0r.detach().numpy(), "steps": steps, "keep_t": np.array(keep_t),
+           "stride_t": stride_t, "dx": rc.dx, "dt": rc.dt,
+           "mu_up": getattr(rc, "mu_up", np.nan)}
+    for k, v in rc.state_dict().items():
+        rec["param/" + k] = v.numpy()
+    for t in keep_t:
+        rec[f"traj/{t}"] = tr[t].detach().numpy()
+    for lname, lf in (("meansq", lambda x: (x ** 2).mean()),
+                      ("data", lambda x: data_loss(x, stride_t, ndim))):
+        lr, lo = lf(tr), lf(to)
+        gr, ghr = grads_of(lr, rc, h0r)
+        go, gho = grads_of(lo, oc, h0o)
+        assert torch.equal(lr, lo)
+        for n in gr:
+            assert torch.equal(gr[n], go[n]), f"{case}/{tag}: grad {n} differs"
+            rec[f"grad_{lname}/{n}"] = gr[n].numpy()
+        assert torch.equal(ghr, gho)
+        rec[f"loss_{lname}"] = lr.item()
+        rec[f"grad_{lname}_h0"] = ghr.numpy()
+    # known-answer scalar: the reference's own physics residual of this trajectory
+    # (2dgs:340-353 loss_gen / 3dgs:334-346 loss_func / lo:343-357 loss_gen)
+    lg = mod.loss_generator(rc.dt, rc.dx)
+    phy = mod.loss_func if case == "gs3d" else mod.loss_gen
+    rec["phy_loss"] = float(phy(tr.detach(), lg))
+    fn = os.path.join(OUT, f"{case}_{tag}_{'x'.join(map(str, shape))}.npz")
+    np.savez_compressed(fn, **rec)
+    print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)  "
+          f"loss_meansq={rec['loss_meansq']:.9g}")
+
+
+def rcnn_harness_case(case, mod):
+    """Pins a9: RCNN.forward incl. upscaler / effective_step / second_last_state."""
+    from oracle import restatement as R
+    _, full = ckpt_cell_state(case)
+    g = torch.Generator().manual_seed(1)
+    if case == "gs2d":
+        low = 0.5 + 0.1 * torch.randn((1, 2, 8, 8), generator=g)
+        steps = 12
+        eff = list(range(0, steps, 1))
+        m = mod.RCNN(input_channels=2, hidden_channels=8, init_state_low=low, input_kernel_size=5,
+                     step=steps, effective_step=eff)
+        m.load_state_dict(full)
+        o = R.OracleRCNN(R.gs2d_cell(), step=steps, effective_step=eff, upscaler=R.OracleUpscaler(2),
+                         init_state_low=low)
+    elif case == "gs3d":
+        low = 0.5 + 0.1 * torch.randn((1, 2, 6, 6, 6), generator=g)
+        steps = 6
+        eff = [0, 2, 3, 5]            # sparse effective_step: membership must be honoured
+        m = mod.RCNN(input_channels=2, hidden_channels=2, init_state_low=low, input_kernel_size=5,
+                     step=steps, effective_step=eff)
+        m.load_state_dict(full)
+        o = R.OracleRCNN(R.gs3d_cell(), step=steps, effective_step=eff, upscaler=R.OracleUpscaler(3),
+                         init_state_low=low)
+    else:
+        ini = R.lo_initial_state(20).numpy()
+        steps = 8
+        eff = list(range(steps))
+        m = mod.RCNN(input_kernel_size=1, ini_state=ini, input_stride=1, input_padding=0, step=steps,
+                     effective_step=eff)
+        m.load_state_dict({k.replace("crnn_cell.", "rcnn_cell."): v for k, v in full.items()})
+        o = R.OracleRCNN(R.lo2d_cell(), step=steps, effective_step=eff,
+                         init_state=torch.tensor(ini, dtype=torch.float64), cell_name="rcnn_cell")
+    o.load_state_dict(m.state_dict())
+    assert list(o.state_dict().keys()) == list(m.state_dict().keys())
+    with torch.no_grad():
+        outs_r, sl_r = m()
+        outs_o, sl_o = o()
+    assert len(outs_r) == len(outs_o)
+    for a, b in zip(outs_r, outs_o):
+        assert torch.equal(a, b)
+    assert torch.equal(sl_r, sl_o)
+    rec = {"steps": steps, "effective_step": np.array(eff), "second_last_state": sl_r.numpy(),
+           "outputs": torch.cat(tuple(outs_r), 0).numpy()}
+    if case != "lo2d":
+        rec["init_state_low"] = low.numpy()
+    else:
+        rec["init_state"] = ini
+    for k, v in m.state_dict().items():
+        rec["state/" + k] = v.numpy()
+    fn = os.path.join(OUT, f"{case}_rcnn_harness.npz")
+    np.savez_compressed(fn, **rec)
+    print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
+
+
+def big_case(case, mod, shape, checkpoints):
+    """Full-size reference run on CPU; keeps an every-8th-point subsample + statistics."""
+    state, _ = ckpt_cell_state(case)
+    rc = ref_cell(mod, case)
+    rc.load_state_dict(state)
+    h = initial_state(case, shape)
+    ndim = len(shape)
+    sub = (slice(None), slice(None)) + (slice(None, None, 8),) * ndim
+    rec = {"h0_seed": 0, "checkpoints": np.array(checkpoints)}
+    for k, v in rc.state_dict().items():
+        rec["param/" + k] = v.numpy()
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        for t in range(1, max(checkpoints) + 1):
+            h, _ = rc(h)
+            if t in checkpoints:
+                rec[f"sub/{t}"] = h[sub].numpy()
+                rec[f"l2/{t}"] = float(torch.linalg.vector_norm(h.double()))
+                rec[f"minmax/{t}"] = np.array([h[:, 0].min(), h[:, 0].max(), h[:, 1].min(), h[:, 1].max()])
+                print(f"   t={t} ({time.time()-t0:.0f}s) |h|={rec[f'l2/{t}']:.9g}")
+    fn = os.path.join(OUT, f"{case}_big_{'x'.join(map(str, shape))}.npz")
+    np.savez_compressed(fn, **rec)
+    print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
+
+
+def run_case(case, big):
+    mod = import_reference(case)
+    torch.set_num_threads(8)
+    state, _ = ckpt_cell_state(case)
+    print(f"[{case}] reference imported; default dtype {torch.get_default_dtype()}")
+    if big:
+        if case == "gs2d":
+            big_case(case, mod, (512, 512), [1, 100, 1000])
+        elif case == "gs3d":
+            big_case(case, mod, (128, 128, 128), [1, 50, 500])
+        else:
+            big_case(case, mod, (512, 512), [1, 20, 100])
+        return
+    if case in ("gs2d", "lo2d"):
+        small_case(case, mod, "ckpt", state, (32, 32), 50, [1, 2, 10, 50], 5)
+        small_case(case, mod, "fresh", None, (32, 32), 10, [1, 2, 10], 5)
+        small_case(case, mod, "ckpt", state, (64, 64), 200, [1, 2, 10, 50, 200], 20)
+        if case == "gs2d":
+            small_case(case, mod, "ckpt", state, (24, 40), 10, [1, 2, 10], 5)   # non-square
+    else:
+        small_case(case, mod, "ckpt", state, (16, 16, 16), 50, [1, 2, 10, 50], 5)
+        small_case(case, mod, "fresh", None, (16, 16, 16), 10, [1, 2, 10], 5)
+        small_case(case, mod, "ckpt", state, (24, 24, 24), 50, [1, 2, 10, 50], 5)
+        small_case(case, mod, "ckpt", state, (8, 12, 20), 10, [1, 2, 10], 5)    # non-cubic
+    rcnn_harness_case(case, mod)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", choices=list(SCRIPTS))
+    ap.add_argument("--big", action="store_true")
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    if a.case:
+        run_case(a.case, a.big)
+    else:
+        for c in SCRIPTS:
+            cmd = [sys.executable, os.path.abspath(__file__), "--case", c] + (["--big"] if a.big else [])
+            subprocess.check_call(cmd)
