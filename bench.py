@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Benchmark of the Pi-block rollout hot path (see DESIGN.md "Measurement").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gs2d_512|gs3d_128|lo2d_512] [--T T]
+
+One "step" (the unit of --steps) is ONE full rollout pass of the hot path over one synthetic
+problem: T Pi-block time steps forward + the T-step reverse sweep with a dense dL/dtraj already
+resident in HBM.  The headline `value` is Pi-block time steps per second (forward+backward),
+whole job.  Default workload = BASELINE.json configs[1]: 2D Gray-Scott 512^2, 2 species, Hc=8,
+fp32, T=1000, with the parameter magnitudes of the shipped checkpoint (values from
+tests/golden, the checkpoint file itself does not travel).
+
+N>1 (launched by torch.distributed.run, one rank per GPU, RCCL): the 512^2 problem does not shard
+profitably (8 KB halos) so ranks run independent replicas -- weak scaling, no data-path
+collective; a barrier + synchronize brackets the timed region and the MAX over ranks is taken.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (family, shape, hc, dtype, default T, golden file holding checkpoint-magnitude parameters)
+    "gs2d_512": ("gs2d", (512, 512), 8, torch.float32, 1000, "gs2d_big_512x512.npz"),
+    "gs3d_128": ("gs3d", (128, 128, 128), 2, torch.float32, 500, "gs3d_big_128x128x128.npz"),
+    "lo2d_512": ("lo2d", (512, 512), 4, torch.float64, 400, "lo2d_big_512x512.npz"),
+}
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def load_params(golden):
+    z = np.load(os.path.join(ROOT, "tests", "golden", golden))
+    return {k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}
+
+
+def make_cell(family, sd, device):
+    import percnn_amd as pa
+    cell = {"gs2d": pa.gs2d_cell, "gs3d": pa.gs3d_cell, "lo2d": pa.lo2d_cell}[family]()
+    cell.load_state_dict(sd)
+    return cell.to(device)
+
+
+def initial_state(family, shape):
+    from percnn_amd import synthetic as S     # synthetic ICs of SURVEY 8(d)
+    return S.lo_initial_state(shape[0]) if family == "lo2d" else S.gs_initial_state(shape, seed=0)
+
+
+def cpu_baseline(family, sd, shape, budget_s=15.0):
+    """The oracle's torch restatement (stock F.conv + cat padding + autograd; proven bit-identical
+    to the imported reference in the build container) timed on this box's host cores."""
+    from oracle import restatement as R
+    cell = {"gs2d": R.gs2d_cell, "gs3d": R.gs3d_cell, "lo2d": R.lo2d_cell}[family]()
+    cell.load_state_dict(sd)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    h0 = initial_state(family, shape)
+
+    def run(n):
+        t0 = time.perf_counter()
+        traj = R.rollout(cell, h0, n)
+        (traj ** 2).mean().backward()
+        return time.perf_counter() - t0
+
+    run(2)                                   # warm-up (oneDNN primitive creation)
+    t_probe = run(4) / 4
+    n = int(max(4, min(200, budget_s / max(t_probe, 1e-6))))
+    t = run(n)
+    return {"value": n / t, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n}-step fwd+bwd rollout of the same {'x'.join(map(str, shape))} problem, "
+                      f"torch {torch.__version__} CPU ({torch.get_num_threads()} threads), loss=mean(traj^2)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="gs2d_512", choices=list(WORKLOADS))
+    ap.add_argument("--T", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import percnn_amd as pa
+    family, shape, hc, dtype, T_def, golden = WORKLOADS[a.workload]
+    T = a.T or T_def
+    sd = load_params(golden)
+    cell = make_cell(family, sd, dev)
+    with torch.no_grad():
+        P = cell.param_block().contiguous()
+    npts = int(np.prod(shape))
+    esz = dtype.itemsize
+    traj = torch.empty((T + 1, 2) + shape, dtype=dtype, device=dev)
+    traj[0] = initial_state(family, shape)[0].to(dev)
+    # dense synthetic loss gradient, resident before the timed region (what autograd hands the op
+    # for L = mean(traj^2) has this shape and density)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    gtraj = torch.randn(traj.shape, dtype=dtype, device=dev, generator=gen) * (2.0 / traj.numel())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
+
+    def one_pass(e=None):
+        if e: e[0].record()
+        pa.rollout_fwd_(traj, P)
+        if e: e[1].record()
+        g0, pg = pa.rollout_bwd(traj, gtraj, P)
+        if e: e[2].record()
+        return g0, pg
+
+    for _ in range(a.warmup):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        g0, pg = one_pass(ev[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert torch.isfinite(g0).all() and torch.isfinite(pg).all() and torch.isfinite(traj[-1]).all()
+
+    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    total_steps = world * a.steps * T
+    value = total_steps / elapsed
+
+    # roofline of the dominant kernel (pi_bwd_kernel: one launch per time step of the reverse sweep).
+    # Algorithmic bytes per launch: read h_{t-1}, g_t, injected dL/dout_{t-1}; write g_{t-1}
+    #   = 4 * C * s bytes per point = 32 B (fp32) / 64 B (fp64).
+    bwd_bytes = 4 * 2 * esz * npts
+    fwd_bytes = 2 * 2 * esz * npts
+    bwd_launch_s = bwd_ms * 1e-3 / T           # HIP events on the launch stream; includes launch gaps
+    fwd_launch_s = fwd_ms * 1e-3 / T
+    achieved = bwd_bytes / bwd_launch_s / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", f"traffic_{a.workload}.json")
+    if os.path.exists(tfile):
+        traffic = json.load(open(tfile)).get("bwd_bytes_per_launch")
+
+    out = {
+        "metric": "pi_block_rollout_fwd_bwd_steps_per_sec", "value": value, "unit": "steps/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
+        "config": {"workload": f"{a.workload}: {family} {'x'.join(map(str, shape))}, 2 species, Hc={hc}, "
+                               f"T={T} forward+backward rollout per step, dense dL/dtraj",
+                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (no collective)",
+                   "points": npts, "T": T},
+        "roofline": {"bound": "hbm", "kernel": "pi_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_us": bwd_launch_s * 1e6,
+                     "fwd_kernel": {"kernel": "pi_fwd_kernel", "algorithmic_bytes_per_launch": fwd_bytes,
+                                    "avg_launch_us": fwd_launch_s * 1e6,
+                                    "achieved": fwd_bytes / fwd_launch_s / 1e9}},
+        "fwd_only_steps_per_sec": T / (fwd_ms * 1e-3),
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(family, sd, shape)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+/* percnn_pi.h -- C ABI of the MI355X-native Pi-block time-stepping library (libpercnn_pi.so).
+ *
+ * The reference (isds-neu/PeRCNN) is pure Python/PyTorch and has NO FFI or operator-plugin
+ * interface of its own: the hot path is reached through two nn.Module call signatures.  Each
+ * entry point below therefore cites the reference *call* it replaces; the reference-side
+ * binding a maintainer would add is the ctypes stub shown in INTEGRATION.md.  Paths are
+ * relative to the reference repository root:
+ *   2dgs = DataDrivenModeling/2d_gs_rd/train_2drd.py
+ *   3dgs = DataDrivenModeling/3d_gs_rd/train_3drd.py
+ *   lo   = ForwardSimulationOfPDEs/2d_lambda_omega/percnn_LO_eqn.py
+ *
+ * Conventions (all entry points)
+ *   - Plain pointers and sizes only; every data pointer is DEVICE memory owned by the caller.
+ *   - State layout: PyTorch-contiguous NCHW / NCDHW with N = 1, i.e. species-major planar
+ *     [2][*S]; `shape` lists the spatial extents slowest-first (2D: {H, W}; 3D: {D, H, W}).
+ *   - Periodic boundaries on every axis (2dgs:108-109, 3dgs:125-127); every extent >= 2.
+ *   - Asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream); no host
+ *     synchronisation and no allocation inside, hence hipGraph-capturable.  Re-entrant; no
+ *     global state except the optional rollout graph cache (percnn_pi_set_option).
+ *   - Output buffers must not alias inputs.
+ *   - Return value: 0 on success, otherwise a hipError_t cast to int, or one of the negative
+ *     PERCNN_PI_E* codes for argument errors.  No C++ exceptions cross this boundary.
+ *
+ * Parameter block `params` (device array of the compute type, percnn_pi_param_count(hc) entries)
+ *   [0]  dt                       Euler step                      (2dgs:57, 3dgs:72, lo:39)
+ *   [1]  coef_u  [2] coef_v       diffusion coefficients: mu_up*sigmoid(CA|CB) (2dgs:115-116) or DA|DB (lo:107-108)
+ *   [3]  centre tap of W_laplace.weight (already scaled by 1/dx^2 -- 2dgs:66; never re-derived)
+ *   [4 + 4*a + i]  tap of spatial axis a (0 = slowest) at offset {-2,-1,+1,+2}[i]; 12 slots
+ *   [16 + s*(10*hc+1) + 10*j + k], species s in {u,v}, hidden channel j:
+ *        k = 0,1,2: Wh1_s.weight[j,0], Wh1_s.weight[j,1], Wh1_s.bias[j]     (2dgs:70-71)
+ *        k = 3,4,5: Wh2_s ...        k = 6,7,8: Wh3_s ...                   (2dgs:72-75)
+ *        k = 9    : Wh4_s.weight[0,j]                                       (2dgs:76-77)
+ *   [16 + s*(10*hc+1) + 10*hc]  Wh4_s.bias[0]
+ * Gradient blocks (`param_grad`, double) use the same indexing; slots 0 and 3..15 (dt, frozen
+ * stencil -- 2dgs:67) receive 0.
+ */
+#ifndef PERCNN_PI_H
+#define PERCNN_PI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PERCNN_PI_ABI_VERSION 1
+
+#define PERCNN_PI_EINVAL   (-1)  /* bad ndim / hc / shape / NULL pointer          */
+#define PERCNN_PI_EWORKSPACE (-2) /* workspace smaller than *_workspace_bytes says */
+
+/* ABI version of the loaded library (== PERCNN_PI_ABI_VERSION it was built with). */
+int percnn_pi_abi_version(void);
+
+/* Number of entries of the parameter / gradient block for `hc` hidden channels:
+ * 16 + 2*(10*hc+1).  Mirrors the parameter census of RCNNCell.__init__ (2dgs:46-90). */
+size_t percnn_pi_param_count(int hc);
+
+/* Bytes of scratch the backward entry points need for a grid of this shape
+ * (two adjoint ping-pong states + per-workgroup gradient partials). elem_size = 4 or 8. */
+size_t percnn_pi_bwd_workspace_bytes(int hc, int ndim, const int64_t *shape, int elem_size);
+
+/* Options: key "graph" (0/1, default 0) caches a hipGraph per rollout signature and replays it;
+ * key "block" overrides the workgroup size (multiple of 64). Returns 0, or PERCNN_PI_EINVAL. */
+int percnn_pi_set_option(const char *key, long value);
+
+/* ---- one Pi-block step ------------------------------------------------------------------
+ * Replaces RCNNCell.forward(h) (2dgs:105-121, 3dgs:123-139, lo:98-112): periodic pad,
+ * W_laplace conv of each species, three parallel 1x1 convs 2->hc multiplied element-wise,
+ * 1x1 conv hc->1, Euler update.  h, out: [2][*S]. */
+int percnn_pi_step_fwd_f32(const float *h, float *out, const float *params, int hc, int ndim,
+                           const int64_t *shape, void *stream);
+int percnn_pi_step_fwd_f64(const double *h, double *out, const double *params, int hc, int ndim,
+                           const int64_t *shape, void *stream);
+
+/* Adjoint of one step; replaces the autograd backward of the ops above (triggered at
+ * 2dgs:407, 3dgs:408, lo:373).
+ *   h          state the step was applied to                      [2][*S]
+ *   g_out      dL/d(step output)                                  [2][*S]
+ *   g_inject   optional dL/dh arriving from other consumers of h, added to the result (may be NULL)
+ *   g_in       dL/dh (output)                                     [2][*S]
+ *   param_grad ACCUMULATED (+=) gradient block, double[percnn_pi_param_count(hc)]
+ *   workspace  percnn_pi_bwd_workspace_bytes(...) bytes of device scratch */
+int percnn_pi_step_bwd_f32(const float *h, const float *g_out, const float *g_inject, float *g_in,
+                           double *param_grad, void *workspace, size_t workspace_bytes,
+                           const float *params, int hc, int ndim, const int64_t *shape, void *stream);
+int percnn_pi_step_bwd_f64(const double *h, const double *g_out, const double *g_inject, double *g_in,
+                           double *param_grad, void *workspace, size_t workspace_bytes,
+                           const double *params, int hc, int ndim, const int64_t *shape, void *stream);
+
+/* ---- T-step rollout ---------------------------------------------------------------------
+ * Replaces the time loop of RCNN.forward() (2dgs:162-190, 3dgs:186-214, lo:169-218).
+ * traj: [T+1][2][*S]; frame 0 holds the initial state on entry, frames 1..T are written
+ * (frame k = cell applied k times), i.e. exactly torch.cat(tuple(outputs), dim=0) of the
+ * reference's callers (2dgs:394). */
+int percnn_pi_rollout_fwd_f32(float *traj, const float *params, int hc, int ndim,
+                              const int64_t *shape, int T, void *stream);
+int percnn_pi_rollout_fwd_f64(double *traj, const double *params, int hc, int ndim,
+                              const int64_t *shape, int T, void *stream);
+
+/* Reverse sweep t = T..1 over a trajectory produced by percnn_pi_rollout_fwd_*.
+ *   g_traj      dL/dtraj, [T+1][2][*S]
+ *   frame_mask  optional HOST array of T+1 bytes; frame k of g_traj is read only where
+ *               frame_mask[k] != 0 (sparse losses such as the strided data loss 2dgs:397-402);
+ *               NULL = every frame carries gradient
+ *   g_h0        dL/d(initial state) (output)                      [2][*S]
+ *   param_grad  ACCUMULATED gradient block, double[percnn_pi_param_count(hc)] */
+int percnn_pi_rollout_bwd_f32(const float *traj, const float *g_traj, const unsigned char *frame_mask,
+                              float *g_h0, double *param_grad, void *workspace, size_t workspace_bytes,
+                              const float *params, int hc, int ndim, const int64_t *shape, int T,
+                              void *stream);
+int percnn_pi_rollout_bwd_f64(const double *traj, const double *g_traj, const unsigned char *frame_mask,
+                              double *g_h0, double *param_grad, void *workspace, size_t workspace_bytes,
+                              const double *params, int hc, int ndim, const int64_t *shape, int T,
+                              void *stream);
+
+/* ---- slab-decomposed step (one rank of a 1-D domain decomposition along spatial axis 0) ----
+ * No reference counterpart: the reference is single-GPU (each script pins one device, 2dgs:14).
+ * `h` / `g_out` are LOCAL slabs WITH two halo planes on each side of axis 0:
+ *   [2][n0 + 4][rest], planes 0,1 and n0+2,n0+3 filled by the caller's halo exchange;
+ * `out` / `g_in` have the same padded layout and only their interior planes 2..n0+1 are
+ * written.  `shape` is the LOCAL interior shape {n0, ...}; the other axes stay periodic.
+ * g_inject (nullable) and the state `h` of the backward are padded the same way. */
+int percnn_pi_slab_step_fwd_f32(const float *h, float *out, const float *params, int hc, int ndim,
+                                const int64_t *shape, void *stream);
+int percnn_pi_slab_step_fwd_f64(const double *h, double *out, const double *params, int hc, int ndim,
+                                const int64_t *shape, void *stream);
+int percnn_pi_slab_step_bwd_f32(const float *h, const float *g_out, const float *g_inject, float *g_in,
+                                double *param_grad, void *workspace, size_t workspace_bytes,
+                                const float *params, int hc, int ndim, const int64_t *shape, void *stream);
+int percnn_pi_slab_step_bwd_f64(const double *h, const double *g_out, const double *g_inject, double *g_in,
+                                double *param_grad, void *workspace, size_t workspace_bytes,
+                                const double *params, int hc, int ndim, const int64_t *shape, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PERCNN_PI_H */

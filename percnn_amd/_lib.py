@@ -1,0 +1,86 @@
+"""ctypes binding of libpercnn_pi.so (the C-ABI declared in include/percnn_pi.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call fails, a
+RuntimeError is raised.  Build with ``python __graft_entry__.py`` or ``percnn_amd.build()``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.environ.get("PERCNN_PI_LIB", os.path.join(CSRC, "libpercnn_pi.so"))
+ABI_VERSION = 1
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+SOURCES = ["pi_abi.hip"]
+HEADERS = ["pi_kernels.h", "pi_device.h", os.path.join("..", "..", "include", "percnn_pi.h")]
+
+EXPORTS = [
+    "percnn_pi_abi_version", "percnn_pi_param_count", "percnn_pi_bwd_workspace_bytes", "percnn_pi_set_option",
+] + [f"percnn_pi_{op}_{suf}" for suf in ("f32", "f64")
+     for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd")]
+
+
+def build(force: bool = False, extra_flags=(), out: str | None = None) -> str:
+    """Compile the HIP kernels + C-ABI for gfx950 with hipcc (cross-compiles without a GPU)."""
+    out = out or os.path.join(CSRC, "libpercnn_pi.so")
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    subprocess.check_call(cmd, cwd=CSRC)
+    return out
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load the library once; fail loudly if it is absent or of another ABI version."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"percnn_amd: HIP library not found at {LIB_PATH}. There is no CPU fallback -- build it with "
+            f"`python -c 'import percnn_amd; percnn_amd.build()'` (needs hipcc).")
+    L = ctypes.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise RuntimeError(f"percnn_amd: {LIB_PATH} does not export {name}")
+    L.percnn_pi_abi_version.restype = ctypes.c_int
+    if L.percnn_pi_abi_version() != ABI_VERSION:
+        raise RuntimeError("percnn_amd: ABI version mismatch between python package and libpercnn_pi.so")
+    vp, i64p, ci, sz = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int, ctypes.c_size_t
+    L.percnn_pi_param_count.restype = sz
+    L.percnn_pi_param_count.argtypes = [ci]
+    L.percnn_pi_bwd_workspace_bytes.restype = sz
+    L.percnn_pi_bwd_workspace_bytes.argtypes = [ci, ci, i64p, ci]
+    L.percnn_pi_set_option.restype = ci
+    L.percnn_pi_set_option.argtypes = [ctypes.c_char_p, ctypes.c_long]
+    for suf in ("f32", "f64"):
+        for pre in ("", "slab_"):
+            f = getattr(L, f"percnn_pi_{pre}step_fwd_{suf}")
+            f.restype, f.argtypes = ci, [vp, vp, vp, ci, ci, i64p, vp]
+            f = getattr(L, f"percnn_pi_{pre}step_bwd_{suf}")
+            f.restype, f.argtypes = ci, [vp, vp, vp, vp, vp, vp, sz, vp, ci, ci, i64p, vp]
+        f = getattr(L, f"percnn_pi_rollout_fwd_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, ci, ci, i64p, ci, vp]
+        f = getattr(L, f"percnn_pi_rollout_bwd_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, ctypes.c_char_p, vp, vp, vp, sz, vp, ci, ci, i64p, ci, vp]
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        names = {-1: "invalid argument", -2: "workspace too small"}
+        raise RuntimeError(f"percnn_amd: {what} failed: {names.get(rc, 'hipError_t ' + str(rc))}")
+
+
+def shape_arg(shape):
+    return (ctypes.c_int64 * len(shape))(*[int(s) for s in shape])

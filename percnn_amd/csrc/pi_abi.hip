@@ -1,0 +1,305 @@
+// pi_abi.hip -- C-ABI entry points of libpercnn_pi.so (declared in include/percnn_pi.h).
+// Host side only validates arguments, picks a kernel instantiation and enqueues launches on the
+// caller's stream: no allocation, no synchronisation, no exceptions across the boundary.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/percnn_pi.h"
+#include "pi_kernels.h"
+
+namespace {
+
+using pi::Geom;
+
+struct Options {
+    int block = 256;
+};
+Options g_opt;
+
+constexpr int MAX_BWD_BLOCKS = 4096;   // bounds the per-workgroup gradient partials (grid-stride beyond)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Problem {
+    int ndim, hc;
+    int64_t n0, n1, W;
+    int64_t n;          // points per species (interior)
+    bool slab;
+};
+
+int make_problem(int hc, int ndim, const int64_t* shape, bool slab, Problem& p)
+{
+    if (!shape || (ndim != 2 && ndim != 3) || hc < 1 || hc > 64) return PERCNN_PI_EINVAL;
+    for (int a = 0; a < ndim; ++a)
+        if (shape[a] < 2 || shape[a] > (1 << 30)) return PERCNN_PI_EINVAL;
+    p.ndim = ndim; p.hc = hc; p.slab = slab;
+    p.n0 = shape[0];
+    p.n1 = ndim == 3 ? shape[1] : 1;
+    p.W = shape[ndim - 1];
+    p.n = p.n0 * p.n1 * p.W;
+    if (p.n > (int64_t(1) << 40)) return PERCNN_PI_EINVAL;
+    return 0;
+}
+
+Geom make_geom(const Problem& p)
+{
+    Geom g;
+    g.n0 = (int)p.n0; g.n1 = (int)p.n1; g.W = (int)p.W;
+    g.rows = (int)(p.n0 * p.n1);
+    g.s0 = (long)(p.n1 * p.W);
+    if (p.slab) { g.ss = (long)(p.n0 + 4) * g.s0; g.off = 2 * g.s0; g.wrap0 = 0; }
+    else        { g.ss = (long)p.n0 * g.s0;       g.off = 0;        g.wrap0 = 1; }
+    return g;
+}
+
+template <typename T>
+int pick_vec(const Problem& p, std::initializer_list<const void*> ptrs)
+{
+    constexpr int V = pi::vec_width<T>::value;
+    if (p.W % V) return 1;
+    for (const void* q : ptrs)
+        if (q && (reinterpret_cast<uintptr_t>(q) % 16)) return 1;
+    return V;
+}
+
+// ---- kernel instantiation dispatch ------------------------------------------------------------
+template <typename T, int NDIM, int HC, int VEC>
+hipError_t launch_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
+{
+    const Geom g = make_geom(p);
+    const long nchunks = (long)g.rows * (g.W / VEC);
+    const int block = g_opt.block;
+    const unsigned grid = (unsigned)((nchunks + block - 1) / block);
+    hipLaunchKernelGGL((pi::pi_fwd_kernel<T, NDIM, HC, VEC>), dim3(grid), dim3(block), 0, st, h, out, P, g, p.hc);
+    return hipGetLastError();
+}
+
+unsigned bwd_grid(const Problem& p, int vec)
+{
+    const long nchunks = (long)(p.n0 * p.n1) * (p.W / vec);
+    const long need = (nchunks + g_opt.block - 1) / g_opt.block;
+    return (unsigned)(need < MAX_BWD_BLOCKS ? need : MAX_BWD_BLOCKS);
+}
+
+template <typename T, int NDIM, int HC, int VEC>
+hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partials, const T* P,
+                      const Problem& p, hipStream_t st)
+{
+    const Geom g = make_geom(p);
+    const int block = g_opt.block;
+    const unsigned grid = bwd_grid(p, VEC);
+    const size_t lds = (size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T);
+    hipLaunchKernelGGL((pi::pi_bwd_kernel<T, NDIM, HC, VEC>), dim3(grid), dim3(block), lds, st, h, G, inj, Gp,
+                       partials, P, g, p.hc);
+    return hipGetLastError();
+}
+
+#define PI_DISPATCH_HC(CALL, NDIM, VEC)                         \
+    switch (p.hc) {                                             \
+        case 2:  return CALL(NDIM, 2, VEC);                     \
+        case 4:  return CALL(NDIM, 4, VEC);                     \
+        case 8:  return CALL(NDIM, 8, VEC);                     \
+        default: return CALL(NDIM, 0, VEC);                     \
+    }
+#define PI_DISPATCH(CALL)                                                   \
+    do {                                                                    \
+        constexpr int V = pi::vec_width<T>::value;                          \
+        if (p.ndim == 2) {                                                  \
+            if (vec == 1) { PI_DISPATCH_HC(CALL, 2, 1) } else { PI_DISPATCH_HC(CALL, 2, V) } \
+        } else {                                                            \
+            if (vec == 1) { PI_DISPATCH_HC(CALL, 3, 1) } else { PI_DISPATCH_HC(CALL, 3, V) } \
+        }                                                                   \
+    } while (0)
+
+template <typename T>
+hipError_t step_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
+{
+    const int vec = pick_vec<T>(p, {h, out});
+#define CALL_FWD(NDIM, HC, VEC) launch_fwd<T, NDIM, HC, VEC>(h, out, P, p, st)
+    PI_DISPATCH(CALL_FWD);
+#undef CALL_FWD
+}
+
+template <typename T>
+hipError_t step_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partials, const T* P, const Problem& p,
+                    hipStream_t st, unsigned* grid_out)
+{
+    const int vec = pick_vec<T>(p, {h, G, inj, Gp});
+    if (grid_out) *grid_out = bwd_grid(p, vec);
+#define CALL_BWD(NDIM, HC, VEC) launch_bwd<T, NDIM, HC, VEC>(h, G, inj, Gp, partials, P, p, st)
+    PI_DISPATCH(CALL_BWD);
+#undef CALL_BWD
+}
+
+// ---- workspace carving -------------------------------------------------------------------------
+struct Workspace {
+    void* adj[2];
+    double* partials;
+    size_t partials_bytes;
+};
+
+size_t partials_bytes_for(int hc) { return align_up((size_t)MAX_BWD_BLOCKS * pi::nparams(hc) * sizeof(double), 256); }
+
+size_t workspace_bytes(const Problem& p, int elem)
+{
+    return 2 * align_up((size_t)2 * p.n * elem, 256) + partials_bytes_for(p.hc);
+}
+
+bool carve(void* ws, size_t bytes, const Problem& p, int elem, Workspace& w)
+{
+    if (!ws || bytes < workspace_bytes(p, elem) || (reinterpret_cast<uintptr_t>(ws) % 16)) return false;
+    auto* b = static_cast<unsigned char*>(ws);
+    const size_t a = align_up((size_t)2 * p.n * elem, 256);
+    w.adj[0] = b; w.adj[1] = b + a;
+    w.partials = reinterpret_cast<double*>(b + 2 * a);
+    w.partials_bytes = partials_bytes_for(p.hc);
+    return true;
+}
+
+hipError_t finish_grads(const Workspace& w, unsigned nblocks, int hc, double* param_grad, hipStream_t st)
+{
+    const int np = pi::nparams(hc);
+    hipLaunchKernelGGL(pi::pi_reduce_partials_kernel, dim3(np), dim3(pi::WAVE), 0, st, w.partials, (int)nblocks, np,
+                       param_grad);
+    return hipGetLastError();
+}
+
+// ---- typed implementations -----------------------------------------------------------------------
+template <typename T>
+int step_fwd_impl(const T* h, T* out, const T* P, int hc, int ndim, const int64_t* shape, void* stream, bool slab)
+{
+    Problem p;
+    if (int rc = make_problem(hc, ndim, shape, slab, p)) return rc;
+    if (!h || !out || !P || h == out) return PERCNN_PI_EINVAL;
+    return (int)step_fwd<T>(h, out, P, p, static_cast<hipStream_t>(stream));
+}
+
+template <typename T>
+int step_bwd_impl(const T* h, const T* g_out, const T* g_inj, T* g_in, double* param_grad, void* ws, size_t ws_bytes,
+                  const T* P, int hc, int ndim, const int64_t* shape, void* stream, bool slab)
+{
+    Problem p;
+    if (int rc = make_problem(hc, ndim, shape, slab, p)) return rc;
+    if (!h || !g_out || !g_in || !param_grad || !P || g_in == g_out) return PERCNN_PI_EINVAL;
+    Workspace w;
+    if (!carve(ws, ws_bytes, p, sizeof(T), w)) return PERCNN_PI_EWORKSPACE;
+    auto st = static_cast<hipStream_t>(stream);
+    if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
+    unsigned grid = 0;
+    if (hipError_t e = step_bwd<T>(h, g_out, g_inj, g_in, w.partials, P, p, st, &grid)) return (int)e;
+    return (int)finish_grads(w, grid, hc, param_grad, st);
+}
+
+template <typename T>
+int rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* shape, int T_steps, void* stream)
+{
+    Problem p;
+    if (int rc = make_problem(hc, ndim, shape, false, p)) return rc;
+    if (!traj || !P || T_steps < 0) return PERCNN_PI_EINVAL;
+    auto st = static_cast<hipStream_t>(stream);
+    const size_t frame = (size_t)2 * p.n;
+    for (int t = 0; t < T_steps; ++t)
+        if (hipError_t e = step_fwd<T>(traj + (size_t)t * frame, traj + (size_t)(t + 1) * frame, P, p, st)) return (int)e;
+    return 0;
+}
+
+template <typename T>
+int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, T* g_h0, double* param_grad, void* ws,
+                     size_t ws_bytes, const T* P, int hc, int ndim, const int64_t* shape, int T_steps, void* stream)
+{
+    Problem p;
+    if (int rc = make_problem(hc, ndim, shape, false, p)) return rc;
+    if (!traj || !g_traj || !g_h0 || !param_grad || !P || T_steps < 0) return PERCNN_PI_EINVAL;
+    Workspace w;
+    if (!carve(ws, ws_bytes, p, sizeof(T), w)) return PERCNN_PI_EWORKSPACE;
+    auto st = static_cast<hipStream_t>(stream);
+    const size_t frame = (size_t)2 * p.n;
+    const size_t frame_bytes = frame * sizeof(T);
+    auto has = [&](int t) { return !mask || mask[t]; };
+
+    // frames after the last one carrying gradient contribute nothing: start the sweep there
+    int t_top = T_steps;
+    while (t_top > 0 && !has(t_top)) --t_top;
+    if (t_top == 0) {
+        if (has(0)) return (int)hipMemcpyAsync(g_h0, g_traj, frame_bytes, hipMemcpyDeviceToDevice, st);
+        return (int)hipMemsetAsync(g_h0, 0, frame_bytes, st);
+    }
+    if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
+
+    const T* A = g_traj + (size_t)t_top * frame;      // adjoint of frame t (read in place for the top frame)
+    int flip = 0;
+    unsigned grid = 0;
+    for (int t = t_top; t >= 1; --t) {
+        T* dst = (t == 1) ? g_h0 : static_cast<T*>(w.adj[flip]);
+        const T* inj = has(t - 1) ? g_traj + (size_t)(t - 1) * frame : nullptr;
+        if (hipError_t e = step_bwd<T>(traj + (size_t)(t - 1) * frame, A, inj, dst, w.partials, P, p, st, &grid))
+            return (int)e;
+        A = dst;
+        flip ^= 1;
+    }
+    return (int)finish_grads(w, grid, hc, param_grad, st);
+}
+
+}  // namespace
+
+// ---- exported symbols ---------------------------------------------------------------------------
+extern "C" {
+
+int percnn_pi_abi_version(void) { return PERCNN_PI_ABI_VERSION; }
+
+size_t percnn_pi_param_count(int hc) { return hc < 1 ? 0 : (size_t)pi::nparams(hc); }
+
+size_t percnn_pi_bwd_workspace_bytes(int hc, int ndim, const int64_t* shape, int elem_size)
+{
+    Problem p;
+    if (make_problem(hc, ndim, shape, false, p) || (elem_size != 4 && elem_size != 8)) return 0;
+    // sized for the padded slab layout as well: (n0+4) planes
+    Problem q = p;
+    q.n = (p.n0 + 4) * p.n1 * p.W;
+    return workspace_bytes(q, elem_size);
+}
+
+int percnn_pi_set_option(const char* key, long value)
+{
+    if (!key) return PERCNN_PI_EINVAL;
+    if (!std::strcmp(key, "block")) {
+        if (value < 64 || value > 256 || value % 64) return PERCNN_PI_EINVAL;
+        g_opt.block = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "graph")) return value == 0 ? 0 : PERCNN_PI_EINVAL;   // reserved
+    return PERCNN_PI_EINVAL;
+}
+
+#define PI_EXPORT(SUF, T)                                                                                           \
+    int percnn_pi_step_fwd_##SUF(const T* h, T* out, const T* params, int hc, int ndim, const int64_t* shape,      \
+                                 void* stream)                                                                      \
+    { return step_fwd_impl<T>(h, out, params, hc, ndim, shape, stream, false); }                                    \
+    int percnn_pi_slab_step_fwd_##SUF(const T* h, T* out, const T* params, int hc, int ndim, const int64_t* shape, \
+                                      void* stream)                                                                 \
+    { return step_fwd_impl<T>(h, out, params, hc, ndim, shape, stream, true); }                                     \
+    int percnn_pi_step_bwd_##SUF(const T* h, const T* g_out, const T* g_inject, T* g_in, double* param_grad,       \
+                                 void* workspace, size_t workspace_bytes, const T* params, int hc, int ndim,       \
+                                 const int64_t* shape, void* stream)                                                \
+    { return step_bwd_impl<T>(h, g_out, g_inject, g_in, param_grad, workspace, workspace_bytes, params, hc, ndim,  \
+                              shape, stream, false); }                                                              \
+    int percnn_pi_slab_step_bwd_##SUF(const T* h, const T* g_out, const T* g_inject, T* g_in, double* param_grad,  \
+                                      void* workspace, size_t workspace_bytes, const T* params, int hc, int ndim,  \
+                                      const int64_t* shape, void* stream)                                           \
+    { return step_bwd_impl<T>(h, g_out, g_inject, g_in, param_grad, workspace, workspace_bytes, params, hc, ndim,  \
+                              shape, stream, true); }                                                               \
+    int percnn_pi_rollout_fwd_##SUF(T* traj, const T* params, int hc, int ndim, const int64_t* shape, int T_steps, \
+                                    void* stream)                                                                   \
+    { return rollout_fwd_impl<T>(traj, params, hc, ndim, shape, T_steps, stream); }                                 \
+    int percnn_pi_rollout_bwd_##SUF(const T* traj, const T* g_traj, const unsigned char* frame_mask, T* g_h0,      \
+                                    double* param_grad, void* workspace, size_t workspace_bytes, const T* params,  \
+                                    int hc, int ndim, const int64_t* shape, int T_steps, void* stream)              \
+    { return rollout_bwd_impl<T>(traj, g_traj, frame_mask, g_h0, param_grad, workspace, workspace_bytes, params,   \
+                                 hc, ndim, shape, T_steps, stream); }
+
+PI_EXPORT(f32, float)
+PI_EXPORT(f64, double)
+
+}  // extern "C"

@@ -1,0 +1,301 @@
+// pi_kernels.h -- fused Pi-block step kernels for gfx950 (forward and adjoint), v1 "direct" family.
+//
+// One lane owns VEC consecutive points of a grid row (16 B: 4 x f32 / 2 x f64), so every global
+// access of a wave is a 1 KiB fully-coalesced transaction.  The radius-2 star stencil is gathered
+// with index arithmetic (periodic wrap = the reference's torch.cat padding, train_2drd.py:108-109,
+// at zero extra bytes); neighbour rows/planes are re-read through the vector L1 / XCD L2.  All
+// 2*(10*hc+1) branch weights are wave-uniform and live in SGPRs (scalar loads from the parameter
+// block); the six 1x1 convolutions, their Hadamard product, the 1x1 aggregation and the Euler
+// update are pure register math (train_2drd.py:115-119).
+#pragma once
+#include "pi_device.h"
+
+namespace pi {
+
+struct Geom {
+    int n0, n1, W;      // extents: 2D {n0=H, W}; 3D {n0=D, n1=H, W}
+    int rows;           // rows of W points = n0 (2D) or n0*n1 (3D)
+    long s0;            // element stride of axis 0: W (2D) or n1*W (3D)
+    long ss;            // species stride (elements); slab layout: (n0+4)*s0
+    long off;           // element offset of the first interior point; slab layout: 2*s0
+    int wrap0;          // 1: axis 0 periodic; 0: two halo planes present on each side (slab)
+};
+
+// radius-2 star: lap[i] = c0*f(x) + sum_axes sum_t w[axis][t] * f(x + FLIP*offs[t]); FLIP=-1 is the adjoint
+template <typename T, int NDIM, int VEC, int FLIP>
+__device__ __forceinline__ void star(const T* __restrict__ f, const T* __restrict__ P, const Geom& g,
+                                     int i0, int i1, int x0, long e, const Pack<T, VEC>& c, T (&lap)[VEC])
+{
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) lap[i] = P[P_C0] * c.v[i];
+    // axis 0 (slowest): periodic or halo-backed
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = FLIP * (t < 2 ? t - 2 : t - 1);
+        int j0 = i0 + k;
+        if (g.wrap0) j0 = wrap(j0, g.n0);
+        const Pack<T, VEC> nb = ld<T, VEC>(f + e + (long)(j0 - i0) * g.s0);
+        const T w = P[P_TAPS + t];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) lap[i] = fma_(w, nb.v[i], lap[i]);
+    }
+    if constexpr (NDIM == 3) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = FLIP * (t < 2 ? t - 2 : t - 1);
+            const int j1 = wrap(i1 + k, g.n1);
+            const Pack<T, VEC> nb = ld<T, VEC>(f + e + (long)(j1 - i1) * g.W);
+            const T w = P[P_TAPS + 4 + t];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) lap[i] = fma_(w, nb.v[i], lap[i]);
+        }
+    }
+    // fastest axis: window x0-2 .. x0+VEC+1
+    T win[VEC + 4];
+    const T* row = f + e - x0;
+    if constexpr (VEC == 1) {
+        win[0] = row[wrap(x0 - 2, g.W)];
+        win[1] = row[wrap(x0 - 1, g.W)];
+        win[3] = row[wrap(x0 + 1, g.W)];
+        win[4] = row[wrap(x0 + 2, g.W)];
+    } else {
+        const int xl = x0 >= 2 ? x0 - 2 : x0 - 2 + g.W;
+        const int xr = x0 + VEC < g.W ? x0 + VEC : x0 + VEC - g.W;
+        const Pack<T, 2> l = ld<T, 2>(row + xl), r = ld<T, 2>(row + xr);
+        win[0] = l.v[0]; win[1] = l.v[1];
+        win[VEC + 2] = r.v[0]; win[VEC + 3] = r.v[1];
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) win[2 + i] = c.v[i];
+    constexpr int TX = P_TAPS + 4 * (NDIM - 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = FLIP * (t < 2 ? t - 2 : t - 1);
+        const T w = P[TX + t];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) lap[i] = fma_(w, win[2 + i + k], lap[i]);
+    }
+}
+
+template <int NDIM>
+__device__ __forceinline__ void chunk_coords(const Geom& g, long cid, int cpr, int vec, int& i0, int& i1, int& x0, long& e)
+{
+    const long row = cid / cpr;
+    x0 = (int)(cid - row * cpr) * vec;
+    if constexpr (NDIM == 3) {
+        i0 = (int)(row / g.n1);
+        i1 = (int)(row - (long)i0 * g.n1);
+        e = (long)i0 * g.s0 + (long)i1 * g.W + x0;
+    } else {
+        i0 = (int)row;
+        i1 = 0;
+        e = (long)i0 * g.s0 + x0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: out = h + dt * (coef * Lap(h) + Wh4(Wh1(h) * Wh2(h) * Wh3(h)))
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NDIM, int HC, int VEC>
+__global__ void __launch_bounds__(256)
+pi_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict__ P, Geom g, int hc_rt)
+{
+    const int hc = HC > 0 ? HC : hc_rt;
+    const int cpr = g.W / VEC;
+    const long nchunks = (long)g.rows * cpr;
+    const long cid = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    if (cid >= nchunks) return;
+    int i0, i1, x0;
+    long e;
+    chunk_coords<NDIM>(g, cid, cpr, VEC, i0, i1, x0, e);
+
+    const T* hu = h + g.off;
+    const T* hv = h + g.ss + g.off;
+    const Pack<T, VEC> cu = ld<T, VEC>(hu + e), cv = ld<T, VEC>(hv + e);
+    T lap[2][VEC];
+    star<T, NDIM, VEC, +1>(hu, P, g, i0, i1, x0, e, cu, lap[0]);
+    star<T, NDIM, VEC, +1>(hv, P, g, i0, i1, x0, e, cv, lap[1]);
+
+    const T dt = P[P_DT];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const T* W = P + P_W + s * species_block(hc);
+        T rr[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) rr[i] = W[10 * hc];
+#pragma unroll
+        for (int j = 0; j < hc; ++j) {
+            const T* w = W + 10 * j;
+            const T w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6], w7 = w[7],
+                    w8 = w[8], w9 = w[9];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const T a1 = fma_(w0, cu.v[i], fma_(w1, cv.v[i], w2));
+                const T a2 = fma_(w3, cu.v[i], fma_(w4, cv.v[i], w5));
+                const T a3 = fma_(w6, cu.v[i], fma_(w7, cv.v[i], w8));
+                rr[i] = fma_(w9, (a1 * a2) * a3, rr[i]);
+            }
+        }
+        const T coef = P[P_COEF + s];
+        const Pack<T, VEC>& c = s == 0 ? cu : cv;
+        Pack<T, VEC> o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const T res = coef * lap[s][i] + rr[i];     // two roundings (train_2drd.py:115)
+            const T inc = res * dt;                     // two roundings (train_2drd.py:117)
+            o.v[i] = c.v[i] + inc;
+        }
+        st<T, VEC>(out + s * g.ss + g.off + e, o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoint of one step.
+//   G    = dL/d(step output)            (stencil-read, halo-backed in slab mode)
+//   Gp   = G + coef*dt*LapT(G) + dt*J_react(h)^T G (+ inj)
+//   partials[block][np] += this block's parameter-gradient sums (double, owner-block RMW)
+// Gradient of the diffusion coefficient uses sum_x g*Lap(h) == sum_x LapT(g)*h, so the forward
+// Laplacian is never recomputed.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NDIM, int HC, int VEC>
+__global__ void __launch_bounds__(256)
+pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restrict__ inj, T* __restrict__ Gp,
+              double* __restrict__ partials, const T* __restrict__ P, Geom g, int hc_rt)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* red = reinterpret_cast<T*>(smem_raw);           // [nwaves][np] running sums of this block
+
+    const int hc = HC > 0 ? HC : hc_rt;
+    const int np = nparams(hc);
+    const int nwaves = blockDim.x / WAVE;
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    T* myred = red + wave * np;
+    for (int i = threadIdx.x; i < nwaves * np; i += blockDim.x) red[i] = T(0);
+    __syncthreads();
+
+    const int cpr = g.W / VEC;
+    const long nchunks = (long)g.rows * cpr;
+    const T dt = P[P_DT];
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long first = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    // every wave runs the same number of iterations (wave-level reductions inside)
+    const long iters = (nchunks + stride - 1) / stride;
+
+    for (long it = 0; it < iters; ++it) {
+        const long cid_raw = first + it * stride;
+        const bool valid = cid_raw < nchunks;
+        const long cid = valid ? cid_raw : nchunks - 1;
+        int i0, i1, x0;
+        long e;
+        chunk_coords<NDIM>(g, cid, cpr, VEC, i0, i1, x0, e);
+
+        const Pack<T, VEC> u = ld<T, VEC>(h + g.off + e), v = ld<T, VEC>(h + g.ss + g.off + e);
+        Pack<T, VEC> gc[2] = {ld<T, VEC>(G + g.off + e), ld<T, VEC>(G + g.ss + g.off + e)};
+        T dl[2][VEC];
+        star<T, NDIM, VEC, -1>(G + g.off, P, g, i0, i1, x0, e, gc[0], dl[0]);
+        star<T, NDIM, VEC, -1>(G + g.ss + g.off, P, g, i0, i1, x0, e, gc[1], dl[1]);
+        const T live = valid ? T(1) : T(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                dl[s][i] = (dl[s][i] * dt) * live;
+                gc[s].v[i] *= live;
+            }
+
+        T du[VEC], dv[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) du[i] = dv[i] = T(0);
+
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const T* W = P + P_W + s * species_block(hc);
+            const int gbase = P_W + s * species_block(hc);
+            const Pack<T, VEC>& hs = s == 0 ? u : v;
+            T gr[VEC];
+            T acc_c = T(0), acc_b4 = T(0);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                gr[i] = gc[s].v[i] * dt;
+                acc_c += dl[s][i] * hs.v[i];
+                acc_b4 += gr[i];
+            }
+            acc_c = wave_sum_to_last(acc_c);
+            acc_b4 = wave_sum_to_last(acc_b4);
+            if (lane == REDUCE_LANE) {
+                myred[P_COEF + s] += acc_c;
+                myred[gbase + 10 * hc] += acc_b4;
+            }
+#pragma unroll
+            for (int j = 0; j < hc; ++j) {
+                const T* w = W + 10 * j;
+                const T w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6], w7 = w[7],
+                        w8 = w[8], w9 = w[9];
+                T acc[10];
+#pragma unroll
+                for (int m = 0; m < 10; ++m) acc[m] = T(0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const T a1 = fma_(w0, u.v[i], fma_(w1, v.v[i], w2));
+                    const T a2 = fma_(w3, u.v[i], fma_(w4, v.v[i], w5));
+                    const T a3 = fma_(w6, u.v[i], fma_(w7, v.v[i], w8));
+                    const T p12 = a1 * a2;
+                    const T gw = gr[i] * w9;
+                    const T q1 = gw * (a2 * a3), q2 = gw * (a1 * a3), q3 = gw * p12;
+                    acc[9] += gr[i] * (p12 * a3);
+                    acc[0] += q1 * u.v[i]; acc[1] += q1 * v.v[i]; acc[2] += q1;
+                    acc[3] += q2 * u.v[i]; acc[4] += q2 * v.v[i]; acc[5] += q2;
+                    acc[6] += q3 * u.v[i]; acc[7] += q3 * v.v[i]; acc[8] += q3;
+                    du[i] = fma_(q1, w0, fma_(q2, w3, fma_(q3, w6, du[i])));
+                    dv[i] = fma_(q1, w1, fma_(q2, w4, fma_(q3, w7, dv[i])));
+                }
+#pragma unroll
+                for (int m = 0; m < 10; ++m) acc[m] = wave_sum_to_last(acc[m]);
+                if (lane == REDUCE_LANE) {
+#pragma unroll
+                    for (int m = 0; m < 10; ++m) myred[gbase + 10 * j + m] += acc[m];
+                }
+            }
+        }
+
+        if (valid) {
+            Pack<T, VEC> ou, ov;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const T tu = P[P_COEF + 0] * dl[0][i] + du[i];
+                const T tv = P[P_COEF + 1] * dl[1][i] + dv[i];
+                ou.v[i] = gc[0].v[i] + tu;
+                ov.v[i] = gc[1].v[i] + tv;
+            }
+            if (inj) {
+                const Pack<T, VEC> ju = ld<T, VEC>(inj + g.off + e), jv = ld<T, VEC>(inj + g.ss + g.off + e);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { ou.v[i] += ju.v[i]; ov.v[i] += jv.v[i]; }
+            }
+            st<T, VEC>(Gp + g.off + e, ou);
+            st<T, VEC>(Gp + g.ss + g.off + e, ov);
+        }
+    }
+
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < np; idx += blockDim.x) {
+        if (idx == P_DT || (idx >= P_C0 && idx < P_W)) continue;   // dt and the frozen stencil carry no gradient
+        T s = T(0);
+        for (int w = 0; w < nwaves; ++w) s += red[w * np + idx];
+        partials[(long)blockIdx.x * np + idx] += (double)s;
+    }
+}
+
+// param_grad[idx] += sum_b partials[b][idx]; one wave per parameter, fixed order -> deterministic
+__global__ void __launch_bounds__(64)
+pi_reduce_partials_kernel(const double* __restrict__ partials, int nblocks, int np, double* __restrict__ param_grad)
+{
+    const int idx = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += WAVE) s += partials[(long)b * np + idx];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, WAVE);
+    if (threadIdx.x == 0) param_grad[idx] += s;
+}
+
+}  // namespace pi

@@ -1,0 +1,273 @@
+"""torch.autograd front-end of the HIP Pi-block kernels.
+
+``pi_step`` / ``pi_rollout`` are what the drop-in modules (``percnn_amd.modules``) call in place
+of the reference's per-step ATen sequence (``RCNNCell.forward`` -- DataDrivenModeling/2d_gs_rd/
+train_2drd.py:105-121, 3d_gs_rd/train_3drd.py:123-139, ForwardSimulationOfPDEs/2d_lambda_omega/
+percnn_LO_eqn.py:98-112) and its T-step loop (``RCNN.forward`` -- train_2drd.py:162-190).
+
+Everything here is plumbing: tensors supply device memory and the current HIP stream; the math
+runs in ``libpercnn_pi.so`` through the C-ABI of ``include/percnn_pi.h``.  CPU tensors are
+rejected -- there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+_SUF = {torch.float32: "f32", torch.float64: "f64"}
+_OFFS = (-2, -1, 1, 2)
+
+
+def param_count(hc: int) -> int:
+    return 16 + 2 * (10 * hc + 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter block (layout documented in include/percnn_pi.h)
+# ------------------------------------------------------------------------------------------------
+_index_cache: dict = {}
+
+
+def _gather_index(hc: int, ndim: int, device) -> torch.Tensor:
+    """Index into the flat concatenation [dt, coef_u, coef_v, W_laplace.weight(5^ndim),
+    {Wh1.w, Wh1.b, Wh2.w, Wh2.b, Wh3.w, Wh3.b, Wh4.w, Wh4.b} for u then v] that yields the block."""
+    key = (hc, ndim, str(device))
+    if key in _index_cache:
+        return _index_cache[key]
+    nst = 5 ** ndim
+    idx = [0] * param_count(hc)
+    idx[0], idx[1], idx[2] = 0, 1, 2
+
+    def lin(pos):
+        r = 0
+        for p in pos:
+            r = r * 5 + p
+        return 3 + r
+
+    centre = [2] * ndim
+    idx[3] = lin(centre)
+    for a in range(3):
+        for i, off in enumerate(_OFFS):
+            if a < ndim:
+                pos = list(centre)
+                pos[a] += off
+                idx[4 + 4 * a + i] = lin(pos)
+            else:
+                idx[4 + 4 * a + i] = lin(centre)   # unused slots (2D): any finite value
+    per_species = 3 * (2 * hc + hc) + hc + 1
+    for s in range(2):
+        src = 3 + nst + s * per_species
+        dst = 16 + s * (10 * hc + 1)
+        for k in range(3):
+            wsrc = src + k * 3 * hc
+            for j in range(hc):
+                idx[dst + 10 * j + 3 * k + 0] = wsrc + 2 * j
+                idx[dst + 10 * j + 3 * k + 1] = wsrc + 2 * j + 1
+                idx[dst + 10 * j + 3 * k + 2] = wsrc + 2 * hc + j
+        w4 = src + 9 * hc
+        for j in range(hc):
+            idx[dst + 10 * j + 9] = w4 + j
+        idx[dst + 10 * hc] = w4 + hc
+    t = torch.tensor(idx, dtype=torch.long, device=device)
+    _index_cache[key] = t
+    return t
+
+
+def pack_params(dt: torch.Tensor, coef_u: torch.Tensor, coef_v: torch.Tensor, w_laplace: torch.Tensor,
+                branch: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Differentiable (cat + index_select) assembly of the parameter block on the device.
+
+    ``branch`` = [Wh1_u.w, Wh1_u.b, Wh2_u.w, Wh2_u.b, Wh3_u.w, Wh3_u.b, Wh4_u.w, Wh4_u.b, (same for v)].
+    Gradients flow back to every input through stock autograd, so e.g. dL/dCA falls out of
+    ``coef_u = mu_up * sigmoid(CA)`` (train_2drd.py:115) without any kernel support.
+    """
+    hc = branch[0].shape[0]
+    ndim = w_laplace.dim() - 2
+    flat = torch.cat([dt.reshape(1), coef_u.reshape(1), coef_v.reshape(1), w_laplace.reshape(-1)]
+                     + [b.reshape(-1) for b in branch])
+    return flat.index_select(0, _gather_index(hc, ndim, flat.device))
+
+
+def check_star_stencil(w_laplace: torch.Tensor) -> None:
+    """The kernels implement star stencils of radius 2 (what the reference ships: train_2drd.py:20-24,
+    train_3drd.py:22-39).  Anything else is rejected loudly (host check, one sync)."""
+    ndim = w_laplace.dim() - 2
+    if ndim not in (2, 3) or tuple(w_laplace.shape) != (1, 1) + (5,) * ndim:
+        raise ValueError(f"W_laplace.weight must be [1,1,{','.join(['5'] * ndim)}], got {tuple(w_laplace.shape)}")
+    w = w_laplace.detach().reshape((5,) * ndim).cpu()
+    mask = torch.zeros_like(w, dtype=torch.bool)
+    centre = (2,) * ndim
+    mask[centre] = True
+    for a in range(ndim):
+        for off in _OFFS:
+            pos = list(centre)
+            pos[a] += off
+            mask[tuple(pos)] = True
+    if bool((w[~mask] != 0).any()):
+        raise ValueError("W_laplace.weight has non-zero entries off the radius-2 star; unsupported stencil")
+
+
+# ------------------------------------------------------------------------------------------------
+# raw calls
+# ------------------------------------------------------------------------------------------------
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require(t: torch.Tensor, name: str, dtype=None) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"percnn_amd: {name} must live on a HIP device (got {t.device}); there is no CPU path")
+    if t.dtype not in _SUF:
+        raise RuntimeError(f"percnn_amd: {name} must be float32 or float64, got {t.dtype}")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"percnn_amd: {name} has dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"percnn_amd: {name} must be contiguous")
+
+
+def _hc_of(P: torch.Tensor) -> int:
+    n = P.numel() - 16
+    if P.dim() != 1 or n < 22 or n % 2 or (n // 2 - 1) % 10:
+        raise RuntimeError(f"percnn_amd: parameter block has {P.numel()} entries; expected 16 + 2*(10*hc+1)")
+    return (n // 2 - 1) // 10
+
+
+def workspace(hc: int, shape: Sequence[int], dtype, device) -> torch.Tensor:
+    nbytes = _lib.lib().percnn_pi_bwd_workspace_bytes(hc, len(shape), _lib.shape_arg(shape), dtype.itemsize)
+    if nbytes == 0:
+        raise RuntimeError("percnn_amd: invalid problem shape")
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def rollout_fwd_(traj: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
+    """In place: traj[0] holds the initial state; frames 1..T are written."""
+    _require(traj, "traj"); _require(P, "params", traj.dtype)
+    T = traj.shape[0] - 1
+    shape = traj.shape[2:]
+    f = getattr(_lib.lib(), "percnn_pi_rollout_fwd_" + _SUF[traj.dtype])
+    with torch.cuda.device(traj.device):
+        _lib.check(f(traj.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape), T, _stream()),
+                   "rollout_fwd")
+    return traj
+
+
+def rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor,
+                frame_mask: Optional[Sequence[bool]] = None):
+    """-> (dL/dh0 [2,*S], dL/dparams double[np])"""
+    _require(traj, "traj"); _require(g_traj, "g_traj", traj.dtype); _require(P, "params", traj.dtype)
+    T = traj.shape[0] - 1
+    shape = traj.shape[2:]
+    hc = _hc_of(P)
+    g_h0 = torch.empty_like(traj[0])
+    pg = torch.zeros(P.numel(), dtype=torch.float64, device=traj.device)
+    ws = workspace(hc, shape, traj.dtype, traj.device)
+    mask = None
+    if frame_mask is not None:
+        assert len(frame_mask) == T + 1
+        mask = bytes(bytearray(1 if m else 0 for m in frame_mask))
+    f = getattr(_lib.lib(), "percnn_pi_rollout_bwd_" + _SUF[traj.dtype])
+    with torch.cuda.device(traj.device):
+        _lib.check(f(traj.data_ptr(), g_traj.data_ptr(), mask, g_h0.data_ptr(), pg.data_ptr(), ws.data_ptr(),
+                     ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), T, _stream()), "rollout_bwd")
+    return g_h0, pg
+
+
+def step_fwd(h: torch.Tensor, P: torch.Tensor, out: Optional[torch.Tensor] = None, slab: bool = False):
+    """h: [2,*S] (slab=True: [2, n0+4, ...] with halo planes) -> next state, same layout."""
+    _require(h, "h"); _require(P, "params", h.dtype)
+    if out is None:
+        out = torch.empty_like(h)
+    _require(out, "out", h.dtype)
+    shape = list(h.shape[1:])
+    if slab:
+        shape[0] -= 4
+    f = getattr(_lib.lib(), f"percnn_pi_{'slab_' if slab else ''}step_fwd_" + _SUF[h.dtype])
+    with torch.cuda.device(h.device):
+        _lib.check(f(h.data_ptr(), out.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape),
+                     _stream()), "step_fwd")
+    return out
+
+
+def step_bwd(h: torch.Tensor, g_out: torch.Tensor, P: torch.Tensor, g_inject: Optional[torch.Tensor] = None,
+             g_in: Optional[torch.Tensor] = None, param_grad: Optional[torch.Tensor] = None, slab: bool = False,
+             ws: Optional[torch.Tensor] = None):
+    """-> (dL/dh, param_grad double[np] (accumulated if given))"""
+    _require(h, "h"); _require(g_out, "g_out", h.dtype); _require(P, "params", h.dtype)
+    if g_inject is not None:
+        _require(g_inject, "g_inject", h.dtype)
+    if g_in is None:
+        g_in = torch.zeros_like(h) if slab else torch.empty_like(h)
+    hc = _hc_of(P)
+    if param_grad is None:
+        param_grad = torch.zeros(P.numel(), dtype=torch.float64, device=h.device)
+    shape = list(h.shape[1:])
+    if slab:
+        shape[0] -= 4
+    if ws is None:
+        ws = workspace(hc, shape, h.dtype, h.device)
+    f = getattr(_lib.lib(), f"percnn_pi_{'slab_' if slab else ''}step_bwd_" + _SUF[h.dtype])
+    with torch.cuda.device(h.device):
+        _lib.check(f(h.data_ptr(), g_out.data_ptr(), g_inject.data_ptr() if g_inject is not None else None,
+                     g_in.data_ptr(), param_grad.data_ptr(), ws.data_ptr(), ws.numel(), P.data_ptr(), hc,
+                     len(shape), _lib.shape_arg(shape), _stream()), "step_bwd")
+    return g_in, param_grad
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd
+# ------------------------------------------------------------------------------------------------
+def _check_state(h: torch.Tensor) -> None:
+    if h.dim() not in (4, 5) or h.shape[0] != 1 or h.shape[1] != 2:
+        raise RuntimeError(f"percnn_amd: state must be [1,2,*S] (batch 1, two species), got {tuple(h.shape)}")
+
+
+class PiStepFunction(torch.autograd.Function):
+    """One fused step: replaces the ~30 ATen launches of RCNNCell.forward."""
+
+    @staticmethod
+    def forward(ctx, h, P):
+        _check_state(h)
+        h = h.contiguous()
+        P = P.contiguous()
+        out = step_fwd(h[0], P)
+        ctx.save_for_backward(h, P)
+        return out[None]
+
+    @staticmethod
+    def backward(ctx, g):
+        h, P = ctx.saved_tensors
+        g_in, pg = step_bwd(h[0], g.contiguous()[0], P)
+        return g_in[None], pg.to(P.dtype)
+
+
+class PiRolloutFunction(torch.autograd.Function):
+    """T fused steps; returns the whole trajectory [T+1,2,*S] (frame 0 = h0), i.e. what the
+    reference's callers build with torch.cat(tuple(outputs), dim=0) (train_2drd.py:394)."""
+
+    @staticmethod
+    def forward(ctx, h0, P, steps):
+        _check_state(h0)
+        P = P.contiguous()
+        traj = torch.empty((steps + 1,) + tuple(h0.shape[1:]), dtype=h0.dtype, device=h0.device)
+        traj[0].copy_(h0[0])
+        rollout_fwd_(traj, P)
+        ctx.save_for_backward(traj, P)
+        return traj
+
+    @staticmethod
+    def backward(ctx, g_traj):
+        traj, P = ctx.saved_tensors
+        g_h0, pg = rollout_bwd(traj, g_traj.contiguous(), P)
+        return g_h0[None], pg.to(P.dtype), None
+
+
+def pi_step(h: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
+    return PiStepFunction.apply(h, P)
+
+
+def pi_rollout(h0: torch.Tensor, P: torch.Tensor, steps: int) -> torch.Tensor:
+    return PiRolloutFunction.apply(h0, P, int(steps))

@@ -1,0 +1,198 @@
+"""Drop-in ``RCNNCell`` / ``RCNN`` modules backed by the HIP Pi-block kernels.
+
+Same parameter names, shapes and dtypes as the reference modules, so the shipped checkpoints
+load with ``load_state_dict`` (keys ``CA, CB | DA, DB, W_laplace.weight, Wh{1..4}_{u,v}.{weight,
+bias}`` under prefix ``crnn_cell.`` -- DataDrivenModeling/2d_gs_rd/train_2drd.py:46-90,152-158;
+``rcnn_cell.`` in ForwardSimulationOfPDEs/2d_lambda_omega/percnn_LO_eqn.py:160).  Unlike the
+reference, the per-PDE constants are real constructor arguments instead of source literals.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as F_pi
+
+
+def laplace_stencil(ndim: int) -> np.ndarray:
+    """4th-order star Laplacian, dense [1,1,5,5(,5)] (train_2drd.py:20-24; train_3drd.py:22-39)."""
+    w = np.zeros((1, 1) + (5,) * ndim)
+    c = (0, 0) + (2,) * ndim
+    w[c] = -5.0 if ndim == 2 else -7.5
+    for a in range(ndim):
+        for off, val in ((-2, -1 / 12), (-1, 4 / 3), (1, 4 / 3), (2, -1 / 12)):
+            i = list(c)
+            i[2 + a] += off
+            w[tuple(i)] = val
+    return w
+
+
+class RCNNCell(nn.Module):
+    """Pi-block cell: ``forward(h[1,2,*S]) -> (h_next, h_next)`` (train_2drd.py:105-121).
+
+    diffusion='sigmoid' -> coefficient mu_up*sigmoid(CA|CB) (train_2drd.py:115-116);
+    diffusion='raw'     -> coefficient DA|DB                 (percnn_LO_eqn.py:107-108).
+    """
+
+    def __init__(self, ndim: int = 2, hidden_channels: int = 8, dx: float = 0.01, dt: float = 0.5,
+                 mu_up: Optional[float] = 3.99e-5, diffusion: str = "sigmoid", dtype=torch.float32,
+                 stencil_scale: str = "premul", init: str = "xavier", init_c: float = 0.02):
+        super().__init__()
+        if ndim not in (2, 3):
+            raise ValueError("ndim must be 2 or 3")
+        if diffusion not in ("sigmoid", "raw"):
+            raise ValueError("diffusion must be 'sigmoid' or 'raw'")
+        self.ndim, self.hidden_channels = ndim, hidden_channels
+        self.input_channels = 2
+        self.dx, self.dt, self.mu_up, self.diffusion = dx, dt, mu_up, diffusion
+        Conv = nn.Conv2d if ndim == 2 else nn.Conv3d
+        if diffusion == "sigmoid":
+            rs = np.random.RandomState(1234)                      # train_2drd.py:60-62
+            self.CA = nn.Parameter(torch.tensor((rs.rand() - 0.5) * 2, dtype=dtype))
+            self.CB = nn.Parameter(torch.tensor((rs.rand() - 0.5) * 2, dtype=dtype))
+        else:
+            self.DA = nn.Parameter(torch.tensor(0.2, dtype=dtype))  # percnn_LO_eqn.py:42-43
+            self.DB = nn.Parameter(torch.tensor(0.2, dtype=dtype))
+        # frozen but serialised (train_2drd.py:65-67); the kernels read THESE values tap by tap
+        self.W_laplace = Conv(1, 1, 5, 1, padding=0, bias=False, dtype=dtype)
+        st = torch.tensor(laplace_stencil(ndim), dtype=dtype)
+        self.W_laplace.weight.data = (1 / dx ** 2 * st) if stencil_scale == "premul" else (st / dx ** 2)
+        self.W_laplace.weight.requires_grad = False
+        for s in ("u", "v"):
+            for k in (1, 2, 3):
+                setattr(self, f"Wh{k}_{s}", Conv(2, hidden_channels, 1, 1, padding=0, bias=True, dtype=dtype))
+            setattr(self, f"Wh4_{s}", Conv(hidden_channels, 1, 1, 1, padding=0, bias=True, dtype=dtype))
+        self.filter_list = [getattr(self, f"Wh{k}_{s}") for s in ("u", "v") for k in (1, 2, 3, 4)]
+        self.init_filter(self.filter_list, init_c, init)
+        self._stencil_checked_version = None
+        self._dt_cache = None
+
+    def init_filter(self, filter_list, c, mode="xavier"):
+        for f in filter_list:
+            if mode == "xavier":                                   # train_2drd.py:92-103
+                nn.init.xavier_uniform_(f.weight)
+                f.weight.data = c * f.weight.data
+            else:                                                  # percnn_LO_eqn.py:86-95
+                b = c * np.sqrt(1 / np.prod(f.weight.shape[:-1]))
+                f.weight.data.uniform_(-b, b)
+            if f.bias is not None:
+                f.bias.data.fill_(0.0)
+
+    # -- parameter block ----------------------------------------------------------------------
+    def coefficients(self):
+        if self.diffusion == "sigmoid":
+            return self.mu_up * torch.sigmoid(self.CA), self.mu_up * torch.sigmoid(self.CB)
+        return self.DA, self.DB
+
+    def _validate_stencil(self):
+        w = self.W_laplace.weight
+        key = (w._version, w.data_ptr())
+        if self._stencil_checked_version != key:
+            F_pi.check_star_stencil(w)
+            self._stencil_checked_version = key
+
+    def param_block(self) -> torch.Tensor:
+        self._validate_stencil()
+        w = self.W_laplace.weight
+        if self._dt_cache is None or self._dt_cache.device != w.device or self._dt_cache.dtype != w.dtype:
+            self._dt_cache = torch.tensor([self.dt], dtype=w.dtype, device=w.device)
+        cu, cv = self.coefficients()
+        branch = []
+        for s in ("u", "v"):
+            for k in (1, 2, 3, 4):
+                m = getattr(self, f"Wh{k}_{s}")
+                branch += [m.weight, m.bias]
+        return F_pi.pack_params(self._dt_cache, cu, cv, w, branch)
+
+    # -- reference interface -------------------------------------------------------------------
+    def forward(self, h):
+        ch = F_pi.pi_step(h, self.param_block())
+        return ch, ch
+
+    def init_hidden_tensor(self, prev_state):
+        return prev_state.to(self.W_laplace.weight.device)
+
+
+def gs2d_cell(hidden_channels: int = 8) -> RCNNCell:
+    """2D Gray-Scott constants (train_2drd.py:56-58, init c=0.02 :90)."""
+    return RCNNCell(2, hidden_channels, dx=0.01, dt=0.5, mu_up=3.99e-5, diffusion="sigmoid", dtype=torch.float32,
+                    stencil_scale="premul", init="xavier", init_c=0.02)
+
+
+def gs3d_cell(hidden_channels: int = 2) -> RCNNCell:
+    """3D Gray-Scott constants (train_3drd.py:71-73, init c=0.01 :106)."""
+    return RCNNCell(3, hidden_channels, dx=100 / 48, dt=0.5, mu_up=0.274, diffusion="sigmoid", dtype=torch.float32,
+                    stencil_scale="premul", init="xavier", init_c=0.01)
+
+
+def lo2d_cell(hidden_channels: int = 4) -> RCNNCell:
+    """2D lambda-omega constants, float64 (percnn_LO_eqn.py:12,38-43, init c=0.5 :73)."""
+    return RCNNCell(2, hidden_channels, dx=0.2, dt=0.0125, mu_up=None, diffusion="raw", dtype=torch.float64,
+                    stencil_scale="div", init="uniform", init_c=0.5)
+
+
+class Upscaler(nn.Module):
+    """IC generator (train_2drd.py:26-41, train_3drd.py:41-56): stock torch.nn, runs once per
+    rollout and is off the hot path; provided so whole-model checkpoints load."""
+
+    def __init__(self, ndim: int = 2):
+        super().__init__()
+        if ndim == 2:
+            layers = [nn.ConvTranspose2d(2, 8, 5, padding=2, stride=2, output_padding=1, bias=True), nn.Sigmoid(),
+                      nn.ConvTranspose2d(8, 8, 5, padding=2, stride=2, output_padding=1, bias=True),
+                      nn.Conv2d(8, 2, 1, 1, padding=0, bias=True)]
+        else:
+            layers = [nn.ConvTranspose3d(2, 8, 5, padding=2, stride=2, output_padding=1, bias=True), nn.Sigmoid(),
+                      nn.ConvTranspose3d(8, 8, 5, padding=2, stride=1, output_padding=0, bias=True),
+                      nn.Conv3d(8, 2, 1, 1, padding=0, bias=True)]
+        self.convnet = nn.Sequential(*layers)
+
+    def forward(self, h):
+        return self.convnet(h)
+
+
+class RCNN(nn.Module):
+    """Rollout: ``forward() -> (outputs, second_last_state)`` (train_2drd.py:162-190).
+
+    ``outputs[0]`` is the initial state, ``outputs[k]`` the state after the k-th *effective* step
+    (membership in ``effective_step`` honoured -- train_2drd.py:187); all are views of ONE
+    trajectory buffer produced by a single fused rollout call.  ``second_last_state`` is the state
+    after ``step-1`` steps (clone taken at loop index ``step-2`` -- train_2drd.py:182-184).
+    Initial state: a fixed tensor (percnn_LO_eqn.py:158) or ``upscaler(init_state_low)``
+    (train_2drd.py:150,164).
+    """
+
+    def __init__(self, cell: RCNNCell, step: int = 1, effective_step: Sequence[int] = (1,),
+                 init_state: Optional[torch.Tensor] = None, upscaler: Optional[nn.Module] = None,
+                 init_state_low: Optional[torch.Tensor] = None, cell_name: str = "crnn_cell"):
+        super().__init__()
+        if (init_state is None) == (upscaler is None):
+            raise ValueError("give either init_state or upscaler+init_state_low")
+        self.step = step
+        self.effective_step = list(effective_step)
+        self.cell_name = cell_name
+        self.init_state = init_state
+        self.init_state_low = init_state_low
+        if upscaler is not None:
+            self.UpconvBlock = upscaler            # registered first, as in the reference (state_dict order)
+        setattr(self, cell_name, cell)
+
+    @property
+    def cell(self) -> RCNNCell:
+        return getattr(self, self.cell_name)
+
+    def trajectory(self) -> torch.Tensor:
+        """[step+1, 2, *S]: every state of the rollout (what callers cat together, train_2drd.py:394)."""
+        if hasattr(self, "UpconvBlock"):
+            self.init_state = self.UpconvBlock(self.init_state_low)
+        return F_pi.pi_rollout(self.init_state, self.cell.param_block(), self.step)
+
+    def forward(self):
+        traj = self.trajectory()
+        eff = set(self.effective_step)
+        outputs = [traj[0:1]] + [traj[k + 1:k + 2] for k in range(self.step) if k in eff]
+        second_last_state = traj[self.step - 1:self.step].clone() if self.step >= 2 else []
+        return outputs, second_last_state

@@ -1,0 +1,289 @@
+"""GPU: the HIP path (through the C-ABI) against the oracle and the golden vectors.
+
+Tolerances: BASELINE.json asks <= 1e-5 rel-L2 vs the reference path in fp32; the float64
+(lambda-omega) path is held to 1e-12.  Against the plain-C oracle (same explicit op order,
+-ffp-contract=off on both sides) the state and adjoint-state fields must be BIT-IDENTICAL.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import GOLDEN, Golden, TOL_GRAD, TOL_TRAJ, case_id, data_loss, rel_l2, small_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_t(a, device):
+    return torch.tensor(np.ascontiguousarray(a), device=device)
+
+
+def random_block(hc, ndim, dtype, seed, scale=0.5):
+    """Random but well-conditioned parameter block for the plain-C oracle and the kernels."""
+    rs = np.random.RandomState(seed)
+    P = np.zeros(16 + 2 * (10 * hc + 1), dtype=dtype)
+    P[0] = 0.1
+    P[1:3] = rs.uniform(0.01, 0.05, 2)
+    P[3] = -2.0 * ndim * 1.25
+    for a in range(ndim):
+        P[4 + 4 * a:8 + 4 * a] = (-1 / 12, 4 / 3, 4 / 3, -1 / 12) + rs.uniform(-0.01, 0.01, 4)  # asymmetric on purpose
+    P[16:] = rs.uniform(-scale, scale, len(P) - 16)
+    return P
+
+
+# ---------------------------------------------------------------------------------------------
+# forward
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fn", small_cases(), ids=case_id)
+def test_step_and_rollout_forward(fn, hip_device):
+    import percnn_amd as pa
+    from oracle import pi_oracle as O
+    g = Golden(fn)
+    P = g.packed()
+    Pd = dev_t(P, hip_device)
+    # one step: bit-identical to the plain-C oracle, within tolerance of the reference
+    out = pa.step_fwd(dev_t(g.h0[0], hip_device), Pd).cpu().numpy()
+    assert np.array_equal(out, O.step_fwd(g.h0[0], P, g.hc))
+    assert rel_l2(out, g.traj(1)) < (5e-7 if g.dtype == np.float32 else 1e-14)
+    # rollout
+    traj = torch.empty((g.steps + 1,) + g.h0.shape[1:], dtype=torch.from_numpy(g.h0).dtype, device=hip_device)
+    traj[0] = dev_t(g.h0[0], hip_device)
+    pa.rollout_fwd_(traj, Pd)
+    traj = traj.cpu().numpy()
+    assert np.array_equal(traj, O.rollout_fwd(g.h0[0], P, g.hc, g.steps))
+    for t in g.keep_t:
+        assert rel_l2(traj[t], g.traj(t)) < TOL_TRAJ[g.dtype], f"frame {t}"
+
+
+@pytest.mark.parametrize("shape", [(5, 7), (2, 2), (3, 64), (64, 6), (6, 10, 9), (2, 3, 4), (4, 4, 8), (20, 12, 16)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("hc", [2, 3, 8, 16])
+def test_forward_ragged_shapes_and_channel_counts(shape, dtype, hc, hip_device):
+    """Odd extents (scalar path), extents below the stencil width (multiple wraps), generic hc."""
+    import percnn_amd as pa
+    from oracle import pi_oracle as O
+    P = random_block(hc, len(shape), dtype, seed=hc + len(shape))
+    h = np.random.RandomState(1).uniform(-1, 1, (2,) + shape).astype(dtype)
+    out = pa.step_fwd(dev_t(h, hip_device), dev_t(P, hip_device)).cpu().numpy()
+    assert np.array_equal(out, O.step_fwd(h, P, hc))
+
+
+# ---------------------------------------------------------------------------------------------
+# backward
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(5, 7), (2, 2), (16, 32), (64, 6), (6, 10, 9), (2, 3, 4), (8, 8, 16)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("hc", [2, 3, 8, 16])
+def test_step_backward_vs_c_oracle(shape, dtype, hc, hip_device):
+    import percnn_amd as pa
+    from oracle import pi_oracle as O
+    rs = np.random.RandomState(7)
+    P = random_block(hc, len(shape), dtype, seed=hc)
+    h = rs.uniform(-1, 1, (2,) + shape).astype(dtype)
+    G = rs.uniform(-1, 1, (2,) + shape).astype(dtype)
+    inj = rs.uniform(-1, 1, (2,) + shape).astype(dtype)
+    for use_inj in (False, True):
+        gi, pg = pa.step_bwd(dev_t(h, hip_device), dev_t(G, hip_device), dev_t(P, hip_device),
+                             g_inject=dev_t(inj, hip_device) if use_inj else None)
+        gi_o, pg_o = O.step_bwd(h, G, inj if use_inj else None, P, hc)
+        assert np.array_equal(gi.cpu().numpy(), gi_o)            # adjoint state: bit-identical
+        tol = 2e-5 if dtype == np.float32 else 1e-12
+        assert rel_l2(pg.cpu().numpy(), pg_o) < tol              # reductions: order differs
+
+
+@pytest.mark.parametrize("fn", small_cases(), ids=case_id)
+def test_autograd_through_modules_vs_golden(fn, hip_device):
+    """dL/dparams (all 164/44/84 values) and dL/dh0 for the two captured losses."""
+    import percnn_amd as pa
+    g = Golden(fn)
+    cell = g.product_cell(hip_device)
+    for lname in ("meansq", "data"):
+        h0 = dev_t(g.h0, hip_device).requires_grad_(True)
+        model = pa.RCNN(cell, step=g.steps, effective_step=list(range(g.steps)), init_state=h0)
+        outs, _ = model()
+        traj = torch.cat(tuple(outs), dim=0)
+        assert traj.shape[0] == g.steps + 1
+        loss = (traj ** 2).mean() if lname == "meansq" else data_loss(traj, g.stride_t, g.ndim)
+        assert abs(loss.item() - float(g.z[f"loss_{lname}"])) <= 1e-5 * abs(float(g.z[f"loss_{lname}"]))
+        names = [n for n, p in cell.named_parameters() if p.requires_grad]
+        grads = torch.autograd.grad(loss, [p for n, p in cell.named_parameters() if p.requires_grad] + [h0])
+        ref = g.grads(lname)
+        assert sorted(names) == sorted(ref.keys())
+        allm = np.concatenate([gr.cpu().numpy().ravel() for gr in grads[:-1]])
+        allr = np.concatenate([ref[n].ravel() for n in names])
+        assert rel_l2(allm, allr) < TOL_GRAD[g.dtype]
+        for n, gr in zip(names, grads[:-1]):
+            assert gr.shape == ref[n].shape
+            assert rel_l2(gr.cpu().numpy(), ref[n]) < 10 * TOL_GRAD[g.dtype], n
+        assert rel_l2(grads[-1].cpu().numpy(), g.z[f"grad_{lname}_h0"]) < TOL_GRAD[g.dtype]
+
+
+def test_sparse_frame_mask_equals_dense(hip_device):
+    import percnn_amd as pa
+    g = Golden(os.path.join(GOLDEN, "gs2d_ckpt_32x32.npz"))
+    Pd = dev_t(g.packed(), hip_device)
+    T = 23
+    traj = torch.empty((T + 1, 2, 32, 32), device=hip_device)
+    traj[0] = dev_t(g.h0[0], hip_device)
+    pa.rollout_fwd_(traj, Pd)
+    for keep in ([0, 5, 10, 15, 20], [7], [0], [23], []):
+        gt = torch.zeros_like(traj)
+        mask = [False] * (T + 1)
+        for k in keep:
+            gt[k] = torch.randn_like(gt[k])
+            mask[k] = True
+        a0, apg = pa.rollout_bwd(traj, gt, Pd)
+        b0, bpg = pa.rollout_bwd(traj, gt, Pd, frame_mask=mask)
+        assert torch.equal(a0, b0)
+        assert torch.allclose(apg, bpg, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_gradcheck_fp64(ndim, hip_device):
+    """torch.autograd.gradcheck of the custom Functions in float64 on tiny grids (SURVEY 4 iv)."""
+    import percnn_amd as pa
+    shape = (6, 8) if ndim == 2 else (4, 6, 4)
+    P = dev_t(random_block(3, ndim, np.float64, 3), hip_device).requires_grad_(True)
+    h = torch.rand((1, 2) + shape, dtype=torch.float64, device=hip_device, requires_grad=True)
+    assert torch.autograd.gradcheck(pa.pi_step, (h, P), eps=1e-6, atol=1e-7, rtol=1e-5)
+    assert torch.autograd.gradcheck(lambda a, b: pa.pi_rollout(a, b, 3), (h, P), eps=1e-6, atol=1e-7, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# modules: rollout harness (a9), checkpoints (a2)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fam", ["gs2d", "gs3d", "lo2d"])
+def test_rcnn_harness_vs_reference_capture(fam, hip_device):
+    import percnn_amd as pa
+    z = np.load(os.path.join(GOLDEN, f"{fam}_rcnn_harness.npz"))
+    steps, eff = int(z["steps"]), [int(e) for e in z["effective_step"]]
+    sd = {k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("state/")}
+    if fam == "lo2d":
+        m = pa.RCNN(pa.lo2d_cell(), step=steps, effective_step=eff,
+                    init_state=dev_t(z["init_state"], hip_device), cell_name="rcnn_cell")
+    else:
+        nd = 2 if fam == "gs2d" else 3
+        m = pa.RCNN(pa.gs2d_cell() if nd == 2 else pa.gs3d_cell(), step=steps, effective_step=eff,
+                    upscaler=pa.Upscaler(nd), init_state_low=dev_t(z["init_state_low"], hip_device))
+    m.load_state_dict(sd)
+    m.to(hip_device)
+    with torch.no_grad():
+        outs, sl = m()
+    assert len(outs) == z["outputs"].shape[0]
+    tol = 1e-5 if fam != "lo2d" else 1e-12
+    # the upscaler is stock MIOpen/rocBLAS (not ours): compare the rollout relative to ITS output
+    assert rel_l2(torch.cat(outs, 0).cpu().numpy(), z["outputs"]) < tol
+    assert rel_l2(sl.cpu().numpy(), z["second_last_state"]) < tol
+    if steps >= 2:
+        outs_all, _ = pa.RCNN(m.cell, step=steps, effective_step=list(range(steps)), init_state=outs[0])()
+        assert torch.equal(sl, outs_all[steps - 1])
+
+
+def test_cell_forward_signature(hip_device):
+    import percnn_amd as pa
+    g = Golden(os.path.join(GOLDEN, "gs2d_ckpt_32x32.npz"))
+    cell = g.product_cell(hip_device)
+    a, b = cell(dev_t(g.h0, hip_device))
+    assert a is b and tuple(a.shape) == g.h0.shape
+    assert rel_l2(a.detach().cpu().numpy()[0], g.traj(1)) < 5e-7
+
+
+# ---------------------------------------------------------------------------------------------
+# slab layout (one rank of the domain decomposition) against the periodic single-domain step
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(16, 32), (12, 8, 16)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_slab_step_equals_periodic_step(shape, dtype, hip_device):
+    import percnn_amd as pa
+    ndim, hc = len(shape), 4
+    npd = np.float32 if dtype == torch.float32 else np.float64
+    P = dev_t(random_block(hc, ndim, npd, 11), hip_device)
+    h = torch.rand((2,) + shape, dtype=dtype, device=hip_device)
+    G = torch.rand((2,) + shape, dtype=dtype, device=hip_device)
+    full = pa.step_fwd(h, P)
+    gfull, pgfull = pa.step_bwd(h, G, P)
+    n0 = shape[0]
+    pgsum = torch.zeros_like(pgfull)
+    for lo, hi in ((0, n0 // 2), (n0 // 2, n0)):
+        idx = torch.arange(lo - 2, hi + 2, device=hip_device) % n0
+        hs, Gs = h[:, idx].contiguous(), G[:, idx].contiguous()
+        out = pa.step_fwd(hs, P, slab=True)
+        assert torch.equal(out[:, 2:-2], full[:, lo:hi])
+        gi, pg = pa.step_bwd(hs, Gs, P, slab=True)
+        assert torch.equal(gi[:, 2:-2], gfull[:, lo:hi])
+        pgsum += pg
+    assert torch.allclose(pgsum, pgfull, rtol=1e-5 if dtype == torch.float32 else 1e-12, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full sizes
+# ---------------------------------------------------------------------------------------------
+def _big(fam):
+    fn = [f for f in os.listdir(GOLDEN) if f.startswith(fam + "_big_")]
+    if not fn:
+        pytest.skip("big golden absent")
+    return np.load(os.path.join(GOLDEN, fn[0]))
+
+
+@pytest.mark.parametrize("fam,shape", [("gs2d", (512, 512)), ("gs3d", (128, 128, 128)), ("lo2d", (512, 512))])
+def test_full_size_rollout_vs_reference_subsample(fam, shape, hip_device):
+    """configs[1..3]: the reference's own CPU run (every 8th point of h_T + |h_T|) at full size."""
+    import percnn_amd as pa
+    from oracle import restatement as R
+    z = _big(fam)
+    sd = {k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}
+    cell = {"gs2d": pa.gs2d_cell, "gs3d": pa.gs3d_cell, "lo2d": pa.lo2d_cell}[fam]()
+    cell.load_state_dict(sd)
+    cell.to(hip_device)
+    h0 = (R.lo_initial_state(shape[0]) if fam == "lo2d" else R.gs_initial_state(shape, seed=0)).to(hip_device)
+    cps = [int(c) for c in z["checkpoints"]]
+    with torch.no_grad():
+        traj = pa.pi_rollout(h0, cell.param_block(), max(cps))
+    sub = (slice(None),) + (slice(None, None, 8),) * len(shape)
+    tol = 1e-5 if fam != "lo2d" else 1e-12
+    for t in cps:
+        got = traj[t]
+        assert rel_l2(got[sub].cpu().numpy(), z[f"sub/{t}"][0]) < tol, f"t={t}"
+        assert abs(float(torch.linalg.vector_norm(got.double())) - float(z[f"l2/{t}"])) < tol * float(z[f"l2/{t}"])
+        assert torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("shape,hc,dtype", [((512, 512), 8, np.float32), ((128, 128, 128), 2, np.float32),
+                                            ((512, 512), 4, np.float64)])
+def test_full_size_step_bitwise_and_translation_equivariance(shape, hc, dtype, hip_device):
+    """One step at BASELINE sizes: bit-identical to the C oracle (fwd + adjoint state); a periodic
+    shift of the input shifts the output identically (size-independent property of the wrap)."""
+    import percnn_amd as pa
+    from oracle import pi_oracle as O
+    rs = np.random.RandomState(5)
+    P = random_block(hc, len(shape), dtype, 21, scale=0.3)
+    h = rs.uniform(0, 1, (2,) + shape).astype(dtype)
+    G = rs.uniform(-1, 1, (2,) + shape).astype(dtype)
+    hd, Gd, Pd = dev_t(h, hip_device), dev_t(G, hip_device), dev_t(P, hip_device)
+    out = pa.step_fwd(hd, Pd)
+    assert np.array_equal(out.cpu().numpy(), O.step_fwd(h, P, hc))
+    gi, pg = pa.step_bwd(hd, Gd, Pd)
+    gi_o, pg_o = O.step_bwd(h, G, None, P, hc)
+    assert np.array_equal(gi.cpu().numpy(), gi_o)
+    assert rel_l2(pg.cpu().numpy(), pg_o) < (2e-5 if dtype == np.float32 else 1e-12)
+    shifts = tuple(int(s) for s in rs.randint(1, 50, len(shape)))
+    dims = tuple(range(1, 1 + len(shape)))
+    out_s = pa.step_fwd(torch.roll(hd, shifts, dims).contiguous(), Pd)
+    assert torch.equal(out_s, torch.roll(out, shifts, dims))
+
+
+def test_adjoint_dot_product_identity_fp64_full_size(hip_device):
+    """<J v, w> == <v, J^T w> for the 512^2 float64 step (linearisation by central differences)."""
+    import percnn_amd as pa
+    shape, hc = (512, 512), 4
+    P = dev_t(random_block(hc, 2, np.float64, 4, scale=0.3), hip_device)
+    gen = torch.Generator(device=hip_device).manual_seed(0)
+    h = torch.rand((2,) + shape, dtype=torch.float64, device=hip_device, generator=gen)
+    v = torch.randn((2,) + shape, dtype=torch.float64, device=hip_device, generator=gen)
+    w = torch.randn((2,) + shape, dtype=torch.float64, device=hip_device, generator=gen)
+    eps = 1e-6
+    jv = (pa.step_fwd(h + eps * v, P) - pa.step_fwd(h - eps * v, P)) / (2 * eps)
+    jtw, _ = pa.step_bwd(h, w, P)
+    lhs, rhs = (jv * w).sum().item(), (v * jtw).sum().item()
+    assert abs(lhs - rhs) < 1e-7 * max(abs(lhs), abs(rhs), 1.0)

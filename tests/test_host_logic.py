@@ -1,0 +1,137 @@
+"""CPU: host-side logic of the product package and the C-ABI surface (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from util import GOLDEN, Golden, case_id, small_cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = []
+    inc = os.path.join(ROOT, "include")
+    for fn in sorted(os.listdir(inc)):
+        if fn.endswith(".h"):
+            src = open(os.path.join(inc, fn)).read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+            names += re.findall(r"\b(percnn_pi_\w+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    import percnn_amd
+    so = percnn_amd.build()
+    L = ctypes.CDLL(so)
+    names = declared_symbols()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/*.h but not exported"
+    assert percnn_amd.lib().percnn_pi_abi_version() == 1
+    for hc in (2, 4, 8, 16):
+        assert percnn_amd.lib().percnn_pi_param_count(hc) == 16 + 2 * (10 * hc + 1) == percnn_amd.param_count(hc)
+    shape = (ctypes.c_int64 * 2)(512, 512)
+    assert percnn_amd.lib().percnn_pi_bwd_workspace_bytes(8, 2, shape, 4) > 2 * 2 * 512 * 512 * 4
+    assert percnn_amd.lib().percnn_pi_bwd_workspace_bytes(8, 4, shape, 4) == 0       # bad ndim
+    assert percnn_amd.lib().percnn_pi_set_option(b"nonsense", 1) == -1
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    """Validation happens before any launch: bad arguments return PERCNN_PI_EINVAL."""
+    import percnn_amd
+    L = percnn_amd.lib()
+    shape = (ctypes.c_int64 * 2)(8, 8)
+    assert L.percnn_pi_step_fwd_f32(None, None, None, 8, 2, shape, None) == -1
+    assert L.percnn_pi_step_fwd_f32(1, 2, 3, 8, 5, shape, None) == -1
+    assert L.percnn_pi_step_fwd_f32(1, 2, 3, 0, 2, shape, None) == -1
+    bad = (ctypes.c_int64 * 2)(1, 8)
+    assert L.percnn_pi_step_fwd_f64(1, 2, 3, 4, 2, bad, None) == -1
+    assert L.percnn_pi_rollout_fwd_f32(1, 2, 8, 2, shape, -1, None) == -1
+    assert L.percnn_pi_step_bwd_f32(1, 2, None, 3, 4, None, 0, 5, 8, 2, shape, None) == -2   # no workspace
+
+
+@pytest.mark.parametrize("fn", small_cases(), ids=case_id)
+def test_param_block_matches_oracle_layout(fn):
+    g = Golden(fn)
+    cell = g.product_cell("cpu")
+    P = cell.param_block().detach().numpy()
+    Po = g.packed()
+    used = np.ones(len(P), bool)
+    if g.ndim == 2:
+        used[12:16] = False
+    assert P.dtype == Po.dtype == g.dtype
+    assert np.array_equal(P[used], Po[used])
+
+
+def test_param_block_is_differentiable_to_named_parameters():
+    import percnn_amd as pa
+    cell = pa.gs2d_cell(4)
+    P = cell.param_block()
+    w = torch.arange(P.numel(), dtype=P.dtype)
+    (P * w).sum().backward()
+    assert cell.CA.grad is not None and cell.CA.grad.abs() > 0
+    assert cell.W_laplace.weight.grad is None
+    base = 16
+    assert torch.equal(cell.Wh1_u.weight.grad.reshape(4, 2), torch.stack(
+        [torch.tensor([w[base + 10 * j], w[base + 10 * j + 1]]) for j in range(4)]))
+    assert cell.Wh4_v.bias.grad.item() == w[16 + 41 + 40].item()
+
+
+@pytest.mark.parametrize("fam", ["gs2d", "gs3d", "lo2d"])
+def test_state_dict_schema_equals_reference(fam):
+    """Keys, order, shapes and dtypes of the drop-in RCNN equal the reference module's
+    (captured state_dict of the shipped checkpoint)."""
+    import percnn_amd as pa
+    z = np.load(os.path.join(GOLDEN, f"{fam}_rcnn_harness.npz"))
+    sd = {k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("state/")}
+    if fam == "lo2d":
+        m = pa.RCNN(pa.lo2d_cell(), step=2, effective_step=[0, 1], init_state=torch.zeros(1, 2, 8, 8, dtype=torch.float64),
+                    cell_name="rcnn_cell")
+    else:
+        nd = 2 if fam == "gs2d" else 3
+        m = pa.RCNN(pa.gs2d_cell() if nd == 2 else pa.gs3d_cell(), step=2, effective_step=[0, 1],
+                    upscaler=pa.Upscaler(nd), init_state_low=torch.zeros((1, 2) + (4,) * nd))
+    mine = m.state_dict()
+    assert list(mine.keys()) == list(sd.keys())
+    for k in sd:
+        assert mine[k].shape == sd[k].shape and mine[k].dtype == sd[k].dtype, k
+    m.load_state_dict(sd)     # "All keys matched"
+
+
+def test_fresh_cell_deterministic_scalars():
+    """CA/CB = (rand-0.5)*2 under np.random.seed(1234) (train_2drd.py:60-62)."""
+    import percnn_amd as pa
+    c = pa.gs2d_cell()
+    assert abs(c.CA.item() - (-0.6169611)) < 1e-6 and abs(c.CB.item() - 0.2442175) < 1e-6
+    w = c.W_laplace.weight
+    assert w.requires_grad is False
+    assert w[0, 0, 2, 2].item() == -50000.0 and w[0, 0, 2, 1].item() == np.float32(13333.333984375)
+    z = np.load(os.path.join(GOLDEN, "gs2d_fresh_32x32.npz"))
+    assert np.array_equal(w.numpy(), z["param/W_laplace.weight"])
+    z3 = np.load(os.path.join(GOLDEN, "gs3d_fresh_16x16x16.npz"))
+    assert np.array_equal(pa.gs3d_cell().W_laplace.weight.numpy(), z3["param/W_laplace.weight"])
+    zl = np.load(os.path.join(GOLDEN, "lo2d_fresh_32x32.npz"))
+    assert np.array_equal(pa.lo2d_cell().W_laplace.weight.numpy(), zl["param/W_laplace.weight"])
+
+
+def test_no_cpu_fallback_and_bad_stencil_rejected():
+    import percnn_amd as pa
+    c = pa.gs2d_cell()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        c(torch.zeros(1, 2, 8, 8))
+    with torch.no_grad():
+        c.W_laplace.weight[0, 0, 0, 0] = 1.0           # off the star
+    with pytest.raises(ValueError, match="star"):
+        c.param_block()
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "percnn_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"

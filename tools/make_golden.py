@@ -243,7 +243,7 @@ def run_case(case, big):
         elif case == "gs3d":
             big_case(case, mod, (128, 128, 128), [1, 50, 500])
         else:
-            big_case(case, mod, (512, 512), [1, 20, 100])
+            big_case(case, mod, (512, 512), [1, 100, 400])
         return
     if case in ("gs2d", "lo2d"):
         small_case(case, mod, "ckpt", state, (32, 32), 50, [1, 2, 10, 50], 5)
