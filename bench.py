@@ -58,8 +58,6 @@ def cpu_baseline(family, sd, shape, budget_s=15.0):
     from oracle import restatement as R
     cell = {"gs2d": R.gs2d_cell, "gs3d": R.gs3d_cell, "lo2d": R.lo2d_cell}[family]()
     cell.load_state_dict(sd)
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     h0 = initial_state(family, shape)
 
     def run(n):
@@ -68,8 +66,20 @@ def cpu_baseline(family, sd, shape, budget_s=15.0):
         (traj ** 2).mean().backward()
         return time.perf_counter() - t0
 
-    run(2)                                   # warm-up (oneDNN primitive creation)
-    t_probe = run(4) / 4
+    # pick the thread count that is actually fastest on this host (all cores is NOT: oneDNN's
+    # small single-image convolutions oversubscribe badly on 100+ core boxes)
+    ncpu = os.cpu_count() or 1
+    best = None
+    for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
+        torch.set_num_threads(th)
+        run(1)                                # warm-up (oneDNN primitive creation)
+        t1 = run(2) / 2
+        if best is None or t1 < best[1]:
+            best = (th, t1)
+        if t1 > 4 * best[1]:
+            break
+    cores, t_probe = best
+    torch.set_num_threads(cores)
     n = int(max(4, min(200, budget_s / max(t_probe, 1e-6))))
     t = run(n)
     return {"value": n / t, "unit": "steps/s", "cores": cores, "kind": "port",
