@@ -60,8 +60,13 @@ size_t percnn_pi_param_count(int hc);
  * (two adjoint ping-pong states + per-workgroup gradient partials). elem_size = 4 or 8. */
 size_t percnn_pi_bwd_workspace_bytes(int hc, int ndim, const int64_t *shape, int elem_size);
 
-/* Options: key "graph" (0/1, default 0) caches a hipGraph per rollout signature and replays it;
- * key "block" overrides the workgroup size (multiple of 64). Returns 0, or PERCNN_PI_EINVAL. */
+/* Bytes of scratch percnn_pi_rollout_bwd_* needs for a T-step rollout: the adjoint trajectory
+ * (T+1 frames of [2][*S]) + per-workgroup gradient partials. */
+size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *shape, int T, int elem_size);
+
+/* Tuning options (process-wide): "block" = workgroup size of the step kernels (64..256, multiple of
+ * 64); "vec" = 1 forces one point per lane instead of 16 bytes per lane; "wgrad_blocks" = grid cap
+ * of the weight-gradient kernel.  Returns 0, or PERCNN_PI_EINVAL for an unknown key / bad value. */
 int percnn_pi_set_option(const char *key, long value);
 
 /* ---- one Pi-block step ------------------------------------------------------------------
@@ -98,7 +103,10 @@ int percnn_pi_rollout_fwd_f32(float *traj, const float *params, int hc, int ndim
 int percnn_pi_rollout_fwd_f64(double *traj, const double *params, int hc, int ndim,
                               const int64_t *shape, int T, void *stream);
 
-/* Reverse sweep t = T..1 over a trajectory produced by percnn_pi_rollout_fwd_*.
+/* Backward of the rollout over a trajectory produced by percnn_pi_rollout_fwd_*: a sequential
+ * reverse sweep t = T..1 that stores the adjoint trajectory in `workspace`, then ONE time-parallel
+ * reduction over all (step, point) pairs for the branch-weight gradients.
+ *   workspace   percnn_pi_rollout_bwd_workspace_bytes(...) bytes of device scratch
  *   g_traj      dL/dtraj, [T+1][2][*S]
  *   frame_mask  optional HOST array of T+1 bytes; frame k of g_traj is read only where
  *               frame_mask[k] != 0 (sparse losses such as the strided data loss 2dgs:397-402);

@@ -19,7 +19,8 @@ SOURCES = ["pi_abi.hip"]
 HEADERS = ["pi_kernels.h", "pi_device.h", os.path.join("..", "..", "include", "percnn_pi.h")]
 
 EXPORTS = [
-    "percnn_pi_abi_version", "percnn_pi_param_count", "percnn_pi_bwd_workspace_bytes", "percnn_pi_set_option",
+    "percnn_pi_abi_version", "percnn_pi_param_count", "percnn_pi_bwd_workspace_bytes",
+    "percnn_pi_rollout_bwd_workspace_bytes", "percnn_pi_set_option",
 ] + [f"percnn_pi_{op}_{suf}" for suf in ("f32", "f64")
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd")]
 
@@ -60,6 +61,8 @@ def lib() -> ctypes.CDLL:
     L.percnn_pi_param_count.argtypes = [ci]
     L.percnn_pi_bwd_workspace_bytes.restype = sz
     L.percnn_pi_bwd_workspace_bytes.argtypes = [ci, ci, i64p, ci]
+    L.percnn_pi_rollout_bwd_workspace_bytes.restype = sz
+    L.percnn_pi_rollout_bwd_workspace_bytes.argtypes = [ci, ci, i64p, ci, ci]
     L.percnn_pi_set_option.restype = ci
     L.percnn_pi_set_option.argtypes = [ctypes.c_char_p, ctypes.c_long]
     for suf in ("f32", "f64"):
@@ -84,3 +87,7 @@ def check(rc: int, what: str) -> None:
 
 def shape_arg(shape):
     return (ctypes.c_int64 * len(shape))(*[int(s) for s in shape])
+
+
+def set_option(key: str, value: int) -> None:
+    check(lib().percnn_pi_set_option(key.encode(), int(value)), f"set_option({key}={value})")

@@ -15,6 +15,8 @@ using pi::Geom;
 
 struct Options {
     int block = 256;
+    int vec = 0;            // 0 = widest legal (16 B per lane); 1/2/4 = cap (tuning aid)
+    int wgrad_blocks = 1024;
 };
 Options g_opt;
 
@@ -58,6 +60,7 @@ template <typename T>
 int pick_vec(const Problem& p, std::initializer_list<const void*> ptrs)
 {
     constexpr int V = pi::vec_width<T>::value;
+    if (g_opt.vec == 1) return 1;
     if (p.W % V) return 1;
     for (const void* q : ptrs)
         if (q && (reinterpret_cast<uintptr_t>(q) % 16)) return 1;
@@ -83,7 +86,7 @@ unsigned bwd_grid(const Problem& p, int vec)
     return (unsigned)(need < MAX_BWD_BLOCKS ? need : MAX_BWD_BLOCKS);
 }
 
-template <typename T, int NDIM, int HC, int VEC>
+template <typename T, int NDIM, int HC, int VEC, bool WGRAD>
 hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partials, const T* P,
                       const Problem& p, hipStream_t st)
 {
@@ -91,9 +94,47 @@ hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* parti
     const int block = g_opt.block;
     const unsigned grid = bwd_grid(p, VEC);
     const size_t lds = (size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T);
-    hipLaunchKernelGGL((pi::pi_bwd_kernel<T, NDIM, HC, VEC>), dim3(grid), dim3(block), lds, st, h, G, inj, Gp,
-                       partials, P, g, p.hc);
+    hipLaunchKernelGGL((pi::pi_bwd_kernel<T, NDIM, HC, VEC, WGRAD>), dim3(grid), dim3(block), lds, st, h, G, inj,
+                       Gp, partials, P, g, p.hc);
     return hipGetLastError();
+}
+
+// time-parallel weight gradients over steps (t_lo, t_hi]
+template <typename T, int JC, int NS, int VEC>
+hipError_t launch_wgrad_pass(const T* traj, const T* adj, double* partials, const T* P, const Problem& p, int t_lo,
+                             int t_hi, int j0, unsigned nb, hipStream_t st)
+{
+    const int block = 256;
+    const size_t lds = (size_t)(block / pi::WAVE) * NS * (10 * JC + 1) * sizeof(T);
+    hipLaunchKernelGGL((pi::pi_wgrad_kernel<T, JC, NS, VEC>), dim3(nb, NS == 2 ? 1 : 2), dim3(block), lds, st, traj,
+                       adj, partials, P, (long)p.n, t_lo, t_hi, p.hc, j0);
+    return hipGetLastError();
+}
+
+template <typename T, int VEC>
+hipError_t launch_wgrad(const T* traj, const T* adj, double* partials, const T* P, const Problem& p, int t_lo,
+                        int t_hi, unsigned* rows_out, hipStream_t st)
+{
+    const long total = (long)(t_hi - t_lo) * (p.n / VEC);
+    long nb = (total + 256L * 16 - 1) / (256L * 16);          // >= 16 chunks per lane before adding blocks
+    if (nb > g_opt.wgrad_blocks) nb = g_opt.wgrad_blocks;
+    if (nb < 1) nb = 1;
+    *rows_out = (unsigned)(2 * nb);
+    // small hidden widths: one workgroup handles both species (the state is streamed once)
+    if (p.hc == 2) return launch_wgrad_pass<T, 2, 2, VEC>(traj, adj, partials, P, p, t_lo, t_hi, 0, (unsigned)nb, st);
+    if (p.hc == 4) return launch_wgrad_pass<T, 4, 2, VEC>(traj, adj, partials, P, p, t_lo, t_hi, 0, (unsigned)nb, st);
+    const int jc = p.hc % 8 == 0 ? 8 : p.hc % 4 == 0 ? 4 : p.hc % 2 == 0 ? 2 : 1;
+    for (int j0 = 0; j0 < p.hc; j0 += jc) {
+        hipError_t e;
+        switch (jc) {
+            case 8:  e = launch_wgrad_pass<T, 8, 1, VEC>(traj, adj, partials, P, p, t_lo, t_hi, j0, (unsigned)nb, st); break;
+            case 4:  e = launch_wgrad_pass<T, 4, 1, VEC>(traj, adj, partials, P, p, t_lo, t_hi, j0, (unsigned)nb, st); break;
+            case 2:  e = launch_wgrad_pass<T, 2, 1, VEC>(traj, adj, partials, P, p, t_lo, t_hi, j0, (unsigned)nb, st); break;
+            default: e = launch_wgrad_pass<T, 1, 1, VEC>(traj, adj, partials, P, p, t_lo, t_hi, j0, (unsigned)nb, st); break;
+        }
+        if (e) return e;
+    }
+    return hipSuccess;
 }
 
 #define PI_DISPATCH_HC(CALL, NDIM, VEC)                         \
@@ -120,15 +161,18 @@ hipError_t step_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_
 #define CALL_FWD(NDIM, HC, VEC) launch_fwd<T, NDIM, HC, VEC>(h, out, P, p, st)
     PI_DISPATCH(CALL_FWD);
 #undef CALL_FWD
+
 }
 
-template <typename T>
+// WGRAD=true: fused single-step adjoint incl. all parameter gradients (step API);
+// WGRAD=false: adjoint state + diffusion-coefficient gradients only (rollout sweep)
+template <typename T, bool WGRAD>
 hipError_t step_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partials, const T* P, const Problem& p,
                     hipStream_t st, unsigned* grid_out)
 {
     const int vec = pick_vec<T>(p, {h, G, inj, Gp});
     if (grid_out) *grid_out = bwd_grid(p, vec);
-#define CALL_BWD(NDIM, HC, VEC) launch_bwd<T, NDIM, HC, VEC>(h, G, inj, Gp, partials, P, p, st)
+#define CALL_BWD(NDIM, HC, VEC) launch_bwd<T, NDIM, HC, VEC, WGRAD>(h, G, inj, Gp, partials, P, p, st)
     PI_DISPATCH(CALL_BWD);
 #undef CALL_BWD
 }
@@ -188,7 +232,7 @@ int step_bwd_impl(const T* h, const T* g_out, const T* g_inj, T* g_in, double* p
     auto st = static_cast<hipStream_t>(stream);
     if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
     unsigned grid = 0;
-    if (hipError_t e = step_bwd<T>(h, g_out, g_inj, g_in, w.partials, P, p, st, &grid)) return (int)e;
+    if (hipError_t e = step_bwd<T, true>(h, g_out, g_inj, g_in, w.partials, P, p, st, &grid)) return (int)e;
     return (int)finish_grads(w, grid, hc, param_grad, st);
 }
 
@@ -205,6 +249,11 @@ int rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* shape
     return 0;
 }
 
+size_t rollout_workspace_bytes(const Problem& p, int T_steps, int elem)
+{
+    return align_up((size_t)(T_steps + 1) * 2 * p.n * elem, 256) + partials_bytes_for(p.hc);
+}
+
 template <typename T>
 int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, T* g_h0, double* param_grad, void* ws,
                      size_t ws_bytes, const T* P, int hc, int ndim, const int64_t* shape, int T_steps, void* stream)
@@ -212,11 +261,16 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     Problem p;
     if (int rc = make_problem(hc, ndim, shape, false, p)) return rc;
     if (!traj || !g_traj || !g_h0 || !param_grad || !P || T_steps < 0) return PERCNN_PI_EINVAL;
-    Workspace w;
-    if (!carve(ws, ws_bytes, p, sizeof(T), w)) return PERCNN_PI_EWORKSPACE;
+    if (!ws || ws_bytes < rollout_workspace_bytes(p, T_steps, sizeof(T)) || (reinterpret_cast<uintptr_t>(ws) % 16))
+        return PERCNN_PI_EWORKSPACE;
     auto st = static_cast<hipStream_t>(stream);
     const size_t frame = (size_t)2 * p.n;
     const size_t frame_bytes = frame * sizeof(T);
+    T* adj = static_cast<T*>(ws);                       // adjoint trajectory: adj[t] = dL/dh_t (all consumers)
+    Workspace w;
+    w.partials = reinterpret_cast<double*>(static_cast<unsigned char*>(ws) +
+                                           align_up((size_t)(T_steps + 1) * frame_bytes, 256));
+    w.partials_bytes = partials_bytes_for(p.hc);
     auto has = [&](int t) { return !mask || mask[t]; };
 
     // frames after the last one carrying gradient contribute nothing: start the sweep there
@@ -227,19 +281,27 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
         return (int)hipMemsetAsync(g_h0, 0, frame_bytes, st);
     }
     if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
+    if (hipError_t e = hipMemcpyAsync(adj + (size_t)t_top * frame, g_traj + (size_t)t_top * frame, frame_bytes,
+                                      hipMemcpyDeviceToDevice, st))
+        return (int)e;
 
-    const T* A = g_traj + (size_t)t_top * frame;      // adjoint of frame t (read in place for the top frame)
-    int flip = 0;
-    unsigned grid = 0;
+    // 1) sequential reverse sweep: adjoint states (+ diffusion-coefficient gradients)
+    unsigned rows = 0;
     for (int t = t_top; t >= 1; --t) {
-        T* dst = (t == 1) ? g_h0 : static_cast<T*>(w.adj[flip]);
+        T* dst = (t == 1) ? g_h0 : adj + (size_t)(t - 1) * frame;
         const T* inj = has(t - 1) ? g_traj + (size_t)(t - 1) * frame : nullptr;
-        if (hipError_t e = step_bwd<T>(traj + (size_t)(t - 1) * frame, A, inj, dst, w.partials, P, p, st, &grid))
+        if (hipError_t e = step_bwd<T, false>(traj + (size_t)(t - 1) * frame, adj + (size_t)t * frame, inj, dst,
+                                              w.partials, P, p, st, &rows))
             return (int)e;
-        A = dst;
-        flip ^= 1;
     }
-    return (int)finish_grads(w, grid, hc, param_grad, st);
+    // 2) branch-weight gradients of all t_top steps at once (time-parallel reduction)
+    unsigned wrows = 0;
+    const bool vec_ok = (p.n % pi::vec_width<T>::value == 0) && g_opt.vec != 1 &&
+                        (reinterpret_cast<uintptr_t>(traj) % 16 == 0);
+    hipError_t e = vec_ok ? launch_wgrad<T, pi::vec_width<T>::value>(traj, adj, w.partials, P, p, 0, t_top, &wrows, st)
+                          : launch_wgrad<T, 1>(traj, adj, w.partials, P, p, 0, t_top, &wrows, st);
+    if (e) return (int)e;
+    return (int)finish_grads(w, rows > wrows ? rows : wrows, hc, param_grad, st);
 }
 
 }  // namespace
@@ -261,9 +323,26 @@ size_t percnn_pi_bwd_workspace_bytes(int hc, int ndim, const int64_t* shape, int
     return workspace_bytes(q, elem_size);
 }
 
+size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t* shape, int T_steps, int elem_size)
+{
+    Problem p;
+    if (make_problem(hc, ndim, shape, false, p) || (elem_size != 4 && elem_size != 8) || T_steps < 0) return 0;
+    return rollout_workspace_bytes(p, T_steps, elem_size);
+}
+
 int percnn_pi_set_option(const char* key, long value)
 {
     if (!key) return PERCNN_PI_EINVAL;
+    if (!std::strcmp(key, "vec")) {
+        if (value != 0 && value != 1) return PERCNN_PI_EINVAL;
+        g_opt.vec = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "wgrad_blocks")) {
+        if (value < 1 || value > MAX_BWD_BLOCKS / 2) return PERCNN_PI_EINVAL;
+        g_opt.wgrad_blocks = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "block")) {
         if (value < 64 || value > 256 || value % 64) return PERCNN_PI_EINVAL;
         g_opt.block = (int)value;

@@ -157,7 +157,7 @@ pi_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict_
 // Gradient of the diffusion coefficient uses sum_x g*Lap(h) == sum_x LapT(g)*h, so the forward
 // Laplacian is never recomputed.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NDIM, int HC, int VEC>
+template <typename T, int NDIM, int HC, int VEC, bool WGRAD>
 __global__ void __launch_bounds__(256)
 pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restrict__ inj, T* __restrict__ Gp,
               double* __restrict__ partials, const T* __restrict__ P, Geom g, int hc_rt)
@@ -221,10 +221,10 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
                 acc_b4 += gr[i];
             }
             acc_c = wave_sum_to_last(acc_c);
-            acc_b4 = wave_sum_to_last(acc_b4);
+            if constexpr (WGRAD) acc_b4 = wave_sum_to_last(acc_b4);
             if (lane == REDUCE_LANE) {
                 myred[P_COEF + s] += acc_c;
-                myred[gbase + 10 * hc] += acc_b4;
+                if constexpr (WGRAD) myred[gbase + 10 * hc] += acc_b4;
             }
 #pragma unroll
             for (int j = 0; j < hc; ++j) {
@@ -242,18 +242,22 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
                     const T p12 = a1 * a2;
                     const T gw = gr[i] * w9;
                     const T q1 = gw * (a2 * a3), q2 = gw * (a1 * a3), q3 = gw * p12;
-                    acc[9] += gr[i] * (p12 * a3);
-                    acc[0] += q1 * u.v[i]; acc[1] += q1 * v.v[i]; acc[2] += q1;
-                    acc[3] += q2 * u.v[i]; acc[4] += q2 * v.v[i]; acc[5] += q2;
-                    acc[6] += q3 * u.v[i]; acc[7] += q3 * v.v[i]; acc[8] += q3;
+                    if constexpr (WGRAD) {
+                        acc[9] += gr[i] * (p12 * a3);
+                        acc[0] += q1 * u.v[i]; acc[1] += q1 * v.v[i]; acc[2] += q1;
+                        acc[3] += q2 * u.v[i]; acc[4] += q2 * v.v[i]; acc[5] += q2;
+                        acc[6] += q3 * u.v[i]; acc[7] += q3 * v.v[i]; acc[8] += q3;
+                    }
                     du[i] = fma_(q1, w0, fma_(q2, w3, fma_(q3, w6, du[i])));
                     dv[i] = fma_(q1, w1, fma_(q2, w4, fma_(q3, w7, dv[i])));
                 }
+                if constexpr (WGRAD) {
 #pragma unroll
-                for (int m = 0; m < 10; ++m) acc[m] = wave_sum_to_last(acc[m]);
-                if (lane == REDUCE_LANE) {
+                    for (int m = 0; m < 10; ++m) acc[m] = wave_sum_to_last(acc[m]);
+                    if (lane == REDUCE_LANE) {
 #pragma unroll
-                    for (int m = 0; m < 10; ++m) myred[gbase + 10 * j + m] += acc[m];
+                        for (int m = 0; m < 10; ++m) myred[gbase + 10 * j + m] += acc[m];
+                    }
                 }
             }
         }
@@ -280,9 +284,114 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
     __syncthreads();
     for (int idx = threadIdx.x; idx < np; idx += blockDim.x) {
         if (idx == P_DT || (idx >= P_C0 && idx < P_W)) continue;   // dt and the frozen stencil carry no gradient
+        if (!WGRAD && idx >= P_W) break;                           // sweep-only flavour: coefficients only
         T s = T(0);
         for (int w = 0; w < nwaves; ++w) s += red[w * np + idx];
         partials[(long)blockIdx.x * np + idx] += (double)s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradients of the whole rollout in ONE launch (the "wgrad" kernel).
+//
+// The reverse sweep is sequential in time, but once the adjoint trajectory adj[t] = dL/dh_t is
+// stored, the parameter gradients  sum_t sum_x (...)  are an embarrassingly parallel reduction over
+// all T*P (step, point) pairs.  Every lane streams (h_{t-1}, adj_t) chunks with 16-byte loads,
+// keeps its NS*(10*JC+1) running sums in registers for the whole kernel and the cross-lane
+// reduction happens exactly once at the end -- no per-step reductions, no per-step launch
+// latency, full chip.  NS = 2: one workgroup differentiates both species' branches (small hc, the
+// state is read once); NS = 1: blockIdx.y picks the species.  Hidden channels [j0, j0+JC).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int JC, int NS, int VEC>
+__global__ void __launch_bounds__(256)
+pi_wgrad_kernel(const T* __restrict__ traj, const T* __restrict__ adj, double* __restrict__ partials,
+                const T* __restrict__ P, long n, int t_lo, int t_hi, int hc, int j0)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* red = reinterpret_cast<T*>(smem_raw);            // [nwaves][NS*(10*JC+1)]
+    constexpr int NA = 10 * JC + 1;
+    const int np = nparams(hc);
+    const T dt = P[P_DT];
+    const long frame = 2 * n;
+    const long cpf = n / VEC;                            // chunks per frame
+    const long nsteps = t_hi - t_lo;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long stride_t = stride / cpf, stride_x = stride - stride_t * cpf;
+
+    T acc[NS][JC][10];
+    T acc_b4[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        acc_b4[q] = T(0);
+#pragma unroll
+        for (int jj = 0; jj < JC; ++jj)
+#pragma unroll
+            for (int m = 0; m < 10; ++m) acc[q][jj][m] = T(0);
+    }
+
+    const long c0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long tt = c0 / cpf, xc = c0 - tt * cpf;
+    while (tt < nsteps) {
+        const long t = t_lo + 1 + tt;                    // step t maps frame t-1 -> frame t
+        const long x = xc * VEC;
+        const Pack<T, VEC> u = ld<T, VEC>(traj + (t - 1) * frame + x);
+        const Pack<T, VEC> v = ld<T, VEC>(traj + (t - 1) * frame + n + x);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const int s = NS == 2 ? q : (int)blockIdx.y;
+            const T* W = P + P_W + s * species_block(hc) + 10 * j0;
+            const Pack<T, VEC> a = ld<T, VEC>(adj + t * frame + s * n + x);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const T gr = a.v[i] * dt;
+                acc_b4[q] += gr;
+#pragma unroll
+                for (int jj = 0; jj < JC; ++jj) {
+                    const T* w = W + 10 * jj;
+                    const T a1 = fma_(w[0], u.v[i], fma_(w[1], v.v[i], w[2]));
+                    const T a2 = fma_(w[3], u.v[i], fma_(w[4], v.v[i], w[5]));
+                    const T a3 = fma_(w[6], u.v[i], fma_(w[7], v.v[i], w[8]));
+                    const T p12 = a1 * a2;
+                    const T gw = gr * w[9];
+                    const T q1 = gw * (a2 * a3), q2 = gw * (a1 * a3), q3 = gw * p12;
+                    T* A = acc[q][jj];
+                    A[9] = fma_(gr, p12 * a3, A[9]);
+                    A[0] = fma_(q1, u.v[i], A[0]); A[1] = fma_(q1, v.v[i], A[1]); A[2] += q1;
+                    A[3] = fma_(q2, u.v[i], A[3]); A[4] = fma_(q2, v.v[i], A[4]); A[5] += q2;
+                    A[6] = fma_(q3, u.v[i], A[6]); A[7] = fma_(q3, v.v[i], A[7]); A[8] += q3;
+                }
+            }
+        }
+        xc += stride_x;
+        tt += stride_t;
+        if (xc >= cpf) { xc -= cpf; ++tt; }
+    }
+
+    const int nwaves = blockDim.x / WAVE;
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+#pragma unroll
+        for (int jj = 0; jj < JC; ++jj)
+#pragma unroll
+            for (int m = 0; m < 10; ++m) {
+                const T r = wave_sum_to_last(acc[q][jj][m]);
+                if (lane == REDUCE_LANE) red[(wave * NS + q) * NA + 10 * jj + m] = r;
+            }
+        const T r = wave_sum_to_last(acc_b4[q]);
+        if (lane == REDUCE_LANE) red[(wave * NS + q) * NA + 10 * JC] = r;
+    }
+    __syncthreads();
+    const long row = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    for (int k = threadIdx.x; k < NS * NA; k += blockDim.x) {
+        const int q = k / NA, idx = k - q * NA;
+        if (idx == 10 * JC && j0 != 0) continue;         // the Wh4 bias is accumulated by the j0 == 0 pass only
+        const int s = NS == 2 ? q : (int)blockIdx.y;
+        const int gbase = P_W + s * species_block(hc);
+        T sum = T(0);
+        for (int w = 0; w < nwaves; ++w) sum += red[(w * NS + q) * NA + idx];
+        const int col = idx == 10 * JC ? gbase + 10 * hc : gbase + 10 * j0 + idx;
+        partials[row * np + col] += (double)sum;
     }
 }
 

@@ -143,6 +143,14 @@ def workspace(hc: int, shape: Sequence[int], dtype, device) -> torch.Tensor:
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
+def rollout_workspace(hc: int, shape: Sequence[int], T: int, dtype, device) -> torch.Tensor:
+    nbytes = _lib.lib().percnn_pi_rollout_bwd_workspace_bytes(hc, len(shape), _lib.shape_arg(shape), T,
+                                                              dtype.itemsize)
+    if nbytes == 0:
+        raise RuntimeError("percnn_amd: invalid problem shape")
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
 def rollout_fwd_(traj: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
     """In place: traj[0] holds the initial state; frames 1..T are written."""
     _require(traj, "traj"); _require(P, "params", traj.dtype)
@@ -156,7 +164,7 @@ def rollout_fwd_(traj: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
 
 
 def rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor,
-                frame_mask: Optional[Sequence[bool]] = None):
+                frame_mask: Optional[Sequence[bool]] = None, ws: Optional[torch.Tensor] = None):
     """-> (dL/dh0 [2,*S], dL/dparams double[np])"""
     _require(traj, "traj"); _require(g_traj, "g_traj", traj.dtype); _require(P, "params", traj.dtype)
     T = traj.shape[0] - 1
@@ -164,7 +172,8 @@ def rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor,
     hc = _hc_of(P)
     g_h0 = torch.empty_like(traj[0])
     pg = torch.zeros(P.numel(), dtype=torch.float64, device=traj.device)
-    ws = workspace(hc, shape, traj.dtype, traj.device)
+    if ws is None:
+        ws = rollout_workspace(hc, shape, T, traj.dtype, traj.device)
     mask = None
     if frame_mask is not None:
         assert len(frame_mask) == T + 1
