@@ -124,21 +124,26 @@ int percnn_pi_rollout_bwd_f64(const double *traj, const double *g_traj, const un
 
 /* ---- slab-decomposed step (one rank of a 1-D domain decomposition along spatial axis 0) ----
  * No reference counterpart: the reference is single-GPU (each script pins one device, 2dgs:14).
- * `h` / `g_out` are LOCAL slabs WITH two halo planes on each side of axis 0:
- *   [2][n0 + 4][rest], planes 0,1 and n0+2,n0+3 filled by the caller's halo exchange;
- * `out` / `g_in` have the same padded layout and only their interior planes 2..n0+1 are
- * written.  `shape` is the LOCAL interior shape {n0, ...}; the other axes stay periodic.
- * g_inject (nullable) and the state `h` of the backward are padded the same way. */
+ * All state-shaped arrays are LOCAL slabs with `halo` planes (even, >= 2) on each side of axis 0:
+ *   [2][n0 + 2*halo][rest];  `shape` = LOCAL interior shape {n0, ...}; other axes stay periodic.
+ * Forward: planes [skip, n0+2*halo-skip) of `h` must be valid (filled by the caller's halo
+ * exchange or by a previous call with skip-2); planes [skip+2, n0+2*halo-skip-2) of `out` are
+ * written.  skip = 0, 2, ..., halo-2 lets the caller take halo/2 steps per exchange (wide halos,
+ * the outer planes being recomputed redundantly); the last of them writes exactly the interior.
+ * Backward: `g_out` needs 2 valid planes next to the interior; `h`, `g_inject` (nullable) and
+ * `g_in` are touched on the interior planes [halo, halo+n0) only; param_grad sums over them. */
 int percnn_pi_slab_step_fwd_f32(const float *h, float *out, const float *params, int hc, int ndim,
-                                const int64_t *shape, void *stream);
+                                const int64_t *shape, int halo, int skip, void *stream);
 int percnn_pi_slab_step_fwd_f64(const double *h, double *out, const double *params, int hc, int ndim,
-                                const int64_t *shape, void *stream);
+                                const int64_t *shape, int halo, int skip, void *stream);
 int percnn_pi_slab_step_bwd_f32(const float *h, const float *g_out, const float *g_inject, float *g_in,
                                 double *param_grad, void *workspace, size_t workspace_bytes,
-                                const float *params, int hc, int ndim, const int64_t *shape, void *stream);
+                                const float *params, int hc, int ndim, const int64_t *shape, int halo,
+                                void *stream);
 int percnn_pi_slab_step_bwd_f64(const double *h, const double *g_out, const double *g_inject, double *g_in,
                                 double *param_grad, void *workspace, size_t workspace_bytes,
-                                const double *params, int hc, int ndim, const int64_t *shape, void *stream);
+                                const double *params, int hc, int ndim, const int64_t *shape, int halo,
+                                void *stream);
 
 #ifdef __cplusplus
 }

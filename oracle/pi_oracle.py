@@ -143,3 +143,26 @@ def rollout_bwd(traj: np.ndarray, gtraj: np.ndarray, P: np.ndarray, hc: int):
                                                    _ptr(pg, ctypes.c_double), _ptr(work, ct), _ptr(P, ct),
                                                    hc, len(S), _shape(S), T)
     return g0, pg
+
+
+# ---- range-restricted steps (used by the slab / halo-exchange tests) -------------------------------
+def step_fwd_range(h: np.ndarray, out: np.ndarray, P: np.ndarray, hc: int, lo: int, hi: int) -> np.ndarray:
+    """Planes [lo, hi) of axis 0 of ``out`` are overwritten with the step applied to ``h``."""
+    ct, suf = _ct(h.dtype)
+    assert h.flags.c_contiguous and out.flags.c_contiguous
+    S = h.shape[1:]
+    getattr(lib(), "pi_oracle_step_fwd_range_" + suf)(_ptr(h, ct), _ptr(out, ct), _ptr(P, ct), hc, len(S), _shape(S),
+                                                      ctypes.c_long(lo), ctypes.c_long(hi))
+    return out
+
+
+def step_bwd_range(h, G, inj, Gp, pg, P, hc, lo, hi):
+    """Adjoint restricted to planes [lo, hi): writes those planes of ``Gp``, accumulates into ``pg``."""
+    ct, suf = _ct(h.dtype)
+    assert all(a.flags.c_contiguous for a in (h, G, Gp)) and pg.dtype == np.float64
+    S = h.shape[1:]
+    injp = _ptr(inj, ct) if inj is not None else None
+    getattr(lib(), "pi_oracle_step_bwd_range_" + suf)(_ptr(h, ct), _ptr(G, ct), injp, _ptr(Gp, ct),
+                                                      _ptr(pg, ctypes.c_double), _ptr(P, ct), hc, len(S), _shape(S),
+                                                      ctypes.c_long(lo), ctypes.c_long(hi))
+    return Gp, pg

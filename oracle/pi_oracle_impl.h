@@ -41,7 +41,9 @@ static REAL FN(star_)(const REAL *f, const REAL *P, int ndim, const long *S, con
     return lap;
 }
 
-void FN(pi_oracle_step_fwd_)(const REAL *h, REAL *out, const REAL *P, int hc, int ndim, const long *S)
+/* planes [lo0, hi0) of axis 0 are computed, the rest of `out` is left untouched (slab tests) */
+void FN(pi_oracle_step_fwd_range_)(const REAL *h, REAL *out, const REAL *P, int hc, int ndim, const long *S,
+                                   long lo0, long hi0)
 {
     long n = 1;
     for (int a = 0; a < ndim; ++a) n *= S[a];
@@ -50,6 +52,7 @@ void FN(pi_oracle_step_fwd_)(const REAL *h, REAL *out, const REAL *P, int hc, in
     for (long p = 0; p < n; ++p) {
         long r = p;
         for (int a = ndim - 1; a >= 0; --a) { idx[a] = r % S[a]; r /= S[a]; }
+        if (idx[0] < lo0 || idx[0] >= hi0) continue;
         const REAL u = h[p], v = h[n + p];
         for (int s = 0; s < 2; ++s) {
             const REAL *W = P + 16 + s * (10 * hc + 1);
@@ -69,10 +72,16 @@ void FN(pi_oracle_step_fwd_)(const REAL *h, REAL *out, const REAL *P, int hc, in
     }
 }
 
+void FN(pi_oracle_step_fwd_)(const REAL *h, REAL *out, const REAL *P, int hc, int ndim, const long *S)
+{
+    FN(pi_oracle_step_fwd_range_)(h, out, P, hc, ndim, S, 0, S[0]);
+}
+
 /* Adjoint of one step.  G = dL/d(next state) [2][n]; inj (nullable) = dL/d(out_{t-1}) added at the end;
- * Gprev = dL/d(prev state); pg accumulates parameter gradients (double). */
-void FN(pi_oracle_step_bwd_)(const REAL *h, const REAL *G, const REAL *inj, REAL *Gprev, double *pg,
-                             const REAL *P, int hc, int ndim, const long *S)
+ * Gprev = dL/d(prev state); pg accumulates parameter gradients (double).
+ * Only planes [lo0, hi0) of axis 0 are computed / accumulated (slab tests). */
+void FN(pi_oracle_step_bwd_range_)(const REAL *h, const REAL *G, const REAL *inj, REAL *Gprev, double *pg,
+                                   const REAL *P, int hc, int ndim, const long *S, long lo0, long hi0)
 {
     long n = 1;
     for (int a = 0; a < ndim; ++a) n *= S[a];
@@ -81,6 +90,7 @@ void FN(pi_oracle_step_bwd_)(const REAL *h, const REAL *G, const REAL *inj, REAL
     for (long p = 0; p < n; ++p) {
         long r = p;
         for (int a = ndim - 1; a >= 0; --a) { idx[a] = r % S[a]; r /= S[a]; }
+        if (idx[0] < lo0 || idx[0] >= hi0) continue;
         const REAL u = h[p], v = h[n + p];
         REAL du = 0, dv = 0;
         REAL dl[2];
@@ -116,6 +126,12 @@ void FN(pi_oracle_step_bwd_)(const REAL *h, const REAL *G, const REAL *inj, REAL
         Gprev[p] = gu;
         Gprev[n + p] = gv;
     }
+}
+
+void FN(pi_oracle_step_bwd_)(const REAL *h, const REAL *G, const REAL *inj, REAL *Gprev, double *pg,
+                             const REAL *P, int hc, int ndim, const long *S)
+{
+    FN(pi_oracle_step_bwd_range_)(h, G, inj, Gprev, pg, P, hc, ndim, S, 0, S[0]);
 }
 
 /* traj: [T+1][2][n], frame 0 filled by the caller (2dgs:162-190 rollout loop) */

@@ -66,11 +66,14 @@ def lib() -> ctypes.CDLL:
     L.percnn_pi_set_option.restype = ci
     L.percnn_pi_set_option.argtypes = [ctypes.c_char_p, ctypes.c_long]
     for suf in ("f32", "f64"):
-        for pre in ("", "slab_"):
-            f = getattr(L, f"percnn_pi_{pre}step_fwd_{suf}")
-            f.restype, f.argtypes = ci, [vp, vp, vp, ci, ci, i64p, vp]
-            f = getattr(L, f"percnn_pi_{pre}step_bwd_{suf}")
-            f.restype, f.argtypes = ci, [vp, vp, vp, vp, vp, vp, sz, vp, ci, ci, i64p, vp]
+        f = getattr(L, f"percnn_pi_step_fwd_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, vp, ci, ci, i64p, vp]
+        f = getattr(L, f"percnn_pi_step_bwd_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, vp, vp, vp, vp, sz, vp, ci, ci, i64p, vp]
+        f = getattr(L, f"percnn_pi_slab_step_fwd_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, vp, ci, ci, i64p, ci, ci, vp]
+        f = getattr(L, f"percnn_pi_slab_step_bwd_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, vp, vp, vp, vp, sz, vp, ci, ci, i64p, ci, vp]
         f = getattr(L, f"percnn_pi_rollout_fwd_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, ci, ci, i64p, ci, vp]
         f = getattr(L, f"percnn_pi_rollout_bwd_{suf}")

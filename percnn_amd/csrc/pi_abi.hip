@@ -29,6 +29,8 @@ struct Problem {
     int64_t n0, n1, W;
     int64_t n;          // points per species (interior)
     bool slab;
+    int halo = 2;       // slab layout: planes present on each side of axis 0 (even, >= 2)
+    int skip = 0;       // slab layout: outermost planes per side that this call neither reads nor writes
 };
 
 int make_problem(int hc, int ndim, const int64_t* shape, bool slab, Problem& p)
@@ -51,8 +53,16 @@ Geom make_geom(const Problem& p)
     g.n0 = (int)p.n0; g.n1 = (int)p.n1; g.W = (int)p.W;
     g.rows = (int)(p.n0 * p.n1);
     g.s0 = (long)(p.n1 * p.W);
-    if (p.slab) { g.ss = (long)(p.n0 + 4) * g.s0; g.off = 2 * g.s0; g.wrap0 = 0; }
-    else        { g.ss = (long)p.n0 * g.s0;       g.off = 0;        g.wrap0 = 1; }
+    if (p.slab) {
+        // local array: n0 + 2*halo planes; this call computes planes [skip+2, n0+2*halo-skip-2)
+        g.ss = (long)(p.n0 + 2 * p.halo) * g.s0;
+        g.off = (long)(p.skip + 2) * g.s0;
+        g.n0 = (int)(p.n0 + 2 * p.halo - 2 * p.skip - 4);
+        g.rows = g.n0 * (int)p.n1;
+        g.wrap0 = 0;
+    } else {
+        g.ss = (long)p.n0 * g.s0; g.off = 0; g.wrap0 = 1;
+    }
     return g;
 }
 
@@ -75,13 +85,14 @@ hipError_t launch_fwd(const T* h, T* out, const T* P, const Problem& p, hipStrea
     const long nchunks = (long)g.rows * (g.W / VEC);
     const int block = g_opt.block;
     const unsigned grid = (unsigned)((nchunks + block - 1) / block);
+    if (nchunks <= 0) return hipSuccess;
     hipLaunchKernelGGL((pi::pi_fwd_kernel<T, NDIM, HC, VEC>), dim3(grid), dim3(block), 0, st, h, out, P, g, p.hc);
     return hipGetLastError();
 }
 
 unsigned bwd_grid(const Problem& p, int vec)
 {
-    const long nchunks = (long)(p.n0 * p.n1) * (p.W / vec);
+    const long nchunks = (long)make_geom(p).rows * (p.W / vec);
     const long need = (nchunks + g_opt.block - 1) / g_opt.block;
     return (unsigned)(need < MAX_BWD_BLOCKS ? need : MAX_BWD_BLOCKS);
 }
@@ -211,21 +222,31 @@ hipError_t finish_grads(const Workspace& w, unsigned nblocks, int hc, double* pa
 }
 
 // ---- typed implementations -----------------------------------------------------------------------
+int set_slab(Problem& p, int halo, int skip)
+{
+    if (halo < 2 || (halo & 1) || skip < 0 || (skip & 1) || skip > halo - 2) return PERCNN_PI_EINVAL;
+    p.halo = halo; p.skip = skip;
+    return 0;
+}
+
 template <typename T>
-int step_fwd_impl(const T* h, T* out, const T* P, int hc, int ndim, const int64_t* shape, void* stream, bool slab)
+int step_fwd_impl(const T* h, T* out, const T* P, int hc, int ndim, const int64_t* shape, void* stream, bool slab,
+                  int halo = 2, int skip = 0)
 {
     Problem p;
     if (int rc = make_problem(hc, ndim, shape, slab, p)) return rc;
+    if (slab) if (int rc = set_slab(p, halo, skip)) return rc;
     if (!h || !out || !P || h == out) return PERCNN_PI_EINVAL;
     return (int)step_fwd<T>(h, out, P, p, static_cast<hipStream_t>(stream));
 }
 
 template <typename T>
 int step_bwd_impl(const T* h, const T* g_out, const T* g_inj, T* g_in, double* param_grad, void* ws, size_t ws_bytes,
-                  const T* P, int hc, int ndim, const int64_t* shape, void* stream, bool slab)
+                  const T* P, int hc, int ndim, const int64_t* shape, void* stream, bool slab, int halo = 2)
 {
     Problem p;
     if (int rc = make_problem(hc, ndim, shape, slab, p)) return rc;
+    if (slab) if (int rc = set_slab(p, halo, halo - 2)) return rc;     // adjoint: interior planes only
     if (!h || !g_out || !g_in || !param_grad || !P || g_in == g_out) return PERCNN_PI_EINVAL;
     Workspace w;
     if (!carve(ws, ws_bytes, p, sizeof(T), w)) return PERCNN_PI_EWORKSPACE;
@@ -357,8 +378,8 @@ int percnn_pi_set_option(const char* key, long value)
                                  void* stream)                                                                      \
     { return step_fwd_impl<T>(h, out, params, hc, ndim, shape, stream, false); }                                    \
     int percnn_pi_slab_step_fwd_##SUF(const T* h, T* out, const T* params, int hc, int ndim, const int64_t* shape, \
-                                      void* stream)                                                                 \
-    { return step_fwd_impl<T>(h, out, params, hc, ndim, shape, stream, true); }                                     \
+                                      int halo, int skip, void* stream)                                             \
+    { return step_fwd_impl<T>(h, out, params, hc, ndim, shape, stream, true, halo, skip); }                                     \
     int percnn_pi_step_bwd_##SUF(const T* h, const T* g_out, const T* g_inject, T* g_in, double* param_grad,       \
                                  void* workspace, size_t workspace_bytes, const T* params, int hc, int ndim,       \
                                  const int64_t* shape, void* stream)                                                \
@@ -366,9 +387,9 @@ int percnn_pi_set_option(const char* key, long value)
                               shape, stream, false); }                                                              \
     int percnn_pi_slab_step_bwd_##SUF(const T* h, const T* g_out, const T* g_inject, T* g_in, double* param_grad,  \
                                       void* workspace, size_t workspace_bytes, const T* params, int hc, int ndim,  \
-                                      const int64_t* shape, void* stream)                                           \
+                                      const int64_t* shape, int halo, void* stream)                                 \
     { return step_bwd_impl<T>(h, g_out, g_inject, g_in, param_grad, workspace, workspace_bytes, params, hc, ndim,  \
-                              shape, stream, true); }                                                               \
+                              shape, stream, true, halo); }                                                               \
     int percnn_pi_rollout_fwd_##SUF(T* traj, const T* params, int hc, int ndim, const int64_t* shape, int T_steps, \
                                     void* stream)                                                                   \
     { return rollout_fwd_impl<T>(traj, params, hc, ndim, shape, T_steps, stream); }                                 \

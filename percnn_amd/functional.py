@@ -185,25 +185,31 @@ def rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor,
     return g_h0, pg
 
 
-def step_fwd(h: torch.Tensor, P: torch.Tensor, out: Optional[torch.Tensor] = None, slab: bool = False):
-    """h: [2,*S] (slab=True: [2, n0+4, ...] with halo planes) -> next state, same layout."""
+def step_fwd(h: torch.Tensor, P: torch.Tensor, out: Optional[torch.Tensor] = None, slab: bool = False,
+             halo: int = 2, skip: int = 0):
+    """h: [2,*S] -> next state.  slab=True: h is a local slab [2, n0+2*halo, ...] (see include/percnn_pi.h)."""
     _require(h, "h"); _require(P, "params", h.dtype)
     if out is None:
         out = torch.empty_like(h)
     _require(out, "out", h.dtype)
     shape = list(h.shape[1:])
-    if slab:
-        shape[0] -= 4
-    f = getattr(_lib.lib(), f"percnn_pi_{'slab_' if slab else ''}step_fwd_" + _SUF[h.dtype])
+    L = _lib.lib()
     with torch.cuda.device(h.device):
-        _lib.check(f(h.data_ptr(), out.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape),
-                     _stream()), "step_fwd")
+        if slab:
+            shape[0] -= 2 * halo
+            f = getattr(L, "percnn_pi_slab_step_fwd_" + _SUF[h.dtype])
+            rc = f(h.data_ptr(), out.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape), halo,
+                   skip, _stream())
+        else:
+            f = getattr(L, "percnn_pi_step_fwd_" + _SUF[h.dtype])
+            rc = f(h.data_ptr(), out.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape), _stream())
+    _lib.check(rc, "step_fwd")
     return out
 
 
 def step_bwd(h: torch.Tensor, g_out: torch.Tensor, P: torch.Tensor, g_inject: Optional[torch.Tensor] = None,
              g_in: Optional[torch.Tensor] = None, param_grad: Optional[torch.Tensor] = None, slab: bool = False,
-             ws: Optional[torch.Tensor] = None):
+             halo: int = 2, ws: Optional[torch.Tensor] = None):
     """-> (dL/dh, param_grad double[np] (accumulated if given))"""
     _require(h, "h"); _require(g_out, "g_out", h.dtype); _require(P, "params", h.dtype)
     if g_inject is not None:
@@ -215,14 +221,21 @@ def step_bwd(h: torch.Tensor, g_out: torch.Tensor, P: torch.Tensor, g_inject: Op
         param_grad = torch.zeros(P.numel(), dtype=torch.float64, device=h.device)
     shape = list(h.shape[1:])
     if slab:
-        shape[0] -= 4
+        shape[0] -= 2 * halo
     if ws is None:
         ws = workspace(hc, shape, h.dtype, h.device)
-    f = getattr(_lib.lib(), f"percnn_pi_{'slab_' if slab else ''}step_bwd_" + _SUF[h.dtype])
+    L = _lib.lib()
+    inj = g_inject.data_ptr() if g_inject is not None else None
     with torch.cuda.device(h.device):
-        _lib.check(f(h.data_ptr(), g_out.data_ptr(), g_inject.data_ptr() if g_inject is not None else None,
-                     g_in.data_ptr(), param_grad.data_ptr(), ws.data_ptr(), ws.numel(), P.data_ptr(), hc,
-                     len(shape), _lib.shape_arg(shape), _stream()), "step_bwd")
+        if slab:
+            f = getattr(L, "percnn_pi_slab_step_bwd_" + _SUF[h.dtype])
+            rc = f(h.data_ptr(), g_out.data_ptr(), inj, g_in.data_ptr(), param_grad.data_ptr(), ws.data_ptr(),
+                   ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), halo, _stream())
+        else:
+            f = getattr(L, "percnn_pi_step_bwd_" + _SUF[h.dtype])
+            rc = f(h.data_ptr(), g_out.data_ptr(), inj, g_in.data_ptr(), param_grad.data_ptr(), ws.data_ptr(),
+                   ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), _stream())
+    _lib.check(rc, "step_bwd")
     return g_in, param_grad
 
 

@@ -204,26 +204,63 @@ def test_cell_forward_signature(hip_device):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(16, 32), (12, 8, 16)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-def test_slab_step_equals_periodic_step(shape, dtype, hip_device):
+@pytest.mark.parametrize("halo", [2, 4])
+def test_slab_step_equals_periodic_step(shape, dtype, halo, hip_device):
+    """Two half-domain slabs (halo planes copied by hand) reproduce the periodic single-domain step
+    bit for bit -- forward (incl. the wide-halo multi-step scheme) and adjoint."""
     import percnn_amd as pa
     ndim, hc = len(shape), 4
     npd = np.float32 if dtype == torch.float32 else np.float64
     P = dev_t(random_block(hc, ndim, npd, 11), hip_device)
     h = torch.rand((2,) + shape, dtype=dtype, device=hip_device)
     G = torch.rand((2,) + shape, dtype=dtype, device=hip_device)
-    full = pa.step_fwd(h, P)
+    k = halo // 2
+    full = [h]
+    for _ in range(k):
+        full.append(pa.step_fwd(full[-1], P))
     gfull, pgfull = pa.step_bwd(h, G, P)
     n0 = shape[0]
     pgsum = torch.zeros_like(pgfull)
     for lo, hi in ((0, n0 // 2), (n0 // 2, n0)):
-        idx = torch.arange(lo - 2, hi + 2, device=hip_device) % n0
-        hs, Gs = h[:, idx].contiguous(), G[:, idx].contiguous()
-        out = pa.step_fwd(hs, P, slab=True)
-        assert torch.equal(out[:, 2:-2], full[:, lo:hi])
-        gi, pg = pa.step_bwd(hs, Gs, P, slab=True)
-        assert torch.equal(gi[:, 2:-2], gfull[:, lo:hi])
+        idx = torch.arange(lo - halo, hi + halo, device=hip_device) % n0
+        cur = h[:, idx].contiguous()
+        for m in range(k):                                   # k steps on one exchange
+            nxt = torch.full_like(cur, float("nan"))
+            pa.step_fwd(cur, P, out=nxt, slab=True, halo=halo, skip=2 * m)
+            assert torch.equal(nxt[:, halo:-halo], full[m + 1][:, lo:hi])
+            cur = nxt
+        gi, pg = pa.step_bwd(h[:, idx].contiguous(), G[:, idx].contiguous(), P, slab=True, halo=halo)
+        assert torch.equal(gi[:, halo:-halo], gfull[:, lo:hi])
         pgsum += pg
     assert torch.allclose(pgsum, pgfull, rtol=1e-5 if dtype == torch.float32 else 1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("fam,halo", [("gs2d", 2), ("gs2d", 4), ("gs3d", 2), ("lo2d", 6)])
+def test_slab_rollout_single_rank_equals_rollout(fam, halo, hip_device):
+    """world_size 1 (local wrap) through the slab orchestration + autograd == the plain rollout."""
+    import percnn_amd as pa
+    from percnn_amd import slab
+    fn = {"gs2d": "gs2d_ckpt_32x32.npz", "gs3d": "gs3d_ckpt_16x16x16.npz", "lo2d": "lo2d_ckpt_32x32.npz"}[fam]
+    g = Golden(os.path.join(GOLDEN, fn))
+    cell = g.product_cell(hip_device)
+    T = 7
+    h0 = dev_t(g.h0, hip_device)
+    P = cell.param_block()
+    traj = pa.pi_rollout(h0, P, T)
+    gt = torch.randn_like(traj)
+    (traj * gt).sum().backward()
+    ref_grads = {n: p.grad.clone() for n, p in cell.named_parameters() if p.grad is not None}
+    cell.zero_grad()
+    n0 = g.h0.shape[2]
+    local = slab.scatter_slab(h0[0], 0, 1, halo)
+    trajs = slab.slab_rollout(local, cell.param_block(), T, halo=halo)
+    inner = trajs[:, :, halo:halo + n0]
+    assert torch.equal(inner, traj.detach())
+    (inner * gt).sum().backward()
+    tol = 2e-5 if g.dtype == np.float32 else 1e-11
+    for n, p in cell.named_parameters():
+        if p.grad is not None:
+            assert rel_l2(p.grad.cpu().numpy(), ref_grads[n].cpu().numpy()) < tol, n
 
 
 # ---------------------------------------------------------------------------------------------
@@ -297,3 +334,31 @@ def test_adjoint_dot_product_identity_fp64_full_size(hip_device):
     jtw, _ = pa.step_bwd(h, w, P)
     lhs, rhs = (jv * w).sum().item(), (v * jtw).sum().item()
     assert abs(lhs - rhs) < 1e-7 * max(abs(lhs), abs(rhs), 1.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# RCCL path on one GPU: halo exchange through ncclSend/ncclRecv-to-self must equal the local wrap
+# ---------------------------------------------------------------------------------------------
+def test_rccl_halo_exchange_to_self(hip_device):
+    import socket
+    import torch.distributed as dist
+    from percnn_amd import slab
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=hip_device)
+    try:
+        for halo, width in ((2, 2), (4, 4), (6, 2)):
+            a = torch.rand((2, 10 + 2 * halo, 6, 8), device=hip_device)
+            b = a.clone()
+            slab.HaloExchanger().exchange(a, halo, width)                     # local copies
+            slab.HaloExchanger(force_p2p=True).exchange(b, halo, width)       # RCCL send/recv
+            torch.cuda.synchronize()
+            assert torch.equal(a, b)
+            n = 10
+            assert torch.equal(a[:, halo - width:halo], a[:, halo + n - width:halo + n])
+            assert torch.equal(a[:, halo + n:halo + n + width], a[:, halo:halo + width])
+        t = torch.ones(5, dtype=torch.float64, device=hip_device)
+        dist.all_reduce(t)
+        assert torch.equal(t, torch.ones_like(t))
+    finally:
+        dist.destroy_process_group()
