@@ -41,9 +41,9 @@ def load_params(golden):
     return {k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}
 
 
-def make_cell(family, sd, device):
+def make_cell(family, sd, device, reaction="poly"):
     import percnn_amd as pa
-    cell = {"gs2d": pa.gs2d_cell, "gs3d": pa.gs3d_cell, "lo2d": pa.lo2d_cell}[family]()
+    cell = {"gs2d": pa.gs2d_cell, "gs3d": pa.gs3d_cell, "lo2d": pa.lo2d_cell}[family](reaction=reaction)
     cell.load_state_dict(sd)
     return cell.to(device)
 
@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--workload", default="gs2d_512", choices=list(WORKLOADS))
     ap.add_argument("--T", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reaction", default="poly", choices=["poly", "factored"],
+                    help="poly: branch product pre-contracted to a cubic (module default); factored: per-point 1x1 branches")
+    ap.add_argument("--opt", action="append", default=[], help="library tuning option key=value (repeatable)")
     ap.add_argument("--slab-extra", action="store_true", help="also time the slab-sharded 3D path at N=1")
     ap.add_argument("--slab-timeout", type=float, default=240.0)
     a = ap.parse_args()
@@ -113,10 +116,13 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import percnn_amd as pa
+    for kv in a.opt:
+        k, v = kv.split("=")
+        pa.set_option(k, int(v))
     family, shape, hc, dtype, T_def, golden = WORKLOADS[a.workload]
     T = a.T or T_def
     sd = load_params(golden)
-    cell = make_cell(family, sd, dev)
+    cell = make_cell(family, sd, dev, a.reaction)
     with torch.no_grad():
         P = cell.param_block().contiguous()
     npts = int(np.prod(shape))
@@ -137,9 +143,11 @@ def main():
 
     def one_pass(e=None):
         if e: e[0].record()
-        pa.rollout_fwd_(traj, P)
+        with torch.no_grad():
+            Pc = cell.param_block().contiguous()     # parameter packing / contraction is part of every pass
+        pa.rollout_fwd_(traj, Pc)
         if e: e[1].record()
-        g0, pg = pa.rollout_bwd(traj, gtraj, P)
+        g0, pg = pa.rollout_bwd(traj, gtraj, Pc)
         if e: e[2].record()
         return g0, pg
 
@@ -182,6 +190,7 @@ def main():
         "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
         "config": {"workload": f"{a.workload}: {family} {'x'.join(map(str, shape))}, 2 species, Hc={hc}, "
                                f"T={T} forward+backward rollout per step, dense dL/dtraj",
+                   "reaction": a.reaction,
                    "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (no collective)",
                    "points": npts, "T": T},
         "roofline": {"bound": "hbm", "kernel": "pi_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -166,3 +166,113 @@ def step_bwd_range(h, G, inj, Gp, pg, P, hc, lo, hi):
                                                       _ptr(pg, ctypes.c_double), _ptr(P, ct), hc, len(S), _shape(S),
                                                       ctypes.c_long(lo), ctypes.c_long(hi))
     return Gp, pg
+
+
+# ---- pre-contracted polynomial reaction ("poly" mode) ----------------------------------------------
+MONOMIALS = {(0, 0): 0, (1, 0): 1, (0, 1): 2, (2, 0): 3, (1, 1): 4, (0, 2): 5, (3, 0): 6, (2, 1): 7, (1, 2): 8, (0, 3): 9}
+
+
+def expand_poly(sd: dict, name: str) -> np.ndarray:
+    """float64 coefficients c[10] of r(u,v) = Wh4(Wh1(h)*Wh2(h)*Wh3(h)) for species `name`
+    (train_2drd.py:115-116; cf. the reference's own symbolic read-out train_3drd.py:442-468).
+    Plain triple loop over the (u, v, 1) factors of the three linear forms."""
+    hc = sd[f"Wh1_{name}.weight"].shape[0]
+    L = [np.concatenate([np.asarray(sd[f"Wh{k}_{name}.weight"], dtype=np.float64).reshape(hc, 2),
+                         np.asarray(sd[f"Wh{k}_{name}.bias"], dtype=np.float64).reshape(hc, 1)], 1) for k in (1, 2, 3)]
+    w4 = np.asarray(sd[f"Wh4_{name}.weight"], dtype=np.float64).reshape(hc)
+    ex = [(1, 0), (0, 1), (0, 0)]
+    c = np.zeros(10)
+    for a in range(3):
+        for b in range(3):
+            for d in range(3):
+                e = (ex[a][0] + ex[b][0] + ex[d][0], ex[a][1] + ex[b][1] + ex[d][1])
+                c[MONOMIALS[e]] += np.sum(w4 * L[0][:, a] * L[1][:, b] * L[2][:, d])
+    c[0] += float(np.asarray(sd[f"Wh4_{name}.bias"], dtype=np.float64).reshape(()))
+    return c
+
+
+def pack_poly(sd: dict, dt, coef_u, coef_v, dtype) -> np.ndarray:
+    P = pack_params(sd, dt, coef_u, coef_v, dtype)
+    Q = np.zeros(36, dtype=dtype)
+    Q[:16] = P[:16]
+    Q[16:26] = expand_poly(sd, "u").astype(dtype)
+    Q[26:36] = expand_poly(sd, "v").astype(dtype)
+    return Q
+
+
+def poly_step_fwd(h, Q):
+    ct, suf = _ct(h.dtype)
+    h = np.ascontiguousarray(h)
+    out = np.empty_like(h)
+    S = h.shape[1:]
+    getattr(lib(), "pi_oracle_poly_step_fwd_range_" + suf)(_ptr(h, ct), _ptr(out, ct), _ptr(Q, ct), len(S), _shape(S),
+                                                           ctypes.c_long(0), ctypes.c_long(S[0]))
+    return out
+
+
+def poly_step_bwd(h, G, inj, Q):
+    ct, suf = _ct(h.dtype)
+    h, G = np.ascontiguousarray(h), np.ascontiguousarray(G)
+    S = h.shape[1:]
+    Gp = np.empty_like(h)
+    qg = np.zeros(36, dtype=np.float64)
+    injp = _ptr(np.ascontiguousarray(inj), ct) if inj is not None else None
+    getattr(lib(), "pi_oracle_poly_step_bwd_range_" + suf)(_ptr(h, ct), _ptr(G, ct), injp, _ptr(Gp, ct),
+                                                           _ptr(qg, ctypes.c_double), _ptr(Q, ct), len(S), _shape(S),
+                                                           ctypes.c_long(0), ctypes.c_long(S[0]))
+    return Gp, qg
+
+
+def poly_rollout_fwd(h0, Q, T):
+    ct, suf = _ct(h0.dtype)
+    S = h0.shape[1:]
+    traj = np.empty((T + 1,) + h0.shape, dtype=h0.dtype)
+    traj[0] = h0
+    getattr(lib(), "pi_oracle_poly_rollout_fwd_" + suf)(_ptr(traj, ct), _ptr(Q, ct), len(S), _shape(S), T)
+    return traj
+
+
+def poly_rollout_bwd(traj, gtraj, Q):
+    ct, suf = _ct(traj.dtype)
+    T = traj.shape[0] - 1
+    S = traj.shape[2:]
+    traj, gtraj = np.ascontiguousarray(traj), np.ascontiguousarray(gtraj)
+    g0 = np.empty(traj.shape[1:], dtype=traj.dtype)
+    work = np.empty((2,) + traj.shape[1:], dtype=traj.dtype)
+    qg = np.zeros(36, dtype=np.float64)
+    getattr(lib(), "pi_oracle_poly_rollout_bwd_" + suf)(_ptr(traj, ct), _ptr(gtraj, ct), _ptr(g0, ct),
+                                                        _ptr(qg, ctypes.c_double), _ptr(work, ct), _ptr(Q, ct), len(S),
+                                                        _shape(S), T)
+    return g0, qg
+
+
+def poly_grads_to_params(qg: np.ndarray, sd: dict) -> dict:
+    """Chain rule dL/dc -> dL/d{Wh1..4 weights, biases} by finite-difference-free analytic
+    differentiation of expand_poly (multilinear in the factors): float64, independent of torch."""
+    out = {"coef_u": qg[1], "coef_v": qg[2]}
+    ex = [(1, 0), (0, 1), (0, 0)]
+    for s, name in enumerate("uv"):
+        hc = sd[f"Wh1_{name}.weight"].shape[0]
+        ndim = np.asarray(sd[f"Wh1_{name}.weight"]).ndim - 2
+        one = (1,) * ndim
+        L = [np.concatenate([np.asarray(sd[f"Wh{k}_{name}.weight"], dtype=np.float64).reshape(hc, 2),
+                             np.asarray(sd[f"Wh{k}_{name}.bias"], dtype=np.float64).reshape(hc, 1)], 1) for k in (1, 2, 3)]
+        w4 = np.asarray(sd[f"Wh4_{name}.weight"], dtype=np.float64).reshape(hc)
+        M = qg[16 + 10 * s:26 + 10 * s]
+        gL = [np.zeros((hc, 3)) for _ in range(3)]
+        gw4 = np.zeros(hc)
+        for a in range(3):
+            for b in range(3):
+                for d in range(3):
+                    e = (ex[a][0] + ex[b][0] + ex[d][0], ex[a][1] + ex[b][1] + ex[d][1])
+                    m = M[MONOMIALS[e]]
+                    gw4 += m * L[0][:, a] * L[1][:, b] * L[2][:, d]
+                    gL[0][:, a] += m * w4 * L[1][:, b] * L[2][:, d]
+                    gL[1][:, b] += m * w4 * L[0][:, a] * L[2][:, d]
+                    gL[2][:, d] += m * w4 * L[0][:, a] * L[1][:, b]
+        for k in (1, 2, 3):
+            out[f"Wh{k}_{name}.weight"] = gL[k - 1][:, :2].reshape((hc, 2) + one).copy()
+            out[f"Wh{k}_{name}.bias"] = gL[k - 1][:, 2].copy()
+        out[f"Wh4_{name}.weight"] = gw4.reshape((1, hc) + one)
+        out[f"Wh4_{name}.bias"] = np.array([M[0]])
+    return out

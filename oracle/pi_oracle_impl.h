@@ -160,6 +160,109 @@ void FN(pi_oracle_rollout_bwd_)(const REAL *traj, const REAL *gtraj, REAL *g0, d
     if (T == 0) for (long i = 0; i < 2 * n; ++i) g0[i] = A[i];
 }
 
+/* ---- pre-contracted ("poly") reaction --------------------------------------------------------
+ * The Hadamard product of the three 1x1 branches followed by the 1x1 aggregation
+ * (train_2drd.py:115-116) is, per species, a cubic polynomial in (u, v):
+ *     r_s(u,v) = sum_m c[s][m] * phi_m(u,v),  phi = {1,u,v,u^2,uv,v^2,u^3,u^2 v,u v^2,v^3}
+ * (the reference itself prints this expansion: train_3drd.py:442-468 get_expression).
+ * Block Q: Q[0..15] as P[0..15]; Q[16 + 10*s + m] = c[s][m].  Gradient block: same indexing,
+ * qg[16+10*s+m] = dL/dc[s][m] = sum_x g_s(x) dt phi_m(x)  (the "moments"). */
+static inline REAL FN(poly_r_)(const REAL *c, REAL u, REAL v)
+{
+    REAL A0 = FMA(v, FMA(v, FMA(v, c[9], c[5]), c[2]), c[0]);
+    REAL A1 = FMA(v, FMA(v, c[8], c[4]), c[1]);
+    REAL A2 = FMA(v, c[7], c[3]);
+    return FMA(u, FMA(u, FMA(u, c[6], A2), A1), A0);
+}
+
+void FN(pi_oracle_poly_step_fwd_range_)(const REAL *h, REAL *out, const REAL *Q, int ndim, const long *S,
+                                        long lo0, long hi0)
+{
+    long n = 1;
+    for (int a = 0; a < ndim; ++a) n *= S[a];
+    const REAL dt = Q[0];
+    long idx[3] = {0, 0, 0};
+    for (long p = 0; p < n; ++p) {
+        long r = p;
+        for (int a = ndim - 1; a >= 0; --a) { idx[a] = r % S[a]; r /= S[a]; }
+        if (idx[0] < lo0 || idx[0] >= hi0) continue;
+        const REAL u = h[p], v = h[n + p];
+        for (int s = 0; s < 2; ++s) {
+            REAL lap = FN(star_)(h + s * n, Q, ndim, S, idx, +1);
+            REAL rr = FN(poly_r_)(Q + 16 + 10 * s, u, v);
+            REAL res = Q[1 + s] * lap + rr;
+            REAL t = res * dt;
+            out[s * n + p] = h[s * n + p] + t;
+        }
+    }
+}
+
+void FN(pi_oracle_poly_step_bwd_range_)(const REAL *h, const REAL *G, const REAL *inj, REAL *Gprev, double *qg,
+                                        const REAL *Q, int ndim, const long *S, long lo0, long hi0)
+{
+    long n = 1;
+    for (int a = 0; a < ndim; ++a) n *= S[a];
+    const REAL dt = Q[0];
+    long idx[3] = {0, 0, 0};
+    for (long p = 0; p < n; ++p) {
+        long r = p;
+        for (int a = ndim - 1; a >= 0; --a) { idx[a] = r % S[a]; r /= S[a]; }
+        if (idx[0] < lo0 || idx[0] >= hi0) continue;
+        const REAL u = h[p], v = h[n + p];
+        const REAL u2 = u * u, uv = u * v, v2 = v * v;
+        const REAL phi[10] = {1, u, v, u2, uv, v2, u2 * u, u2 * v, u * v2, v2 * v};
+        REAL du = 0, dv = 0, dl[2];
+        for (int s = 0; s < 2; ++s) {
+            const REAL *c = Q + 16 + 10 * s;
+            REAL lg = FN(star_)(G + s * n, Q, ndim, S, idx, -1);
+            dl[s] = lg * dt;
+            qg[1 + s] += (double)(dl[s] * h[s * n + p]);
+            const REAL gr = G[s * n + p] * dt;
+            qg[16 + 10 * s] += (double)gr;
+            for (int m = 1; m < 10; ++m) qg[16 + 10 * s + m] += (double)(gr * phi[m]);
+            /* dr/du = A1 + u (2 A2 + 3 c6 u);  dr/dv = B0 + u (B1 + c7 u) */
+            REAL A1 = FMA(v, FMA(v, c[8], c[4]), c[1]);
+            REAL A2x2 = FMA(v, 2 * c[7], 2 * c[3]);
+            REAL ru = FMA(u, FMA(u, 3 * c[6], A2x2), A1);
+            REAL B0 = FMA(v, FMA(v, 3 * c[9], 2 * c[5]), c[2]);
+            REAL B1 = FMA(v, 2 * c[8], c[4]);
+            REAL rv = FMA(u, FMA(u, c[7], B1), B0);
+            du = FMA(gr, ru, du);
+            dv = FMA(gr, rv, dv);
+        }
+        REAL tu = Q[1] * dl[0] + du;
+        REAL tv = Q[2] * dl[1] + dv;
+        REAL gu = G[p] + tu, gv = G[n + p] + tv;
+        if (inj) { gu += inj[p]; gv += inj[n + p]; }
+        Gprev[p] = gu;
+        Gprev[n + p] = gv;
+    }
+}
+
+void FN(pi_oracle_poly_rollout_fwd_)(REAL *traj, const REAL *Q, int ndim, const long *S, int T)
+{
+    long n = 1;
+    for (int a = 0; a < ndim; ++a) n *= S[a];
+    for (int t = 0; t < T; ++t)
+        FN(pi_oracle_poly_step_fwd_range_)(traj + (long)t * 2 * n, traj + (long)(t + 1) * 2 * n, Q, ndim, S, 0, S[0]);
+}
+
+void FN(pi_oracle_poly_rollout_bwd_)(const REAL *traj, const REAL *gtraj, REAL *g0, double *qg, REAL *work,
+                                     const REAL *Q, int ndim, const long *S, int T)
+{
+    long n = 1;
+    for (int a = 0; a < ndim; ++a) n *= S[a];
+    REAL *A = work, *B = work + 2 * n;
+    for (long i = 0; i < 2 * n; ++i) A[i] = gtraj[(long)T * 2 * n + i];
+    for (int t = T; t >= 1; --t) {
+        REAL *dst = (t == 1) ? g0 : B;
+        FN(pi_oracle_poly_step_bwd_range_)(traj + (long)(t - 1) * 2 * n, A, gtraj + (long)(t - 1) * 2 * n, dst, qg,
+                                           Q, ndim, S, 0, S[0]);
+        if (t > 1) { REAL *tmp = A; A = B; B = tmp; }
+    }
+    if (T == 0) for (long i = 0; i < 2 * n; ++i) g0[i] = A[i];
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

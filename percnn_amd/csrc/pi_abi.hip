@@ -8,6 +8,7 @@
 
 #include "../../include/percnn_pi.h"
 #include "pi_kernels.h"
+#include "pi_tile2d.h"
 
 namespace {
 
@@ -17,8 +18,20 @@ struct Options {
     int block = 256;
     int vec = 0;            // 0 = widest legal (16 B per lane); 1/2/4 = cap (tuning aid)
     int wgrad_blocks = 1024;
+    int tile = 1;           // 2D: temporally blocked LDS kernels where the shape allows
+    int tile_k = 4;         // sub-steps per launch (2 or 4)
+    int tile_nt = 256;      // workgroup size of the tile kernels (256 or 512)
+    int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
+                            // small grid is spread over all CUs instead of being packed onto a few
 };
 Options g_opt;
+
+template <typename F>
+hipError_t allow_lds(F* f, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 
 constexpr int MAX_BWD_BLOCKS = 4096;   // bounds the per-workgroup gradient partials (grid-stride beyond)
 
@@ -35,7 +48,7 @@ struct Problem {
 
 int make_problem(int hc, int ndim, const int64_t* shape, bool slab, Problem& p)
 {
-    if (!shape || (ndim != 2 && ndim != 3) || hc < 1 || hc > 64) return PERCNN_PI_EINVAL;
+    if (!shape || (ndim != 2 && ndim != 3) || hc < 0 || hc > 64) return PERCNN_PI_EINVAL;   // hc == 0: poly mode
     for (int a = 0; a < ndim; ++a)
         if (shape[a] < 2 || shape[a] > (1 << 30)) return PERCNN_PI_EINVAL;
     p.ndim = ndim; p.hc = hc; p.slab = slab;
@@ -86,7 +99,9 @@ hipError_t launch_fwd(const T* h, T* out, const T* P, const Problem& p, hipStrea
     const int block = g_opt.block;
     const unsigned grid = (unsigned)((nchunks + block - 1) / block);
     if (nchunks <= 0) return hipSuccess;
-    hipLaunchKernelGGL((pi::pi_fwd_kernel<T, NDIM, HC, VEC>), dim3(grid), dim3(block), 0, st, h, out, P, g, p.hc);
+    auto* k = pi::pi_fwd_kernel<T, NDIM, HC, VEC>;
+    if (hipError_t e = allow_lds(k, (size_t)g_opt.lds_pad)) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(block), (size_t)g_opt.lds_pad, st, h, out, P, g, p.hc);
     return hipGetLastError();
 }
 
@@ -104,9 +119,10 @@ hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* parti
     const Geom g = make_geom(p);
     const int block = g_opt.block;
     const unsigned grid = bwd_grid(p, VEC);
-    const size_t lds = (size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T);
-    hipLaunchKernelGGL((pi::pi_bwd_kernel<T, NDIM, HC, VEC, WGRAD>), dim3(grid), dim3(block), lds, st, h, G, inj,
-                       Gp, partials, P, g, p.hc);
+    const size_t lds = (size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T) + (size_t)g_opt.lds_pad;
+    auto* k = pi::pi_bwd_kernel<T, NDIM, HC, VEC, WGRAD>;
+    if (hipError_t e = allow_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, st, h, G, inj, Gp, partials, P, g, p.hc);
     return hipGetLastError();
 }
 
@@ -131,6 +147,12 @@ hipError_t launch_wgrad(const T* traj, const T* adj, double* partials, const T* 
     if (nb > g_opt.wgrad_blocks) nb = g_opt.wgrad_blocks;
     if (nb < 1) nb = 1;
     *rows_out = (unsigned)(2 * nb);
+    if (p.hc == 0) {                                           // pre-contracted mode: coefficient moments
+        const size_t lds = (size_t)(256 / pi::WAVE) * 20 * sizeof(T);
+        hipLaunchKernelGGL((pi::pi_moments_kernel<T, VEC>), dim3((unsigned)nb), dim3(256), lds, st, traj, adj, partials,
+                           P, (long)p.n, t_lo, t_hi);
+        return hipGetLastError();
+    }
     // small hidden widths: one workgroup handles both species (the state is streamed once)
     if (p.hc == 2) return launch_wgrad_pass<T, 2, 2, VEC>(traj, adj, partials, P, p, t_lo, t_hi, 0, (unsigned)nb, st);
     if (p.hc == 4) return launch_wgrad_pass<T, 4, 2, VEC>(traj, adj, partials, P, p, t_lo, t_hi, 0, (unsigned)nb, st);
@@ -150,6 +172,7 @@ hipError_t launch_wgrad(const T* traj, const T* adj, double* partials, const T* 
 
 #define PI_DISPATCH_HC(CALL, NDIM, VEC)                         \
     switch (p.hc) {                                             \
+        case 0:  return CALL(NDIM, pi::POLY, VEC);              \
         case 2:  return CALL(NDIM, 2, VEC);                     \
         case 4:  return CALL(NDIM, 4, VEC);                     \
         case 8:  return CALL(NDIM, 8, VEC);                     \
@@ -186,6 +209,83 @@ hipError_t step_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partial
 #define CALL_BWD(NDIM, HC, VEC) launch_bwd<T, NDIM, HC, VEC, WGRAD>(h, G, inj, Gp, partials, P, p, st)
     PI_DISPATCH(CALL_BWD);
 #undef CALL_BWD
+}
+
+
+// ---- temporally blocked 2D path -----------------------------------------------------------------
+constexpr int TILE_B = 32;
+
+template <typename T>
+bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs)
+{
+    if (!g_opt.tile || g_opt.vec == 1 || p.ndim != 2 || p.slab) return false;
+    if (p.hc != 0 && p.hc != 2 && p.hc != 4 && p.hc != 8) return false;
+    if (p.n0 % TILE_B || p.W % TILE_B || p.n0 < 16 || p.W < 16) return false;
+    for (const void* q : ptrs)
+        if (q && (reinterpret_cast<uintptr_t>(q) % 16)) return false;
+    return true;
+}
+
+template <typename T, int HC, int K, int NT>
+hipError_t launch_fwd_tile(T* frame_t, const T* P, const Problem& p, hipStream_t st)
+{
+    using TL = pi::Tile<K, TILE_B, TILE_B>;
+    pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, (int)(p.W / TILE_B)};
+    const unsigned grid = (unsigned)((p.n0 / TILE_B) * (p.W / TILE_B));
+    const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + (size_t)g_opt.lds_pad;
+    auto* k = pi::pi_fwd2d_tile_kernel<T, HC, K, TILE_B, TILE_B, NT>;
+    if (hipError_t e = allow_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, frame_t, (long)(2 * p.n), P, g);
+    return hipGetLastError();
+}
+
+template <typename T, int HC, int K, int NT>
+hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, unsigned inj_mask, T* g_h0,
+                           int steps_to_zero, double* partials, const T* P, const Problem& p, hipStream_t st)
+{
+    using TL = pi::Tile<K, TILE_B, TILE_B>;
+    pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, (int)(p.W / TILE_B)};
+    const unsigned grid = (unsigned)((p.n0 / TILE_B) * (p.W / TILE_B));
+    const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + (size_t)g_opt.lds_pad;
+    auto* k = pi::pi_adj2d_tile_kernel<T, HC, K, TILE_B, TILE_B, NT>;
+    if (hipError_t e = allow_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, hframe_t, gframe_t, aframe_t, (long)(2 * p.n), inj_mask, g_h0,
+                       steps_to_zero, partials, pi::nparams(p.hc), P, g);
+    return hipGetLastError();
+}
+
+#define PI_TILE_VARIANTS(CALL, HC)                                              \
+    do {                                                                        \
+        if (g_opt.tile_k == 2) return CALL(HC, 2, 256);                         \
+        if (g_opt.tile_nt == 512) return CALL(HC, 4, 512);                      \
+        return CALL(HC, 4, 256);                                                \
+    } while (0)
+#define PI_TILE_DISPATCH(CALL)                                                  \
+    do {                                                                        \
+        switch (p.hc) {                                                         \
+            case 0: PI_TILE_VARIANTS(CALL, pi::POLY);                           \
+            case 2: PI_TILE_VARIANTS(CALL, 2);                                  \
+            case 4: PI_TILE_VARIANTS(CALL, 4);                                  \
+            default: PI_TILE_VARIANTS(CALL, 8);                                 \
+        }                                                                       \
+    } while (0)
+
+template <typename T>
+hipError_t fwd_tile(T* frame_t, const T* P, const Problem& p, hipStream_t st)
+{
+#define CALL_FT(HC, K, NT) launch_fwd_tile<T, HC, K, NT>(frame_t, P, p, st)
+    PI_TILE_DISPATCH(CALL_FT);
+#undef CALL_FT
+}
+
+template <typename T>
+hipError_t adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, unsigned inj_mask, T* g_h0, int steps_to_zero,
+                    double* partials, const T* P, const Problem& p, hipStream_t st)
+{
+#define CALL_AT(HC, K, NT) \
+    launch_adj_tile<T, HC, K, NT>(hframe_t, gframe_t, aframe_t, inj_mask, g_h0, steps_to_zero, partials, P, p, st)
+    PI_TILE_DISPATCH(CALL_AT);
+#undef CALL_AT
 }
 
 // ---- workspace carving -------------------------------------------------------------------------
@@ -265,7 +365,13 @@ int rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* shape
     if (!traj || !P || T_steps < 0) return PERCNN_PI_EINVAL;
     auto st = static_cast<hipStream_t>(stream);
     const size_t frame = (size_t)2 * p.n;
-    for (int t = 0; t < T_steps; ++t)
+    int t = 0;
+    if (tile_eligible<T>(p, {traj})) {
+        const int K = g_opt.tile_k;
+        for (; t + K <= T_steps; t += K)
+            if (hipError_t e = fwd_tile<T>(traj + (size_t)t * frame, P, p, st)) return (int)e;
+    }
+    for (; t < T_steps; ++t)
         if (hipError_t e = step_fwd<T>(traj + (size_t)t * frame, traj + (size_t)(t + 1) * frame, P, p, st)) return (int)e;
     return 0;
 }
@@ -308,12 +414,26 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
 
     // 1) sequential reverse sweep: adjoint states (+ diffusion-coefficient gradients)
     unsigned rows = 0;
-    for (int t = t_top; t >= 1; --t) {
+    int t_cur = t_top;
+    if (tile_eligible<T>(p, {traj, g_traj, g_h0, adj})) {
+        const int K = g_opt.tile_k;
+        rows = (unsigned)((p.n0 / TILE_B) * (p.W / TILE_B));
+        for (; t_cur - K >= 0; t_cur -= K) {
+            unsigned m = 0;
+            for (int q = 0; q < K; ++q) if (has(t_cur - 1 - q)) m |= 1u << q;
+            if (hipError_t e = adj_tile<T>(traj + (size_t)t_cur * frame, g_traj + (size_t)t_cur * frame,
+                                           adj + (size_t)t_cur * frame, m, g_h0, t_cur == K ? K : 0, w.partials, P, p, st))
+                return (int)e;
+        }
+    }
+    for (int t = t_cur; t >= 1; --t) {
         T* dst = (t == 1) ? g_h0 : adj + (size_t)(t - 1) * frame;
         const T* inj = has(t - 1) ? g_traj + (size_t)(t - 1) * frame : nullptr;
+        unsigned r2 = 0;
         if (hipError_t e = step_bwd<T, false>(traj + (size_t)(t - 1) * frame, adj + (size_t)t * frame, inj, dst,
-                                              w.partials, P, p, st, &rows))
+                                              w.partials, P, p, st, &r2))
             return (int)e;
+        if (r2 > rows) rows = r2;
     }
     // 2) branch-weight gradients of all t_top steps at once (time-parallel reduction)
     unsigned wrows = 0;
@@ -332,7 +452,7 @@ extern "C" {
 
 int percnn_pi_abi_version(void) { return PERCNN_PI_ABI_VERSION; }
 
-size_t percnn_pi_param_count(int hc) { return hc < 1 ? 0 : (size_t)pi::nparams(hc); }
+size_t percnn_pi_param_count(int hc) { return hc < 0 ? 0 : (size_t)pi::nparams(hc); }
 
 size_t percnn_pi_bwd_workspace_bytes(int hc, int ndim, const int64_t* shape, int elem_size)
 {
@@ -357,6 +477,22 @@ int percnn_pi_set_option(const char* key, long value)
     if (!std::strcmp(key, "vec")) {
         if (value != 0 && value != 1) return PERCNN_PI_EINVAL;
         g_opt.vec = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "tile")) { g_opt.tile = value != 0; return 0; }
+    if (!std::strcmp(key, "lds_pad")) {
+        if (value < 0 || value > 80 * 1024 || value % 16) return PERCNN_PI_EINVAL;
+        g_opt.lds_pad = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "tile_k")) {
+        if (value != 2 && value != 4) return PERCNN_PI_EINVAL;
+        g_opt.tile_k = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "tile_nt")) {
+        if (value != 256 && value != 512) return PERCNN_PI_EINVAL;
+        g_opt.tile_nt = (int)value;
         return 0;
     }
     if (!std::strcmp(key, "wgrad_blocks")) {

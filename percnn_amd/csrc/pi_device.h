@@ -8,7 +8,10 @@ namespace pi {
 // ---- parameter block layout (documented in include/percnn_pi.h) ------------------------------
 constexpr int P_DT = 0, P_COEF = 1, P_C0 = 3, P_TAPS = 4, P_W = 16;
 __host__ __device__ constexpr int species_block(int hc) { return 10 * hc + 1; }
-__host__ __device__ constexpr int nparams(int hc) { return P_W + 2 * species_block(hc); }
+// hc == 0 selects the pre-contracted polynomial reaction: 16 header slots + 2 x 10 cubic coefficients
+constexpr int POLY = -1;          // template tag for that mode
+constexpr int NPOLY = P_W + 20;
+__host__ __device__ constexpr int nparams(int hc) { return hc == 0 ? NPOLY : P_W + 2 * species_block(hc); }
 
 constexpr int WAVE = 64;          // CDNA wavefront
 constexpr int NXCD = 8;           // MI355X: 8 XCDs, block b is dispatched to XCD b % 8
@@ -30,6 +33,41 @@ __device__ __forceinline__ void st(T* p, const Pack<T, N>& x) { *reinterpret_cas
 // separately -- train_2drd.py:115-118).
 __device__ __forceinline__ float  fma_(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// the 10 wave-uniform scalars of one hidden channel {w1u,w1v,b1, w2u,w2v,b2, w3u,w3v,b3, w4}
+template <typename T> struct W10 { T w[10]; };
+template <typename T>
+__device__ __forceinline__ W10<T> load_w10(const T* __restrict__ p)
+{
+    W10<T> r;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) r.w[i] = p[i];
+    return r;
+}
+
+// ---- pre-contracted reaction: r_s(u,v) = sum_m c[m] phi_m, phi = {1,u,v,u2,uv,v2,u3,u2v,uv2,v3} -------
+// The Hadamard product of the three 1x1 branches followed by the 1x1 aggregation
+// (train_2drd.py:115-116) IS this cubic; evaluating it in Horner form costs 9 FMAs per species
+// instead of 72 VALU ops at Hc = 8, independent of Hc.
+template <typename T>
+__device__ __forceinline__ T poly_r(const T* __restrict__ c, T u, T v)
+{
+    const T A0 = fma_(v, fma_(v, fma_(v, c[9], c[5]), c[2]), c[0]);
+    const T A1 = fma_(v, fma_(v, c[8], c[4]), c[1]);
+    const T A2 = fma_(v, c[7], c[3]);
+    return fma_(u, fma_(u, fma_(u, c[6], A2), A1), A0);
+}
+// dr/du and dr/dv
+template <typename T>
+__device__ __forceinline__ void poly_dr(const T* __restrict__ c, T u, T v, T& ru, T& rv)
+{
+    const T A1 = fma_(v, fma_(v, c[8], c[4]), c[1]);
+    const T A2x2 = fma_(v, T(2) * c[7], T(2) * c[3]);
+    ru = fma_(u, fma_(u, T(3) * c[6], A2x2), A1);
+    const T B0 = fma_(v, fma_(v, T(3) * c[9], T(2) * c[5]), c[2]);
+    const T B1 = fma_(v, T(2) * c[8], c[4]);
+    rv = fma_(u, fma_(u, c[7], B1), B0);
+}
 
 __device__ __forceinline__ int wrap(int i, int n) { i %= n; return i < 0 ? i + n : i; }
 

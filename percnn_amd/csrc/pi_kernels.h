@@ -100,7 +100,7 @@ template <typename T, int NDIM, int HC, int VEC>
 __global__ void __launch_bounds__(256)
 pi_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict__ P, Geom g, int hc_rt)
 {
-    const int hc = HC > 0 ? HC : hc_rt;
+    const int hc = HC > 0 ? HC : hc_rt;      // unused when HC == POLY
     const int cpr = g.W / VEC;
     const long nchunks = (long)g.rows * cpr;
     const long cid = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
@@ -117,33 +117,44 @@ pi_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict_
     star<T, NDIM, VEC, +1>(hv, P, g, i0, i1, x0, e, cv, lap[1]);
 
     const T dt = P[P_DT];
-#pragma unroll
+    // The species / hidden-channel loops stay ROLLED on purpose: a fully unrolled body is several KiB
+    // of straight-line code that every wave executes exactly once, and at one wave per SIMD the
+    // kernel then runs at instruction-fetch speed (measured ~16 cycles per VALU op).  The rolled
+    // body is ~40 instructions, I$-resident, with next channel's 10 scalars prefetched into SGPRs.
+#pragma clang loop unroll(disable)
     for (int s = 0; s < 2; ++s) {
-        const T* W = P + P_W + s * species_block(hc);
         T rr[VEC];
+        if constexpr (HC == POLY) {
+            const T* c = P + P_W + 10 * s;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) rr[i] = W[10 * hc];
+            for (int i = 0; i < VEC; ++i) rr[i] = poly_r(c, cu.v[i], cv.v[i]);
+        } else {
+            const T* W = P + P_W + s * species_block(hc);
 #pragma unroll
-        for (int j = 0; j < hc; ++j) {
-            const T* w = W + 10 * j;
-            const T w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6], w7 = w[7],
-                    w8 = w[8], w9 = w[9];
+            for (int i = 0; i < VEC; ++i) rr[i] = W[10 * hc];
+            W10<T> nx = load_w10(W);
+#pragma clang loop unroll(disable)
+            for (int j = 0; j < hc; ++j) {
+                const W10<T> c = nx;
+                if (j + 1 < hc) nx = load_w10(W + 10 * (j + 1));
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                const T a1 = fma_(w0, cu.v[i], fma_(w1, cv.v[i], w2));
-                const T a2 = fma_(w3, cu.v[i], fma_(w4, cv.v[i], w5));
-                const T a3 = fma_(w6, cu.v[i], fma_(w7, cv.v[i], w8));
-                rr[i] = fma_(w9, (a1 * a2) * a3, rr[i]);
+                for (int i = 0; i < VEC; ++i) {
+                    const T a1 = fma_(c.w[0], cu.v[i], fma_(c.w[1], cv.v[i], c.w[2]));
+                    const T a2 = fma_(c.w[3], cu.v[i], fma_(c.w[4], cv.v[i], c.w[5]));
+                    const T a3 = fma_(c.w[6], cu.v[i], fma_(c.w[7], cv.v[i], c.w[8]));
+                    rr[i] = fma_(c.w[9], (a1 * a2) * a3, rr[i]);
+                }
             }
         }
         const T coef = P[P_COEF + s];
-        const Pack<T, VEC>& c = s == 0 ? cu : cv;
         Pack<T, VEC> o;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const T res = coef * lap[s][i] + rr[i];     // two roundings (train_2drd.py:115)
+            const T hs = s == 0 ? cu.v[i] : cv.v[i];
+            const T lp = s == 0 ? lap[0][i] : lap[1][i];
+            const T res = coef * lp + rr[i];            // two roundings (train_2drd.py:115)
             const T inc = res * dt;                     // two roundings (train_2drd.py:117)
-            o.v[i] = c.v[i] + inc;
+            o.v[i] = hs + inc;
         }
         st<T, VEC>(out + s * g.ss + g.off + e, o);
     }
@@ -165,7 +176,7 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* red = reinterpret_cast<T*>(smem_raw);           // [nwaves][np] running sums of this block
 
-    const int hc = HC > 0 ? HC : hc_rt;
+    const int hc = HC == POLY ? 0 : (HC > 0 ? HC : hc_rt);
     const int np = nparams(hc);
     const int nwaves = blockDim.x / WAVE;
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
@@ -207,6 +218,47 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
 #pragma unroll
         for (int i = 0; i < VEC; ++i) du[i] = dv[i] = T(0);
 
+        if constexpr (HC == POLY) {
+            // monomials shared by both species (only needed for the moment sums)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const T* c = P + P_W + 10 * s;
+                const int gbase = P_W + 10 * s;
+                const Pack<T, VEC>& hs = s == 0 ? u : v;
+                T acc_c = T(0);
+                T acc[10];
+#pragma unroll
+                for (int m = 0; m < 10; ++m) acc[m] = T(0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const T gr = gc[s].v[i] * dt;
+                    acc_c += dl[s][i] * hs.v[i];
+                    T ru, rv;
+                    poly_dr(c, u.v[i], v.v[i], ru, rv);
+                    du[i] = fma_(gr, ru, du[i]);
+                    dv[i] = fma_(gr, rv, dv[i]);
+                    if constexpr (WGRAD) {
+                        const T uu = u.v[i], vv = v.v[i];
+                        const T u2 = uu * uu, uv = uu * vv, v2 = vv * vv;
+                        acc[0] += gr;
+                        acc[1] = fma_(gr, uu, acc[1]); acc[2] = fma_(gr, vv, acc[2]);
+                        acc[3] = fma_(gr, u2, acc[3]); acc[4] = fma_(gr, uv, acc[4]); acc[5] = fma_(gr, v2, acc[5]);
+                        acc[6] = fma_(gr, u2 * uu, acc[6]); acc[7] = fma_(gr, u2 * vv, acc[7]);
+                        acc[8] = fma_(gr, uu * v2, acc[8]); acc[9] = fma_(gr, v2 * vv, acc[9]);
+                    }
+                }
+                acc_c = wave_sum_to_last(acc_c);
+                if (lane == REDUCE_LANE) myred[P_COEF + s] += acc_c;
+                if constexpr (WGRAD) {
+#pragma unroll
+                    for (int m = 0; m < 10; ++m) acc[m] = wave_sum_to_last(acc[m]);
+                    if (lane == REDUCE_LANE) {
+#pragma unroll
+                        for (int m = 0; m < 10; ++m) myred[gbase + m] += acc[m];
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const T* W = P + P_W + s * species_block(hc);
@@ -260,6 +312,8 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
                     }
                 }
             }
+        }
+
         }
 
         if (valid) {
@@ -392,6 +446,75 @@ pi_wgrad_kernel(const T* __restrict__ traj, const T* __restrict__ adj, double* _
         for (int w = 0; w < nwaves; ++w) sum += red[(w * NS + q) * NA + idx];
         const int col = idx == 10 * JC ? gbase + 10 * hc : gbase + 10 * j0 + idx;
         partials[row * np + col] += (double)sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pre-contracted mode: gradients w.r.t. the 2 x 10 cubic coefficients are the "moments"
+//   dL/dc[s][m] = sum_t sum_x (adj_t[s](x) * dt) * phi_m(h_{t-1}(x))
+// again one time-parallel streaming reduction over all (step, point) pairs (16 B per point-step read,
+// ~30 VALU ops): HBM-bound.  The map back to the branch weights (dc/dW, multilinear) is a
+// 20 x (2*(10*hc+1)) chain rule done by the caller.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+pi_moments_kernel(const T* __restrict__ traj, const T* __restrict__ adj, double* __restrict__ partials,
+                  const T* __restrict__ P, long n, int t_lo, int t_hi)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* red = reinterpret_cast<T*>(smem_raw);            // [nwaves][20]
+    const T dt = P[P_DT];
+    const long frame = 2 * n;
+    const long cpf = n / VEC;
+    const long nsteps = t_hi - t_lo;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long stride_t = stride / cpf, stride_x = stride - stride_t * cpf;
+    T acc[2][10];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int m = 0; m < 10; ++m) acc[s][m] = T(0);
+
+    const long c0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long tt = c0 / cpf, xc = c0 - tt * cpf;
+    while (tt < nsteps) {
+        const long t = t_lo + 1 + tt;
+        const long x = xc * VEC;
+        const Pack<T, VEC> u = ld<T, VEC>(traj + (t - 1) * frame + x);
+        const Pack<T, VEC> v = ld<T, VEC>(traj + (t - 1) * frame + n + x);
+        const Pack<T, VEC> au = ld<T, VEC>(adj + t * frame + x);
+        const Pack<T, VEC> av = ld<T, VEC>(adj + t * frame + n + x);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const T uu = u.v[i], vv = v.v[i];
+            const T u2 = uu * uu, uv = uu * vv, v2 = vv * vv;
+            const T phi[10] = {T(1), uu, vv, u2, uv, v2, u2 * uu, u2 * vv, uu * v2, v2 * vv};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const T gr = (s == 0 ? au.v[i] : av.v[i]) * dt;
+                acc[s][0] += gr;
+#pragma unroll
+                for (int m = 1; m < 10; ++m) acc[s][m] = fma_(gr, phi[m], acc[s][m]);
+            }
+        }
+        xc += stride_x;
+        tt += stride_t;
+        if (xc >= cpf) { xc -= cpf; ++tt; }
+    }
+    const int nwaves = blockDim.x / WAVE;
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int m = 0; m < 10; ++m) {
+            const T r = wave_sum_to_last(acc[s][m]);
+            if (lane == REDUCE_LANE) red[wave * 20 + 10 * s + m] = r;
+        }
+    __syncthreads();
+    if (threadIdx.x < 20) {
+        T sum = T(0);
+        for (int w = 0; w < nwaves; ++w) sum += red[w * 20 + threadIdx.x];
+        partials[(long)blockIdx.x * NPOLY + P_W + threadIdx.x] += (double)sum;
     }
 }
 

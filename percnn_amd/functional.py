@@ -92,6 +92,50 @@ def pack_params(dt: torch.Tensor, coef_u: torch.Tensor, coef_v: torch.Tensor, w_
     return flat.index_select(0, _gather_index(hc, ndim, flat.device))
 
 
+# ------------------------------------------------------------------------------------------------
+# pre-contracted ("poly") reaction: Wh4(Wh1(h)*Wh2(h)*Wh3(h)) as a cubic in (u, v)
+# ------------------------------------------------------------------------------------------------
+NPOLY = 36
+_MONO = {(0, 0): 0, (1, 0): 1, (0, 1): 2, (2, 0): 3, (1, 1): 4, (0, 2): 5, (3, 0): 6, (2, 1): 7, (1, 2): 8, (0, 3): 9}
+_k_cache: dict = {}
+
+
+def _contraction_tensor(device) -> torch.Tensor:
+    """K[m,a,b,c] = 1 iff e_a*e_b*e_c == phi_m with e = (u, v, 1) and
+    phi = (1, u, v, u^2, uv, v^2, u^3, u^2 v, u v^2, v^3)."""
+    key = str(device)
+    if key not in _k_cache:
+        ex = [(1, 0), (0, 1), (0, 0)]
+        K = torch.zeros(10, 3, 3, 3, dtype=torch.float64)
+        for a in range(3):
+            for b in range(3):
+                for c in range(3):
+                    e = (ex[a][0] + ex[b][0] + ex[c][0], ex[a][1] + ex[b][1] + ex[c][1])
+                    K[_MONO[e], a, b, c] = 1.0
+        e0 = torch.zeros(10, dtype=torch.float64)
+        e0[0] = 1.0
+        _k_cache[key] = (K.to(device), e0.to(device))
+    return _k_cache[key]
+
+
+def contract_block(P: torch.Tensor) -> torch.Tensor:
+    """Factored parameter block [16 + 2*(10*hc+1)] -> polynomial block [36], differentiably.
+
+    Per species the product of the three 1x1 branches followed by the 1x1 aggregation
+    (train_2drd.py:115-116) is the cubic  r(u,v) = sum_m c_m phi_m(u,v)  with
+    c_m = sum_j Wh4[j] * sum_{abc} K[m,a,b,c] L1[j,a] L2[j,b] L3[j,c]  (+ Wh4.bias for m = 0),
+    L_k[j] = (Wh_k.weight[j,0], Wh_k.weight[j,1], Wh_k.bias[j]) -- the same expansion the reference
+    prints symbolically (train_3drd.py:442-468).  Evaluated in float64, rounded once to the compute
+    dtype.  Autograd of this function is the exact chain rule dL/dc -> dL/dWh*."""
+    hc = _hc_of(P)
+    K, e0 = _contraction_tensor(P.device)
+    B = P[16:].to(torch.float64).reshape(2, 10 * hc + 1)
+    Wm = B[:, :10 * hc].reshape(2, hc, 10)
+    c = torch.einsum("mabc,sja,sjb,sjc,sj->sm", K, Wm[..., 0:3], Wm[..., 3:6], Wm[..., 6:9], Wm[..., 9])
+    c = c + B[:, 10 * hc:] * e0
+    return torch.cat([P[:16], c.to(P.dtype).reshape(20)])
+
+
 def check_star_stencil(w_laplace: torch.Tensor) -> None:
     """The kernels implement star stencils of radius 2 (what the reference ships: train_2drd.py:20-24,
     train_3drd.py:22-39).  Anything else is rejected loudly (host check, one sync)."""
@@ -130,6 +174,9 @@ def _require(t: torch.Tensor, name: str, dtype=None) -> None:
 
 
 def _hc_of(P: torch.Tensor) -> int:
+    """hidden width encoded by the block length; 0 = pre-contracted polynomial block (36 entries)."""
+    if P.dim() == 1 and P.numel() == NPOLY:
+        return 0
     n = P.numel() - 16
     if P.dim() != 1 or n < 22 or n % 2 or (n // 2 - 1) % 10:
         raise RuntimeError(f"percnn_amd: parameter block has {P.numel()} entries; expected 16 + 2*(10*hc+1)")

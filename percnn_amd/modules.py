@@ -39,8 +39,17 @@ class RCNNCell(nn.Module):
 
     def __init__(self, ndim: int = 2, hidden_channels: int = 8, dx: float = 0.01, dt: float = 0.5,
                  mu_up: Optional[float] = 3.99e-5, diffusion: str = "sigmoid", dtype=torch.float32,
-                 stencil_scale: str = "premul", init: str = "xavier", init_c: float = 0.02):
+                 stencil_scale: str = "premul", init: str = "xavier", init_c: float = 0.02,
+                 reaction: str = "poly"):
         super().__init__()
+        if reaction not in ("poly", "factored"):
+            raise ValueError("reaction must be 'poly' or 'factored'")
+        # 'factored': the kernels evaluate the six 1x1 branches, their Hadamard product and the 1x1
+        #             aggregation per point, in the reference's operation order.
+        # 'poly'    : the same cubic, pre-contracted on the device to 2 x 10 monomial coefficients
+        #             (functional.contract_block) -- ~4x fewer VALU operations per point at Hc = 8,
+        #             cost independent of Hc; same function, different rounding (parity-tested).
+        self.reaction = reaction
         if ndim not in (2, 3):
             raise ValueError("ndim must be 2 or 3")
         if diffusion not in ("sigmoid", "raw"):
@@ -105,7 +114,8 @@ class RCNNCell(nn.Module):
             for k in (1, 2, 3, 4):
                 m = getattr(self, f"Wh{k}_{s}")
                 branch += [m.weight, m.bias]
-        return F_pi.pack_params(self._dt_cache, cu, cv, w, branch)
+        P = F_pi.pack_params(self._dt_cache, cu, cv, w, branch)
+        return F_pi.contract_block(P) if self.reaction == "poly" else P
 
     # -- reference interface -------------------------------------------------------------------
     def forward(self, h):
@@ -116,22 +126,22 @@ class RCNNCell(nn.Module):
         return prev_state.to(self.W_laplace.weight.device)
 
 
-def gs2d_cell(hidden_channels: int = 8) -> RCNNCell:
+def gs2d_cell(hidden_channels: int = 8, reaction: str = "poly") -> RCNNCell:
     """2D Gray-Scott constants (train_2drd.py:56-58, init c=0.02 :90)."""
     return RCNNCell(2, hidden_channels, dx=0.01, dt=0.5, mu_up=3.99e-5, diffusion="sigmoid", dtype=torch.float32,
-                    stencil_scale="premul", init="xavier", init_c=0.02)
+                    stencil_scale="premul", init="xavier", init_c=0.02, reaction=reaction)
 
 
-def gs3d_cell(hidden_channels: int = 2) -> RCNNCell:
+def gs3d_cell(hidden_channels: int = 2, reaction: str = "poly") -> RCNNCell:
     """3D Gray-Scott constants (train_3drd.py:71-73, init c=0.01 :106)."""
     return RCNNCell(3, hidden_channels, dx=100 / 48, dt=0.5, mu_up=0.274, diffusion="sigmoid", dtype=torch.float32,
-                    stencil_scale="premul", init="xavier", init_c=0.01)
+                    stencil_scale="premul", init="xavier", init_c=0.01, reaction=reaction)
 
 
-def lo2d_cell(hidden_channels: int = 4) -> RCNNCell:
+def lo2d_cell(hidden_channels: int = 4, reaction: str = "poly") -> RCNNCell:
     """2D lambda-omega constants, float64 (percnn_LO_eqn.py:12,38-43, init c=0.5 :73)."""
     return RCNNCell(2, hidden_channels, dx=0.2, dt=0.0125, mu_up=None, diffusion="raw", dtype=torch.float64,
-                    stencil_scale="div", init="uniform", init_c=0.5)
+                    stencil_scale="div", init="uniform", init_c=0.5, reaction=reaction)
 
 
 class Upscaler(nn.Module):

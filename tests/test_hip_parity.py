@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 import torch
 
-from util import GOLDEN, Golden, TOL_GRAD, TOL_TRAJ, case_id, data_loss, rel_l2, small_cases
+from util import (GOLDEN, Golden, TOL_GRAD, TOL_TRAJ, case_id, data_loss, rel_l2, small_cases, random_block,
+                  o_step_fwd, o_step_bwd, o_rollout_fwd, o_rollout_bwd)
 
 pytestmark = pytest.mark.gpu
 
@@ -19,54 +20,41 @@ def dev_t(a, device):
     return torch.tensor(np.ascontiguousarray(a), device=device)
 
 
-def random_block(hc, ndim, dtype, seed, scale=0.5):
-    """Random but well-conditioned parameter block for the plain-C oracle and the kernels."""
-    rs = np.random.RandomState(seed)
-    P = np.zeros(16 + 2 * (10 * hc + 1), dtype=dtype)
-    P[0] = 0.1
-    P[1:3] = rs.uniform(0.01, 0.05, 2)
-    P[3] = -2.0 * ndim * 1.25
-    for a in range(ndim):
-        P[4 + 4 * a:8 + 4 * a] = (-1 / 12, 4 / 3, 4 / 3, -1 / 12) + rs.uniform(-0.01, 0.01, 4)  # asymmetric on purpose
-    P[16:] = rs.uniform(-scale, scale, len(P) - 16)
-    return P
-
-
 # ---------------------------------------------------------------------------------------------
 # forward
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("reaction", ["factored", "poly"])
 @pytest.mark.parametrize("fn", small_cases(), ids=case_id)
-def test_step_and_rollout_forward(fn, hip_device):
+def test_step_and_rollout_forward(fn, reaction, hip_device):
     import percnn_amd as pa
-    from oracle import pi_oracle as O
     g = Golden(fn)
-    P = g.packed()
+    P = g.packed(reaction)
     Pd = dev_t(P, hip_device)
     # one step: bit-identical to the plain-C oracle, within tolerance of the reference
     out = pa.step_fwd(dev_t(g.h0[0], hip_device), Pd).cpu().numpy()
-    assert np.array_equal(out, O.step_fwd(g.h0[0], P, g.hc))
+    assert np.array_equal(out, o_step_fwd(g.h0[0], P))
     assert rel_l2(out, g.traj(1)) < (5e-7 if g.dtype == np.float32 else 1e-14)
     # rollout
     traj = torch.empty((g.steps + 1,) + g.h0.shape[1:], dtype=torch.from_numpy(g.h0).dtype, device=hip_device)
     traj[0] = dev_t(g.h0[0], hip_device)
     pa.rollout_fwd_(traj, Pd)
     traj = traj.cpu().numpy()
-    assert np.array_equal(traj, O.rollout_fwd(g.h0[0], P, g.hc, g.steps))
+    assert np.array_equal(traj, o_rollout_fwd(g.h0[0], P, g.steps))
     for t in g.keep_t:
         assert rel_l2(traj[t], g.traj(t)) < TOL_TRAJ[g.dtype], f"frame {t}"
 
 
 @pytest.mark.parametrize("shape", [(5, 7), (2, 2), (3, 64), (64, 6), (6, 10, 9), (2, 3, 4), (4, 4, 8), (20, 12, 16)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("hc", [2, 3, 8, 16])
+@pytest.mark.parametrize("hc", [0, 2, 3, 8, 16])
 def test_forward_ragged_shapes_and_channel_counts(shape, dtype, hc, hip_device):
-    """Odd extents (scalar path), extents below the stencil width (multiple wraps), generic hc."""
+    """Odd extents (scalar path), extents below the stencil width (multiple wraps), generic hc,
+    hc = 0 = pre-contracted polynomial block."""
     import percnn_amd as pa
-    from oracle import pi_oracle as O
     P = random_block(hc, len(shape), dtype, seed=hc + len(shape))
     h = np.random.RandomState(1).uniform(-1, 1, (2,) + shape).astype(dtype)
     out = pa.step_fwd(dev_t(h, hip_device), dev_t(P, hip_device)).cpu().numpy()
-    assert np.array_equal(out, O.step_fwd(h, P, hc))
+    assert np.array_equal(out, o_step_fwd(h, P))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -74,10 +62,9 @@ def test_forward_ragged_shapes_and_channel_counts(shape, dtype, hc, hip_device):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(5, 7), (2, 2), (16, 32), (64, 6), (6, 10, 9), (2, 3, 4), (8, 8, 16)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("hc", [2, 3, 8, 16])
+@pytest.mark.parametrize("hc", [0, 2, 3, 8, 16])
 def test_step_backward_vs_c_oracle(shape, dtype, hc, hip_device):
     import percnn_amd as pa
-    from oracle import pi_oracle as O
     rs = np.random.RandomState(7)
     P = random_block(hc, len(shape), dtype, seed=hc)
     h = rs.uniform(-1, 1, (2,) + shape).astype(dtype)
@@ -86,18 +73,19 @@ def test_step_backward_vs_c_oracle(shape, dtype, hc, hip_device):
     for use_inj in (False, True):
         gi, pg = pa.step_bwd(dev_t(h, hip_device), dev_t(G, hip_device), dev_t(P, hip_device),
                              g_inject=dev_t(inj, hip_device) if use_inj else None)
-        gi_o, pg_o = O.step_bwd(h, G, inj if use_inj else None, P, hc)
+        gi_o, pg_o = o_step_bwd(h, G, inj if use_inj else None, P)
         assert np.array_equal(gi.cpu().numpy(), gi_o)            # adjoint state: bit-identical
         tol = 2e-5 if dtype == np.float32 else 1e-12
         assert rel_l2(pg.cpu().numpy(), pg_o) < tol              # reductions: order differs
 
 
+@pytest.mark.parametrize("reaction", ["factored", "poly"])
 @pytest.mark.parametrize("fn", small_cases(), ids=case_id)
-def test_autograd_through_modules_vs_golden(fn, hip_device):
+def test_autograd_through_modules_vs_golden(fn, reaction, hip_device):
     """dL/dparams (all 164/44/84 values) and dL/dh0 for the two captured losses."""
     import percnn_amd as pa
     g = Golden(fn)
-    cell = g.product_cell(hip_device)
+    cell = g.product_cell(hip_device, reaction)
     for lname in ("meansq", "data"):
         h0 = dev_t(g.h0, hip_device).requires_grad_(True)
         model = pa.RCNN(cell, step=g.steps, effective_step=list(range(g.steps)), init_state=h0)
@@ -119,10 +107,11 @@ def test_autograd_through_modules_vs_golden(fn, hip_device):
         assert rel_l2(grads[-1].cpu().numpy(), g.z[f"grad_{lname}_h0"]) < TOL_GRAD[g.dtype]
 
 
-def test_sparse_frame_mask_equals_dense(hip_device):
+@pytest.mark.parametrize("reaction", ["factored", "poly"])
+def test_sparse_frame_mask_equals_dense(reaction, hip_device):
     import percnn_amd as pa
     g = Golden(os.path.join(GOLDEN, "gs2d_ckpt_32x32.npz"))
-    Pd = dev_t(g.packed(), hip_device)
+    Pd = dev_t(g.packed(reaction), hip_device)
     T = 23
     traj = torch.empty((T + 1, 2, 32, 32), device=hip_device)
     traj[0] = dev_t(g.h0[0], hip_device)
@@ -137,17 +126,18 @@ def test_sparse_frame_mask_equals_dense(hip_device):
         b0, bpg = pa.rollout_bwd(traj, gt, Pd, frame_mask=mask)
         assert torch.equal(a0, b0)
         # the weight-gradient reduction is partitioned over the swept range, so only the order differs
-        assert rel_l2(bpg.cpu().numpy(), apg.cpu().numpy()) < 1e-6
+        assert rel_l2(bpg.cpu().numpy(), apg.cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("hc", [3, 0])
 @pytest.mark.parametrize("ndim", [2, 3])
-def test_gradcheck_fp64(ndim, hip_device):
+def test_gradcheck_fp64(ndim, hc, hip_device):
     """torch.autograd.gradcheck of the custom Functions in float64 on tiny grids (SURVEY 4 iv).
     dt and the frozen stencil (slots 0, 3..15) are constants of the op, so only the trainable
     slots (coefficients + branch weights) are perturbed."""
     import percnn_amd as pa
     shape = (6, 8) if ndim == 2 else (4, 6, 4)
-    base = dev_t(random_block(3, ndim, np.float64, 3), hip_device)
+    base = dev_t(random_block(hc, ndim, np.float64, 3), hip_device)
     idx = torch.tensor([1, 2] + list(range(16, base.numel())), device=hip_device)
     free = base[idx].clone().requires_grad_(True)
     h = torch.rand((1, 2) + shape, dtype=torch.float64, device=hip_device, requires_grad=True)
@@ -163,19 +153,20 @@ def test_gradcheck_fp64(ndim, hip_device):
 # ---------------------------------------------------------------------------------------------
 # modules: rollout harness (a9), checkpoints (a2)
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("reaction", ["factored", "poly"])
 @pytest.mark.parametrize("fam", ["gs2d", "gs3d", "lo2d"])
-def test_rcnn_harness_vs_reference_capture(fam, hip_device):
+def test_rcnn_harness_vs_reference_capture(fam, reaction, hip_device):
     import percnn_amd as pa
     z = np.load(os.path.join(GOLDEN, f"{fam}_rcnn_harness.npz"))
     steps, eff = int(z["steps"]), [int(e) for e in z["effective_step"]]
     sd = {k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("state/")}
     if fam == "lo2d":
-        m = pa.RCNN(pa.lo2d_cell(), step=steps, effective_step=eff,
+        m = pa.RCNN(pa.lo2d_cell(reaction=reaction), step=steps, effective_step=eff,
                     init_state=dev_t(z["init_state"], hip_device), cell_name="rcnn_cell")
     else:
         nd = 2 if fam == "gs2d" else 3
-        m = pa.RCNN(pa.gs2d_cell() if nd == 2 else pa.gs3d_cell(), step=steps, effective_step=eff,
-                    upscaler=pa.Upscaler(nd), init_state_low=dev_t(z["init_state_low"], hip_device))
+        m = pa.RCNN(pa.gs2d_cell(reaction=reaction) if nd == 2 else pa.gs3d_cell(reaction=reaction), step=steps,
+                    effective_step=eff, upscaler=pa.Upscaler(nd), init_state_low=dev_t(z["init_state_low"], hip_device))
     m.load_state_dict(sd)
     m.to(hip_device)
     with torch.no_grad():
@@ -205,11 +196,12 @@ def test_cell_forward_signature(hip_device):
 @pytest.mark.parametrize("shape", [(16, 32), (12, 8, 16)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("halo", [2, 4])
-def test_slab_step_equals_periodic_step(shape, dtype, halo, hip_device):
+@pytest.mark.parametrize("hc", [4, 0])
+def test_slab_step_equals_periodic_step(shape, dtype, halo, hc, hip_device):
     """Two half-domain slabs (halo planes copied by hand) reproduce the periodic single-domain step
     bit for bit -- forward (incl. the wide-halo multi-step scheme) and adjoint."""
     import percnn_amd as pa
-    ndim, hc = len(shape), 4
+    ndim = len(shape)
     npd = np.float32 if dtype == torch.float32 else np.float64
     P = dev_t(random_block(hc, ndim, npd, 11), hip_device)
     h = torch.rand((2,) + shape, dtype=dtype, device=hip_device)
@@ -273,14 +265,15 @@ def _big(fam):
     return np.load(os.path.join(GOLDEN, fn[0]))
 
 
+@pytest.mark.parametrize("reaction", ["factored", "poly"])
 @pytest.mark.parametrize("fam,shape", [("gs2d", (512, 512)), ("gs3d", (128, 128, 128)), ("lo2d", (512, 512))])
-def test_full_size_rollout_vs_reference_subsample(fam, shape, hip_device):
+def test_full_size_rollout_vs_reference_subsample(fam, shape, reaction, hip_device):
     """configs[1..3]: the reference's own CPU run (every 8th point of h_T + |h_T|) at full size."""
     import percnn_amd as pa
     from oracle import restatement as R
     z = _big(fam)
     sd = {k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}
-    cell = {"gs2d": pa.gs2d_cell, "gs3d": pa.gs3d_cell, "lo2d": pa.lo2d_cell}[fam]()
+    cell = {"gs2d": pa.gs2d_cell, "gs3d": pa.gs3d_cell, "lo2d": pa.lo2d_cell}[fam](reaction=reaction)
     cell.load_state_dict(sd)
     cell.to(hip_device)
     h0 = (R.lo_initial_state(shape[0]) if fam == "lo2d" else R.gs_initial_state(shape, seed=0)).to(hip_device)
@@ -297,21 +290,21 @@ def test_full_size_rollout_vs_reference_subsample(fam, shape, hip_device):
 
 
 @pytest.mark.parametrize("shape,hc,dtype", [((512, 512), 8, np.float32), ((128, 128, 128), 2, np.float32),
-                                            ((512, 512), 4, np.float64)])
+                                            ((512, 512), 4, np.float64), ((512, 512), 0, np.float32),
+                                            ((128, 128, 128), 0, np.float32), ((512, 512), 0, np.float64)])
 def test_full_size_step_bitwise_and_translation_equivariance(shape, hc, dtype, hip_device):
     """One step at BASELINE sizes: bit-identical to the C oracle (fwd + adjoint state); a periodic
     shift of the input shifts the output identically (size-independent property of the wrap)."""
     import percnn_amd as pa
-    from oracle import pi_oracle as O
     rs = np.random.RandomState(5)
     P = random_block(hc, len(shape), dtype, 21, scale=0.3)
     h = rs.uniform(0, 1, (2,) + shape).astype(dtype)
     G = rs.uniform(-1, 1, (2,) + shape).astype(dtype)
     hd, Gd, Pd = dev_t(h, hip_device), dev_t(G, hip_device), dev_t(P, hip_device)
     out = pa.step_fwd(hd, Pd)
-    assert np.array_equal(out.cpu().numpy(), O.step_fwd(h, P, hc))
+    assert np.array_equal(out.cpu().numpy(), o_step_fwd(h, P))
     gi, pg = pa.step_bwd(hd, Gd, Pd)
-    gi_o, pg_o = O.step_bwd(h, G, None, P, hc)
+    gi_o, pg_o = o_step_bwd(h, G, None, P)
     assert np.array_equal(gi.cpu().numpy(), gi_o)
     assert rel_l2(pg.cpu().numpy(), pg_o) < (2e-5 if dtype == np.float32 else 1e-12)
     shifts = tuple(int(s) for s in rs.randint(1, 50, len(shape)))
@@ -362,3 +355,40 @@ def test_rccl_halo_exchange_to_self(hip_device):
         assert torch.equal(t, torch.ones_like(t))
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------
+# temporally blocked 2D kernels: every variant must stay bit-identical to the oracle
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("opts", [{"tile": 0}, {"tile_k": 2}, {"tile_k": 4, "tile_nt": 256},
+                                  {"tile_k": 4, "tile_nt": 512}, {"vec": 1}])
+@pytest.mark.parametrize("dtype,hc", [(np.float32, 8), (np.float32, 2), (np.float64, 4), (np.float32, 0),
+                                      (np.float64, 0)])
+def test_tile_variants_bitwise(opts, dtype, hc, hip_device):
+    import percnn_amd as pa
+    shape, T = (64, 96), 11                      # non-square multiple of the 32x32 tile; T not a multiple of K
+    rs = np.random.RandomState(9)
+    P = random_block(hc, 2, dtype, 13, scale=0.3)
+    h0 = rs.uniform(0, 1, (2,) + shape).astype(dtype)
+    gt = rs.uniform(-1, 1, (T + 1, 2) + shape).astype(dtype)
+    ref = o_rollout_fwd(h0, P, T)
+    g0_ref, pg_ref = o_rollout_bwd(ref, gt, P)
+    defaults = {"tile": 1, "tile_k": 4, "tile_nt": 256, "vec": 0}
+    try:
+        for k, v in opts.items():
+            pa.set_option(k, v)
+        traj = torch.empty((T + 1, 2) + shape, dtype=torch.from_numpy(h0).dtype, device=hip_device)
+        traj[0] = dev_t(h0, hip_device)
+        pa.rollout_fwd_(traj, dev_t(P, hip_device))
+        assert np.array_equal(traj.cpu().numpy(), ref)
+        for mask in (None, [t % 3 == 0 for t in range(T + 1)]):
+            g = gt.copy()
+            if mask is not None:
+                g[[not m for m in mask]] = 0
+                g0_ref, pg_ref = o_rollout_bwd(ref, g, P)
+            g0, pg = pa.rollout_bwd(traj, dev_t(g, hip_device), dev_t(P, hip_device), frame_mask=mask)
+            assert np.array_equal(g0.cpu().numpy(), g0_ref)
+            assert rel_l2(pg.cpu().numpy(), pg_ref) < (2e-5 if dtype == np.float32 else 1e-12)
+    finally:
+        for k, v in defaults.items():
+            pa.set_option(k, v)

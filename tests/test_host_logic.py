@@ -34,6 +34,7 @@ def test_library_exports_every_declared_symbol():
     assert percnn_amd.lib().percnn_pi_abi_version() == 1
     for hc in (2, 4, 8, 16):
         assert percnn_amd.lib().percnn_pi_param_count(hc) == 16 + 2 * (10 * hc + 1) == percnn_amd.param_count(hc)
+    assert percnn_amd.lib().percnn_pi_param_count(0) == 36          # pre-contracted polynomial block
     shape = (ctypes.c_int64 * 2)(512, 512)
     assert percnn_amd.lib().percnn_pi_bwd_workspace_bytes(8, 2, shape, 4) > 2 * 2 * 512 * 512 * 4
     assert percnn_amd.lib().percnn_pi_bwd_workspace_bytes(8, 4, shape, 4) == 0       # bad ndim
@@ -47,29 +48,58 @@ def test_argument_errors_do_not_need_a_gpu():
     shape = (ctypes.c_int64 * 2)(8, 8)
     assert L.percnn_pi_step_fwd_f32(None, None, None, 8, 2, shape, None) == -1
     assert L.percnn_pi_step_fwd_f32(1, 2, 3, 8, 5, shape, None) == -1
-    assert L.percnn_pi_step_fwd_f32(1, 2, 3, 0, 2, shape, None) == -1
+    assert L.percnn_pi_step_fwd_f32(1, 2, 3, -1, 2, shape, None) == -1
     bad = (ctypes.c_int64 * 2)(1, 8)
     assert L.percnn_pi_step_fwd_f64(1, 2, 3, 4, 2, bad, None) == -1
     assert L.percnn_pi_rollout_fwd_f32(1, 2, 8, 2, shape, -1, None) == -1
     assert L.percnn_pi_step_bwd_f32(1, 2, None, 3, 4, None, 0, 5, 8, 2, shape, None) == -2   # no workspace
 
 
+@pytest.mark.parametrize("reaction", ["factored", "poly"])
 @pytest.mark.parametrize("fn", small_cases(), ids=case_id)
-def test_param_block_matches_oracle_layout(fn):
+def test_param_block_matches_oracle_layout(fn, reaction):
+    """Factored block: bit-equal.  Polynomial block: the device-side einsum contraction against the
+    oracle's plain triple-loop expansion (float64 summation order differs -> 1 ulp of the dtype)."""
     g = Golden(fn)
-    cell = g.product_cell("cpu")
+    cell = g.product_cell("cpu", reaction)
     P = cell.param_block().detach().numpy()
-    Po = g.packed()
+    Po = g.packed(reaction)
+    assert len(P) == len(Po) == (36 if reaction == "poly" else 16 + 2 * (10 * g.hc + 1))
     used = np.ones(len(P), bool)
     if g.ndim == 2:
         used[12:16] = False
     assert P.dtype == Po.dtype == g.dtype
-    assert np.array_equal(P[used], Po[used])
+    assert np.array_equal(P[:12], Po[:12])
+    if reaction == "factored":
+        assert np.array_equal(P[used], Po[used])
+    else:
+        np.testing.assert_allclose(P[16:], Po[16:], rtol=4 * np.finfo(g.dtype).eps,
+                                   atol=4 * np.finfo(g.dtype).eps * np.abs(Po[16:]).max())   # cancelled (true-zero) terms
+
+
+@pytest.mark.parametrize("fn", small_cases()[::3], ids=case_id)
+def test_contraction_chain_rule_matches_independent_expansion(fn):
+    """autograd of contract_block == the oracle's hand-written multilinear chain rule dL/dc -> dL/dWh*."""
+    from oracle import pi_oracle as O
+    g = Golden(fn)
+    cell = g.product_cell("cpu", "poly")
+    Q = cell.param_block()
+    qg = np.random.RandomState(0).randn(36)
+    qg[0] = 0
+    qg[3:16] = 0
+    (Q.double() * torch.tensor(qg)).sum().backward()
+    ref = O.poly_grads_to_params(qg, g.sd)
+    for n, r in ref.items():
+        if "." not in n:
+            continue
+        mod, attr = n.split(".")
+        got = getattr(getattr(cell, mod), attr).grad.numpy().astype(np.float64)
+        assert np.abs(got - r).max() <= 1e-6 * (np.abs(r).max() + 1e-30), n
 
 
 def test_param_block_is_differentiable_to_named_parameters():
     import percnn_amd as pa
-    cell = pa.gs2d_cell(4)
+    cell = pa.gs2d_cell(4, reaction="factored")
     P = cell.param_block()
     w = torch.arange(P.numel(), dtype=P.dtype)
     (P * w).sum().backward()

@@ -62,17 +62,19 @@ class Golden:
         cell.load_state_dict({k: torch.tensor(v) for k, v in self.sd.items()})
         return cell
 
-    def product_cell(self, device):
+    def product_cell(self, device, reaction="poly"):
         import percnn_amd as pa
-        cell = {"gs2d": pa.gs2d_cell, "gs3d": pa.gs3d_cell, "lo2d": pa.lo2d_cell}[self.family]()
+        cell = {"gs2d": pa.gs2d_cell, "gs3d": pa.gs3d_cell, "lo2d": pa.lo2d_cell}[self.family](reaction=reaction)
         cell.load_state_dict({k: torch.tensor(v) for k, v in self.sd.items()})
         return cell.to(device)
 
-    def packed(self):
+    def packed(self, reaction="factored"):
         """Parameter block for the plain-C oracle, coefficient computed as the reference does."""
         from oracle import pi_oracle as O
         cell = self.oracle_cell()
         cu, cv = [c.detach().numpy() for c in cell.coefficients()]
+        if reaction == "poly":
+            return O.pack_poly(self.sd, self.dt, cu, cv, self.dtype)
         return O.pack_params(self.sd, self.dt, cu, cv, self.dtype)
 
     def named_grads_from_packed(self, pg):
@@ -92,3 +94,42 @@ class Golden:
 def data_loss(traj, stride_t, ndim):
     sl = (slice(0, -1, stride_t), slice(None)) + (slice(None, None, 4),) * ndim
     return ((traj[sl] - 0.5) ** 2).mean()
+
+
+# ---- oracle dispatch on the block kind (36 entries = pre-contracted polynomial block, "hc = 0") ----
+def hc_of(P):
+    return 0 if len(P) == 36 else ((len(P) - 16) // 2 - 1) // 10
+
+
+def o_step_fwd(h, P):
+    from oracle import pi_oracle as O
+    return O.poly_step_fwd(h, P) if len(P) == 36 else O.step_fwd(h, P, hc_of(P))
+
+
+def o_step_bwd(h, G, inj, P):
+    from oracle import pi_oracle as O
+    return O.poly_step_bwd(h, G, inj, P) if len(P) == 36 else O.step_bwd(h, G, inj, P, hc_of(P))
+
+
+def o_rollout_fwd(h0, P, T):
+    from oracle import pi_oracle as O
+    return O.poly_rollout_fwd(h0, P, T) if len(P) == 36 else O.rollout_fwd(h0, P, hc_of(P), T)
+
+
+def o_rollout_bwd(traj, g, P):
+    from oracle import pi_oracle as O
+    return O.poly_rollout_bwd(traj, g, P) if len(P) == 36 else O.rollout_bwd(traj, g, P, hc_of(P))
+
+
+def random_block(hc, ndim, dtype, seed, scale=0.5):
+    """Random but well-conditioned parameter block (hc = 0: polynomial block of 36 entries)."""
+    rs = np.random.RandomState(seed)
+    n = 36 if hc == 0 else 16 + 2 * (10 * hc + 1)
+    P = np.zeros(n, dtype=dtype)
+    P[0] = 0.1
+    P[1:3] = rs.uniform(0.01, 0.05, 2)
+    P[3] = -2.0 * ndim * 1.25
+    for a in range(ndim):
+        P[4 + 4 * a:8 + 4 * a] = (-1 / 12, 4 / 3, 4 / 3, -1 / 12) + rs.uniform(-0.01, 0.01, 4)  # asymmetric on purpose
+    P[16:] = rs.uniform(-scale, scale, n - 16)
+    return P

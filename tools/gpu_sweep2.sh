@@ -1,0 +1,13 @@
+export TMPDIR=/tmp
+run() { (timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --T 400 "$@" 2>&1 | tail -1) | python -c "
+import sys,json
+l=sys.stdin.read().strip().splitlines()[-1]
+try:
+    d=json.loads(l); print('$*', '| fwd+bwd %.0f steps/s'%d['value'], '| fwd us/step %.2f'%d['roofline']['fwd_kernel']['avg_launch_us'], '| bwd us/step %.2f'%d['roofline']['avg_launch_us'])
+except Exception as e: print('$*', 'ERR', l[-300:])
+"; }
+(timeout 600 python -m pytest tests/test_hip_parity.py -m gpu -q -x -k "forward" 2>&1 | tail -3)
+run --workload gs2d_512 --opt tile=0
+run --workload gs2d_512 --opt tile=0 --opt block=64
+run --workload lo2d_512 --opt tile=0
+run --workload gs3d_128
