@@ -170,18 +170,47 @@ def main():
     total_steps = world * a.steps * T
     value = total_steps / elapsed
 
-    # roofline of the dominant kernel (pi_bwd_kernel: one launch per time step of the reverse sweep).
-    # Algorithmic bytes per launch: read h_{t-1}, g_t, injected dL/dout_{t-1}; write g_{t-1}
-    #   = 4 * C * s bytes per point = 32 B (fp32) / 64 B (fp64).
-    bwd_bytes = 4 * 2 * esz * npts
-    fwd_bytes = 2 * 2 * esz * npts
-    bwd_launch_s = bwd_ms * 1e-3 / T           # HIP events on the launch stream; includes launch gaps
-    fwd_launch_s = fwd_ms * 1e-3 / T
-    achieved = bwd_bytes / bwd_launch_s / 1e9
+    # ---- per-kernel roofline, measured live with HIP events on the launch stream ------------------
+    # The backward is two kernels: the sequential adjoint sweep and ONE time-parallel gradient
+    # reduction.  Time the sweep alone (library diagnostic option) so each kernel gets its own line.
+    pa.set_option("skip_wgrad", 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    pa.rollout_bwd(traj, gtraj, P)
+    e0.record()
+    for _ in range(a.steps):
+        pa.rollout_bwd(traj, gtraj, P)
+    e1.record()
+    torch.cuda.synchronize()
+    pa.set_option("skip_wgrad", 0)
+    sweep_ms = e0.elapsed_time(e1) / a.steps
+    red_ms = max(bwd_ms - sweep_ms, 1e-6)
+
+    opts = dict(kv.split("=") for kv in a.opt)
+    tiled = len(shape) == 2 and all(n % 32 == 0 for n in shape) and opts.get("tile", "1") != "0"
+    K = int(opts.get("tile_k", 4)) if tiled else 1
+    poly = a.reaction == "poly"
+    # algorithmic bytes per point and time step: fwd read+write state = 2*C*s;
+    # sweep read h, adj, dL/dout + write adj = 4*C*s; gradient reduction read h + adj = 2*C*s
+    # (the factored Hc=8 reduction streams h once per species: 3*C*s)
+    Cs = 2 * esz
+    red_bytes_pt = 2 * Cs if (poly or hc <= 4) else 3 * Cs
+    kernels = [
+        {"kernel": ("pi_fwd2d_tile_kernel" if tiled else "pi_fwd_kernel"), "launches_per_pass": T // K,
+         "algorithmic_bytes_per_launch": 2 * Cs * npts * K, "avg_launch_us": fwd_ms * 1e3 / (T / K)},
+        {"kernel": ("pi_adj2d_tile_kernel" if tiled else "pi_bwd_kernel<sweep>"), "launches_per_pass": T // K,
+         "algorithmic_bytes_per_launch": 4 * Cs * npts * K, "avg_launch_us": sweep_ms * 1e3 / (T / K)},
+        {"kernel": ("pi_moments_kernel" if poly else "pi_wgrad_kernel"), "launches_per_pass": 1,
+         "algorithmic_bytes_per_launch": red_bytes_pt * npts * T, "avg_launch_us": red_ms * 1e3},
+    ]
+    for k in kernels:
+        k["achieved"] = k["algorithmic_bytes_per_launch"] / (k["avg_launch_us"] * 1e-6) / 1e9
+        k["frac"] = k["achieved"] / HBM_PEAK_GBS
+        k["share_of_pass"] = k["avg_launch_us"] * k["launches_per_pass"] / ((fwd_ms + bwd_ms) * 1e3)
+    dom = max(kernels, key=lambda k: k["share_of_pass"])
     traffic = None
     tfile = os.path.join(ROOT, "profiles", f"traffic_{a.workload}.json")
     if os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get("bwd_bytes_per_launch")
+        traffic = json.load(open(tfile)).get(dom["kernel"].split("<")[0])
 
     out = {
         "metric": "pi_block_rollout_fwd_bwd_steps_per_sec", "value": value, "unit": "steps/s",
@@ -192,13 +221,12 @@ def main():
                                f"T={T} forward+backward rollout per step, dense dL/dtraj",
                    "reaction": a.reaction,
                    "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (no collective)",
-                   "points": npts, "T": T},
-        "roofline": {"bound": "hbm", "kernel": "pi_bwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_us": bwd_launch_s * 1e6,
-                     "fwd_kernel": {"kernel": "pi_fwd_kernel", "algorithmic_bytes_per_launch": fwd_bytes,
-                                    "avg_launch_us": fwd_launch_s * 1e6,
-                                    "achieved": fwd_bytes / fwd_launch_s / 1e9}},
+                   "points": npts, "T": T, "time_steps_per_launch": K},
+        "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
+                     "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                     "avg_launch_us": dom["avg_launch_us"], "all_kernels": kernels},
+        "fwd_us_per_time_step": fwd_ms * 1e3 / T, "bwd_us_per_time_step": bwd_ms * 1e3 / T,
         "fwd_only_steps_per_sec": T / (fwd_ms * 1e-3),
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

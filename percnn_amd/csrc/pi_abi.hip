@@ -20,7 +20,8 @@ struct Options {
     int wgrad_blocks = 1024;
     int tile = 1;           // 2D: temporally blocked LDS kernels where the shape allows
     int tile_k = 4;         // sub-steps per launch (2 or 4)
-    int tile_nt = 256;      // workgroup size of the tile kernels (256 or 512)
+    int tile_nt = 512;      // workgroup size of the tile kernels (256 or 512)
+    int skip_wgrad = 0;     // diagnostics: rollout_bwd runs the adjoint sweep only (bench uses it to time the sweep alone)
     int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
                             // small grid is spread over all CUs instead of being packed onto a few
 };
@@ -437,6 +438,7 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     }
     // 2) branch-weight gradients of all t_top steps at once (time-parallel reduction)
     unsigned wrows = 0;
+    if (g_opt.skip_wgrad) return (int)finish_grads(w, rows, hc, param_grad, st);
     const bool vec_ok = (p.n % pi::vec_width<T>::value == 0) && g_opt.vec != 1 &&
                         (reinterpret_cast<uintptr_t>(traj) % 16 == 0);
     hipError_t e = vec_ok ? launch_wgrad<T, pi::vec_width<T>::value>(traj, adj, w.partials, P, p, 0, t_top, &wrows, st)
@@ -480,6 +482,7 @@ int percnn_pi_set_option(const char* key, long value)
         return 0;
     }
     if (!std::strcmp(key, "tile")) { g_opt.tile = value != 0; return 0; }
+    if (!std::strcmp(key, "skip_wgrad")) { g_opt.skip_wgrad = value != 0; return 0; }
     if (!std::strcmp(key, "lds_pad")) {
         if (value < 0 || value > 80 * 1024 || value % 16) return PERCNN_PI_EINVAL;
         g_opt.lds_pad = (int)value;

@@ -373,7 +373,7 @@ def test_tile_variants_bitwise(opts, dtype, hc, hip_device):
     gt = rs.uniform(-1, 1, (T + 1, 2) + shape).astype(dtype)
     ref = o_rollout_fwd(h0, P, T)
     g0_ref, pg_ref = o_rollout_bwd(ref, gt, P)
-    defaults = {"tile": 1, "tile_k": 4, "tile_nt": 256, "vec": 0}
+    defaults = {"tile": 1, "tile_k": 4, "tile_nt": 512, "vec": 0}
     try:
         for k, v in opts.items():
             pa.set_option(k, v)

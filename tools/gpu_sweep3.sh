@@ -3,7 +3,7 @@ run() { (timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --T 
 import sys,json
 l=sys.stdin.read().strip().splitlines()[-1]
 try:
-    d=json.loads(l); print('$*', '| fwd+bwd %.0f steps/s'%d['value'], '| fwd us/step %.2f'%d['roofline']['fwd_kernel']['avg_launch_us'], '| bwd us/step %.2f'%d['roofline']['avg_launch_us'])
+    d=json.loads(l); print('$*', '| fwd+bwd %.0f steps/s'%d['value'], '| fwd us/step %.2f'%d['fwd_us_per_time_step'], '| bwd us/step %.2f'%d['bwd_us_per_time_step'])
 except Exception as e: print('$*', 'ERR', l[-300:])
 "; }
 run --workload gs2d_512 --opt tile=0
