@@ -9,6 +9,7 @@
 #include "../../include/percnn_pi.h"
 #include "pi_kernels.h"
 #include "pi_tile2d.h"
+#include "pi_stream3d.h"
 
 namespace {
 
@@ -21,6 +22,8 @@ struct Options {
     int tile = 1;           // 2D: temporally blocked LDS kernels where the shape allows
     int tile_k = 4;         // sub-steps per launch (2 or 4)
     int tile_nt = 512;      // workgroup size of the tile kernels (256 or 512)
+    int stream3d = 1;       // 3D: plane-streaming kernels where the shape allows (W = 64*VEC)
+    int zc = 8;             // planes per workgroup of the streaming kernels
     int skip_wgrad = 0;     // diagnostics: rollout_bwd runs the adjoint sweep only (bench uses it to time the sweep alone)
     int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
                             // small grid is spread over all CUs instead of being packed onto a few
@@ -189,9 +192,77 @@ hipError_t launch_wgrad(const T* traj, const T* adj, double* partials, const T* 
         }                                                                   \
     } while (0)
 
+
+// ---- plane-streaming 3D path ---------------------------------------------------------------------
+constexpr int STREAM_TY = 4;
+
+// VEC such that one wave spans a full row (W == 64*VEC), 0 if the shape does not qualify
+template <typename T>
+int stream3d_vec(const Problem& p, std::initializer_list<const void*> ptrs)
+{
+    if (!g_opt.stream3d || p.ndim != 3) return 0;
+    // measured on MI355X: the plane-streaming kernels win from ~4M points per rank upwards (256^3: 4.1 vs
+    // 2.7 TB/s forward); at 128^3 there are too few waves to cover their per-plane barrier chain.
+    if (g_opt.stream3d == 1 && (p.n0 + (p.slab ? 2 * p.halo : 0)) * p.n1 * p.W < (int64_t)3 << 20) return 0;
+    if (p.hc != 0 && p.hc != 2 && p.hc != 4 && p.hc != 8) return 0;
+    if (p.n1 % STREAM_TY) return 0;
+    int vec = 0;
+    for (int v = pi::vec_width<T>::value; v >= 1; v /= 2)
+        if (p.W == (int64_t)pi::WAVE * v) { vec = v; break; }
+    if (!vec) return 0;
+    for (const void* q : ptrs)
+        if (q && (reinterpret_cast<uintptr_t>(q) % (vec * sizeof(T)))) return 0;
+    return vec;
+}
+
+inline int stream3d_zc(const Problem& p, const Geom& g, bool adj)
+{
+    int zc = adj ? 2 * g_opt.zc : g_opt.zc;               // the heavier adjoint body amortises its prologue over more planes
+    const long ytiles = p.n1 / STREAM_TY;
+    while ((long)((g.n0 + zc - 1) / zc) * ytiles > MAX_BWD_BLOCKS) zc *= 2;
+    return zc;
+}
+
+template <typename T, int HC, int VEC, bool ADJ>
+hipError_t launch_stream3d(const T* f, T* out, const T* h, const T* inj, double* partials, const T* P, const Problem& p,
+                           hipStream_t st, unsigned* rows_out)
+{
+    const Geom g = make_geom(p);
+    const int zc = stream3d_zc(p, g, ADJ);
+    const unsigned grid = (unsigned)(((g.n0 + zc - 1) / zc) * (p.n1 / STREAM_TY));
+    if (rows_out) *rows_out = grid;
+    if (g.n0 <= 0) return hipSuccess;
+    const size_t lds = (size_t)4 * pi::Strip<T, VEC, STREAM_TY>::PLANE * sizeof(T);
+    hipLaunchKernelGGL((pi::pi_stream3d_kernel<T, HC, VEC, STREAM_TY, ADJ>), dim3(grid), dim3(pi::WAVE * STREAM_TY), lds,
+                       st, f, out, h, inj, partials, P, g, zc, p.hc);
+    return hipGetLastError();
+}
+
+template <typename T, bool ADJ>
+hipError_t stream3d(int vec, const T* f, T* out, const T* h, const T* inj, double* partials, const T* P,
+                    const Problem& p, hipStream_t st, unsigned* rows_out)
+{
+#define CALL_S3(HC, VEC) launch_stream3d<T, HC, VEC, ADJ>(f, out, h, inj, partials, P, p, st, rows_out)
+#define S3_HC(VEC)                                                  \
+    switch (p.hc) {                                                 \
+        case 0:  return CALL_S3(pi::POLY, VEC);                     \
+        case 2:  return CALL_S3(2, VEC);                            \
+        case 4:  return CALL_S3(4, VEC);                            \
+        default: return CALL_S3(8, VEC);                            \
+    }
+    if (vec == 1) { S3_HC(1) }
+    if (vec == 2) { S3_HC(2) }
+    if constexpr (pi::vec_width<T>::value == 4) { S3_HC(4) }
+    return hipErrorInvalidValue;
+#undef S3_HC
+#undef CALL_S3
+}
+
 template <typename T>
 hipError_t step_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
 {
+    if (const int sv = stream3d_vec<T>(p, {h, out}))
+        return stream3d<T, false>(sv, h, out, nullptr, nullptr, nullptr, P, p, st, nullptr);
     const int vec = pick_vec<T>(p, {h, out});
 #define CALL_FWD(NDIM, HC, VEC) launch_fwd<T, NDIM, HC, VEC>(h, out, P, p, st)
     PI_DISPATCH(CALL_FWD);
@@ -205,6 +276,9 @@ template <typename T, bool WGRAD>
 hipError_t step_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partials, const T* P, const Problem& p,
                     hipStream_t st, unsigned* grid_out)
 {
+    if constexpr (!WGRAD)
+        if (const int sv = stream3d_vec<T>(p, {h, G, inj, Gp}))
+            return stream3d<T, true>(sv, G, Gp, h, inj, partials, P, p, st, grid_out);
     const int vec = pick_vec<T>(p, {h, G, inj, Gp});
     if (grid_out) *grid_out = bwd_grid(p, vec);
 #define CALL_BWD(NDIM, HC, VEC) launch_bwd<T, NDIM, HC, VEC, WGRAD>(h, G, inj, Gp, partials, P, p, st)
@@ -483,6 +557,16 @@ int percnn_pi_set_option(const char* key, long value)
     }
     if (!std::strcmp(key, "tile")) { g_opt.tile = value != 0; return 0; }
     if (!std::strcmp(key, "skip_wgrad")) { g_opt.skip_wgrad = value != 0; return 0; }
+    if (!std::strcmp(key, "stream3d")) {                         // 0 = never, 1 = size heuristic, 2 = whenever eligible
+        if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
+        g_opt.stream3d = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "zc")) {
+        if (value < 1 || value > 1024) return PERCNN_PI_EINVAL;
+        g_opt.zc = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "lds_pad")) {
         if (value < 0 || value > 80 * 1024 || value % 16) return PERCNN_PI_EINVAL;
         g_opt.lds_pad = (int)value;

@@ -69,6 +69,11 @@ __device__ __forceinline__ void poly_dr(const T* __restrict__ c, T u, T v, T& ru
     rv = fma_(u, fma_(u, c[7], B1), B0);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc drain the vector-memory
+// counter (s_waitcnt vmcnt(0)) first, which would serialise every software-prefetched global load and
+// every in-flight trajectory store behind the barrier; LDS visibility needs lgkmcnt(0) alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ int wrap(int i, int n) { i %= n; return i < 0 ? i + n : i; }
 
 // XCD-aware block remap: hand each XCD (private 4 MiB L2) a contiguous range of the grid so the

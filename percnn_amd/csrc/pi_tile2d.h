@@ -158,7 +158,7 @@ __device__ __forceinline__ void fwd_substeps(T* b0, T* b1, T* __restrict__ frame
     T* cur = (M & 1) ? b1 : b0;
     T* nxt = (M & 1) ? b0 : b1;
     fwd_substep<T, HC, K, BX, BY, NT, M>(cur, nxt, P);
-    __syncthreads();
+    lds_barrier();                                         // do not drain the previous frame's global stores
     tile_store<T, K, BX, BY, NT>(nxt, frames + (long)(M + 1) * frame_stride, g, ty0, tx0);
     if constexpr (M + 1 < K) fwd_substeps<T, HC, K, BX, BY, NT, M + 1>(b0, b1, frames, frame_stride, g, ty0, tx0, P);
 }
@@ -286,7 +286,7 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
     const long fo = -(long)(M + 1) * frame_stride;         // frame t-1-M relative to frame t
     adj_substep<T, HC, K, BX, BY, NT, M>(cur, nxt, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g, ty0,
                                          tx0, P, acc_c);
-    __syncthreads();
+    lds_barrier();
     // the adjoint of frame 0 is the caller's dL/dh0 output
     T* dst = (M + 1 == steps_to_zero && g_h0) ? g_h0 : abase + fo;
     tile_store<T, K, BX, BY, NT>(nxt, dst, g, ty0, tx0);

@@ -193,7 +193,7 @@ def test_cell_forward_signature(hip_device):
 # ---------------------------------------------------------------------------------------------
 # slab layout (one rank of the domain decomposition) against the periodic single-domain step
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(16, 32), (12, 8, 16)])
+@pytest.mark.parametrize("shape", [(16, 32), (12, 8, 16), (12, 8, 64)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("halo", [2, 4])
 @pytest.mark.parametrize("hc", [4, 0])
@@ -206,6 +206,7 @@ def test_slab_step_equals_periodic_step(shape, dtype, halo, hc, hip_device):
     P = dev_t(random_block(hc, ndim, npd, 11), hip_device)
     h = torch.rand((2,) + shape, dtype=dtype, device=hip_device)
     G = torch.rand((2,) + shape, dtype=dtype, device=hip_device)
+    pa.set_option("stream3d", 2)                 # small shapes: force the streaming kernels where eligible
     k = halo // 2
     full = [h]
     for _ in range(k):
@@ -224,6 +225,7 @@ def test_slab_step_equals_periodic_step(shape, dtype, halo, hc, hip_device):
         gi, pg = pa.step_bwd(h[:, idx].contiguous(), G[:, idx].contiguous(), P, slab=True, halo=halo)
         assert torch.equal(gi[:, halo:-halo], gfull[:, lo:hi])
         pgsum += pg
+    pa.set_option("stream3d", 1)
     assert torch.allclose(pgsum, pgfull, rtol=1e-5 if dtype == torch.float32 else 1e-12, atol=1e-9)
 
 
@@ -249,7 +251,8 @@ def test_slab_rollout_single_rank_equals_rollout(fam, halo, hip_device):
     inner = trajs[:, :, halo:halo + n0]
     assert torch.equal(inner, traj.detach())
     (inner * gt).sum().backward()
-    tol = 2e-5 if g.dtype == np.float32 else 1e-11
+    # two different fp32 reduction orders (per-step fused kernel vs sweep + time-parallel reduction)
+    tol = 1e-4 if g.dtype == np.float32 else 1e-11
     for n, p in cell.named_parameters():
         if p.grad is not None:
             assert rel_l2(p.grad.cpu().numpy(), ref_grads[n].cpu().numpy()) < tol, n
@@ -389,6 +392,45 @@ def test_tile_variants_bitwise(opts, dtype, hc, hip_device):
             g0, pg = pa.rollout_bwd(traj, dev_t(g, hip_device), dev_t(P, hip_device), frame_mask=mask)
             assert np.array_equal(g0.cpu().numpy(), g0_ref)
             assert rel_l2(pg.cpu().numpy(), pg_ref) < (2e-5 if dtype == np.float32 else 1e-12)
+    finally:
+        for k, v in defaults.items():
+            pa.set_option(k, v)
+
+
+# ---------------------------------------------------------------------------------------------
+# plane-streaming 3D kernels (W = 64*VEC): bit-identical to the oracle for every chunking
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("opts", [{"stream3d": 0}, {"stream3d": 2, "zc": 1}, {"stream3d": 2, "zc": 3}, {"stream3d": 2, "zc": 8},
+                                  {"stream3d": 2, "zc": 64}])
+@pytest.mark.parametrize("shape,dtype", [((6, 8, 64), np.float32), ((5, 4, 128), np.float32), ((9, 12, 256), np.float32),
+                                         ((6, 8, 64), np.float64), ((7, 4, 128), np.float64)])
+@pytest.mark.parametrize("hc", [0, 2, 8])
+def test_stream3d_bitwise(opts, shape, dtype, hc, hip_device):
+    import percnn_amd as pa
+    T = 3
+    rs = np.random.RandomState(17)
+    P = random_block(hc, 3, dtype, 19, scale=0.3)
+    h0 = rs.uniform(0, 1, (2,) + shape).astype(dtype)
+    gt = rs.uniform(-1, 1, (T + 1, 2) + shape).astype(dtype)
+    ref = o_rollout_fwd(h0, P, T)
+    g0_ref, pg_ref = o_rollout_bwd(ref, gt, P)
+    defaults = {"stream3d": 1, "zc": 8}
+    try:
+        for k, v in opts.items():
+            pa.set_option(k, v)
+        traj = torch.empty((T + 1, 2) + shape, dtype=torch.from_numpy(h0).dtype, device=hip_device)
+        traj[0] = dev_t(h0, hip_device)
+        pa.rollout_fwd_(traj, dev_t(P, hip_device))
+        assert np.array_equal(traj.cpu().numpy(), ref)
+        g0, pg = pa.rollout_bwd(traj, dev_t(gt, hip_device), dev_t(P, hip_device))
+        assert np.array_equal(g0.cpu().numpy(), g0_ref)
+        assert rel_l2(pg.cpu().numpy(), pg_ref) < (2e-5 if dtype == np.float32 else 1e-12)
+        # no injection on some frames
+        mask = [True, False, True, False]
+        g = gt.copy(); g[1] = 0; g[3] = 0
+        g0m_ref, _ = o_rollout_bwd(ref, g, P)
+        g0m, _ = pa.rollout_bwd(traj, dev_t(g, hip_device), dev_t(P, hip_device), frame_mask=mask)
+        assert np.array_equal(g0m.cpu().numpy(), g0m_ref)
     finally:
         for k, v in defaults.items():
             pa.set_option(k, v)
