@@ -123,7 +123,8 @@ hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* parti
     const Geom g = make_geom(p);
     const int block = g_opt.block;
     const unsigned grid = bwd_grid(p, VEC);
-    const size_t lds = (size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T) + (size_t)g_opt.lds_pad;
+    const size_t lds = align_up((size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T), 16) +
+                       (size_t)(block / pi::WAVE) * 2 * sizeof(double) + (size_t)g_opt.lds_pad;
     auto* k = pi::pi_bwd_kernel<T, NDIM, HC, VEC, WGRAD>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, st, h, G, inj, Gp, partials, P, g, p.hc);
@@ -332,8 +333,12 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
 #define PI_TILE_VARIANTS(CALL, HC)                                              \
     do {                                                                        \
         if (g_opt.tile_k == 2) return CALL(HC, 2, 256);                         \
-        if (g_opt.tile_nt == 512) return CALL(HC, 4, 512);                      \
-        return CALL(HC, 4, 256);                                                \
+        if constexpr (HC == pi::POLY) {                                         \
+            if (g_opt.tile_k == 8) return CALL(HC, 8, 1024);                    \
+            if (g_opt.tile_nt == 1024) return CALL(HC, 4, 1024);                \
+        }                                                                       \
+        if (g_opt.tile_nt == 256) return CALL(HC, 4, 256);                      \
+        return CALL(HC, 4, 512);                                                \
     } while (0)
 #define PI_TILE_DISPATCH(CALL)                                                  \
     do {                                                                        \
@@ -442,7 +447,7 @@ int rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* shape
     const size_t frame = (size_t)2 * p.n;
     int t = 0;
     if (tile_eligible<T>(p, {traj})) {
-        const int K = g_opt.tile_k;
+        const int K = (g_opt.tile_k == 8 && p.hc != 0) ? 4 : g_opt.tile_k;
         for (; t + K <= T_steps; t += K)
             if (hipError_t e = fwd_tile<T>(traj + (size_t)t * frame, P, p, st)) return (int)e;
     }
@@ -491,7 +496,7 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     unsigned rows = 0;
     int t_cur = t_top;
     if (tile_eligible<T>(p, {traj, g_traj, g_h0, adj})) {
-        const int K = g_opt.tile_k;
+        const int K = (g_opt.tile_k == 8 && p.hc != 0) ? 4 : g_opt.tile_k;
         rows = (unsigned)((p.n0 / TILE_B) * (p.W / TILE_B));
         for (; t_cur - K >= 0; t_cur -= K) {
             unsigned m = 0;
@@ -525,6 +530,13 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
 
 // ---- exported symbols ---------------------------------------------------------------------------
 extern "C" {
+
+#ifdef PI_TILE_TIMING
+int percnn_pi_debug_stamps(long long* host_out, int n)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pi::pi_tile_stamps), (size_t)n * sizeof(long long));
+}
+#endif
 
 int percnn_pi_abi_version(void) { return PERCNN_PI_ABI_VERSION; }
 
@@ -573,12 +585,12 @@ int percnn_pi_set_option(const char* key, long value)
         return 0;
     }
     if (!std::strcmp(key, "tile_k")) {
-        if (value != 2 && value != 4) return PERCNN_PI_EINVAL;
+        if (value != 2 && value != 4 && value != 8) return PERCNN_PI_EINVAL;   // 8: poly mode only (else 4)
         g_opt.tile_k = (int)value;
         return 0;
     }
     if (!std::strcmp(key, "tile_nt")) {
-        if (value != 256 && value != 512) return PERCNN_PI_EINVAL;
+        if (value != 256 && value != 512 && value != 1024) return PERCNN_PI_EINVAL;   // 1024: poly mode only
         g_opt.tile_nt = (int)value;
         return 0;
     }

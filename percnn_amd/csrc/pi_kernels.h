@@ -181,7 +181,9 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
     const int nwaves = blockDim.x / WAVE;
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
     T* myred = red + wave * np;
+    double* redc = reinterpret_cast<double*>(smem_raw + ((size_t)nwaves * np * sizeof(T) + 15) / 16 * 16);   // [nwaves][2]
     for (int i = threadIdx.x; i < nwaves * np; i += blockDim.x) red[i] = T(0);
+    if (threadIdx.x < 2 * nwaves) redc[threadIdx.x] = 0.0;
     __syncthreads();
 
     const int cpr = g.W / VEC;
@@ -225,14 +227,14 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
                 const T* c = P + P_W + 10 * s;
                 const int gbase = P_W + 10 * s;
                 const Pack<T, VEC>& hs = s == 0 ? u : v;
-                T acc_c = T(0);
+                double acc_c = 0.0;                      // heavily cancelling sum (stencil row-sum ~ 0): keep it in fp64
                 T acc[10];
 #pragma unroll
                 for (int m = 0; m < 10; ++m) acc[m] = T(0);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     const T gr = gc[s].v[i] * dt;
-                    acc_c += dl[s][i] * hs.v[i];
+                    acc_c += (double)(dl[s][i] * hs.v[i]);
                     T ru, rv;
                     poly_dr(c, u.v[i], v.v[i], ru, rv);
                     du[i] = fma_(gr, ru, du[i]);
@@ -248,7 +250,7 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
                     }
                 }
                 acc_c = wave_sum_to_last(acc_c);
-                if (lane == REDUCE_LANE) myred[P_COEF + s] += acc_c;
+                if (lane == REDUCE_LANE) redc[wave * 2 + s] += acc_c;
                 if constexpr (WGRAD) {
 #pragma unroll
                     for (int m = 0; m < 10; ++m) acc[m] = wave_sum_to_last(acc[m]);
@@ -265,17 +267,18 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
             const int gbase = P_W + s * species_block(hc);
             const Pack<T, VEC>& hs = s == 0 ? u : v;
             T gr[VEC];
-            T acc_c = T(0), acc_b4 = T(0);
+            double acc_c = 0.0;                          // heavily cancelling sum: fp64
+            T acc_b4 = T(0);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 gr[i] = gc[s].v[i] * dt;
-                acc_c += dl[s][i] * hs.v[i];
+                acc_c += (double)(dl[s][i] * hs.v[i]);
                 acc_b4 += gr[i];
             }
             acc_c = wave_sum_to_last(acc_c);
             if constexpr (WGRAD) acc_b4 = wave_sum_to_last(acc_b4);
             if (lane == REDUCE_LANE) {
-                myred[P_COEF + s] += acc_c;
+                redc[wave * 2 + s] += acc_c;
                 if constexpr (WGRAD) myred[gbase + 10 * hc] += acc_b4;
             }
 #pragma unroll
@@ -339,9 +342,12 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
     for (int idx = threadIdx.x; idx < np; idx += blockDim.x) {
         if (idx == P_DT || (idx >= P_C0 && idx < P_W)) continue;   // dt and the frozen stencil carry no gradient
         if (!WGRAD && idx >= P_W) break;                           // sweep-only flavour: coefficients only
-        T s = T(0);
-        for (int w = 0; w < nwaves; ++w) s += red[w * np + idx];
-        partials[(long)blockIdx.x * np + idx] += (double)s;
+        double s = 0.0;
+        if (idx == P_COEF || idx == P_COEF + 1)
+            for (int w = 0; w < nwaves; ++w) s += redc[w * 2 + idx - P_COEF];
+        else
+            for (int w = 0; w < nwaves; ++w) s += (double)red[w * np + idx];
+        partials[(long)blockIdx.x * np + idx] += s;
     }
 }
 

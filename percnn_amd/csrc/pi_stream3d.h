@@ -75,7 +75,7 @@ struct Stream3D {
     Pack<T, VEC> q[2][R];
     Pack<T, VEC> hp[2][RH];
     Pack<T, VEC> ph[2][ADJ ? RH : 1], pj[2][ADJ ? RH : 1];
-    T acc_c[2];
+    double acc_c[2];        // heavily cancelling sums: fp64
     // uniform state
     const T* f; T* out; const T* h; const T* inj; const T* P; T* lds;
     Geom g; int hc, wy, x0, y, hy, hrow, z1;
@@ -193,8 +193,8 @@ struct Stream3D {
                 du[i] = dv[i] = T(0);
                 dl[0][i] = lap[0][i] * dt;
                 dl[1][i] = lap[1][i] * dt;
-                acc_c[0] += dl[0][i] * hu.v[i];
-                acc_c[1] += dl[1][i] * hv.v[i];
+                acc_c[0] += (double)(dl[0][i] * hu.v[i]);
+                acc_c[1] += (double)(dl[1][i] * hv.v[i]);
             }
 #pragma clang loop unroll(disable)
             for (int s = 0; s < 2; ++s) {
@@ -289,7 +289,7 @@ pi_stream3d_kernel(const T* __restrict__ f,        // stencil-read field: state 
     k.hrow = k.wy < 2 ? k.wy : TY + k.wy;
     k.rowoff = (long)k.y * S::W + k.x0;
     k.hrowoff = (long)k.hy * S::W + k.x0;
-    k.acc_c[0] = k.acc_c[1] = T(0);
+    k.acc_c[0] = k.acc_c[1] = 0.0;
 
     // prologue: planes z0-2 .. z0+5 -> slots 0..7; halo rows / operands of planes z0 .. z0+3 -> slots 0..3
     int zz = g.wrap0 ? wrap(z0 - 2, g.n0) : z0 - 2;
@@ -321,16 +321,17 @@ pi_stream3d_kernel(const T* __restrict__ f,        // stencil-read field: state 
     if constexpr (ADJ) {
         // diffusion-coefficient gradients of this strip over its planes: one reduction per launch
         __syncthreads();
+        double* red = reinterpret_cast<double*>(k.lds);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const T r = wave_sum_to_last(k.acc_c[s]);
-            if (lane == REDUCE_LANE) k.lds[k.wy * 2 + s] = r;
+            const double r = wave_sum_to_last(k.acc_c[s]);
+            if (lane == REDUCE_LANE) red[k.wy * 2 + s] = r;
         }
         __syncthreads();
         if (threadIdx.x < 2) {
-            T sum = T(0);
-            for (int w = 0; w < TY; ++w) sum += k.lds[w * 2 + threadIdx.x];
-            partials[(long)blockIdx.x * nparams(HC == POLY ? 0 : k.hc) + P_COEF + threadIdx.x] += (double)sum;
+            double sum = 0.0;
+            for (int w = 0; w < TY; ++w) sum += red[w * 2 + threadIdx.x];
+            partials[(long)blockIdx.x * nparams(HC == POLY ? 0 : k.hc) + P_COEF + threadIdx.x] += sum;
         }
     }
 }

@@ -241,7 +241,8 @@ def test_slab_rollout_single_rank_equals_rollout(fam, halo, hip_device):
     h0 = dev_t(g.h0, hip_device)
     P = cell.param_block()
     traj = pa.pi_rollout(h0, P, T)
-    gt = torch.randn_like(traj)
+    gt = torch.randn(traj.shape, dtype=traj.dtype, device=traj.device,
+                     generator=torch.Generator(device=hip_device).manual_seed(5))
     (traj * gt).sum().backward()
     ref_grads = {n: p.grad.clone() for n, p in cell.named_parameters() if p.grad is not None}
     cell.zero_grad()
@@ -251,8 +252,9 @@ def test_slab_rollout_single_rank_equals_rollout(fam, halo, hip_device):
     inner = trajs[:, :, halo:halo + n0]
     assert torch.equal(inner, traj.detach())
     (inner * gt).sum().backward()
-    # two different fp32 reduction orders (per-step fused kernel vs sweep + time-parallel reduction)
-    tol = 1e-4 if g.dtype == np.float32 else 1e-11
+    # two different fp32 reduction orders (per-step fused kernel vs sweep + time-parallel reduction); for a
+    # random dL/dtraj the diffusion-coefficient gradient is a heavily cancelling sum, hence the loose bound
+    tol = 5e-4 if g.dtype == np.float32 else 1e-11
     for n, p in cell.named_parameters():
         if p.grad is not None:
             assert rel_l2(p.grad.cpu().numpy(), ref_grads[n].cpu().numpy()) < tol, n
@@ -364,12 +366,12 @@ def test_rccl_halo_exchange_to_self(hip_device):
 # temporally blocked 2D kernels: every variant must stay bit-identical to the oracle
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opts", [{"tile": 0}, {"tile_k": 2}, {"tile_k": 4, "tile_nt": 256},
-                                  {"tile_k": 4, "tile_nt": 512}, {"vec": 1}])
+                                  {"tile_k": 4, "tile_nt": 512}, {"tile_k": 4, "tile_nt": 1024}, {"tile_k": 8}, {"vec": 1}])
 @pytest.mark.parametrize("dtype,hc", [(np.float32, 8), (np.float32, 2), (np.float64, 4), (np.float32, 0),
                                       (np.float64, 0)])
 def test_tile_variants_bitwise(opts, dtype, hc, hip_device):
     import percnn_amd as pa
-    shape, T = (64, 96), 11                      # non-square multiple of the 32x32 tile; T not a multiple of K
+    shape, T = (64, 96), 19                      # non-square multiple of the 32x32 tile; T not a multiple of K
     rs = np.random.RandomState(9)
     P = random_block(hc, 2, dtype, 13, scale=0.3)
     h0 = rs.uniform(0, 1, (2,) + shape).astype(dtype)

@@ -1,0 +1,29 @@
+"""Debug aid: per-phase device timestamps of pi_fwd2d_tile_kernel (needs the -DPI_TILE_TIMING build)."""
+import ctypes, os, sys
+os.environ["PERCNN_PI_LIB"] = os.path.join(os.path.dirname(__file__), "..", "percnn_amd", "csrc", "libpercnn_pi_dbg.so")
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np, torch
+import percnn_amd as pa
+from bench import load_params, make_cell
+dev = torch.device("cuda:0")
+for reaction in ("poly", "factored"):
+    cell = make_cell("gs2d", load_params("gs2d_big_512x512.npz"), dev, reaction)
+    with torch.no_grad():
+        P = cell.param_block().contiguous()
+    traj = torch.rand((41, 2, 512, 512), device=dev) * 0.1 + 0.5
+    for nt in (512, 256):
+        pa.set_option("tile_nt", nt)
+        for _ in range(3):
+            pa.rollout_fwd_(traj, P)
+        torch.cuda.synchronize()
+        L = pa.lib()
+        buf = (ctypes.c_longlong * (256 * 16))()
+        L.percnn_pi_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        assert L.percnn_pi_debug_stamps(buf, 256 * 16) == 0
+        st = np.array(buf, dtype=np.int64).reshape(256, 16)
+        t0 = st[:, 0].min()
+        rel = (st - t0) / 100.0            # wall_clock64: 100 MHz constant clock -> 10 ns ticks -> us/100
+        names = ["start", "loaded", "c0", "s0", "c1", "s1", "c2", "s2", "c3", "s3"] + ["-"] * 5 + ["end"]
+        print(f"{reaction} NT={nt}: last launch, us since first block start (median over 256 blocks | max)")
+        for i in [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15]:
+            print(f"   {names[i]:7s} median {np.median(rel[:, i]):7.2f}  min {rel[:, i].min():7.2f}  max {rel[:, i].max():7.2f}")
