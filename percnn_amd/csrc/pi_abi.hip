@@ -24,7 +24,10 @@ struct Options {
     int tile_nt = 512;      // workgroup size of the tile kernels (256 or 512)
     int stream3d = 1;       // 3D: plane-streaming kernels where the shape allows (W = 64*VEC)
     int zc = 8;             // planes per workgroup of the streaming kernels
+    int fuse_wgrad = 0;     // rollout sweep uses the fused per-step kernel (all gradients reduced every step) instead of
+                            // sweep + one time-parallel reduction (experiment: saves the reduction pass, costs per-step reductions)
     int skip_wgrad = 0;     // diagnostics: rollout_bwd runs the adjoint sweep only (bench uses it to time the sweep alone)
+    int tile_by = 32;       // tile height of the 2D tile kernels (32, or 16 = twice the workgroups: 2 per CU at 512^2)
     int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
                             // small grid is spread over all CUs instead of being packed onto a few
 };
@@ -302,28 +305,28 @@ bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs)
     return true;
 }
 
-template <typename T, int HC, int K, int NT>
+template <typename T, int HC, int K, int NT, int BY = TILE_B>
 hipError_t launch_fwd_tile(T* frame_t, const T* P, const Problem& p, hipStream_t st)
 {
-    using TL = pi::Tile<K, TILE_B, TILE_B>;
+    using TL = pi::Tile<K, TILE_B, BY>;
     pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, (int)(p.W / TILE_B)};
-    const unsigned grid = (unsigned)((p.n0 / TILE_B) * (p.W / TILE_B));
+    const unsigned grid = (unsigned)((p.n0 / BY) * (p.W / TILE_B));
     const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + (size_t)g_opt.lds_pad;
-    auto* k = pi::pi_fwd2d_tile_kernel<T, HC, K, TILE_B, TILE_B, NT>;
+    auto* k = pi::pi_fwd2d_tile_kernel<T, HC, K, TILE_B, BY, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, frame_t, (long)(2 * p.n), P, g);
     return hipGetLastError();
 }
 
-template <typename T, int HC, int K, int NT>
+template <typename T, int HC, int K, int NT, int BY = TILE_B>
 hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, unsigned inj_mask, T* g_h0,
                            int steps_to_zero, double* partials, const T* P, const Problem& p, hipStream_t st)
 {
-    using TL = pi::Tile<K, TILE_B, TILE_B>;
+    using TL = pi::Tile<K, TILE_B, BY>;
     pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, (int)(p.W / TILE_B)};
-    const unsigned grid = (unsigned)((p.n0 / TILE_B) * (p.W / TILE_B));
+    const unsigned grid = (unsigned)((p.n0 / BY) * (p.W / TILE_B));
     const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + (size_t)g_opt.lds_pad;
-    auto* k = pi::pi_adj2d_tile_kernel<T, HC, K, TILE_B, TILE_B, NT>;
+    auto* k = pi::pi_adj2d_tile_kernel<T, HC, K, TILE_B, BY, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, hframe_t, gframe_t, aframe_t, (long)(2 * p.n), inj_mask, g_h0,
                        steps_to_zero, partials, pi::nparams(p.hc), P, g);
@@ -336,6 +339,7 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
         if constexpr (HC == pi::POLY) {                                         \
             if (g_opt.tile_k == 8) return CALL(HC, 8, 1024);                    \
             if (g_opt.tile_nt == 1024) return CALL(HC, 4, 1024);                \
+            if (g_opt.tile_by == 16) return CALL(HC, 4, 320, 16);               \
         }                                                                       \
         if (g_opt.tile_nt == 256) return CALL(HC, 4, 256);                      \
         return CALL(HC, 4, 512);                                                \
@@ -353,7 +357,7 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
 template <typename T>
 hipError_t fwd_tile(T* frame_t, const T* P, const Problem& p, hipStream_t st)
 {
-#define CALL_FT(HC, K, NT) launch_fwd_tile<T, HC, K, NT>(frame_t, P, p, st)
+#define CALL_FT(HC, K, NT, ...) launch_fwd_tile<T, HC, K, NT, ##__VA_ARGS__>(frame_t, P, p, st)
     PI_TILE_DISPATCH(CALL_FT);
 #undef CALL_FT
 }
@@ -362,8 +366,8 @@ template <typename T>
 hipError_t adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, unsigned inj_mask, T* g_h0, int steps_to_zero,
                     double* partials, const T* P, const Problem& p, hipStream_t st)
 {
-#define CALL_AT(HC, K, NT) \
-    launch_adj_tile<T, HC, K, NT>(hframe_t, gframe_t, aframe_t, inj_mask, g_h0, steps_to_zero, partials, P, p, st)
+#define CALL_AT(HC, K, NT, ...) \
+    launch_adj_tile<T, HC, K, NT, ##__VA_ARGS__>(hframe_t, gframe_t, aframe_t, inj_mask, g_h0, steps_to_zero, partials, P, p, st)
     PI_TILE_DISPATCH(CALL_AT);
 #undef CALL_AT
 }
@@ -497,7 +501,7 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     int t_cur = t_top;
     if (tile_eligible<T>(p, {traj, g_traj, g_h0, adj})) {
         const int K = (g_opt.tile_k == 8 && p.hc != 0) ? 4 : g_opt.tile_k;
-        rows = (unsigned)((p.n0 / TILE_B) * (p.W / TILE_B));
+        rows = (unsigned)((p.n0 / (p.hc == 0 ? g_opt.tile_by : TILE_B)) * (p.W / TILE_B));
         for (; t_cur - K >= 0; t_cur -= K) {
             unsigned m = 0;
             for (int q = 0; q < K; ++q) if (has(t_cur - 1 - q)) m |= 1u << q;
@@ -510,14 +514,15 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
         T* dst = (t == 1) ? g_h0 : adj + (size_t)(t - 1) * frame;
         const T* inj = has(t - 1) ? g_traj + (size_t)(t - 1) * frame : nullptr;
         unsigned r2 = 0;
-        if (hipError_t e = step_bwd<T, false>(traj + (size_t)(t - 1) * frame, adj + (size_t)t * frame, inj, dst,
-                                              w.partials, P, p, st, &r2))
-            return (int)e;
+        hipError_t e = g_opt.fuse_wgrad
+            ? step_bwd<T, true>(traj + (size_t)(t - 1) * frame, adj + (size_t)t * frame, inj, dst, w.partials, P, p, st, &r2)
+            : step_bwd<T, false>(traj + (size_t)(t - 1) * frame, adj + (size_t)t * frame, inj, dst, w.partials, P, p, st, &r2);
+        if (e) return (int)e;
         if (r2 > rows) rows = r2;
     }
     // 2) branch-weight gradients of all t_top steps at once (time-parallel reduction)
     unsigned wrows = 0;
-    if (g_opt.skip_wgrad) return (int)finish_grads(w, rows, hc, param_grad, st);
+    if (g_opt.skip_wgrad || (g_opt.fuse_wgrad && t_cur == t_top)) return (int)finish_grads(w, rows, hc, param_grad, st);
     const bool vec_ok = (p.n % pi::vec_width<T>::value == 0) && g_opt.vec != 1 &&
                         (reinterpret_cast<uintptr_t>(traj) % 16 == 0);
     hipError_t e = vec_ok ? launch_wgrad<T, pi::vec_width<T>::value>(traj, adj, w.partials, P, p, 0, t_top, &wrows, st)
@@ -568,7 +573,13 @@ int percnn_pi_set_option(const char* key, long value)
         return 0;
     }
     if (!std::strcmp(key, "tile")) { g_opt.tile = value != 0; return 0; }
+    if (!std::strcmp(key, "tile_by")) {
+        if (value != 16 && value != 32) return PERCNN_PI_EINVAL;
+        g_opt.tile_by = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "skip_wgrad")) { g_opt.skip_wgrad = value != 0; return 0; }
+    if (!std::strcmp(key, "fuse_wgrad")) { g_opt.fuse_wgrad = value != 0; return 0; }
     if (!std::strcmp(key, "stream3d")) {                         // 0 = never, 1 = size heuristic, 2 = whenever eligible
         if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
         g_opt.stream3d = (int)value;

@@ -366,7 +366,7 @@ def test_rccl_halo_exchange_to_self(hip_device):
 # temporally blocked 2D kernels: every variant must stay bit-identical to the oracle
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opts", [{"tile": 0}, {"tile_k": 2}, {"tile_k": 4, "tile_nt": 256},
-                                  {"tile_k": 4, "tile_nt": 512}, {"tile_k": 4, "tile_nt": 1024}, {"tile_k": 8}, {"vec": 1}])
+                                  {"tile_k": 4, "tile_nt": 512}, {"tile_k": 4, "tile_nt": 1024}, {"tile_k": 8}, {"tile_by": 16}, {"vec": 1}])
 @pytest.mark.parametrize("dtype,hc", [(np.float32, 8), (np.float32, 2), (np.float64, 4), (np.float32, 0),
                                       (np.float64, 0)])
 def test_tile_variants_bitwise(opts, dtype, hc, hip_device):
@@ -378,7 +378,7 @@ def test_tile_variants_bitwise(opts, dtype, hc, hip_device):
     gt = rs.uniform(-1, 1, (T + 1, 2) + shape).astype(dtype)
     ref = o_rollout_fwd(h0, P, T)
     g0_ref, pg_ref = o_rollout_bwd(ref, gt, P)
-    defaults = {"tile": 1, "tile_k": 4, "tile_nt": 512, "vec": 0}
+    defaults = {"tile": 1, "tile_k": 4, "tile_nt": 512, "tile_by": 32, "vec": 0}
     try:
         for k, v in opts.items():
             pa.set_option(k, v)
@@ -436,3 +436,91 @@ def test_stream3d_bitwise(opts, shape, dtype, hc, hip_device):
     finally:
         for k, v in defaults.items():
             pa.set_option(k, v)
+
+
+# ---------------------------------------------------------------------------------------------
+# configs[4] at full size on ONE GPU: 256^3 cut into 8 slabs of 32 planes ("virtual ranks"), halos
+# copied between neighbours exactly as the ring exchange does, wide halo (2 steps per exchange).
+# ---------------------------------------------------------------------------------------------
+def test_256cubed_eight_virtual_slabs_equal_single_domain(hip_device):
+    import percnn_amd as pa
+    from percnn_amd import slab, synthetic
+    shape, world, halo, T = (256, 256, 256), 8, 4, 4
+    z = np.load(os.path.join(GOLDEN, "gs3d_big_128x128x128.npz"))
+    cell = pa.gs3d_cell()
+    cell.load_state_dict({k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")})
+    cell.to(hip_device)
+    with torch.no_grad():
+        P = cell.param_block().contiguous()
+    h0 = synthetic.gs_initial_state(shape, seed=0)[0].to(hip_device)
+    ref = torch.empty((T + 1, 2) + shape, device=hip_device)
+    ref[0] = h0
+    pa.rollout_fwd_(ref, P)
+    slabs = [slab.scatter_slab(h0, r, world, halo) for r in range(world)]
+    n = shape[0] // world
+
+    def exchange(fr, width):
+        for r in range(world):
+            lo, hi = fr[(r - 1) % world], fr[(r + 1) % world]
+            fr[r][:, halo - width:halo] = lo[:, halo + n - width:halo + n]
+            fr[r][:, halo + n:halo + n + width] = hi[:, halo:halo + width]
+
+    cur = slabs
+    for t in range(T):
+        m = t % (halo // 2)
+        if m == 0:
+            exchange(cur, halo)
+        nxt = [torch.zeros_like(c) for c in cur]
+        for r in range(world):
+            pa.step_fwd(cur[r], P, out=nxt[r], slab=True, halo=halo, skip=2 * m)
+        cur = nxt
+        for r in range(world):
+            assert torch.equal(cur[r][:, halo:halo + n], ref[t + 1][:, r * n:(r + 1) * n]), (t, r)
+    # adjoint: one step over the 8 slabs == the single-domain adjoint step
+    G = torch.randn((2,) + shape, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(3))
+    gfull, pgfull = pa.step_bwd(ref[T - 1], G, P)
+    Gs = [slab.scatter_slab(G, r, world, halo) for r in range(world)]
+    hs = [slab.scatter_slab(ref[T - 1], r, world, halo) for r in range(world)]
+    exchange(Gs, 2)
+    pgsum = torch.zeros_like(pgfull)
+    for r in range(world):
+        gi, pg = pa.step_bwd(hs[r], Gs[r], P, slab=True, halo=halo)
+        assert torch.equal(gi[:, halo:halo + n], gfull[:, r * n:(r + 1) * n])
+        pgsum += pg
+    assert rel_l2(pgsum.cpu().numpy(), pgfull.cpu().numpy()) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases of the host interface
+# ---------------------------------------------------------------------------------------------
+def test_edge_cases(hip_device):
+    import percnn_amd as pa
+    g = Golden(os.path.join(GOLDEN, "gs2d_ckpt_32x32.npz"))
+    for reaction in ("poly", "factored"):
+        cell = g.product_cell(hip_device, reaction)
+        h0 = dev_t(g.h0, hip_device).requires_grad_(True)
+        # T = 0: the trajectory is just the initial state and gradients pass straight through
+        traj = pa.pi_rollout(h0, cell.param_block(), 0)
+        assert traj.shape[0] == 1 and torch.equal(traj[0], h0[0].detach())
+        (traj * 3.0).sum().backward()
+        assert torch.equal(h0.grad, torch.full_like(h0, 3.0))
+        # T = 1 through RCNN: second_last_state is [] like the reference (train_2drd.py:182: never reached)
+        outs, sl = pa.RCNN(cell, step=1, effective_step=[0], init_state=h0.detach())()
+        assert len(outs) == 2 and sl == []
+        # non-contiguous initial state and parameter-free call are accepted
+        hnc = dev_t(np.ascontiguousarray(g.h0.transpose(0, 1, 3, 2)), hip_device).transpose(2, 3)
+        assert not hnc.is_contiguous()
+        a = pa.pi_rollout(hnc, cell.param_block().detach(), 3)
+        b = pa.pi_rollout(hnc.contiguous(), cell.param_block().detach(), 3)
+        assert torch.equal(a, b)
+    # wrong state shapes / dtypes fail loudly
+    with pytest.raises(RuntimeError):
+        pa.pi_step(torch.zeros(2, 2, 8, 8, device=hip_device), cell.param_block())
+    with pytest.raises(RuntimeError):
+        pa.pi_step(torch.zeros(1, 2, 8, 8, device=hip_device, dtype=torch.float16), cell.param_block())
+    with pytest.raises(RuntimeError):
+        pa.step_fwd(torch.zeros(2, 8, 8, device=hip_device), torch.zeros(37, device=hip_device))
+    # hidden width 1 (generic kernel) against the oracle
+    P1 = random_block(1, 2, np.float32, 4)
+    h = np.random.RandomState(0).rand(2, 16, 16).astype(np.float32)
+    assert np.array_equal(pa.step_fwd(dev_t(h, hip_device), dev_t(P1, hip_device)).cpu().numpy(), o_step_fwd(h, P1))
