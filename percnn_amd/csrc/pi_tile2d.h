@@ -218,14 +218,46 @@ pi_fwd2d_tile_kernel(T* __restrict__ frames /* frame t; t+1..t+K are written */,
 //   gframes : dL/dtraj;   gframes + (t-1-m)*frame_stride is injected at sub-step m if inj_mask bit m
 //   aframes : adjoint trajectory; frame t is read, frames t-1..t-K are written
 // ------------------------------------------------------------------------------------------------
-template <typename T, int HC, int K, int BX, int BY, int NT, int M>
+// pointwise operands (state h_{t-1-M}, injected dL/dout_{t-1-M}) of one 4-point strip
+template <typename T> struct StripOps { T u[4], v[4], ju[4], jv[4]; };
+
+template <typename T, int K, int BX, int BY, int NT, int M>
+__device__ __forceinline__ void adj_load_ops(StripOps<T>& o, int q, const T* __restrict__ hfr, const T* __restrict__ gfr,
+                                             const TileGeom& g, int ty0, int tx0)
+{
+    using TL = Tile<K, BX, BY>;
+    constexpr int RW4 = TL::region_w(M) / 4, RN4 = TL::region_n(M) / 4, O = 2 * (M + 1);
+    int idx = threadIdx.x + q * NT;
+    if (idx >= RN4) idx = RN4 - 1;
+    const int ry = idx / RW4, rc = idx - ry * RW4;
+    const int ly = ry + O, lx = 4 * rc + O;
+    // two 8/16-byte pieces per row: the strip may straddle the periodic wrap
+    const int gy = wrap1(ty0 - 2 * K + ly, g.H);
+    const int gx0 = wrap1(tx0 - 2 * K + lx, g.W), gx1 = wrap1(tx0 - 2 * K + lx + 2, g.W);
+    const long e0 = (long)gy * g.W + gx0, e1 = (long)gy * g.W + gx1;
+    const Pack<T, 2> a = ld<T, 2>(hfr + e0), b = ld<T, 2>(hfr + e1);
+    const Pack<T, 2> c = ld<T, 2>(hfr + g.ss + e0), d = ld<T, 2>(hfr + g.ss + e1);
+    o.u[0] = a.v[0]; o.u[1] = a.v[1]; o.u[2] = b.v[0]; o.u[3] = b.v[1];
+    o.v[0] = c.v[0]; o.v[1] = c.v[1]; o.v[2] = d.v[0]; o.v[3] = d.v[1];
+    if (gfr) {
+        const Pack<T, 2> a2 = ld<T, 2>(gfr + e0), b2 = ld<T, 2>(gfr + e1);
+        const Pack<T, 2> c2 = ld<T, 2>(gfr + g.ss + e0), d2 = ld<T, 2>(gfr + g.ss + e1);
+        o.ju[0] = a2.v[0]; o.ju[1] = a2.v[1]; o.ju[2] = b2.v[0]; o.ju[3] = b2.v[1];
+        o.jv[0] = c2.v[0]; o.jv[1] = c2.v[1]; o.jv[2] = d2.v[0]; o.jv[3] = d2.v[1];
+    }
+}
+
+// PRE = true: the strip operands of this sub-step were requested at kernel start (`pre`), so the cold
+// HBM latency of the trajectory / loss-gradient frames overlaps the window load and earlier sub-steps.
+template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE>
 __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict__ hfr, const T* __restrict__ gfr,
                                             const TileGeom& g, int ty0, int tx0, const T* __restrict__ P,
-                                            double (&acc_c)[2])
+                                            double (&acc_c)[2], const StripOps<T>& pre)
 {
     using TL = Tile<K, BX, BY>;
     constexpr int RW4 = TL::region_w(M) / 4, RN4 = TL::region_n(M) / 4, O = 2 * (M + 1);
     constexpr int PT = (RN4 + NT - 1) / NT;
+    static_assert(!PRE || PT == 1, "prefetched operands cover one strip per lane");
     const T dt = P[P_DT];
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
@@ -235,23 +267,13 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
         const int ry = idx / RW4, rc = idx - ry * RW4;
         const int ly = ry + O, lx = 4 * rc + O;
         const int off = ly * TL::LX + lx;
-        // pointwise operands straight from HBM: two 8/16-byte pieces (the strip may straddle the wrap)
-        const int gy = wrap1(ty0 - 2 * K + ly, g.H);
-        const int gx0 = wrap1(tx0 - 2 * K + lx, g.W), gx1 = wrap1(tx0 - 2 * K + lx + 2, g.W);
-        const long e0 = (long)gy * g.W + gx0, e1 = (long)gy * g.W + gx1;
-        T u[4], v[4], ju[4], jv[4];
-        {
-            const Pack<T, 2> a = ld<T, 2>(hfr + e0), b = ld<T, 2>(hfr + e1);
-            const Pack<T, 2> c = ld<T, 2>(hfr + g.ss + e0), d = ld<T, 2>(hfr + g.ss + e1);
-            u[0] = a.v[0]; u[1] = a.v[1]; u[2] = b.v[0]; u[3] = b.v[1];
-            v[0] = c.v[0]; v[1] = c.v[1]; v[2] = d.v[0]; v[3] = d.v[1];
-            if (gfr) {
-                const Pack<T, 2> a2 = ld<T, 2>(gfr + e0), b2 = ld<T, 2>(gfr + e1);
-                const Pack<T, 2> c2 = ld<T, 2>(gfr + g.ss + e0), d2 = ld<T, 2>(gfr + g.ss + e1);
-                ju[0] = a2.v[0]; ju[1] = a2.v[1]; ju[2] = b2.v[0]; ju[3] = b2.v[1];
-                jv[0] = c2.v[0]; jv[1] = c2.v[1]; jv[2] = d2.v[0]; jv[3] = d2.v[1];
-            }
-        }
+        StripOps<T> lo;
+        if constexpr (!PRE) adj_load_ops<T, K, BX, BY, NT, M>(lo, q, hfr, gfr, g, ty0, tx0);
+        const StripOps<T>& op = PRE ? pre : lo;
+        const T (&u)[4] = op.u;
+        const T (&v)[4] = op.v;
+        const T (&ju)[4] = op.ju;
+        const T (&jv)[4] = op.jv;
         T gc[2][4], dl[2][4];
         lds_star4<T, TL::LX, -1>(cur, ly, lx, P, gc[0], dl[0]);
         lds_star4<T, TL::LX, -1>(cur + TL::PLANE, ly, lx, P, gc[1], dl[1]);
@@ -317,24 +339,35 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
     }
 }
 
-template <typename T, int HC, int K, int BX, int BY, int NT, int M>
+template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE>
 __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__ hbase, const T* __restrict__ gbase,
                                              T* __restrict__ abase, long frame_stride, unsigned inj_mask,
                                              T* __restrict__ g_h0, int steps_to_zero, const TileGeom& g, int ty0,
-                                             int tx0, const T* __restrict__ P, double (&acc_c)[2])
+                                             int tx0, const T* __restrict__ P, double (&acc_c)[2],
+                                             const StripOps<T> (&pre)[PRE ? K : 1])
 {
     T* cur = (M & 1) ? b1 : b0;
     T* nxt = (M & 1) ? b0 : b1;
     const long fo = -(long)(M + 1) * frame_stride;         // frame t-1-M relative to frame t
-    adj_substep<T, HC, K, BX, BY, NT, M>(cur, nxt, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g, ty0,
-                                         tx0, P, acc_c);
+    adj_substep<T, HC, K, BX, BY, NT, M, PRE>(cur, nxt, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g,
+                                              ty0, tx0, P, acc_c, pre[PRE ? M : 0]);
     lds_barrier();
     // the adjoint of frame 0 is the caller's dL/dh0 output
     T* dst = (M + 1 == steps_to_zero && g_h0) ? g_h0 : abase + fo;
     tile_store<T, K, BX, BY, NT>(nxt, dst, g, ty0, tx0);
     if constexpr (M + 1 < K)
-        adj_substeps<T, HC, K, BX, BY, NT, M + 1>(b0, b1, hbase, gbase, abase, frame_stride, inj_mask, g_h0,
-                                                  steps_to_zero, g, ty0, tx0, P, acc_c);
+        adj_substeps<T, HC, K, BX, BY, NT, M + 1, PRE>(b0, b1, hbase, gbase, abase, frame_stride, inj_mask, g_h0,
+                                                       steps_to_zero, g, ty0, tx0, P, acc_c, pre);
+}
+
+template <typename T, int K, int BX, int BY, int NT, int M>
+__device__ __forceinline__ void adj_prefetch_all(StripOps<T> (&pre)[K], const T* __restrict__ hbase,
+                                                 const T* __restrict__ gbase, long frame_stride, unsigned inj_mask,
+                                                 const TileGeom& g, int ty0, int tx0)
+{
+    const long fo = -(long)(M + 1) * frame_stride;
+    adj_load_ops<T, K, BX, BY, NT, M>(pre[M], 0, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g, ty0, tx0);
+    if constexpr (M + 1 < K) adj_prefetch_all<T, K, BX, BY, NT, M + 1>(pre, hbase, gbase, frame_stride, inj_mask, g, ty0, tx0);
 }
 
 template <typename T, int HC, int K, int BX, int BY, int NT>
@@ -344,16 +377,21 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
                      double* __restrict__ partials, int np, const T* __restrict__ P, TileGeom g)
 {
     using TL = Tile<K, BX, BY>;
+    // Prefetching every sub-step's operands at kernel start was measured SLOWER on MI355X (17.6 vs 15.5 us per
+    // K=4 launch: 64 extra VGPRs and the requests queue ahead of the window load), so it stays off.
+    constexpr bool PRE = false;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* b0 = reinterpret_cast<T*>(smem_raw);
     T* b1 = b0 + 2 * TL::PLANE;
     const int tile = blockIdx.x;
     const int ty0 = (tile / g.tiles_x) * BY, tx0 = (tile % g.tiles_x) * BX;
+    StripOps<T> pre[PRE ? K : 1];
+    if constexpr (PRE) adj_prefetch_all<T, K, BX, BY, NT, 0>(pre, hframe_t, gframe_t, frame_stride, inj_mask, g, ty0, tx0);
     tile_load<T, K, BX, BY, NT>(aframe_t, g, ty0, tx0, b0);
-    __syncthreads();
+    lds_barrier();                                         // LDS only: the operand prefetches stay in flight
     double acc_c[2] = {0.0, 0.0};                          // heavily cancelling sums (stencil row-sum ~ 0): fp64
-    adj_substeps<T, HC, K, BX, BY, NT, 0>(b0, b1, hframe_t, gframe_t, aframe_t, frame_stride, inj_mask, g_h0,
-                                          steps_to_zero, g, ty0, tx0, P, acc_c);
+    adj_substeps<T, HC, K, BX, BY, NT, 0, PRE>(b0, b1, hframe_t, gframe_t, aframe_t, frame_stride, inj_mask, g_h0,
+                                               steps_to_zero, g, ty0, tx0, P, acc_c, pre);
     // diffusion-coefficient gradients of this tile over the K sub-steps: one reduction per launch
     __syncthreads();
     double* red = reinterpret_cast<double*>(b0);           // state buffers are dead now
