@@ -269,7 +269,7 @@ def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=3):
     cell = make_cell("gs3d", sd, dev)
     with torch.no_grad():
         P = cell.param_block().contiguous()
-    ex = slab.HaloExchanger(force_p2p=bool(int(os.environ.get("PERCNN_FORCE_P2P", "0"))))
+    ex = slab.make_exchanger(force_p2p=bool(int(os.environ.get("PERCNN_FORCE_P2P", "0"))))
     full_shape = (planes * world, hw, hw)
     lo = planes * rank
     g = torch.Generator().manual_seed(0)
@@ -308,7 +308,7 @@ def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=3):
     assert torch.isfinite(pg).all() and torch.isfinite(traj[-1][:, halo:-halo]).all()
     return {"workload": f"gs3d {'x'.join(map(str, full_shape))} sharded into {world} slabs of {planes} planes, Hc=2, "
                         f"T={T} fwd+bwd, forward halo {halo} (={halo // 2} steps per exchange), adjoint sweep "
-                        f"exchanges 2 planes per step; host-driven loop",
+                        f"exchanges 2 planes per step; host-driven loop; exchanger={type(ex).__name__}",
             "steps_per_sec_fwd_bwd": reps * T / el, "ms_per_time_step_fwd_bwd": el / (reps * T) * 1e3,
             "points_per_rank": planes * hw * hw, "global_points": planes * world * hw * hw,
             "halo_bytes_per_exchange_per_direction": 2 * halo * hw * hw * 4}

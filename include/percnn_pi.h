@@ -46,6 +46,9 @@ extern "C" {
 
 #define PERCNN_PI_ABI_VERSION 1
 
+#define PERCNN_PI_SWEEP_ONLY 1    /* flags of percnn_pi_slab_step_bwd_*: adjoint state + diffusion-coefficient
+                                   * gradients only; branch gradients come from percnn_pi_slab_wgrad_* later */
+
 #define PERCNN_PI_EINVAL   (-1)  /* bad ndim / hc / shape / NULL pointer          */
 #define PERCNN_PI_EWORKSPACE (-2) /* workspace smaller than *_workspace_bytes says */
 
@@ -139,11 +142,21 @@ int percnn_pi_slab_step_fwd_f64(const double *h, double *out, const double *para
 int percnn_pi_slab_step_bwd_f32(const float *h, const float *g_out, const float *g_inject, float *g_in,
                                 double *param_grad, void *workspace, size_t workspace_bytes,
                                 const float *params, int hc, int ndim, const int64_t *shape, int halo,
-                                void *stream);
+                                int flags, void *stream);
 int percnn_pi_slab_step_bwd_f64(const double *h, const double *g_out, const double *g_inject, double *g_in,
                                 double *param_grad, void *workspace, size_t workspace_bytes,
                                 const double *params, int hc, int ndim, const int64_t *shape, int halo,
-                                void *stream);
+                                int flags, void *stream);
+
+/* Time-parallel gradient reduction over the INTERIOR of local slab trajectories (same padded layout):
+ * traj frames 0..T-1 and adjoint frames 1..T ([T+1][2][n0+2*halo][rest] each), accumulated into param_grad.
+ * Pairs with percnn_pi_slab_step_bwd_* called with PERCNN_PI_SWEEP_ONLY. */
+int percnn_pi_slab_wgrad_f32(const float *traj, const float *adj, double *param_grad, void *workspace,
+                             size_t workspace_bytes, const float *params, int hc, int ndim, const int64_t *shape,
+                             int halo, int T, void *stream);
+int percnn_pi_slab_wgrad_f64(const double *traj, const double *adj, double *param_grad, void *workspace,
+                             size_t workspace_bytes, const double *params, int hc, int ndim, const int64_t *shape,
+                             int halo, int T, void *stream);
 
 #ifdef __cplusplus
 }

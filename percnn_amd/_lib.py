@@ -22,7 +22,7 @@ EXPORTS = [
     "percnn_pi_abi_version", "percnn_pi_param_count", "percnn_pi_bwd_workspace_bytes",
     "percnn_pi_rollout_bwd_workspace_bytes", "percnn_pi_set_option",
 ] + [f"percnn_pi_{op}_{suf}" for suf in ("f32", "f64")
-     for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd")]
+     for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad")]
 
 
 def build(force: bool = False, extra_flags=(), out: str | None = None) -> str:
@@ -73,7 +73,9 @@ def lib() -> ctypes.CDLL:
         f = getattr(L, f"percnn_pi_slab_step_fwd_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, vp, ci, ci, i64p, ci, ci, vp]
         f = getattr(L, f"percnn_pi_slab_step_bwd_{suf}")
-        f.restype, f.argtypes = ci, [vp, vp, vp, vp, vp, vp, sz, vp, ci, ci, i64p, ci, vp]
+        f.restype, f.argtypes = ci, [vp, vp, vp, vp, vp, vp, sz, vp, ci, ci, i64p, ci, ci, vp]
+        f = getattr(L, f"percnn_pi_slab_wgrad_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, vp, vp, sz, vp, ci, ci, i64p, ci, ci, vp]
         f = getattr(L, f"percnn_pi_rollout_fwd_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, ci, ci, i64p, ci, vp]
         f = getattr(L, f"percnn_pi_rollout_bwd_{suf}")

@@ -141,8 +141,10 @@ hipError_t launch_wgrad_pass(const T* traj, const T* adj, double* partials, cons
 {
     const int block = 256;
     const size_t lds = (size_t)(block / pi::WAVE) * NS * (10 * JC + 1) * sizeof(T);
+    const Geom g = make_geom(p);
+    const long ss = p.slab ? g.ss : (long)p.n, off = p.slab ? (long)p.halo * g.s0 : 0;
     hipLaunchKernelGGL((pi::pi_wgrad_kernel<T, JC, NS, VEC>), dim3(nb, NS == 2 ? 1 : 2), dim3(block), lds, st, traj,
-                       adj, partials, P, (long)p.n, t_lo, t_hi, p.hc, j0);
+                       adj, partials, P, (long)p.n, ss, off, t_lo, t_hi, p.hc, j0);
     return hipGetLastError();
 }
 
@@ -157,8 +159,10 @@ hipError_t launch_wgrad(const T* traj, const T* adj, double* partials, const T* 
     *rows_out = (unsigned)(2 * nb);
     if (p.hc == 0) {                                           // pre-contracted mode: coefficient moments
         const size_t lds = (size_t)(256 / pi::WAVE) * 20 * sizeof(T);
+        const Geom g = make_geom(p);
+        const long ss = p.slab ? g.ss : (long)p.n, off = p.slab ? (long)p.halo * g.s0 : 0;
         hipLaunchKernelGGL((pi::pi_moments_kernel<T, VEC>), dim3((unsigned)nb), dim3(256), lds, st, traj, adj, partials,
-                           P, (long)p.n, t_lo, t_hi);
+                           P, (long)p.n, ss, off, t_lo, t_hi);
         return hipGetLastError();
     }
     // small hidden widths: one workgroup handles both species (the state is streamed once)
@@ -426,7 +430,8 @@ int step_fwd_impl(const T* h, T* out, const T* P, int hc, int ndim, const int64_
 
 template <typename T>
 int step_bwd_impl(const T* h, const T* g_out, const T* g_inj, T* g_in, double* param_grad, void* ws, size_t ws_bytes,
-                  const T* P, int hc, int ndim, const int64_t* shape, void* stream, bool slab, int halo = 2)
+                  const T* P, int hc, int ndim, const int64_t* shape, void* stream, bool slab, int halo = 2,
+                  int flags = 0)
 {
     Problem p;
     if (int rc = make_problem(hc, ndim, shape, slab, p)) return rc;
@@ -437,8 +442,35 @@ int step_bwd_impl(const T* h, const T* g_out, const T* g_inj, T* g_in, double* p
     auto st = static_cast<hipStream_t>(stream);
     if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
     unsigned grid = 0;
-    if (hipError_t e = step_bwd<T, true>(h, g_out, g_inj, g_in, w.partials, P, p, st, &grid)) return (int)e;
+    const bool sweep_only = flags & PERCNN_PI_SWEEP_ONLY;
+    hipError_t e = sweep_only ? step_bwd<T, false>(h, g_out, g_inj, g_in, w.partials, P, p, st, &grid)
+                              : step_bwd<T, true>(h, g_out, g_inj, g_in, w.partials, P, p, st, &grid);
+    if (e) return (int)e;
     return (int)finish_grads(w, grid, hc, param_grad, st);
+}
+
+// branch-weight / coefficient-moment gradients of T steps over the interior of LOCAL slab trajectories
+template <typename T>
+int slab_wgrad_impl(const T* traj, const T* adj, double* param_grad, void* ws, size_t ws_bytes, const T* P, int hc,
+                    int ndim, const int64_t* shape, int halo, int T_steps, void* stream)
+{
+    Problem p;
+    if (int rc = make_problem(hc, ndim, shape, true, p)) return rc;
+    if (int rc = set_slab(p, halo, halo - 2)) return rc;
+    if (!traj || !adj || !param_grad || !P || T_steps < 0) return PERCNN_PI_EINVAL;
+    Workspace w;
+    if (!carve(ws, ws_bytes, p, sizeof(T), w)) return PERCNN_PI_EWORKSPACE;
+    if (T_steps == 0) return 0;
+    auto st = static_cast<hipStream_t>(stream);
+    if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
+    unsigned rows = 0;
+    const Geom g = make_geom(p);
+    const bool vec_ok = (p.W % pi::vec_width<T>::value == 0) && g_opt.vec != 1 &&
+                        (reinterpret_cast<uintptr_t>(traj) % 16 == 0) && (reinterpret_cast<uintptr_t>(adj) % 16 == 0);
+    hipError_t e = vec_ok ? launch_wgrad<T, pi::vec_width<T>::value>(traj, adj, w.partials, P, p, 0, T_steps, &rows, st)
+                          : launch_wgrad<T, 1>(traj, adj, w.partials, P, p, 0, T_steps, &rows, st);
+    if (e) return (int)e;
+    return (int)finish_grads(w, rows, hc, param_grad, st);
 }
 
 template <typename T>
@@ -633,9 +665,14 @@ int percnn_pi_set_option(const char* key, long value)
                               shape, stream, false); }                                                              \
     int percnn_pi_slab_step_bwd_##SUF(const T* h, const T* g_out, const T* g_inject, T* g_in, double* param_grad,  \
                                       void* workspace, size_t workspace_bytes, const T* params, int hc, int ndim,  \
-                                      const int64_t* shape, int halo, void* stream)                                 \
+                                      const int64_t* shape, int halo, int flags, void* stream)                      \
     { return step_bwd_impl<T>(h, g_out, g_inject, g_in, param_grad, workspace, workspace_bytes, params, hc, ndim,  \
-                              shape, stream, true, halo); }                                                               \
+                              shape, stream, true, halo, flags); }                                                  \
+    int percnn_pi_slab_wgrad_##SUF(const T* traj, const T* adj, double* param_grad, void* workspace,               \
+                                   size_t workspace_bytes, const T* params, int hc, int ndim, const int64_t* shape, \
+                                   int halo, int T_steps, void* stream)                                             \
+    { return slab_wgrad_impl<T>(traj, adj, param_grad, workspace, workspace_bytes, params, hc, ndim, shape, halo,  \
+                                T_steps, stream); }                                                               \
     int percnn_pi_rollout_fwd_##SUF(T* traj, const T* params, int hc, int ndim, const int64_t* shape, int T_steps, \
                                     void* stream)                                                                   \
     { return rollout_fwd_impl<T>(traj, params, hc, ndim, shape, T_steps, stream); }                                 \

@@ -365,14 +365,16 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
 template <typename T, int JC, int NS, int VEC>
 __global__ void __launch_bounds__(256)
 pi_wgrad_kernel(const T* __restrict__ traj, const T* __restrict__ adj, double* __restrict__ partials,
-                const T* __restrict__ P, long n, int t_lo, int t_hi, int hc, int j0)
+                const T* __restrict__ P, long n, long ss, long off, int t_lo, int t_hi, int hc, int j0)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* red = reinterpret_cast<T*>(smem_raw);            // [nwaves][NS*(10*JC+1)]
     constexpr int NA = 10 * JC + 1;
     const int np = nparams(hc);
     const T dt = P[P_DT];
-    const long frame = 2 * n;
+    // frames are [2][ss] with the n interior points of a species starting at `off` (slab layout: halo planes
+    // skipped; plain layout: ss = n, off = 0)
+    const long frame = 2 * ss;
     const long cpf = n / VEC;                            // chunks per frame
     const long nsteps = t_hi - t_lo;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -393,14 +395,14 @@ pi_wgrad_kernel(const T* __restrict__ traj, const T* __restrict__ adj, double* _
     long tt = c0 / cpf, xc = c0 - tt * cpf;
     while (tt < nsteps) {
         const long t = t_lo + 1 + tt;                    // step t maps frame t-1 -> frame t
-        const long x = xc * VEC;
+        const long x = off + xc * VEC;
         const Pack<T, VEC> u = ld<T, VEC>(traj + (t - 1) * frame + x);
-        const Pack<T, VEC> v = ld<T, VEC>(traj + (t - 1) * frame + n + x);
+        const Pack<T, VEC> v = ld<T, VEC>(traj + (t - 1) * frame + ss + x);
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             const int s = NS == 2 ? q : (int)blockIdx.y;
             const T* W = P + P_W + s * species_block(hc) + 10 * j0;
-            const Pack<T, VEC> a = ld<T, VEC>(adj + t * frame + s * n + x);
+            const Pack<T, VEC> a = ld<T, VEC>(adj + t * frame + s * ss + x);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 const T gr = a.v[i] * dt;
@@ -465,12 +467,12 @@ pi_wgrad_kernel(const T* __restrict__ traj, const T* __restrict__ adj, double* _
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
 pi_moments_kernel(const T* __restrict__ traj, const T* __restrict__ adj, double* __restrict__ partials,
-                  const T* __restrict__ P, long n, int t_lo, int t_hi)
+                  const T* __restrict__ P, long n, long ss, long off, int t_lo, int t_hi)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* red = reinterpret_cast<T*>(smem_raw);            // [nwaves][20]
     const T dt = P[P_DT];
-    const long frame = 2 * n;
+    const long frame = 2 * ss;
     const long cpf = n / VEC;
     const long nsteps = t_hi - t_lo;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -485,11 +487,11 @@ pi_moments_kernel(const T* __restrict__ traj, const T* __restrict__ adj, double*
     long tt = c0 / cpf, xc = c0 - tt * cpf;
     while (tt < nsteps) {
         const long t = t_lo + 1 + tt;
-        const long x = xc * VEC;
+        const long x = off + xc * VEC;
         const Pack<T, VEC> u = ld<T, VEC>(traj + (t - 1) * frame + x);
-        const Pack<T, VEC> v = ld<T, VEC>(traj + (t - 1) * frame + n + x);
+        const Pack<T, VEC> v = ld<T, VEC>(traj + (t - 1) * frame + ss + x);
         const Pack<T, VEC> au = ld<T, VEC>(adj + t * frame + x);
-        const Pack<T, VEC> av = ld<T, VEC>(adj + t * frame + n + x);
+        const Pack<T, VEC> av = ld<T, VEC>(adj + t * frame + ss + x);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             const T uu = u.v[i], vv = v.v[i];

@@ -256,8 +256,9 @@ def step_fwd(h: torch.Tensor, P: torch.Tensor, out: Optional[torch.Tensor] = Non
 
 def step_bwd(h: torch.Tensor, g_out: torch.Tensor, P: torch.Tensor, g_inject: Optional[torch.Tensor] = None,
              g_in: Optional[torch.Tensor] = None, param_grad: Optional[torch.Tensor] = None, slab: bool = False,
-             halo: int = 2, ws: Optional[torch.Tensor] = None):
-    """-> (dL/dh, param_grad double[np] (accumulated if given))"""
+             halo: int = 2, ws: Optional[torch.Tensor] = None, sweep_only: bool = False):
+    """-> (dL/dh, param_grad double[np] (accumulated if given)).  sweep_only (slab): adjoint state and
+    diffusion-coefficient gradients only; the branch gradients come from ``slab_wgrad`` afterwards."""
     _require(h, "h"); _require(g_out, "g_out", h.dtype); _require(P, "params", h.dtype)
     if g_inject is not None:
         _require(g_inject, "g_inject", h.dtype)
@@ -277,13 +278,32 @@ def step_bwd(h: torch.Tensor, g_out: torch.Tensor, P: torch.Tensor, g_inject: Op
         if slab:
             f = getattr(L, "percnn_pi_slab_step_bwd_" + _SUF[h.dtype])
             rc = f(h.data_ptr(), g_out.data_ptr(), inj, g_in.data_ptr(), param_grad.data_ptr(), ws.data_ptr(),
-                   ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), halo, _stream())
+                   ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), halo, 1 if sweep_only else 0,
+                   _stream())
         else:
             f = getattr(L, "percnn_pi_step_bwd_" + _SUF[h.dtype])
             rc = f(h.data_ptr(), g_out.data_ptr(), inj, g_in.data_ptr(), param_grad.data_ptr(), ws.data_ptr(),
                    ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), _stream())
     _lib.check(rc, "step_bwd")
     return g_in, param_grad
+
+
+def slab_wgrad(traj: torch.Tensor, adj: torch.Tensor, P: torch.Tensor, halo: int, param_grad: torch.Tensor,
+               ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Accumulate the branch-weight (or coefficient-moment) gradients of all steps of LOCAL padded
+    trajectories [T+1, 2, n0+2*halo, ...] into ``param_grad`` -- one time-parallel reduction."""
+    _require(traj, "traj"); _require(adj, "adj", traj.dtype); _require(P, "params", traj.dtype)
+    T = traj.shape[0] - 1
+    shape = list(traj.shape[2:])
+    shape[0] -= 2 * halo
+    hc = _hc_of(P)
+    if ws is None:
+        ws = workspace(hc, shape, traj.dtype, traj.device)
+    f = getattr(_lib.lib(), "percnn_pi_slab_wgrad_" + _SUF[traj.dtype])
+    with torch.cuda.device(traj.device):
+        _lib.check(f(traj.data_ptr(), adj.data_ptr(), param_grad.data_ptr(), ws.data_ptr(), ws.numel(), P.data_ptr(),
+                     hc, len(shape), _lib.shape_arg(shape), halo, T, _stream()), "slab_wgrad")
+    return param_grad
 
 
 # ------------------------------------------------------------------------------------------------

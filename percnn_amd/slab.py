@@ -55,6 +55,7 @@ class HaloExchanger:
             self.rank, self.world = 0, 1
         self.prev = (self.rank - 1) % self.world
         self.next = (self.rank + 1) % self.world
+        self._bufs = {}
 
     def _global(self, r):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
@@ -74,8 +75,14 @@ class HaloExchanger:
             lo_halo.copy_(bot)
             hi_halo.copy_(top)
             return
-        send_bot, send_top = bot.contiguous(), top.contiguous()
-        recv_lo, recv_hi = torch.empty_like(send_bot), torch.empty_like(send_top)
+        # persistent packed buffers (one set per face shape): no allocation on the per-step path
+        key = (tuple(top.shape), slab.dtype, slab.device)
+        bufs = self._bufs.get(key)
+        if bufs is None:
+            bufs = self._bufs[key] = [torch.empty(top.shape, dtype=slab.dtype, device=slab.device) for _ in range(4)]
+        send_bot, send_top, recv_lo, recv_hi = bufs
+        send_bot.copy_(bot)
+        send_top.copy_(top)
         # order matters when prev == next (world 2): first message to a peer is my *bottom* face,
         # the first message expected from a peer is the face for my *lower* halo.
         ops = [dist.P2POp(dist.isend, send_bot, self._global(self.next), self.group, tag=0),
@@ -91,6 +98,95 @@ class HaloExchanger:
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+
+class RcclHaloExchanger(HaloExchanger):
+    """Same ring exchange issued directly through RCCL (``ncclGroupStart / ncclSend / ncclRecv /
+    ncclGroupEnd`` of the librccl that PyTorch already loaded) on the CURRENT HIP stream:
+
+    * each face is sent per species straight out of the slab (the ``width`` planes of one species are
+      contiguous) and received straight into the neighbour's halo planes -- no packing copies;
+    * everything is enqueued asynchronously on the compute stream: no host wait, no extra stream hop.
+
+    The communicator is created once from an ``ncclUniqueId`` broadcast over the existing
+    ``torch.distributed`` group.  Falls back to the parent class for CPU tensors / world size 1 without
+    ``force_p2p``."""
+
+    _DT = {torch.float32: 7, torch.float64: 8}
+
+    def __init__(self, group=None, force_p2p: bool = False):
+        super().__init__(group, force_p2p)
+        import ctypes
+        import os
+        self._ct = ctypes
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self._nccl = ctypes.CDLL(path)
+
+        class UniqueId(ctypes.Structure):
+            _fields_ = [("internal", ctypes.c_byte * 128)]
+
+        uid = UniqueId()
+        if self.rank == 0:
+            self._check(self._nccl.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+        payload = [bytes(uid.internal)]
+        if self.world > 1:
+            dist.broadcast_object_list(payload, src=self._global(0), group=self.group)
+        ctypes.memmove(ctypes.byref(uid), payload[0], 128)
+        self._comm = ctypes.c_void_p()
+        self._nccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+        self._check(self._nccl.ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")
+        vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        self._nccl.ncclSend.argtypes = [vp, sz, ci, ci, vp, vp]
+        self._nccl.ncclRecv.argtypes = [vp, sz, ci, ci, vp, vp]
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"percnn_amd: {what} failed with ncclResult_t {rc}")
+
+    def exchange(self, slab: torch.Tensor, halo: int, width: Optional[int] = None) -> None:
+        if not slab.is_cuda or (self.world == 1 and not self.force_p2p):
+            return super().exchange(slab, halo, width)
+        width = halo if width is None else width
+        n = slab.shape[1] - 2 * halo
+        if width > n:
+            raise ValueError("halo wider than the neighbour's interior")
+        assert slab.is_contiguous()
+        ct = self._ct
+        stream = ct.c_void_p(torch.cuda.current_stream(slab.device).cuda_stream)
+        dt = self._DT[slab.dtype]
+        plane = slab[0, 0].numel()
+        cnt = width * plane
+        esz = slab.element_size()
+        base, ss = slab.data_ptr(), slab.shape[1] * plane * esz
+
+        def ptr(s, p0):
+            return ct.c_void_p(base + s * ss + p0 * plane * esz)
+
+        N = self._nccl
+        self._check(N.ncclGroupStart(), "ncclGroupStart")
+        # order matters when prev == next (world 1 or 2): per peer, sends and receives pair up in issue order
+        for s in range(2):
+            self._check(N.ncclSend(ptr(s, halo + n - width), cnt, dt, self.next, self._comm, stream), "ncclSend")
+            self._check(N.ncclSend(ptr(s, halo), cnt, dt, self.prev, self._comm, stream), "ncclSend")
+        for s in range(2):
+            self._check(N.ncclRecv(ptr(s, halo - width), cnt, dt, self.prev, self._comm, stream), "ncclRecv")
+            self._check(N.ncclRecv(ptr(s, halo + n), cnt, dt, self.next, self._comm, stream), "ncclRecv")
+        self._check(N.ncclGroupEnd(), "ncclGroupEnd")
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._nccl.ncclCommDestroy(self._comm)
+            self._comm = None
+
+
+def make_exchanger(group=None, prefer_rccl: bool = True, force_p2p: bool = False) -> HaloExchanger:
+    """RCCL-direct exchanger on GPU jobs when it can be set up, else the torch.distributed one."""
+    if prefer_rccl and torch.cuda.is_available():
+        try:
+            return RcclHaloExchanger(group, force_p2p)
+        except Exception:                       # missing symbols / init failure: keep the portable path
+            pass
+    return HaloExchanger(group, force_p2p)
 
 
 def slab_rollout_fwd_(traj: torch.Tensor, P: torch.Tensor, ex: HaloExchanger, halo: int,
@@ -110,21 +206,43 @@ def slab_rollout_fwd_(traj: torch.Tensor, P: torch.Tensor, ex: HaloExchanger, ha
 
 
 def slab_rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor, ex: HaloExchanger, halo: int,
-                     step_bwd: Callable = F_pi.step_bwd):
+                     step_bwd: Callable = F_pi.step_bwd, wgrad: Optional[Callable] = F_pi.slab_wgrad):
     """Reverse sweep over local slabs.  g_traj has the padded layout of traj (halo planes ignored).
-    Returns (dL/dh0 local padded, dL/dparams double[np] summed over ALL ranks)."""
+    Returns (dL/dh0 local padded, dL/dparams double[np] summed over ALL ranks).
+
+    With ``wgrad`` (default) the per-step kernel only advances the adjoint state (+ the two
+    diffusion-coefficient sums) into a local adjoint trajectory, and ONE time-parallel reduction over
+    the local interior yields the branch gradients at the end; ``wgrad=None`` reduces everything in
+    the per-step kernel instead (what the injected CPU stand-ins of the tests do)."""
     T = traj.shape[0] - 1
     n = traj.shape[2] - 2 * halo
     pg = torch.zeros(P.numel(), dtype=torch.float64, device=traj.device)
-    A = torch.zeros_like(traj[0])
-    A[:, halo:halo + n] = g_traj[T][:, halo:halo + n]
-    B = torch.zeros_like(A)
-    for t in range(T, 0, -1):
-        ex.exchange(A, halo, 2)
-        step_bwd(traj[t - 1], A, P, g_inject=g_traj[t - 1], g_in=B, param_grad=pg, slab=True, halo=halo)
-        A, B = B, A
+    ws = None
+    if step_bwd is F_pi.step_bwd:                     # one scratch buffer for the whole sweep
+        shape = list(traj.shape[2:])
+        shape[0] -= 2 * halo
+        ws = F_pi.workspace(F_pi._hc_of(P), shape, traj.dtype, traj.device)
+    if wgrad is None:
+        A = torch.zeros_like(traj[0])
+        A[:, halo:halo + n] = g_traj[T][:, halo:halo + n]
+        B = torch.zeros_like(A)
+        for t in range(T, 0, -1):
+            ex.exchange(A, halo, 2)
+            kw = {"ws": ws} if ws is not None else {}
+            step_bwd(traj[t - 1], A, P, g_inject=g_traj[t - 1], g_in=B, param_grad=pg, slab=True, halo=halo, **kw)
+            A, B = B, A
+        g0 = A
+    else:
+        adj = torch.zeros_like(traj)                  # local adjoint trajectory (halo planes: exchange targets)
+        adj[T][:, halo:halo + n] = g_traj[T][:, halo:halo + n]
+        for t in range(T, 0, -1):
+            ex.exchange(adj[t], halo, 2)
+            step_bwd(traj[t - 1], adj[t], P, g_inject=g_traj[t - 1], g_in=adj[t - 1], param_grad=pg, slab=True,
+                     halo=halo, ws=ws, sweep_only=True)
+        wgrad(traj, adj, P, halo, pg, ws=ws)
+        g0 = adj[0]
     ex.all_reduce_sum_(pg)
-    return A, pg
+    return g0, pg
 
 
 class SlabRolloutFunction(torch.autograd.Function):
@@ -151,4 +269,4 @@ class SlabRolloutFunction(torch.autograd.Function):
 
 def slab_rollout(h0_local: torch.Tensor, P: torch.Tensor, steps: int, halo: int = 2,
                  ex: Optional[HaloExchanger] = None) -> torch.Tensor:
-    return SlabRolloutFunction.apply(h0_local, P, int(steps), int(halo), ex or HaloExchanger())
+    return SlabRolloutFunction.apply(h0_local, P, int(steps), int(halo), ex or make_exchanger())

@@ -349,9 +349,21 @@ def test_rccl_halo_exchange_to_self(hip_device):
             a = torch.rand((2, 10 + 2 * halo, 6, 8), device=hip_device)
             b = a.clone()
             slab.HaloExchanger().exchange(a, halo, width)                     # local copies
-            slab.HaloExchanger(force_p2p=True).exchange(b, halo, width)       # RCCL send/recv
+            slab.HaloExchanger(force_p2p=True).exchange(b, halo, width)       # RCCL send/recv via torch.distributed
             torch.cuda.synchronize()
             assert torch.equal(a, b)
+            c = torch.rand((2, 10 + 2 * halo, 6, 8), device=hip_device)
+            c[:, halo:halo + 10] = a[:, halo:halo + 10]
+            rx = slab.RcclHaloExchanger(force_p2p=True)                       # direct ncclSend/ncclRecv, no packing
+            rx.exchange(c, halo, width)
+            torch.cuda.synchronize()
+            assert torch.equal(a[:, halo - width:halo + 10 + width], c[:, halo - width:halo + 10 + width])
+            c64 = c.double()
+            d64 = c64.clone()
+            rx.exchange(c64, halo, width)
+            torch.cuda.synchronize()
+            assert torch.equal(c64[:, halo - width:halo + 10 + width], d64[:, halo - width:halo + 10 + width])
+            rx.close()
             n = 10
             assert torch.equal(a[:, halo - width:halo], a[:, halo + n - width:halo + n])
             assert torch.equal(a[:, halo + n:halo + n + width], a[:, halo:halo + width])

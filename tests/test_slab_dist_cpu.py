@@ -90,7 +90,7 @@ def _worker(rank, world, port, shape, halo, T, hc, dtype_name, q):
 
         g_local = torch.zeros_like(traj)
         g_local[:, :, halo:halo + n] = torch.tensor(g_ref[:, :, lo:hi])
-        g0, pg = slab.slab_rollout_bwd(traj, g_local, Pt, ex, halo, step_bwd=bwd)
+        g0, pg = slab.slab_rollout_bwd(traj, g_local, Pt, ex, halo, step_bwd=bwd, wgrad=None)
         ok_g0 = np.array_equal(g0[:, halo:halo + n].numpy(), g0_ref[:, lo:hi])
         err_pg = float(np.linalg.norm(pg.numpy() - pg_ref) / np.linalg.norm(pg_ref))
         q.put((rank, ok_fwd, ok_g0, err_pg))
