@@ -158,6 +158,23 @@ int percnn_pi_slab_wgrad_f64(const double *traj, const double *adj, double *para
                              size_t workspace_bytes, const double *params, int hc, int ndim, const int64_t *shape,
                              int halo, int T, void *stream);
 
+/* ---- physics residual of the trajectory (the loss consumer next to the path) -------
+ * Replaces loss_generator.get_phy_Loss (2dgs:270-329, 3dgs:287-323, lo:283-341): a 5x5(x5) Laplacian
+ * convolution over all frames plus a permute/reshape/Conv1d time difference.  ONE launch, frame-parallel:
+ *   resid[f][s](x) = coef_s * Lap(traj[f])_s + r_s(traj[f]) - (traj[f+1][s] - traj[f][s]) / dt,  f < nframes
+ * `params` is a PRE-CONTRACTED block (36 entries, "hc = 0") holding the TRUE equation's constants
+ * (e.g. Gray-Scott Du, Dv, f, k -- 2dgs:321-327), not the model's.  traj: [nframes+1][2][*S].
+ * _bwd: g_state[f] = (d resid[f] / d traj[f])^T g_resid[f]; the part w.r.t. traj[f+1] is -g_resid[f]/dt,
+ * pointwise, and is left to the caller. */
+int percnn_pi_residual_fwd_f32(const float *traj, float *resid, const float *params, int ndim,
+                               const int64_t *shape, int nframes, void *stream);
+int percnn_pi_residual_fwd_f64(const double *traj, double *resid, const double *params, int ndim,
+                               const int64_t *shape, int nframes, void *stream);
+int percnn_pi_residual_bwd_f32(const float *traj, const float *g_resid, float *g_state, const float *params,
+                               int ndim, const int64_t *shape, int nframes, void *stream);
+int percnn_pi_residual_bwd_f64(const double *traj, const double *g_resid, double *g_state, const double *params,
+                               int ndim, const int64_t *shape, int nframes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -233,3 +233,39 @@ def rollout(cell, h0, steps):
     model = OracleRCNN(cell, step=steps, effective_step=list(range(steps)), init_state=h0)
     outs, _ = model()
     return torch.cat(tuple(outs), dim=0)
+
+
+# --------------------------------------------------------------------------------------
+# physics-residual loss -- restatement of loss_generator.get_phy_Loss + loss_gen
+# (2dgs:270-353, 3dgs:287-346, lo:283-357): same padding (2 low / 3 high), same dense Laplacian conv
+# divided by dx^2, same staggered time difference, same analytic right-hand sides.
+# --------------------------------------------------------------------------------------
+def physics_loss_reference(output: torch.Tensor, family: str, dx: float, dt: float) -> torch.Tensor:
+    ndim = output.dim() - 2
+    for ax in range(ndim - 1, -1, -1):                       # 2dgs:345-346 / 3dgs:337-339
+        d = 2 + ax
+        n = output.shape[d]
+        output = torch.cat((output.narrow(d, n - 2, 2), output, output.narrow(d, 0, 3)), dim=d)
+    W = torch.tensor(laplace_stencil(ndim), dtype=output.dtype)
+    conv = F.conv2d if ndim == 2 else F.conv3d
+    inner = (slice(2, -2),) * ndim
+    lap_u = conv(output[0:-2, 0:1], W) / (dx ** 2)           # Conv2dDerivative: filter(input) / deno (2dgs:214-216)
+    lap_v = conv(output[0:-2, 1:2], W) / (dx ** 2)
+    uu = output[(slice(None), slice(0, 1)) + inner]
+    vv = output[(slice(None), slice(1, 2)) + inner]
+    u_t = (uu[1:-1] - uu[:-2]) / dt                           # Conv1d with [-1, 1, 0] then / deno (2dgs:265-268)
+    v_t = (vv[1:-1] - vv[:-2]) / dt
+    u, v = uu[0:-2], vv[0:-2]
+    if family == "gs2d":                                      # 2dgs:321-327
+        Du = 2e-5; Dv = Du / 4; f = 1 / 25; k = 3 / 50
+        f_u = (Du * lap_u - u * (v ** 2) + f * (1 - u) - u_t) / 1
+        f_v = (Dv * lap_v + u * (v ** 2) - (f + k) * v - v_t) / 1
+    elif family == "gs3d":                                    # 3dgs:316-322
+        Du = 0.2; Dv = 0.1; f = 0.025; k = 0.055
+        f_u = (Du * lap_u - u * v ** 2 + f * (1 - u) - u_t)
+        f_v = (Dv * lap_v + u * v ** 2 - (f + k) * v - v_t)
+    else:                                                     # lo:339-340
+        f_u = 0.1 * lap_u + (1 - u ** 2 - v ** 2) * u + (u ** 2 + v ** 2) * v - u_t
+        f_v = 0.1 * lap_v - (u ** 2 + v ** 2) * u + (1 - u ** 2 - v ** 2) * v - v_t
+    mse = torch.nn.MSELoss()
+    return mse(f_u, torch.zeros_like(f_u)) + mse(f_v, torch.zeros_like(f_v))

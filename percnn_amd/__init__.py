@@ -10,6 +10,6 @@ from .functional import (pi_step, pi_rollout, pack_params, contract_block, param
                          step_fwd, step_bwd, PiStepFunction, PiRolloutFunction)
 from .modules import RCNNCell, RCNN, Upscaler, gs2d_cell, gs3d_cell, lo2d_cell, laplace_stencil  # noqa: F401
 
-from . import slab, synthetic  # noqa: F401
+from . import slab, synthetic, physics  # noqa: F401
 
 __version__ = "0.1.0"

@@ -22,7 +22,8 @@ EXPORTS = [
     "percnn_pi_abi_version", "percnn_pi_param_count", "percnn_pi_bwd_workspace_bytes",
     "percnn_pi_rollout_bwd_workspace_bytes", "percnn_pi_set_option",
 ] + [f"percnn_pi_{op}_{suf}" for suf in ("f32", "f64")
-     for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad")]
+     for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
+                "residual_fwd", "residual_bwd")]
 
 
 def build(force: bool = False, extra_flags=(), out: str | None = None) -> str:
@@ -76,6 +77,10 @@ def lib() -> ctypes.CDLL:
         f.restype, f.argtypes = ci, [vp, vp, vp, vp, vp, vp, sz, vp, ci, ci, i64p, ci, ci, vp]
         f = getattr(L, f"percnn_pi_slab_wgrad_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, vp, vp, sz, vp, ci, ci, i64p, ci, ci, vp]
+        f = getattr(L, f"percnn_pi_residual_fwd_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, vp, ci, i64p, ci, vp]
+        f = getattr(L, f"percnn_pi_residual_bwd_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, vp, vp, ci, i64p, ci, vp]
         f = getattr(L, f"percnn_pi_rollout_fwd_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, ci, ci, i64p, ci, vp]
         f = getattr(L, f"percnn_pi_rollout_bwd_{suf}")

@@ -563,6 +563,32 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     return (int)finish_grads(w, rows > wrows ? rows : wrows, hc, param_grad, st);
 }
 
+
+// ---- physics residual over a trajectory (time-parallel; pre-contracted block of the TRUE equation) ----
+template <typename T, bool ADJ>
+int residual_impl(const T* traj, const T* G, T* out, const T* Q, int ndim, const int64_t* shape, int nframes, void* stream)
+{
+    Problem p;
+    if (int rc = make_problem(0, ndim, shape, false, p)) return rc;
+    if (!traj || !out || !Q || (ADJ && !G) || nframes < 0 || nframes > 65535) return PERCNN_PI_EINVAL;
+    if (nframes == 0) return 0;
+    const Geom g = make_geom(p);
+    const int vec = pick_vec<T>(p, {traj, G, out});
+    const long nchunks = (long)g.rows * (g.W / vec);
+    const dim3 grid((unsigned)((nchunks + 255) / 256), (unsigned)nframes), block(256);
+    auto st = static_cast<hipStream_t>(stream);
+    constexpr int V = pi::vec_width<T>::value;
+#define PI_RES(NDIM, VEC)                                                                                      \
+    do {                                                                                                       \
+        if constexpr (ADJ) hipLaunchKernelGGL((pi::pi_residual_adj_kernel<T, NDIM, VEC>), grid, block, 0, st, traj, G, out, Q, g); \
+        else hipLaunchKernelGGL((pi::pi_residual_kernel<T, NDIM, VEC>), grid, block, 0, st, traj, out, Q, g);    \
+    } while (0)
+    if (ndim == 2) { if (vec == 1) PI_RES(2, 1); else PI_RES(2, V); }
+    else           { if (vec == 1) PI_RES(3, 1); else PI_RES(3, V); }
+#undef PI_RES
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 // ---- exported symbols ---------------------------------------------------------------------------
@@ -684,5 +710,16 @@ int percnn_pi_set_option(const char* key, long value)
 
 PI_EXPORT(f32, float)
 PI_EXPORT(f64, double)
+
+#define PI_EXPORT_RES(SUF, T)                                                                                       \
+    int percnn_pi_residual_fwd_##SUF(const T* traj, T* resid, const T* params, int ndim, const int64_t* shape,     \
+                                     int nframes, void* stream)                                                     \
+    { return residual_impl<T, false>(traj, nullptr, resid, params, ndim, shape, nframes, stream); }                 \
+    int percnn_pi_residual_bwd_##SUF(const T* traj, const T* g_resid, T* g_state, const T* params, int ndim,       \
+                                     const int64_t* shape, int nframes, void* stream)                               \
+    { return residual_impl<T, true>(traj, g_resid, g_state, params, ndim, shape, nframes, stream); }
+
+PI_EXPORT_RES(f32, float)
+PI_EXPORT_RES(f64, double)
 
 }  // extern "C"

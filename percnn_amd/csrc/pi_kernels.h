@@ -526,6 +526,83 @@ pi_moments_kernel(const T* __restrict__ traj, const T* __restrict__ adj, double*
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// physics residual of a polynomial reaction-diffusion equation over a whole trajectory, time-parallel
+// (reference: loss_generator.get_phy_Loss, train_2drd.py:270-329, train_3drd.py:287-323,
+// percnn_LO_eqn.py:283-341 -- a 5x5(x5) Laplacian conv over all frames + a permute/reshape/Conv1d time
+// difference; here ONE launch, blockIdx.y = frame):
+//   R_s(f, x) = coef_s * Lap(h_f)_s + r_s(h_f) - (h_{f+1,s} - h_{f,s}) / dt
+// Q is a pre-contracted block holding the TRUE equation (coefficients of the PDE, not of the model).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NDIM, int VEC>
+__global__ void __launch_bounds__(256)
+pi_residual_kernel(const T* __restrict__ traj, T* __restrict__ R, const T* __restrict__ Q, Geom g)
+{
+    const int cpr = g.W / VEC;
+    const long nchunks = (long)g.rows * cpr;
+    const long cid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cid >= nchunks) return;
+    int i0, i1, x0;
+    long e;
+    chunk_coords<NDIM>(g, cid, cpr, VEC, i0, i1, x0, e);
+    const long frame = 2 * g.ss;
+    const T* h = traj + (long)blockIdx.y * frame;
+    const T* hn = h + frame;
+    const Pack<T, VEC> cu = ld<T, VEC>(h + e), cv = ld<T, VEC>(h + g.ss + e);
+    T lap[2][VEC];
+    star<T, NDIM, VEC, +1>(h, Q, g, i0, i1, x0, e, cu, lap[0]);
+    star<T, NDIM, VEC, +1>(h + g.ss, Q, g, i0, i1, x0, e, cv, lap[1]);
+    const T dt = Q[P_DT];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const Pack<T, VEC> nx = ld<T, VEC>(hn + s * g.ss + e);
+        const T* c = Q + P_W + 10 * s;
+        Pack<T, VEC> o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const T hs = s == 0 ? cu.v[i] : cv.v[i];
+            const T rhs = Q[P_COEF + s] * lap[s][i] + poly_r(c, cu.v[i], cv.v[i]);
+            o.v[i] = rhs - (nx.v[i] - hs) / dt;
+        }
+        st<T, VEC>(R + (long)blockIdx.y * frame + s * g.ss + e, o);
+    }
+}
+
+// (dR_f/dh_f)^T G  =  coef * LapT(G) + J_r(h_f)^T G + G / dt        (the -G/dt part w.r.t. h_{f+1} is pointwise)
+template <typename T, int NDIM, int VEC>
+__global__ void __launch_bounds__(256)
+pi_residual_adj_kernel(const T* __restrict__ traj, const T* __restrict__ G, T* __restrict__ out,
+                       const T* __restrict__ Q, Geom g)
+{
+    const int cpr = g.W / VEC;
+    const long nchunks = (long)g.rows * cpr;
+    const long cid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cid >= nchunks) return;
+    int i0, i1, x0;
+    long e;
+    chunk_coords<NDIM>(g, cid, cpr, VEC, i0, i1, x0, e);
+    const long frame = 2 * g.ss;
+    const T* h = traj + (long)blockIdx.y * frame;
+    const T* Gf = G + (long)blockIdx.y * frame;
+    const Pack<T, VEC> u = ld<T, VEC>(h + e), v = ld<T, VEC>(h + g.ss + e);
+    const Pack<T, VEC> gu = ld<T, VEC>(Gf + e), gv = ld<T, VEC>(Gf + g.ss + e);
+    T lg[2][VEC];
+    star<T, NDIM, VEC, -1>(Gf, Q, g, i0, i1, x0, e, gu, lg[0]);
+    star<T, NDIM, VEC, -1>(Gf + g.ss, Q, g, i0, i1, x0, e, gv, lg[1]);
+    const T dt = Q[P_DT];
+    Pack<T, VEC> ou, ov;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        T ruu, ruv, rvu, rvv;                            // d r_u / d(u,v), d r_v / d(u,v)
+        poly_dr(Q + P_W, u.v[i], v.v[i], ruu, ruv);
+        poly_dr(Q + P_W + 10, u.v[i], v.v[i], rvu, rvv);
+        ou.v[i] = fma_(Q[P_COEF + 0], lg[0][i], fma_(gu.v[i], ruu, gv.v[i] * rvu)) + gu.v[i] / dt;
+        ov.v[i] = fma_(Q[P_COEF + 1], lg[1][i], fma_(gu.v[i], ruv, gv.v[i] * rvv)) + gv.v[i] / dt;
+    }
+    st<T, VEC>(out + (long)blockIdx.y * frame + e, ou);
+    st<T, VEC>(out + (long)blockIdx.y * frame + g.ss + e, ov);
+}
+
 // param_grad[idx] += sum_b partials[b][idx]; one wave per parameter, fixed order -> deterministic
 __global__ void __launch_bounds__(64)
 pi_reduce_partials_kernel(const double* __restrict__ partials, int nblocks, int np, double* __restrict__ param_grad)

@@ -81,3 +81,14 @@ def test_rcnn_harness_restatement(fam):
     assert len(outs) == z["outputs"].shape[0]
     assert np.array_equal(torch.cat(outs, 0).numpy(), z["outputs"])
     assert np.array_equal(sl.numpy(), z["second_last_state"])
+
+
+@pytest.mark.parametrize("fn", small_cases(), ids=case_id)
+def test_physics_loss_restatement_equals_reference(fn):
+    """The reference's own physics-residual scalar of its trajectory (captured by make_golden.py)."""
+    from oracle import restatement as R
+    g = Golden(fn)
+    traj = R.rollout(g.oracle_cell(), torch.tensor(g.h0), g.steps).detach()
+    loss = R.physics_loss_reference(traj, g.family, g.dx, g.dt)
+    ref = float(g.z["phy_loss"])
+    assert abs(loss.item() - ref) <= 1e-6 * abs(ref), (loss.item(), ref)
