@@ -559,7 +559,7 @@ def test_physics_loss_vs_reference(fn, hip_device):
     ref = float(g.z["phy_loss"])
     # fp32: the residual is a difference of O(1e-2..1) terms that nearly cancel; reference and kernel round
     # the Laplacian differently (conv/dx^2 vs pre-scaled taps), so the scalar agrees to ~1e-3 relative
-    tol_v = 2e-3 if g.dtype == np.float32 else 1e-9
+    tol_v = 2e-3 if g.dtype == np.float32 else 1e-7      # converged lambda-omega model: loss ~1e-14 is pure round-off
     assert abs(loss.item() - ref) <= tol_v * abs(ref), (loss.item(), ref)
     loss.backward()
     oc = traj_cpu.clone().requires_grad_(True)
