@@ -1,0 +1,27 @@
+# Round-end evidence: bench lines, rocprofv3 kernel-trace summaries of the same commands, PMC traffic.
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+cd /tmp
+for wl in gs2d_512 gs3d_128 lo2d_512; do
+  (timeout 900 python $R/bench.py --workload $wl 2>&1 | tail -1) > $R/gpurun_out/final_bench_$wl.json
+  rm -rf /tmp/kt; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --workload $wl --no-cpu-baseline --steps 3 --warmup 1 > /tmp/kt.log 2>&1
+  python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) > $R/gpurun_out/final_kernel_stats_$wl.txt 2>&1
+  tail -1 /tmp/kt.log > $R/gpurun_out/final_bench_under_rocprof_$wl.json
+done
+(timeout 900 python $R/bench.py --workload gs2d_512 --reaction factored --no-cpu-baseline 2>&1 | tail -1) > $R/gpurun_out/final_bench_gs2d_512_factored.json
+: > $R/gpurun_out/final_pmc_summary.txt
+for wl in gs2d_512 gs3d_128; do
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmcout
+  timeout 900 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmcout -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --workload $wl --T 100 > /tmp/pmc.log 2>&1
+  python $R/tools/pmc_summary.py $(find /tmp/pmcout -name "*.db" | head -1) "$wl T=100" | grep "pi::" >> $R/gpurun_out/final_pmc_summary.txt 2>&1
+done
+done
+cd $R
+cat gpurun_out/final_pmc_summary.txt | cut -c1-200
+for f in gpurun_out/final_bench_*.json; do echo $f; python -c "
+import json,sys
+d=json.loads(open('$f').read().strip().splitlines()[-1])
+print('  value %.0f steps/s  fwd %.2f us  bwd %.2f us'%(d['value'], d['fwd_us_per_time_step'], d['bwd_us_per_time_step']), ' dominant', d['roofline']['kernel'], 'frac %.3f'%d['roofline']['frac'], 'cpu', d.get('cpu_baseline',{}).get('value'))
+"; done
