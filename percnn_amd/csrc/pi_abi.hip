@@ -24,6 +24,8 @@ struct Options {
     int tile_nt = 512;      // workgroup size of the tile kernels (256 or 512)
     int stream3d = 1;       // 3D: plane-streaming kernels where the shape allows (W = 64*VEC)
     int zc = 8;             // planes per workgroup of the streaming kernels
+    int overlap = 0;        // 1: run the gradient reduction on a side stream, chunk by chunk, under the sweep (measured: no gain on MI355X)
+    int overlap_chunk = 128; // time steps per chunk
     int fuse_wgrad = 0;     // rollout sweep uses the fused per-step kernel (all gradients reduced every step) instead of
                             // sweep + one time-parallel reduction (experiment: saves the reduction pass, costs per-step reductions)
     int skip_wgrad = 0;     // diagnostics: rollout_bwd runs the adjoint sweep only (bench uses it to time the sweep alone)
@@ -38,6 +40,31 @@ hipError_t allow_lds(F* f, size_t bytes)
 {
     if (bytes <= 64 * 1024) return hipSuccess;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// One side stream + a small event ring per device for sweep || reduction overlap (created lazily, never destroyed;
+// fork/join through events only -- no host synchronisation).
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    hipEvent_t done = nullptr;
+    int next = 0;
+    bool ok = false;
+};
+SideStream* side_stream()
+{
+    static SideStream per_dev[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStream& s = per_dev[dev];
+    if (!s.ok) {
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (auto& e : s.ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) return nullptr;
+        s.ok = true;
+    }
+    return &s;
 }
 
 constexpr int MAX_BWD_BLOCKS = 4096;   // bounds the per-workgroup gradient partials (grid-stride beyond)
@@ -528,8 +555,39 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
                                       hipMemcpyDeviceToDevice, st))
         return (int)e;
 
-    // 1) sequential reverse sweep: adjoint states (+ diffusion-coefficient gradients)
-    unsigned rows = 0;
+    // 1) sequential reverse sweep: adjoint states (+ diffusion-coefficient gradients), with
+    // 2) the time-parallel branch-gradient reduction of every finished chunk of steps running UNDER it on a side
+    //    stream (the sweep is latency-bound, the reduction HBM-bound); partial rows are disjoint columns.
+    const bool vec_ok = (p.n % pi::vec_width<T>::value == 0) && g_opt.vec != 1 &&
+                        (reinterpret_cast<uintptr_t>(traj) % 16 == 0);
+    unsigned rows = 0, wrows = 0;
+    auto reduce_range = [&](int lo, int hi, hipStream_t s2) -> hipError_t {      // steps (lo, hi]
+        if (hi <= lo || g_opt.skip_wgrad || g_opt.fuse_wgrad) return hipSuccess;
+        unsigned r = 0;
+        hipError_t e = vec_ok ? launch_wgrad<T, pi::vec_width<T>::value>(traj, adj, w.partials, P, p, lo, hi, &r, s2)
+                              : launch_wgrad<T, 1>(traj, adj, w.partials, P, p, lo, hi, &r, s2);
+        if (r > wrows) wrows = r;
+        return e;
+    };
+    SideStream* ss = (g_opt.overlap && !g_opt.skip_wgrad && !g_opt.fuse_wgrad && t_top >= 2 * g_opt.overlap_chunk)
+                         ? side_stream() : nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (ss && (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) ss = nullptr;
+    int reduced_above = t_top;                       // steps (reduced_above, t_top] are already handed to the reduction
+    auto hand_over = [&](int t_done) -> hipError_t { // adj frames > t_done ... are final: reduce steps (t_done, reduced_above]
+        if (!ss || reduced_above - t_done < g_opt.overlap_chunk) return hipSuccess;
+        hipEvent_t ev = ss->ev[ss->next++ % 8];
+        if (hipError_t e = hipEventRecord(ev, st)) return e;
+        if (hipError_t e = hipStreamWaitEvent(ss->stream, ev, 0)) return e;
+        if (hipError_t e = reduce_range(t_done, reduced_above, ss->stream)) return e;
+        reduced_above = t_done;
+        return hipSuccess;
+    };
+    if (ss) {                                         // the side stream must see the memset / top-frame copy
+        hipEvent_t ev = ss->ev[ss->next++ % 8];
+        if (hipError_t e = hipEventRecord(ev, st)) return (int)e;
+        if (hipError_t e = hipStreamWaitEvent(ss->stream, ev, 0)) return (int)e;
+    }
     int t_cur = t_top;
     if (tile_eligible<T>(p, {traj, g_traj, g_h0, adj})) {
         const int K = (g_opt.tile_k == 8 && p.hc != 0) ? 4 : g_opt.tile_k;
@@ -540,6 +598,8 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
             if (hipError_t e = adj_tile<T>(traj + (size_t)t_cur * frame, g_traj + (size_t)t_cur * frame,
                                            adj + (size_t)t_cur * frame, m, g_h0, t_cur == K ? K : 0, w.partials, P, p, st))
                 return (int)e;
+            // frames t_cur-K .. t_cur-1 were just written; steps (t_cur - K, ...] need adj frames > t_cur - K: all final
+            if (hipError_t e = hand_over(t_cur - K)) return (int)e;
         }
     }
     for (int t = t_cur; t >= 1; --t) {
@@ -551,15 +611,20 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
             : step_bwd<T, false>(traj + (size_t)(t - 1) * frame, adj + (size_t)t * frame, inj, dst, w.partials, P, p, st, &r2);
         if (e) return (int)e;
         if (r2 > rows) rows = r2;
+        if (hipError_t e2 = hand_over(t - 1)) return (int)e2;
     }
-    // 2) branch-weight gradients of all t_top steps at once (time-parallel reduction)
-    unsigned wrows = 0;
     if (g_opt.skip_wgrad || (g_opt.fuse_wgrad && t_cur == t_top)) return (int)finish_grads(w, rows, hc, param_grad, st);
-    const bool vec_ok = (p.n % pi::vec_width<T>::value == 0) && g_opt.vec != 1 &&
-                        (reinterpret_cast<uintptr_t>(traj) % 16 == 0);
-    hipError_t e = vec_ok ? launch_wgrad<T, pi::vec_width<T>::value>(traj, adj, w.partials, P, p, 0, t_top, &wrows, st)
-                          : launch_wgrad<T, 1>(traj, adj, w.partials, P, p, 0, t_top, &wrows, st);
-    if (e) return (int)e;
+    if (ss) {
+        // remaining steps (0, reduced_above] on the side stream too (ordered behind the earlier chunks), then join
+        hipEvent_t ev = ss->ev[ss->next++ % 8];
+        if (hipError_t e = hipEventRecord(ev, st)) return (int)e;
+        if (hipError_t e = hipStreamWaitEvent(ss->stream, ev, 0)) return (int)e;
+        if (hipError_t e = reduce_range(0, reduced_above, ss->stream)) return (int)e;
+        if (hipError_t e = hipEventRecord(ss->done, ss->stream)) return (int)e;
+        if (hipError_t e = hipStreamWaitEvent(st, ss->done, 0)) return (int)e;
+    } else {
+        if (hipError_t e = reduce_range(0, t_top, st)) return (int)e;
+    }
     return (int)finish_grads(w, rows > wrows ? rows : wrows, hc, param_grad, st);
 }
 
@@ -638,6 +703,12 @@ int percnn_pi_set_option(const char* key, long value)
     }
     if (!std::strcmp(key, "skip_wgrad")) { g_opt.skip_wgrad = value != 0; return 0; }
     if (!std::strcmp(key, "fuse_wgrad")) { g_opt.fuse_wgrad = value != 0; return 0; }
+    if (!std::strcmp(key, "overlap")) { g_opt.overlap = value != 0; return 0; }
+    if (!std::strcmp(key, "overlap_chunk")) {
+        if (value < 1 || value > (1 << 20)) return PERCNN_PI_EINVAL;
+        g_opt.overlap_chunk = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "stream3d")) {                         // 0 = never, 1 = size heuristic, 2 = whenever eligible
         if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
         g_opt.stream3d = (int)value;
