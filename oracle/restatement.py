@@ -269,3 +269,47 @@ def physics_loss_reference(output: torch.Tensor, family: str, dx: float, dt: flo
         f_v = 0.1 * lap_v - (u ** 2 + v ** 2) * u + (1 - u ** 2 - v ** 2) * v - v_t
     mse = torch.nn.MSELoss()
     return mse(f_u, torch.zeros_like(f_u)) + mse(f_v, torch.zeros_like(f_v))
+
+
+# --------------------------------------------------------------------------------------
+# Stage-3 physics-based cell, lambda-omega.  Restates
+# DataDrivenDiscoveryOfPDEs/2D_Lambda_Omega_eqn/stage-3/fine_tuning_LO_[10%noise,41x51x51].py  (tag lo3):
+#   Conv2dDerivative (circular 5x5 conv, result / resol)  lo3:56-82
+#   RCNNCell.__init__ (13 scalar coefficients, dx=dy=0.2, dt=0.0125)  lo3:83-147
+#   f_rhs  lo3:149-152,  Euler forward  lo3:203-216
+# --------------------------------------------------------------------------------------
+class OracleStage3LOCell(nn.Module):
+    INIT = dict(nu_u=0.09465, nu_v=0.09455, C1_u=1.0081, C2_u=-1.0167, C3_u=0.9973, C4_u=-1.0176, C5_u=0.9981,
+                C1_v=0.9873, C2_v=-0.9987, C3_v=-0.9945, C4_v=-0.9985, C5_v=-0.9928, C6_v=0.0065)
+
+    def __init__(self):
+        super().__init__()
+        for k, v in self.INIT.items():
+            setattr(self, k, nn.Parameter(torch.tensor(v, dtype=torch.float64)))
+        self.dx, self.dy, self.dt = 0.2, 0.2, 0.0125
+
+        class _Lap(nn.Module):
+            def __init__(self, resol):
+                super().__init__()
+                self.resol = resol
+                self.filter = nn.Conv2d(1, 1, 5, 1, padding=2, padding_mode="circular", bias=False)
+                self.filter.weight.data = torch.tensor(laplace_stencil(2), dtype=torch.float64)
+                self.filter.weight.requires_grad = False
+
+            def forward(self, x):
+                return self.filter(x) / self.resol
+
+        self.laplace_op = _Lap(self.dx ** 2)
+
+    def f_rhs(self, u, v):
+        f_u = self.nu_u*self.laplace_op(u) + self.C1_u*u + self.C2_u*u**3 + self.C3_u*u**2*v + self.C4_u*u*v**2 + self.C5_u*v**3
+        f_v = self.nu_v*self.laplace_op(v) + self.C1_v*v + self.C2_v*u**3 + self.C3_v*u**2*v + self.C4_v*u*v**2 + self.C5_v*v**3 + self.C6_v*u
+        return f_u, f_v
+
+    def forward(self, h):
+        u0, v0 = h[:, 0:1, ...], h[:, 1:2, ...]
+        f_u, f_v = self.f_rhs(u0, v0)
+        u_next = u0 + self.dt * f_u
+        v_next = v0 + self.dt * f_v
+        ch = torch.cat((u_next, v_next), dim=1)
+        return ch, ch

@@ -144,6 +144,63 @@ def lo2d_cell(hidden_channels: int = 4, reaction: str = "poly") -> RCNNCell:
                     stencil_scale="div", init="uniform", init_c=0.5, reaction=reaction)
 
 
+class Stage3LambdaOmegaCell(nn.Module):
+    """Stage-3 physics-based lambda-omega cell: drop-in for ``RCNNCell`` of
+    DataDrivenDiscoveryOfPDEs/2D_Lambda_Omega_eqn/stage-3/fine_tuning_LO_[10%noise,41x51x51].py:83-216 --
+    13 trainable scalars of the discovered PDE
+
+        u_t = nu_u Lap u + C1_u u + C2_u u^3 + C3_u u^2 v + C4_u u v^2 + C5_u v^3
+        v_t = nu_v Lap v + C1_v v + C2_v u^3 + C3_v u^2 v + C4_v u v^2 + C5_v v^3 + C6_v u     (f_rhs, :149-152)
+
+    advanced by explicit Euler (forward, :203-216), float64, periodic.  Same parameter names as the reference
+    (``nu_u, nu_v, C1_u..C5_u, C1_v..C6_v, laplace_op.filter.weight``).  It runs on the pre-contracted kernels:
+    the scalars ARE the monomial coefficients of the 36-entry block."""
+
+    INIT = dict(nu_u=0.09465, nu_v=0.09455, C1_u=1.0081, C2_u=-1.0167, C3_u=0.9973, C4_u=-1.0176, C5_u=0.9981,
+                C1_v=0.9873, C2_v=-0.9987, C3_v=-0.9945, C4_v=-0.9985, C5_v=-0.9928, C6_v=0.0065)   # :126-140
+
+    class _Derivative(nn.Module):
+        def __init__(self, resol):
+            super().__init__()
+            self.resol = resol
+            self.filter = nn.Conv2d(1, 1, 5, 1, padding=2, padding_mode="circular", bias=False, dtype=torch.float64)
+            self.filter.weight.data = torch.tensor(laplace_stencil(2), dtype=torch.float64)
+            self.filter.weight.requires_grad = False
+
+    def __init__(self, dx: float = 0.2, dt: float = 0.0125):
+        super().__init__()
+        for k, v in self.INIT.items():
+            setattr(self, k, nn.Parameter(torch.tensor(v, dtype=torch.float64)))
+        self.dx = self.dy = dx
+        self.dt = dt
+        self.ndim, self.reaction = 2, "poly"
+        self.laplace_op = self._Derivative(dx ** 2)
+        self._checked = None
+
+    def param_block(self) -> torch.Tensor:
+        w = self.laplace_op.filter.weight
+        key = (w._version, w.data_ptr())
+        if self._checked != key:
+            F_pi.check_star_stencil(w)
+            self._checked = key
+        z = torch.zeros((), dtype=w.dtype, device=w.device)
+        taps = (w / self.laplace_op.resol).reshape(-1)              # the reference divides the conv result by dx^2 (:78-80)
+        flat = torch.cat([torch.tensor([self.dt], dtype=w.dtype, device=w.device), self.nu_u.reshape(1),
+                          self.nu_v.reshape(1), taps])
+        head = flat.index_select(0, F_pi._gather_index(1, 2, w.device)[:16])
+        # monomial order: 1, u, v, u^2, uv, v^2, u^3, u^2 v, u v^2, v^3
+        cu = torch.stack([z, self.C1_u, z, z, z, z, self.C2_u, self.C3_u, self.C4_u, self.C5_u])
+        cv = torch.stack([z, self.C6_v, self.C1_v, z, z, z, self.C2_v, self.C3_v, self.C4_v, self.C5_v])
+        return torch.cat([head, cu, cv])
+
+    def forward(self, h):
+        ch = F_pi.pi_step(h, self.param_block())
+        return ch, ch
+
+    def init_hidden_tensor(self, prev_state):
+        return prev_state.to(self.nu_u.device)
+
+
 class Upscaler(nn.Module):
     """IC generator (train_2drd.py:26-41, train_3drd.py:41-56): stock torch.nn, runs once per
     rollout and is off the hot path; provided so whole-model checkpoints load."""
@@ -191,7 +248,7 @@ class RCNN(nn.Module):
         setattr(self, cell_name, cell)
 
     @property
-    def cell(self) -> RCNNCell:
+    def cell(self):
         return getattr(self, self.cell_name)
 
     def trajectory(self) -> torch.Tensor:

@@ -585,3 +585,31 @@ def test_physics_residual_gradcheck_fp64(hip_device):
     Q3 = physics.gray_scott_block(cell3, 0.2, 0.1, 0.025, 0.055)
     traj3 = torch.rand((3, 2, 4, 6, 4), dtype=torch.float64, device=hip_device, requires_grad=True)
     assert torch.autograd.gradcheck(lambda t: physics.physics_residual(t, Q3), (traj3,), eps=1e-6, atol=1e-6, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# Stage-3 physics-based lambda-omega cell vs the reference script's cell
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["lo3_stage3_32x32.npz", "lo3_stage3_24x40.npz"])
+def test_stage3_lambda_omega_cell_vs_reference(name, hip_device):
+    import percnn_amd as pa
+    z = np.load(os.path.join(GOLDEN, name))
+    cell = pa.Stage3LambdaOmegaCell()
+    cell.load_state_dict({k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")})
+    cell.to(hip_device)
+    steps = int(z["steps"])
+    h0 = dev_t(z["h0"], hip_device).requires_grad_(True)
+    outs, _ = pa.RCNN(cell, step=steps, effective_step=list(range(steps)), init_state=h0)()
+    traj = torch.cat(tuple(outs), 0)
+    for t in z["keep_t"]:
+        assert rel_l2(traj[int(t)].detach().cpu().numpy(), z[f"traj/{int(t)}"]) < 1e-13, int(t)
+    loss = (traj ** 2).mean()
+    assert abs(loss.item() - float(z["loss_meansq"])) < 1e-13
+    names = list(pa.Stage3LambdaOmegaCell.INIT)
+    grads = torch.autograd.grad(loss, [getattr(cell, n) for n in names] + [h0])
+    for n, g in zip(names, grads[:-1]):
+        ref = float(z["grad_meansq/" + n])
+        assert abs(g.item() - ref) <= 1e-9 * max(abs(ref), 1e-6), (n, g.item(), ref)
+    assert rel_l2(grads[-1].cpu().numpy(), z["grad_meansq_h0"]) < 1e-11
+    a, b = cell(h0.detach())
+    assert a is b and rel_l2(a.detach().cpu().numpy()[0], z["traj/1"]) < 1e-14

@@ -165,3 +165,19 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_stage3_cell_schema_and_block():
+    """Stage-3 lambda-omega cell -- parameter names/order of the reference, coefficient block."""
+    import percnn_amd as pa
+    z = np.load(os.path.join(GOLDEN, "lo3_stage3_32x32.npz"))
+    sd = {k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}
+    cell = pa.Stage3LambdaOmegaCell()
+    assert list(cell.state_dict().keys()) == list(sd.keys())
+    cell.load_state_dict(sd)
+    Q = cell.param_block()
+    assert Q.shape == (36,) and Q.dtype == torch.float64
+    assert Q[0].item() == 0.0125 and Q[1].item() == sd["nu_u"].item() and Q[3].item() == -5.0 / 0.2 ** 2
+    assert Q[16 + 1].item() == sd["C1_u"].item() and Q[26 + 1].item() == sd["C6_v"].item() and Q[26 + 2].item() == sd["C1_v"].item()
+    Q.sum().backward()
+    assert all(getattr(cell, n).grad is not None for n in pa.Stage3LambdaOmegaCell.INIT)

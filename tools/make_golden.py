@@ -30,6 +30,7 @@ SCRIPTS = {
     "gs2d": "DataDrivenModeling/2d_gs_rd/train_2drd.py",
     "gs3d": "DataDrivenModeling/3d_gs_rd/train_3drd.py",
     "lo2d": "ForwardSimulationOfPDEs/2d_lambda_omega/percnn_LO_eqn.py",
+    "lo3": "DataDrivenDiscoveryOfPDEs/2D_Lambda_Omega_eqn/stage-3/fine_tuning_LO_[10%noise,41x51x51].py",
 }
 CKPT = {
     "gs2d": "DataDrivenModeling/2d_gs_rd/model/checkpoint.pt",
@@ -232,9 +233,48 @@ def big_case(case, mod, shape, checkpoints):
     print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
 
 
+def stage3_lo_case(mod):
+    """the Stage-3 physics-based lambda-omega cell (13 trainable scalars, Euler)."""
+    from oracle import restatement as R
+    rc = mod.RCNNCell(input_channels=2, hidden_channels=16, output_channels=2, input_kernel_size=5,
+                      input_stride=1, input_padding=2)
+    oc = R.OracleStage3LOCell()
+    assert list(rc.state_dict().keys()) == list(oc.state_dict().keys())
+    oc.load_state_dict(rc.state_dict())
+    for shape, steps, keep in (((32, 32), 40, [1, 2, 10, 40]), ((24, 40), 10, [1, 10])):
+        x = [(torch.arange(n, dtype=torch.float64) - n / 2) * 0.2 for n in shape]
+        yy, xx = torch.meshgrid(*x, indexing="ij")
+        r, th = torch.sqrt(xx ** 2 + yy ** 2), torch.atan2(yy, xx)
+        h0 = torch.stack((torch.tanh(r) * torch.cos(th - r), torch.tanh(r) * torch.sin(th - r)))[None]
+        h0r, h0o = h0.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+        tr, to = run_traj(rc, h0r, steps), run_traj(oc, h0o, steps)
+        assert torch.equal(tr, to), "stage-3 restatement differs from the reference"
+        rec = {"h0": h0.numpy(), "steps": steps, "keep_t": np.array(keep), "dx": rc.dx, "dt": rc.dt}
+        for k, v in rc.state_dict().items():
+            rec["param/" + k] = v.numpy()
+        for t in keep:
+            rec[f"traj/{t}"] = tr[t].detach().numpy()
+        lr, lo = (tr ** 2).mean(), (to ** 2).mean()
+        gr, ghr = grads_of(lr, rc, h0r)
+        go, gho = grads_of(lo, oc, h0o)
+        for n in gr:
+            assert torch.equal(gr[n], go[n]), n
+            rec["grad_meansq/" + n] = gr[n].numpy()
+        assert torch.equal(ghr, gho)
+        rec["loss_meansq"] = lr.item()
+        rec["grad_meansq_h0"] = ghr.numpy()
+        fn = os.path.join(OUT, f"lo3_stage3_{'x'.join(map(str, shape))}.npz")
+        np.savez_compressed(fn, **rec)
+        print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
+
+
 def run_case(case, big):
     mod = import_reference(case)
     torch.set_num_threads(8)
+    if case == "lo3":
+        if not big:
+            stage3_lo_case(mod)
+        return
     state, _ = ckpt_cell_state(case)
     print(f"[{case}] reference imported; default dtype {torch.get_default_dtype()}")
     if big:
