@@ -231,6 +231,11 @@ def main():
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(family, sd, shape)
+    if world == 1:
+        try:
+            out["physics_residual"] = physics_extra(pa, cell, family, traj, esz, npts)
+        except Exception as e:                       # an add-on measurement must never cost the headline line
+            out["physics_residual"] = {"error": repr(e)[:200]}
 
     # N > 1: additionally time the spatially sharded path (slab decomposition + RCCL halo exchange over
     # xGMI) on the configs[4]-shaped problem, weak-scaled: 32 planes of 256^2 per rank (256^3 at N = 8).
@@ -259,6 +264,35 @@ def main():
     emit()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def physics_extra(pa, cell, family, traj, esz, npts):
+    """the physics-residual loss consumer on the trajectory just produced -- one
+    frame-parallel residual launch and one adjoint launch, timed with HIP events."""
+    from percnn_amd import physics
+    Q = {"gs2d": lambda: physics.gray_scott_block(cell, 2e-5, 2e-5 / 4, 1 / 25, 3 / 50),
+         "gs3d": lambda: physics.gray_scott_block(cell, 0.2, 0.1, 0.025, 0.055),
+         "lo2d": lambda: physics.lambda_omega_block(cell, 0.1)}[family]()
+    F = min(traj.shape[0] - 1, 200)                   # frames (bounded: the residual tensor is another F frames)
+    sub = traj[:F + 1]
+    R = physics.physics_residual(sub, Q)              # warm-up
+    gR = torch.ones_like(R)
+    g = torch.zeros_like(sub)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record()
+    for _ in range(3):
+        physics._call("percnn_pi_residual_fwd_", sub, R, Q=Q, nframes=F)
+    ev[1].record()
+    for _ in range(3):
+        physics._call("percnn_pi_residual_bwd_", sub, gR, g[:F], Q=Q, nframes=F)
+    ev[2].record()
+    torch.cuda.synchronize()
+    tf, tb = ev[0].elapsed_time(ev[1]) / 3 * 1e-3, ev[1].elapsed_time(ev[2]) / 3 * 1e-3
+    # algorithmic bytes per point-frame: fwd read h_f, h_{f+1}, write R = 3*C*s; adjoint read h_f, g_f, write = 3*C*s
+    b = 3 * 2 * esz * npts * F
+    return {"frames": F, "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_GBps": b / tf / 1e9, "bwd_GBps": b / tb / 1e9,
+            "fwd_frac_of_8TBps": b / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac_of_8TBps": b / tb / 1e9 / HBM_PEAK_GBS,
+            "loss_value": float(physics.physics_loss(sub, Q))}
 
 
 def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=3):
