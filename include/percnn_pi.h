@@ -33,6 +33,17 @@
  *   [16 + s*(10*hc+1) + 10*hc]  Wh4_s.bias[0]
  * Gradient blocks (`param_grad`, double) use the same indexing; slots 0 and 3..15 (dt, frozen
  * stencil -- 2dgs:67) receive 0.
+ *
+ * Two further block kinds are selected through the `hc` argument of every entry point:
+ *   hc ==  0  pre-contracted polynomial block, 36 entries: [16 + 10*s + m] = coefficient of monomial m of
+ *             {1,u,v,u^2,uv,v^2,u^3,u^2 v,u v^2,v^3} in the reaction term of species s (the expansion of
+ *             Wh4(Wh1*Wh2*Wh3) the reference prints at 3dgs:442-468; also the Stage-3 lambda-omega cell,
+ *             DataDrivenDiscoveryOfPDEs/2D_Lambda_Omega_eqn/stage-3/fine_tuning_LO_[10%noise,41x51x51].py:149-152)
+ *   hc == -1  advective polynomial block, 60 entries (not in slab mode): [0..35] as above,
+ *             [36 + 4*a + i] first-derivative tap of axis a at offset {-2,-1,+1,+2}[i],
+ *             [48 + 6*s + 2*a + {0,1}] = (cu, cv) of the term (cu*u + cv*v) * D_a(h_s) in species s
+ *             (2D Burgers Stage-3 f_rhs, DataDrivenDiscoveryOfPDEs/2D_Burgers_eqn/Stage-3/
+ *             fine_tuning_[5%noise,41x51x51].py:154-157)
  */
 #ifndef PERCNN_PI_H
 #define PERCNN_PI_H

@@ -276,3 +276,42 @@ def poly_grads_to_params(qg: np.ndarray, sd: dict) -> dict:
         out[f"Wh4_{name}.weight"] = gw4.reshape((1, hc) + one)
         out[f"Wh4_{name}.bias"] = np.array([M[0]])
     return out
+
+
+# ---- advective polynomial block (Stage-3 physics-based cells) -------------------------------------------
+def adv_rollout_fwd(h0, A, T):
+    ct, suf = _ct(h0.dtype)
+    S = h0.shape[1:]
+    traj = np.empty((T + 1,) + h0.shape, dtype=h0.dtype)
+    traj[0] = h0
+    getattr(lib(), "pi_oracle_adv_rollout_fwd_" + suf)(_ptr(traj, ct), _ptr(A, ct), len(S), _shape(S), T)
+    return traj
+
+
+def adv_rollout_bwd(traj, gtraj, A):
+    ct, suf = _ct(traj.dtype)
+    T = traj.shape[0] - 1
+    S = traj.shape[2:]
+    traj, gtraj = np.ascontiguousarray(traj), np.ascontiguousarray(gtraj)
+    g0 = np.empty(traj.shape[1:], dtype=traj.dtype)
+    work = np.empty((2,) + traj.shape[1:], dtype=traj.dtype)
+    ag = np.zeros(60, dtype=np.float64)
+    getattr(lib(), "pi_oracle_adv_rollout_bwd_" + suf)(_ptr(traj, ct), _ptr(gtraj, ct), _ptr(g0, ct),
+                                                       _ptr(ag, ctypes.c_double), _ptr(work, ct), _ptr(A, ct), len(S),
+                                                       _shape(S), T)
+    return g0, ag
+
+
+def pack_burgers_stage3(sd: dict, dx: float, dt: float, dtype=np.float64) -> np.ndarray:
+    """Advective block of the Stage-3 Burgers cell (bur3:154-157) from its state_dict-like mapping."""
+    A = np.zeros(60, dtype=dtype)
+    lap = np.asarray(sd["laplace_op.filter.weight"], dtype=np.float64).reshape(5, 5) / dx ** 2
+    A[0], A[1], A[2], A[3] = dt, float(sd["nu_u"]), float(sd["nu_v"]), lap[2, 2]
+    d0 = np.asarray(sd["dx_op.filter.weight"], dtype=np.float64).reshape(5, 5) / dx      # rows: axis 0
+    d1 = np.asarray(sd["dy_op.filter.weight"], dtype=np.float64).reshape(5, 5) / dx      # columns: axis 1
+    for i, o in enumerate((-2, -1, 1, 2)):
+        A[4 + i], A[8 + i] = lap[2 + o, 2], lap[2, 2 + o]
+        A[36 + i], A[40 + i] = d0[2 + o, 2], d1[2, 2 + o]
+    A[48 + 0], A[48 + 3] = float(sd["C1_u"]), float(sd["C2_u"])          # u: C1_u*u*D0(u) + C2_u*v*D1(u)
+    A[54 + 0], A[54 + 3] = float(sd["C1_v"]), float(sd["C2_v"])          # v: C1_v*u*D0(v) + C2_v*v*D1(v)
+    return A

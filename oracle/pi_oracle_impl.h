@@ -263,6 +263,132 @@ void FN(pi_oracle_poly_rollout_bwd_)(const REAL *traj, const REAL *gtraj, REAL *
     if (T == 0) for (long i = 0; i < 2 * n; ++i) g0[i] = A[i];
 }
 
+/* ---- advective polynomial block ("adv", 60 entries) -- Stage-3 physics-based cells --------
+ * A[0..35] as the poly block Q; A[36 + 4*a + i] = first-derivative tap of axis a at offset {-2,-1,+1,+2}[i];
+ * A[48 + 6*s + 2*a + {0,1}] = coefficients (cu, cv) of the advective term (cu*u + cv*v) * D_a(h_s) in species s:
+ *   rhs_s = coef_s Lap(h_s) + r_s(u,v) + sum_a (cu_{s,a} u + cv_{s,a} v) D_a(h_s);   next = h + dt*rhs
+ * Reference: Burgers Stage-3 f_rhs, DataDrivenDiscoveryOfPDEs/2D_Burgers_eqn/Stage-3/fine_tuning_[5%noise,41x51x51].py:154-157
+ * (dx_2d_op differentiates along tensor dim 2 = axis 0, dy_2d_op along axis 1; :20-30). */
+static REAL FN(nbr_)(const REAL *f, int ndim, const long *S, const long *idx, int a, int off)
+{
+    long str = 1, lin = 0, acc = 1;
+    for (int b = ndim - 1; b >= 0; --b) { if (b == a) str = acc; lin += idx[b] * acc; acc *= S[b]; }
+    long j = FN(wrap_)(idx[a] + off, S[a]);
+    return f[lin + (j - idx[a]) * str];
+}
+
+void FN(pi_oracle_adv_step_fwd_)(const REAL *h, REAL *out, const REAL *A, int ndim, const long *S)
+{
+    static const int offs[4] = {-2, -1, 1, 2};
+    long n = 1;
+    for (int a = 0; a < ndim; ++a) n *= S[a];
+    const REAL dt = A[0];
+    long idx[3] = {0, 0, 0};
+    for (long p = 0; p < n; ++p) {
+        long r = p;
+        for (int a = ndim - 1; a >= 0; --a) { idx[a] = r % S[a]; r /= S[a]; }
+        const REAL u = h[p], v = h[n + p];
+        for (int s = 0; s < 2; ++s) {
+            REAL lap = FN(star_)(h + s * n, A, ndim, S, idx, +1);
+            REAL rr = FN(poly_r_)(A + 16 + 10 * s, u, v);
+            REAL adv = 0;
+            for (int a = 0; a < ndim; ++a) {
+                REAL d = A[36 + 4 * a] * FN(nbr_)(h + s * n, ndim, S, idx, a, offs[0]);
+                for (int i = 1; i < 4; ++i) d = FMA(A[36 + 4 * a + i], FN(nbr_)(h + s * n, ndim, S, idx, a, offs[i]), d);
+                REAL c = FMA(A[48 + 6 * s + 2 * a], u, A[48 + 6 * s + 2 * a + 1] * v);
+                adv = FMA(c, d, adv);
+            }
+            REAL res = A[1 + s] * lap + (rr + adv);
+            REAL t = res * dt;
+            out[s * n + p] = h[s * n + p] + t;
+        }
+    }
+}
+
+/* ag: double[60] accumulated gradient block (slots 1,2 coef; 16..35 moments; 48..59 advection coefficients) */
+void FN(pi_oracle_adv_step_bwd_)(const REAL *h, const REAL *G, const REAL *inj, REAL *Gprev, double *ag,
+                                 const REAL *A, int ndim, const long *S)
+{
+    static const int offs[4] = {-2, -1, 1, 2};
+    long n = 1;
+    for (int a = 0; a < ndim; ++a) n *= S[a];
+    const REAL dt = A[0];
+    long idx[3] = {0, 0, 0};
+    for (long p = 0; p < n; ++p) {
+        long r = p;
+        for (int a = ndim - 1; a >= 0; --a) { idx[a] = r % S[a]; r /= S[a]; }
+        const REAL u = h[p], v = h[n + p];
+        const REAL u2 = u * u, uv = u * v, v2 = v * v;
+        const REAL phi[10] = {1, u, v, u2, uv, v2, u2 * u, u2 * v, u * v2, v2 * v};
+        REAL dsp[2] = {0, 0};             /* pointwise contributions to (du, dv) */
+        REAL advT[2] = {0, 0};            /* transposed first-derivative stencils, per species */
+        REAL dl[2];
+        for (int s = 0; s < 2; ++s) {
+            const REAL *c = A + 16 + 10 * s;
+            REAL lg = FN(star_)(G + s * n, A, ndim, S, idx, -1);
+            dl[s] = lg * dt;
+            ag[1 + s] += (double)(dl[s] * h[s * n + p]);
+            const REAL gr = G[s * n + p] * dt;
+            ag[16 + 10 * s] += (double)gr;
+            for (int m = 1; m < 10; ++m) ag[16 + 10 * s + m] += (double)(gr * phi[m]);
+            REAL A1 = FMA(v, FMA(v, c[8], c[4]), c[1]);
+            REAL A2x2 = FMA(v, 2 * c[7], 2 * c[3]);
+            REAL ru = FMA(u, FMA(u, 3 * c[6], A2x2), A1);
+            REAL B0 = FMA(v, FMA(v, 3 * c[9], 2 * c[5]), c[2]);
+            REAL B1 = FMA(v, 2 * c[8], c[4]);
+            REAL rv = FMA(u, FMA(u, c[7], B1), B0);
+            dsp[0] = FMA(gr, ru, dsp[0]);
+            dsp[1] = FMA(gr, rv, dsp[1]);
+            for (int a = 0; a < ndim; ++a) {
+                const REAL cu = A[48 + 6 * s + 2 * a], cv = A[48 + 6 * s + 2 * a + 1];
+                REAL d = A[36 + 4 * a] * FN(nbr_)(h + s * n, ndim, S, idx, a, offs[0]);
+                for (int i = 1; i < 4; ++i) d = FMA(A[36 + 4 * a + i], FN(nbr_)(h + s * n, ndim, S, idx, a, offs[i]), d);
+                const REAL gd = gr * d;
+                ag[48 + 6 * s + 2 * a] += (double)(gd * u);
+                ag[48 + 6 * s + 2 * a + 1] += (double)(gd * v);
+                dsp[0] = FMA(gd, cu, dsp[0]);
+                dsp[1] = FMA(gd, cv, dsp[1]);
+                /* transposed stencil: sum_i tap_i * m(x - offs_i e_a),  m = (cu u + cv v) * G_s * dt */
+                for (int i = 0; i < 4; ++i) {
+                    REAL un = FN(nbr_)(h, ndim, S, idx, a, -offs[i]), vn = FN(nbr_)(h + n, ndim, S, idx, a, -offs[i]);
+                    REAL gn = FN(nbr_)(G + s * n, ndim, S, idx, a, -offs[i]);
+                    REAL m = FMA(cu, un, cv * vn) * (gn * dt);
+                    advT[s] = FMA(A[36 + 4 * a + i], m, advT[s]);
+                }
+            }
+        }
+        for (int s = 0; s < 2; ++s) {
+            REAL t = A[1 + s] * dl[s] + (dsp[s] + advT[s]);
+            REAL g = G[s * n + p] + t;
+            if (inj) g += inj[s * n + p];
+            Gprev[s * n + p] = g;
+        }
+    }
+}
+
+void FN(pi_oracle_adv_rollout_fwd_)(REAL *traj, const REAL *A, int ndim, const long *S, int T)
+{
+    long n = 1;
+    for (int a = 0; a < ndim; ++a) n *= S[a];
+    for (int t = 0; t < T; ++t)
+        FN(pi_oracle_adv_step_fwd_)(traj + (long)t * 2 * n, traj + (long)(t + 1) * 2 * n, A, ndim, S);
+}
+
+void FN(pi_oracle_adv_rollout_bwd_)(const REAL *traj, const REAL *gtraj, REAL *g0, double *ag, REAL *work,
+                                    const REAL *A, int ndim, const long *S, int T)
+{
+    long n = 1;
+    for (int a = 0; a < ndim; ++a) n *= S[a];
+    REAL *X = work, *Y = work + 2 * n;
+    for (long i = 0; i < 2 * n; ++i) X[i] = gtraj[(long)T * 2 * n + i];
+    for (int t = T; t >= 1; --t) {
+        REAL *dst = (t == 1) ? g0 : Y;
+        FN(pi_oracle_adv_step_bwd_)(traj + (long)(t - 1) * 2 * n, X, gtraj + (long)(t - 1) * 2 * n, dst, ag, A, ndim, S);
+        if (t > 1) { REAL *tmp = X; X = Y; Y = tmp; }
+    }
+    if (T == 0) for (long i = 0; i < 2 * n; ++i) g0[i] = X[i];
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

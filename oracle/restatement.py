@@ -313,3 +313,53 @@ class OracleStage3LOCell(nn.Module):
         v_next = v0 + self.dt * f_v
         ch = torch.cat((u_next, v_next), dim=1)
         return ch, ch
+
+
+# --------------------------------------------------------------------------------------
+# Stage-3 physics-based cell, 2D Burgers.  Restates
+# DataDrivenDiscoveryOfPDEs/2D_Burgers_eqn/Stage-3/fine_tuning_[5%noise,41x51x51].py (tag bur3):
+#   dx_2d_op / dy_2d_op / lap_2d_op  bur3:20-36;  Conv2dDerivative (circular conv, / resol)  bur3:56-82
+#   RCNNCell.__init__  bur3:84-152 (6 scalars, dx=dy=1/100, dt=0.00025);  f_rhs  bur3:154-157;  forward  bur3:209-221
+# --------------------------------------------------------------------------------------
+def first_derivative_stencils():
+    dx_op = np.zeros((1, 1, 5, 5)); dy_op = np.zeros((1, 1, 5, 5))
+    for i, val in zip((0, 1, 3, 4), (1 / 12, -8 / 12, 8 / 12, -1 / 12)):
+        dx_op[0, 0, i, 2] = val          # differentiates along tensor dim 2 (rows)   bur3:20-24
+        dy_op[0, 0, 2, i] = val          # along dim 3 (columns)                      bur3:26-30
+    return dx_op, dy_op
+
+
+class OracleStage3BurgersCell(nn.Module):
+    INIT = dict(nu_u=0.0050078, nu_v=0.0050228, C1_u=-0.982252, C2_u=-0.992132, C1_v=-0.983758, C2_v=-0.971269)
+
+    class _Der(nn.Module):
+        def __init__(self, stencil, resol):
+            super().__init__()
+            self.resol = resol
+            self.filter = nn.Conv2d(1, 1, 5, 1, padding=2, padding_mode="circular", bias=False)
+            self.filter.weight.data = torch.tensor(stencil, dtype=torch.float64)
+            self.filter.weight.requires_grad = False
+
+        def forward(self, x):
+            return self.filter(x) / self.resol
+
+    def __init__(self):
+        super().__init__()
+        for k, v in self.INIT.items():
+            setattr(self, k, nn.Parameter(torch.tensor(v, dtype=torch.float64)))
+        self.dx, self.dy, self.dt = 1 / 100, 1 / 100, 0.00025
+        dxo, dyo = first_derivative_stencils()
+        self.laplace_op = self._Der(laplace_stencil(2), self.dx ** 2)
+        self.dx_op = self._Der(dxo, self.dx)
+        self.dy_op = self._Der(dyo, self.dy)
+
+    def f_rhs(self, u, v):
+        f_u = self.nu_u*self.laplace_op(u) + self.C1_u*u*self.dx_op(u) + self.C2_u*v*self.dy_op(u)
+        f_v = self.nu_v*self.laplace_op(v) + self.C1_v*u*self.dx_op(v) + self.C2_v*v*self.dy_op(v)
+        return f_u, f_v
+
+    def forward(self, h):
+        u0, v0 = h[:, 0:1, ...], h[:, 1:2, ...]
+        f_u, f_v = self.f_rhs(u0, v0)
+        ch = torch.cat((u0 + self.dt * f_u, v0 + self.dt * f_v), dim=1)
+        return ch, ch

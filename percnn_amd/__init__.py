@@ -8,7 +8,7 @@ update, their adjoint, and the T-step rollout -- as hand-written HIP kernels beh
 from ._lib import build, lib, set_option, LIB_PATH  # noqa: F401
 from .functional import (pi_step, pi_rollout, pack_params, contract_block, param_count, rollout_fwd_, rollout_bwd,  # noqa: F401
                          step_fwd, step_bwd, PiStepFunction, PiRolloutFunction)
-from .modules import RCNNCell, RCNN, Upscaler, Stage3LambdaOmegaCell, gs2d_cell, gs3d_cell, lo2d_cell, laplace_stencil  # noqa: F401
+from .modules import RCNNCell, RCNN, Upscaler, Stage3LambdaOmegaCell, Stage3BurgersCell, gs2d_cell, gs3d_cell, lo2d_cell, laplace_stencil  # noqa: F401
 
 from . import slab, synthetic, physics  # noqa: F401
 

@@ -16,7 +16,7 @@ ABI_VERSION = 1
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 SOURCES = ["pi_abi.hip"]
-HEADERS = ["pi_kernels.h", "pi_tile2d.h", "pi_stream3d.h", "pi_device.h", os.path.join("..", "..", "include", "percnn_pi.h")]
+HEADERS = ["pi_kernels.h", "pi_tile2d.h", "pi_stream3d.h", "pi_adv.h", "pi_device.h", os.path.join("..", "..", "include", "percnn_pi.h")]
 
 EXPORTS = [
     "percnn_pi_abi_version", "percnn_pi_param_count", "percnn_pi_bwd_workspace_bytes",

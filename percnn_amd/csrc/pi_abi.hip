@@ -10,6 +10,7 @@
 #include "pi_kernels.h"
 #include "pi_tile2d.h"
 #include "pi_stream3d.h"
+#include "pi_adv.h"
 
 namespace {
 
@@ -82,7 +83,8 @@ struct Problem {
 
 int make_problem(int hc, int ndim, const int64_t* shape, bool slab, Problem& p)
 {
-    if (!shape || (ndim != 2 && ndim != 3) || hc < 0 || hc > 64) return PERCNN_PI_EINVAL;   // hc == 0: poly mode
+    if (!shape || (ndim != 2 && ndim != 3) || hc < -1 || hc > 64) return PERCNN_PI_EINVAL;   // hc == 0: poly, -1: advective
+    if (hc == -1 && slab) return PERCNN_PI_EINVAL;
     for (int a = 0; a < ndim; ++a)
         if (shape[a] < 2 || shape[a] > (1 << 30)) return PERCNN_PI_EINVAL;
     p.ndim = ndim; p.hc = hc; p.slab = slab;
@@ -228,6 +230,32 @@ hipError_t launch_wgrad(const T* traj, const T* adj, double* partials, const T* 
     } while (0)
 
 
+
+// ---- advective polynomial blocks (hc == -1): one fused launch per step / adjoint step -----------------
+template <typename T>
+hipError_t adv_fwd(const T* h, T* out, const T* A, const Problem& p, hipStream_t st)
+{
+    const Geom g = make_geom(p);
+    const unsigned grid = (unsigned)((p.n + 255) / 256);
+    if (p.ndim == 2) hipLaunchKernelGGL((pi::pi_adv_fwd_kernel<T, 2>), dim3(grid), dim3(256), 0, st, h, out, A, g);
+    else             hipLaunchKernelGGL((pi::pi_adv_fwd_kernel<T, 3>), dim3(grid), dim3(256), 0, st, h, out, A, g);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t adv_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partials, const T* A, const Problem& p,
+                   hipStream_t st, unsigned* rows)
+{
+    const Geom g = make_geom(p);
+    long need = (p.n + 255) / 256;
+    const unsigned grid = (unsigned)(need < MAX_BWD_BLOCKS ? need : MAX_BWD_BLOCKS);
+    if (rows) *rows = grid;
+    const size_t lds = (size_t)(256 / pi::WAVE) * pi::NADV * sizeof(double);
+    if (p.ndim == 2) hipLaunchKernelGGL((pi::pi_adv_bwd_kernel<T, 2>), dim3(grid), dim3(256), lds, st, h, G, inj, Gp, partials, A, g);
+    else             hipLaunchKernelGGL((pi::pi_adv_bwd_kernel<T, 3>), dim3(grid), dim3(256), lds, st, h, G, inj, Gp, partials, A, g);
+    return hipGetLastError();
+}
+
 // ---- plane-streaming 3D path ---------------------------------------------------------------------
 constexpr int STREAM_TY = 4;
 
@@ -296,6 +324,7 @@ hipError_t stream3d(int vec, const T* f, T* out, const T* h, const T* inj, doubl
 template <typename T>
 hipError_t step_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
 {
+    if (p.hc == -1) return adv_fwd<T>(h, out, P, p, st);
     if (const int sv = stream3d_vec<T>(p, {h, out}))
         return stream3d<T, false>(sv, h, out, nullptr, nullptr, nullptr, P, p, st, nullptr);
     const int vec = pick_vec<T>(p, {h, out});
@@ -311,6 +340,7 @@ template <typename T, bool WGRAD>
 hipError_t step_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partials, const T* P, const Problem& p,
                     hipStream_t st, unsigned* grid_out)
 {
+    if (p.hc == -1) return adv_bwd<T>(h, G, inj, Gp, partials, P, p, st, grid_out);   // always fused (tiny grids)
     if constexpr (!WGRAD)
         if (const int sv = stream3d_vec<T>(p, {h, G, inj, Gp}))
             return stream3d<T, true>(sv, G, Gp, h, inj, partials, P, p, st, grid_out);
@@ -613,7 +643,8 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
         if (r2 > rows) rows = r2;
         if (hipError_t e2 = hand_over(t - 1)) return (int)e2;
     }
-    if (g_opt.skip_wgrad || (g_opt.fuse_wgrad && t_cur == t_top)) return (int)finish_grads(w, rows, hc, param_grad, st);
+    if (g_opt.skip_wgrad || hc == -1 || (g_opt.fuse_wgrad && t_cur == t_top))
+        return (int)finish_grads(w, rows, hc, param_grad, st);
     if (ss) {
         // remaining steps (0, reduced_above] on the side stream too (ordered behind the earlier chunks), then join
         hipEvent_t ev = ss->ev[ss->next++ % 8];
@@ -668,7 +699,7 @@ int percnn_pi_debug_stamps(long long* host_out, int n)
 
 int percnn_pi_abi_version(void) { return PERCNN_PI_ABI_VERSION; }
 
-size_t percnn_pi_param_count(int hc) { return hc < 0 ? 0 : (size_t)pi::nparams(hc); }
+size_t percnn_pi_param_count(int hc) { return hc < -1 ? 0 : (size_t)pi::nparams(hc); }
 
 size_t percnn_pi_bwd_workspace_bytes(int hc, int ndim, const int64_t* shape, int elem_size)
 {

@@ -11,7 +11,8 @@ __host__ __device__ constexpr int species_block(int hc) { return 10 * hc + 1; }
 // hc == 0 selects the pre-contracted polynomial reaction: 16 header slots + 2 x 10 cubic coefficients
 constexpr int POLY = -1;          // template tag for that mode
 constexpr int NPOLY = P_W + 20;
-__host__ __device__ constexpr int nparams(int hc) { return hc == 0 ? NPOLY : P_W + 2 * species_block(hc); }
+// hc == -1 selects the advective polynomial block of the Stage-3 physics-based cells (60 entries, pi_adv.h)
+__host__ __device__ constexpr int nparams(int hc) { return hc == 0 ? NPOLY : (hc == -1 ? 60 : P_W + 2 * species_block(hc)); }
 
 constexpr int WAVE = 64;          // CDNA wavefront
 constexpr int NXCD = 8;           // MI355X: 8 XCDs, block b is dispatched to XCD b % 8

@@ -96,6 +96,7 @@ def pack_params(dt: torch.Tensor, coef_u: torch.Tensor, coef_v: torch.Tensor, w_
 # pre-contracted ("poly") reaction: Wh4(Wh1(h)*Wh2(h)*Wh3(h)) as a cubic in (u, v)
 # ------------------------------------------------------------------------------------------------
 NPOLY = 36
+NADV = 60            # advective polynomial block of the Stage-3 physics-based cells (hc = -1)
 _MONO = {(0, 0): 0, (1, 0): 1, (0, 1): 2, (2, 0): 3, (1, 1): 4, (0, 2): 5, (3, 0): 6, (2, 1): 7, (1, 2): 8, (0, 3): 9}
 _k_cache: dict = {}
 
@@ -177,6 +178,8 @@ def _hc_of(P: torch.Tensor) -> int:
     """hidden width encoded by the block length; 0 = pre-contracted polynomial block (36 entries)."""
     if P.dim() == 1 and P.numel() == NPOLY:
         return 0
+    if P.dim() == 1 and P.numel() == NADV:
+        return -1
     n = P.numel() - 16
     if P.dim() != 1 or n < 22 or n % 2 or (n // 2 - 1) % 10:
         raise RuntimeError(f"percnn_amd: parameter block has {P.numel()} entries; expected 16 + 2*(10*hc+1)")

@@ -201,6 +201,77 @@ class Stage3LambdaOmegaCell(nn.Module):
         return prev_state.to(self.nu_u.device)
 
 
+class Stage3BurgersCell(nn.Module):
+    """Stage-3 physics-based 2D Burgers cell: drop-in for ``RCNNCell`` of
+    DataDrivenDiscoveryOfPDEs/2D_Burgers_eqn/Stage-3/fine_tuning_[5%noise,41x51x51].py:84-221 --
+
+        u_t = nu_u Lap u + C1_u u u_x + C2_u v u_y,      v_t = nu_v Lap v + C1_v u v_x + C2_v v v_y    (f_rhs, :154-157)
+
+    with 4th-order central first derivatives (``dx_2d_op`` differentiates along tensor dim 2, ``dy_2d_op`` along
+    dim 3, :20-30), explicit Euler (:209-221), float64, periodic.  Parameter names as in the reference
+    (``nu_u, nu_v, C1_u, C2_u, C1_v, C2_v, laplace_op/dx_op/dy_op.filter.weight``).  One fused launch per step
+    and per adjoint step (``csrc/pi_adv.h``) instead of 6 convolutions + ~20 elementwise launches."""
+
+    INIT = dict(nu_u=0.0050078, nu_v=0.0050228, C1_u=-0.982252, C2_u=-0.992132, C1_v=-0.983758, C2_v=-0.971269)  # :123-130
+
+    class _Derivative(nn.Module):
+        def __init__(self, stencil, resol):
+            super().__init__()
+            self.resol = resol
+            self.filter = nn.Conv2d(1, 1, 5, 1, padding=2, padding_mode="circular", bias=False, dtype=torch.float64)
+            self.filter.weight.data = torch.tensor(stencil, dtype=torch.float64)
+            self.filter.weight.requires_grad = False
+
+    def __init__(self, dx: float = 1 / 100, dt: float = 0.00025):
+        super().__init__()
+        for k, v in self.INIT.items():
+            setattr(self, k, nn.Parameter(torch.tensor(v, dtype=torch.float64)))
+        self.dx = self.dy = dx
+        self.dt = dt
+        self.ndim, self.reaction = 2, "adv"
+        d0, d1 = np.zeros((1, 1, 5, 5)), np.zeros((1, 1, 5, 5))
+        for i, val in zip((0, 1, 3, 4), (1 / 12, -8 / 12, 8 / 12, -1 / 12)):
+            d0[0, 0, i, 2] = val
+            d1[0, 0, 2, i] = val
+        self.laplace_op = self._Derivative(laplace_stencil(2), dx ** 2)
+        self.dx_op = self._Derivative(d0, dx)
+        self.dy_op = self._Derivative(d1, dx)
+        self._checked = None
+
+    def param_block(self) -> torch.Tensor:
+        w = self.laplace_op.filter.weight
+        key = (w._version, w.data_ptr(), self.dx_op.filter.weight._version, self.dy_op.filter.weight._version)
+        if self._checked != key:
+            F_pi.check_star_stencil(w)
+            for op, ax in ((self.dx_op, 0), (self.dy_op, 1)):          # derivative taps must sit on their own axis
+                m = torch.ones(5, 5, dtype=torch.bool)
+                if ax == 0:
+                    m[:, 2] = False
+                else:
+                    m[2, :] = False
+                if bool((op.filter.weight.detach().reshape(5, 5).cpu()[m] != 0).any()):
+                    raise ValueError("first-derivative stencil has entries off its axis; unsupported")
+            self._checked = key
+        dev, dt_ = w.device, w.dtype
+        z = torch.zeros((), dtype=dt_, device=dev)
+        flat = torch.cat([torch.tensor([self.dt], dtype=dt_, device=dev), self.nu_u.reshape(1), self.nu_v.reshape(1),
+                          (w / self.laplace_op.resol).reshape(-1)])
+        head = flat.index_select(0, F_pi._gather_index(1, 2, dev)[:16])
+        d0 = (self.dx_op.filter.weight / self.dx_op.resol).reshape(5, 5)
+        d1 = (self.dy_op.filter.weight / self.dy_op.resol).reshape(5, 5)
+        taps = torch.stack([d0[0, 2], d0[1, 2], d0[3, 2], d0[4, 2], d1[2, 0], d1[2, 1], d1[2, 3], d1[2, 4], z, z, z, z])
+        # species u: (C1_u u) D0(u) + (C2_u v) D1(u);  species v: (C1_v u) D0(v) + (C2_v v) D1(v);  third axis unused
+        adv = torch.stack([self.C1_u, z, z, self.C2_u, z, z, self.C1_v, z, z, self.C2_v, z, z])
+        return torch.cat([head, torch.zeros(20, dtype=dt_, device=dev), taps, adv])
+
+    def forward(self, h):
+        ch = F_pi.pi_step(h, self.param_block())
+        return ch, ch
+
+    def init_hidden_tensor(self, prev_state):
+        return prev_state.to(self.nu_u.device)
+
+
 class Upscaler(nn.Module):
     """IC generator (train_2drd.py:26-41, train_3drd.py:41-56): stock torch.nn, runs once per
     rollout and is off the hot path; provided so whole-model checkpoints load."""

@@ -613,3 +613,61 @@ def test_stage3_lambda_omega_cell_vs_reference(name, hip_device):
     assert rel_l2(grads[-1].cpu().numpy(), z["grad_meansq_h0"]) < 1e-11
     a, b = cell(h0.detach())
     assert a is b and rel_l2(a.detach().cpu().numpy()[0], z["traj/1"]) < 1e-14
+
+
+@pytest.mark.parametrize("name", ["bur3_stage3_32x32.npz", "bur3_stage3_24x40.npz"])
+def test_stage3_burgers_cell_vs_reference(name, hip_device):
+    """Advective kernels (first-derivative stencils, u*u_x terms): reference script's cell (golden) and the
+    plain-C oracle (bit-identical state / adjoint state)."""
+    import percnn_amd as pa
+    from oracle import pi_oracle as O
+    z = np.load(os.path.join(GOLDEN, name))
+    sd = {k[6:]: z[k] for k in z.files if k.startswith("param/")}
+    cell = pa.Stage3BurgersCell()
+    cell.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    cell.to(hip_device)
+    steps = int(z["steps"])
+    h0 = dev_t(z["h0"], hip_device).requires_grad_(True)
+    outs, _ = pa.RCNN(cell, step=steps, effective_step=list(range(steps)), init_state=h0)()
+    traj = torch.cat(tuple(outs), 0)
+    for t in z["keep_t"]:
+        assert rel_l2(traj[int(t)].detach().cpu().numpy(), z[f"traj/{int(t)}"]) < 1e-13, int(t)
+    A = O.pack_burgers_stage3(sd, float(z["dx"]), float(z["dt"]))
+    ref = O.adv_rollout_fwd(z["h0"][0], A, steps)
+    assert np.array_equal(traj.detach().cpu().numpy(), ref)
+    loss = (traj ** 2).mean()
+    assert abs(loss.item() - float(z["loss_meansq"])) < 1e-13
+    names = list(pa.Stage3BurgersCell.INIT)
+    grads = torch.autograd.grad(loss, [getattr(cell, n) for n in names] + [h0])
+    for n, g in zip(names, grads[:-1]):
+        r = float(z["grad_meansq/" + n])
+        assert abs(g.item() - r) <= 1e-9 * abs(r), (n, g.item(), r)
+    assert rel_l2(grads[-1].cpu().numpy(), z["grad_meansq_h0"]) < 1e-11
+    g0_o, _ = O.adv_rollout_bwd(ref, 2 * ref / ref.size, A)      # autograd's dL/dtraj differs by an ulp from this one
+    assert rel_l2(grads[-1].cpu().numpy()[0], g0_o) < 1e-13
+
+
+def test_advective_block_3d_and_fp32_vs_oracle(hip_device):
+    """The advective kernels are generic over 2D/3D and fp32/fp64 (random blocks, incl. polynomial part)."""
+    import percnn_amd as pa
+    from oracle import pi_oracle as O
+    for shape, dtype in (((6, 8, 10), np.float64), ((12, 20), np.float32), ((5, 6, 7), np.float32)):
+        nd = len(shape)
+        rs = np.random.RandomState(8)
+        A = np.zeros(60, dtype=dtype)
+        A[:36] = random_block(0, nd, dtype, 3, scale=0.3)
+        A[36:36 + 4 * nd] = rs.uniform(-1, 1, 4 * nd)
+        adv = rs.uniform(-0.5, 0.5, (2, 3, 2)); adv[:, nd:] = 0
+        A[48:] = adv.reshape(-1)
+        h0 = rs.uniform(0, 1, (2,) + shape).astype(dtype)
+        T = 3
+        gt = rs.uniform(-1, 1, (T + 1, 2) + shape).astype(dtype)
+        ref = O.adv_rollout_fwd(h0, A, T)
+        g0_ref, ag_ref = O.adv_rollout_bwd(ref, gt, A)
+        traj = torch.empty((T + 1, 2) + shape, dtype=torch.from_numpy(h0).dtype, device=hip_device)
+        traj[0] = dev_t(h0, hip_device)
+        pa.rollout_fwd_(traj, dev_t(A, hip_device))
+        assert np.array_equal(traj.cpu().numpy(), ref)
+        g0, ag = pa.rollout_bwd(traj, dev_t(gt, hip_device), dev_t(A, hip_device))
+        assert np.array_equal(g0.cpu().numpy(), g0_ref)
+        assert rel_l2(ag.cpu().numpy(), ag_ref) < (2e-5 if dtype == np.float32 else 1e-12)

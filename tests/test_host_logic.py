@@ -181,3 +181,23 @@ def test_stage3_cell_schema_and_block():
     assert Q[16 + 1].item() == sd["C1_u"].item() and Q[26 + 1].item() == sd["C6_v"].item() and Q[26 + 2].item() == sd["C1_v"].item()
     Q.sum().backward()
     assert all(getattr(cell, n).grad is not None for n in pa.Stage3LambdaOmegaCell.INIT)
+
+
+def test_stage3_burgers_cell_schema_and_block():
+    """Stage-3 Burgers cell -- reference parameter names/order; advective block == oracle's."""
+    import percnn_amd as pa
+    from oracle import pi_oracle as O
+    z = np.load(os.path.join(GOLDEN, "bur3_stage3_32x32.npz"))
+    sd = {k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}
+    cell = pa.Stage3BurgersCell()
+    assert list(cell.state_dict().keys()) == list(sd.keys())
+    cell.load_state_dict(sd)
+    A = cell.param_block()
+    assert A.shape == (60,) and A.dtype == torch.float64
+    Ao = O.pack_burgers_stage3({k: v.numpy() for k, v in sd.items()}, float(z["dx"]), float(z["dt"]))
+    used = np.ones(60, bool)
+    used[12:16] = False                                    # unused third-axis Laplacian slots
+    assert np.array_equal(A.detach().numpy()[used], Ao[used])
+    A.sum().backward()
+    assert all(getattr(cell, n).grad is not None for n in pa.Stage3BurgersCell.INIT)
+    assert pa.lib().percnn_pi_param_count(-1) == 60

@@ -31,6 +31,7 @@ SCRIPTS = {
     "gs3d": "DataDrivenModeling/3d_gs_rd/train_3drd.py",
     "lo2d": "ForwardSimulationOfPDEs/2d_lambda_omega/percnn_LO_eqn.py",
     "lo3": "DataDrivenDiscoveryOfPDEs/2D_Lambda_Omega_eqn/stage-3/fine_tuning_LO_[10%noise,41x51x51].py",
+    "bur3": "DataDrivenDiscoveryOfPDEs/2D_Burgers_eqn/Stage-3/fine_tuning_[5%noise,41x51x51].py",
 }
 CKPT = {
     "gs2d": "DataDrivenModeling/2d_gs_rd/model/checkpoint.pt",
@@ -268,9 +269,51 @@ def stage3_lo_case(mod):
         print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
 
 
+def stage3_burgers_case(mod):
+    """the Stage-3 physics-based 2D Burgers cell (6 trainable scalars, Euler)."""
+    from oracle import restatement as R
+    rc = mod.RCNNCell(input_channels=2, hidden_channels=16, output_channels=2, input_kernel_size=5,
+                      input_stride=1, input_padding=2)
+    oc = R.OracleStage3BurgersCell()
+    assert list(rc.state_dict().keys()) == list(oc.state_dict().keys())
+    oc.load_state_dict(rc.state_dict())
+    for shape, steps, keep in (((32, 32), 40, [1, 2, 10, 40]), ((24, 40), 10, [1, 10])):
+        ys = torch.arange(shape[0], dtype=torch.float64) / shape[0]
+        xs = torch.arange(shape[1], dtype=torch.float64) / shape[1]
+        yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+        two_pi = 2 * np.pi
+        u = torch.sin(two_pi * xx) * torch.cos(two_pi * yy) + 0.3 * torch.cos(2 * two_pi * xx + 0.5)
+        v = torch.cos(two_pi * xx) * torch.sin(two_pi * yy) - 0.2 * torch.sin(two_pi * (xx + 2 * yy))
+        h0 = torch.stack((u, v))[None]
+        h0r, h0o = h0.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+        tr, to = run_traj(rc, h0r, steps), run_traj(oc, h0o, steps)
+        assert torch.equal(tr, to), "stage-3 Burgers restatement differs from the reference"
+        rec = {"h0": h0.numpy(), "steps": steps, "keep_t": np.array(keep), "dx": rc.dx, "dt": rc.dt}
+        for k, v_ in rc.state_dict().items():
+            rec["param/" + k] = v_.numpy()
+        for t in keep:
+            rec[f"traj/{t}"] = tr[t].detach().numpy()
+        lr, lo = (tr ** 2).mean(), (to ** 2).mean()
+        gr, ghr = grads_of(lr, rc, h0r)
+        go, gho = grads_of(lo, oc, h0o)
+        for n in gr:
+            assert torch.equal(gr[n], go[n]), n
+            rec["grad_meansq/" + n] = gr[n].numpy()
+        assert torch.equal(ghr, gho)
+        rec["loss_meansq"] = lr.item()
+        rec["grad_meansq_h0"] = ghr.numpy()
+        fn = os.path.join(OUT, f"bur3_stage3_{'x'.join(map(str, shape))}.npz")
+        np.savez_compressed(fn, **rec)
+        print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
+
+
 def run_case(case, big):
     mod = import_reference(case)
     torch.set_num_threads(8)
+    if case == "bur3":
+        if not big:
+            stage3_burgers_case(mod)
+        return
     if case == "lo3":
         if not big:
             stage3_lo_case(mod)
