@@ -360,7 +360,9 @@ bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs)
 {
     if (!g_opt.tile || g_opt.vec == 1 || p.ndim != 2 || p.slab) return false;
     if (p.hc != 0 && p.hc != 2 && p.hc != 4 && p.hc != 8) return false;
-    if (p.n0 % TILE_B || p.W % TILE_B || p.n0 < 16 || p.W < 16) return false;
+    // ragged grids (e.g. the reference's 100^2) run with partial edge tiles; the window must not wrap onto itself
+    auto fits = [](int64_t n) { return (n + TILE_B - 1) / TILE_B * TILE_B + 16 <= 2 * n; };   // one wrap per window coordinate
+    if (p.W % pi::vec_width<T>::value || !fits(p.n0) || !fits(p.W)) return false;
     for (const void* q : ptrs)
         if (q && (reinterpret_cast<uintptr_t>(q) % 16)) return false;
     return true;
@@ -370,8 +372,9 @@ template <typename T, int HC, int K, int NT, int BY = TILE_B>
 hipError_t launch_fwd_tile(T* frame_t, const T* P, const Problem& p, hipStream_t st)
 {
     using TL = pi::Tile<K, TILE_B, BY>;
-    pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, (int)(p.W / TILE_B)};
-    const unsigned grid = (unsigned)((p.n0 / BY) * (p.W / TILE_B));
+    const int tiles_x = (int)((p.W + TILE_B - 1) / TILE_B);
+    pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, tiles_x};
+    const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * tiles_x);
     const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + (size_t)g_opt.lds_pad;
     auto* k = pi::pi_fwd2d_tile_kernel<T, HC, K, TILE_B, BY, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
@@ -384,8 +387,9 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
                            int steps_to_zero, double* partials, const T* P, const Problem& p, hipStream_t st)
 {
     using TL = pi::Tile<K, TILE_B, BY>;
-    pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, (int)(p.W / TILE_B)};
-    const unsigned grid = (unsigned)((p.n0 / BY) * (p.W / TILE_B));
+    const int tiles_x = (int)((p.W + TILE_B - 1) / TILE_B);
+    pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, tiles_x};
+    const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * tiles_x);
     const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + (size_t)g_opt.lds_pad;
     auto* k = pi::pi_adj2d_tile_kernel<T, HC, K, TILE_B, BY, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
@@ -621,7 +625,10 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     int t_cur = t_top;
     if (tile_eligible<T>(p, {traj, g_traj, g_h0, adj})) {
         const int K = (g_opt.tile_k == 8 && p.hc != 0) ? 4 : g_opt.tile_k;
-        rows = (unsigned)((p.n0 / (p.hc == 0 ? g_opt.tile_by : TILE_B)) * (p.W / TILE_B));
+        {
+            const int by = p.hc == 0 ? g_opt.tile_by : TILE_B;
+            rows = (unsigned)(((p.n0 + by - 1) / by) * ((p.W + TILE_B - 1) / TILE_B));
+        }
         for (; t_cur - K >= 0; t_cur -= K) {
             unsigned m = 0;
             for (int q = 0; q < K; ++q) if (has(t_cur - 1 - q)) m |= 1u << q;

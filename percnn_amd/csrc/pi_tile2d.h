@@ -39,9 +39,10 @@ struct Tile {
 struct TileGeom {
     int H, W;          // grid
     long ss;           // species stride = H*W
-    int tiles_x;       // W / BX
+    int tiles_x;       // ceil(W / BX)
 };
 
+// window coordinates lie in [-2K, n + BX + 2K): one conditional add / subtract suffices for n >= BX + 2K (checked by the host)
 __device__ __forceinline__ int wrap1(int g, int n) { return g < 0 ? g + n : (g >= n ? g - n : g); }
 
 // stage the (LY x LX) periodic window of both species of `src` into buf[2][LY][LX]
@@ -75,6 +76,7 @@ __device__ __forceinline__ void tile_store(const T* buf, T* __restrict__ dst, co
         const int s = i / (BY * BXV);
         const int r = i - s * (BY * BXV);
         const int y = r / BXV, c = r - y * BXV;
+        if (ty0 + y >= g.H || tx0 + c * VEC >= g.W) continue;          // partial edge tile of a ragged grid
         const Pack<T, VEC> p = ld<T, VEC>(buf + s * TL::PLANE + (2 * K + y) * TL::LX + 2 * K + c * VEC);
         st<T, VEC>(dst + s * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC, p);
     }
@@ -277,12 +279,12 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
         T gc[2][4], dl[2][4];
         lds_star4<T, TL::LX, -1>(cur, ly, lx, P, gc[0], dl[0]);
         lds_star4<T, TL::LX, -1>(cur + TL::PLANE, ly, lx, P, gc[1], dl[1]);
-        const bool rowin = live && ly >= 2 * K && ly < 2 * K + BY;
+        const bool rowin = live && ly >= 2 * K && ly < 2 * K + BY && ty0 + ly - 2 * K < g.H;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             dl[0][i] *= dt;
             dl[1][i] *= dt;
-            if (rowin && lx + i >= 2 * K && lx + i < 2 * K + BX) {      // diffusion-coefficient sums: owned points only
+            if (rowin && lx + i >= 2 * K && lx + i < 2 * K + BX && tx0 + lx + i - 2 * K < g.W) {   // owned, in-grid points only
                 acc_c[0] += (double)(dl[0][i] * u[i]);
                 acc_c[1] += (double)(dl[1][i] * v[i]);
             }

@@ -381,9 +381,11 @@ def test_rccl_halo_exchange_to_self(hip_device):
                                   {"tile_k": 4, "tile_nt": 512}, {"tile_k": 4, "tile_nt": 1024}, {"tile_k": 8}, {"tile_by": 16}, {"vec": 1}])
 @pytest.mark.parametrize("dtype,hc", [(np.float32, 8), (np.float32, 2), (np.float64, 4), (np.float32, 0),
                                       (np.float64, 0)])
-def test_tile_variants_bitwise(opts, dtype, hc, hip_device):
+@pytest.mark.parametrize("shape", [(64, 96), (40, 100)])
+def test_tile_variants_bitwise(opts, dtype, hc, shape, hip_device):
+    """(64, 96): whole tiles; (40, 100): ragged grid with partial edge tiles (the reference trains on 100^2)."""
     import percnn_amd as pa
-    shape, T = (64, 96), 19                      # non-square multiple of the 32x32 tile; T not a multiple of K
+    T = 19                                       # not a multiple of K
     rs = np.random.RandomState(9)
     P = random_block(hc, 2, dtype, 13, scale=0.3)
     h0 = rs.uniform(0, 1, (2,) + shape).astype(dtype)
