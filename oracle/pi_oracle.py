@@ -315,3 +315,46 @@ def pack_burgers_stage3(sd: dict, dx: float, dt: float, dtype=np.float64) -> np.
     A[48 + 0], A[48 + 3] = float(sd["C1_u"]), float(sd["C2_u"])          # u: C1_u*u*D0(u) + C2_u*v*D1(u)
     A[54 + 0], A[54 + 3] = float(sd["C1_v"]), float(sd["C2_v"])          # v: C1_v*u*D0(v) + C2_v*v*D1(v)
     return A
+
+
+# ---------------------------------------------------------------------------------------------
+# Stage-1 Pi-block (5x5 conv branches 2 -> 16; float32).  Block layout: see pi_oracle.c / include/percnn_pi_stage1.h
+# ---------------------------------------------------------------------------------------------
+S1_NP = 16 + 6 * 16 * 52 + 32 + 2
+
+
+def s1_pack(sd: dict, dt: float, coef_u: float, coef_v: float) -> np.ndarray:
+    """state_dict of the reference's Stage-1 RCNNCell (numpy arrays) -> float32 block;
+    coef_* = nu_up * sigmoid(CA / CB) evaluated by the caller in float32 as the reference does (bur1:172-173)."""
+    P = np.zeros(S1_NP, dtype=np.float32)
+    P[0], P[1], P[2] = dt, coef_u, coef_v
+    c, taps = star_taps(np.asarray(sd["W_laplace.weight"], dtype=np.float32))
+    P[3] = c
+    P[4:8], P[8:12] = taps[0], taps[1]
+    for s, sp in enumerate("uv"):
+        for k in range(3):
+            w = np.asarray(sd[f"Wh{k + 1}_{sp}.weight"], dtype=np.float32).reshape(16, 50)
+            b = np.asarray(sd[f"Wh{k + 1}_{sp}.bias"], dtype=np.float32)
+            blk = P[16 + (s * 3 + k) * 16 * 52: 16 + (s * 3 + k + 1) * 16 * 52].reshape(16, 52)
+            blk[:, :50], blk[:, 50] = w, b
+        P[16 + 4992 + s * 16: 16 + 4992 + (s + 1) * 16] = np.asarray(sd[f"Wh4_{sp}.weight"], dtype=np.float32).reshape(16)
+        P[16 + 4992 + 32 + s] = np.asarray(sd[f"Wh4_{sp}.bias"], dtype=np.float32).reshape(())
+    return P
+
+
+def s1_step_fwd(h: np.ndarray, P: np.ndarray) -> np.ndarray:
+    h = np.ascontiguousarray(h, dtype=np.float32)
+    out = np.empty_like(h)
+    H, W = h.shape[1:]
+    lib().pi_oracle_s1_step_fwd_f32(_ptr(h, ctypes.c_float), _ptr(out, ctypes.c_float), _ptr(P, ctypes.c_float),
+                                    ctypes.c_long(H), ctypes.c_long(W))
+    return out
+
+
+def s1_rollout_fwd(h0: np.ndarray, P: np.ndarray, T: int) -> np.ndarray:
+    H, W = h0.shape[1:]
+    traj = np.empty((T + 1,) + h0.shape, dtype=np.float32)
+    traj[0] = h0
+    lib().pi_oracle_s1_rollout_fwd_f32(_ptr(traj, ctypes.c_float), _ptr(P, ctypes.c_float), ctypes.c_long(H),
+                                       ctypes.c_long(W), ctypes.c_int(T))
+    return traj

@@ -363,3 +363,59 @@ class OracleStage3BurgersCell(nn.Module):
         f_u, f_v = self.f_rhs(u0, v0)
         ch = torch.cat((u0 + self.dt * f_u, v0 + self.dt * f_v), dim=1)
         return ch, ch
+
+
+# ---------------------------------------------------------------------------------------------
+# Stage-1 Pi-block of the equation-discovery pipeline: the three parallel branches
+# are 5x5 convolutions 2 -> 16 (periodic), their Hadamard product is contracted by a 1x1 conv 16 -> 1.
+#   Burgers   DataDrivenDiscoveryOfPDEs/2D_Burgers_eqn/Stage-1/rcnn_Burgers_[...].py:54-178
+#             (explicit cat padding :160-163, convs with padding=0 :103-124, update :172-176)
+#   lambda-omega  .../2D_Lambda_Omega_eqn/stage-1/rcnn_LO_[...].py:53-172
+#             (padding_mode='circular' :102-124, update :165-168)
+# Both are float32; the state_dict schema (CA, CB, W_laplace.weight, Wh{1..4}_{u,v}.{weight,bias}) is shared.
+# ---------------------------------------------------------------------------------------------
+class OracleStage1Cell(nn.Module):
+    CONFIG = {"burgers": dict(dx=1 / 100, dt=0.00025, nu_up=0.01),
+              "lo": dict(dx=0.2, dt=0.0125, nu_up=0.2)}
+
+    def __init__(self, family="burgers", hidden_channels=16, dtype=torch.float32):
+        super().__init__()
+        cfg = self.CONFIG[family]
+        self.family, self.hidden_channels = family, hidden_channels
+        self.dx, self.dt, self.nu_up = cfg["dx"], cfg["dt"], cfg["nu_up"]
+        rs = np.random.RandomState(1234)                                   # bur1:97-99
+        self.CA = nn.Parameter(torch.tensor(rs.rand(), dtype=dtype))
+        self.CB = nn.Parameter(torch.tensor(rs.rand(), dtype=dtype))
+        # the two reference scripts pad differently (same values, different autograd graph => the backward
+        # accumulates in a different order); mirror each so gradients are bit-identical too
+        pad = dict(padding=0) if family == "burgers" else dict(padding=2, padding_mode="circular")
+        self.W_laplace = nn.Conv2d(1, 1, 5, 1, bias=False, **pad)
+        self.W_laplace.weight.data = (1 / self.dx ** 2 * torch.tensor(laplace_stencil(2))).to(dtype).reshape(1, 1, 5, 5)
+        self.W_laplace.weight.requires_grad = False
+        for s in "uv":
+            for k in (1, 2, 3):
+                setattr(self, f"Wh{k}_{s}", nn.Conv2d(2, hidden_channels, 5, 1, bias=True, dtype=dtype, **pad))
+            setattr(self, f"Wh4_{s}", nn.Conv2d(hidden_channels, 1, 1, 1, padding=0, bias=True, dtype=dtype))
+        for s in "uv":                                                     # bur1:130-141 (c = 0.5)
+            for k in (1, 2, 3, 4):
+                f = getattr(self, f"Wh{k}_{s}")
+                bound = 0.5 * np.sqrt(1 / np.prod(f.weight.shape[:-1]))
+                f.weight.data.uniform_(-bound, bound)
+                f.bias.data.fill_(0.0)
+
+    def forward(self, h):
+        if self.family == "burgers":                                       # bur1:160-166
+            hp = torch.cat((h[:, :, :, -2:], h, h[:, :, :, 0:2]), dim=3)
+            hp = torch.cat((hp[:, :, -2:, :], hp, hp[:, :, 0:2, :]), dim=2)
+            lap_in = (hp[:, 0:1, ...], hp[:, 1:2, ...])
+            u_prev, v_prev = h[:, 0:1, ...], h[:, 1:2, ...]
+        else:                                                              # lo1:161-166 (one slice feeds both uses)
+            hp = h
+            u_prev, v_prev = h[:, 0:1, ...], h[:, 1:2, ...]
+            lap_in = (u_prev, v_prev)
+        u_res = self.nu_up * torch.sigmoid(self.CA) * self.W_laplace(lap_in[0]) + self.Wh4_u(self.Wh1_u(hp) * self.Wh2_u(hp) * self.Wh3_u(hp))
+        v_res = self.nu_up * torch.sigmoid(self.CB) * self.W_laplace(lap_in[1]) + self.Wh4_v(self.Wh1_v(hp) * self.Wh2_v(hp) * self.Wh3_v(hp))
+        u_next = u_prev + u_res * self.dt
+        v_next = v_prev + v_res * self.dt
+        ch = torch.cat((u_next, v_next), dim=1)
+        return ch, ch

@@ -10,6 +10,7 @@ from .functional import (pi_step, pi_rollout, pack_params, contract_block, param
                          step_fwd, step_bwd, PiStepFunction, PiRolloutFunction)
 from .modules import RCNNCell, RCNN, Upscaler, Stage3LambdaOmegaCell, Stage3BurgersCell, gs2d_cell, gs3d_cell, lo2d_cell, laplace_stencil  # noqa: F401
 
-from . import slab, synthetic, physics  # noqa: F401
+from . import slab, synthetic, physics, stage1  # noqa: F401
+from .stage1 import Stage1Cell  # noqa: F401
 
 __version__ = "0.1.0"

@@ -14,27 +14,46 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("PERCNN_PI_LIB", os.path.join(CSRC, "libpercnn_pi.so"))
 ABI_VERSION = 1
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
-SOURCES = ["pi_abi.hip"]
-HEADERS = ["pi_kernels.h", "pi_tile2d.h", "pi_stream3d.h", "pi_adv.h", "pi_device.h", os.path.join("..", "..", "include", "percnn_pi.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+_INC = os.path.join("..", "..", "include")
+# translation unit -> headers it depends on (all under csrc/ unless a path is given)
+SOURCES = {
+    "pi_abi.hip": ["pi_kernels.h", "pi_tile2d.h", "pi_stream3d.h", "pi_adv.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h")],
+    "pi_s1_abi.hip": ["pi_s1.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h"), os.path.join(_INC, "percnn_pi_stage1.h")],
+}
 
 EXPORTS = [
     "percnn_pi_abi_version", "percnn_pi_param_count", "percnn_pi_bwd_workspace_bytes",
     "percnn_pi_rollout_bwd_workspace_bytes", "percnn_pi_set_option",
 ] + [f"percnn_pi_{op}_{suf}" for suf in ("f32", "f64")
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
-                "residual_fwd", "residual_bwd")]
+                "residual_fwd", "residual_bwd")] + [
+    "percnn_pi_s1_param_count", "percnn_pi_s1_step_fwd_f32", "percnn_pi_s1_rollout_fwd_f32",
+    "percnn_pi_s1_rollout_bwd_workspace_bytes", "percnn_pi_s1_rollout_bwd_f32",
+]
 
 
 def build(force: bool = False, extra_flags=(), out: str | None = None) -> str:
-    """Compile the HIP kernels + C-ABI for gfx950 with hipcc (cross-compiles without a GPU)."""
+    """Compile the HIP kernels + C-ABI for gfx950 with hipcc (cross-compiles without a GPU).
+    One object per translation unit (rebuilt only when it or its headers changed), linked into one library."""
     out = out or os.path.join(CSRC, "libpercnn_pi.so")
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
-        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
-    subprocess.check_call(cmd, cwd=CSRC)
+    tag = "" if not extra_flags else "_" + str(abs(hash(tuple(extra_flags))) % 10 ** 8)
+    objs, relink = [], force or not os.path.exists(out)
+    procs = []
+    for src, hdrs in SOURCES.items():
+        obj = os.path.join(CSRC, src.replace(".hip", tag + ".o"))
+        deps = [os.path.join(CSRC, d) for d in [src] + hdrs]
+        objs.append(obj)
+        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in deps):
+            cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-c", "-o", obj, os.path.join(CSRC, src)]
+            procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+            relink = True
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    if relink or any(os.path.getmtime(out) < os.path.getmtime(o) for o in objs):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs, cwd=CSRC)
     return out
 
 
@@ -85,6 +104,14 @@ def lib() -> ctypes.CDLL:
         f.restype, f.argtypes = ci, [vp, vp, ci, ci, i64p, ci, vp]
         f = getattr(L, f"percnn_pi_rollout_bwd_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, ctypes.c_char_p, vp, vp, vp, sz, vp, ci, ci, i64p, ci, vp]
+    L.percnn_pi_s1_param_count.restype = sz
+    L.percnn_pi_s1_param_count.argtypes = []
+    L.percnn_pi_s1_step_fwd_f32.restype, L.percnn_pi_s1_step_fwd_f32.argtypes = ci, [vp, vp, vp, i64p, vp]
+    L.percnn_pi_s1_rollout_fwd_f32.restype, L.percnn_pi_s1_rollout_fwd_f32.argtypes = ci, [vp, vp, i64p, ci, vp]
+    L.percnn_pi_s1_rollout_bwd_workspace_bytes.restype = sz
+    L.percnn_pi_s1_rollout_bwd_workspace_bytes.argtypes = [i64p, ci]
+    L.percnn_pi_s1_rollout_bwd_f32.restype = ci
+    L.percnn_pi_s1_rollout_bwd_f32.argtypes = [vp, vp, ctypes.c_char_p, vp, vp, vp, sz, vp, i64p, ci, vp]
     _lib = L
     return L
 

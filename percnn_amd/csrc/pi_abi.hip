@@ -363,6 +363,13 @@ bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs)
     // ragged grids (e.g. the reference's 100^2) run with partial edge tiles; the window must not wrap onto itself
     auto fits = [](int64_t n) { return (n + TILE_B - 1) / TILE_B * TILE_B + 16 <= 2 * n; };   // one wrap per window coordinate
     if (p.W % pi::vec_width<T>::value || !fits(p.n0) || !fits(p.W)) return false;
+    // the adjoint tile kernel owns one partial row per workgroup: beyond MAX_BWD_BLOCKS tiles the grid-stride
+    // direct kernels take over (4096^2 = 16384 tiles)
+    const int64_t by = p.hc == 0 ? g_opt.tile_by : TILE_B;
+    if (((p.n0 + by - 1) / by) * ((p.W + TILE_B - 1) / TILE_B) > MAX_BWD_BLOCKS) return false;
+    // temporal blocking pays while launches are latency-bound; from ~1 M points the halo ring's redundant traffic
+    // costs more than the launches it saves (measured: profiles/r01_size_sweep.txt), tile = 2 forces the tile path
+    if (g_opt.tile == 1 && p.n >= (1 << 20)) return false;
     for (const void* q : ptrs)
         if (q && (reinterpret_cast<uintptr_t>(q) % 16)) return false;
     return true;
@@ -733,7 +740,11 @@ int percnn_pi_set_option(const char* key, long value)
         g_opt.vec = (int)value;
         return 0;
     }
-    if (!std::strcmp(key, "tile")) { g_opt.tile = value != 0; return 0; }
+    if (!std::strcmp(key, "tile")) {                       // 0 = never, 1 = size heuristic, 2 = whenever eligible
+        if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
+        g_opt.tile = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "tile_by")) {
         if (value != 16 && value != 32) return PERCNN_PI_EINVAL;
         g_opt.tile_by = (int)value;

@@ -1,0 +1,135 @@
+// C-ABI of the Stage-1 Pi-block (include/percnn_pi_stage1.h); second translation unit of libpercnn_pi.so.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/percnn_pi.h"
+#include "../../include/percnn_pi_stage1.h"
+#include "pi_s1.h"
+
+namespace {
+
+using pi::s1::Geom;
+
+constexpr int MAX_GRID_X = 2048;      // workgroups per species; waves grid-stride over patches beyond that
+
+bool make_geom(const int64_t* shape, Geom& g)
+{
+    if (!shape || shape[0] < 8 || shape[1] < 8 || shape[0] > (1 << 15) || shape[1] > (1 << 15)) return false;
+    g.H = (int)shape[0];
+    g.W = (int)shape[1];
+    g.px = (g.W + 3) / 4;
+    g.npatch = ((g.H + 3) / 4) * g.px;
+    g.n = (long)g.H * g.W;
+    return true;
+}
+
+unsigned grid_x(const Geom& g)
+{
+    const int need = (g.npatch + pi::s1::WAVES - 1) / pi::s1::WAVES;
+    return (unsigned)(need < MAX_GRID_X ? need : MAX_GRID_X);
+}
+
+hipError_t step_fwd(const float* h, float* out, const float* P, const Geom& g, hipStream_t st)
+{
+    hipLaunchKernelGGL(pi::s1::s1_fwd_kernel, dim3(grid_x(g), 2), dim3(64 * pi::s1::WAVES), 0, st, h, out, P, g);
+    return hipGetLastError();
+}
+
+constexpr int WGRAD_GRID_X = 256;     // x 2 species = 2 workgroups per CU; one float row of partials each
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Workspace {
+    float* adj;        // [T+1][2][n]
+    float* D;          // [2 (step parity)][2 species][50 taps][n]
+    float* partials;   // [WGRAD_GRID_X][2][ROW]
+    double* partials_d;// [WGRAD_GRID_X][2][ROWD]
+    size_t bytes;
+};
+
+Workspace carve(void* base, const Geom& g, int T)
+{
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t nfloat) { float* p = base ? reinterpret_cast<float*>((char*)base + off) : nullptr;
+                                     off += align_up(nfloat * sizeof(float), 256); return p; };
+    w.adj = take((size_t)(T + 1) * 2 * g.n);
+    w.D = take((size_t)2 * 2 * pi::s1::NTAP * g.n);
+    w.partials = take((size_t)WGRAD_GRID_X * 2 * pi::s1::ROW);
+    w.partials_d = reinterpret_cast<double*>(take((size_t)WGRAD_GRID_X * 2 * pi::s1::ROWD * 2));
+    w.bytes = off;
+    return w;
+}
+
+hipError_t adj_step(const float* h_prev, const float* inj, const float* adj_next, const float* D_next, float* adj_out,
+                    float* D_out, const float* P, const Geom& g, hipStream_t st)
+{
+    hipLaunchKernelGGL(pi::s1::s1_adj_kernel, dim3(grid_x(g), 2), dim3(64 * pi::s1::WAVES), 0, st, h_prev, inj, adj_next,
+                       D_next, adj_out, D_out, P, g);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t percnn_pi_s1_param_count(void) { return pi::s1::NP; }
+
+int percnn_pi_s1_step_fwd_f32(const float* h, float* h_next, const float* params, const int64_t* shape, void* stream)
+{
+    Geom g;
+    if (!h || !h_next || !params || h == h_next || !make_geom(shape, g)) return PERCNN_PI_EINVAL;
+    return (int)step_fwd(h, h_next, params, g, static_cast<hipStream_t>(stream));
+}
+
+int percnn_pi_s1_rollout_fwd_f32(float* traj, const float* params, const int64_t* shape, int T_steps, void* stream)
+{
+    Geom g;
+    if (!traj || !params || T_steps < 0 || !make_geom(shape, g)) return PERCNN_PI_EINVAL;
+    const size_t frame = (size_t)2 * g.n;
+    for (int t = 0; t < T_steps; ++t)
+        if (hipError_t e = step_fwd(traj + t * frame, traj + (t + 1) * frame, params, g, static_cast<hipStream_t>(stream)))
+            return (int)e;
+    return 0;
+}
+
+size_t percnn_pi_s1_rollout_bwd_workspace_bytes(const int64_t* shape, int T_steps)
+{
+    Geom g;
+    if (T_steps < 0 || !make_geom(shape, g)) return 0;
+    return carve(nullptr, g, T_steps).bytes;
+}
+
+int percnn_pi_s1_rollout_bwd_f32(const float* traj, const float* g_traj, const unsigned char* frame_mask, float* g_h0,
+                                 double* param_grad, void* workspace, size_t workspace_bytes, const float* params,
+                                 const int64_t* shape, int T_steps, void* stream)
+{
+    Geom g;
+    if (!traj || !g_traj || !g_h0 || !param_grad || !params || T_steps < 0 || !make_geom(shape, g))
+        return PERCNN_PI_EINVAL;
+    const Workspace w = carve(workspace, g, T_steps);
+    if (!workspace || workspace_bytes < w.bytes || (reinterpret_cast<uintptr_t>(workspace) % 16)) return PERCNN_PI_EWORKSPACE;
+    auto st = static_cast<hipStream_t>(stream);
+    const size_t frame = (size_t)2 * g.n, dsz = (size_t)2 * pi::s1::NTAP * g.n;
+    auto inj = [&](int t) { return (!frame_mask || frame_mask[t]) ? g_traj + t * frame : nullptr; };
+    auto D = [&](int t) { return w.D + (size_t)(t & 1) * dsz; };
+    for (int t = T_steps; t >= 0; --t) {
+        const bool top = t == T_steps;
+        hipError_t e = adj_step(t > 0 ? traj + (size_t)(t - 1) * frame : nullptr, inj(t),
+                                top ? nullptr : w.adj + (size_t)(t + 1) * frame, top ? nullptr : D(t + 1),
+                                t > 0 ? w.adj + (size_t)t * frame : g_h0, t > 0 ? D(t) : nullptr, params, g, st);
+        if (e) return (int)e;
+    }
+    const long ntask = (long)T_steps * g.npatch;
+    long gx = (ntask + pi::s1::WAVES - 1) / pi::s1::WAVES;
+    gx = gx < 1 ? 1 : (gx > WGRAD_GRID_X ? WGRAD_GRID_X : gx);
+    hipLaunchKernelGGL(pi::s1::s1_wgrad_kernel, dim3((unsigned)gx, 2), dim3(64 * pi::s1::WAVES), 0, st, traj, w.adj,
+                       w.partials, w.partials_d, params, g, T_steps);
+    if (hipError_t e = hipGetLastError()) return (int)e;
+    hipLaunchKernelGGL(pi::s1::s1_reduce_kernel, dim3((pi::s1::NP + 255) / 256), dim3(256), 0, st, w.partials, w.partials_d,
+                       (int)gx, param_grad);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

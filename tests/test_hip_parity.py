@@ -318,6 +318,32 @@ def test_full_size_step_bitwise_and_translation_equivariance(shape, hc, dtype, h
     assert torch.equal(out_s, torch.roll(out, shifts, dims))
 
 
+@pytest.mark.parametrize("shape,hc,T", [((4096, 4096), 0, 4), ((4096, 4096), 8, 2), ((2048, 4096), 0, 4)])
+def test_large_2d_rollout_bitwise(shape, hc, T, hip_device):
+    """Grids larger than any reference config (16.7 M points: more tiles than the adjoint tile kernel has
+    partial rows -> grid-stride kernels; 8.4 M points: 4096 tiles, the tile path's upper edge): short rollout
+    forward and adjoint state bit-identical to the C oracle."""
+    import percnn_amd as pa
+    rs = np.random.RandomState(11)
+    P = random_block(hc, 2, np.float32, 8, scale=0.3)
+    h0 = rs.uniform(0.2, 0.8, (2,) + shape).astype(np.float32)
+    traj_o = o_rollout_fwd(h0, P, T)
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=hip_device)
+    traj[0] = dev_t(h0, hip_device)
+    Pd = dev_t(P, hip_device)
+    g = (rs.standard_normal(traj_o.shape) * 1e-3).astype(np.float32)
+    pa.set_option("tile", 2)          # 2 = tile kernels whenever eligible (default 1 switches to direct kernels at 1 M points)
+    try:
+        pa.rollout_fwd_(traj, Pd)
+        g0, pg = pa.rollout_bwd(traj, dev_t(g, hip_device), Pd)
+    finally:
+        pa.set_option("tile", 1)
+    assert np.array_equal(traj.cpu().numpy(), traj_o)
+    g0_o, pg_o = o_rollout_bwd(traj_o, g, P)
+    assert np.array_equal(g0.cpu().numpy(), g0_o)
+    assert rel_l2(pg.cpu().numpy(), pg_o) < 5e-5
+
+
 def test_adjoint_dot_product_identity_fp64_full_size(hip_device):
     """<J v, w> == <v, J^T w> for the 512^2 float64 step (linearisation by central differences)."""
     import percnn_amd as pa

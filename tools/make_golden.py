@@ -32,11 +32,15 @@ SCRIPTS = {
     "lo2d": "ForwardSimulationOfPDEs/2d_lambda_omega/percnn_LO_eqn.py",
     "lo3": "DataDrivenDiscoveryOfPDEs/2D_Lambda_Omega_eqn/stage-3/fine_tuning_LO_[10%noise,41x51x51].py",
     "bur3": "DataDrivenDiscoveryOfPDEs/2D_Burgers_eqn/Stage-3/fine_tuning_[5%noise,41x51x51].py",
+    "bur1": "DataDrivenDiscoveryOfPDEs/2D_Burgers_eqn/Stage-1/rcnn_Burgers_[resnet,GT41x51x51,LAPLACE,5%noise].py",
+    "lo1": "DataDrivenDiscoveryOfPDEs/2D_Lambda_Omega_eqn/stage-1/rcnn_LO_[resnet,GT41x51x51,LAPLACE,5%noise].py",
 }
 CKPT = {
     "gs2d": "DataDrivenModeling/2d_gs_rd/model/checkpoint.pt",
     "gs3d": "DataDrivenModeling/3d_gs_rd/model/checkpoint.pt",
     "lo2d": "ForwardSimulationOfPDEs/2d_lambda_omega/model/rcnn_pde.pt",
+    "bur1": "DataDrivenDiscoveryOfPDEs/2D_Burgers_eqn/Stage-1/model/checkpoint.pt",
+    "lo1": "DataDrivenDiscoveryOfPDEs/2D_Lambda_Omega_eqn/stage-1/model/checkpoint.pt",
 }
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -307,9 +311,71 @@ def stage3_burgers_case(mod):
         print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
 
 
+def stage1_case(mod, case):
+    """the Stage-1 Pi-block (three 5x5 conv branches 2 -> 16 per species), float32, with the
+    reference's own trained weights (Stage-1 checkpoint)."""
+    from oracle import restatement as R
+    fam = {"bur1": "burgers", "lo1": "lo"}[case]
+    state, _ = ckpt_cell_state(case)
+    rc = mod.RCNNCell(input_channels=2, hidden_channels=16, output_channels=2, input_kernel_size=5,
+                      input_stride=1, input_padding=2)
+    oc = R.OracleStage1Cell(fam)
+    assert list(rc.state_dict().keys()) == list(oc.state_dict().keys())
+    assert all(rc.state_dict()[k].shape == oc.state_dict()[k].shape and rc.state_dict()[k].dtype == oc.state_dict()[k].dtype
+               for k in rc.state_dict())
+    assert (rc.dx, rc.dt, rc.nu_up) == (oc.dx, oc.dt, oc.nu_up)
+    rc.load_state_dict(state); oc.load_state_dict(state)
+    o64 = R.OracleStage1Cell(fam, dtype=torch.float64)
+    o64.load_state_dict({k: v.double() for k, v in state.items()})
+    for shape, steps, keep in (((32, 32), 40, [1, 2, 10, 40]), ((24, 40), 10, [1, 10]), ((22, 26), 6, [1, 6]),
+                               ((100, 100), 200, [1, 20, 200])):
+        ys = torch.arange(shape[0], dtype=torch.float64) / shape[0]
+        xs = torch.arange(shape[1], dtype=torch.float64) / shape[1]
+        yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+        two_pi = 2 * np.pi
+        u = 0.6 * torch.sin(two_pi * xx) * torch.cos(two_pi * yy) + 0.3 * torch.cos(2 * two_pi * xx + 0.5)
+        v = 0.6 * torch.cos(two_pi * xx) * torch.sin(two_pi * yy) - 0.2 * torch.sin(two_pi * (xx + 2 * yy))
+        h0 = torch.stack((u, v))[None].float()
+        h0r, h0o = h0.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+        tr, to = run_traj(rc, h0r, steps), run_traj(oc, h0o, steps)
+        assert torch.equal(tr, to), "stage-1 restatement differs from the reference"
+        assert torch.isfinite(tr).all()
+        rec = {"h0": h0.numpy(), "steps": steps, "keep_t": np.array(keep), "dx": rc.dx, "dt": rc.dt, "nu_up": rc.nu_up}
+        for k, v_ in rc.state_dict().items():
+            rec["param/" + k] = v_.numpy()
+        for t in keep:
+            rec[f"traj/{t}"] = tr[t].detach().numpy()
+        lr, lo = (tr ** 2).mean(), (to ** 2).mean()
+        gr, ghr = grads_of(lr, rc, h0r)
+        go, gho = grads_of(lo, oc, h0o)
+        h64 = h0.double().requires_grad_(True)
+        t64 = run_traj(o64, h64, steps)
+        g64, gh64 = grads_of((t64 ** 2).mean(), o64, h64)
+        worst = 0.0
+        for n in gr:
+            assert torch.equal(gr[n], go[n]), n
+            rec["grad_meansq/" + n] = gr[n].numpy()
+            rec["grad64_meansq/" + n] = g64[n].numpy()
+            worst = max(worst, ((gr[n].double() - g64[n]).norm() / g64[n].norm()).item())
+        assert torch.equal(ghr, gho)
+        rec["loss_meansq"] = lr.item()
+        rec["grad_meansq_h0"] = ghr.numpy()
+        rec["grad64_meansq_h0"] = gh64.numpy()
+        rec["traj64_last"] = t64[-1].detach().numpy()
+        print(f"  {case} {shape}: fp32 reference vs fp64: traj rel {((tr[-1].double()-t64[-1]).norm()/t64[-1].norm()).item():.2e}, "
+              f"worst param-grad rel {worst:.2e}, |h| max {tr.abs().max().item():.3f}")
+        fn = os.path.join(OUT, f"{case}_stage1_{'x'.join(map(str, shape))}.npz")
+        np.savez_compressed(fn, **rec)
+        print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
+
+
 def run_case(case, big):
     mod = import_reference(case)
     torch.set_num_threads(8)
+    if case in ("bur1", "lo1"):
+        if not big:
+            stage1_case(mod, case)
+        return
     if case == "bur3":
         if not big:
             stage3_burgers_case(mod)
