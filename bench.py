@@ -33,6 +33,13 @@ WORKLOADS = {
     "gs3d_128": ("gs3d", (128, 128, 128), 2, torch.float32, 500, "gs3d_big_128x128x128.npz"),
     "lo2d_512": ("lo2d", (512, 512), 4, torch.float64, 400, "lo2d_big_512x512.npz"),
 }
+# Stage-1 Pi-block (5x5 conv branches 2 -> 16 on the matrix cores): name -> (family, shape, T, golden)
+STAGE1 = {
+    "bur1_100": ("burgers", (100, 100), 200, "bur1_stage1_32x32.npz"),      # the reference's Stage-1 grid and horizon (bur1:914-935)
+    "lo1_100": ("lo", (100, 100), 200, "lo1_stage1_32x32.npz"),
+    "bur1_512": ("burgers", (512, 512), 50, "bur1_stage1_32x32.npz"),
+}
+MFMA_F32_PEAK_TFS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, 2.4 GHz
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
@@ -93,7 +100,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="gs2d_512", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="gs2d_512", choices=list(WORKLOADS) + list(STAGE1))
     ap.add_argument("--T", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reaction", default="poly", choices=["poly", "factored"],
@@ -116,6 +123,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import percnn_amd as pa
+    if a.workload in STAGE1:
+        return stage1_main(a, pa, dev, dist, rank, world)
     for kv in a.opt:
         k, v = kv.split("=")
         pa.set_option(k, int(v))
@@ -264,6 +273,146 @@ def main():
     emit()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def stage1_main(a, pa, dev, dist, rank, world):
+    """Stage-1 Pi-block: T-step rollout forward + backward on the matrix cores.  Same JSON contract; the roofline of the
+    dominant kernel is priced against the dense f32 MFMA peak (the branch evaluation is a K = 51 contraction)."""
+    family, shape, T_def, golden = STAGE1[a.workload]
+    T = a.T or T_def
+    sd = load_params(golden)
+    cell = pa.Stage1Cell(family).to(dev)
+    cell.load_state_dict(sd)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        pa.stage1.set_option(k, int(v))
+    n = shape[0] * shape[1]
+    ys, xs = torch.meshgrid(torch.arange(shape[0]) / shape[0], torch.arange(shape[1]) / shape[1], indexing="ij")
+    h0 = torch.stack((0.6 * torch.sin(2 * np.pi * xs) * torch.cos(2 * np.pi * ys) + 0.3 * torch.cos(4 * np.pi * xs + 0.5),
+                      0.6 * torch.cos(2 * np.pi * xs) * torch.sin(2 * np.pi * ys) - 0.2 * torch.sin(2 * np.pi * (xs + 2 * ys))))
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=dev)
+    traj[0] = h0.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    gtraj = torch.randn(traj.shape, dtype=torch.float32, device=dev, generator=gen) * (2.0 / traj.numel())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
+
+    def one_pass(e=None):
+        if e: e[0].record()
+        with torch.no_grad():
+            P = cell.param_block().contiguous()       # packing is part of every pass
+        pa.stage1.rollout_fwd_(traj, P)
+        if e: e[1].record()
+        g0, pg = pa.stage1.rollout_bwd(traj, gtraj, P)
+        if e: e[2].record()
+        return g0, pg, P
+
+    for _ in range(a.warmup):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        g0, pg, P = one_pass(ev[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert torch.isfinite(g0).all() and torch.isfinite(pg).all() and torch.isfinite(traj[-1]).all()
+    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    value = world * a.steps * T / elapsed
+
+    pa.stage1.set_option("skip_wgrad", 1)            # time the sweep kernel alone
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    pa.stage1.rollout_bwd(traj, gtraj, P)
+    e0.record()
+    for _ in range(a.steps):
+        pa.stage1.rollout_bwd(traj, gtraj, P)
+    e1.record()
+    torch.cuda.synchronize()
+    pa.stage1.set_option("skip_wgrad", 0)
+    sweep_ms = e0.elapsed_time(e1) / a.steps
+    red_ms = max(bwd_ms - sweep_ms, 1e-6)
+
+    # algorithmic flops per point and time step: one branch evaluation = 2 species x 3 branches x 16 channels x 50 taps
+    # MACs = 9600 flop; the sweep adds the input-gradient contraction (same size), the gradient kernel recomputes the
+    # branches and adds the weight-gradient contraction (same size)
+    FB = 2 * 2 * 3 * 16 * 50
+    kernels = [
+        {"kernel": "s1_fwd_kernel", "launches_per_pass": T, "algorithmic_flops_per_launch": FB * n,
+         "avg_launch_us": fwd_ms * 1e3 / T},
+        {"kernel": "s1_adj_kernel", "launches_per_pass": T + 1, "algorithmic_flops_per_launch": 2 * FB * n,
+         "avg_launch_us": sweep_ms * 1e3 / (T + 1)},
+        {"kernel": "s1_wgrad_kernel", "launches_per_pass": 1, "algorithmic_flops_per_launch": 2 * FB * n * T,
+         "avg_launch_us": red_ms * 1e3},
+    ]
+    for k in kernels:
+        k["achieved"] = k["algorithmic_flops_per_launch"] / (k["avg_launch_us"] * 1e-6) / 1e12
+        k["frac"] = k["achieved"] / MFMA_F32_PEAK_TFS
+        k["share_of_pass"] = k["avg_launch_us"] * k["launches_per_pass"] / ((fwd_ms + bwd_ms) * 1e3)
+    dom = max(kernels, key=lambda k: k["share_of_pass"])
+    out = {
+        "metric": "pi_block_rollout_fwd_bwd_steps_per_sec", "value": value, "unit": "steps/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{a.workload}: Stage-1 Pi-block ({family}; three 5x5 conv branches 2->16 per species) "
+                               f"{shape[0]}x{shape[1]}, T={T} forward+backward rollout per step, dense dL/dtraj",
+                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (no collective)",
+                   "points": n, "T": T, "time_steps_per_launch": 1},
+        "roofline": {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": MFMA_F32_PEAK_TFS,
+                     "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None,
+                     "algorithmic_flops_per_launch": dom["algorithmic_flops_per_launch"],
+                     "avg_launch_us": dom["avg_launch_us"], "all_kernels": kernels},
+        "fwd_us_per_time_step": fwd_ms * 1e3 / T, "bwd_us_per_time_step": bwd_ms * 1e3 / T,
+        "fwd_only_steps_per_sec": T / (fwd_ms * 1e-3),
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = stage1_cpu_baseline(family, sd, h0, shape)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def stage1_cpu_baseline(family, sd, h0, shape, budget_s=15.0):
+    """The torch restatement of the reference's Stage-1 cell (bit-identical to the imported reference scripts, trajectory
+    and gradients) on this box's host cores."""
+    from oracle import restatement as R
+    cell = R.OracleStage1Cell(family)
+    cell.load_state_dict(sd)
+
+    def run(nsteps):
+        t0 = time.perf_counter()
+        h = h0[None].clone().requires_grad_(True)
+        outs, x = [h], h
+        for _ in range(nsteps):
+            x, _ = cell(x)
+            outs.append(x)
+        (torch.cat(outs) ** 2).mean().backward()
+        return time.perf_counter() - t0
+
+    ncpu = os.cpu_count() or 1
+    best = None
+    for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(th)
+        run(1)
+        t1 = run(4) / 4
+        if best is None or t1 < best[1]:
+            best = (th, t1)
+    cores, t_probe = best
+    torch.set_num_threads(cores)
+    nsteps = int(max(4, min(400, budget_s / max(t_probe, 1e-6))))
+    t = run(nsteps)
+    return {"value": nsteps / t, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{nsteps}-step fwd+bwd rollout of the same {shape[0]}x{shape[1]} Stage-1 problem, "
+                      f"torch {torch.__version__} CPU ({cores} threads), loss=mean(traj^2)"}
 
 
 def physics_extra(pa, cell, family, traj, esz, npts):

@@ -35,6 +35,12 @@ extern "C" {
 /* number of floats in the parameter block (= PERCNN_PI_S1_PARAMS) */
 size_t percnn_pi_s1_param_count(void);
 
+/* tuning / diagnostics (results stay within the documented tolerance): "etile" = 1 (default) hands the input-gradient
+ * contributions between consecutive launches of the backward sweep as 8x8 footprint tiles when H and W are multiples
+ * of 4, 0 = always per-tap planes;  "skip_wgrad" = 1 runs the adjoint sweep only (parameter gradients come back as
+ * zeros; used to time the sweep kernel alone).  Returns PERCNN_PI_EINVAL for an unknown key. */
+int percnn_pi_s1_set_option(const char* key, long value);
+
 /* one time step; shape = {H, W}, H and W >= 8;  h and h_next: [2][H][W], must not alias */
 int percnn_pi_s1_step_fwd_f32(const float* h, float* h_next, const float* params, const int64_t* shape, void* stream);
 

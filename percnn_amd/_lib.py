@@ -29,7 +29,7 @@ EXPORTS = [
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
                 "residual_fwd", "residual_bwd")] + [
     "percnn_pi_s1_param_count", "percnn_pi_s1_step_fwd_f32", "percnn_pi_s1_rollout_fwd_f32",
-    "percnn_pi_s1_rollout_bwd_workspace_bytes", "percnn_pi_s1_rollout_bwd_f32",
+    "percnn_pi_s1_rollout_bwd_workspace_bytes", "percnn_pi_s1_rollout_bwd_f32", "percnn_pi_s1_set_option",
 ]
 
 
@@ -110,6 +110,7 @@ def lib() -> ctypes.CDLL:
     L.percnn_pi_s1_rollout_fwd_f32.restype, L.percnn_pi_s1_rollout_fwd_f32.argtypes = ci, [vp, vp, i64p, ci, vp]
     L.percnn_pi_s1_rollout_bwd_workspace_bytes.restype = sz
     L.percnn_pi_s1_rollout_bwd_workspace_bytes.argtypes = [i64p, ci]
+    L.percnn_pi_s1_set_option.restype, L.percnn_pi_s1_set_option.argtypes = ci, [ctypes.c_char_p, ctypes.c_long]
     L.percnn_pi_s1_rollout_bwd_f32.restype = ci
     L.percnn_pi_s1_rollout_bwd_f32.argtypes = [vp, vp, ctypes.c_char_p, vp, vp, vp, sz, vp, i64p, ci, vp]
     _lib = L

@@ -12,8 +12,8 @@
 //   D            lane l holds channels j = 4*(l>>4) + r (r = 0..3) of point l&15
 // so the product of the three branches, the Wh4 contraction and the Euler update are per-lane VALU work plus two
 // cross-lane adds.  One wave = one (patch, species) task; a wave needs no other wave => no workgroup barriers.
-// f32 MFMA is an exact k-ordered fmaf chain, so the forward is bit-identical to oracle/pi_oracle.c's
-// pi_oracle_s1_step_fwd_f32.
+// f32 MFMA is an exact k-ordered fmaf chain, so the forward is reproducible bit for bit by a scalar fmaf loop over
+// kk = 0..51 (that is what the parity tests compare against).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "pi_device.h"
@@ -33,10 +33,21 @@ constexpr int NP = OFF_B4 + 2;         // 5042
 constexpr int WIN = 8;                 // 4x4 patch + radius-2 halo
 constexpr int WAVES = 4;               // independent waves per workgroup
 
+#ifdef PI_S1_TIMING
+// debug build only: 100 MHz stamps of {species 0, wave 0} (slot 0) and {species 1, last wave} (slot 1) of every workgroup
+__device__ long long s1_stamps[2 * 512 * 8];
+#define S1_STAMP(i, dep) do { asm volatile("" ::"v"(dep)); \
+        const int which_ = (blockIdx.y == 0 && threadIdx.x == 0) ? 0 : ((blockIdx.y == 1 && threadIdx.x == 64 * (WAVES - 1)) ? 1 : -1); \
+        if (which_ >= 0 && blockIdx.x < 512) s1_stamps[(which_ * 512 + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define S1_STAMP(i, dep) do { } while (0)
+#endif
+
 struct Geom {
     int H, W;
     int px;        // patches per row = ceil(W / 4)
-    int npatch;    // ceil(H/4) * ceil(W/4)
+    int npy;       // patch rows = ceil(H / 4)
+    int npatch;    // npy * px
     long n;        // H * W
 };
 
@@ -98,26 +109,53 @@ __device__ __forceinline__ void branches(const float (&a)[3][NKS], const float* 
     }
 }
 
-__device__ __forceinline__ void load_branch_weights(const float* __restrict__ P, int s, int lane, float (&a)[3][NKS])
+// The species' three weight matrices [3][16][52] (10 KB) are staged in LDS by the whole workgroup with coalesced
+// 16-byte loads (a per-lane gather straight from global touches 64 cache lines per instruction and dominated the
+// launch at small grids), then each wave fills its resident A operands from LDS.
+constexpr int WMAT = 3 * HC * KK;
+
+__device__ __forceinline__ void stage_weights(const float* __restrict__ P, int s, float* wl)
+{
+    const float4* src = reinterpret_cast<const float4*>(P + OFF_W + s * WMAT);      // OFF_W, WMAT: multiples of 4
+    float4* dst = reinterpret_cast<float4*>(wl);
+    for (int i = threadIdx.x; i < WMAT / 4; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void load_branch_weights(const float* wl, int lane, float (&a)[3][NKS])
 {
     const int j = lane & 15, grp = lane >> 4;
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int q = 0; q < NKS; ++q) a[k][q] = P[OFF_W + ((s * 3 + k) * HC + j) * KK + 4 * q + grp];
+        for (int q = 0; q < NKS; ++q) a[k][q] = wl[(k * HC + j) * KK + 4 * q + grp];
 }
 
-// star Laplacian of species plane `w` (a [8][8] window) at patch point (py, px); oracle order: centre, axis 0, axis 1
+// the scalars of the block, fetched at the very top of a kernel: every launch starts with cold caches, so a load issued
+// after the weight-staging barrier would cost a second ~1 us round trip
+struct Consts {
+    float dt, coef, b4, c0, taps[8], w4[4];
+    __device__ __forceinline__ void load(const float* __restrict__ P, int s, int grp)
+    {
+        dt = P[P_DT]; coef = P[P_COEF + s]; b4 = P[OFF_B4 + s]; c0 = P[P_C0];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) taps[i] = P[P_TAPS + i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w4[r] = P[OFF_W4 + s * HC + 4 * grp + r];
+    }
+};
+
+// star Laplacian of species plane `w` (a [8][8] window) at patch point (py, px); summation order: centre, axis 0, axis 1
 template <int FLIP>
-__device__ __forceinline__ float win_star(const float* w, const float* __restrict__ P, int py, int px)
+__device__ __forceinline__ float win_star(const float* w, const Consts& k, int py, int px)
 {
     const int c = (py + 2) * WIN + (px + 2);
-    float lap = P[P_C0] * w[c];
+    float lap = k.c0 * w[c];
     constexpr int offs[4] = {-2, -1, 1, 2};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lap = fma_(P[P_TAPS + i], w[c + FLIP * offs[i] * WIN], lap);
+    for (int i = 0; i < 4; ++i) lap = fma_(k.taps[i], w[c + FLIP * offs[i] * WIN], lap);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lap = fma_(P[P_TAPS + 4 + i], w[c + FLIP * offs[i]], lap);
+    for (int i = 0; i < 4; ++i) lap = fma_(k.taps[4 + i], w[c + FLIP * offs[i]], lap);
     return lap;
 }
 
@@ -129,6 +167,7 @@ __global__ __launch_bounds__(64 * WAVES) void s1_fwd_kernel(const float* __restr
                                                             const float* __restrict__ P, Geom g)
 {
     __shared__ float lds[WAVES][2 * WIN * WIN];
+    __shared__ __attribute__((aligned(16))) float wl[WMAT];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int s = blockIdx.y;
     const int grp = lane >> 4, pt = lane & 15, py = pt >> 2, px = pt & 3;
@@ -136,20 +175,20 @@ __global__ __launch_bounds__(64 * WAVES) void s1_fwd_kernel(const float* __restr
 
     int patch = blockIdx.x * WAVES + wv;
     const int stride = gridDim.x * WAVES;
+    S1_STAMP(0, lane);
+    Window wnd;
+    if (patch < g.npatch) wnd.load(h, g, (patch / g.px) * 4, (patch % g.px) * 4, lane);
+    Consts k;
+    k.load(P, s, grp);
+    stage_weights(P, s, wl);
     if (patch >= g.npatch) return;
 
-    Window wnd;
-    wnd.load(h, g, (patch / g.px) * 4, (patch % g.px) * 4, lane);
-
     float a[3][NKS];
-    load_branch_weights(P, s, lane, a);
+    load_branch_weights(wl, lane, a);
+    S1_STAMP(1, a[2][NKS - 1]);
     int toff[NKS];
 #pragma unroll
     for (int q = 0; q < NKS; ++q) toff[q] = tap_offset(q, grp, py, px);
-    float w4[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) w4[r] = P[OFF_W4 + s * HC + 4 * grp + r];
-    const float b4 = P[OFF_B4 + s], coef = P[P_COEF + s], dt = P[P_DT];
 
     for (; patch < g.npatch; patch += stride) {
         const int y0 = (patch / g.px) * 4, x0 = (patch % g.px) * 4;
@@ -160,20 +199,23 @@ __global__ __launch_bounds__(64 * WAVES) void s1_fwd_kernel(const float* __restr
             const int pn = patch + stride;
             wnd.load(h, g, (pn / g.px) * 4, (pn % g.px) * 4, lane);
         }
+        S1_STAMP(2, wnd.v[0]);
         f4 acc[3];
         branches(a, win, toff, grp, acc);
+        S1_STAMP(3, acc[2][3]);
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t = fma_(w4[r], (acc[0][r] * acc[1][r]) * acc[2][r], t);
+        for (int r = 0; r < 4; ++r) t = fma_(k.w4[r], (acc[0][r] * acc[1][r]) * acc[2][r], t);
         t = xor_add(t, 16);                            // (c0 + c1), (c2 + c3)
         t = xor_add(t, 32);                            // + the other pair
-        const float rr = t + b4;
+        const float rr = t + k.b4;
         const float* ws = win + s * (WIN * WIN);
-        const float lap = win_star<1>(ws, P, py, px);
-        const float res = coef * lap + rr;
-        const float upd = res * dt;
+        const float lap = win_star<1>(ws, k, py, px);
+        const float res = k.coef * lap + rr;
+        const float upd = res * k.dt;
         const int y = y0 + py, x = x0 + px;
         if (grp == 0 && y < g.H && x < g.W) out[s * g.n + (long)y * g.W + x] = ws[(py + 2) * WIN + (px + 2)] + upd;
+        S1_STAMP(4, upd);
     }
 }
 
@@ -191,6 +233,62 @@ __global__ __launch_bounds__(64 * WAVES) void s1_fwd_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------
 constexpr int NTAP = 50;
 
+// everything a wave reads from global memory for one (patch, species) task of the sweep -- issued in one go, for the
+// first task BEFORE the weights are staged and for task i+1 while task i is on the matrix cores: every launch starts
+// with cold caches (the inputs were written by the previous launch, mostly on other XCDs), so each dependent round
+// trip costs ~1.5 us
+// Two hand-over formats between consecutive launches:
+//   ETILE (H, W multiples of 4 -- the reference's 100^2): each wave folds its 50 x 16 tap contributions into ONE 8x8
+//         tile per input channel (the patch's footprint), 512 B per wave, written / read as whole cache lines; a point
+//         then collects from the 4 tiles covering it (x 2 source species).  8x less hand-over traffic, no partial lines.
+//   planes (any shape): D[s'][kk][n], one plane per tap, gathered with the tap's shift.
+template <bool ETILE>
+struct AdjIn {
+    Window wnd;          // h_{t-1}, both species
+    float aw;            // a_{t+1}[s] window, one value per lane
+    float inj;           // dL/dtraj[t][s] at the own point
+    float d[ETILE ? 2 : NKS];   // hand-over terms of the own lane group
+    __device__ __forceinline__ void load(const float* __restrict__ h_prev, const float* __restrict__ inj_p,
+                                         const float* __restrict__ adj_next, const float* __restrict__ D_next,
+                                         const Geom& g, int patch, int s, int lane)
+    {
+        const int grp = lane >> 4, pt = lane & 15;
+        const int y0 = (patch / g.px) * 4, x0 = (patch % g.px) * 4;
+        const int y = y0 + (pt >> 2), x = x0 + (pt & 3);
+        const bool inside = y < g.H && x < g.W;
+        if (h_prev) wnd.load(h_prev, g, y0, x0, lane);
+        inj = (inj_p && inside) ? inj_p[s * g.n + (long)y * g.W + x] : 0.f;
+        aw = 0.f;
+        if (adj_next) {
+            const int row = wrap1(y0 + (lane >> 3) - 2, g.H), col = wrap1(x0 + (lane & 7) - 2, g.W);
+            aw = adj_next[s * g.n + (long)row * g.W + col];
+            if constexpr (ETILE) {
+                // lane group = (source species, own / neighbouring patch row); both patch columns per lane
+                const int py = pt >> 2, px = pt & 3, sp = grp >> 1;
+                const int dyy = (grp & 1) ? (py >= 2 ? 1 : -1) : 0;
+                const int qy = wrap1(patch / g.px + dyy, g.npy), wyq = py - 4 * dyy + 2;
+#pragma unroll
+                for (int xs = 0; xs < 2; ++xs) {
+                    const int dxx = xs ? (px >= 2 ? 1 : -1) : 0;
+                    const int qx = wrap1(patch % g.px + dxx, g.px), wxq = px - 4 * dxx + 2;
+                    d[xs] = D_next[(((long)sp * g.npatch + qy * g.px + qx) * 2 + s) * (WIN * WIN) + wyq * WIN + wxq];
+                }
+            } else
+#pragma unroll
+            for (int m = 0; m < NKS; ++m) {
+                const int i = 4 * m + grp;
+                const int ii = i < NTAP ? i : 0;
+                const int sp = ii >= 25 ? 1 : 0, dd = ii - 25 * sp;
+                const int dy = dd / 5, dx = dd - 5 * dy;
+                const int row2 = wrap1(y - dy + 2, g.H), col2 = wrap1(x - dx + 2, g.W);
+                const float v = D_next[(long)(sp * NTAP + s * 25 + dd) * g.n + (long)row2 * g.W + col2];
+                d[m] = i < NTAP ? v : 0.f;
+            }
+        }
+    }
+};
+
+template <bool ETILE>
 __global__ __launch_bounds__(64 * WAVES) void s1_adj_kernel(const float* __restrict__ h_prev,
                                                             const float* __restrict__ inj,
                                                             const float* __restrict__ adj_next,
@@ -198,39 +296,34 @@ __global__ __launch_bounds__(64 * WAVES) void s1_adj_kernel(const float* __restr
                                                             float* __restrict__ adj_out, float* __restrict__ D_out,
                                                             const float* __restrict__ P, Geom g)
 {
-    __shared__ float lds[WAVES][3 * WIN * WIN];          // h window (2 species) + adjoint window (own species)
+    __shared__ float lds[WAVES][3 * WIN * WIN + (ETILE ? NTAP * 16 : 0)];   // h window, adjoint window, tap tile
+    __shared__ __attribute__((aligned(16))) float wl[WMAT];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int s = blockIdx.y;
     const int grp = lane >> 4, pt = lane & 15, py = pt >> 2, px = pt & 3;
     float* win = lds[wv];
     float* awin = win + 2 * WIN * WIN;
+    float* dl = awin + WIN * WIN;
 
     int patch = blockIdx.x * WAVES + wv;
     const int stride = gridDim.x * WAVES;
+    const bool phase2 = D_out != nullptr;
+    if (phase2) S1_STAMP(0, lane);
+    AdjIn<ETILE> cur;
+    if (patch < g.npatch) cur.load(h_prev, inj, adj_next, D_next, g, patch, s, lane);
+    Consts k;
+    k.load(P, s, grp);
+    if (phase2) stage_weights(P, s, wl);
     if (patch >= g.npatch) return;
 
-    const bool phase2 = D_out != nullptr;
     float a[3][NKS];
-    float wT[4][3][4];                                   // [M-tile][branch][r]: W[s][k][4*grp + r][16*mt + (lane & 15)]
     int toff[NKS];
-    float w4[4];
     if (phase2) {
-        load_branch_weights(P, s, lane, a);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int kk = 16 * mt + pt;
-                    wT[mt][k][r] = kk < NTAP ? P[OFF_W + ((s * 3 + k) * HC + 4 * grp + r) * KK + kk] : 0.f;
-                }
+        load_branch_weights(wl, lane, a);
 #pragma unroll
         for (int q = 0; q < NKS; ++q) toff[q] = tap_offset(q, grp, py, px);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w4[r] = P[OFF_W4 + s * HC + 4 * grp + r];
     }
-    const float coef = P[P_COEF + s], dt = P[P_DT];
+    if (phase2) S1_STAMP(1, a[2][NKS - 1]);
 
     for (; patch < g.npatch; patch += stride) {
         const int y0 = (patch / g.px) * 4, x0 = (patch % g.px) * 4;
@@ -239,63 +332,80 @@ __global__ __launch_bounds__(64 * WAVES) void s1_adj_kernel(const float* __restr
         const long pidx = (long)(inside ? y : 0) * g.W + (inside ? x : 0);
 
         wave_sync();
-        if (phase2) {
-            Window wnd;
-            wnd.load(h_prev, g, y0, x0, lane);
-            wnd.store(win, lane);
-        }
-        float at = inj ? inj[s * g.n + pidx] : 0.f;
-        if (adj_next) {
-            {   // adjoint window of the own species: 64 values, one per lane
-                const int row = wrap1(y0 + (lane >> 3) - 2, g.H), col = wrap1(x0 + (lane & 7) - 2, g.W);
-                awin[lane] = adj_next[s * g.n + (long)row * g.W + col];
-            }
-            // scatter planes: 50 (s', d) terms per point, 13 per lane group
-            float gsum = 0.f;
+        if (phase2) cur.wnd.store(win, lane);
+        awin[lane] = cur.aw;
+        float gsum = 0.f;
 #pragma unroll
-            for (int m = 0; m < NKS; ++m) {
-                const int i = 4 * m + grp;
-                if (i < NTAP) {
-                    const int sp = i >= 25 ? 1 : 0, d = i - 25 * sp;
-                    const int dy = d / 5, dx = d - 5 * dy;
-                    const int row = wrap1(y - dy + 2, g.H), col = wrap1(x - dx + 2, g.W);
-                    gsum += D_next[(long)(sp * NTAP + s * 25 + d) * g.n + (long)row * g.W + col];
-                }
-            }
+        for (int m = 0; m < (ETILE ? 2 : NKS); ++m) gsum += cur.d[m];
+        float at = cur.inj;
+        const bool more = patch + stride < g.npatch;
+        if (more) cur.load(h_prev, inj, adj_next, D_next, g, patch + stride, s, lane);
+        wave_sync();
+        if (adj_next) {
             gsum = xor_add(gsum, 16);
             gsum = xor_add(gsum, 32);
-            wave_sync();
-            const float lapT = win_star<-1>(awin, P, py, px);
-            at += awin[(py + 2) * WIN + (px + 2)] + fma_(dt * coef, lapT, gsum);
-        } else {
-            wave_sync();
+            const float lapT = win_star<-1>(awin, k, py, px);
+            at += awin[(py + 2) * WIN + (px + 2)] + fma_(k.dt * k.coef, lapT, gsum);
         }
         if (!inside) at = 0.f;
         if (grp == 0 && inside) adj_out[s * g.n + pidx] = at;
+        if (phase2) S1_STAMP(2, at);
         if (!phase2) continue;
 
         f4 acc[3];
         branches(a, win, toff, grp, acc);
-        const float ga = at * dt;
+        S1_STAMP(3, acc[2][3]);
+        const float ga = at * k.dt;
         float G[3][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float gw = ga * w4[r];
+            const float gw = ga * k.w4[r];
             G[0][r] = gw * (acc[1][r] * acc[2][r]);
             G[1][r] = gw * (acc[0][r] * acc[2][r]);
             G[2][r] = gw * (acc[0][r] * acc[1][r]);
         }
+        // input-gradient GEMM; its A operand W[s][k][4*grp + r][16*mt + pt] comes straight from the staged weights
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             f4 d = f4{0.f, 0.f, 0.f, 0.f};
+            const int kk_a = 16 * mt + pt;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wT[mt][k][r], G[k][r], d, 0, 0, 0);
+                for (int r = 0; r < 4; ++r) {
+                    const float w = kk_a < NTAP ? wl[(k * HC + 4 * grp + r) * KK + kk_a] : 0.f;
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(w, G[k][r], d, 0, 0, 0);
+                }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int kk = 16 * mt + 4 * grp + r;
-                if (kk < NTAP && inside) D_out[(long)(s * NTAP + kk) * g.n + pidx] = d[r];
+                if constexpr (ETILE) {
+                    if (kk < NTAP) dl[kk * 16 + pt] = d[r];
+                } else {
+                    if (kk < NTAP && inside) D_out[(long)(s * NTAP + kk) * g.n + pidx] = d[r];
+                }
+            }
+            if (mt == 3) S1_STAMP(4, d[3]);
+        }
+        if constexpr (ETILE) {
+            // fold the 50 x 16 tap contributions into the patch's 8x8 footprint per input channel: window position
+            // (wy, wx) collects tap (dy, dx) of source point (wy - dy, wx - dx) when that point is inside the patch
+            wave_sync();
+            const int wy = lane >> 3, wx = lane & 7;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float e = 0.f;
+#pragma unroll
+                for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 5; ++dx) {
+                        const int qy = wy - dy, qx = wx - dx;
+                        const bool ok = (unsigned)qy < 4u && (unsigned)qx < 4u;
+                        const float v = dl[(c * 25 + dy * 5 + dx) * 16 + (ok ? qy * 4 + qx : 0)];
+                        e += ok ? v : 0.f;
+                    }
+                D_out[(((long)s * g.npatch + patch) * 2 + c) * (WIN * WIN) + lane] = e;
+                if (c == 1) S1_STAMP(5, e);
             }
         }
     }
@@ -322,7 +432,7 @@ __global__ __launch_bounds__(64 * WAVES) void s1_wgrad_kernel(const float* __res
                                                               const float* __restrict__ P, Geom g, int T)
 {
     __shared__ __attribute__((aligned(16))) float lds[WAVES][2 * WIN * WIN + 3 * HC * GT_LD];
-    __shared__ float rowsum[ROW];
+    __shared__ __attribute__((aligned(16))) float rowsum[ROW];          // first the staged weights, at the end the row sums
     __shared__ double rowsum_d[ROWD];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int s = blockIdx.y;
@@ -330,15 +440,16 @@ __global__ __launch_bounds__(64 * WAVES) void s1_wgrad_kernel(const float* __res
     float* win = lds[wv];
     float* gt = win + 2 * WIN * WIN;
 
+    static_assert(WMAT <= ROW, "weights are staged in the row-sum buffer");
     float a[3][NKS];
-    load_branch_weights(P, s, lane, a);
+    Consts k;
+    k.load(P, s, grp);
+    stage_weights(P, s, rowsum);
+    load_branch_weights(rowsum, lane, a);
+    __syncthreads();                                     // rowsum is reused for the final reduction
     int toff[NKS];
 #pragma unroll
     for (int q = 0; q < NKS; ++q) toff[q] = tap_offset(q, grp, py, px);
-    float w4[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) w4[r] = P[OFF_W4 + s * HC + 4 * grp + r];
-    const float dt = P[P_DT];
     // B operand of the wgrad GEMM: lane (k-slot grp, n = pt) reads col[kk = 16*nt + pt] of point (py', px') = (grp, q')
     int tb[4];
 #pragma unroll
@@ -359,16 +470,23 @@ __global__ __launch_bounds__(64 * WAVES) void s1_wgrad_kernel(const float* __res
 
     const long ntask = (long)T * g.npatch;
     const long frame = 2 * g.n;
-    for (long task = (long)blockIdx.x * WAVES + wv; task < ntask; task += (long)gridDim.x * WAVES) {
+    const long tstride = (long)gridDim.x * WAVES;
+    Window wnd;
+    float a_raw = 0.f;
+    auto fetch = [&](long task) {                      // global reads of one task: h_{t-1} window + a_t at the own point
         const int t = (int)(task / g.npatch) + 1, patch = (int)(task % g.npatch);
         const int y0 = (patch / g.px) * 4, x0 = (patch % g.px) * 4;
         const int y = y0 + py, x = x0 + px;
-        const bool inside = y < g.H && x < g.W;
-        wave_sync();
-        Window wnd;
         wnd.load(traj + (t - 1) * frame, g, y0, x0, lane);
+        a_raw = (y < g.H && x < g.W) ? adj[t * frame + s * g.n + (long)y * g.W + x] : 0.f;
+    };
+    long task = (long)blockIdx.x * WAVES + wv;
+    if (task < ntask) fetch(task);
+    for (; task < ntask; task += tstride) {
+        wave_sync();
         wnd.store(win, lane);
-        const float ga = inside ? adj[t * frame + s * g.n + (long)y * g.W + x] * dt : 0.f;
+        const float ga = a_raw * k.dt;
+        if (task + tstride < ntask) fetch(task + tstride);        // travels while this task is on the matrix cores
         wave_sync();
 
         f4 acc[3];
@@ -377,7 +495,7 @@ __global__ __launch_bounds__(64 * WAVES) void s1_wgrad_kernel(const float* __res
         for (int r = 0; r < 4; ++r) {
             const float p12 = acc[0][r] * acc[1][r];
             acc_w4[r] += (double)(ga * (p12 * acc[2][r]));
-            const float gw = ga * w4[r];
+            const float gw = ga * k.w4[r];
             const int j = 4 * grp + r;
             gt[(0 * HC + j) * GT_LD + pt] = gw * (acc[1][r] * acc[2][r]);
             gt[(1 * HC + j) * GT_LD + pt] = gw * (acc[0][r] * acc[2][r]);
@@ -385,7 +503,7 @@ __global__ __launch_bounds__(64 * WAVES) void s1_wgrad_kernel(const float* __res
         }
         if (grp == 0) {
             acc_b4 += (double)ga;
-            acc_cf += (double)(ga * win_star<1>(win + s * (WIN * WIN), P, py, px));
+            acc_cf += (double)(ga * win_star<1>(win + s * (WIN * WIN), k, py, px));
         }
         wave_sync();
         // A operand: lane (m = j = pt, k-slot grp) holds G[k][j][points 4*grp .. 4*grp+3]
@@ -443,13 +561,16 @@ __global__ __launch_bounds__(64 * WAVES) void s1_wgrad_kernel(const float* __res
 }
 
 // one thread per gradient slot: fixed-order double sum over the workgroup rows
+// blockDim = (64 slots, 4 row lanes): lane r sums rows r, r+4, ...; the four partial sums are combined in a fixed order
 __global__ void s1_reduce_kernel(const float* __restrict__ partials, const double* __restrict__ partials_d, int nrows,
                                  double* __restrict__ pg)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= NP) return;
+    __shared__ double part[4][64];
+    const int i = blockIdx.x * 64 + threadIdx.x, rl = threadIdx.y;
+    const bool live = i < NP;
     int s = 0, idx = -1, didx = -1;
-    if (i == P_COEF || i == P_COEF + 1) { s = i - P_COEF; didx = HC + 1; }
+    if (!live) { }
+    else if (i == P_COEF || i == P_COEF + 1) { s = i - P_COEF; didx = HC + 1; }
     else if (i >= OFF_B4) { s = i - OFF_B4; didx = HC; }
     else if (i >= OFF_W4) { s = (i - OFF_W4) / HC; didx = (i - OFF_W4) % HC; }
     else if (i >= OFF_W) {
@@ -458,11 +579,17 @@ __global__ void s1_reduce_kernel(const float* __restrict__ partials, const doubl
         if (kk <= NTAP) idx = (kj % (3 * HC)) * 64 + kk;
     }
     double sum = 0.0;
-    if (idx >= 0)
-        for (int b = 0; b < nrows; ++b) sum += (double)partials[((long)b * 2 + s) * ROW + idx];
-    if (didx >= 0)
-        for (int b = 0; b < nrows; ++b) sum += partials_d[((long)b * 2 + s) * ROWD + didx];
-    pg[i] = sum;
+    if (live && idx >= 0) {
+#pragma unroll 4
+        for (int b = rl; b < nrows; b += 4) sum += (double)partials[((long)b * 2 + s) * ROW + idx];
+    }
+    if (live && didx >= 0) {
+#pragma unroll 4
+        for (int b = rl; b < nrows; b += 4) sum += partials_d[((long)b * 2 + s) * ROWD + didx];
+    }
+    part[rl][threadIdx.x] = sum;
+    __syncthreads();
+    if (live && rl == 0) pg[i] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 }  // namespace s1

@@ -11,7 +11,12 @@ namespace {
 
 using pi::s1::Geom;
 
-constexpr int MAX_GRID_X = 2048;      // workgroups per species; waves grid-stride over patches beyond that
+struct S1Options {
+    int etile = 1;      // hand the input-gradient contributions over as 8x8 footprint tiles when H, W are multiples of 4
+    int skip_wgrad = 0; // diagnostics: run the adjoint sweep only (parameter gradients are returned as zeros)
+} g_s1;
+
+constexpr int MAX_GRID_X = 384;       // workgroups per species (x 2 species = 3 per CU); waves grid-stride over patches beyond that
 
 bool make_geom(const int64_t* shape, Geom& g)
 {
@@ -19,7 +24,8 @@ bool make_geom(const int64_t* shape, Geom& g)
     g.H = (int)shape[0];
     g.W = (int)shape[1];
     g.px = (g.W + 3) / 4;
-    g.npatch = ((g.H + 3) / 4) * g.px;
+    g.npy = (g.H + 3) / 4;
+    g.npatch = g.npy * g.px;
     g.n = (long)g.H * g.W;
     return true;
 }
@@ -65,8 +71,13 @@ Workspace carve(void* base, const Geom& g, int T)
 hipError_t adj_step(const float* h_prev, const float* inj, const float* adj_next, const float* D_next, float* adj_out,
                     float* D_out, const float* P, const Geom& g, hipStream_t st)
 {
-    hipLaunchKernelGGL(pi::s1::s1_adj_kernel, dim3(grid_x(g), 2), dim3(64 * pi::s1::WAVES), 0, st, h_prev, inj, adj_next,
-                       D_next, adj_out, D_out, P, g);
+    const bool etile = g_s1.etile && g.H % 4 == 0 && g.W % 4 == 0;
+    if (etile)
+        hipLaunchKernelGGL(pi::s1::s1_adj_kernel<true>, dim3(grid_x(g), 2), dim3(64 * pi::s1::WAVES), 0, st, h_prev, inj,
+                           adj_next, D_next, adj_out, D_out, P, g);
+    else
+        hipLaunchKernelGGL(pi::s1::s1_adj_kernel<false>, dim3(grid_x(g), 2), dim3(64 * pi::s1::WAVES), 0, st, h_prev, inj,
+                           adj_next, D_next, adj_out, D_out, P, g);
     return hipGetLastError();
 }
 
@@ -75,6 +86,14 @@ hipError_t adj_step(const float* h_prev, const float* inj, const float* adj_next
 extern "C" {
 
 size_t percnn_pi_s1_param_count(void) { return pi::s1::NP; }
+
+int percnn_pi_s1_set_option(const char* key, long value)
+{
+    if (!key) return PERCNN_PI_EINVAL;
+    if (!std::strcmp(key, "etile")) { g_s1.etile = value != 0; return 0; }
+    if (!std::strcmp(key, "skip_wgrad")) { g_s1.skip_wgrad = value != 0; return 0; }
+    return PERCNN_PI_EINVAL;
+}
 
 int percnn_pi_s1_step_fwd_f32(const float* h, float* h_next, const float* params, const int64_t* shape, void* stream)
 {
@@ -121,15 +140,23 @@ int percnn_pi_s1_rollout_bwd_f32(const float* traj, const float* g_traj, const u
                                 t > 0 ? w.adj + (size_t)t * frame : g_h0, t > 0 ? D(t) : nullptr, params, g, st);
         if (e) return (int)e;
     }
+    if (g_s1.skip_wgrad) return (int)hipMemsetAsync(param_grad, 0, sizeof(double) * pi::s1::NP, st);
     const long ntask = (long)T_steps * g.npatch;
     long gx = (ntask + pi::s1::WAVES - 1) / pi::s1::WAVES;
     gx = gx < 1 ? 1 : (gx > WGRAD_GRID_X ? WGRAD_GRID_X : gx);
     hipLaunchKernelGGL(pi::s1::s1_wgrad_kernel, dim3((unsigned)gx, 2), dim3(64 * pi::s1::WAVES), 0, st, traj, w.adj,
                        w.partials, w.partials_d, params, g, T_steps);
     if (hipError_t e = hipGetLastError()) return (int)e;
-    hipLaunchKernelGGL(pi::s1::s1_reduce_kernel, dim3((pi::s1::NP + 255) / 256), dim3(256), 0, st, w.partials, w.partials_d,
+    hipLaunchKernelGGL(pi::s1::s1_reduce_kernel, dim3((pi::s1::NP + 63) / 64), dim3(64, 4), 0, st, w.partials, w.partials_d,
                        (int)gx, param_grad);
     return (int)hipGetLastError();
 }
+
+#ifdef PI_S1_TIMING
+int percnn_pi_s1_debug_stamps(long long* host_out, int n)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pi::s1::s1_stamps), (size_t)n * sizeof(long long));
+}
+#endif
 
 }  // extern "C"

@@ -69,6 +69,10 @@ def pack_params(dt, coef_u, coef_v, w_laplace, branch: Sequence[torch.Tensor]) -
     return flat.index_select(0, _gather_index(dev))
 
 
+def set_option(key: str, value: int) -> None:
+    _lib.check(_lib.lib().percnn_pi_s1_set_option(key.encode(), int(value)), f"s1 set_option({key}={value})")
+
+
 def _check(P: torch.Tensor, *states: torch.Tensor) -> None:
     _require(P, "params", torch.float32)
     if P.numel() != NP:

@@ -48,11 +48,21 @@ def test_argument_errors_do_not_need_a_gpu():
     shape = (ctypes.c_int64 * 2)(8, 8)
     assert L.percnn_pi_step_fwd_f32(None, None, None, 8, 2, shape, None) == -1
     assert L.percnn_pi_step_fwd_f32(1, 2, 3, 8, 5, shape, None) == -1
-    assert L.percnn_pi_step_fwd_f32(1, 2, 3, -1, 2, shape, None) == -1
+    assert L.percnn_pi_step_fwd_f32(1, 2, 3, -7, 2, shape, None) == -1          # -1 = advective block, 0 = polynomial block
     bad = (ctypes.c_int64 * 2)(1, 8)
     assert L.percnn_pi_step_fwd_f64(1, 2, 3, 4, 2, bad, None) == -1
     assert L.percnn_pi_rollout_fwd_f32(1, 2, 8, 2, shape, -1, None) == -1
     assert L.percnn_pi_step_bwd_f32(1, 2, None, 3, 4, None, 0, 5, 8, 2, shape, None) == -2   # no workspace
+    # Stage-1 block (include/percnn_pi_stage1.h)
+    assert L.percnn_pi_s1_param_count() == 5042 == percnn_amd.stage1.NP
+    assert L.percnn_pi_s1_step_fwd_f32(None, None, None, shape, None) == -1
+    assert L.percnn_pi_s1_step_fwd_f32(1, 1, 3, shape, None) == -1                 # aliasing
+    small = (ctypes.c_int64 * 2)(4, 8)
+    assert L.percnn_pi_s1_step_fwd_f32(1, 2, 3, small, None) == -1                 # H < 8
+    assert L.percnn_pi_s1_rollout_bwd_workspace_bytes(small, 3) == 0
+    assert L.percnn_pi_s1_rollout_bwd_workspace_bytes(shape, 3) > 4 * 2 * 64 * 4
+    assert L.percnn_pi_s1_rollout_bwd_f32(1, 2, None, 3, 4, None, 0, 5, shape, 3, None) == -2
+    assert L.percnn_pi_s1_set_option(b"nonsense", 1) == -1
 
 
 @pytest.mark.parametrize("reaction", ["factored", "poly"])

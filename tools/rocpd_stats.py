@@ -21,7 +21,7 @@ def summarise(db):
     for n, (k, t, mn, mx) in sorted(stats.items(), key=lambda kv: -kv[1][1])[:12]:
         print(f"{k:8d} {t/1e6:10.3f} {t/k/1e3:9.2f} {mn/1e3:9.2f} {mx/1e3:9.2f} {100*t/total:6.1f}  {n[:110]}")
     # gaps between consecutive dispatches of the two step kernels
-    for key in ("pi_fwd", "pi_bwd", "pi_adj", "pi_wgrad"):
+    for key in ("pi_fwd", "pi_bwd", "pi_adj", "pi_wgrad", "s1_fwd", "s1_adj"):
         seq = [(s, e) for n, s, e in rows if key in n]
         if len(seq) > 10:
             gaps = sorted(seq[i + 1][0] - seq[i][1] for i in range(len(seq) - 1))
