@@ -86,6 +86,9 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks)
 }
 
 // ---- wave-level sum (all 64 lanes) -----------------------------------------------------------
+#ifndef PI_USE_DPP
+#define PI_USE_DPP 1      // 0 = ds_bpermute butterflies: 6 dependent LDS-crossbar round trips per sum (measured: the
+#endif                    // two fp64 sums at the end of the tile adjoint kernel cost ~1 us that way)
 #if PI_USE_DPP
 // DPP row shifts + row broadcasts: 6 VALU adds, no LDS crossbar traffic. Total lands in lane 63.
 template <int CTRL, int ROW_MASK>

@@ -19,6 +19,10 @@
 
 namespace pi {
 
+#ifndef PI_TILE_ADJ_PIPE
+#define PI_TILE_ADJ_PIPE 1
+#endif
+
 #ifdef PI_TILE_TIMING
 // debug build only: per-workgroup s_memtime stamps {start, window loaded, after each sub-step (compute, store issued), end}
 __device__ long long pi_tile_stamps[4096 * 16];
@@ -45,23 +49,50 @@ struct TileGeom {
 // window coordinates lie in [-2K, n + BX + 2K): one conditional add / subtract suffices for n >= BX + 2K (checked by the host)
 __device__ __forceinline__ int wrap1(int g, int n) { return g < 0 ? g + n : (g >= n ? g - n : g); }
 
-// stage the (LY x LX) periodic window of both species of `src` into buf[2][LY][LX]
+// stage the (LY x LX) periodic window of both species of `src` into buf[2][LY][LX].
+// issue() puts all global loads in flight, commit() writes them to LDS: a load -> wait -> write loop costs one full
+// memory round trip per trip (3 trips = +0.8 us per launch at 512^2, measured from the device timeline), and the
+// adjoint kernel issues its first operand loads between the two.
+template <typename T, int K, int BX, int BY, int NT>
+struct WindowLoader {
+    using TL = Tile<K, BX, BY>;
+    static constexpr int VEC = vec_width<T>::value;
+    static constexpr int LXV = TL::LX / VEC;
+    static constexpr int N = 2 * TL::LY * LXV;
+    static constexpr int TRIPS = (N + NT - 1) / NT;
+    Pack<T, VEC> p[TRIPS];
+    int dst[TRIPS];
+    __device__ __forceinline__ void issue(const T* __restrict__ src, const TileGeom& g, int ty0, int tx0)
+    {
+#pragma unroll
+        for (int q = 0; q < TRIPS; ++q) {
+            const int i = threadIdx.x + q * NT;
+            dst[q] = -1;
+            if (i < N) {
+                const int s = i / (TL::LY * LXV);
+                const int r = i - s * (TL::LY * LXV);
+                const int ly = r / LXV, c = r - ly * LXV;
+                const int gy = wrap1(ty0 - 2 * K + ly, g.H);
+                const int gx = wrap1(tx0 - 2 * K + c * VEC, g.W);
+                p[q] = ld<T, VEC>(src + s * g.ss + (long)gy * g.W + gx);
+                dst[q] = s * TL::PLANE + ly * TL::LX + c * VEC;
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(T* buf) const
+    {
+#pragma unroll
+        for (int q = 0; q < TRIPS; ++q)
+            if (dst[q] >= 0) st<T, VEC>(buf + dst[q], p[q]);
+    }
+};
+
 template <typename T, int K, int BX, int BY, int NT>
 __device__ __forceinline__ void tile_load(const T* __restrict__ src, const TileGeom& g, int ty0, int tx0, T* buf)
 {
-    using TL = Tile<K, BX, BY>;
-    constexpr int VEC = vec_width<T>::value;
-    constexpr int LXV = TL::LX / VEC;
-    constexpr int N = 2 * TL::LY * LXV;
-    for (int i = threadIdx.x; i < N; i += NT) {
-        const int s = i / (TL::LY * LXV);
-        const int r = i - s * (TL::LY * LXV);
-        const int ly = r / LXV, c = r - ly * LXV;
-        const int gy = wrap1(ty0 - 2 * K + ly, g.H);
-        const int gx = wrap1(tx0 - 2 * K + c * VEC, g.W);
-        const Pack<T, VEC> p = ld<T, VEC>(src + s * g.ss + (long)gy * g.W + gx);
-        st<T, VEC>(buf + s * TL::PLANE + ly * TL::LX + c * VEC, p);
-    }
+    WindowLoader<T, K, BX, BY, NT> w;
+    w.issue(src, g, ty0, tx0);
+    w.commit(buf);
 }
 
 // write the BX x BY centre of buf to frame `dst`
@@ -122,6 +153,64 @@ __device__ __forceinline__ void lds_store4(T* p, const T (&v)[4])
     st<T, 2>(p + 2, Pack<T, 2>{{v[2], v[3]}});
 }
 
+// ---- explicit 2-wide arithmetic ---------------------------------------------------------------------------------
+// The adjoint sub-step is VALU-bound and hipcc's SLP vectoriser left it entirely scalar (0 v_pk_* against 900 scalar
+// fp32 ops per launch, while it packs the forward body); written on 2-vectors the same IEEE operations in the same
+// order issue as v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (fp64: scalarised again by the compiler, same results).
+template <typename T> using V2 = T __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ V2<T> vs(T x) { return V2<T>{x, x}; }
+template <typename T> __device__ __forceinline__ V2<T> vfma(V2<T> a, V2<T> b, V2<T> c) { return __builtin_elementwise_fma(a, b, c); }
+template <typename T> __device__ __forceinline__ V2<T> ldv2(const T* p)
+{
+    const Pack<T, 2> q = ld<T, 2>(p);
+    return V2<T>{q.v[0], q.v[1]};
+}
+template <typename T> __device__ __forceinline__ void stv2(T* p, V2<T> v) { st<T, 2>(p, Pack<T, 2>{{v.x, v.y}}); }
+// elements idx, idx+1 of the 8-point row window W[4]
+template <typename T> __device__ __forceinline__ V2<T> win_pair(const V2<T> (&W)[4], int idx)
+{
+    return (idx & 1) ? V2<T>{W[idx / 2].y, W[idx / 2 + 1].x} : W[idx / 2];
+}
+
+// lds_star4 on 2-vectors: ctr/lap[0] = points 0,1 of the strip, [1] = points 2,3; identical operation order
+template <typename T, int LX, int FLIP>
+__device__ __forceinline__ void lds_star4v(const T* pl, int ly, int lx, const T* __restrict__ P, V2<T> (&ctr)[2], V2<T> (&lap)[2])
+{
+    const T* c = pl + ly * LX + lx;
+    V2<T> W[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) W[j] = ldv2(c - 2 + 2 * j);
+    ctr[0] = W[1]; ctr[1] = W[2];
+    const V2<T> c0 = vs(P[P_C0]);
+    lap[0] = c0 * ctr[0]; lap[1] = c0 * ctr[1];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = FLIP * (t < 2 ? t - 2 : t - 1);
+        const V2<T> a = ldv2(c + k * LX), b = ldv2(c + k * LX + 2);
+        const V2<T> w = vs(P[P_TAPS + t]);
+        lap[0] = vfma(w, a, lap[0]);
+        lap[1] = vfma(w, b, lap[1]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = FLIP * (t < 2 ? t - 2 : t - 1);
+        const V2<T> w = vs(P[P_TAPS + 4 + t]);
+        lap[0] = vfma(w, win_pair(W, 2 + k), lap[0]);
+        lap[1] = vfma(w, win_pair(W, 4 + k), lap[1]);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void poly_dr_v(const T* __restrict__ c, V2<T> u, V2<T> v, V2<T>& ru, V2<T>& rv)
+{
+    const V2<T> A1 = vfma(v, vfma(v, vs(c[8]), vs(c[4])), vs(c[1]));
+    const V2<T> A2x2 = vfma(v, vs(T(2) * c[7]), vs(T(2) * c[3]));
+    ru = vfma(u, vfma(u, vs(T(3) * c[6]), A2x2), A1);
+    const V2<T> B0 = vfma(v, vfma(v, vs(T(3) * c[9]), vs(T(2) * c[5])), vs(c[2]));
+    const V2<T> B1 = vfma(v, vs(T(2) * c[8]), vs(c[4]));
+    rv = vfma(u, vfma(u, vs(c[7]), B1), B0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward: frames t+1 .. t+K from frame t
 // ------------------------------------------------------------------------------------------------
@@ -141,15 +230,34 @@ __device__ __forceinline__ void fwd_substep(T* cur, T* nxt, const T* __restrict_
         T u[4], v[4], lap[2][4];
         lds_star4<T, TL::LX, +1>(cur, ry + O, 4 * rc + O, P, u, lap[0]);
         lds_star4<T, TL::LX, +1>(cur + TL::PLANE, ry + O, 4 * rc + O, P, v, lap[1]);
-        // species / hidden-channel loops stay rolled (small I$-resident body, scalars prefetched)
-#pragma clang loop unroll(disable)
-        for (int s = 0; s < 2; ++s) {
-            T rr[4];
-            if constexpr (HC == POLY) {
+        auto emit = [&](int s, const T (&rr)[4]) {
+            const T coef = P[P_COEF + s];
+            T o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const T lp = s == 0 ? lap[0][i] : lap[1][i];
+                const T res = coef * lp + rr[i];
+                const T inc = res * dt;
+                o[i] = (s == 0 ? u[i] : v[i]) + inc;
+            }
+            lds_store4(nxt + s * TL::PLANE + off, o);
+        };
+        if constexpr (HC == POLY) {
+            // 9 FMAs per species: unrolled, so the 20 coefficients are loop-invariant scalar loads the compiler hoists
+            // (rolled, every iteration re-issued them and waited on lgkmcnt(0))
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                T rr[4];
                 const T* c = P + P_W + 10 * s;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rr[i] = poly_r(c, u[i], v[i]);
-            } else {
+                emit(s, rr);
+            }
+        } else {
+            // species / hidden-channel loops stay rolled (small I$-resident body, scalars prefetched)
+#pragma clang loop unroll(disable)
+            for (int s = 0; s < 2; ++s) {
+                T rr[4];
                 const T* W = P + P_W + s * species_block(HC);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) rr[i] = W[10 * HC];
@@ -166,17 +274,8 @@ __device__ __forceinline__ void fwd_substep(T* cur, T* nxt, const T* __restrict_
                         rr[i] = fma_(c.w[9], (a1 * a2) * a3, rr[i]);
                     }
                 }
+                emit(s, rr);
             }
-            const T coef = P[P_COEF + s];
-            T o[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const T lp = s == 0 ? lap[0][i] : lap[1][i];
-                const T res = coef * lp + rr[i];
-                const T inc = res * dt;
-                o[i] = (s == 0 ? u[i] : v[i]) + inc;
-            }
-            lds_store4(nxt + s * TL::PLANE + off, o);
         }
     }
 }
@@ -241,12 +340,14 @@ __device__ __forceinline__ void adj_load_ops(StripOps<T>& o, int q, const T* __r
     const Pack<T, 2> c = ld<T, 2>(hfr + g.ss + e0), d = ld<T, 2>(hfr + g.ss + e1);
     o.u[0] = a.v[0]; o.u[1] = a.v[1]; o.u[2] = b.v[0]; o.u[3] = b.v[1];
     o.v[0] = c.v[0]; o.v[1] = c.v[1]; o.v[2] = d.v[0]; o.v[3] = d.v[1];
-    if (gfr) {
-        const Pack<T, 2> a2 = ld<T, 2>(gfr + e0), b2 = ld<T, 2>(gfr + e1);
-        const Pack<T, 2> c2 = ld<T, 2>(gfr + g.ss + e0), d2 = ld<T, 2>(gfr + g.ss + e1);
-        o.ju[0] = a2.v[0]; o.ju[1] = a2.v[1]; o.ju[2] = b2.v[0]; o.ju[3] = b2.v[1];
-        o.jv[0] = c2.v[0]; o.jv[1] = c2.v[1]; o.jv[2] = d2.v[0]; o.jv[3] = d2.v[1];
-    }
+    // Unconditional (a frame without gradient re-reads the state frame; the values are ignored): with the loads in a
+    // branch the compiler cannot count the outstanding requests and makes the window commit wait for these
+    // HBM-cold operands too (s_waitcnt vmcnt(4) instead of vmcnt(8): +1.5 us per launch on the device timeline).
+    const T* gsrc = gfr ? gfr : hfr;
+    const Pack<T, 2> a2 = ld<T, 2>(gsrc + e0), b2 = ld<T, 2>(gsrc + e1);
+    const Pack<T, 2> c2 = ld<T, 2>(gsrc + g.ss + e0), d2 = ld<T, 2>(gsrc + g.ss + e1);
+    o.ju[0] = a2.v[0]; o.ju[1] = a2.v[1]; o.ju[2] = b2.v[0]; o.ju[3] = b2.v[1];
+    o.jv[0] = c2.v[0]; o.jv[1] = c2.v[1]; o.jv[2] = d2.v[0]; o.jv[3] = d2.v[1];
 }
 
 // PRE = true: the strip operands of this sub-step were requested at kernel start (`pre`), so the cold
@@ -276,37 +377,45 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
         const T (&v)[4] = op.v;
         const T (&ju)[4] = op.ju;
         const T (&jv)[4] = op.jv;
-        T gc[2][4], dl[2][4];
-        lds_star4<T, TL::LX, -1>(cur, ly, lx, P, gc[0], dl[0]);
-        lds_star4<T, TL::LX, -1>(cur + TL::PLANE, ly, lx, P, gc[1], dl[1]);
+        const V2<T> U[2] = {V2<T>{u[0], u[1]}, V2<T>{u[2], u[3]}}, V[2] = {V2<T>{v[0], v[1]}, V2<T>{v[2], v[3]}};
+        V2<T> gc[2][2], dl[2][2];                          // [species][half of the strip]
+        lds_star4v<T, TL::LX, -1>(cur, ly, lx, P, gc[0], dl[0]);
+        lds_star4v<T, TL::LX, -1>(cur + TL::PLANE, ly, lx, P, gc[1], dl[1]);
         const bool rowin = live && ly >= 2 * K && ly < 2 * K + BY && ty0 + ly - 2 * K < g.H;
+        const V2<T> dtv = vs(dt);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            dl[0][i] *= dt;
-            dl[1][i] *= dt;
-            if (rowin && lx + i >= 2 * K && lx + i < 2 * K + BX && tx0 + lx + i - 2 * K < g.W) {   // owned, in-grid points only
-                acc_c[0] += (double)(dl[0][i] * u[i]);
-                acc_c[1] += (double)(dl[1][i] * v[i]);
+        for (int h = 0; h < 2; ++h) {
+            dl[0][h] *= dtv;
+            dl[1][h] *= dtv;
+            const V2<T> mu = dl[0][h] * U[h], mv = dl[1][h] * V[h];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = 2 * h + e;
+                if (rowin && lx + i >= 2 * K && lx + i < 2 * K + BX && tx0 + lx + i - 2 * K < g.W) {   // owned, in-grid points only
+                    acc_c[0] += (double)mu[e];
+                    acc_c[1] += (double)mv[e];
+                }
             }
         }
-        T du[4], dv[4];
+        V2<T> du[2] = {vs(T(0)), vs(T(0))}, dv[2] = {vs(T(0)), vs(T(0))};
+        if constexpr (HC == POLY) {
+            // unrolled over the species: the 20 coefficients become loop-invariant scalar loads
 #pragma unroll
-        for (int i = 0; i < 4; ++i) du[i] = dv[i] = T(0);
-#pragma clang loop unroll(disable)
-        for (int s = 0; s < 2; ++s) {
-            T gr[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gr[i] = (s == 0 ? gc[0][i] : gc[1][i]) * dt;
-            if constexpr (HC == POLY) {
+            for (int s = 0; s < 2; ++s) {
                 const T* c = P + P_W + 10 * s;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    T ru, rv;
-                    poly_dr(c, u[i], v[i], ru, rv);
-                    du[i] = fma_(gr[i], ru, du[i]);
-                    dv[i] = fma_(gr[i], rv, dv[i]);
+                for (int h = 0; h < 2; ++h) {
+                    const V2<T> gr = gc[s][h] * dtv;
+                    V2<T> ru, rv;
+                    poly_dr_v(c, U[h], V[h], ru, rv);
+                    du[h] = vfma(gr, ru, du[h]);
+                    dv[h] = vfma(gr, rv, dv[h]);
                 }
-            } else {
+            }
+        } else {
+#pragma clang loop unroll(disable)
+            for (int s = 0; s < 2; ++s) {
+                const V2<T> gr[2] = {(s == 0 ? gc[0][0] : gc[1][0]) * dtv, (s == 0 ? gc[0][1] : gc[1][1]) * dtv};
                 const T* W = P + P_W + s * species_block(HC);
                 W10<T> nx = load_w10(W);
 #pragma clang loop unroll(disable)
@@ -314,62 +423,65 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
                     const W10<T> c = nx;
                     if (j + 1 < HC) nx = load_w10(W + 10 * (j + 1));
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const T a1 = fma_(c.w[0], u[i], fma_(c.w[1], v[i], c.w[2]));
-                        const T a2 = fma_(c.w[3], u[i], fma_(c.w[4], v[i], c.w[5]));
-                        const T a3 = fma_(c.w[6], u[i], fma_(c.w[7], v[i], c.w[8]));
-                        const T p12 = a1 * a2;
-                        const T gw = gr[i] * c.w[9];
-                        const T q1 = gw * (a2 * a3), q2 = gw * (a1 * a3), q3 = gw * p12;
-                        du[i] = fma_(q1, c.w[0], fma_(q2, c.w[3], fma_(q3, c.w[6], du[i])));
-                        dv[i] = fma_(q1, c.w[1], fma_(q2, c.w[4], fma_(q3, c.w[7], dv[i])));
+                    for (int h = 0; h < 2; ++h) {
+                        const V2<T> a1 = vfma(vs(c.w[0]), U[h], vfma(vs(c.w[1]), V[h], vs(c.w[2])));
+                        const V2<T> a2 = vfma(vs(c.w[3]), U[h], vfma(vs(c.w[4]), V[h], vs(c.w[5])));
+                        const V2<T> a3 = vfma(vs(c.w[6]), U[h], vfma(vs(c.w[7]), V[h], vs(c.w[8])));
+                        const V2<T> p12 = a1 * a2;
+                        const V2<T> gw = gr[h] * vs(c.w[9]);
+                        const V2<T> q1 = gw * (a2 * a3), q2 = gw * (a1 * a3), q3 = gw * p12;
+                        du[h] = vfma(q1, vs(c.w[0]), vfma(q2, vs(c.w[3]), vfma(q3, vs(c.w[6]), du[h])));
+                        dv[h] = vfma(q1, vs(c.w[1]), vfma(q2, vs(c.w[4]), vfma(q3, vs(c.w[7]), dv[h])));
                     }
                 }
             }
         }
-        T ou[4], ov[4];
+        const V2<T> cu = vs(P[P_COEF + 0]), cv = vs(P[P_COEF + 1]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const T tu = P[P_COEF + 0] * dl[0][i] + du[i];
-            const T tv = P[P_COEF + 1] * dl[1][i] + dv[i];
-            ou[i] = gc[0][i] + tu;
-            ov[i] = gc[1][i] + tv;
-            if (gfr) { ou[i] += ju[i]; ov[i] += jv[i]; }
+        for (int h = 0; h < 2; ++h) {
+            const V2<T> tu = cu * dl[0][h] + du[h];
+            const V2<T> tv = cv * dl[1][h] + dv[h];
+            V2<T> ou = gc[0][h] + tu, ov = gc[1][h] + tv;
+            if (gfr) {
+                ou += V2<T>{ju[2 * h], ju[2 * h + 1]};
+                ov += V2<T>{jv[2 * h], jv[2 * h + 1]};
+            }
+            stv2(nxt + off + 2 * h, ou);
+            stv2(nxt + TL::PLANE + off + 2 * h, ov);
         }
-        lds_store4(nxt + off, ou);
-        lds_store4(nxt + TL::PLANE + off, ov);
     }
 }
 
+// PRE: the pointwise operands of sub-step M+1 are requested before sub-step M is computed and stay in flight across
+// its LDS barrier (one strip per lane only); `ops` holds the operands of sub-step M, requested one sub-step earlier.
 template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE>
 __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__ hbase, const T* __restrict__ gbase,
                                              T* __restrict__ abase, long frame_stride, unsigned inj_mask,
                                              T* __restrict__ g_h0, int steps_to_zero, const TileGeom& g, int ty0,
                                              int tx0, const T* __restrict__ P, double (&acc_c)[2],
-                                             const StripOps<T> (&pre)[PRE ? K : 1])
+                                             const StripOps<T>& ops)
 {
     T* cur = (M & 1) ? b1 : b0;
     T* nxt = (M & 1) ? b0 : b1;
     const long fo = -(long)(M + 1) * frame_stride;         // frame t-1-M relative to frame t
+    StripOps<T> ahead;
+    if constexpr (PRE && M + 1 < K) {
+        const long fn = -(long)(M + 2) * frame_stride;
+        adj_load_ops<T, K, BX, BY, NT, M + 1>(ahead, 0, hbase + fn, (inj_mask >> (M + 1)) & 1u ? gbase + fn : nullptr, g,
+                                              ty0, tx0);
+    }
     adj_substep<T, HC, K, BX, BY, NT, M, PRE>(cur, nxt, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g,
-                                              ty0, tx0, P, acc_c, pre[PRE ? M : 0]);
+                                              ty0, tx0, P, acc_c, ops);
+    PI_STAMP(2 + 3 * M);
     lds_barrier();
+    PI_STAMP(3 + 3 * M);
     // the adjoint of frame 0 is the caller's dL/dh0 output
     T* dst = (M + 1 == steps_to_zero && g_h0) ? g_h0 : abase + fo;
     tile_store<T, K, BX, BY, NT>(nxt, dst, g, ty0, tx0);
+    PI_STAMP(4 + 3 * M);
     if constexpr (M + 1 < K)
         adj_substeps<T, HC, K, BX, BY, NT, M + 1, PRE>(b0, b1, hbase, gbase, abase, frame_stride, inj_mask, g_h0,
-                                                       steps_to_zero, g, ty0, tx0, P, acc_c, pre);
-}
-
-template <typename T, int K, int BX, int BY, int NT, int M>
-__device__ __forceinline__ void adj_prefetch_all(StripOps<T> (&pre)[K], const T* __restrict__ hbase,
-                                                 const T* __restrict__ gbase, long frame_stride, unsigned inj_mask,
-                                                 const TileGeom& g, int ty0, int tx0)
-{
-    const long fo = -(long)(M + 1) * frame_stride;
-    adj_load_ops<T, K, BX, BY, NT, M>(pre[M], 0, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g, ty0, tx0);
-    if constexpr (M + 1 < K) adj_prefetch_all<T, K, BX, BY, NT, M + 1>(pre, hbase, gbase, frame_stride, inj_mask, g, ty0, tx0);
+                                                       steps_to_zero, g, ty0, tx0, P, acc_c, ahead);
 }
 
 template <typename T, int HC, int K, int BX, int BY, int NT>
@@ -379,23 +491,34 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
                      double* __restrict__ partials, int np, const T* __restrict__ P, TileGeom g)
 {
     using TL = Tile<K, BX, BY>;
-    // Prefetching every sub-step's operands at kernel start was measured SLOWER on MI355X (17.6 vs 15.5 us per
-    // K=4 launch: 64 extra VGPRs and the requests queue ahead of the window load), so it stays off.
-    constexpr bool PRE = false;
+    // Operand pipeline: one sub-step ahead (2 x 16 VGPRs).  Requesting ALL sub-steps' operands at kernel start was
+    // measured slower (17.6 vs 15.5 us per K=4 launch: 64 extra VGPRs, requests queued ahead of the window load).
+    constexpr bool PRE = PI_TILE_ADJ_PIPE && TL::region_n(0) / 4 <= NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* b0 = reinterpret_cast<T*>(smem_raw);
     T* b1 = b0 + 2 * TL::PLANE;
     const int tile = blockIdx.x;
     const int ty0 = (tile / g.tiles_x) * BY, tx0 = (tile % g.tiles_x) * BX;
-    StripOps<T> pre[PRE ? K : 1];
-    if constexpr (PRE) adj_prefetch_all<T, K, BX, BY, NT, 0>(pre, hframe_t, gframe_t, frame_stride, inj_mask, g, ty0, tx0);
-    tile_load<T, K, BX, BY, NT>(aframe_t, g, ty0, tx0, b0);
-    lds_barrier();                                         // LDS only: the operand prefetches stay in flight
+    PI_STAMP(0);
+    WindowLoader<T, K, BX, BY, NT> wl;
+    wl.issue(aframe_t, g, ty0, tx0);                       // adjoint window first, then the operands of sub-step 0
+    // running diffusion-coefficient partial of this tile: requested now, needed at the very end (was a dependent
+    // load -> add -> store at the end of every launch: 1 us)
+    double* pslot = partials + (long)blockIdx.x * np + P_COEF + (threadIdx.x & 1);
+    const double pold = threadIdx.x < 2 ? *pslot : 0.0;
+    StripOps<T> ops0;
+    if constexpr (PRE)
+        adj_load_ops<T, K, BX, BY, NT, 0>(ops0, 0, hframe_t - frame_stride, inj_mask & 1u ? gframe_t - frame_stride : nullptr,
+                                          g, ty0, tx0);
+    wl.commit(b0);
+    lds_barrier();                                         // LDS only: the operand loads stay in flight
+    PI_STAMP(1);
     double acc_c[2] = {0.0, 0.0};                          // heavily cancelling sums (stencil row-sum ~ 0): fp64
     adj_substeps<T, HC, K, BX, BY, NT, 0, PRE>(b0, b1, hframe_t, gframe_t, aframe_t, frame_stride, inj_mask, g_h0,
-                                               steps_to_zero, g, ty0, tx0, P, acc_c, pre);
+                                               steps_to_zero, g, ty0, tx0, P, acc_c, ops0);
     // diffusion-coefficient gradients of this tile over the K sub-steps: one reduction per launch
-    __syncthreads();
+    // (LDS-only barriers: the last frame's global stores need not drain first)
+    lds_barrier();
     double* red = reinterpret_cast<double*>(b0);           // state buffers are dead now
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
 #pragma unroll
@@ -403,12 +526,13 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
         const double r = wave_sum_to_last(acc_c[s]);
         if (lane == REDUCE_LANE) red[wave * 2 + s] = r;
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < 2) {
         double sum = 0.0;
         for (int w = 0; w < NT / WAVE; ++w) sum += red[w * 2 + threadIdx.x];
-        partials[(long)blockIdx.x * np + P_COEF + threadIdx.x] += sum;
+        *pslot = pold + sum;
     }
+    PI_STAMP(15);
 }
 
 }  // namespace pi

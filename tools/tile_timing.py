@@ -6,12 +6,12 @@ import numpy as np, torch
 import percnn_amd as pa
 from bench import load_params, make_cell
 dev = torch.device("cuda:0")
-for reaction in ("poly", "factored"):
+for reaction in ("poly",):
     cell = make_cell("gs2d", load_params("gs2d_big_512x512.npz"), dev, reaction)
     with torch.no_grad():
         P = cell.param_block().contiguous()
     traj = torch.rand((41, 2, 512, 512), device=dev) * 0.1 + 0.5
-    for nt in (512, 256):
+    for nt in (512,):
         pa.set_option("tile_nt", nt)
         for _ in range(3):
             pa.rollout_fwd_(traj, P)
@@ -27,3 +27,17 @@ for reaction in ("poly", "factored"):
         print(f"{reaction} NT={nt}: last launch, us since first block start (median over 256 blocks | max)")
         for i in [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15]:
             print(f"   {names[i]:7s} median {np.median(rel[:, i]):7.2f}  min {rel[:, i].min():7.2f}  max {rel[:, i].max():7.2f}")
+        # adjoint sweep (sweep only)
+        g = torch.randn_like(traj) * 1e-6
+        pa.set_option("skip_wgrad", 1)
+        for _ in range(2):
+            pa.rollout_bwd(traj, g, P)
+        torch.cuda.synchronize()
+        pa.set_option("skip_wgrad", 0)
+        assert L.percnn_pi_debug_stamps(buf, 256 * 16) == 0
+        st = np.array(buf, dtype=np.int64).reshape(256, 16)
+        rel = (st - st[:, 0].min()) / 100.0
+        an = ["start", "window"] + [f"{w}{m}" for m in range(4) for w in ("comp", "barr", "stor")] + ["-", "end"]
+        print(f"{reaction} NT={nt}: ADJOINT last launch")
+        for i in list(range(14)) + [15]:
+            print(f"   {an[i]:7s} median {np.median(rel[:, i]):7.2f}  min {rel[:, i].min():7.2f}  max {rel[:, i].max():7.2f}")
