@@ -30,6 +30,7 @@ struct Options {
     int fuse_wgrad = 0;     // rollout sweep uses the fused per-step kernel (all gradients reduced every step) instead of
                             // sweep + one time-parallel reduction (experiment: saves the reduction pass, costs per-step reductions)
     int skip_wgrad = 0;     // diagnostics: rollout_bwd runs the adjoint sweep only (bench uses it to time the sweep alone)
+    int tile_xcd = 1;       // XCD-aware block -> tile map of the 2D tile kernels (0 = identity)
     int tile_by = 32;       // tile height of the 2D tile kernels (32, or 16 = twice the workgroups: 2 per CU at 512^2)
     int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
                             // small grid is spread over all CUs instead of being packed onto a few
@@ -96,9 +97,30 @@ int make_problem(int hc, int ndim, const int64_t* shape, bool slab, Problem& p)
     return 0;
 }
 
+pi::FastDiv make_fastdiv(unsigned d)
+{
+    pi::FastDiv f{0u, 0u};
+    if (d <= 1) return f;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;                                   // l = ceil(log2 d) >= 1
+    f.m = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+    f.s = l - 1;
+    return f;
+}
+
+// chunk-id decomposition of the direct kernels without integer division (vec = points per lane of this launch)
+void set_fastdiv(Geom& g, int vec)
+{
+    const long nchunks = (long)g.rows * (g.W / vec);
+    g.fastdiv = nchunks < (1L << 31) ? 1 : 0;
+    g.dcpr = make_fastdiv((unsigned)(g.W / vec));
+    g.dn1 = make_fastdiv((unsigned)g.n1);
+}
+
 Geom make_geom(const Problem& p)
 {
     Geom g;
+    g.fastdiv = 0; g.dcpr = pi::FastDiv{0u, 0u}; g.dn1 = pi::FastDiv{0u, 0u};
     g.n0 = (int)p.n0; g.n1 = (int)p.n1; g.W = (int)p.W;
     g.rows = (int)(p.n0 * p.n1);
     g.s0 = (long)(p.n1 * p.W);
@@ -130,7 +152,8 @@ int pick_vec(const Problem& p, std::initializer_list<const void*> ptrs)
 template <typename T, int NDIM, int HC, int VEC>
 hipError_t launch_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
 {
-    const Geom g = make_geom(p);
+    Geom g = make_geom(p);
+    set_fastdiv(g, VEC);
     const long nchunks = (long)g.rows * (g.W / VEC);
     const int block = g_opt.block;
     const unsigned grid = (unsigned)((nchunks + block - 1) / block);
@@ -152,7 +175,8 @@ template <typename T, int NDIM, int HC, int VEC, bool WGRAD>
 hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partials, const T* P,
                       const Problem& p, hipStream_t st)
 {
-    const Geom g = make_geom(p);
+    Geom g = make_geom(p);
+    set_fastdiv(g, VEC);
     const int block = g_opt.block;
     const unsigned grid = bwd_grid(p, VEC);
     const size_t lds = align_up((size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T), 16) +
@@ -375,13 +399,30 @@ bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs)
     return true;
 }
 
+// XCD-aware tile map (pi::tile_of_block): split the tiles_y x tiles_x tile grid into 8 equal rectangles, as square as
+// possible; identity when the counts do not divide (ragged grids, small grids)
+pi::TileGeom make_tile_geom(const Problem& p, int by)
+{
+    const int tiles_x = (int)((p.W + TILE_B - 1) / TILE_B), tiles_y = (int)((p.n0 + by - 1) / by);
+    pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, tiles_x, 0, 0, 0};
+    if (!g_opt.tile_xcd) return g;
+    int best = -1;
+    for (int rx : {1, 2, 4, 8}) {
+        const int ry = pi::NXCD / rx;
+        if (tiles_x % rx || tiles_y % ry) continue;
+        const int rw = tiles_x / rx, rh = tiles_y / ry;
+        const int perim = rw + rh;                          // halo traffic of a rectangle ~ its perimeter
+        if (best < 0 || perim < best) { best = perim; g.rx = rx; g.rw = rw; g.rh = rh; }
+    }
+    return g;
+}
+
 template <typename T, int HC, int K, int NT, int BY = TILE_B>
 hipError_t launch_fwd_tile(T* frame_t, const T* P, const Problem& p, hipStream_t st)
 {
     using TL = pi::Tile<K, TILE_B, BY>;
-    const int tiles_x = (int)((p.W + TILE_B - 1) / TILE_B);
-    pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, tiles_x};
-    const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * tiles_x);
+    const pi::TileGeom g = make_tile_geom(p, BY);
+    const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
     const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + (size_t)g_opt.lds_pad;
     auto* k = pi::pi_fwd2d_tile_kernel<T, HC, K, TILE_B, BY, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
@@ -394,9 +435,8 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
                            int steps_to_zero, double* partials, const T* P, const Problem& p, hipStream_t st)
 {
     using TL = pi::Tile<K, TILE_B, BY>;
-    const int tiles_x = (int)((p.W + TILE_B - 1) / TILE_B);
-    pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, tiles_x};
-    const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * tiles_x);
+    const pi::TileGeom g = make_tile_geom(p, BY);
+    const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
     const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + (size_t)g_opt.lds_pad;
     auto* k = pi::pi_adj2d_tile_kernel<T, HC, K, TILE_B, BY, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
@@ -745,6 +785,7 @@ int percnn_pi_set_option(const char* key, long value)
         g_opt.tile = (int)value;
         return 0;
     }
+    if (!std::strcmp(key, "tile_xcd")) { g_opt.tile_xcd = value != 0; return 0; }
     if (!std::strcmp(key, "tile_by")) {
         if (value != 16 && value != 32) return PERCNN_PI_EINVAL;
         g_opt.tile_by = (int)value;

@@ -22,9 +22,9 @@ template <int NDIM>
 __device__ __forceinline__ long shifted(const Geom& g, int i0, int i1, int x, int a, int off)
 {
     int j0 = i0, j1 = i1, jx = x;
-    if (a == 0) j0 = wrap(i0 + off, g.n0);
-    else if (NDIM == 3 && a == 1) j1 = wrap(i1 + off, g.n1);
-    else jx = wrap(x + off, g.W);
+    if (a == 0) j0 = wrap_near(i0 + off, g.n0);
+    else if (NDIM == 3 && a == 1) j1 = wrap_near(i1 + off, g.n1);
+    else jx = wrap_near(x + off, g.W);
     return (long)j0 * g.s0 + (NDIM == 3 ? (long)j1 * g.W : 0) + jx;
 }
 

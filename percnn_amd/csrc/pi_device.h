@@ -76,6 +76,16 @@ __device__ __forceinline__ void poly_dr(const T* __restrict__ c, T u, T v, T& ru
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ int wrap(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+// stencil neighbours: i in [-2, n+1] and n >= 2, so one conditional add/sub is the periodic wrap.  The runtime `%`
+// above is ~20 quarter-rate integer instructions; eight of them per point made the direct 3D kernels VALU-bound.
+__device__ __forceinline__ int wrap_near(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
+
+// exact x / d for 0 <= x < 2^31 from host-computed (m, s): d == 1 -> m = 0;  else l = ceil(log2 d),
+// m = ceil(2^(31+l) / d) (< 2^32), s = l - 1 and  x / d == umulhi(x, m) >> s   (Granlund-Montgomery, N = 31)
+struct FastDiv {
+    unsigned m, s;
+    __device__ __forceinline__ unsigned div(unsigned x) const { return m ? (__umulhi(x, m) >> s) : x; }
+};
 
 // XCD-aware block remap: hand each XCD (private 4 MiB L2) a contiguous range of the grid so the
 // axis-0 neighbours of a block's rows are served by the same L2.  Pure speed; any mapping is correct.

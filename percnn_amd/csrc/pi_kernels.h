@@ -19,6 +19,8 @@ struct Geom {
     long ss;            // species stride (elements); slab layout: (n0+4)*s0
     long off;           // element offset of the first interior point; slab layout: 2*s0
     int wrap0;          // 1: axis 0 periodic; 0: two halo planes present on each side (slab)
+    FastDiv dcpr, dn1;  // chunk id -> (row, chunk in row) and row -> (plane, row in plane) without integer division;
+    int fastdiv;        // set by the launcher when the chunk count is < 2^31 (else the 64-bit path below is used)
 };
 
 // radius-2 star: lap[i] = c0*f(x) + sum_axes sum_t w[axis][t] * f(x + FLIP*offs[t]); FLIP=-1 is the adjoint
@@ -33,7 +35,7 @@ __device__ __forceinline__ void star(const T* __restrict__ f, const T* __restric
     for (int t = 0; t < 4; ++t) {
         const int k = FLIP * (t < 2 ? t - 2 : t - 1);
         int j0 = i0 + k;
-        if (g.wrap0) j0 = wrap(j0, g.n0);
+        if (g.wrap0) j0 = wrap_near(j0, g.n0);
         const Pack<T, VEC> nb = ld<T, VEC>(f + e + (long)(j0 - i0) * g.s0);
         const T w = P[P_TAPS + t];
 #pragma unroll
@@ -43,7 +45,7 @@ __device__ __forceinline__ void star(const T* __restrict__ f, const T* __restric
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int k = FLIP * (t < 2 ? t - 2 : t - 1);
-            const int j1 = wrap(i1 + k, g.n1);
+            const int j1 = wrap_near(i1 + k, g.n1);
             const Pack<T, VEC> nb = ld<T, VEC>(f + e + (long)(j1 - i1) * g.W);
             const T w = P[P_TAPS + 4 + t];
 #pragma unroll
@@ -54,10 +56,10 @@ __device__ __forceinline__ void star(const T* __restrict__ f, const T* __restric
     T win[VEC + 4];
     const T* row = f + e - x0;
     if constexpr (VEC == 1) {
-        win[0] = row[wrap(x0 - 2, g.W)];
-        win[1] = row[wrap(x0 - 1, g.W)];
-        win[3] = row[wrap(x0 + 1, g.W)];
-        win[4] = row[wrap(x0 + 2, g.W)];
+        win[0] = row[wrap_near(x0 - 2, g.W)];
+        win[1] = row[wrap_near(x0 - 1, g.W)];
+        win[3] = row[wrap_near(x0 + 1, g.W)];
+        win[4] = row[wrap_near(x0 + 2, g.W)];
     } else {
         const int xl = x0 >= 2 ? x0 - 2 : x0 - 2 + g.W;
         const int xr = x0 + VEC < g.W ? x0 + VEC : x0 + VEC - g.W;
@@ -80,6 +82,20 @@ __device__ __forceinline__ void star(const T* __restrict__ f, const T* __restric
 template <int NDIM>
 __device__ __forceinline__ void chunk_coords(const Geom& g, long cid, int cpr, int vec, int& i0, int& i1, int& x0, long& e)
 {
+    if (g.fastdiv) {
+        const unsigned row = g.dcpr.div((unsigned)cid);
+        x0 = (int)((unsigned)cid - row * (unsigned)cpr) * vec;
+        if constexpr (NDIM == 3) {
+            i0 = (int)g.dn1.div(row);
+            i1 = (int)(row - (unsigned)i0 * (unsigned)g.n1);
+            e = (long)i0 * g.s0 + (long)i1 * g.W + x0;
+        } else {
+            i0 = (int)row;
+            i1 = 0;
+            e = (long)i0 * g.s0 + x0;
+        }
+        return;
+    }
     const long row = cid / cpr;
     x0 = (int)(cid - row * cpr) * vec;
     if constexpr (NDIM == 3) {
@@ -194,6 +210,8 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
     // every wave runs the same number of iterations (wave-level reductions inside)
     const long iters = (nchunks + stride - 1) / stride;
 
+    double lane_c[2] = {0.0, 0.0};
+
     for (long it = 0; it < iters; ++it) {
         const long cid_raw = first + it * stride;
         const bool valid = cid_raw < nchunks;
@@ -249,8 +267,12 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
                         acc[8] = fma_(gr, uu * v2, acc[8]); acc[9] = fma_(gr, v2 * vv, acc[9]);
                     }
                 }
-                acc_c = wave_sum_to_last(acc_c);
-                if (lane == REDUCE_LANE) redc[wave * 2 + s] += acc_c;
+                if constexpr (WGRAD) {
+                    acc_c = wave_sum_to_last(acc_c);
+                    if (lane == REDUCE_LANE) redc[wave * 2 + s] += acc_c;
+                } else {
+                    lane_c[s] += acc_c;                  // sweep flavour: one cross-lane reduction per launch, not per chunk
+                }
                 if constexpr (WGRAD) {
 #pragma unroll
                     for (int m = 0; m < 10; ++m) acc[m] = wave_sum_to_last(acc[m]);
@@ -275,11 +297,15 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
                 acc_c += (double)(dl[s][i] * hs.v[i]);
                 acc_b4 += gr[i];
             }
-            acc_c = wave_sum_to_last(acc_c);
-            if constexpr (WGRAD) acc_b4 = wave_sum_to_last(acc_b4);
-            if (lane == REDUCE_LANE) {
-                redc[wave * 2 + s] += acc_c;
-                if constexpr (WGRAD) myred[gbase + 10 * hc] += acc_b4;
+            if constexpr (WGRAD) {
+                acc_c = wave_sum_to_last(acc_c);
+                acc_b4 = wave_sum_to_last(acc_b4);
+                if (lane == REDUCE_LANE) {
+                    redc[wave * 2 + s] += acc_c;
+                    myred[gbase + 10 * hc] += acc_b4;
+                }
+            } else {
+                lane_c[s] += acc_c;
             }
 #pragma unroll
             for (int j = 0; j < hc; ++j) {
@@ -338,6 +364,13 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
         }
     }
 
+    if constexpr (!WGRAD) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const double r = wave_sum_to_last(lane_c[s]);
+            if (lane == REDUCE_LANE) redc[wave * 2 + s] += r;
+        }
+    }
     __syncthreads();
     for (int idx = threadIdx.x; idx < np; idx += blockDim.x) {
         if (idx == P_DT || (idx >= P_C0 && idx < P_W)) continue;   // dt and the frozen stencil carry no gradient
