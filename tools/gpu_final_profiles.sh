@@ -3,7 +3,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
-for wl in gs2d_512 gs3d_128 lo2d_512; do
+for wl in gs2d_512 gs3d_128 lo2d_512 bur1_100 lo1_100; do
   (timeout 900 python $R/bench.py --workload $wl 2>&1 | tail -1) > $R/gpurun_out/final_bench_$wl.json
   rm -rf /tmp/kt; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --workload $wl --no-cpu-baseline --steps 3 --warmup 1 > /tmp/kt.log 2>&1
   python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) > $R/gpurun_out/final_kernel_stats_$wl.txt 2>&1
@@ -18,7 +18,10 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   python $R/tools/pmc_summary.py $(find /tmp/pmcout -name "*.db" | head -1) "$wl T=100" | grep "pi::" >> $R/gpurun_out/final_pmc_summary.txt 2>&1
 done
 done
+(timeout 900 python $R/bench.py --workload bur1_512 --no-cpu-baseline 2>&1 | tail -1) > $R/gpurun_out/final_bench_bur1_512.json
 cd $R
+timeout 900 python tools/size_sweep.py --out gpurun_out/size_sweep.json 2>&1 | grep -v amdgpu.ids > gpurun_out/size_sweep.txt
+timeout 600 python tools/s1_bench.py --out gpurun_out/s1_size_sweep.json 2>&1 | grep -v amdgpu.ids > gpurun_out/s1_size_sweep.txt
 cat gpurun_out/final_pmc_summary.txt | cut -c1-200
 for f in gpurun_out/final_bench_*.json; do echo $f; python -c "
 import json,sys

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""profiles/traffic_<workload>.json (read by bench.py for roofline.traffic) from the per-kernel PMC summary that
+tools/gpu_final_profiles.sh wrote (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes;
+values are KiB per launch).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams."""
+import json, re, sys, os
+
+src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01_final_pmc_fetch_write_summary.txt"
+rows = {}
+for line in open(src):
+    m = re.match(r"(\S+) T=(\d+) \| (\w+) \| n=(\d+) avg=([\d.]+).*\| (?:void )?pi::(\w+)", line)
+    if m:
+        wl, T, ctr, n, avg, kern = m.groups()
+        rows.setdefault(wl, {}).setdefault(kern, {})[ctr] = float(avg) * 1024.0
+for wl, kernels in rows.items():
+    out = {"_source": f"{src} (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --workload {wl} --T 100)",
+           "_note": "bytes per launch. FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane coalesced reads "
+                    "(verified on pi_moments_kernel: raw FETCH = 0.49 x the 16 B/point-step it streams)", "detail": {}}
+    for k, v in kernels.items():
+        f, w = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
+        out["detail"][k] = {"fetch_raw_bytes": f, "fetch_corrected_bytes": 2 * f, "write_bytes": w, "hbm_bytes_per_launch": 2 * f + w}
+        if k in ("pi_adj2d_tile_kernel", "pi_fwd2d_tile_kernel", "pi_fwd_kernel", "pi_bwd_kernel"):
+            out[k] = 2 * f + w
+    out["pi_moments_kernel"] = None        # one launch per rollout: per-launch bytes depend on T
+    json.dump(out, open(os.path.join("profiles", f"traffic_{wl}.json"), "w"), indent=1)
+    print(wl, {k: round(v / 1e6, 2) for k, v in out.items() if isinstance(v, float)})
