@@ -272,9 +272,95 @@ class Stage3BurgersCell(nn.Module):
         return prev_state.to(self.nu_u.device)
 
 
+# ------------------------------------------------------------------------------------------------
+# 3D IC generator: same layers, same parameters, different evaluation.  On MI355X the stock path (MIOpen
+# ConvTranspose3d 8 -> 8, 5^3, at 128^3) takes 320 ms forward+backward -- 88 % of a whole 500-step training iteration
+# once the rollout is fused (tools/upscaler_share.py) -- so the two transposed convolutions are evaluated as dense
+# contractions on rocBLAS instead: 40 -> ~2 ms and 320 -> ~21 ms, results equal to 1e-6 (tests/test_host_logic.py).
+# ------------------------------------------------------------------------------------------------
+def _unfold3(x: torch.Tensor, k: int) -> torch.Tensor:
+    """[1,C,D,H,W] -> [(D-k+1)*(H-k+1)*(W-k+1), C*k^3] (row = output point, column = (c, dz, dy, dx))"""
+    c = x.unfold(2, k, 1).unfold(3, k, 1).unfold(4, k, 1)               # [1,C,D',H',W',k,k,k]
+    d, h, w = c.shape[2:5]
+    return c.permute(0, 2, 3, 4, 1, 5, 6, 7).reshape(d * h * w, -1)
+
+
+def conv_transpose3d_s2k5(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose3d(k=5, stride=2, padding=2, output_padding=1) as ONE matmul on the input grid: output point
+    2m+p (p = parity per axis) only sees inputs m-1, m, m+1 through tap d = 2 + p - 2e, so
+    out[(p, co)](m) = sum_{ci, e in {-1,0,1}^3} x[ci](m + e) * W[ci, co, d(p, e)]  (tap 5 does not exist -> 0)."""
+    assert x.dim() == 5 and x.shape[0] == 1 and tuple(weight.shape[2:]) == (5, 5, 5)
+    ci, co = weight.shape[:2]
+    D, H, W = x.shape[2:]
+    dev = x.device
+    e = torch.arange(3, device=dev) - 1                                   # -1, 0, 1
+    pz = torch.arange(2, device=dev)
+    d = 2 + pz[:, None] - 2 * e[None, :]                                  # [parity, e] -> tap, 5 = missing
+    ok = d <= 4
+    d = d.clamp(max=4)
+    # Wp[(ci, ez, ey, ex), (pz, py, px, co)]
+    wz = weight[:, :, d]                                                  # [ci, co, p, e, 5, 5]
+    wzy = wz[:, :, :, :, d]                                               # [ci, co, pz, ez, py, ey, 5]
+    wzyx = wzy[:, :, :, :, :, :, d]                                       # [ci, co, pz, ez, py, ey, px, ex]
+    m = (ok[:, :, None, None, None, None] & ok[None, None, :, :, None, None] & ok[None, None, None, None, :, :])
+    wzyx = wzyx * m.to(weight.dtype)
+    Wp = wzyx.permute(0, 3, 5, 7, 2, 4, 6, 1).reshape(ci * 27, 8 * co)
+    cols = _unfold3(torch.nn.functional.pad(x, (1, 1, 1, 1, 1, 1)), 3)    # [D*H*W, ci*27]
+    out = cols @ Wp                                                       # [D*H*W, 8*co]
+    out = out.reshape(D, H, W, 2, 2, 2, co).permute(6, 0, 3, 1, 4, 2, 5).reshape(1, co, 2 * D, 2 * H, 2 * W)
+    return out + bias.view(1, co, 1, 1, 1)
+
+
+def _conv3d_k5_slabs(x: torch.Tensor, w2d: torch.Tensor, slab: int) -> torch.Tensor:
+    """'same' 5^3 cross-correlation of x [1,Ci,D,H,W] with w2d [Co, Ci*125], im2col in z-slabs of `slab` planes."""
+    D = x.shape[2]
+    xp = torch.nn.functional.pad(x, (2, 2, 2, 2, 2, 2))
+    outs = []
+    for z0 in range(0, D, slab):
+        z1 = min(z0 + slab, D)
+        cols = _unfold3(xp[:, :, z0:z1 + 4], 5)                          # [(z1-z0)*H*W, Ci*125]
+        outs.append((cols @ w2d.t()).reshape(z1 - z0, x.shape[3], x.shape[4], -1))
+    return torch.cat(outs, 0).permute(3, 0, 1, 2)[None]
+
+
+class _ConvTranspose3dS1K5(torch.autograd.Function):
+    """ConvTranspose3d(k=5, stride=1, padding=2) == cross-correlation with the flipped, channel-transposed kernel.
+    Forward, input gradient and weight gradient are all slab-wise im2col + matmul; the unfolded columns (1 GB per
+    16 planes of 128^2 x 8 channels) are never kept between forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ci, co = weight.shape[:2]
+        wf = weight.flip(2, 3, 4).transpose(0, 1).reshape(co, ci * 125)   # [co, (ci, d)]
+        ctx.save_for_backward(x, weight)
+        ctx.slab = max(1, int(2 ** 28 // max(1, x.shape[3] * x.shape[4] * ci * 125)))
+        return _conv3d_k5_slabs(x, wf, ctx.slab) + bias.view(1, co, 1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        ci, co = weight.shape[:2]
+        g = g.contiguous()
+        # dL/dx = 'same' cross-correlation of g with W itself: [ci, (co, d)]
+        wg = weight.reshape(ci, co * 125)
+        gx = _conv3d_k5_slabs(g, wg, ctx.slab)
+        # dL/dW[ci, co, d] = sum_o x[ci](o + 2 - d) g[co](o)  ->  correlate padded x columns with g, then flip the taps
+        D, H, W = x.shape[2:]
+        xp = torch.nn.functional.pad(x, (2, 2, 2, 2, 2, 2))
+        gw = torch.zeros(co, ci * 125, dtype=x.dtype, device=x.device)
+        gm = g[0].reshape(co, D, H * W)
+        for z0 in range(0, D, ctx.slab):
+            z1 = min(z0 + ctx.slab, D)
+            cols = _unfold3(xp[:, :, z0:z1 + 4], 5)                      # [(z1-z0)*H*W, ci*125], column (ci, t): x(o + t - 2)
+            gw += gm[:, z0:z1].reshape(co, -1) @ cols
+        gweight = gw.reshape(co, ci, 5, 5, 5).flip(2, 3, 4).transpose(0, 1)
+        return gx, gweight, g.sum(dim=(0, 2, 3, 4))
+
+
 class Upscaler(nn.Module):
-    """IC generator (train_2drd.py:26-41, train_3drd.py:41-56): stock torch.nn, runs once per
-    rollout and is off the hot path; provided so whole-model checkpoints load."""
+    """IC generator (train_2drd.py:26-41, train_3drd.py:41-56): stock torch.nn parameters (whole-model checkpoints
+    load); 2D runs on the stock path (0.6 ms at 512^2), 3D evaluates its two transposed convolutions as dense
+    contractions (see above).  Runs once per rollout."""
 
     def __init__(self, ndim: int = 2):
         super().__init__()
@@ -289,6 +375,11 @@ class Upscaler(nn.Module):
         self.convnet = nn.Sequential(*layers)
 
     def forward(self, h):
+        if h.dim() == 5 and h.shape[0] == 1:
+            ct1, act, ct2, out = self.convnet
+            y = act(conv_transpose3d_s2k5(h, ct1.weight, ct1.bias))
+            y = _ConvTranspose3dS1K5.apply(y, ct2.weight, ct2.bias)
+            return out(y)
         return self.convnet(h)
 
 
@@ -329,8 +420,14 @@ class RCNN(nn.Module):
         return F_pi.pi_rollout(self.init_state, self.cell.param_block(), self.step)
 
     def forward(self):
-        traj = self.trajectory()
+        if hasattr(self, "UpconvBlock"):
+            self.init_state = self.UpconvBlock(self.init_state_low)
         eff = set(self.effective_step)
-        outputs = [traj[0:1]] + [traj[k + 1:k + 2] for k in range(self.step) if k in eff]
-        second_last_state = traj[self.step - 1:self.step].clone() if self.step >= 2 else []
+        frames = [0] + [k + 1 for k in range(self.step) if k in eff]
+        n_out = len(frames)
+        if self.step >= 2:
+            frames.append(self.step - 1)                    # second_last_state rides along as one more output
+        outs = F_pi.pi_rollout_frames(self.init_state, self.cell.param_block(), self.step, frames)
+        outputs = list(outs[:n_out])
+        second_last_state = outs[n_out].clone() if self.step >= 2 else []
         return outputs, second_last_state

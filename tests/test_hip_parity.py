@@ -700,3 +700,48 @@ def test_advective_block_3d_and_fp32_vs_oracle(hip_device):
         g0, ag = pa.rollout_bwd(traj, dev_t(gt, hip_device), dev_t(A, hip_device))
         assert np.array_equal(g0.cpu().numpy(), g0_ref)
         assert rel_l2(ag.cpu().numpy(), ag_ref) < (2e-5 if dtype == np.float32 else 1e-12)
+
+
+@pytest.mark.parametrize("eff", ["dense", "sparse"])
+def test_module_frame_list_path_equals_trajectory_path(eff, hip_device):
+    """RCNN.forward() (list of frames, reference API) and RCNN.trajectory() (one tensor) give the same gradients;
+    second_last_state participates in autograd; an iteration with T = 300 frames stays cheap (the per-frame slicing
+    it replaces cost O(T^2) memory traffic in autograd)."""
+    import time
+    import percnn_amd as pa
+    torch.manual_seed(0)
+    steps = 300
+    cell = pa.gs2d_cell(8).to(hip_device)
+    for p in cell.filter_list:
+        p.weight.data.mul_(20.0)
+    from percnn_amd import synthetic
+    h0 = synthetic.gs_initial_state((64, 64), seed=0).to(hip_device).requires_grad_(True)
+    effective = list(range(steps)) if eff == "dense" else list(range(0, steps, 7))
+    w = torch.randn(steps + 1, 2, 64, 64, device=hip_device)
+
+    def via_list():
+        m = pa.RCNN(cell, step=steps, effective_step=effective, init_state=h0)
+        outs, sl = m()
+        out = torch.cat(tuple(outs), 0)
+        idx = [0] + [k + 1 for k in effective]
+        return (out * w[idx]).sum() + (sl ** 2).sum()
+
+    def via_traj():
+        m = pa.RCNN(cell, step=steps, effective_step=effective, init_state=h0)
+        traj = m.trajectory()
+        idx = [0] + [k + 1 for k in effective]
+        return (traj[idx] * w[idx]).sum() + (traj[steps - 1] ** 2).sum()
+
+    grads = []
+    for fn in (via_list, via_traj):
+        cell.zero_grad(); h0.grad = None
+        fn().backward()
+        grads.append([h0.grad.clone()] + [p.grad.clone() for p in cell.parameters() if p.grad is not None])
+    for a, b in zip(*grads):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    via_list().backward()
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.5
+

@@ -211,3 +211,48 @@ def test_stage3_burgers_cell_schema_and_block():
     A.sum().backward()
     assert all(getattr(cell, n).grad is not None for n in pa.Stage3BurgersCell.INIT)
     assert pa.lib().percnn_pi_param_count(-1) == 60
+
+
+def test_frame_gradient_assembly_zero_copy_and_masked():
+    """RCNN.forward hands back T+1 frames; their gradients come back as slices of one buffer when the caller cats
+    them (zero-copy), or individually / partly missing (copied, rest masked)."""
+    from percnn_amd import functional as Fp
+    traj = torch.zeros(6, 2, 4, 4)
+    big = torch.arange(2 * 6 * 2 * 4 * 4, dtype=torch.float32).reshape(12, 2, 4, 4)
+    dense = big[3:9]                                        # a gradient buffer that does not start at its storage's origin
+    grads = tuple(dense[k:k + 1] for k in range(6))         # what CatBackward produces
+    g, mask = Fp._assemble_frame_grads(grads, tuple(range(6)), traj)
+    assert mask is None and g.data_ptr() == dense.data_ptr() and torch.equal(g, dense)
+    # the last frame would run past the end of the storage -> no aliasing, falls back to copies
+    tail = tuple(big[7 + k:8 + k] for k in range(5)) + (torch.ones(1, 2, 4, 4),)
+    g, mask = Fp._assemble_frame_grads(tail, tuple(range(6)), traj)
+    assert mask == [True] * 6 and torch.equal(g[:5], big[7:12]) and torch.equal(g[5], torch.ones(2, 4, 4))
+    # sparse frames, one missing gradient, one frame listed twice (second_last_state): summed
+    frames = (0, 2, 5, 4, 4)
+    gr = (torch.full((1, 2, 4, 4), 1.0), None, torch.full((1, 2, 4, 4), 3.0), torch.full((1, 2, 4, 4), 4.0),
+          torch.full((1, 2, 4, 4), 0.5))
+    g, mask = Fp._assemble_frame_grads(gr, frames, traj)
+    assert mask == [True, False, False, False, True, True]
+    assert float(g[0].mean()) == 1.0 and float(g[5].mean()) == 3.0 and float(g[4].mean()) == 4.5
+
+
+def test_3d_upscaler_contraction_path_equals_stock_layers():
+    """The 3D IC generator evaluates its transposed convolutions as matmuls (MIOpen's ConvTranspose3d is 15x slower on
+    MI355X); values and all gradients must equal the stock torch.nn layers it holds (train_3drd.py:41-56)."""
+    import percnn_amd as pa
+    torch.manual_seed(1)
+    up = pa.Upscaler(3).double()
+    x = torch.rand(1, 2, 6, 5, 7, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(1, 2, 12, 10, 14, dtype=torch.float64)
+    ref = up.convnet(x)
+    gref = torch.autograd.grad((ref * w).sum(), [x] + list(up.parameters()))
+    out = up(x)
+    assert out.shape == ref.shape and torch.allclose(out, ref, rtol=1e-12, atol=1e-12)
+    gout = torch.autograd.grad((out * w).sum(), [x] + list(up.parameters()))
+    for a, b in zip(gout, gref):
+        assert torch.allclose(a, b, rtol=1e-10, atol=1e-12)
+    # float32, cubic, several z-slabs
+    up32 = pa.Upscaler(3)
+    x32 = torch.rand(1, 2, 8, 8, 8)
+    assert torch.allclose(up32(x32), up32.convnet(x32), rtol=1e-4, atol=1e-5)
+
