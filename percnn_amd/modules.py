@@ -417,6 +417,8 @@ class RCNN(nn.Module):
         """[step+1, 2, *S]: every state of the rollout (what callers cat together, train_2drd.py:394)."""
         if hasattr(self, "UpconvBlock"):
             self.init_state = self.UpconvBlock(self.init_state_low)
+        if hasattr(self.cell, "rollout"):                   # cells with their own kernels (Stage-1 block)
+            return self.cell.rollout(self.init_state, self.step)
         return F_pi.pi_rollout(self.init_state, self.cell.param_block(), self.step)
 
     def forward(self):
@@ -427,7 +429,10 @@ class RCNN(nn.Module):
         n_out = len(frames)
         if self.step >= 2:
             frames.append(self.step - 1)                    # second_last_state rides along as one more output
-        outs = F_pi.pi_rollout_frames(self.init_state, self.cell.param_block(), self.step, frames)
+        if hasattr(self.cell, "rollout_frames"):            # cells with their own kernels (Stage-1 block)
+            outs = self.cell.rollout_frames(self.init_state, self.step, frames)
+        else:
+            outs = F_pi.pi_rollout_frames(self.init_state, self.cell.param_block(), self.step, frames)
         outputs = list(outs[:n_out])
         second_last_state = outs[n_out].clone() if self.step >= 2 else []
         return outputs, second_last_state

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .functional import _require, _stream, check_star_stencil
+from .functional import _require, _stream, check_star_stencil, _assemble_frame_grads
 
 NP = 16 + 6 * 16 * 52 + 32 + 2          # PERCNN_PI_S1_PARAMS
 _OFF_W, _OFF_W4, _OFF_B4 = 16, 16 + 4992, 16 + 4992 + 32
@@ -148,6 +148,48 @@ def stage1_rollout(h0: torch.Tensor, P: torch.Tensor, steps: int) -> torch.Tenso
     return Stage1RolloutFunction.apply(h0, P, int(steps))
 
 
+class Stage1RolloutFramesFunction(torch.autograd.Function):
+    """T fused steps returned as the reference returns them -- a tuple of [1,2,H,W] frames (bur1:277-303 appends to a
+    Python list) -- as the outputs of ONE autograd node (see functional.PiRolloutFramesFunction for why)."""
+
+    @staticmethod
+    def forward(ctx, h0, P, steps, frames):
+        if h0.dim() != 4 or h0.shape[0] != 1 or h0.shape[1] != 2:
+            raise RuntimeError("percnn_amd.stage1: state must be [1,2,H,W] (batch 1, as everywhere in the reference)")
+        P = P.contiguous()
+        traj = torch.empty((steps + 1,) + tuple(h0.shape[1:]), dtype=torch.float32, device=h0.device)
+        traj[0].copy_(h0[0])
+        rollout_fwd_(traj, P)
+        ctx.save_for_backward(traj, P)
+        ctx.frames = tuple(int(k) for k in frames)
+        return tuple(traj[k:k + 1] for k in ctx.frames)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        traj, P = ctx.saved_tensors
+        if all(g is None for g in grads):
+            return None, None, None, None
+        g_traj, mask = _assemble_frame_grads(grads, ctx.frames, traj)
+        g_h0, pg = rollout_bwd(traj, g_traj, P, frame_mask=mask)
+        return g_h0[None], pg.to(torch.float32), None, None
+
+
+class Upscaler(nn.Module):
+    """IC generator of the Stage-1 scripts (bur1:38-52, lo1:38-51): ConvTranspose2d(2 -> 16, 5, stride 2) - tanh -
+    Conv2d(16 -> 2, 1); stock torch.nn, off the hot path.  Registers ``up0`` / ``out`` AND ``convnet`` like the
+    reference, so the checkpoint's duplicated keys (UpconvBlock.up0.* and UpconvBlock.convnet.0.*) load."""
+
+    def __init__(self):
+        super().__init__()
+        self.up0 = nn.ConvTranspose2d(2, 16, kernel_size=5, padding=2, stride=2, output_padding=1, bias=True)
+        self.tanh = nn.Tanh()
+        self.out = nn.Conv2d(16, 2, 1, 1, padding=0, bias=True)
+        self.convnet = nn.Sequential(self.up0, self.tanh, self.out)
+
+    def forward(self, h):
+        return self.convnet(h)
+
+
 class Stage1Cell(nn.Module):
     """Drop-in for the Stage-1 ``RCNNCell`` (bur1:54-187, lo1:53-180).  ``cell(h) -> (ch, ch)``;
     ``cell.rollout(h0, T)`` -> [T+1,2,H,W] runs the reference's T-step loop (bur1:283-303) fused."""
@@ -197,6 +239,10 @@ class Stage1Cell(nn.Module):
 
     def rollout(self, h0: torch.Tensor, steps: int) -> torch.Tensor:
         return stage1_rollout(h0, self.param_block(), steps)
+
+    def rollout_frames(self, h0: torch.Tensor, steps: int, frames: Sequence[int]):
+        """hook used by ``percnn_amd.RCNN``: the requested frames as outputs of one autograd node"""
+        return Stage1RolloutFramesFunction.apply(h0, self.param_block(), int(steps), tuple(frames))
 
     def forward(self, h: torch.Tensor):
         ch = self.rollout(h, 1)[1:2]

@@ -89,6 +89,26 @@ def test_state_dict_schema_and_block_layout():
         cell(torch.zeros(1, 2, 16, 16))                 # CPU tensors are refused: no fallback path
 
 
+def test_whole_model_schema_matches_the_stage1_checkpoints():
+    """pa.RCNN(Stage1Cell, upscaler=stage1.Upscaler()) has exactly the key set / shapes of the reference's Stage-1
+    checkpoint['model_state_dict'] (both scripts; listed from the shipped checkpoint.pt files)."""
+    import percnn_amd as pa
+    m = pa.RCNN(pa.Stage1Cell("lo"), step=4, effective_step=[0, 1, 2, 3], upscaler=pa.stage1.Upscaler(),
+                init_state_low=torch.zeros(1, 2, 8, 8))
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    exp = {"UpconvBlock.up0.weight": (2, 16, 5, 5), "UpconvBlock.up0.bias": (16,), "UpconvBlock.out.weight": (2, 16, 1, 1),
+           "UpconvBlock.out.bias": (2,), "UpconvBlock.convnet.0.weight": (2, 16, 5, 5), "UpconvBlock.convnet.0.bias": (16,),
+           "UpconvBlock.convnet.2.weight": (2, 16, 1, 1), "UpconvBlock.convnet.2.bias": (2,),
+           "crnn_cell.CA": (), "crnn_cell.CB": (), "crnn_cell.W_laplace.weight": (1, 1, 5, 5)}
+    for s in "uv":
+        for k in (1, 2, 3):
+            exp[f"crnn_cell.Wh{k}_{s}.weight"] = (16, 2, 5, 5)
+            exp[f"crnn_cell.Wh{k}_{s}.bias"] = (16,)
+        exp[f"crnn_cell.Wh4_{s}.weight"] = (1, 16, 1, 1)
+        exp[f"crnn_cell.Wh4_{s}.bias"] = (1,)
+    assert got == exp
+
+
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def dev():
@@ -210,3 +230,29 @@ def test_edge_cases(dev):
     out = pa.stage1.step_fwd(h, P)
     out_s = pa.stage1.step_fwd(torch.roll(h, (5, 7), (1, 2)).contiguous(), P)
     assert torch.equal(out_s, torch.roll(out, (5, 7), (1, 2)))
+
+
+@pytest.mark.gpu
+def test_rcnn_wrapper_drives_the_stage1_cell(dev):
+    """pa.RCNN + Stage1Cell: the reference's RCNN.forward contract (list of frames, second_last_state) on the fused
+    Stage-1 rollout; same gradients as the one-tensor path."""
+    import percnn_amd as pa
+    torch.manual_seed(2)
+    cell = pa.Stage1Cell("burgers").to(dev)
+    up = pa.stage1.Upscaler().to(dev)
+    low = torch.rand(1, 2, 12, 12, device=dev)
+    steps = 9
+    m = pa.RCNN(cell, step=steps, effective_step=list(range(steps)), upscaler=up, init_state_low=low)
+    outs, sl = m()
+    assert len(outs) == steps + 1 and outs[0].shape == (1, 2, 24, 24)
+    traj = m.trajectory()
+    assert torch.equal(torch.cat(tuple(outs), 0), traj) and torch.equal(sl, traj[steps - 1:steps])
+    w = torch.randn_like(traj)
+    params = [p for p in m.parameters() if p.requires_grad]          # W_laplace is frozen
+    g1 = torch.autograd.grad((torch.cat(tuple(outs), 0) * w).sum() + (sl ** 2).sum(), params, allow_unused=True)
+    g2 = torch.autograd.grad((traj * w).sum() + (traj[steps - 1] ** 2).sum(), params, allow_unused=True)
+    for a, b in zip(g1, g2):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+
