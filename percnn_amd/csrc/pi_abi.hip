@@ -290,7 +290,11 @@ int stream3d_vec(const Problem& p, std::initializer_list<const void*> ptrs)
     if (!g_opt.stream3d || p.ndim != 3) return 0;
     // measured on MI355X: the plane-streaming kernels win from ~4M points per rank upwards (256^3: 4.1 vs
     // 2.7 TB/s forward); at 128^3 there are too few waves to cover their per-plane barrier chain.
-    if (g_opt.stream3d == 1 && (p.n0 + (p.slab ? 2 * p.halo : 0)) * p.n1 * p.W < (int64_t)3 << 20) return 0;
+    // Rows as wide as a full 16-B/lane wave (W = 256 fp32 -- the 32 x 256^2 slabs of the 8-GPU 256^3 problem) win
+    // from ~2M points already (slab rollout 69 -> 63 us per step).
+    const int64_t pts = (p.n0 + (p.slab ? 2 * p.halo : 0)) * p.n1 * p.W;
+    const bool full_width = p.W == (int64_t)pi::WAVE * pi::vec_width<T>::value;
+    if (g_opt.stream3d == 1 && pts < ((int64_t)(full_width ? 2 : 3) << 20)) return 0;
     if (p.hc != 0 && p.hc != 2 && p.hc != 4 && p.hc != 8) return 0;
     if (p.n1 % STREAM_TY) return 0;
     int vec = 0;
