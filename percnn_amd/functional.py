@@ -417,6 +417,47 @@ def pi_rollout_frames(h0: torch.Tensor, P: torch.Tensor, steps: int, frames: Seq
     return PiRolloutFramesFunction.apply(h0, P, int(steps), tuple(frames))
 
 
+class PiRolloutObserveFunction(torch.autograd.Function):
+    """Rollout + observation operator in one autograd node: returns ``traj[t_idx][:, :, ::sx, ::sy(, ::sz)]`` -- what the
+    reference's training loss looks at (``output[0:-1:20, :, ::4, ::4]``, train_2drd.py:397; ``[:-1:15, :, ::2, ::2, ::2]``,
+    train_3drd.py:403).  Going through ``torch.cat(outputs)[...]`` instead makes autograd materialise a dense, almost
+    entirely zero dL/dtraj (2 GB at 512^2 x 1000) that the sweep then streams; here the backward fills only the
+    observed frames of an uninitialised buffer and masks every other frame out of the sweep."""
+
+    @staticmethod
+    def forward(ctx, h0, P, steps, t_idx, strides):
+        _check_state(h0)
+        P = P.contiguous()
+        traj = torch.empty((steps + 1,) + tuple(h0.shape[1:]), dtype=h0.dtype, device=h0.device)
+        traj[0].copy_(h0[0])
+        rollout_fwd_(traj, P)
+        ctx.save_for_backward(traj, P)
+        ctx.t_idx = tuple(int(t) % (steps + 1) for t in t_idx)
+        ctx.sub = (slice(None),) + tuple(slice(None, None, int(s)) for s in strides)
+        idx = torch.tensor(ctx.t_idx, dtype=torch.long, device=h0.device)
+        pred = traj.index_select(0, idx)[(slice(None),) + ctx.sub].contiguous()
+        ctx.mark_non_differentiable(traj)
+        return pred, traj
+
+    @staticmethod
+    def backward(ctx, g_pred, _g_traj_unused):
+        traj, P = ctx.saved_tensors
+        g_traj = torch.empty_like(traj)                    # never initialised as a whole: unobserved frames are masked
+        mask = [False] * traj.shape[0]
+        for i, t in enumerate(ctx.t_idx):
+            if not mask[t]:
+                g_traj[t].zero_()
+                mask[t] = True
+            g_traj[t][ctx.sub] += g_pred[i]
+        g_h0, pg = rollout_bwd(traj, g_traj, P, frame_mask=mask)
+        return g_h0[None], pg.to(P.dtype), None, None, None
+
+
+def pi_rollout_observe(h0: torch.Tensor, P: torch.Tensor, steps: int, t_idx: Sequence[int], strides: Sequence[int]):
+    """-> (pred [len(t_idx), 2, ceil(S/stride)...], traj [steps+1, 2, *S] detached)"""
+    return PiRolloutObserveFunction.apply(h0, P, int(steps), tuple(t_idx), tuple(strides))
+
+
 def pi_step(h: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
     return PiStepFunction.apply(h, P)
 

@@ -421,6 +421,24 @@ class RCNN(nn.Module):
             return self.cell.rollout(self.init_state, self.step)
         return F_pi.pi_rollout(self.init_state, self.cell.param_block(), self.step)
 
+    def observe(self, t_slice=slice(None), space_stride: int = 1):
+        """``torch.cat(self()[0])[t_slice][:, :, ::s, ::s(, ::s)]`` -- the tensor the reference's data loss is computed
+        on (train_2drd.py:397, train_3drd.py:403) -- from ONE autograd node that never builds the dense dL/dtraj.
+        Needs a dense ``effective_step``.  The full (detached) trajectory of the same rollout is kept in
+        ``self.last_trajectory`` for validation-only consumers (the physics loss, train_2drd.py:405)."""
+        if self.effective_step != list(range(self.step)):
+            raise ValueError("observe() indexes the dense output list: effective_step must be list(range(step))")
+        if hasattr(self.cell, "rollout_frames"):
+            raise NotImplementedError("observe() is implemented for the base Pi-block cells")
+        if hasattr(self, "UpconvBlock"):
+            self.init_state = self.UpconvBlock(self.init_state_low)
+        t_idx = list(range(self.step + 1))[t_slice]
+        ndim = self.init_state.dim() - 2
+        pred, traj = F_pi.pi_rollout_observe(self.init_state, self.cell.param_block(), self.step, t_idx,
+                                             (space_stride,) * ndim)
+        self.last_trajectory = traj
+        return pred
+
     def forward(self):
         if hasattr(self, "UpconvBlock"):
             self.init_state = self.UpconvBlock(self.init_state_low)

@@ -745,3 +745,37 @@ def test_module_frame_list_path_equals_trajectory_path(eff, hip_device):
     torch.cuda.synchronize()
     assert time.perf_counter() - t0 < 0.5
 
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_observe_equals_cat_and_slice(ndim, hip_device):
+    """RCNN.observe(t_slice, stride) == torch.cat(outputs)[t_slice][:, :, ::s, ...] in value and in every gradient
+    (the reference's data-loss operand, train_2drd.py:397 / train_3drd.py:403), without the dense dL/dtraj."""
+    import percnn_amd as pa
+    from percnn_amd import synthetic
+    torch.manual_seed(0)
+    steps = 41
+    shape = (64, 48) if ndim == 2 else (16, 12, 24)
+    cell = (pa.gs2d_cell(8) if ndim == 2 else pa.gs3d_cell(2)).to(hip_device)
+    for p in cell.filter_list:
+        p.weight.data.mul_(20.0)
+    h0 = synthetic.gs_initial_state(shape, seed=0).to(hip_device).requires_grad_(True)
+    stride = 4 if ndim == 2 else 2
+    sub = (slice(None), slice(None)) + (slice(None, None, stride),) * ndim
+    tsl = slice(0, -1, 5)
+
+    def grads(loss):
+        cell.zero_grad(); h0.grad = None
+        loss.backward()
+        return [h0.grad.clone()] + [p.grad.clone() for p in cell.parameters() if p.grad is not None]
+
+    m = pa.RCNN(cell, step=steps, effective_step=list(range(steps)), init_state=h0)
+    outs, _ = m()
+    ref = torch.cat(tuple(outs), 0)[tsl][sub]
+    truth = torch.rand_like(ref)
+    g_ref = grads(torch.nn.functional.mse_loss(ref, truth))
+    pred = m.observe(tsl, stride)
+    assert torch.equal(pred, ref) and m.last_trajectory.shape[0] == steps + 1 and not m.last_trajectory.requires_grad
+    g_obs = grads(torch.nn.functional.mse_loss(pred, truth))
+    for a, b in zip(g_obs, g_ref):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+
