@@ -480,10 +480,12 @@ def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=5):
             dist.barrier()
         torch.cuda.synchronize()
 
+    overlap = bool(int(os.environ.get("PERCNN_SLAB_OVERLAP", "0")))
+
     def run():
-        slab.slab_rollout_fwd_(traj, P, ex, halo)
+        slab.slab_rollout_fwd_(traj, P, ex, halo, overlap=overlap)
         t1 = time.perf_counter()
-        g0, pg = slab.slab_rollout_bwd(traj, gtraj, P, ex, halo)
+        g0, pg = slab.slab_rollout_bwd(traj, gtraj, P, ex, halo, overlap=overlap)
         return t1, pg
 
     run()
@@ -505,7 +507,8 @@ def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=5):
     assert torch.isfinite(pg).all() and torch.isfinite(traj[-1][:, halo:-halo]).all()
     return {"workload": f"gs3d {'x'.join(map(str, full_shape))} sharded into {world} slabs of {planes} planes, Hc=2, "
                         f"T={T} fwd+bwd, forward halo {halo} (={halo // 2} steps per exchange), adjoint sweep "
-                        f"exchanges 2 planes per step; host-driven loop; exchanger={type(ex).__name__}",
+                        f"exchanges 2 planes per step; native C loop (one call per rollout), overlap={int(overlap)}; "
+                        f"exchanger={type(ex).__name__}",
             "steps_per_sec_fwd_bwd": reps * T / el, "ms_per_time_step_fwd_bwd": el / (reps * T) * 1e3,
             "points_per_rank": planes * hw * hw, "global_points": planes * world * hw * hw,
             "halo_bytes_per_exchange_per_direction": 2 * halo * hw * hw * 4}

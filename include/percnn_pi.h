@@ -59,6 +59,9 @@ extern "C" {
 
 #define PERCNN_PI_SWEEP_ONLY 1    /* flags of percnn_pi_slab_step_bwd_*: adjoint state + diffusion-coefficient
                                    * gradients only; branch gradients come from percnn_pi_slab_wgrad_* later */
+#define PERCNN_PI_NO_RESET 2      /* the workspace's partial rows already hold sums of earlier launches of this sweep */
+#define PERCNN_PI_NO_FINISH 4     /* leave this launch's sums in the partial rows; a later launch without this flag
+                                   * (and with NO_RESET) reduces everything into param_grad */
 
 #define PERCNN_PI_EINVAL   (-1)  /* bad ndim / hc / shape / NULL pointer          */
 #define PERCNN_PI_EWORKSPACE (-2) /* workspace smaller than *_workspace_bytes says */
@@ -158,6 +161,58 @@ int percnn_pi_slab_step_bwd_f64(const double *h, const double *g_out, const doub
                                 double *param_grad, void *workspace, size_t workspace_bytes,
                                 const double *params, int hc, int ndim, const int64_t *shape, int halo,
                                 int flags, void *stream);
+
+/* ---- native slab rollouts (multi-GPU): the whole T-step loop, halo exchanges included, in ONE call ---------------
+ * The ring is described by plain function pointers so that the library needs no link-time dependency on RCCL: the host
+ * side passes the addresses of ncclGroupStart / ncclGroupEnd / ncclSend / ncclRecv of the librccl it already uses
+ * (percnn_amd.slab does this with ctypes for the librccl PyTorch loaded) plus its communicator and neighbour ranks.
+ * ring == NULL: single rank, the periodic wrap is done with device-to-device copies.
+ * overlap != 0: the step that produces a frame about to be exchanged computes the two faces first, the exchange runs
+ * on an internal side stream (ordered by events) while the planes in between are computed.
+ * Layout: local padded trajectories [T+1][2][n0_local + 2*halo][...]; shape = local interior shape. */
+typedef struct percnn_pi_halo_ring {
+    void* comm;                 /* ncclComm_t */
+    int prev, next;             /* neighbour ranks on the ring (periodic) */
+    int dtype_f32, dtype_f64;   /* ncclFloat32 / ncclFloat64 enum values of that RCCL */
+    int (*group_start)(void);
+    int (*group_end)(void);
+    int (*send)(const void* buf, size_t count, int dtype, int peer, void* comm, void* stream);
+    int (*recv)(void* buf, size_t count, int dtype, int peer, void* comm, void* stream);
+} percnn_pi_halo_ring;
+
+int percnn_pi_slab_rollout_fwd_f32(float* traj, const float* params, int hc, int ndim, const int64_t* shape, int halo,
+                                   int T_steps, const percnn_pi_halo_ring* ring, int overlap, void* stream);
+int percnn_pi_slab_rollout_fwd_f64(double* traj, const double* params, int hc, int ndim, const int64_t* shape, int halo,
+                                   int T_steps, const percnn_pi_halo_ring* ring, int overlap, void* stream);
+/* adj: caller-provided local adjoint trajectory (same layout as traj, contents irrelevant on entry; adj[0] holds
+ * dL/d(frame 0) on return); g_traj: dL/dtraj in the same padded layout (halo planes ignored); param_grad: double[np],
+ * ACCUMULATED (local sums of this rank; the caller all-reduces them); workspace: percnn_pi_bwd_workspace_bytes(). */
+int percnn_pi_slab_rollout_bwd_f32(const float* traj, const float* g_traj, float* adj, double* param_grad,
+                                   void* workspace, size_t workspace_bytes, const float* params, int hc, int ndim,
+                                   const int64_t* shape, int halo, int T_steps, const percnn_pi_halo_ring* ring,
+                                   int overlap, void* stream);
+int percnn_pi_slab_rollout_bwd_f64(const double* traj, const double* g_traj, double* adj, double* param_grad,
+                                   void* workspace, size_t workspace_bytes, const double* params, int hc, int ndim,
+                                   const int64_t* shape, int halo, int T_steps, const percnn_pi_halo_ring* ring,
+                                   int overlap, void* stream);
+
+/* Plane-range variants of the slab steps, for communication / computation overlap: compute only the padded plane
+ * indices [lo, hi) (2 <= lo < hi <= n0_local + 2*halo - 2) of the output -- e.g. first the faces a neighbour is waiting
+ * for, then, while they travel, the planes in between.  The union of the ranges of one step must be what the
+ * un-split call computes; values are bit-identical to it.  Backward: split launches of ONE sweep share their gradient
+ * sums through the workspace (PERCNN_PI_NO_RESET / PERCNN_PI_NO_FINISH). */
+int percnn_pi_slab_step_fwd_range_f32(const float* h, float* h_next, const float* params, int hc, int ndim,
+                                      const int64_t* shape, int halo, int lo, int hi, void* stream);
+int percnn_pi_slab_step_fwd_range_f64(const double* h, double* h_next, const double* params, int hc, int ndim,
+                                      const int64_t* shape, int halo, int lo, int hi, void* stream);
+int percnn_pi_slab_step_bwd_range_f32(const float* h, const float* g_out, const float* g_inject, float* g_in,
+                                      double* param_grad, void* workspace, size_t workspace_bytes, const float* params,
+                                      int hc, int ndim, const int64_t* shape, int halo, int lo, int hi, int flags,
+                                      void* stream);
+int percnn_pi_slab_step_bwd_range_f64(const double* h, const double* g_out, const double* g_inject, double* g_in,
+                                      double* param_grad, void* workspace, size_t workspace_bytes, const double* params,
+                                      int hc, int ndim, const int64_t* shape, int halo, int lo, int hi, int flags,
+                                      void* stream);
 
 /* Time-parallel gradient reduction over the INTERIOR of local slab trajectories (same padded layout):
  * traj frames 0..T-1 and adjoint frames 1..T ([T+1][2][n0+2*halo][rest] each), accumulated into param_grad.

@@ -27,7 +27,8 @@ EXPORTS = [
     "percnn_pi_rollout_bwd_workspace_bytes", "percnn_pi_set_option",
 ] + [f"percnn_pi_{op}_{suf}" for suf in ("f32", "f64")
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
-                "residual_fwd", "residual_bwd")] + [
+                "slab_step_fwd_range", "slab_step_bwd_range", "slab_rollout_fwd", "slab_rollout_bwd", "residual_fwd",
+                "residual_bwd")] + [
     "percnn_pi_s1_param_count", "percnn_pi_s1_step_fwd_f32", "percnn_pi_s1_rollout_fwd_f32",
     "percnn_pi_s1_rollout_bwd_workspace_bytes", "percnn_pi_s1_rollout_bwd_f32", "percnn_pi_s1_set_option",
 ]
@@ -94,6 +95,14 @@ def lib() -> ctypes.CDLL:
         f.restype, f.argtypes = ci, [vp, vp, vp, ci, ci, i64p, ci, ci, vp]
         f = getattr(L, f"percnn_pi_slab_step_bwd_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, vp, vp, vp, vp, sz, vp, ci, ci, i64p, ci, ci, vp]
+        f = getattr(L, f"percnn_pi_slab_step_fwd_range_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, vp, ci, ci, i64p, ci, ci, ci, vp]
+        f = getattr(L, f"percnn_pi_slab_step_bwd_range_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, vp, vp, vp, vp, sz, vp, ci, ci, i64p, ci, ci, ci, ci, vp]
+        f = getattr(L, f"percnn_pi_slab_rollout_fwd_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, ci, ci, i64p, ci, ci, vp, ci, vp]
+        f = getattr(L, f"percnn_pi_slab_rollout_bwd_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, vp, vp, vp, sz, vp, ci, ci, i64p, ci, ci, vp, ci, vp]
         f = getattr(L, f"percnn_pi_slab_wgrad_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, vp, vp, sz, vp, ci, ci, i64p, ci, ci, vp]
         f = getattr(L, f"percnn_pi_residual_fwd_{suf}")
@@ -115,6 +124,14 @@ def lib() -> ctypes.CDLL:
     L.percnn_pi_s1_rollout_bwd_f32.argtypes = [vp, vp, ctypes.c_char_p, vp, vp, vp, sz, vp, i64p, ci, vp]
     _lib = L
     return L
+
+
+class HaloRing(ctypes.Structure):
+    """percnn_pi_halo_ring of include/percnn_pi.h: communicator, neighbours and the four RCCL entry points as addresses"""
+    _fields_ = [("comm", ctypes.c_void_p), ("prev", ctypes.c_int), ("next", ctypes.c_int),
+                ("dtype_f32", ctypes.c_int), ("dtype_f64", ctypes.c_int),
+                ("group_start", ctypes.c_void_p), ("group_end", ctypes.c_void_p),
+                ("send", ctypes.c_void_p), ("recv", ctypes.c_void_p)]
 
 
 def check(rc: int, what: str) -> None:

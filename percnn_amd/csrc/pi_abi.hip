@@ -80,6 +80,7 @@ struct Problem {
     bool slab;
     int halo = 2;       // slab layout: planes present on each side of axis 0 (even, >= 2)
     int skip = 0;       // slab layout: outermost planes per side that this call neither reads nor writes
+    int lo = -1, hi = -1;   // slab layout, plane-range calls: padded plane indices [lo, hi) this call computes
 };
 
 int make_problem(int hc, int ndim, const int64_t* shape, bool slab, Problem& p)
@@ -127,8 +128,13 @@ Geom make_geom(const Problem& p)
     if (p.slab) {
         // local array: n0 + 2*halo planes; this call computes planes [skip+2, n0+2*halo-skip-2)
         g.ss = (long)(p.n0 + 2 * p.halo) * g.s0;
-        g.off = (long)(p.skip + 2) * g.s0;
-        g.n0 = (int)(p.n0 + 2 * p.halo - 2 * p.skip - 4);
+        if (p.lo >= 0) {                                   // explicit plane range (communication overlap: faces first)
+            g.off = (long)p.lo * g.s0;
+            g.n0 = p.hi - p.lo;
+        } else {
+            g.off = (long)(p.skip + 2) * g.s0;
+            g.n0 = (int)(p.n0 + 2 * p.halo - 2 * p.skip - 4);
+        }
         g.rows = g.n0 * (int)p.n1;
         g.wrap0 = 0;
     } else {
@@ -292,6 +298,9 @@ int stream3d_vec(const Problem& p, std::initializer_list<const void*> ptrs)
     // 2.7 TB/s forward); at 128^3 there are too few waves to cover their per-plane barrier chain.
     // Rows as wide as a full 16-B/lane wave (W = 256 fp32 -- the 32 x 256^2 slabs of the 8-GPU 256^3 problem) win
     // from ~2M points already (slab rollout 69 -> 63 us per step).
+    // (plane-range calls are judged by the whole local slab -- the range in between the faces is most of it -- except
+    // the few-plane faces themselves, which are not worth a z-march)
+    if (p.lo >= 0 && p.hi - p.lo < 8 && g_opt.stream3d == 1) return 0;
     const int64_t pts = (p.n0 + (p.slab ? 2 * p.halo : 0)) * p.n1 * p.W;
     const bool full_width = p.W == (int64_t)pi::WAVE * pi::vec_width<T>::value;
     if (g_opt.stream3d == 1 && pts < ((int64_t)(full_width ? 2 : 3) << 20)) return 0;
@@ -529,6 +538,24 @@ int set_slab(Problem& p, int halo, int skip)
     return 0;
 }
 
+int set_slab_range(Problem& p, int halo, int lo, int hi)
+{
+    if (halo < 2 || (halo & 1) || lo < 2 || hi <= lo || hi > p.n0 + 2 * halo - 2) return PERCNN_PI_EINVAL;
+    p.halo = halo; p.skip = 0; p.lo = lo; p.hi = hi;
+    return 0;
+}
+
+template <typename T>
+int slab_step_fwd_range_impl(const T* h, T* out, const T* P, int hc, int ndim, const int64_t* shape, int halo, int lo,
+                             int hi, void* stream)
+{
+    Problem p;
+    if (int rc = make_problem(hc, ndim, shape, true, p)) return rc;
+    if (int rc = set_slab_range(p, halo, lo, hi)) return rc;
+    if (!h || !out || !P || h == out) return PERCNN_PI_EINVAL;
+    return (int)step_fwd<T>(h, out, P, p, static_cast<hipStream_t>(stream));
+}
+
 template <typename T>
 int step_fwd_impl(const T* h, T* out, const T* P, int hc, int ndim, const int64_t* shape, void* stream, bool slab,
                   int halo = 2, int skip = 0)
@@ -543,22 +570,29 @@ int step_fwd_impl(const T* h, T* out, const T* P, int hc, int ndim, const int64_
 template <typename T>
 int step_bwd_impl(const T* h, const T* g_out, const T* g_inj, T* g_in, double* param_grad, void* ws, size_t ws_bytes,
                   const T* P, int hc, int ndim, const int64_t* shape, void* stream, bool slab, int halo = 2,
-                  int flags = 0)
+                  int flags = 0, int lo = -1, int hi = -1)
 {
     Problem p;
     if (int rc = make_problem(hc, ndim, shape, slab, p)) return rc;
-    if (slab) if (int rc = set_slab(p, halo, halo - 2)) return rc;     // adjoint: interior planes only
+    if (slab) {
+        if (lo >= 0) { if (int rc = set_slab_range(p, halo, lo, hi)) return rc; }
+        else if (int rc = set_slab(p, halo, halo - 2)) return rc;     // adjoint: interior planes only
+    }
     if (!h || !g_out || !g_in || !param_grad || !P || g_in == g_out) return PERCNN_PI_EINVAL;
     Workspace w;
     if (!carve(ws, ws_bytes, p, sizeof(T), w)) return PERCNN_PI_EWORKSPACE;
     auto st = static_cast<hipStream_t>(stream);
-    if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
+    // a sweep split into several launches (plane ranges, time steps) keeps its sums in the partial rows:
+    // NO_RESET = rows already hold earlier launches, NO_FINISH = a later launch reduces them into param_grad
+    if (!(flags & PERCNN_PI_NO_RESET))
+        if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
     unsigned grid = 0;
     const bool sweep_only = flags & PERCNN_PI_SWEEP_ONLY;
     hipError_t e = sweep_only ? step_bwd<T, false>(h, g_out, g_inj, g_in, w.partials, P, p, st, &grid)
                               : step_bwd<T, true>(h, g_out, g_inj, g_in, w.partials, P, p, st, &grid);
     if (e) return (int)e;
-    return (int)finish_grads(w, grid, hc, param_grad, st);
+    if (flags & PERCNN_PI_NO_FINISH) return 0;
+    return (int)finish_grads(w, (flags & PERCNN_PI_NO_RESET) ? (unsigned)MAX_BWD_BLOCKS : grid, hc, param_grad, st);
 }
 
 // branch-weight / coefficient-moment gradients of T steps over the interior of LOCAL slab trajectories
@@ -583,6 +617,152 @@ int slab_wgrad_impl(const T* traj, const T* adj, double* param_grad, void* ws, s
                           : launch_wgrad<T, 1>(traj, adj, w.partials, P, p, 0, T_steps, &rows, st);
     if (e) return (int)e;
     return (int)finish_grads(w, rows, hc, param_grad, st);
+}
+
+// ---- native slab rollouts: T-step loops with ring halo exchange (RCCL through function pointers) ------------------
+template <typename T> int ring_dtype(const percnn_pi_halo_ring* r);
+template <> int ring_dtype<float>(const percnn_pi_halo_ring* r) { return r->dtype_f32; }
+template <> int ring_dtype<double>(const percnn_pi_halo_ring* r) { return r->dtype_f64; }
+
+// faces of `slab` ([2][n0 + 2*halo][plane]) -> the neighbours' halo planes, `width` planes per side, on stream st
+template <typename T>
+int ring_exchange(T* slab, const Problem& p, int width, const percnn_pi_halo_ring* r, hipStream_t st)
+{
+    const size_t plane = (size_t)(p.n1 * p.W), cnt = (size_t)width * plane;
+    const size_t ss = (size_t)(p.n0 + 2 * p.halo) * plane;
+    const int64_t n = p.n0, halo = p.halo;
+    auto at = [&](int s, int64_t pl) { return slab + (size_t)s * ss + (size_t)pl * plane; };
+    if (!r) {                                              // single rank: periodic wrap by device-to-device copies
+        for (int s = 0; s < 2; ++s) {
+            if (hipError_t e = hipMemcpyAsync(at(s, halo - width), at(s, halo + n - width), cnt * sizeof(T),
+                                              hipMemcpyDeviceToDevice, st)) return (int)e;
+            if (hipError_t e = hipMemcpyAsync(at(s, halo + n), at(s, halo), cnt * sizeof(T), hipMemcpyDeviceToDevice, st))
+                return (int)e;
+        }
+        return 0;
+    }
+    const int dt = ring_dtype<T>(r);
+    if (int rc = r->group_start()) return rc;
+    // per peer, sends and receives pair up in issue order (matters when prev == next: 2 ranks)
+    for (int s = 0; s < 2; ++s) {
+        if (int rc = r->send(at(s, halo + n - width), cnt, dt, r->next, r->comm, st)) return rc;
+        if (int rc = r->send(at(s, halo), cnt, dt, r->prev, r->comm, st)) return rc;
+    }
+    for (int s = 0; s < 2; ++s) {
+        if (int rc = r->recv(at(s, halo - width), cnt, dt, r->prev, r->comm, st)) return rc;
+        if (int rc = r->recv(at(s, halo + n), cnt, dt, r->next, r->comm, st)) return rc;
+    }
+    return r->group_end();
+}
+
+// exchange on the side stream, ordered after everything enqueued on `st` so far; *done is recorded behind it
+template <typename T>
+int ring_exchange_async(T* slab, const Problem& p, int width, const percnn_pi_halo_ring* r, hipStream_t st, SideStream* ss,
+                        hipEvent_t* done)
+{
+    hipEvent_t ready = ss->ev[ss->next++ % 8];
+    if (hipError_t e = hipEventRecord(ready, st)) return (int)e;
+    if (hipError_t e = hipStreamWaitEvent(ss->stream, ready, 0)) return (int)e;
+    if (int rc = ring_exchange<T>(slab, p, width, r, ss->stream)) return rc;
+    *done = ss->ev[ss->next++ % 8];
+    return (int)hipEventRecord(*done, ss->stream);
+}
+
+template <typename T>
+int slab_rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* shape, int halo, int T_steps,
+                          const percnn_pi_halo_ring* ring, int overlap, void* stream)
+{
+    Problem p;
+    if (int rc = make_problem(hc, ndim, shape, true, p)) return rc;
+    if (int rc = set_slab(p, halo, 0)) return rc;
+    if (!traj || !P || T_steps < 0) return PERCNN_PI_EINVAL;
+    auto st = static_cast<hipStream_t>(stream);
+    const int k = halo / 2;
+    const int64_t n = p.n0;
+    const size_t frame = (size_t)2 * (p.n0 + 2 * halo) * p.n1 * p.W;
+    SideStream* side = overlap && n >= 2 * halo ? side_stream() : nullptr;
+    hipEvent_t pending = nullptr;
+    auto range = [&](T* in, T* out, int lo, int hi) -> int {
+        Problem q = p;
+        if (int rc = set_slab_range(q, halo, lo, hi)) return rc;
+        return (int)step_fwd<T>(in, out, P, q, st);
+    };
+    for (int t = 0; t < T_steps; ++t) {
+        T* cur = traj + (size_t)t * frame;
+        T* nxt = cur + frame;
+        const int m = t % k;
+        if (m == 0) {
+            if (pending) {
+                if (hipError_t e = hipStreamWaitEvent(st, pending, 0)) return (int)e;
+                pending = nullptr;
+            } else if (int rc = ring_exchange<T>(cur, p, halo, ring, st)) return rc;
+        }
+        if (side && m == k - 1 && t + 1 < T_steps) {        // frame t+1 is exchanged next: faces first
+            if (int rc = range(cur, nxt, halo, 2 * halo)) return rc;
+            if (int rc = range(cur, nxt, (int)n, (int)n + halo)) return rc;
+            if (int rc = ring_exchange_async<T>(nxt, p, halo, ring, st, side, &pending)) return rc;
+            if (n > 2 * halo)
+                if (int rc = range(cur, nxt, 2 * halo, (int)n)) return rc;
+        } else {
+            Problem q = p;
+            if (int rc = set_slab(q, halo, 2 * m)) return rc;
+            if (hipError_t e = step_fwd<T>(cur, nxt, P, q, st)) return (int)e;
+        }
+    }
+    if (pending)
+        if (hipError_t e = hipStreamWaitEvent(st, pending, 0)) return (int)e;
+    return 0;
+}
+
+template <typename T>
+int slab_rollout_bwd_impl(const T* traj, const T* g_traj, T* adj, double* param_grad, void* ws, size_t ws_bytes,
+                          const T* P, int hc, int ndim, const int64_t* shape, int halo, int T_steps,
+                          const percnn_pi_halo_ring* ring, int overlap, void* stream)
+{
+    Problem p;
+    if (int rc = make_problem(hc, ndim, shape, true, p)) return rc;
+    if (int rc = set_slab(p, halo, halo - 2)) return rc;
+    if (!traj || !g_traj || !adj || !param_grad || !P || T_steps < 0) return PERCNN_PI_EINVAL;
+    Workspace w;
+    if (!carve(ws, ws_bytes, p, sizeof(T), w)) return PERCNN_PI_EWORKSPACE;
+    auto st = static_cast<hipStream_t>(stream);
+    const int64_t n = p.n0;
+    const size_t plane = (size_t)(p.n1 * p.W), ss = (size_t)(n + 2 * halo) * plane, frame = 2 * ss;
+    // adj[T] interior = dL/dtraj[T] interior
+    for (int s = 0; s < 2; ++s) {
+        const size_t o = (size_t)T_steps * frame + (size_t)s * ss + (size_t)halo * plane;
+        if (hipError_t e = hipMemcpyAsync(adj + o, g_traj + o, (size_t)n * plane * sizeof(T), hipMemcpyDeviceToDevice, st))
+            return (int)e;
+    }
+    if (T_steps == 0) return 0;
+    if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
+    SideStream* side = overlap && n >= 4 ? side_stream() : nullptr;
+    hipEvent_t pending = nullptr;
+    auto sweep = [&](int t, int lo, int hi) -> int {        // adjoint planes [lo, hi) of frame t-1 from frame t
+        Problem q = p;
+        if (int rc = set_slab_range(q, halo, lo, hi)) return rc;
+        unsigned grid = 0;
+        return (int)step_bwd<T, false>(traj + (size_t)(t - 1) * frame, adj + (size_t)t * frame,
+                                       g_traj + (size_t)(t - 1) * frame, adj + (size_t)(t - 1) * frame, w.partials, P, q, st,
+                                       &grid);
+    };
+    for (int t = T_steps; t >= 1; --t) {
+        if (pending) {
+            if (hipError_t e = hipStreamWaitEvent(st, pending, 0)) return (int)e;
+            pending = nullptr;
+        } else if (int rc = ring_exchange<T>(adj + (size_t)t * frame, p, 2, ring, st)) return rc;
+        if (side && t > 1) {
+            if (int rc = sweep(t, halo, halo + 2)) return rc;
+            if (int rc = sweep(t, halo + (int)n - 2, halo + (int)n)) return rc;
+            if (int rc = ring_exchange_async<T>(adj + (size_t)(t - 1) * frame, p, 2, ring, st, side, &pending)) return rc;
+            if (n > 4)
+                if (int rc = sweep(t, halo + 2, halo + (int)n - 2)) return rc;
+        } else if (int rc = sweep(t, halo, halo + (int)n)) return rc;
+    }
+    // diffusion-coefficient sums of the whole sweep (kept in the partial rows across all launches) ...
+    if (hipError_t e = finish_grads(w, MAX_BWD_BLOCKS, hc, param_grad, st)) return (int)e;
+    // ... then the branch gradients of all steps in one time-parallel reduction over the local interior
+    return slab_wgrad_impl<T>(traj, adj, param_grad, ws, ws_bytes, P, hc, ndim, shape, halo, T_steps, stream);
 }
 
 template <typename T>
@@ -859,6 +1039,24 @@ int percnn_pi_set_option(const char* key, long value)
                                       const int64_t* shape, int halo, int flags, void* stream)                      \
     { return step_bwd_impl<T>(h, g_out, g_inject, g_in, param_grad, workspace, workspace_bytes, params, hc, ndim,  \
                               shape, stream, true, halo, flags); }                                                  \
+    int percnn_pi_slab_step_fwd_range_##SUF(const T* h, T* out, const T* params, int hc, int ndim,                 \
+                                            const int64_t* shape, int halo, int lo, int hi, void* stream)          \
+    { return slab_step_fwd_range_impl<T>(h, out, params, hc, ndim, shape, halo, lo, hi, stream); }                  \
+    int percnn_pi_slab_step_bwd_range_##SUF(const T* h, const T* g_out, const T* g_inject, T* g_in,                \
+                                            double* param_grad, void* workspace, size_t workspace_bytes,           \
+                                            const T* params, int hc, int ndim, const int64_t* shape, int halo,     \
+                                            int lo, int hi, int flags, void* stream)                                \
+    { return step_bwd_impl<T>(h, g_out, g_inject, g_in, param_grad, workspace, workspace_bytes, params, hc, ndim,  \
+                              shape, stream, true, halo, flags, lo, hi); }                                          \
+    int percnn_pi_slab_rollout_fwd_##SUF(T* traj, const T* params, int hc, int ndim, const int64_t* shape, int halo, \
+                                         int T_steps, const percnn_pi_halo_ring* ring, int overlap, void* stream)   \
+    { return slab_rollout_fwd_impl<T>(traj, params, hc, ndim, shape, halo, T_steps, ring, overlap, stream); }       \
+    int percnn_pi_slab_rollout_bwd_##SUF(const T* traj, const T* g_traj, T* adj, double* param_grad, void* workspace, \
+                                         size_t workspace_bytes, const T* params, int hc, int ndim,                \
+                                         const int64_t* shape, int halo, int T_steps,                               \
+                                         const percnn_pi_halo_ring* ring, int overlap, void* stream)                \
+    { return slab_rollout_bwd_impl<T>(traj, g_traj, adj, param_grad, workspace, workspace_bytes, params, hc, ndim,  \
+                                      shape, halo, T_steps, ring, overlap, stream); }                               \
     int percnn_pi_slab_wgrad_##SUF(const T* traj, const T* adj, double* param_grad, void* workspace,               \
                                    size_t workspace_bytes, const T* params, int hc, int ndim, const int64_t* shape, \
                                    int halo, int T_steps, void* stream)                                             \

@@ -236,8 +236,9 @@ def rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor,
 
 
 def step_fwd(h: torch.Tensor, P: torch.Tensor, out: Optional[torch.Tensor] = None, slab: bool = False,
-             halo: int = 2, skip: int = 0):
-    """h: [2,*S] -> next state.  slab=True: h is a local slab [2, n0+2*halo, ...] (see include/percnn_pi.h)."""
+             halo: int = 2, skip: int = 0, planes: Optional[Sequence[int]] = None):
+    """h: [2,*S] -> next state.  slab=True: h is a local slab [2, n0+2*halo, ...] (see include/percnn_pi.h);
+    planes=(lo, hi): only those padded planes of the output are computed (communication overlap)."""
     _require(h, "h"); _require(P, "params", h.dtype)
     if out is None:
         out = torch.empty_like(h)
@@ -245,7 +246,12 @@ def step_fwd(h: torch.Tensor, P: torch.Tensor, out: Optional[torch.Tensor] = Non
     shape = list(h.shape[1:])
     L = _lib.lib()
     with torch.cuda.device(h.device):
-        if slab:
+        if slab and planes is not None:
+            shape[0] -= 2 * halo
+            f = getattr(L, "percnn_pi_slab_step_fwd_range_" + _SUF[h.dtype])
+            rc = f(h.data_ptr(), out.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape), halo,
+                   int(planes[0]), int(planes[1]), _stream())
+        elif slab:
             shape[0] -= 2 * halo
             f = getattr(L, "percnn_pi_slab_step_fwd_" + _SUF[h.dtype])
             rc = f(h.data_ptr(), out.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape), halo,
@@ -259,9 +265,12 @@ def step_fwd(h: torch.Tensor, P: torch.Tensor, out: Optional[torch.Tensor] = Non
 
 def step_bwd(h: torch.Tensor, g_out: torch.Tensor, P: torch.Tensor, g_inject: Optional[torch.Tensor] = None,
              g_in: Optional[torch.Tensor] = None, param_grad: Optional[torch.Tensor] = None, slab: bool = False,
-             halo: int = 2, ws: Optional[torch.Tensor] = None, sweep_only: bool = False):
+             halo: int = 2, ws: Optional[torch.Tensor] = None, sweep_only: bool = False,
+             planes: Optional[Sequence[int]] = None, no_reset: bool = False, no_finish: bool = False):
     """-> (dL/dh, param_grad double[np] (accumulated if given)).  sweep_only (slab): adjoint state and
-    diffusion-coefficient gradients only; the branch gradients come from ``slab_wgrad`` afterwards."""
+    diffusion-coefficient gradients only; the branch gradients come from ``slab_wgrad`` afterwards.
+    planes=(lo, hi) (slab): only those padded planes of dL/dh are computed; no_reset / no_finish: the launch shares
+    its gradient sums with earlier / later launches of the same sweep through the workspace (include/percnn_pi.h)."""
     _require(h, "h"); _require(g_out, "g_out", h.dtype); _require(P, "params", h.dtype)
     if g_inject is not None:
         _require(g_inject, "g_inject", h.dtype)
@@ -278,7 +287,13 @@ def step_bwd(h: torch.Tensor, g_out: torch.Tensor, P: torch.Tensor, g_inject: Op
     L = _lib.lib()
     inj = g_inject.data_ptr() if g_inject is not None else None
     with torch.cuda.device(h.device):
-        if slab:
+        flags = (1 if sweep_only else 0) | (2 if no_reset else 0) | (4 if no_finish else 0)
+        if slab and (planes is not None or flags > 1):
+            lo, hi = (int(planes[0]), int(planes[1])) if planes is not None else (halo, halo + shape[0])
+            f = getattr(L, "percnn_pi_slab_step_bwd_range_" + _SUF[h.dtype])
+            rc = f(h.data_ptr(), g_out.data_ptr(), inj, g_in.data_ptr(), param_grad.data_ptr(), ws.data_ptr(),
+                   ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), halo, lo, hi, flags, _stream())
+        elif slab:
             f = getattr(L, "percnn_pi_slab_step_bwd_" + _SUF[h.dtype])
             rc = f(h.data_ptr(), g_out.data_ptr(), inj, g_in.data_ptr(), param_grad.data_ptr(), ws.data_ptr(),
                    ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), halo, 1 if sweep_only else 0,
@@ -289,6 +304,36 @@ def step_bwd(h: torch.Tensor, g_out: torch.Tensor, P: torch.Tensor, g_inject: Op
                    ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), _stream())
     _lib.check(rc, "step_bwd")
     return g_in, param_grad
+
+
+def slab_rollout_fwd_native_(traj: torch.Tensor, P: torch.Tensor, halo: int, ring, overlap: bool) -> torch.Tensor:
+    """The whole T-step slab loop incl. halo exchanges in one C call (include/percnn_pi.h, native slab rollouts).
+    ring: ctypes pointer to a ``_lib.HaloRing`` or None (single rank: periodic wrap by device copies)."""
+    _require(traj, "traj"); _require(P, "params", traj.dtype)
+    shape = list(traj.shape[2:])
+    shape[0] -= 2 * halo
+    f = getattr(_lib.lib(), "percnn_pi_slab_rollout_fwd_" + _SUF[traj.dtype])
+    with torch.cuda.device(traj.device):
+        _lib.check(f(traj.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape), halo,
+                     traj.shape[0] - 1, ring, 1 if overlap else 0, _stream()), "slab_rollout_fwd")
+    return traj
+
+
+def slab_rollout_bwd_native(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor, halo: int, ring, overlap: bool):
+    """-> (adjoint trajectory [T+1, 2, n0+2*halo, ...] (frame 0 = dL/dh0, padded), LOCAL dL/dparams double[np])"""
+    _require(traj, "traj"); _require(g_traj, "g_traj", traj.dtype); _require(P, "params", traj.dtype)
+    shape = list(traj.shape[2:])
+    shape[0] -= 2 * halo
+    hc = _hc_of(P)
+    adj = torch.empty_like(traj)
+    pg = torch.zeros(P.numel(), dtype=torch.float64, device=traj.device)
+    ws = workspace(hc, shape, traj.dtype, traj.device)
+    f = getattr(_lib.lib(), "percnn_pi_slab_rollout_bwd_" + _SUF[traj.dtype])
+    with torch.cuda.device(traj.device):
+        _lib.check(f(traj.data_ptr(), g_traj.data_ptr(), adj.data_ptr(), pg.data_ptr(), ws.data_ptr(), ws.numel(),
+                     P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), halo, traj.shape[0] - 1, ring,
+                     1 if overlap else 0, _stream()), "slab_rollout_bwd")
+    return adj, pg
 
 
 def slab_wgrad(traj: torch.Tensor, adj: torch.Tensor, P: torch.Tensor, halo: int, param_grad: torch.Tensor,

@@ -43,6 +43,20 @@ def scatter_slab(full: torch.Tensor, rank: int, world: int, halo: int) -> torch.
     return local
 
 
+class _Done:
+    """handle of an exchange that has already completed (or is ordered on the caller's stream)"""
+    def wait(self):
+        pass
+
+
+class _StreamDone:
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 class HaloExchanger:
     """Ring exchange of face planes along axis 0 (dim 1 of a [2, planes, ...] slab)."""
 
@@ -93,6 +107,17 @@ class HaloExchanger:
             req.wait()
         lo_halo.copy_(recv_lo)
         hi_halo.copy_(recv_hi)
+
+    def native_ring(self):
+        """-> (usable, ring): whether the native C rollouts (one call per T-step loop, exchanges included) can drive
+        this exchanger, and the ``percnn_pi_halo_ring*`` to pass (None = single rank, local periodic wrap)."""
+        return (self.world == 1 and not self.force_p2p), None
+
+    def exchange_async(self, slab: torch.Tensor, halo: int, width: Optional[int] = None):
+        """Portable exchanger: the exchange completes before returning (the overlapped orchestration stays valid,
+        it just does not overlap)."""
+        self.exchange(slab, halo, width)
+        return _Done()
 
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
         if self.world > 1:
@@ -173,6 +198,36 @@ class RcclHaloExchanger(HaloExchanger):
             self._check(N.ncclRecv(ptr(s, halo + n), cnt, dt, self.next, self._comm, stream), "ncclRecv")
         self._check(N.ncclGroupEnd(), "ncclGroupEnd")
 
+    def native_ring(self):
+        if self.world == 1 and not self.force_p2p:
+            return True, None
+        if getattr(self, "_ring", None) is None:
+            ct, N = self._ct, self._nccl
+            addr = lambda fn: ct.cast(fn, ct.c_void_p).value
+            from . import _lib
+            self._ring = _lib.HaloRing(self._comm.value, self.prev, self.next, self._DT[torch.float32],
+                                       self._DT[torch.float64], addr(N.ncclGroupStart), addr(N.ncclGroupEnd),
+                                       addr(N.ncclSend), addr(N.ncclRecv))
+        return True, self._ct.byref(self._ring)
+
+    def exchange_async(self, slab: torch.Tensor, halo: int, width: Optional[int] = None):
+        """The same exchange on a side stream, ordered after everything enqueued so far on the current stream; the
+        returned handle's ``wait()`` makes the current stream wait for it.  Lets the caller compute the planes between
+        the faces while the faces travel over xGMI."""
+        if not slab.is_cuda or (self.world == 1 and not self.force_p2p):
+            super().exchange(slab, halo, width)
+            return _Done()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=slab.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(slab.device))
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            self.exchange(slab, halo, width)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        return _StreamDone(done)
+
     def close(self):
         if getattr(self, "_comm", None):
             self._nccl.ncclCommDestroy(self._comm)
@@ -190,57 +245,123 @@ def make_exchanger(group=None, prefer_rccl: bool = True, force_p2p: bool = False
 
 
 def slab_rollout_fwd_(traj: torch.Tensor, P: torch.Tensor, ex: HaloExchanger, halo: int,
-                      step_fwd: Callable = F_pi.step_fwd) -> torch.Tensor:
+                      step_fwd: Callable = F_pi.step_fwd, overlap: bool = False) -> torch.Tensor:
     """traj: local padded [T+1, 2, n0_local+2*halo, ...]; frame 0 interior filled on entry.
-    halo/2 steps are taken per exchange."""
+    halo/2 steps are taken per exchange.
+
+    On HIP tensors with an exchanger that exposes its ring (``native_ring``) the whole loop, exchanges included, is ONE
+    C call (``percnn_pi_slab_rollout_fwd_*``); the Python loop below is the portable path (gloo / CPU stand-ins).
+
+    overlap (default off -- measured on MI355X with RCCL-to-self, 32 x 256^2 slab: un-split 84 us per fwd+bwd step,
+    split + side stream 119 us: the two cross-stream hops and two extra launches per step cost more than the ~26 us of
+    exchange they could hide at this slab size; worth it for larger slabs / slower links):
+    the step that produces a frame about to be exchanged computes the two faces the neighbours wait for
+    FIRST (planes [halo, 2*halo) and [n, n+halo)), hands them to ``ex.exchange_async`` (RCCL on a side stream) and
+    computes the planes in between while they travel; the next step waits for the halos.  Values are identical to
+    the un-split schedule (``tests/test_slab_dist_cpu.py`` runs both on gloo, ``tests/test_hip_parity.py`` on RCCL)."""
     if halo < 2 or halo % 2:
         raise ValueError("halo must be even and >= 2")
+    if step_fwd is F_pi.step_fwd and traj.is_cuda:
+        usable, ring = ex.native_ring()
+        if usable:                                    # the whole loop in one C call (no per-step host work)
+            return F_pi.slab_rollout_fwd_native_(traj, P, halo, ring, overlap and ring is not None)
     T = traj.shape[0] - 1
     k = halo // 2
+    n = traj.shape[2] - 2 * halo
+    overlap = overlap and n >= 2 * halo
+    pending = None
     for t in range(T):
         m = t % k
         if m == 0:
-            ex.exchange(traj[t], halo, halo)
-        step_fwd(traj[t], P, out=traj[t + 1], slab=True, halo=halo, skip=2 * m)
+            if pending is not None:
+                pending.wait()
+                pending = None
+            else:
+                ex.exchange(traj[t], halo, halo)
+        if overlap and m == k - 1 and t + 1 < T:           # frame t+1 is exchanged next
+            step_fwd(traj[t], P, out=traj[t + 1], slab=True, halo=halo, planes=(halo, 2 * halo))
+            step_fwd(traj[t], P, out=traj[t + 1], slab=True, halo=halo, planes=(n, n + halo))
+            pending = ex.exchange_async(traj[t + 1], halo, halo)
+            if n > 2 * halo:
+                step_fwd(traj[t], P, out=traj[t + 1], slab=True, halo=halo, planes=(2 * halo, n))
+        else:
+            step_fwd(traj[t], P, out=traj[t + 1], slab=True, halo=halo, skip=2 * m)
     return traj
 
 
 def slab_rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor, ex: HaloExchanger, halo: int,
-                     step_bwd: Callable = F_pi.step_bwd, wgrad: Optional[Callable] = F_pi.slab_wgrad):
+                     step_bwd: Callable = F_pi.step_bwd, wgrad: Optional[Callable] = F_pi.slab_wgrad,
+                     overlap: bool = False):
     """Reverse sweep over local slabs.  g_traj has the padded layout of traj (halo planes ignored).
     Returns (dL/dh0 local padded, dL/dparams double[np] summed over ALL ranks).
 
     With ``wgrad`` (default) the per-step kernel only advances the adjoint state (+ the two
     diffusion-coefficient sums) into a local adjoint trajectory, and ONE time-parallel reduction over
     the local interior yields the branch gradients at the end; ``wgrad=None`` reduces everything in
-    the per-step kernel instead (what the injected CPU stand-ins of the tests do)."""
+    the per-step kernel instead (what the injected CPU stand-ins of the tests do).
+
+    overlap: every step first computes the two 2-plane faces of the new adjoint state, starts their exchange
+    (``ex.exchange_async``) and computes the planes in between while they travel."""
+    if step_bwd is F_pi.step_bwd and wgrad is F_pi.slab_wgrad and traj.is_cuda:
+        usable, ring = ex.native_ring()
+        if usable:
+            adj, pg = F_pi.slab_rollout_bwd_native(traj, g_traj, P, halo, ring, overlap and ring is not None)
+            ex.all_reduce_sum_(pg)
+            return adj[0], pg
     T = traj.shape[0] - 1
     n = traj.shape[2] - 2 * halo
     pg = torch.zeros(P.numel(), dtype=torch.float64, device=traj.device)
     ws = None
-    if step_bwd is F_pi.step_bwd:                     # one scratch buffer for the whole sweep
+    native = step_bwd is F_pi.step_bwd
+    if native:                                        # one scratch buffer for the whole sweep
         shape = list(traj.shape[2:])
         shape[0] -= 2 * halo
         ws = F_pi.workspace(F_pi._hc_of(P), shape, traj.dtype, traj.device)
-    if wgrad is None:
+    overlap = overlap and n >= 4
+    sweep_only = wgrad is not None
+    if sweep_only:
+        adj = torch.zeros_like(traj)                  # local adjoint trajectory (halo planes: exchange targets)
+        adj[T][:, halo:halo + n] = g_traj[T][:, halo:halo + n]
+        src, dst = (lambda t: adj[t]), (lambda t: adj[t - 1])
+    else:
         A = torch.zeros_like(traj[0])
         A[:, halo:halo + n] = g_traj[T][:, halo:halo + n]
         B = torch.zeros_like(A)
-        for t in range(T, 0, -1):
-            ex.exchange(A, halo, 2)
-            kw = {"ws": ws} if ws is not None else {}
-            step_bwd(traj[t - 1], A, P, g_inject=g_traj[t - 1], g_in=B, param_grad=pg, slab=True, halo=halo, **kw)
-            A, B = B, A
-        g0 = A
-    else:
-        adj = torch.zeros_like(traj)                  # local adjoint trajectory (halo planes: exchange targets)
-        adj[T][:, halo:halo + n] = g_traj[T][:, halo:halo + n]
-        for t in range(T, 0, -1):
-            ex.exchange(adj[t], halo, 2)
-            step_bwd(traj[t - 1], adj[t], P, g_inject=g_traj[t - 1], g_in=adj[t - 1], param_grad=pg, slab=True,
-                     halo=halo, ws=ws, sweep_only=True)
+        bufs = [A, B]
+        src, dst = (lambda t: bufs[(T - t) % 2]), (lambda t: bufs[(T - t + 1) % 2])
+
+    launches = [0]
+
+    def step(t, planes, last):
+        # the native sweep keeps its sums in the workspace across ALL launches: reset on the first, reduce on the last
+        kw = {}
+        if native:
+            kw = dict(ws=ws, sweep_only=sweep_only, no_reset=launches[0] > 0, no_finish=not last)
+        if planes is not None:
+            kw["planes"] = planes
+        step_bwd(traj[t - 1], src(t), P, g_inject=g_traj[t - 1], g_in=dst(t), param_grad=pg, slab=True, halo=halo, **kw)
+        launches[0] += 1
+
+    pending = None
+    for t in range(T, 0, -1):
+        if pending is not None:
+            pending.wait()
+            pending = None
+        else:
+            ex.exchange(src(t), halo, 2)
+        if overlap and t > 1:
+            step(t, (halo, halo + 2), False)
+            step(t, (halo + n - 2, halo + n), False)
+            pending = ex.exchange_async(dst(t), halo, 2)
+            if n > 4:
+                step(t, (halo + 2, halo + n - 2), False)
+        else:
+            step(t, None, t == 1)
+    if sweep_only:
         wgrad(traj, adj, P, halo, pg, ws=ws)
         g0 = adj[0]
+    else:
+        g0 = dst(1)
     ex.all_reduce_sum_(pg)
     return g0, pg
 

@@ -40,18 +40,20 @@ def _oracle_slab_steps(hc):
     """Test-only stand-ins for percnn_amd.functional.step_fwd / step_bwd (slab=True) on CPU tensors."""
     from oracle import pi_oracle as O
 
-    def step_fwd(h, P, out=None, slab=True, halo=2, skip=0):
+    def step_fwd(h, P, out=None, slab=True, halo=2, skip=0, planes=None):
         assert slab
         N = h.shape[1]
+        lo, hi = planes if planes is not None else (skip + 2, N - skip - 2)
         hn, on = h.numpy(), out.numpy()
-        O.step_fwd_range(hn, on, P.numpy(), hc, skip + 2, N - skip - 2)
+        O.step_fwd_range(hn, on, P.numpy(), hc, lo, hi)
         return out
 
-    def step_bwd(h, g_out, P, g_inject=None, g_in=None, param_grad=None, slab=True, halo=2, ws=None):
+    def step_bwd(h, g_out, P, g_inject=None, g_in=None, param_grad=None, slab=True, halo=2, ws=None, planes=None):
         assert slab
         n = h.shape[1] - 2 * halo
+        lo, hi = planes if planes is not None else (halo, halo + n)
         inj = g_inject.contiguous().numpy() if g_inject is not None else None
-        O.step_bwd_range(h.numpy(), g_out.numpy(), inj, g_in.numpy(), param_grad.numpy(), P.numpy(), hc, halo, halo + n)
+        O.step_bwd_range(h.numpy(), g_out.numpy(), inj, g_in.numpy(), param_grad.numpy(), P.numpy(), hc, lo, hi)
         return g_in, param_grad
 
     return step_fwd, step_bwd
@@ -82,17 +84,21 @@ def _worker(rank, world, port, shape, halo, T, hc, dtype_name, q):
         fwd, bwd = _oracle_slab_steps(hc)
         Pt = torch.tensor(P)
         local0 = slab.scatter_slab(torch.tensor(h0), rank, world, halo)
-        traj = torch.zeros((T + 1,) + tuple(local0.shape), dtype=local0.dtype)
-        traj[0] = local0
-        slab.slab_rollout_fwd_(traj, Pt, ex, halo, step_fwd=fwd)
-        got = traj[:, :, halo:halo + n].numpy()
-        ok_fwd = np.array_equal(got, traj_ref[:, :, lo:hi])            # bit-identical to the single domain
+        ok_fwd, ok_g0, err_pg = True, True, 0.0
+        # both schedules: faces first + asynchronous exchange + planes in between (what runs on a multi-GPU node),
+        # and the un-split one
+        for overlap in (True, False):
+            traj = torch.zeros((T + 1,) + tuple(local0.shape), dtype=local0.dtype)
+            traj[0] = local0
+            slab.slab_rollout_fwd_(traj, Pt, ex, halo, step_fwd=fwd, overlap=overlap)
+            got = traj[:, :, halo:halo + n].numpy()
+            ok_fwd &= np.array_equal(got, traj_ref[:, :, lo:hi])       # bit-identical to the single domain
 
-        g_local = torch.zeros_like(traj)
-        g_local[:, :, halo:halo + n] = torch.tensor(g_ref[:, :, lo:hi])
-        g0, pg = slab.slab_rollout_bwd(traj, g_local, Pt, ex, halo, step_bwd=bwd, wgrad=None)
-        ok_g0 = np.array_equal(g0[:, halo:halo + n].numpy(), g0_ref[:, lo:hi])
-        err_pg = float(np.linalg.norm(pg.numpy() - pg_ref) / np.linalg.norm(pg_ref))
+            g_local = torch.zeros_like(traj)
+            g_local[:, :, halo:halo + n] = torch.tensor(g_ref[:, :, lo:hi])
+            g0, pg = slab.slab_rollout_bwd(traj, g_local, Pt, ex, halo, step_bwd=bwd, wgrad=None, overlap=overlap)
+            ok_g0 &= np.array_equal(g0[:, halo:halo + n].numpy(), g0_ref[:, lo:hi])
+            err_pg = max(err_pg, float(np.linalg.norm(pg.numpy() - pg_ref) / np.linalg.norm(pg_ref)))
         q.put((rank, ok_fwd, ok_g0, err_pg))
     finally:
         if world > 1:
