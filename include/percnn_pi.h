@@ -162,6 +162,20 @@ int percnn_pi_slab_step_bwd_f64(const double *h, const double *g_out, const doub
                                 const double *params, int hc, int ndim, const int64_t *shape, int halo,
                                 int flags, void *stream);
 
+/* 'same' 5x5x5 cross-correlation 8 -> 8 channels with zero padding on a [8][D][H][W] float32 field -- the contraction
+ * of the 3D IC generator's second layer (ConvTranspose3d(8, 8, 5, padding=2), train_3drd.py:45-52): its forward and its
+ * input gradient are this operation with differently arranged weights.
+ *   out[co](p) = bias[co] + sum_{ci, dz, dy, dx} weights[(((ci*5 + dz)*5 + dy)*5 + dx)*8 + co] * in[ci](p + (dz,dy,dx) - 2)
+ * bias may be NULL; shape = {D, H, W}; in and out must not alias. */
+int percnn_pi_conv3d_k5c8_f32(const float* in, float* out, const float* weights, const float* bias, const int64_t* shape,
+                              void* stream);
+
+/* weight gradient of the same contraction: g_weights[(((ci*5+dz)*5+dy)*5+dx)*8 + co] = sum_p in[ci](p+d-2) * g_out[co](p)
+ * (overwritten); workspace: percnn_pi_conv3d_k5c8_wgrad_workspace_bytes() bytes of device memory. */
+size_t percnn_pi_conv3d_k5c8_wgrad_workspace_bytes(void);
+int percnn_pi_conv3d_k5c8_wgrad_f32(const float* in, const float* g_out, float* g_weights, void* workspace,
+                                    size_t workspace_bytes, const int64_t* shape, void* stream);
+
 /* ---- native slab rollouts (multi-GPU): the whole T-step loop, halo exchanges included, in ONE call ---------------
  * The ring is described by plain function pointers so that the library needs no link-time dependency on RCCL: the host
  * side passes the addresses of ncclGroupStart / ncclGroupEnd / ncclSend / ncclRecv of the librccl it already uses

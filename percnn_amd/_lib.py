@@ -20,6 +20,7 @@ _INC = os.path.join("..", "..", "include")
 SOURCES = {
     "pi_abi.hip": ["pi_kernels.h", "pi_tile2d.h", "pi_stream3d.h", "pi_adv.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h")],
     "pi_s1_abi.hip": ["pi_s1.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h"), os.path.join(_INC, "percnn_pi_stage1.h")],
+    "pi_up3d_abi.hip": ["pi_up3d.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h")],
 }
 
 EXPORTS = [
@@ -31,6 +32,7 @@ EXPORTS = [
                 "residual_bwd")] + [
     "percnn_pi_s1_param_count", "percnn_pi_s1_step_fwd_f32", "percnn_pi_s1_rollout_fwd_f32",
     "percnn_pi_s1_rollout_bwd_workspace_bytes", "percnn_pi_s1_rollout_bwd_f32", "percnn_pi_s1_set_option",
+    "percnn_pi_conv3d_k5c8_f32", "percnn_pi_conv3d_k5c8_wgrad_workspace_bytes", "percnn_pi_conv3d_k5c8_wgrad_f32",
 ]
 
 
@@ -119,6 +121,10 @@ def lib() -> ctypes.CDLL:
     L.percnn_pi_s1_rollout_fwd_f32.restype, L.percnn_pi_s1_rollout_fwd_f32.argtypes = ci, [vp, vp, i64p, ci, vp]
     L.percnn_pi_s1_rollout_bwd_workspace_bytes.restype = sz
     L.percnn_pi_s1_rollout_bwd_workspace_bytes.argtypes = [i64p, ci]
+    L.percnn_pi_conv3d_k5c8_f32.restype, L.percnn_pi_conv3d_k5c8_f32.argtypes = ci, [vp, vp, vp, vp, i64p, vp]
+    L.percnn_pi_conv3d_k5c8_wgrad_workspace_bytes.restype, L.percnn_pi_conv3d_k5c8_wgrad_workspace_bytes.argtypes = sz, []
+    L.percnn_pi_conv3d_k5c8_wgrad_f32.restype = ci
+    L.percnn_pi_conv3d_k5c8_wgrad_f32.argtypes = [vp, vp, vp, vp, sz, i64p, vp]
     L.percnn_pi_s1_set_option.restype, L.percnn_pi_s1_set_option.argtypes = ci, [ctypes.c_char_p, ctypes.c_long]
     L.percnn_pi_s1_rollout_bwd_f32.restype = ci
     L.percnn_pi_s1_rollout_bwd_f32.argtypes = [vp, vp, ctypes.c_char_p, vp, vp, vp, sz, vp, i64p, ci, vp]

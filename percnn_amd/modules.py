@@ -323,6 +323,23 @@ def _conv3d_k5_slabs(x: torch.Tensor, w2d: torch.Tensor, slab: int) -> torch.Ten
     return torch.cat(outs, 0).permute(3, 0, 1, 2)[None]
 
 
+def _conv3d_k5c8_hip(x: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """percnn_pi_conv3d_k5c8_f32: x [1,8,D,H,W] float32 on a HIP device, wt [8,5,5,5,8] = [ci][dz][dy][dx][co]"""
+    from . import _lib
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().percnn_pi_conv3d_k5c8_f32(x.data_ptr(), out.data_ptr(), wt.data_ptr(),
+                                                       bias.data_ptr() if bias is not None else None,
+                                                       _lib.shape_arg(x.shape[2:]),
+                                                       F_pi._stream()), "conv3d_k5c8")
+    return out
+
+
+def _hip_conv_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(weight.shape) == (8, 8, 5, 5, 5)
+            and x.shape[0] == 1)
+
+
 class _ConvTranspose3dS1K5(torch.autograd.Function):
     """ConvTranspose3d(k=5, stride=1, padding=2) == cross-correlation with the flipped, channel-transposed kernel.
     Forward, input gradient and weight gradient are all slab-wise im2col + matmul; the unfolded columns (1 GB per
@@ -331,9 +348,11 @@ class _ConvTranspose3dS1K5(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ci, co = weight.shape[:2]
-        wf = weight.flip(2, 3, 4).transpose(0, 1).reshape(co, ci * 125)   # [co, (ci, d)]
         ctx.save_for_backward(x, weight)
         ctx.slab = max(1, int(2 ** 28 // max(1, x.shape[3] * x.shape[4] * ci * 125)))
+        if _hip_conv_ok(x, weight):                                       # hand-written kernel (csrc/pi_up3d.h)
+            return _conv3d_k5c8_hip(x, weight.flip(2, 3, 4).permute(0, 2, 3, 4, 1).contiguous(), bias.contiguous())
+        wf = weight.flip(2, 3, 4).transpose(0, 1).reshape(co, ci * 125)   # [co, (ci, d)]
         return _conv3d_k5_slabs(x, wf, ctx.slab) + bias.view(1, co, 1, 1, 1)
 
     @staticmethod
@@ -342,8 +361,21 @@ class _ConvTranspose3dS1K5(torch.autograd.Function):
         ci, co = weight.shape[:2]
         g = g.contiguous()
         # dL/dx = 'same' cross-correlation of g with W itself: [ci, (co, d)]
-        wg = weight.reshape(ci, co * 125)
-        gx = _conv3d_k5_slabs(g, wg, ctx.slab)
+        if _hip_conv_ok(g, weight):
+            gx = _conv3d_k5c8_hip(g, weight.permute(1, 2, 3, 4, 0).contiguous(), None)
+        else:
+            gx = _conv3d_k5_slabs(g, weight.reshape(ci, co * 125), ctx.slab)
+        if _hip_conv_ok(g, weight) and _hip_conv_ok(x, weight):
+            from . import _lib
+            L = _lib.lib()
+            ws = torch.empty(L.percnn_pi_conv3d_k5c8_wgrad_workspace_bytes(), dtype=torch.uint8, device=x.device)
+            gwt = torch.empty(8, 5, 5, 5, 8, dtype=torch.float32, device=x.device)     # [ci][dz][dy][dx][co]
+            with torch.cuda.device(x.device):
+                _lib.check(L.percnn_pi_conv3d_k5c8_wgrad_f32(x.data_ptr(), g.data_ptr(), gwt.data_ptr(), ws.data_ptr(),
+                                                             ws.numel(), _lib.shape_arg(x.shape[2:]), F_pi._stream()),
+                           "conv3d_k5c8_wgrad")
+            # the forward used Wt[ci][d'][co] = weight[ci][co][4 - d']
+            return gx, gwt.permute(0, 4, 1, 2, 3).flip(2, 3, 4), g.sum(dim=(0, 2, 3, 4))
         # dL/dW[ci, co, d] = sum_o x[ci](o + 2 - d) g[co](o)  ->  correlate padded x columns with g, then flip the taps
         D, H, W = x.shape[2:]
         xp = torch.nn.functional.pad(x, (2, 2, 2, 2, 2, 2))

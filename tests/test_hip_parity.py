@@ -804,3 +804,21 @@ def test_observe_equals_cat_and_slice(ndim, hip_device):
     for a, b in zip(g_obs, g_ref):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
 
+
+@pytest.mark.parametrize("shape", [(6, 5, 7), (16, 16, 64), (9, 33, 70)])
+def test_3d_upscaler_hip_contraction_equals_stock_layers(shape, hip_device):
+    """The 3D IC generator on a HIP device (layer 2 forward and input gradient through percnn_pi_conv3d_k5c8_f32) gives
+    the values and gradients of the stock torch.nn layers it holds (train_3drd.py:41-56); float32, 1e-5."""
+    import percnn_amd as pa
+    torch.manual_seed(1)
+    up = pa.Upscaler(3).to(hip_device)
+    x = torch.rand((1, 2) + shape, device=hip_device, requires_grad=True)
+    ref = up.convnet(x)
+    w = torch.randn_like(ref)
+    gref = torch.autograd.grad((ref * w).sum(), [x] + list(up.parameters()))
+    out = up(x)
+    assert rel_l2(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-5
+    gout = torch.autograd.grad((out * w).sum(), [x] + list(up.parameters()))
+    for a, b in zip(gout, gref):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
+
