@@ -3,7 +3,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
-for wl in gs2d_512 gs3d_128 lo2d_512 bur1_100 lo1_100; do
+for wl in gs2d_512 gs3d_128 lo2d_512 gs2d_100 bur1_100 lo1_100; do
   (timeout 900 python $R/bench.py --workload $wl 2>&1 | tail -1) > $R/gpurun_out/final_bench_$wl.json
   rm -rf /tmp/kt; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --workload $wl --no-cpu-baseline --steps 3 --warmup 1 > /tmp/kt.log 2>&1
   python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) > $R/gpurun_out/final_kernel_stats_$wl.txt 2>&1
@@ -23,7 +23,9 @@ cd $R
 timeout 900 python tools/size_sweep.py --out gpurun_out/size_sweep.json 2>&1 | grep -v amdgpu.ids > gpurun_out/size_sweep.txt
 timeout 600 python tools/s1_bench.py --out gpurun_out/s1_size_sweep.json 2>&1 | grep -v amdgpu.ids > gpurun_out/s1_size_sweep.txt
 cat gpurun_out/final_pmc_summary.txt | cut -c1-200
-for f in gpurun_out/final_bench_*.json; do echo $f; python -c "
+timeout 900 python tools/upscaler_share.py 2>&1 | grep -v amdgpu.ids > gpurun_out/upscaler_share.txt
+(PERCNN_FORCE_P2P=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --slab-extra 2>/dev/null | tail -1) > gpurun_out/final_bench_gs2d_512_torchrun1_rccl_self.json
+for f in gpurun_out/final_bench_[a-z0-9_]*.json; do case $f in *under_rocprof*) continue;; esac; echo $f; python -c "
 import json,sys
 d=json.loads(open('$f').read().strip().splitlines()[-1])
 print('  value %.0f steps/s  fwd %.2f us  bwd %.2f us'%(d['value'], d['fwd_us_per_time_step'], d['bwd_us_per_time_step']), ' dominant', d['roofline']['kernel'], 'frac %.3f'%d['roofline']['frac'], 'cpu', d.get('cpu_baseline',{}).get('value'))
