@@ -31,7 +31,7 @@ struct Options {
                             // sweep + one time-parallel reduction (experiment: saves the reduction pass, costs per-step reductions)
     int skip_wgrad = 0;     // diagnostics: rollout_bwd runs the adjoint sweep only (bench uses it to time the sweep alone)
     int tile_xcd = 1;       // XCD-aware block -> tile map of the 2D tile kernels (0 = identity)
-    int tile_by = 32;       // tile height of the 2D tile kernels (32, or 16 = twice the workgroups: 2 per CU at 512^2)
+    int tile_by = 0;        // tile height of the 2D tile kernels: 32, 16, or 0 = by grid size (see tile_by_for)
     int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
                             // small grid is spread over all CUs instead of being packed onto a few
 };
@@ -392,6 +392,18 @@ hipError_t step_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partial
 // ---- temporally blocked 2D path -----------------------------------------------------------------
 constexpr int TILE_B = 32;
 
+// Tile height of the poly-mode tile kernels.  32x32 tiles give a 512^2 grid exactly one workgroup per CU; smaller grids
+// leave CUs idle and the launch time is the dependent chain of ONE workgroup, so they get 32x16 tiles (twice the
+// workgroups, shorter chain): measured 243 k vs 208 k steps/s on the reference's 100^2 grid, 135 k vs 171 k at 512^2.
+int tile_by_for(const Problem& p)
+{
+    if (p.hc != 0) return TILE_B;
+    if (g_opt.tile_by == 16 || g_opt.tile_by == 32) return g_opt.tile_by;
+    if (g_opt.tile_k != 4 || g_opt.tile_nt != 512) return TILE_B;
+    const int64_t tiles32 = ((p.n0 + TILE_B - 1) / TILE_B) * ((p.W + TILE_B - 1) / TILE_B);
+    return tiles32 <= 128 ? 16 : TILE_B;
+}
+
 template <typename T>
 bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs)
 {
@@ -402,7 +414,7 @@ bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs)
     if (p.W % pi::vec_width<T>::value || !fits(p.n0) || !fits(p.W)) return false;
     // the adjoint tile kernel owns one partial row per workgroup: beyond MAX_BWD_BLOCKS tiles the grid-stride
     // direct kernels take over (4096^2 = 16384 tiles)
-    const int64_t by = p.hc == 0 ? g_opt.tile_by : TILE_B;
+    const int64_t by = tile_by_for(p);
     if (((p.n0 + by - 1) / by) * ((p.W + TILE_B - 1) / TILE_B) > MAX_BWD_BLOCKS) return false;
     // temporal blocking pays while launches are latency-bound; from ~1 M points the halo ring's redundant traffic
     // costs more than the launches it saves (measured: profiles/r01_size_sweep.txt), tile = 2 forces the tile path
@@ -464,7 +476,7 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
         if constexpr (HC == pi::POLY) {                                         \
             if (g_opt.tile_k == 8) return CALL(HC, 8, 1024);                    \
             if (g_opt.tile_nt == 1024) return CALL(HC, 4, 1024);                \
-            if (g_opt.tile_by == 16) return CALL(HC, 4, 320, 16);               \
+            if (tile_by_for(p) == 16) return CALL(HC, 4, 320, 16);              \
         }                                                                       \
         if (g_opt.tile_nt == 256) return CALL(HC, 4, 256);                      \
         return CALL(HC, 4, 512);                                                \
@@ -857,7 +869,7 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     if (tile_eligible<T>(p, {traj, g_traj, g_h0, adj})) {
         const int K = (g_opt.tile_k == 8 && p.hc != 0) ? 4 : g_opt.tile_k;
         {
-            const int by = p.hc == 0 ? g_opt.tile_by : TILE_B;
+            const int by = tile_by_for(p);
             rows = (unsigned)(((p.n0 + by - 1) / by) * ((p.W + TILE_B - 1) / TILE_B));
         }
         for (; t_cur - K >= 0; t_cur -= K) {
@@ -971,7 +983,7 @@ int percnn_pi_set_option(const char* key, long value)
     }
     if (!std::strcmp(key, "tile_xcd")) { g_opt.tile_xcd = value != 0; return 0; }
     if (!std::strcmp(key, "tile_by")) {
-        if (value != 16 && value != 32) return PERCNN_PI_EINVAL;
+        if (value != 0 && value != 16 && value != 32) return PERCNN_PI_EINVAL;
         g_opt.tile_by = (int)value;
         return 0;
     }

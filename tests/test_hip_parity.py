@@ -429,7 +429,7 @@ def test_rccl_halo_exchange_to_self(hip_device):
 # temporally blocked 2D kernels: every variant must stay bit-identical to the oracle
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opts", [{"tile": 0}, {"tile_xcd": 0}, {"tile_k": 2}, {"tile_k": 4, "tile_nt": 256},
-                                  {"tile_k": 4, "tile_nt": 512}, {"tile_k": 4, "tile_nt": 1024}, {"tile_k": 8}, {"tile_by": 16}, {"vec": 1}])
+                                  {"tile_k": 4, "tile_nt": 512}, {"tile_k": 4, "tile_nt": 1024}, {"tile_k": 8}, {"tile_by": 16}, {"tile_by": 32}, {"vec": 1}])
 @pytest.mark.parametrize("dtype,hc", [(np.float32, 8), (np.float32, 2), (np.float64, 4), (np.float32, 0),
                                       (np.float64, 0)])
 @pytest.mark.parametrize("shape", [(64, 96), (40, 100), (128, 256)])
@@ -444,7 +444,7 @@ def test_tile_variants_bitwise(opts, dtype, hc, shape, hip_device):
     gt = rs.uniform(-1, 1, (T + 1, 2) + shape).astype(dtype)
     ref = o_rollout_fwd(h0, P, T)
     g0_ref, pg_ref = o_rollout_bwd(ref, gt, P)
-    defaults = {"tile": 1, "tile_k": 4, "tile_nt": 512, "tile_by": 32, "vec": 0, "tile_xcd": 1}
+    defaults = {"tile": 1, "tile_k": 4, "tile_nt": 512, "tile_by": 0, "vec": 0, "tile_xcd": 1}
     try:
         for k, v in opts.items():
             pa.set_option(k, v)
