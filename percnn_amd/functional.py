@@ -481,7 +481,8 @@ class PiRolloutFramesFunction(torch.autograd.Function):
         rollout_fwd_(traj, P)
         ctx.save_for_backward(traj, P)
         ctx.frames = tuple(int(k) for k in frames)
-        return tuple(traj[k:k + 1] for k in ctx.frames)
+        views = traj.unsqueeze(1).unbind(0)                 # all [1,2,*S] frame views in one call
+        return tuple(views[k] for k in ctx.frames)
 
     @staticmethod
     def backward(ctx, *grads):
