@@ -214,14 +214,23 @@ def main():
     # (the factored Hc=8 reduction streams h once per species: 3*C*s)
     Cs = 2 * esz
     red_bytes_pt = 2 * Cs if (poly or hc <= 4) else 3 * Cs
+    # float32 poly mode on the direct-kernel path: the gradient reduction is fused into the sweep launches (no separate
+    # pass); the sweep-only timing above then only serves as a lower bound of that kernel
+    fused = (not tiled) and poly and dtype == torch.float32 and opts.get("fuse_wgrad", "2") != "0" and \
+        not (len(shape) == 3 and shape[-1] == 256 and npts >= (2 << 20) and opts.get("stream3d", "1") != "0")
+    if fused:
+        sweep_ms, red_ms = bwd_ms, 1e-6
     kernels = [
         {"kernel": ("pi_fwd2d_tile_kernel" if tiled else "pi_fwd_kernel"), "launches_per_pass": T // K,
          "algorithmic_bytes_per_launch": 2 * Cs * npts * K, "avg_launch_us": fwd_ms * 1e3 / (T / K)},
-        {"kernel": ("pi_adj2d_tile_kernel" if tiled else "pi_bwd_kernel<sweep>"), "launches_per_pass": T // K,
+        {"kernel": ("pi_adj2d_tile_kernel" if tiled else ("pi_bwd_kernel<sweep+moments>" if fused else "pi_bwd_kernel<sweep>")),
+         "launches_per_pass": T // K,
          "algorithmic_bytes_per_launch": 4 * Cs * npts * K, "avg_launch_us": sweep_ms * 1e3 / (T / K)},
         {"kernel": ("pi_moments_kernel" if poly else "pi_wgrad_kernel"), "launches_per_pass": 1,
          "algorithmic_bytes_per_launch": red_bytes_pt * npts * T, "avg_launch_us": red_ms * 1e3},
     ]
+    if fused:
+        kernels.pop()                                   # no separate reduction launch
     for k in kernels:
         k["achieved"] = k["algorithmic_bytes_per_launch"] / (k["avg_launch_us"] * 1e-6) / 1e9
         k["frac"] = k["achieved"] / HBM_PEAK_GBS

@@ -27,8 +27,10 @@ struct Options {
     int zc = 8;             // planes per workgroup of the streaming kernels
     int overlap = 0;        // 1: run the gradient reduction on a side stream, chunk by chunk, under the sweep (measured: no gain on MI355X)
     int overlap_chunk = 128; // time steps per chunk
-    int fuse_wgrad = 0;     // rollout sweep uses the fused per-step kernel (all gradients reduced every step) instead of
-                            // sweep + one time-parallel reduction (experiment: saves the reduction pass, costs per-step reductions)
+    int fuse_wgrad = 2;     // rollout sweep with the fused per-step kernel (all gradients reduced in the sweep launches)
+                            // instead of sweep + one time-parallel reduction: 0 never, 1 whenever the per-step direct kernels
+                            // sweep, 2 = where it measured faster: float32 poly mode on the direct-kernel path (128^3:
+                            // 26.0 -> 23.3 us per step, 2048^2: 45.4 -> 39.8; fp64 and the factored mode lose)
     int skip_wgrad = 0;     // diagnostics: rollout_bwd runs the adjoint sweep only (bench uses it to time the sweep alone)
     int tile_xcd = 1;       // XCD-aware block -> tile map of the 2D tile kernels (0 = identity)
     int tile_by = 0;        // tile height of the 2D tile kernels: 32, 16, or 0 = by grid size (see tile_by_for)
@@ -837,16 +839,22 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     //    stream (the sweep is latency-bound, the reduction HBM-bound); partial rows are disjoint columns.
     const bool vec_ok = (p.n % pi::vec_width<T>::value == 0) && g_opt.vec != 1 &&
                         (reinterpret_cast<uintptr_t>(traj) % 16 == 0);
+    // fused gradient reduction only where the per-step direct kernels sweep EVERY step (no tile launches, no plane
+    // streaming): the other kernel families have no fused flavour
+    const bool direct_sweep = !tile_eligible<T>(p, {traj, g_traj, g_h0, adj}) &&
+                              !stream3d_vec<T>(p, {traj, g_traj, g_h0, adj});
+    const bool fuse = direct_sweep && !g_opt.skip_wgrad && hc != -1 &&
+                      (g_opt.fuse_wgrad == 1 || (g_opt.fuse_wgrad == 2 && hc == 0 && sizeof(T) == 4));
     unsigned rows = 0, wrows = 0;
     auto reduce_range = [&](int lo, int hi, hipStream_t s2) -> hipError_t {      // steps (lo, hi]
-        if (hi <= lo || g_opt.skip_wgrad || g_opt.fuse_wgrad) return hipSuccess;
+        if (hi <= lo || g_opt.skip_wgrad || fuse) return hipSuccess;
         unsigned r = 0;
         hipError_t e = vec_ok ? launch_wgrad<T, pi::vec_width<T>::value>(traj, adj, w.partials, P, p, lo, hi, &r, s2)
                               : launch_wgrad<T, 1>(traj, adj, w.partials, P, p, lo, hi, &r, s2);
         if (r > wrows) wrows = r;
         return e;
     };
-    SideStream* ss = (g_opt.overlap && !g_opt.skip_wgrad && !g_opt.fuse_wgrad && t_top >= 2 * g_opt.overlap_chunk)
+    SideStream* ss = (g_opt.overlap && !g_opt.skip_wgrad && !fuse && t_top >= 2 * g_opt.overlap_chunk)
                          ? side_stream() : nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (ss && (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) ss = nullptr;
@@ -886,14 +894,14 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
         T* dst = (t == 1) ? g_h0 : adj + (size_t)(t - 1) * frame;
         const T* inj = has(t - 1) ? g_traj + (size_t)(t - 1) * frame : nullptr;
         unsigned r2 = 0;
-        hipError_t e = g_opt.fuse_wgrad
+        hipError_t e = fuse
             ? step_bwd<T, true>(traj + (size_t)(t - 1) * frame, adj + (size_t)t * frame, inj, dst, w.partials, P, p, st, &r2)
             : step_bwd<T, false>(traj + (size_t)(t - 1) * frame, adj + (size_t)t * frame, inj, dst, w.partials, P, p, st, &r2);
         if (e) return (int)e;
         if (r2 > rows) rows = r2;
         if (hipError_t e2 = hand_over(t - 1)) return (int)e2;
     }
-    if (g_opt.skip_wgrad || hc == -1 || (g_opt.fuse_wgrad && t_cur == t_top))
+    if (g_opt.skip_wgrad || hc == -1 || fuse)
         return (int)finish_grads(w, rows, hc, param_grad, st);
     if (ss) {
         // remaining steps (0, reduced_above] on the side stream too (ordered behind the earlier chunks), then join
@@ -988,7 +996,11 @@ int percnn_pi_set_option(const char* key, long value)
         return 0;
     }
     if (!std::strcmp(key, "skip_wgrad")) { g_opt.skip_wgrad = value != 0; return 0; }
-    if (!std::strcmp(key, "fuse_wgrad")) { g_opt.fuse_wgrad = value != 0; return 0; }
+    if (!std::strcmp(key, "fuse_wgrad")) {
+        if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
+        g_opt.fuse_wgrad = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "overlap")) { g_opt.overlap = value != 0; return 0; }
     if (!std::strcmp(key, "overlap_chunk")) {
         if (value < 1 || value > (1 << 20)) return PERCNN_PI_EINVAL;

@@ -822,3 +822,30 @@ def test_3d_upscaler_hip_contraction_equals_stock_layers(shape, hip_device):
     for a, b in zip(gout, gref):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
 
+
+@pytest.mark.parametrize("ndim,dtype", [(3, np.float32), (2, np.float32), (3, np.float64)])
+def test_fused_and_separate_gradient_reduction_agree(ndim, dtype, hip_device):
+    """Direct-kernel path (shapes the tile / streaming kernels do not take): rollout_bwd with the gradient reduction fused
+    into the sweep launches (default for float32 poly mode) and as a separate time-parallel pass give the same adjoint
+    state bit for bit and the same parameter gradients to reduction round-off; both match the C oracle."""
+    import percnn_amd as pa
+    rs = np.random.RandomState(4)
+    shape = (12, 10, 36) if ndim == 3 else (37 * 4, 20)       # 2D: W = 20 < 32 + 16 ... not tile-eligible
+    T = 6
+    res = {}
+    for hc in (0, 2):
+        P = random_block(hc, ndim, dtype, 2, scale=0.3)
+        h0 = rs.uniform(0.2, 0.8, (2,) + shape).astype(dtype)
+        traj_o = o_rollout_fwd(h0, P, T)
+        g = rs.standard_normal(traj_o.shape).astype(dtype)
+        g0_o, pg_o = o_rollout_bwd(traj_o, g, P)
+        traj = dev_t(traj_o, hip_device)
+        for fuse in (0, 1, 2):
+            pa.set_option("fuse_wgrad", fuse)
+            try:
+                g0, pg = pa.rollout_bwd(traj, dev_t(g, hip_device), dev_t(P, hip_device))
+            finally:
+                pa.set_option("fuse_wgrad", 2)
+            assert np.array_equal(g0.cpu().numpy(), g0_o)
+            assert rel_l2(pg.cpu().numpy(), pg_o) < (5e-5 if dtype == np.float32 else 1e-11), (hc, fuse)
+
