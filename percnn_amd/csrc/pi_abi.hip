@@ -327,7 +327,7 @@ inline int stream3d_zc(const Problem& p, const Geom& g, bool adj)
 
 template <typename T, int HC, int VEC, bool ADJ>
 hipError_t launch_stream3d(const T* f, T* out, const T* h, const T* inj, double* partials, const T* P, const Problem& p,
-                           hipStream_t st, unsigned* rows_out)
+                           hipStream_t st, unsigned* rows_out, int with_mom)
 {
     const Geom g = make_geom(p);
     const int zc = stream3d_zc(p, g, ADJ);
@@ -336,15 +336,15 @@ hipError_t launch_stream3d(const T* f, T* out, const T* h, const T* inj, double*
     if (g.n0 <= 0) return hipSuccess;
     const size_t lds = (size_t)4 * pi::Strip<T, VEC, STREAM_TY>::PLANE * sizeof(T);
     hipLaunchKernelGGL((pi::pi_stream3d_kernel<T, HC, VEC, STREAM_TY, ADJ>), dim3(grid), dim3(pi::WAVE * STREAM_TY), lds,
-                       st, f, out, h, inj, partials, P, g, zc, p.hc);
+                       st, f, out, h, inj, partials, P, g, zc, p.hc, with_mom);
     return hipGetLastError();
 }
 
 template <typename T, bool ADJ>
 hipError_t stream3d(int vec, const T* f, T* out, const T* h, const T* inj, double* partials, const T* P,
-                    const Problem& p, hipStream_t st, unsigned* rows_out)
+                    const Problem& p, hipStream_t st, unsigned* rows_out, int with_mom = 0)
 {
-#define CALL_S3(HC, VEC) launch_stream3d<T, HC, VEC, ADJ>(f, out, h, inj, partials, P, p, st, rows_out)
+#define CALL_S3(HC, VEC) launch_stream3d<T, HC, VEC, ADJ>(f, out, h, inj, partials, P, p, st, rows_out, with_mom)
 #define S3_HC(VEC)                                                  \
     switch (p.hc) {                                                 \
         case 0:  return CALL_S3(pi::POLY, VEC);                     \
@@ -380,9 +380,9 @@ hipError_t step_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partial
                     hipStream_t st, unsigned* grid_out)
 {
     if (p.hc == -1) return adv_bwd<T>(h, G, inj, Gp, partials, P, p, st, grid_out);   // always fused (tiny grids)
-    if constexpr (!WGRAD)
+    if (!WGRAD || (p.hc == 0 && sizeof(T) == 4))            // fused flavour of the streaming kernel: float32 poly mode only
         if (const int sv = stream3d_vec<T>(p, {h, G, inj, Gp}))
-            return stream3d<T, true>(sv, G, Gp, h, inj, partials, P, p, st, grid_out);
+            return stream3d<T, true>(sv, G, Gp, h, inj, partials, P, p, st, grid_out, WGRAD ? 1 : 0);
     const int vec = pick_vec<T>(p, {h, G, inj, Gp});
     if (grid_out) *grid_out = bwd_grid(p, vec);
 #define CALL_BWD(NDIM, HC, VEC) launch_bwd<T, NDIM, HC, VEC, WGRAD>(h, G, inj, Gp, partials, P, p, st)
@@ -752,13 +752,18 @@ int slab_rollout_bwd_impl(const T* traj, const T* g_traj, T* adj, double* param_
     if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
     SideStream* side = overlap && n >= 4 ? side_stream() : nullptr;
     hipEvent_t pending = nullptr;
+    // float32 poly mode: the 20 coefficient moments are reduced inside the sweep launches (no slab_wgrad pass)
+    const bool fuse = hc == 0 && sizeof(T) == 4 && g_opt.fuse_wgrad != 0;
     auto sweep = [&](int t, int lo, int hi) -> int {        // adjoint planes [lo, hi) of frame t-1 from frame t
         Problem q = p;
         if (int rc = set_slab_range(q, halo, lo, hi)) return rc;
         unsigned grid = 0;
-        return (int)step_bwd<T, false>(traj + (size_t)(t - 1) * frame, adj + (size_t)t * frame,
-                                       g_traj + (size_t)(t - 1) * frame, adj + (size_t)(t - 1) * frame, w.partials, P, q, st,
-                                       &grid);
+        const T* hf = traj + (size_t)(t - 1) * frame;
+        const T* gf = adj + (size_t)t * frame;
+        const T* jf = g_traj + (size_t)(t - 1) * frame;
+        T* of = adj + (size_t)(t - 1) * frame;
+        return fuse ? (int)step_bwd<T, true>(hf, gf, jf, of, w.partials, P, q, st, &grid)
+                    : (int)step_bwd<T, false>(hf, gf, jf, of, w.partials, P, q, st, &grid);
     };
     for (int t = T_steps; t >= 1; --t) {
         if (pending) {
@@ -775,6 +780,7 @@ int slab_rollout_bwd_impl(const T* traj, const T* g_traj, T* adj, double* param_
     }
     // diffusion-coefficient sums of the whole sweep (kept in the partial rows across all launches) ...
     if (hipError_t e = finish_grads(w, MAX_BWD_BLOCKS, hc, param_grad, st)) return (int)e;
+    if (fuse) return 0;
     // ... then the branch gradients of all steps in one time-parallel reduction over the local interior
     return slab_wgrad_impl<T>(traj, adj, param_grad, ws, ws_bytes, P, hc, ndim, shape, halo, T_steps, stream);
 }
@@ -841,10 +847,12 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
                         (reinterpret_cast<uintptr_t>(traj) % 16 == 0);
     // fused gradient reduction only where the per-step direct kernels sweep EVERY step (no tile launches, no plane
     // streaming): the other kernel families have no fused flavour
+    // (the streaming kernel's fused flavour exists for float32 poly mode)
+    const bool f32poly = hc == 0 && sizeof(T) == 4;
     const bool direct_sweep = !tile_eligible<T>(p, {traj, g_traj, g_h0, adj}) &&
-                              !stream3d_vec<T>(p, {traj, g_traj, g_h0, adj});
+                              (f32poly || !stream3d_vec<T>(p, {traj, g_traj, g_h0, adj}));
     const bool fuse = direct_sweep && !g_opt.skip_wgrad && hc != -1 &&
-                      (g_opt.fuse_wgrad == 1 || (g_opt.fuse_wgrad == 2 && hc == 0 && sizeof(T) == 4));
+                      (g_opt.fuse_wgrad == 1 || (g_opt.fuse_wgrad == 2 && f32poly));
     unsigned rows = 0, wrows = 0;
     auto reduce_range = [&](int lo, int hi, hipStream_t s2) -> hipError_t {      // steps (lo, hi]
         if (hi <= lo || g_opt.skip_wgrad || fuse) return hipSuccess;

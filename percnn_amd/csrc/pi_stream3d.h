@@ -76,6 +76,11 @@ struct Stream3D {
     Pack<T, VEC> hp[2][RH];
     Pack<T, VEC> ph[2][ADJ ? RH : 1], pj[2][ADJ ? RH : 1];
     double acc_c[2];        // heavily cancelling sums: fp64
+    // adjoint, float32 poly mode: the 20 coefficient moments sum dt*a[s]*phi_m(h) accumulate per lane over the whole
+    // z-march (one cross-lane reduction per launch) -- replaces the separate pi_moments_kernel pass over both trajectories
+    static constexpr bool MOM = ADJ && HC == POLY && sizeof(T) == 4;
+    T mom[MOM ? 2 : 1][MOM ? 10 : 1];
+    int with_mom;
     // uniform state
     const T* f; T* out; const T* h; const T* inj; const T* P; T* lds;
     Geom g; int hc, wy, x0, y, hy, hrow, z1;
@@ -210,6 +215,20 @@ struct Stream3D {
                         du[i] = fma_(gr[i], ru, du[i]);
                         dv[i] = fma_(gr[i], rv, dv[i]);
                     }
+                    if constexpr (MOM) {
+                        if (with_mom) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) {
+                                const T uu = hu.v[i], vv = hv.v[i];
+                                const T u2 = uu * uu, uv = uu * vv, v2 = vv * vv;
+                                const T phi[10] = {T(1), uu, vv, u2, uv, v2, u2 * uu, u2 * vv, uu * v2, v2 * vv};
+                                T* ms = s == 0 ? mom[0] : mom[MOM ? 1 : 0];
+                                ms[0] += gr[i];
+#pragma unroll
+                                for (int q = 1; q < 10; ++q) ms[q] = fma_(gr[i], phi[q], ms[q]);
+                            }
+                        }
+                    }
                 } else {
                     const T* W = P + P_W + s * species_block(hc);
                     W10<T> nx = load_w10(W);
@@ -265,7 +284,7 @@ pi_stream3d_kernel(const T* __restrict__ f,        // stencil-read field: state 
                    const T* __restrict__ h,         // adj only: state the step was applied to
                    const T* __restrict__ inj,       // adj only, nullable
                    double* __restrict__ partials,   // adj only
-                   const T* __restrict__ P, Geom g, int zc, int hc_rt)
+                   const T* __restrict__ P, Geom g, int zc, int hc_rt, int with_mom)
 {
     using S = Strip<T, VEC, TY>;
     using K = Stream3D<T, HC, VEC, TY, ADJ>;
@@ -290,6 +309,13 @@ pi_stream3d_kernel(const T* __restrict__ f,        // stencil-read field: state 
     k.rowoff = (long)k.y * S::W + k.x0;
     k.hrowoff = (long)k.hy * S::W + k.x0;
     k.acc_c[0] = k.acc_c[1] = 0.0;
+    k.with_mom = with_mom;
+    if constexpr (K::MOM) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int q = 0; q < 10; ++q) k.mom[s][q] = T(0);
+    }
 
     // prologue: planes z0-2 .. z0+5 -> slots 0..7; halo rows / operands of planes z0 .. z0+3 -> slots 0..3
     int zz = g.wrap0 ? wrap(z0 - 2, g.n0) : z0 - 2;
@@ -322,16 +348,30 @@ pi_stream3d_kernel(const T* __restrict__ f,        // stencil-read field: state 
         // diffusion-coefficient gradients of this strip over its planes: one reduction per launch
         __syncthreads();
         double* red = reinterpret_cast<double*>(k.lds);
+        constexpr int NS = K::MOM ? 22 : 2;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const double r = wave_sum_to_last(k.acc_c[s]);
-            if (lane == REDUCE_LANE) red[k.wy * 2 + s] = r;
+            if (lane == REDUCE_LANE) red[k.wy * NS + s] = r;
+        }
+        if constexpr (K::MOM) {
+            if (with_mom) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) {
+                        const double r = wave_sum_to_last((double)k.mom[s][q]);
+                        if (lane == REDUCE_LANE) red[k.wy * NS + 2 + 10 * s + q] = r;
+                    }
+            }
         }
         __syncthreads();
-        if (threadIdx.x < 2) {
+        const int nsum = (K::MOM && with_mom) ? 22 : 2;
+        if ((int)threadIdx.x < nsum) {
             double sum = 0.0;
-            for (int w = 0; w < TY; ++w) sum += red[w * 2 + threadIdx.x];
-            partials[(long)blockIdx.x * nparams(HC == POLY ? 0 : k.hc) + P_COEF + threadIdx.x] += sum;
+            for (int w = 0; w < TY; ++w) sum += red[w * NS + threadIdx.x];
+            const int slot = threadIdx.x < 2 ? P_COEF + (int)threadIdx.x : P_W + (int)threadIdx.x - 2;
+            partials[(long)blockIdx.x * nparams(HC == POLY ? 0 : k.hc) + slot] += sum;
         }
     }
 }

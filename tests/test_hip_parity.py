@@ -398,8 +398,9 @@ def test_rccl_halo_exchange_to_self(hip_device):
         assert torch.equal(t, torch.ones_like(t))
         # overlapped schedule (faces first, RCCL-to-self on the side stream, planes in between) == un-split schedule
         # with local-wrap copies: trajectories and adjoint states bit for bit, gradient sums to round-off
-        for ndim, shape, halo in ((3, (24, 16, 64), 4), (2, (40, 64), 2), (3, (16, 8, 256), 4)):
-            P = dev_t(random_block(2, ndim, np.float32, 3, scale=0.3), hip_device)
+        for ndim, shape, halo, hc in ((3, (24, 16, 64), 4, 2), (2, (40, 64), 2, 2), (3, (16, 8, 256), 4, 2),
+                                      (3, (16, 8, 256), 4, 0), (3, (24, 16, 64), 4, 0)):   # hc = 0: poly mode, fused moments
+            P = dev_t(random_block(hc, ndim, np.float32, 3, scale=0.3), hip_device)
             T = 7
             h0 = torch.rand((2,) + shape, device=hip_device)
             res = []
@@ -420,7 +421,10 @@ def test_rccl_halo_exchange_to_self(hip_device):
                     ex.close()
             for r in res[1:]:
                 assert torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1])
-                assert torch.allclose(res[0][2], r[2], rtol=1e-9, atol=1e-12)
+                if hc == 0:       # native loop: moments reduced inside the sweep; Python loop: separate pass (fp32 order)
+                    assert rel_l2(r[2].cpu().numpy(), res[0][2].cpu().numpy()) < 2e-5
+                else:
+                    assert torch.allclose(res[0][2], r[2], rtol=1e-9, atol=1e-12)
     finally:
         dist.destroy_process_group()
 
@@ -823,14 +827,18 @@ def test_3d_upscaler_hip_contraction_equals_stock_layers(shape, hip_device):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
 
 
-@pytest.mark.parametrize("ndim,dtype", [(3, np.float32), (2, np.float32), (3, np.float64)])
+@pytest.mark.parametrize("ndim,dtype", [(3, np.float32), (2, np.float32), (3, np.float64), (-3, np.float32)])
 def test_fused_and_separate_gradient_reduction_agree(ndim, dtype, hip_device):
     """Direct-kernel path (shapes the tile / streaming kernels do not take): rollout_bwd with the gradient reduction fused
     into the sweep launches (default for float32 poly mode) and as a separate time-parallel pass give the same adjoint
     state bit for bit and the same parameter gradients to reduction round-off; both match the C oracle."""
     import percnn_amd as pa
     rs = np.random.RandomState(4)
-    shape = (12, 10, 36) if ndim == 3 else (37 * 4, 20)       # 2D: W = 20 < 32 + 16 ... not tile-eligible
+    stream = ndim < 0                                         # -3: a shape the plane-streaming kernels take (W = 256)
+    ndim = abs(ndim)
+    shape = (12, 8, 256) if stream else ((12, 10, 36) if ndim == 3 else (37 * 4, 20))   # 2D: W = 20: not tile-eligible
+    if stream:
+        pa.set_option("stream3d", 2)
     T = 6
     res = {}
     for hc in (0, 2):
@@ -848,4 +856,5 @@ def test_fused_and_separate_gradient_reduction_agree(ndim, dtype, hip_device):
                 pa.set_option("fuse_wgrad", 2)
             assert np.array_equal(g0.cpu().numpy(), g0_o)
             assert rel_l2(pg.cpu().numpy(), pg_o) < (5e-5 if dtype == np.float32 else 1e-11), (hc, fuse)
+    pa.set_option("stream3d", 1)
 
