@@ -16,7 +16,7 @@
  *   - Periodic boundaries on every axis (2dgs:108-109, 3dgs:125-127); every extent >= 2.
  *   - Asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream); no host
  *     synchronisation and no allocation inside, hence hipGraph-capturable.  Re-entrant; no
- *     global state except the optional rollout graph cache (percnn_pi_set_option).
+ *     global state except the tuning options below (percnn_pi_set_option) and an internal side stream + events.
  *   - Output buffers must not alias inputs.
  *   - Return value: 0 on success, otherwise a hipError_t cast to int, or one of the negative
  *     PERCNN_PI_E* codes for argument errors.  No C++ exceptions cross this boundary.
@@ -81,9 +81,25 @@ size_t percnn_pi_bwd_workspace_bytes(int hc, int ndim, const int64_t *shape, int
  * (T+1 frames of [2][*S]) + per-workgroup gradient partials. */
 size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *shape, int T, int elem_size);
 
-/* Tuning options (process-wide): "block" = workgroup size of the step kernels (64..256, multiple of
- * 64); "vec" = 1 forces one point per lane instead of 16 bytes per lane; "wgrad_blocks" = grid cap
- * of the weight-gradient kernel.  Returns 0, or PERCNN_PI_EINVAL for an unknown key / bad value. */
+/* Tuning / diagnostic options (process-wide).  Every setting computes the same values (state fields bit-identical,
+ * gradient sums to reduction round-off); defaults are what measured fastest on MI355X:
+ *   "block"        workgroup size of the per-step direct kernels (64..256, multiple of 64; default 256)
+ *   "vec"          1 = one point per lane instead of 16 bytes per lane
+ *   "wgrad_blocks" grid cap of the time-parallel gradient kernels
+ *   "tile"         2D temporally blocked kernels: 0 never, 1 (default) below 1 M points, 2 whenever the shape allows
+ *   "tile_k"       time steps per tile launch: 2, 4 (default), 8 (pre-contracted blocks only)
+ *   "tile_nt"      threads per tile workgroup: 256, 512 (default), 1024
+ *   "tile_by"      tile height: 16, 32, 0 (default) = 16 when 32x32 tiles would leave more than half the CUs idle
+ *   "tile_xcd"     1 (default) = XCD-aware block -> tile map
+ *   "stream3d"     3D plane-streaming kernels: 0 never, 1 (default) by size, 2 whenever W == 64 * lanes' vector width
+ *   "zc"           planes per workgroup of the plane-streaming kernels (default 8; the adjoint uses twice that)
+ *   "fuse_wgrad"   parameter gradients reduced inside the sweep launches instead of one time-parallel pass:
+ *                  0 never, 1 wherever a fused flavour exists, 2 (default) float32 pre-contracted blocks on the direct
+ *                  / plane-streaming kernels
+ *   "overlap", "overlap_chunk"  run the time-parallel gradient pass of finished chunks on a side stream under the sweep
+ *   "skip_wgrad"   diagnostics: adjoint sweep only, parameter gradients of the branches come back as zeros
+ *   "lds_pad"      diagnostics: extra dynamic LDS per workgroup (limits workgroups per CU)
+ * Returns 0, or PERCNN_PI_EINVAL for an unknown key / bad value. */
 int percnn_pi_set_option(const char *key, long value);
 
 /* ---- one Pi-block step ------------------------------------------------------------------
