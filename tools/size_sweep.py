@@ -42,6 +42,9 @@ def measure(family, golden, dtype, shape, reaction, dev, budget_bytes=24e9, reps
     fwd = ev[0].elapsed_time(ev[1]) / reps / T * 1e-3
     bwd = ev[1].elapsed_time(ev[2]) / reps / T * 1e-3
     swp = ev[2].elapsed_time(ev[3]) / reps / T * 1e-3
+    # float32 poly mode on the direct / plane-streaming kernels reduces the gradients INSIDE the sweep launches
+    # (fuse_wgrad): there the sweep-only time (skip_wgrad diagnostic) is only a lower bound and no separate pass exists
+    fused = (bwd - swp) < 0.25 * swp and reaction == "poly" and dtype == torch.float32 and (len(shape) == 3 or npts >= (1 << 20))
     red = max(bwd - swp, 1e-12)
     Cs = 2 * esz
     hc = cell.hidden_channels
@@ -49,7 +52,8 @@ def measure(family, golden, dtype, shape, reaction, dev, budget_bytes=24e9, reps
     r = {"family": family, "shape": list(shape), "dtype": str(dtype)[6:], "reaction": reaction, "T": T,
          "fwd_us_step": fwd * 1e6, "sweep_us_step": swp * 1e6, "reduce_us_step": red * 1e6,
          "fwd_GBs": 2 * Cs * npts / fwd / 1e9, "sweep_GBs": 4 * Cs * npts / swp / 1e9,
-         "reduce_GBs": red_b * npts / red / 1e9, "steps_per_s": 1.0 / (fwd + bwd),
+         "reduce_GBs": None if fused else red_b * npts / red / 1e9, "fused_reduction": bool(fused),
+         "bwd_us_step": bwd * 1e6, "steps_per_s": 1.0 / (fwd + bwd),
          "Mpts_steps_per_s": npts / (fwd + bwd) / 1e6}
     del traj, g
     torch.cuda.empty_cache()
@@ -76,9 +80,12 @@ def main():
                     continue
                 r = measure(family, golden, dtype, shape, reaction, dev)
                 rows.append(r)
-                print("%-5s %-9s %-14s T=%3d  fwd %8.2f us %5.0f GB/s | sweep %8.2f us %5.0f GB/s | reduce %7.2f us %5.0f GB/s | %8.1f Mpt-steps/s"
-                      % (family, reaction, "x".join(map(str, shape)), r["T"], r["fwd_us_step"], r["fwd_GBs"], r["sweep_us_step"],
-                         r["sweep_GBs"], r["reduce_us_step"], r["reduce_GBs"], r["Mpts_steps_per_s"]), flush=True)
+                tail = ("sweep+reduction fused %8.2f us" % r["bwd_us_step"]) if r["fused_reduction"] else \
+                    ("sweep %8.2f us %5.0f GB/s | reduce %7.2f us %5.0f GB/s" % (r["sweep_us_step"], r["sweep_GBs"],
+                                                                               r["reduce_us_step"], r["reduce_GBs"]))
+                print("%-5s %-9s %-14s T=%3d  fwd %8.2f us %5.0f GB/s | %s | %8.1f Mpt-steps/s"
+                      % (family, reaction, "x".join(map(str, shape)), r["T"], r["fwd_us_step"], r["fwd_GBs"], tail,
+                         r["Mpts_steps_per_s"]), flush=True)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(rows, open(a.out, "w"), indent=1)
 
