@@ -164,7 +164,7 @@ def test_module_rollout_and_gradients_vs_reference_golden(fn, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(16, 16), (22, 26), (9, 13), (64, 48)])
+@pytest.mark.parametrize("shape", [(16, 16), (22, 26), (9, 13), (64, 48), (8, 8), (8, 40), (36, 12), (28, 100), (11, 8)])
 def test_step_backward_random_vs_float64_autograd(shape, dev):
     """One step with random weights / state / upstream gradient, sparse frame mask included."""
     from oracle import restatement as R
