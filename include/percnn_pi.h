@@ -210,6 +210,7 @@ typedef struct percnn_pi_halo_ring {
     int (*recv)(void* buf, size_t count, int dtype, int peer, void* comm, void* stream);
 } percnn_pi_halo_ring;
 
+size_t percnn_pi_halo_ring_bytes(void);   /* sizeof(percnn_pi_halo_ring) of the library build: bindings check their layout */
 int percnn_pi_slab_rollout_fwd_f32(float* traj, const float* params, int hc, int ndim, const int64_t* shape, int halo,
                                    int T_steps, const percnn_pi_halo_ring* ring, int overlap, void* stream);
 int percnn_pi_slab_rollout_fwd_f64(double* traj, const double* params, int hc, int ndim, const int64_t* shape, int halo,

@@ -25,7 +25,7 @@ SOURCES = {
 
 EXPORTS = [
     "percnn_pi_abi_version", "percnn_pi_param_count", "percnn_pi_bwd_workspace_bytes",
-    "percnn_pi_rollout_bwd_workspace_bytes", "percnn_pi_set_option",
+    "percnn_pi_rollout_bwd_workspace_bytes", "percnn_pi_set_option", "percnn_pi_halo_ring_bytes",
 ] + [f"percnn_pi_{op}_{suf}" for suf in ("f32", "f64")
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
                 "slab_step_fwd_range", "slab_step_bwd_range", "slab_rollout_fwd", "slab_rollout_bwd", "residual_fwd",
@@ -88,6 +88,9 @@ def lib() -> ctypes.CDLL:
     L.percnn_pi_rollout_bwd_workspace_bytes.argtypes = [ci, ci, i64p, ci, ci]
     L.percnn_pi_set_option.restype = ci
     L.percnn_pi_set_option.argtypes = [ctypes.c_char_p, ctypes.c_long]
+    L.percnn_pi_halo_ring_bytes.restype, L.percnn_pi_halo_ring_bytes.argtypes = sz, []
+    if L.percnn_pi_halo_ring_bytes() != ctypes.sizeof(HaloRing):
+        raise RuntimeError("percnn_amd: percnn_pi_halo_ring layout differs between the python binding and libpercnn_pi.so")
     for suf in ("f32", "f64"):
         f = getattr(L, f"percnn_pi_step_fwd_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, vp, ci, ci, i64p, vp]

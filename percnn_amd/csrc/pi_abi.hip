@@ -964,6 +964,7 @@ int percnn_pi_debug_stamps(long long* host_out, int n)
 #endif
 
 int percnn_pi_abi_version(void) { return PERCNN_PI_ABI_VERSION; }
+size_t percnn_pi_halo_ring_bytes(void) { return sizeof(percnn_pi_halo_ring); }
 
 size_t percnn_pi_param_count(int hc) { return hc < -1 ? 0 : (size_t)pi::nparams(hc); }
 
