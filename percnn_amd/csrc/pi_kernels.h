@@ -307,8 +307,7 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
             } else {
                 lane_c[s] += acc_c;
             }
-#pragma unroll
-            for (int j = 0; j < hc; ++j) {
+            auto channel = [&](int j) {
                 const T* w = W + 10 * j;
                 const T w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6], w7 = w[7],
                         w8 = w[8], w9 = w[9];
@@ -340,6 +339,12 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
                         for (int m = 0; m < 10; ++m) myred[gbase + 10 * j + m] += acc[m];
                     }
                 }
+                        };
+            if constexpr (HC > 0) {                      // compile-time width: fully unrolled
+#pragma unroll
+                for (int j = 0; j < HC; ++j) channel(j);
+            } else {
+                for (int j = 0; j < hc; ++j) channel(j);
             }
         }
 
