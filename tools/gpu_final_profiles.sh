@@ -11,7 +11,7 @@ for wl in gs2d_512 gs3d_128 lo2d_512 gs2d_100 bur1_100 lo1_100; do
 done
 (timeout 900 python $R/bench.py --workload gs2d_512 --reaction factored --no-cpu-baseline 2>&1 | tail -1) > $R/gpurun_out/final_bench_gs2d_512_factored.json
 : > $R/gpurun_out/final_pmc_summary.txt
-for wl in gs2d_512 gs3d_128; do
+for wl in gs2d_512 gs3d_128 lo2d_512 gs2d_100; do
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcout
   timeout 900 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmcout -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --workload $wl --T 100 > /tmp/pmc.log 2>&1

@@ -3,7 +3,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 : > $GRAFT_REPO_ROOT/gpurun_out/pmc_summary.txt
-for wl in gs2d_512 gs3d_128; do
+for wl in gs2d_512 gs3d_128 lo2d_512 gs2d_100; do
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcout
   timeout 900 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmcout -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --workload $wl --T 100 > /tmp/pmc.log 2>&1
