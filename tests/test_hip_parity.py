@@ -870,3 +870,19 @@ def test_reference_style_training_loop_example(hip_device):
     losses = mod.main(["--iters", "12", "--size", "48", "--steps", "60"])
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
+
+def test_c_abi_from_a_plain_cpp_host(hip_device, tmp_path):
+    """examples/c_api_rollout.cpp links libpercnn_pi.so directly (no Python / PyTorch in the process), rolls out a
+    Gray-Scott block, and checks itself: forward bit-identical to a scalar host loop, dL/dh0 vs finite differences."""
+    import subprocess
+    import percnn_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_api_rollout")
+    csrc = os.path.dirname(percnn_amd.LIB_PATH)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off",
+                           "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_api_rollout.cpp"),
+                           "-L" + csrc, "-lpercnn_pi", "-Wl,-rpath," + csrc, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "c_api_rollout ok" in out.stdout
+
