@@ -886,3 +886,33 @@ def test_c_abi_from_a_plain_cpp_host(hip_device, tmp_path):
     assert out.returncode == 0, out.stderr
     assert "c_api_rollout ok" in out.stdout
 
+
+def test_rollouts_are_hipgraph_capturable(hip_device):
+    """include/percnn_pi.h promises no host synchronisation / allocation inside the entry points: capture a forward +
+    backward rollout (tile kernels, the per-step tail, the gradient reduction) in a HIP graph and replay it."""
+    import percnn_amd as pa
+    P = dev_t(random_block(0, 2, np.float32, 6, scale=0.3), hip_device)
+    T, shape = 10, (64, 96)
+    traj = torch.empty((T + 1, 2) + shape, device=hip_device)
+    h0 = torch.rand((2,) + shape, device=hip_device)
+    g = torch.randn_like(traj)
+    traj[0] = h0
+    pa.rollout_fwd_(traj, P)
+    ws = pa.functional.rollout_workspace(0, shape, T, torch.float32, hip_device)
+    g0_ref, pg_ref = pa.rollout_bwd(traj, g, P, ws=ws)
+    ref = traj.clone()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        with torch.cuda.graph(graph, stream=stream):
+            pa.rollout_fwd_(traj, P)
+            g0, pg = pa.rollout_bwd(traj, g, P, ws=ws)
+    traj[1:].zero_()
+    g0.zero_(); pg.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(traj, ref) and torch.equal(g0, g0_ref)
+    assert torch.allclose(pg, pg_ref, rtol=1e-12, atol=0)
+
