@@ -4,6 +4,12 @@ Only the hot path of isds-neu/PeRCNN lives here: the per-step fixed-stencil Lapl
 parallel 1x1-conv branches whose Hadamard product is the reaction term, the explicit Euler
 update, their adjoint, and the T-step rollout -- as hand-written HIP kernels behind a C-ABI
 (``include/percnn_pi.h``), with drop-in ``RCNNCell`` / ``RCNN`` modules on top.
+
+Layout:  ``csrc/`` HIP kernels + the C-ABI translation units (pi_abi.hip: base block, slabs, physics residual;
+pi_s1_abi.hip: Stage-1 block on the matrix cores; pi_up3d_abi.hip: 3D IC-generator contraction) ->
+``libpercnn_pi.so``;  ``_lib`` ctypes binding + build;  ``functional`` autograd front-end;  ``modules`` the reference's
+module interface;  ``stage1`` the Stage-1 cell;  ``slab`` multi-GPU slab decomposition;  ``physics`` physics-residual
+loss;  ``synthetic`` initial states for benchmarks / tests.
 """
 from ._lib import build, lib, set_option, LIB_PATH  # noqa: F401
 from .functional import (pi_step, pi_rollout, pack_params, contract_block, param_count, rollout_fwd_, rollout_bwd,  # noqa: F401
