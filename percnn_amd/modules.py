@@ -460,14 +460,15 @@ class RCNN(nn.Module):
         ``self.last_trajectory`` for validation-only consumers (the physics loss, train_2drd.py:405)."""
         if self.effective_step != list(range(self.step)):
             raise ValueError("observe() indexes the dense output list: effective_step must be list(range(step))")
-        if hasattr(self.cell, "rollout_frames"):
-            raise NotImplementedError("observe() is implemented for the base Pi-block cells")
         if hasattr(self, "UpconvBlock"):
             self.init_state = self.UpconvBlock(self.init_state_low)
         t_idx = list(range(self.step + 1))[t_slice]
         ndim = self.init_state.dim() - 2
-        pred, traj = F_pi.pi_rollout_observe(self.init_state, self.cell.param_block(), self.step, t_idx,
-                                             (space_stride,) * ndim)
+        if hasattr(self.cell, "rollout_observe"):           # cells with their own kernels (Stage-1 block)
+            pred, traj = self.cell.rollout_observe(self.init_state, self.step, t_idx, (space_stride,) * ndim)
+        else:
+            pred, traj = F_pi.pi_rollout_observe(self.init_state, self.cell.param_block(), self.step, t_idx,
+                                                 (space_stride,) * ndim)
         self.last_trajectory = traj
         return pred
 

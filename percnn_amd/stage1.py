@@ -175,6 +175,40 @@ class Stage1RolloutFramesFunction(torch.autograd.Function):
         return g_h0[None], pg.to(torch.float32), None, None
 
 
+class Stage1RolloutObserveFunction(torch.autograd.Function):
+    """Rollout + observation operator ``traj[t_idx][:, :, ::s, ::s]`` in one autograd node (the Stage-1 data loss looks
+    at 41 snapshots of every second grid point, bur1:600-612); see functional.PiRolloutObserveFunction."""
+
+    @staticmethod
+    def forward(ctx, h0, P, steps, t_idx, strides):
+        if h0.dim() != 4 or h0.shape[0] != 1 or h0.shape[1] != 2:
+            raise RuntimeError("percnn_amd.stage1: state must be [1,2,H,W] (batch 1, as everywhere in the reference)")
+        P = P.contiguous()
+        traj = torch.empty((steps + 1,) + tuple(h0.shape[1:]), dtype=torch.float32, device=h0.device)
+        traj[0].copy_(h0[0])
+        rollout_fwd_(traj, P)
+        ctx.save_for_backward(traj, P)
+        ctx.t_idx = tuple(int(t) % (steps + 1) for t in t_idx)
+        ctx.sub = (slice(None),) + tuple(slice(None, None, int(s)) for s in strides)
+        idx = torch.tensor(ctx.t_idx, dtype=torch.long, device=h0.device)
+        pred = traj.index_select(0, idx)[(slice(None),) + ctx.sub].contiguous()
+        ctx.mark_non_differentiable(traj)
+        return pred, traj
+
+    @staticmethod
+    def backward(ctx, g_pred, _unused):
+        traj, P = ctx.saved_tensors
+        g_traj = torch.empty_like(traj)                    # unobserved frames are masked out, never initialised
+        mask = [False] * traj.shape[0]
+        for i, t in enumerate(ctx.t_idx):
+            if not mask[t]:
+                g_traj[t].zero_()
+                mask[t] = True
+            g_traj[t][ctx.sub] += g_pred[i]
+        g_h0, pg = rollout_bwd(traj, g_traj, P, frame_mask=mask)
+        return g_h0[None], pg.to(torch.float32), None, None, None
+
+
 class Upscaler(nn.Module):
     """IC generator of the Stage-1 scripts (bur1:38-52, lo1:38-51): ConvTranspose2d(2 -> 16, 5, stride 2) - tanh -
     Conv2d(16 -> 2, 1); stock torch.nn, off the hot path.  Registers ``up0`` / ``out`` AND ``convnet`` like the
@@ -240,6 +274,10 @@ class Stage1Cell(nn.Module):
 
     def rollout(self, h0: torch.Tensor, steps: int) -> torch.Tensor:
         return stage1_rollout(h0, self.param_block(), steps)
+
+    def rollout_observe(self, h0: torch.Tensor, steps: int, t_idx: Sequence[int], strides: Sequence[int]):
+        """hook used by ``percnn_amd.RCNN.observe``: -> (observed sub-tensor, detached full trajectory)"""
+        return Stage1RolloutObserveFunction.apply(h0, self.param_block(), int(steps), tuple(t_idx), tuple(strides))
 
     def rollout_frames(self, h0: torch.Tensor, steps: int, frames: Sequence[int]):
         """hook used by ``percnn_amd.RCNN``: the requested frames as outputs of one autograd node"""

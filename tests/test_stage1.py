@@ -255,4 +255,14 @@ def test_rcnn_wrapper_drives_the_stage1_cell(dev):
         assert (a is None) == (b is None)
         if a is not None:
             assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+    # observation operator (the data loss's operand) from one autograd node == cat + slice
+    ref = torch.cat(tuple(m()[0]), 0)[0:-1:2][:, :, ::2, ::2]
+    pred = m.observe(slice(0, -1, 2), 2)
+    assert torch.equal(pred, ref)
+    truth = torch.rand_like(ref)
+    g3 = torch.autograd.grad(torch.nn.functional.mse_loss(pred, truth), params, allow_unused=True)
+    g4 = torch.autograd.grad(torch.nn.functional.mse_loss(ref, truth), params, allow_unused=True)
+    for a, b in zip(g3, g4):
+        if a is not None:
+            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
 
