@@ -177,7 +177,7 @@ class Stage1RolloutFramesFunction(torch.autograd.Function):
 
 class Stage1RolloutObserveFunction(torch.autograd.Function):
     """Rollout + observation operator ``traj[t_idx][:, :, ::s, ::s]`` in one autograd node (the Stage-1 data loss looks
-    at 41 snapshots of every second grid point, bur1:600-612); see functional.PiRolloutObserveFunction."""
+    at every 5th snapshot and every second grid point, bur1:610); see functional.PiRolloutObserveFunction."""
 
     @staticmethod
     def forward(ctx, h0, P, steps, t_idx, strides):
