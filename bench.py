@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="library tuning option key=value (repeatable)")
     ap.add_argument("--slab-extra", action="store_true", help="also time the slab-sharded 3D path at N=1")
     ap.add_argument("--slab-timeout", type=float, default=240.0)
+    ap.add_argument("--slab-child", action="store_true", help=argparse.SUPPRESS)   # see slab_extra_isolated
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -134,6 +135,16 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import percnn_amd as pa
+    if a.slab_child:
+        try:
+            res = slab_extra(dev, dist, rank, world)
+        except Exception as e:
+            res = {"error": repr(e)[:300]}
+        if dist is not None:
+            dist.destroy_process_group()
+        flush_c_stdio()
+        print(json.dumps(res), flush=True)
+        return
     if a.workload in STAGE1:
         return stage1_main(a, pa, dev, dist, rank, world)
     for kv in a.opt:
@@ -280,15 +291,18 @@ def main():
 
     if world > 1 or a.slab_extra:
         def watchdog():
-            if not printed.wait(a.slab_timeout):
-                out["slab_3d"] = {"error": f"timed out after {a.slab_timeout}s"}
+            if not printed.wait(a.slab_timeout + 60.0):
+                out["slab_3d"] = {"error": f"timed out after {a.slab_timeout + 60.0}s"}
                 emit()
                 os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             del traj, gtraj
             torch.cuda.empty_cache()
-            out["slab_3d"] = slab_extra(dev, dist, rank, world)
+            if dist is not None:                     # own process per rank: a fault in there cannot cost the line above
+                out["slab_3d"] = slab_extra_isolated(a, dev, dist, rank, world, local_rank)
+            else:
+                out["slab_3d"] = slab_extra(dev, dist, rank, world)
         except Exception as e:                       # keep the headline number whatever happens here
             out["slab_3d"] = {"error": repr(e)[:300]}
     if dist is not None:
@@ -464,6 +478,37 @@ def physics_extra(pa, cell, family, traj, esz, npts):
     return {"frames": F, "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_GBps": b / tf / 1e9, "bwd_GBps": b / tb / 1e9,
             "fwd_frac_of_8TBps": b / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac_of_8TBps": b / tb / 1e9 / HBM_PEAK_GBS,
             "loss_value": float(physics.physics_loss(sub, Q))}
+
+
+def slab_extra_isolated(a, dev, dist, rank, world, local_rank):
+    """Run slab_extra in a child process per rank (its own process group on a fresh port): the halo ring hands RCCL
+    function addresses to the native loop, and a crash or stall in there must not take the headline line with it."""
+    import socket
+    import subprocess
+    port = torch.zeros(1, dtype=torch.int64, device=dev)
+    if rank == 0:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port[0] = so.getsockname()[1]
+    if world > 1:
+        dist.broadcast(port, 0)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(port.item())), RANK=str(rank),
+               WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank))
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RESTART_COUNT",
+              "TORCHELASTIC_MAX_RESTARTS", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME"):
+        env.pop(k, None)                             # plain env:// rendezvous on the new port
+    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--slab-child", "--gpus", str(a.gpus)], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        so, se = child.communicate(timeout=a.slab_timeout)
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        return {"error": f"child timed out after {a.slab_timeout}s"}
+    lines = [l for l in so.splitlines() if l.startswith("{")]
+    if child.returncode != 0 or not lines:
+        return {"error": f"child exit code {child.returncode}", "stderr_tail": se[-300:]}
+    return json.loads(lines[-1])
 
 
 def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=5):
