@@ -450,7 +450,7 @@ hipError_t launch_fwd_tile(T* frame_t, const T* P, const Problem& p, hipStream_t
     using TL = pi::Tile<K, TILE_B, BY>;
     const pi::TileGeom g = make_tile_geom(p, BY);
     const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
-    const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + (size_t)g_opt.lds_pad;
+    const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + 32 /* lds_pad0/1 */ + (size_t)g_opt.lds_pad;
     auto* k = pi::pi_fwd2d_tile_kernel<T, HC, K, TILE_B, BY, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, frame_t, (long)(2 * p.n), P, g);
@@ -464,7 +464,7 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
     using TL = pi::Tile<K, TILE_B, BY>;
     const pi::TileGeom g = make_tile_geom(p, BY);
     const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
-    const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + (size_t)g_opt.lds_pad;
+    const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + 32 /* lds_pad0/1 */ + (size_t)g_opt.lds_pad;
     auto* k = pi::pi_adj2d_tile_kernel<T, HC, K, TILE_B, BY, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, hframe_t, gframe_t, aframe_t, (long)(2 * p.n), inj_mask, g_h0,

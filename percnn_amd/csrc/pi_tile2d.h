@@ -35,6 +35,7 @@ template <int K, int BX, int BY>
 struct Tile {
     static constexpr int LX = BX + 4 * K, LY = BY + 4 * K;
     static constexpr int PLANE = LX * LY;
+    static_assert(LX % 4 == 0 && PLANE % 4 == 0, "quad-aligned rows");
     static constexpr int region_w(int m) { return LX - 4 * (m + 1); }
     static constexpr int region_h(int m) { return LY - 4 * (m + 1); }
     static constexpr int region_n(int m) { return region_w(m) * region_h(m); }
@@ -60,6 +61,16 @@ __device__ __forceinline__ int tile_of_block(int b, const TileGeom& g)
 
 // window coordinates lie in [-2K, n + BX + 2K): one conditional add / subtract suffices for n >= BX + 2K (checked by the host)
 __device__ __forceinline__ int wrap1(int g, int n) { return g < 0 ? g + n : (g >= n ? g - n : g); }
+
+// LDS read width (fp32): a strip starts at window column 4*rc + 2*(M+1), and lanes 16 B apart that read 8 B each touch
+// only half of the banks per pass.  Even sub-steps read buffer 0 at columns = 2 (mod 4), odd sub-steps read buffer 1 at
+// columns = 0 (mod 4), so buffer 0 is shifted by two floats: every strip origin is then 16-byte aligned in the buffer
+// it is READ from and the stencil rows come in as 16-byte reads (5 x b128 + 2 x b64 instead of 12 x b64 per species and
+// strip).  Measured at 512^2: forward 8.54 -> 8.22, sweep 12.51 -> 12.20 us per K=4 launch, SQ_LDS_IDX_ACTIVE -6.5 %.
+// (The LDS is not what bounds these kernels: a what-if build that dropped the four neighbour-row reads altogether --
+// two thirds of the stencil's LDS bytes -- only gained another 0.6 / 0.8 us.)
+template <typename T> struct lds_pad0 { static constexpr int value = sizeof(T) == 4 ? 2 : 0; };
+template <typename T> struct lds_pad1 { static constexpr int value = sizeof(T) == 4 ? 4 : 0; };   // keeps buffer 1 16-B aligned
 
 // stage the (LY x LX) periodic window of both species of `src` into buf[2][LY][LX].
 // issue() puts all global loads in flight, commit() writes them to LDS: a load -> wait -> write loop costs one full
@@ -91,11 +102,18 @@ struct WindowLoader {
             }
         }
     }
-    __device__ __forceinline__ void commit(T* buf) const
+    __device__ __forceinline__ void commit(T* buf) const    // buf = buffer 0 (8-byte aligned only when padded)
     {
 #pragma unroll
         for (int q = 0; q < TRIPS; ++q)
-            if (dst[q] >= 0) st<T, VEC>(buf + dst[q], p[q]);
+            if (dst[q] >= 0) {
+                if constexpr (lds_pad0<T>::value != 0) {
+                    st<T, 2>(buf + dst[q], Pack<T, 2>{{p[q].v[0], p[q].v[1]}});
+                    st<T, 2>(buf + dst[q] + 2, Pack<T, 2>{{p[q].v[2], p[q].v[3]}});
+                } else {
+                    st<T, VEC>(buf + dst[q], p[q]);
+                }
+            }
     }
 };
 
@@ -108,7 +126,7 @@ __device__ __forceinline__ void tile_load(const T* __restrict__ src, const TileG
 }
 
 // write the BX x BY centre of buf to frame `dst`
-template <typename T, int K, int BX, int BY, int NT>
+template <typename T, int K, int BX, int BY, int NT, bool PADDED = false>
 __device__ __forceinline__ void tile_store(const T* buf, T* __restrict__ dst, const TileGeom& g, int ty0, int tx0)
 {
     using TL = Tile<K, BX, BY>;
@@ -120,7 +138,14 @@ __device__ __forceinline__ void tile_store(const T* buf, T* __restrict__ dst, co
         const int r = i - s * (BY * BXV);
         const int y = r / BXV, c = r - y * BXV;
         if (ty0 + y >= g.H || tx0 + c * VEC >= g.W) continue;          // partial edge tile of a ragged grid
-        const Pack<T, VEC> p = ld<T, VEC>(buf + s * TL::PLANE + (2 * K + y) * TL::LX + 2 * K + c * VEC);
+        const T* src = buf + s * TL::PLANE + (2 * K + y) * TL::LX + 2 * K + c * VEC;
+        Pack<T, VEC> p;
+        if constexpr (PADDED && lds_pad0<T>::value != 0) {
+            const Pack<T, 2> a = ld<T, 2>(src), b = ld<T, 2>(src + 2);
+            p.v[0] = a.v[0]; p.v[1] = a.v[1]; p.v[2] = b.v[0]; p.v[3] = b.v[1];
+        } else {
+            p = ld<T, VEC>(src);
+        }
         st<T, VEC>(dst + s * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC, p);
     }
 }
@@ -131,23 +156,39 @@ __device__ __forceinline__ void tile_store(const T* buf, T* __restrict__ dst, co
 template <typename T, int LX, int FLIP>
 __device__ __forceinline__ void lds_star4(const T* pl, int ly, int lx, const T* __restrict__ P, T (&ctr)[4], T (&lap)[4])
 {
-    const T* c = pl + ly * LX + lx;
+    const T* c = pl + ly * LX + lx;                       // fp32: 16-byte aligned (lds_pad0)
     T win[8];                                             // x = lx-2 .. lx+5 of the centre row
+    if constexpr (sizeof(T) == 4) {
+        const Pack<T, 2> l = ld<T, 2>(c - 2), r = ld<T, 2>(c + 4);
+        const Pack<T, 4> m = ld<T, 4>(c);
+        win[0] = l.v[0]; win[1] = l.v[1]; win[6] = r.v[0]; win[7] = r.v[1];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const Pack<T, 2> p = ld<T, 2>(c - 2 + 2 * j);
-        win[2 * j] = p.v[0];
-        win[2 * j + 1] = p.v[1];
+        for (int i = 0; i < 4; ++i) win[2 + i] = m.v[i];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const Pack<T, 2> p = ld<T, 2>(c - 2 + 2 * j);
+            win[2 * j] = p.v[0];
+            win[2 * j + 1] = p.v[1];
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ctr[i] = win[2 + i]; lap[i] = P[P_C0] * win[2 + i]; }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int k = FLIP * (t < 2 ? t - 2 : t - 1);
-        const Pack<T, 2> a = ld<T, 2>(c + k * LX), b = ld<T, 2>(c + k * LX + 2);
+        T n[4];
+        if constexpr (sizeof(T) == 4) {
+            const Pack<T, 4> a = ld<T, 4>(c + k * LX);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) n[i] = a.v[i];
+        } else {
+            const Pack<T, 2> a = ld<T, 2>(c + k * LX), b = ld<T, 2>(c + k * LX + 2);
+            n[0] = a.v[0]; n[1] = a.v[1]; n[2] = b.v[0]; n[3] = b.v[1];
+        }
         const T w = P[P_TAPS + t];
-        lap[0] = fma_(w, a.v[0], lap[0]); lap[1] = fma_(w, a.v[1], lap[1]);
-        lap[2] = fma_(w, b.v[0], lap[2]); lap[3] = fma_(w, b.v[1], lap[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lap[i] = fma_(w, n[i], lap[i]);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -188,17 +229,30 @@ template <typename T> __device__ __forceinline__ V2<T> win_pair(const V2<T> (&W)
 template <typename T, int LX, int FLIP>
 __device__ __forceinline__ void lds_star4v(const T* pl, int ly, int lx, const T* __restrict__ P, V2<T> (&ctr)[2], V2<T> (&lap)[2])
 {
-    const T* c = pl + ly * LX + lx;
+    const T* c = pl + ly * LX + lx;                       // fp32: 16-byte aligned (lds_pad0)
     V2<T> W[4];
+    if constexpr (sizeof(T) == 4) {
+        W[0] = ldv2(c - 2);
+        const Pack<T, 4> m = ld<T, 4>(c);
+        W[1] = V2<T>{m.v[0], m.v[1]}; W[2] = V2<T>{m.v[2], m.v[3]};
+        W[3] = ldv2(c + 4);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) W[j] = ldv2(c - 2 + 2 * j);
+        for (int j = 0; j < 4; ++j) W[j] = ldv2(c - 2 + 2 * j);
+    }
     ctr[0] = W[1]; ctr[1] = W[2];
     const V2<T> c0 = vs(P[P_C0]);
     lap[0] = c0 * ctr[0]; lap[1] = c0 * ctr[1];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int k = FLIP * (t < 2 ? t - 2 : t - 1);
-        const V2<T> a = ldv2(c + k * LX), b = ldv2(c + k * LX + 2);
+        V2<T> a, b;
+        if constexpr (sizeof(T) == 4) {
+            const Pack<T, 4> n = ld<T, 4>(c + k * LX);
+            a = V2<T>{n.v[0], n.v[1]}; b = V2<T>{n.v[2], n.v[3]};
+        } else {
+            a = ldv2(c + k * LX); b = ldv2(c + k * LX + 2);
+        }
         const V2<T> w = vs(P[P_TAPS + t]);
         lap[0] = vfma(w, a, lap[0]);
         lap[1] = vfma(w, b, lap[1]);
@@ -301,7 +355,7 @@ __device__ __forceinline__ void fwd_substeps(T* b0, T* b1, T* __restrict__ frame
     fwd_substep<T, HC, K, BX, BY, NT, M>(cur, nxt, P);
     PI_STAMP(2 + 2 * M);
     lds_barrier();                                         // do not drain the previous frame's global stores
-    tile_store<T, K, BX, BY, NT>(nxt, frames + (long)(M + 1) * frame_stride, g, ty0, tx0);
+    tile_store<T, K, BX, BY, NT, (M & 1) != 0>(nxt, frames + (long)(M + 1) * frame_stride, g, ty0, tx0);
     PI_STAMP(3 + 2 * M);
     if constexpr (M + 1 < K) fwd_substeps<T, HC, K, BX, BY, NT, M + 1>(b0, b1, frames, frame_stride, g, ty0, tx0, P);
 }
@@ -313,8 +367,8 @@ pi_fwd2d_tile_kernel(T* __restrict__ frames /* frame t; t+1..t+K are written */,
 {
     using TL = Tile<K, BX, BY>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* b0 = reinterpret_cast<T*>(smem_raw);
-    T* b1 = b0 + 2 * TL::PLANE;
+    T* b0 = reinterpret_cast<T*>(smem_raw) + lds_pad0<T>::value;
+    T* b1 = reinterpret_cast<T*>(smem_raw) + 2 * TL::PLANE + lds_pad1<T>::value;
     const int tile = tile_of_block(blockIdx.x, g);
     const int ty0 = (tile / g.tiles_x) * BY, tx0 = (tile % g.tiles_x) * BX;
     PI_STAMP(0);
@@ -489,7 +543,7 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
     PI_STAMP(3 + 3 * M);
     // the adjoint of frame 0 is the caller's dL/dh0 output
     T* dst = (M + 1 == steps_to_zero && g_h0) ? g_h0 : abase + fo;
-    tile_store<T, K, BX, BY, NT>(nxt, dst, g, ty0, tx0);
+    tile_store<T, K, BX, BY, NT, (M & 1) != 0>(nxt, dst, g, ty0, tx0);
     PI_STAMP(4 + 3 * M);
     if constexpr (M + 1 < K)
         adj_substeps<T, HC, K, BX, BY, NT, M + 1, PRE>(b0, b1, hbase, gbase, abase, frame_stride, inj_mask, g_h0,
@@ -507,8 +561,8 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
     // measured slower (17.6 vs 15.5 us per K=4 launch: 64 extra VGPRs, requests queued ahead of the window load).
     constexpr bool PRE = PI_TILE_ADJ_PIPE && TL::region_n(0) / 4 <= NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* b0 = reinterpret_cast<T*>(smem_raw);
-    T* b1 = b0 + 2 * TL::PLANE;
+    T* b0 = reinterpret_cast<T*>(smem_raw) + lds_pad0<T>::value;
+    T* b1 = reinterpret_cast<T*>(smem_raw) + 2 * TL::PLANE + lds_pad1<T>::value;
     const int tile = tile_of_block(blockIdx.x, g);
     const int ty0 = (tile / g.tiles_x) * BY, tx0 = (tile % g.tiles_x) * BX;
     PI_STAMP(0);
@@ -531,7 +585,7 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
     // diffusion-coefficient gradients of this tile over the K sub-steps: one reduction per launch
     // (LDS-only barriers: the last frame's global stores need not drain first)
     lds_barrier();
-    double* red = reinterpret_cast<double*>(b0);           // state buffers are dead now
+    double* red = reinterpret_cast<double*>(smem_raw);     // state buffers are dead now
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
