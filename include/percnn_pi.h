@@ -96,6 +96,7 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *   "fuse_wgrad"   parameter gradients reduced inside the sweep launches instead of one time-parallel pass:
  *                  0 never, 1 wherever a fused flavour exists, 2 (default) float32 pre-contracted blocks on the direct
  *                  / plane-streaming kernels
+ *   "bwd_cpl"      direct adjoint kernel: 16-byte chunks per lane (1..16, default 2) once >= 512 workgroups remain
  *   "overlap", "overlap_chunk"  run the time-parallel gradient pass of finished chunks on a side stream under the sweep
  *   "skip_wgrad"   diagnostics: adjoint sweep only, parameter gradients of the branches come back as zeros
  *   "lds_pad"      diagnostics: extra dynamic LDS per workgroup (limits workgroups per CU)

@@ -211,6 +211,16 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
     const long iters = (nchunks + stride - 1) / stride;
 
     double lane_c[2] = {0.0, 0.0};
+    // poly mode with fused gradients: the 20 coefficient moments stay in registers over all chunks of the lane and are
+    // reduced across lanes once per launch (was: 22 wave reductions per chunk)
+    constexpr bool LANE_MOM = WGRAD && HC == POLY;
+    T macc[LANE_MOM ? 2 : 1][LANE_MOM ? 10 : 1];
+    if constexpr (LANE_MOM) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int m = 0; m < 10; ++m) macc[s][m] = T(0);
+    }
 
     for (long it = 0; it < iters; ++it) {
         const long cid_raw = first + it * stride;
@@ -245,10 +255,8 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
                 const T* c = P + P_W + 10 * s;
                 const int gbase = P_W + 10 * s;
                 const Pack<T, VEC>& hs = s == 0 ? u : v;
+                (void)gbase;
                 double acc_c = 0.0;                      // heavily cancelling sum (stencil row-sum ~ 0): keep it in fp64
-                T acc[10];
-#pragma unroll
-                for (int m = 0; m < 10; ++m) acc[m] = T(0);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     const T gr = gc[s].v[i] * dt;
@@ -258,6 +266,7 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
                     du[i] = fma_(gr, ru, du[i]);
                     dv[i] = fma_(gr, rv, dv[i]);
                     if constexpr (WGRAD) {
+                        T (&acc)[10] = macc[s];
                         const T uu = u.v[i], vv = v.v[i];
                         const T u2 = uu * uu, uv = uu * vv, v2 = vv * vv;
                         acc[0] += gr;
@@ -267,20 +276,7 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
                         acc[8] = fma_(gr, uu * v2, acc[8]); acc[9] = fma_(gr, v2 * vv, acc[9]);
                     }
                 }
-                if constexpr (WGRAD) {
-                    acc_c = wave_sum_to_last(acc_c);
-                    if (lane == REDUCE_LANE) redc[wave * 2 + s] += acc_c;
-                } else {
-                    lane_c[s] += acc_c;                  // sweep flavour: one cross-lane reduction per launch, not per chunk
-                }
-                if constexpr (WGRAD) {
-#pragma unroll
-                    for (int m = 0; m < 10; ++m) acc[m] = wave_sum_to_last(acc[m]);
-                    if (lane == REDUCE_LANE) {
-#pragma unroll
-                        for (int m = 0; m < 10; ++m) myred[gbase + m] += acc[m];
-                    }
-                }
+                lane_c[s] += acc_c;                      // one cross-lane reduction per launch, not per chunk
             }
         } else {
 #pragma unroll
@@ -369,12 +365,21 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
         }
     }
 
-    if constexpr (!WGRAD) {
+    if constexpr (!WGRAD || LANE_MOM) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const double r = wave_sum_to_last(lane_c[s]);
             if (lane == REDUCE_LANE) redc[wave * 2 + s] += r;
         }
+    }
+    if constexpr (LANE_MOM) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int m = 0; m < 10; ++m) {
+                const T r = wave_sum_to_last(macc[s][m]);
+                if (lane == REDUCE_LANE) myred[P_W + 10 * s + m] += r;
+            }
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < np; idx += blockDim.x) {
