@@ -39,6 +39,8 @@ def test_library_exports_every_declared_symbol():
     assert percnn_amd.lib().percnn_pi_bwd_workspace_bytes(8, 2, shape, 4) > 2 * 2 * 512 * 512 * 4
     assert percnn_amd.lib().percnn_pi_bwd_workspace_bytes(8, 4, shape, 4) == 0       # bad ndim
     assert percnn_amd.lib().percnn_pi_set_option(b"nonsense", 1) == -1
+    assert percnn_amd.lib().percnn_pi_set_option(b"bwd_cpl", 0) == -1
+    assert percnn_amd.lib().percnn_pi_set_option(b"bwd_cpl", 2) == 0
 
 
 def test_argument_errors_do_not_need_a_gpu():
