@@ -276,6 +276,10 @@ def main():
             out["physics_residual"] = physics_extra(pa, cell, family, traj, esz, npts)
         except Exception as e:                       # an add-on measurement must never cost the headline line
             out["physics_residual"] = {"error": repr(e)[:200]}
+        try:
+            out["strided_data_loss"] = strided_loss_extra(pa, traj, gtraj, P, T, fwd_ms, a.steps)
+        except Exception as e:
+            out["strided_data_loss"] = {"error": repr(e)[:200]}
 
     # N > 1: additionally time the spatially sharded path (slab decomposition + RCCL halo exchange over
     # xGMI) on the configs[4]-shaped problem, weak-scaled: 32 planes of 256^2 per rank (256^3 at N = 8).
@@ -478,6 +482,26 @@ def physics_extra(pa, cell, family, traj, esz, npts):
     return {"frames": F, "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_GBps": b / tf / 1e9, "bwd_GBps": b / tb / 1e9,
             "fwd_frac_of_8TBps": b / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac_of_8TBps": b / tb / 1e9 / HBM_PEAK_GBS,
             "loss_value": float(physics.physics_loss(sub, Q))}
+
+
+def strided_loss_extra(pa, traj, gtraj, P, T, fwd_ms, reps):
+    """SURVEY 8d config (2), second loss: the reference's data loss only looks at every 20th frame
+    (output[0:-1:20, ...], train_2drd.py:397), so dL/dtraj is non-zero on those frames only; the backward is told so
+    (frame mask) and never reads the other frames of dL/dtraj (24 instead of 32 B per point and step)."""
+    mask = [False] * (T + 1)
+    for t in list(range(T + 1))[0:-1:20]:
+        mask[t] = True
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    pa.rollout_bwd(traj, gtraj, P, frame_mask=mask)
+    e0.record()
+    for _ in range(reps):
+        g0, pg = pa.rollout_bwd(traj, gtraj, P, frame_mask=mask)
+    e1.record()
+    torch.cuda.synchronize()
+    bwd_ms = e0.elapsed_time(e1) / reps
+    assert torch.isfinite(g0).all() and torch.isfinite(pg).all()
+    return {"observed_frames": sum(mask), "bwd_us_per_time_step": bwd_ms * 1e3 / T,
+            "fwd_bwd_steps_per_sec": T / ((fwd_ms + bwd_ms) * 1e-3)}
 
 
 def slab_extra_isolated(a, dev, dist, rank, world, local_rank):
