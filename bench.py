@@ -106,6 +106,24 @@ def cpu_baseline(family, sd, shape, budget_s=15.0):
                       f"torch {torch.__version__} CPU ({torch.get_num_threads()} threads), loss=mean(traj^2)"}
 
 
+def ensure_library(local_rank):
+    """The built libpercnn_pi.so normally travels with the tree.  A source-only tree is compiled once per node (local
+    rank 0, hipcc, ~80 s) while the other ranks wait for the file; the package itself never builds or falls back."""
+    from percnn_amd import _lib
+    if os.path.exists(_lib.LIB_PATH):
+        return
+    if local_rank == 0:
+        tmp = _lib.LIB_PATH + ".building"
+        _lib.build(out=tmp)
+        os.replace(tmp, _lib.LIB_PATH)                  # atomic: waiters never load a half-written file
+        return
+    deadline = time.time() + 600
+    while not os.path.exists(_lib.LIB_PATH):
+        if time.time() > deadline:
+            raise SystemExit("bench.py: timed out waiting for local rank 0 to build libpercnn_pi.so")
+        time.sleep(1.0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +152,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    ensure_library(local_rank)
     import percnn_amd as pa
     if a.slab_child:
         try:

@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A source-only tree (no in-tree libpercnn_pi.so yet) is compiled once before the first test; the package itself
+    never builds on import and never falls back."""
+    from percnn_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH) and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        _lib.build()
+
+
 @pytest.fixture(scope="session")
 def hip_device():
     import torch
