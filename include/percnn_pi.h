@@ -73,6 +73,15 @@ int percnn_pi_abi_version(void);
  * 16 + 2*(10*hc+1).  Mirrors the parameter census of RCNNCell.__init__ (2dgs:46-90). */
 size_t percnn_pi_param_count(int hc);
 
+/* Factored block (hc >= 1) -> pre-contracted polynomial block (36 entries, "hc = 0"): the cubic the three 1x1 branches
+ * and the 1x1 aggregation of 2dgs:115-116 multiply out to (the expansion 3dgs:442-468 prints), float64 arithmetic rounded
+ * once; header entries [0,16) are copied.  _bwd is its exact chain rule: g_poly = dL/d(poly block) (36 entries) ->
+ * g_params = dL/d(factored block) (percnn_pi_param_count(hc) entries, overwritten).  One single-workgroup launch each. */
+int percnn_pi_contract_fwd_f32(const float *params, int hc, float *poly, void *stream);
+int percnn_pi_contract_fwd_f64(const double *params, int hc, double *poly, void *stream);
+int percnn_pi_contract_bwd_f32(const float *params, int hc, const float *g_poly, float *g_params, void *stream);
+int percnn_pi_contract_bwd_f64(const double *params, int hc, const double *g_poly, double *g_params, void *stream);
+
 /* Bytes of scratch the backward entry points need for a grid of this shape
  * (two adjoint ping-pong states + per-workgroup gradient partials). elem_size = 4 or 8. */
 size_t percnn_pi_bwd_workspace_bytes(int hc, int ndim, const int64_t *shape, int elem_size);

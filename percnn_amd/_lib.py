@@ -18,7 +18,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 _INC = os.path.join("..", "..", "include")
 # translation unit -> headers it depends on (all under csrc/ unless a path is given)
 SOURCES = {
-    "pi_abi.hip": ["pi_kernels.h", "pi_tile2d.h", "pi_stream3d.h", "pi_adv.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h")],
+    "pi_abi.hip": ["pi_kernels.h", "pi_tile2d.h", "pi_stream3d.h", "pi_adv.h", "pi_contract.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h")],
     "pi_s1_abi.hip": ["pi_s1.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h"), os.path.join(_INC, "percnn_pi_stage1.h")],
     "pi_up3d_abi.hip": ["pi_up3d.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h")],
 }
@@ -29,7 +29,7 @@ EXPORTS = [
 ] + [f"percnn_pi_{op}_{suf}" for suf in ("f32", "f64")
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
                 "slab_step_fwd_range", "slab_step_bwd_range", "slab_rollout_fwd", "slab_rollout_bwd", "residual_fwd",
-                "residual_bwd")] + [
+                "residual_bwd", "contract_fwd", "contract_bwd")] + [
     "percnn_pi_s1_param_count", "percnn_pi_s1_step_fwd_f32", "percnn_pi_s1_rollout_fwd_f32",
     "percnn_pi_s1_rollout_bwd_workspace_bytes", "percnn_pi_s1_rollout_bwd_f32", "percnn_pi_s1_set_option",
     "percnn_pi_conv3d_k5c8_f32", "percnn_pi_conv3d_k5c8_wgrad_workspace_bytes", "percnn_pi_conv3d_k5c8_wgrad_f32",
@@ -92,6 +92,10 @@ def lib() -> ctypes.CDLL:
     if L.percnn_pi_halo_ring_bytes() != ctypes.sizeof(HaloRing):
         raise RuntimeError("percnn_amd: percnn_pi_halo_ring layout differs between the python binding and libpercnn_pi.so")
     for suf in ("f32", "f64"):
+        f = getattr(L, f"percnn_pi_contract_fwd_{suf}")
+        f.restype, f.argtypes = ci, [vp, ci, vp, vp]
+        f = getattr(L, f"percnn_pi_contract_bwd_{suf}")
+        f.restype, f.argtypes = ci, [vp, ci, vp, vp, vp]
         f = getattr(L, f"percnn_pi_step_fwd_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, vp, ci, ci, i64p, vp]
         f = getattr(L, f"percnn_pi_step_bwd_{suf}")

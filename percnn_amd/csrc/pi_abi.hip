@@ -10,6 +10,7 @@
 #include "pi_kernels.h"
 #include "pi_tile2d.h"
 #include "pi_stream3d.h"
+#include "pi_contract.h"
 #include "pi_adv.h"
 
 namespace {
@@ -970,6 +971,25 @@ int percnn_pi_abi_version(void) { return PERCNN_PI_ABI_VERSION; }
 size_t percnn_pi_halo_ring_bytes(void) { return sizeof(percnn_pi_halo_ring); }
 
 size_t percnn_pi_param_count(int hc) { return hc < -1 ? 0 : (size_t)pi::nparams(hc); }
+
+#define PI_CONTRACT(SUF, T)                                                                                             \
+    int percnn_pi_contract_fwd_##SUF(const T* params, int hc, T* poly, void* stream)                                   \
+    {                                                                                                                   \
+        if (!params || !poly || hc < 1) return PERCNN_PI_EINVAL;                                                        \
+        hipLaunchKernelGGL((pi::pi_contract_fwd_kernel<T>), dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),    \
+                           params, hc, poly);                                                                           \
+        return (int)hipGetLastError();                                                                                  \
+    }                                                                                                                   \
+    int percnn_pi_contract_bwd_##SUF(const T* params, int hc, const T* g_poly, T* g_params, void* stream)              \
+    {                                                                                                                   \
+        if (!params || !g_poly || !g_params || hc < 1) return PERCNN_PI_EINVAL;                                         \
+        hipLaunchKernelGGL((pi::pi_contract_bwd_kernel<T>), dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),   \
+                           params, hc, g_poly, g_params);                                                               \
+        return (int)hipGetLastError();                                                                                  \
+    }
+PI_CONTRACT(f32, float)
+PI_CONTRACT(f64, double)
+#undef PI_CONTRACT
 
 size_t percnn_pi_bwd_workspace_bytes(int hc, int ndim, const int64_t* shape, int elem_size)
 {

@@ -135,6 +135,14 @@ class _ContractFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, P):
+        if P.is_cuda:                                      # one launch (csrc/pi_contract.h) instead of ~25
+            P = P.contiguous()
+            Q = torch.empty(NPOLY, dtype=P.dtype, device=P.device)
+            f = getattr(_lib.lib(), "percnn_pi_contract_fwd_" + _SUF[P.dtype])
+            with torch.cuda.device(P.device):
+                _lib.check(f(P.data_ptr(), _hc_of(P), Q.data_ptr(), _stream()), "contract_fwd")
+            ctx.save_for_backward(P)
+            return Q
         K, _e0 = _contraction_tensor(P.device)
         hc, B, L1, L2, L3, w4, T12, T = _ContractFunction._factors(P)
         S = (T * w4[:, :, None, None, None]).sum(1).reshape(2, 27)        # sum over the hidden channels
@@ -146,6 +154,13 @@ class _ContractFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (P,) = ctx.saved_tensors
+        if P.is_cuda:
+            g = g.contiguous()
+            gP = torch.empty_like(P)
+            f = getattr(_lib.lib(), "percnn_pi_contract_bwd_" + _SUF[P.dtype])
+            with torch.cuda.device(P.device):
+                _lib.check(f(P.data_ptr(), _hc_of(P), g.data_ptr(), gP.data_ptr(), _stream()), "contract_bwd")
+            return gP
         K, _e0 = _contraction_tensor(P.device)
         hc, B, L1, L2, L3, w4, T12, T = _ContractFunction._factors(P)
         gc = g[16:].to(torch.float64).reshape(2, 10)

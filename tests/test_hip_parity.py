@@ -888,6 +888,32 @@ def test_direct_adjoint_kernel_chunks_per_lane(shape, hip_device):
         pa.set_option("stream3d", 1)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("hc", [1, 2, 8, 16])
+def test_contraction_kernel_equals_host_expansion(hc, dtype, hip_device):
+    """percnn_pi_contract_fwd/bwd (one launch each) against the tensor-op expansion the CPU path of contract_block uses
+    (itself checked against the oracle's triple loop in test_host_logic): coefficients to 2 ulp of the compute type,
+    chain rule to float64 round-off."""
+    import percnn_amd as pa
+    from percnn_amd import functional as F_pi
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    eps = np.finfo(dtype).eps
+    P = torch.tensor(random_block(hc, 2, dtype, 3, scale=0.5))
+    w = torch.randn(36, dtype=tdt, generator=torch.Generator().manual_seed(hc))
+    Pc = P.clone().requires_grad_(True)
+    Qc = F_pi.contract_block(Pc)
+    (Qc * w).sum().backward()
+    Pd = P.clone().to(hip_device).requires_grad_(True)
+    Qd = F_pi.contract_block(Pd)
+    (Qd * w.to(hip_device)).sum().backward()
+    qc, qd = Qc.detach().numpy(), Qd.detach().cpu().numpy()
+    assert np.array_equal(qc[:16], qd[:16])
+    assert np.abs(qc[16:] - qd[16:]).max() <= 2 * eps * np.abs(qc[16:]).max()
+    gc, gd = Pc.grad.numpy(), Pd.grad.cpu().numpy()
+    assert np.array_equal(gc[:16], gd[:16])
+    assert np.abs(gc - gd).max() <= 4 * eps * np.abs(gc).max()
+
+
 def test_reference_style_training_loop_example(hip_device):
     """examples/train_2dgs_synthetic.py -- the reference's training iteration (Adam, StepLR, 40*data + 0.25*IC loss,
     physics loss monitored) wired to this package -- runs and reduces the loss."""
