@@ -513,6 +513,49 @@ def pi_rollout_frames(h0: torch.Tensor, P: torch.Tensor, steps: int, frames: Seq
     return PiRolloutFramesFunction.apply(h0, P, int(steps), tuple(frames))
 
 
+def _progression(t_idx: Sequence[int]):
+    """(start, step, n) if t_idx is an increasing arithmetic progression (what a slice of range(T+1) gives), else None"""
+    n = len(t_idx)
+    if n == 0:
+        return None
+    step = t_idx[1] - t_idx[0] if n > 1 else 1
+    if step <= 0 or any(t_idx[i + 1] - t_idx[i] != step for i in range(n - 1)):
+        return None
+    return t_idx[0], step, n
+
+
+def _observe(traj: torch.Tensor, t_idx: Sequence[int], sub) -> torch.Tensor:
+    """traj[t_idx][:, :, ::s, ...] gathered with ONE strided copy when t_idx is a progression (no index tensor: building
+    one is a pageable host-to-device copy that stalls the host)"""
+    pr = _progression(t_idx)
+    if pr is not None:
+        t0, step, n = pr
+        return traj[t0:t0 + (n - 1) * step + 1:step][(slice(None),) + sub].contiguous()
+    idx = torch.tensor(t_idx, dtype=torch.long, device=traj.device)
+    return traj.index_select(0, idx)[(slice(None),) + sub].contiguous()
+
+
+def _scatter_observed(g_traj: torch.Tensor, t_idx: Sequence[int], sub, g_pred: torch.Tensor):
+    """adjoint of _observe into an UNINITIALISED dL/dtraj buffer: only observed frames are written (zero + strided add,
+    two launches for a progression); returns the frame mask for the sweep"""
+    mask = [False] * g_traj.shape[0]
+    pr = _progression(t_idx)
+    if pr is not None:
+        t0, step, n = pr
+        view = g_traj[t0:t0 + (n - 1) * step + 1:step]
+        view.zero_()
+        view[(slice(None),) + sub].add_(g_pred)
+        for t in t_idx:
+            mask[t] = True
+        return mask
+    for i, t in enumerate(t_idx):
+        if not mask[t]:
+            g_traj[t].zero_()
+            mask[t] = True
+        g_traj[t][sub] += g_pred[i]
+    return mask
+
+
 class PiRolloutObserveFunction(torch.autograd.Function):
     """Rollout + observation operator in one autograd node: returns ``traj[t_idx][:, :, ::sx, ::sy(, ::sz)]`` -- what the
     reference's training loss looks at (``output[0:-1:20, :, ::4, ::4]``, train_2drd.py:397; ``[:-1:15, :, ::2, ::2, ::2]``,
@@ -530,8 +573,7 @@ class PiRolloutObserveFunction(torch.autograd.Function):
         ctx.save_for_backward(traj, P)
         ctx.t_idx = tuple(int(t) % (steps + 1) for t in t_idx)
         ctx.sub = (slice(None),) + tuple(slice(None, None, int(s)) for s in strides)
-        idx = torch.tensor(ctx.t_idx, dtype=torch.long, device=h0.device)
-        pred = traj.index_select(0, idx)[(slice(None),) + ctx.sub].contiguous()
+        pred = _observe(traj, ctx.t_idx, ctx.sub)
         ctx.mark_non_differentiable(traj)
         return pred, traj
 
@@ -539,12 +581,7 @@ class PiRolloutObserveFunction(torch.autograd.Function):
     def backward(ctx, g_pred, _g_traj_unused):
         traj, P = ctx.saved_tensors
         g_traj = torch.empty_like(traj)                    # never initialised as a whole: unobserved frames are masked
-        mask = [False] * traj.shape[0]
-        for i, t in enumerate(ctx.t_idx):
-            if not mask[t]:
-                g_traj[t].zero_()
-                mask[t] = True
-            g_traj[t][ctx.sub] += g_pred[i]
+        mask = _scatter_observed(g_traj, ctx.t_idx, ctx.sub, g_pred)
         g_h0, pg = rollout_bwd(traj, g_traj, P, frame_mask=mask)
         return g_h0[None], pg.to(P.dtype), None, None, None
 

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .functional import _require, _stream, check_star_stencil, _assemble_frame_grads
+from .functional import _require, _stream, check_star_stencil, _assemble_frame_grads, _observe, _scatter_observed
 
 NP = 16 + 6 * 16 * 52 + 32 + 2          # PERCNN_PI_S1_PARAMS
 _OFF_W, _OFF_W4, _OFF_B4 = 16, 16 + 4992, 16 + 4992 + 32
@@ -190,8 +190,7 @@ class Stage1RolloutObserveFunction(torch.autograd.Function):
         ctx.save_for_backward(traj, P)
         ctx.t_idx = tuple(int(t) % (steps + 1) for t in t_idx)
         ctx.sub = (slice(None),) + tuple(slice(None, None, int(s)) for s in strides)
-        idx = torch.tensor(ctx.t_idx, dtype=torch.long, device=h0.device)
-        pred = traj.index_select(0, idx)[(slice(None),) + ctx.sub].contiguous()
+        pred = _observe(traj, ctx.t_idx, ctx.sub)
         ctx.mark_non_differentiable(traj)
         return pred, traj
 
@@ -199,12 +198,7 @@ class Stage1RolloutObserveFunction(torch.autograd.Function):
     def backward(ctx, g_pred, _unused):
         traj, P = ctx.saved_tensors
         g_traj = torch.empty_like(traj)                    # unobserved frames are masked out, never initialised
-        mask = [False] * traj.shape[0]
-        for i, t in enumerate(ctx.t_idx):
-            if not mask[t]:
-                g_traj[t].zero_()
-                mask[t] = True
-            g_traj[t][ctx.sub] += g_pred[i]
+        mask = _scatter_observed(g_traj, ctx.t_idx, ctx.sub, g_pred)
         g_h0, pg = rollout_bwd(traj, g_traj, P, frame_mask=mask)
         return g_h0[None], pg.to(torch.float32), None, None, None
 
