@@ -136,6 +136,8 @@ def main():
                     help="poly: branch product pre-contracted to a cubic (module default); factored: per-point 1x1 branches")
     ap.add_argument("--opt", action="append", default=[], help="library tuning option key=value (repeatable)")
     ap.add_argument("--slab-extra", action="store_true", help="also time the slab-sharded 3D path at N=1")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="headline measurement only (profiling runs: keeps per-kernel averages free of the add-on passes)")
     ap.add_argument("--slab-timeout", type=float, default=240.0)
     ap.add_argument("--slab-child", action="store_true", help=argparse.SUPPRESS)   # see slab_extra_isolated
     a = ap.parse_args()
@@ -290,7 +292,7 @@ def main():
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(family, sd, shape)
-    if world == 1:
+    if world == 1 and not a.no_extras:
         try:
             out["physics_residual"] = physics_extra(pa, cell, family, traj, esz, npts)
         except Exception as e:                       # an add-on measurement must never cost the headline line

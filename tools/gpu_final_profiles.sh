@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp
 for wl in gs2d_512 gs3d_128 lo2d_512 gs2d_100 bur1_100 lo1_100; do
   (timeout 900 python $R/bench.py --workload $wl 2>&1 | tail -1) > $R/gpurun_out/final_bench_$wl.json
-  rm -rf /tmp/kt; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --workload $wl --no-cpu-baseline --steps 3 --warmup 1 > /tmp/kt.log 2>&1
+  rm -rf /tmp/kt; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --workload $wl --no-cpu-baseline --no-extras --steps 3 --warmup 1 > /tmp/kt.log 2>&1
   python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) > $R/gpurun_out/final_kernel_stats_$wl.txt 2>&1
   tail -1 /tmp/kt.log > $R/gpurun_out/final_bench_under_rocprof_$wl.json
 done
@@ -14,7 +14,7 @@ done
 for wl in gs2d_512 gs3d_128 lo2d_512 gs2d_100; do
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcout
-  timeout 900 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmcout -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --workload $wl --T 100 > /tmp/pmc.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmcout -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --workload $wl --T 100 > /tmp/pmc.log 2>&1
   python $R/tools/pmc_summary.py $(find /tmp/pmcout -name "*.db" | head -1) "$wl T=100" | grep "pi::" >> $R/gpurun_out/final_pmc_summary.txt 2>&1
 done
 done
