@@ -19,10 +19,21 @@ __device__ __forceinline__ int mono_of(int a, int b, int c)
     return deg * (deg + 1) / 2 + nv;
 }
 
+constexpr int CONTRACT_LDS_HC = 64;                       // widest block staged in LDS (wider ones read global memory)
+
 template <typename T>
-__global__ void __launch_bounds__(64) pi_contract_fwd_kernel(const T* __restrict__ P, int hc, T* __restrict__ Q)
+__global__ void __launch_bounds__(64) pi_contract_fwd_kernel(const T* __restrict__ Pg, int hc, T* __restrict__ Q)
 {
+    // the whole block comes in with ONE round trip (the per-channel loop below otherwise pays a cold ~2 us load per
+    // hidden channel: 20 us at Hc = 8)
+    __shared__ T stage[P_W + 2 * (10 * CONTRACT_LDS_HC + 1)];
     const int t = threadIdx.x;
+    const bool staged = hc <= CONTRACT_LDS_HC;
+    if (staged) {
+        for (int i = t; i < nparams(hc); i += 64) stage[i] = Pg[i];
+        __syncthreads();
+    }
+    const T* P = staged ? stage : Pg;
     if (t < P_W) Q[t] = P[t];
     if (t >= 20) return;
     const int s = t / 10, m = t % 10;
