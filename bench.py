@@ -250,12 +250,19 @@ def main():
     # pass); the sweep-only timing above then only serves as a lower bound of that kernel
     fused = (not tiled) and poly and dtype == torch.float32 and opts.get("fuse_wgrad", "2") != "0" and \
         not (len(shape) == 3 and shape[-1] == 256 and npts >= (2 << 20) and opts.get("stream3d", "1") != "0")
+    # 2D tile path, float32 poly, 32x32 tiles (> 128 of them): the tile sweep reduces the moments itself as well
+    # (library option tile_fuse, default on) and keeps only every K-th adjoint frame
+    tiles32 = ((shape[0] + 31) // 32) * ((shape[1] + 31) // 32) if len(shape) == 2 else 0
+    tile_fused = tiled and poly and dtype == torch.float32 and K == 4 and tiles32 > 128 and \
+        opts.get("tile_fuse", "1") != "0" and opts.get("tile_by", "0") != "16" and opts.get("tile_nt", "512") == "512"
+    fused = fused or tile_fused
     if fused:
         sweep_ms, red_ms = bwd_ms, 1e-6
     kernels = [
         {"kernel": ("pi_fwd2d_tile_kernel" if tiled else "pi_fwd_kernel"), "launches_per_pass": T // K,
          "algorithmic_bytes_per_launch": 2 * Cs * npts * K, "avg_launch_us": fwd_ms * 1e3 / (T / K)},
-        {"kernel": ("pi_adj2d_tile_kernel" if tiled else ("pi_bwd_kernel<sweep+moments>" if fused else "pi_bwd_kernel<sweep>")),
+        {"kernel": (("pi_adj2d_tile_kernel<sweep+moments>" if tile_fused else "pi_adj2d_tile_kernel") if tiled
+                    else ("pi_bwd_kernel<sweep+moments>" if fused else "pi_bwd_kernel<sweep>")),
          "launches_per_pass": T // K,
          "algorithmic_bytes_per_launch": 4 * Cs * npts * K, "avg_launch_us": sweep_ms * 1e3 / (T / K)},
         {"kernel": ("pi_moments_kernel" if poly else "pi_wgrad_kernel"), "launches_per_pass": 1,

@@ -105,6 +105,8 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *   "fuse_wgrad"   parameter gradients reduced inside the sweep launches instead of one time-parallel pass:
  *                  0 never, 1 wherever a fused flavour exists, 2 (default) float32 pre-contracted blocks on the direct
  *                  / plane-streaming kernels
+ *   "tile_fuse"    1 (default): the float32 pre-contracted tile sweep with 32x32 tiles reduces the 20 coefficient
+ *                  moments itself and stores only every K-th adjoint frame (no separate moments pass); 0: split schedule
  *   "bwd_cpl"      direct adjoint kernel: 16-byte chunks per lane (1..16, default 2) once >= 512 workgroups remain
  *   "overlap", "overlap_chunk"  run the time-parallel gradient pass of finished chunks on a side stream under the sweep
  *   "skip_wgrad"   diagnostics: adjoint sweep only, parameter gradients of the branches come back as zeros

@@ -25,6 +25,8 @@ struct Options {
     int tile_k = 4;         // sub-steps per launch (2 or 4)
     int tile_nt = 512;      // workgroup size of the tile kernels (256 or 512)
     int stream3d = 1;       // 3D: plane-streaming kernels where the shape allows (W = 64*VEC)
+    int tile_fuse = 1;      // 2D tile sweep (float32 poly, K = 4, 32x32 tiles, 512 threads): reduce the 20 coefficient moments
+                            // inside the sweep launches and keep only the hand-over adjoint frames (no moments pass)
     int bwd_cpl = 2;        // direct adjoint kernel: chunks per lane (grid-stride) while >= 512 workgroups remain; measured
                             // 1 -> 2: 128^3 22.9 -> 21.6, 192^3 76.9 -> 64.7, 2048^2 43.8 -> 37.9 us per fused backward step
     int zc = 8;             // planes per workgroup of the streaming kernels
@@ -461,7 +463,7 @@ hipError_t launch_fwd_tile(T* frame_t, const T* P, const Problem& p, hipStream_t
     return hipGetLastError();
 }
 
-template <typename T, int HC, int K, int NT, int BY = TILE_B>
+template <typename T, int HC, int K, int NT, int BY = TILE_B, bool MOM = false>
 hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, unsigned inj_mask, T* g_h0,
                            int steps_to_zero, double* partials, const T* P, const Problem& p, hipStream_t st)
 {
@@ -469,7 +471,7 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
     const pi::TileGeom g = make_tile_geom(p, BY);
     const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
     const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + 32 /* lds_pad0/1 */ + (size_t)g_opt.lds_pad;
-    auto* k = pi::pi_adj2d_tile_kernel<T, HC, K, TILE_B, BY, NT>;
+    auto* k = pi::pi_adj2d_tile_kernel<T, HC, K, TILE_B, BY, NT, MOM>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, hframe_t, gframe_t, aframe_t, (long)(2 * p.n), inj_mask, g_h0,
                        steps_to_zero, partials, pi::nparams(p.hc), P, g);
@@ -505,10 +507,26 @@ hipError_t fwd_tile(T* frame_t, const T* P, const Problem& p, hipStream_t st)
 #undef CALL_FT
 }
 
+// the fused-moments flavour exists for one variant: float32 poly blocks, K = 4, 32 x 32 tiles, 512 threads
+template <typename T>
+bool tile_fuse_ok(const Problem& p)
+{
+    // measured on MI355X (backward us per step, split -> fused): 384^2 3.37 -> 3.20, 512^2 3.90 -> 3.29, 1000^2 13.4 -> 11.3;
+    // in the 16-row-tile regime (<= 128 tiles of 32x32, e.g. the reference's 100^2) the extra VALU work sits on the one
+    // critical workgroup chain and loses (2.26 -> 2.66), so it keeps the split schedule
+    return g_opt.tile_fuse && !g_opt.skip_wgrad && sizeof(T) == 4 && p.hc == 0 && g_opt.tile_k == 4 &&
+           g_opt.tile_nt == 512 && tile_by_for(p) == TILE_B;
+}
+
 template <typename T>
 hipError_t adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, unsigned inj_mask, T* g_h0, int steps_to_zero,
                     double* partials, const T* P, const Problem& p, hipStream_t st)
 {
+    if constexpr (sizeof(T) == 4) {
+        if (tile_fuse_ok<T>(p))
+            return launch_adj_tile<T, pi::POLY, 4, 512, TILE_B, true>(hframe_t, gframe_t, aframe_t, inj_mask, g_h0,
+                                                                      steps_to_zero, partials, P, p, st);
+    }
 #define CALL_AT(HC, K, NT, ...) \
     launch_adj_tile<T, HC, K, NT, ##__VA_ARGS__>(hframe_t, gframe_t, aframe_t, inj_mask, g_h0, steps_to_zero, partials, P, p, st)
     PI_TILE_DISPATCH(CALL_AT);
@@ -855,8 +873,9 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     const bool f32poly = hc == 0 && sizeof(T) == 4;
     const bool direct_sweep = !tile_eligible<T>(p, {traj, g_traj, g_h0, adj}) &&
                               (f32poly || !stream3d_vec<T>(p, {traj, g_traj, g_h0, adj}));
-    const bool fuse = direct_sweep && !g_opt.skip_wgrad && hc != -1 &&
-                      (g_opt.fuse_wgrad == 1 || (g_opt.fuse_wgrad == 2 && f32poly));
+    const bool tile_fused = !direct_sweep && tile_eligible<T>(p, {traj, g_traj, g_h0, adj}) && tile_fuse_ok<T>(p);
+    const bool fuse = tile_fused || (direct_sweep && !g_opt.skip_wgrad && hc != -1 &&
+                                     (g_opt.fuse_wgrad == 1 || (g_opt.fuse_wgrad == 2 && f32poly)));
     unsigned rows = 0, wrows = 0;
     auto reduce_range = [&](int lo, int hi, hipStream_t s2) -> hipError_t {      // steps (lo, hi]
         if (hi <= lo || g_opt.skip_wgrad || fuse) return hipSuccess;
@@ -1039,6 +1058,7 @@ int percnn_pi_set_option(const char* key, long value)
         g_opt.overlap_chunk = (int)value;
         return 0;
     }
+    if (!std::strcmp(key, "tile_fuse")) { g_opt.tile_fuse = value != 0; return 0; }
     if (!std::strcmp(key, "bwd_cpl")) {
         if (value < 1 || value > 16) return PERCNN_PI_EINVAL;
         g_opt.bwd_cpl = (int)value;

@@ -418,10 +418,14 @@ __device__ __forceinline__ void adj_load_ops(StripOps<T>& o, int q, const T* __r
 
 // PRE = true: the strip operands of this sub-step were requested at kernel start (`pre`), so the cold
 // HBM latency of the trajectory / loss-gradient frames overlaps the window load and earlier sub-steps.
-template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE>
+// MOM (float32 poly mode): the 20 coefficient moments  sum_x dt*adj_t[s]*phi_m(h_{t-1})  of the OWNED points are carried in
+// registers (2-vectors, summed at the end of the launch) -- no adjoint trajectory, no separate moments pass.
+template <typename T, bool MOM> struct TileMoments { V2<T> a[MOM ? 2 : 1][MOM ? 10 : 1]; };
+
+template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE, bool MOM>
 __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict__ hfr, const T* __restrict__ gfr,
                                             const TileGeom& g, int ty0, int tx0, const T* __restrict__ P,
-                                            double (&acc_c)[2], const StripOps<T>& pre)
+                                            double (&acc_c)[2], const StripOps<T>& pre, TileMoments<T, MOM>& mom)
 {
     using TL = Tile<K, BX, BY>;
     constexpr int RW4 = TL::region_w(M) / 4, RN4 = TL::region_n(M) / 4, O = 2 * (M + 1);
@@ -449,6 +453,7 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
         lds_star4v<T, TL::LX, -1>(cur + TL::PLANE, ly, lx, P, gc[1], dl[1]);
         const bool rowin = live && ly >= 2 * K && ly < 2 * K + BY && ty0 + ly - 2 * K < g.H;
         const V2<T> dtv = vs(dt);
+        V2<T> own[2];                                      // 1 for owned, in-grid points, else 0 (MOM only)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             dl[0][h] *= dtv;
@@ -457,10 +462,12 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int i = 2 * h + e;
-                if (rowin && lx + i >= 2 * K && lx + i < 2 * K + BX && tx0 + lx + i - 2 * K < g.W) {   // owned, in-grid points only
+                const bool mine = rowin && lx + i >= 2 * K && lx + i < 2 * K + BX && tx0 + lx + i - 2 * K < g.W;
+                if (mine) {                                // owned, in-grid points only
                     acc_c[0] += (double)mu[e];
                     acc_c[1] += (double)mv[e];
                 }
+                own[h][e] = mine ? T(1) : T(0);
             }
         }
         V2<T> du[2] = {vs(T(0)), vs(T(0))}, dv[2] = {vs(T(0)), vs(T(0))};
@@ -476,6 +483,17 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
                     poly_dr_v(c, U[h], V[h], ru, rv);
                     du[h] = vfma(gr, ru, du[h]);
                     dv[h] = vfma(gr, rv, dv[h]);
+                    if constexpr (MOM) {
+                        V2<T> (&a)[10] = mom.a[s];
+                        const V2<T> gm = gr * own[h];
+                        const V2<T> uu = U[h], vv = V[h];
+                        const V2<T> u2 = uu * uu, uv = uu * vv, v2 = vv * vv;
+                        a[0] += gm;
+                        a[1] = vfma(gm, uu, a[1]); a[2] = vfma(gm, vv, a[2]);
+                        a[3] = vfma(gm, u2, a[3]); a[4] = vfma(gm, uv, a[4]); a[5] = vfma(gm, v2, a[5]);
+                        a[6] = vfma(gm, u2 * uu, a[6]); a[7] = vfma(gm, u2 * vv, a[7]);
+                        a[8] = vfma(gm, uu * v2, a[8]); a[9] = vfma(gm, v2 * vv, a[9]);
+                    }
                 }
             }
         } else {
@@ -520,12 +538,12 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
 
 // PRE: the pointwise operands of sub-step M+1 are requested before sub-step M is computed and stay in flight across
 // its LDS barrier (one strip per lane only); `ops` holds the operands of sub-step M, requested one sub-step earlier.
-template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE>
+template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE, bool MOM>
 __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__ hbase, const T* __restrict__ gbase,
                                              T* __restrict__ abase, long frame_stride, unsigned inj_mask,
                                              T* __restrict__ g_h0, int steps_to_zero, const TileGeom& g, int ty0,
                                              int tx0, const T* __restrict__ P, double (&acc_c)[2],
-                                             const StripOps<T>& ops)
+                                             const StripOps<T>& ops, TileMoments<T, MOM>& mom)
 {
     T* cur = (M & 1) ? b1 : b0;
     T* nxt = (M & 1) ? b0 : b1;
@@ -536,21 +554,24 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
         adj_load_ops<T, K, BX, BY, NT, M + 1>(ahead, 0, hbase + fn, (inj_mask >> (M + 1)) & 1u ? gbase + fn : nullptr, g,
                                               ty0, tx0);
     }
-    adj_substep<T, HC, K, BX, BY, NT, M, PRE>(cur, nxt, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g,
-                                              ty0, tx0, P, acc_c, ops);
+    adj_substep<T, HC, K, BX, BY, NT, M, PRE, MOM>(cur, nxt, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g,
+                                                   ty0, tx0, P, acc_c, ops, mom);
     PI_STAMP(2 + 3 * M);
     lds_barrier();
     PI_STAMP(3 + 3 * M);
-    // the adjoint of frame 0 is the caller's dL/dh0 output
-    T* dst = (M + 1 == steps_to_zero && g_h0) ? g_h0 : abase + fo;
-    tile_store<T, K, BX, BY, NT, (M & 1) != 0>(nxt, dst, g, ty0, tx0);
+    // the adjoint of frame 0 is the caller's dL/dh0 output.  MOM: nobody reads the intermediate adjoint frames (the
+    // moments are reduced right here), only the hand-over frame t-K goes to memory
+    if constexpr (!MOM || M + 1 == K) {
+        T* dst = (M + 1 == steps_to_zero && g_h0) ? g_h0 : abase + fo;
+        tile_store<T, K, BX, BY, NT, (M & 1) != 0>(nxt, dst, g, ty0, tx0);
+    }
     PI_STAMP(4 + 3 * M);
     if constexpr (M + 1 < K)
-        adj_substeps<T, HC, K, BX, BY, NT, M + 1, PRE>(b0, b1, hbase, gbase, abase, frame_stride, inj_mask, g_h0,
-                                                       steps_to_zero, g, ty0, tx0, P, acc_c, ahead);
+        adj_substeps<T, HC, K, BX, BY, NT, M + 1, PRE, MOM>(b0, b1, hbase, gbase, abase, frame_stride, inj_mask, g_h0,
+                                                            steps_to_zero, g, ty0, tx0, P, acc_c, ahead, mom);
 }
 
-template <typename T, int HC, int K, int BX, int BY, int NT>
+template <typename T, int HC, int K, int BX, int BY, int NT, bool MOM = false>
 __global__ void __launch_bounds__(NT)
 pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gframe_t, T* __restrict__ aframe_t,
                      long frame_stride, unsigned inj_mask, T* __restrict__ g_h0, int steps_to_zero,
@@ -570,8 +591,13 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
     wl.issue(aframe_t, g, ty0, tx0);                       // adjoint window first, then the operands of sub-step 0
     // running diffusion-coefficient partial of this tile: requested now, needed at the very end (was a dependent
     // load -> add -> store at the end of every launch: 1 us)
-    double* pslot = partials + (long)blockIdx.x * np + P_COEF + (threadIdx.x & 1);
-    const double pold = threadIdx.x < 2 ? *pslot : 0.0;
+    static_assert(!MOM || (HC == POLY && sizeof(T) == 4), "fused moments: float32 poly mode");
+    // slots of the partial row this thread updates at the end: threads 0,1 the two coefficient sums, MOM: threads
+    // 2..21 the 20 moments (row layout of the direct kernels: P_W + 10*s + m)
+    const int slot = threadIdx.x < 2 ? P_COEF + (int)threadIdx.x : P_W + (int)threadIdx.x - 2;
+    const bool has_slot = threadIdx.x < (MOM ? 22 : 2);
+    double* pslot = partials + (long)blockIdx.x * np + (has_slot ? slot : P_COEF);
+    const double pold = has_slot ? *pslot : 0.0;
     StripOps<T> ops0;
     if constexpr (PRE)
         adj_load_ops<T, K, BX, BY, NT, 0>(ops0, 0, hframe_t - frame_stride, inj_mask & 1u ? gframe_t - frame_stride : nullptr,
@@ -580,22 +606,39 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
     lds_barrier();                                         // LDS only: the operand loads stay in flight
     PI_STAMP(1);
     double acc_c[2] = {0.0, 0.0};                          // heavily cancelling sums (stencil row-sum ~ 0): fp64
-    adj_substeps<T, HC, K, BX, BY, NT, 0, PRE>(b0, b1, hframe_t, gframe_t, aframe_t, frame_stride, inj_mask, g_h0,
-                                               steps_to_zero, g, ty0, tx0, P, acc_c, ops0);
+    TileMoments<T, MOM> mom;
+    if constexpr (MOM) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int m = 0; m < 10; ++m) mom.a[s][m] = vs(T(0));
+    }
+    adj_substeps<T, HC, K, BX, BY, NT, 0, PRE, MOM>(b0, b1, hframe_t, gframe_t, aframe_t, frame_stride, inj_mask, g_h0,
+                                                    steps_to_zero, g, ty0, tx0, P, acc_c, ops0, mom);
     // diffusion-coefficient gradients of this tile over the K sub-steps: one reduction per launch
     // (LDS-only barriers: the last frame's global stores need not drain first)
     lds_barrier();
     double* red = reinterpret_cast<double*>(smem_raw);     // state buffers are dead now
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    constexpr int NRED = MOM ? 22 : 2;                     // per wave: 2 coefficient sums (+ 20 moments)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const double r = wave_sum_to_last(acc_c[s]);
-        if (lane == REDUCE_LANE) red[wave * 2 + s] = r;
+        if (lane == REDUCE_LANE) red[wave * NRED + s] = r;
+    }
+    if constexpr (MOM) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int m = 0; m < 10; ++m) {
+                const T r = wave_sum_to_last(mom.a[s][m].x + mom.a[s][m].y);
+                if (lane == REDUCE_LANE) red[wave * NRED + 2 + 10 * s + m] = (double)r;
+            }
     }
     lds_barrier();
-    if (threadIdx.x < 2) {
+    if (has_slot) {
         double sum = 0.0;
-        for (int w = 0; w < NT / WAVE; ++w) sum += red[w * 2 + threadIdx.x];
+        for (int w = 0; w < NT / WAVE; ++w) sum += red[w * NRED + threadIdx.x];
         *pslot = pold + sum;
     }
     PI_STAMP(15);
