@@ -7,9 +7,14 @@ import json, re, sys, os
 src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01_final_pmc_fetch_write_summary.txt"
 rows = {}
 for line in open(src):
-    m = re.match(r"(\S+) T=(\d+) \| (\w+) \| n=(\d+) avg=([\d.]+).*\| (?:void )?pi::(\w+)", line)
+    m = re.match(r"(\S+) T=(\d+) \| (\w+) \| n=(\d+) avg=([\d.]+).*\| (?:void )?pi::(\w+)(<[^(]*>)?", line)
     if m:
-        wl, T, ctr, n, avg, kern = m.groups()
+        wl, T, ctr, n, avg, kern, targs = m.groups()
+        # the tile sweep exists in two flavours (last template argument): the default run launches the fused one
+        # (`true`); the sweep-only one (`false`) only runs in bench.py's diagnostic timing leg
+        if kern == "pi_adj2d_tile_kernel" and targs and targs.rstrip(">").endswith("false") and \
+                any(l.startswith(wl + " ") and "pi_adj2d_tile_kernel" in l and ", true>" in l for l in open(src)):
+            kern = "pi_adj2d_tile_kernel_sweep_only"
         rows.setdefault(wl, {}).setdefault(kern, {})[ctr] = float(avg) * 1024.0
 for wl, kernels in rows.items():
     out = {"_source": f"{src} (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --workload {wl} --T 100)",
