@@ -30,7 +30,22 @@ def _cases():
     return out
 
 
-@pytest.mark.parametrize("case", _cases(), ids=lambda c: f"{c[0]}-{'x'.join(map(str, c[2]))}-hc{c[3]}-{np.dtype(c[4]).name}-T{c[5]}{'-mask' if c[6] else ''}")
+def _large2d_cases():
+    """2D grids with more than 128 tiles of 32x32: the regime of the fused tile sweep (float32 poly) next to the split
+    schedule (other block kinds / float64) -- ragged edges, rollout lengths around multiples of K = 4, sparse masks."""
+    rs = np.random.RandomState(777)
+    shapes = [(384, 384), (416, 352), (500, 396), (640, 260), (356, 676), (512, 512)]
+    out = []
+    for i in range(14):
+        shape = shapes[i % len(shapes)]
+        hc = [0, 0, 0, 8, 0, 2, 0][i % 7]
+        dtype = np.float64 if i % 5 == 4 else np.float32
+        T = int(rs.choice([3, 4, 5, 8, 9, 11]))
+        out.append((200 + i, 2, shape, hc, dtype, T, bool(i % 2)))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases() + _large2d_cases(), ids=lambda c: f"{c[0]}-{'x'.join(map(str, c[2]))}-hc{c[3]}-{np.dtype(c[4]).name}-T{c[5]}{'-mask' if c[6] else ''}")
 def test_random_rollout_vs_oracle(case, hip_device):
     import percnn_amd as pa
     i, ndim, shape, hc, dtype, T, masked = case
