@@ -55,9 +55,18 @@ def build(force: bool = False, extra_flags=(), out: str | None = None) -> str:
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    if relink or any(os.path.getmtime(out) < os.path.getmtime(o) for o in objs):
+    relinked = relink or any(os.path.getmtime(out) < os.path.getmtime(o) for o in objs)
+    if relinked:
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs, cwd=CSRC)
+    # what this call actually did (a tree that already carries objects / the library compiles nothing unless forced)
+    global last_build
+    last_build = {"build_mode": "forced" if force else "incremental",
+                  "compiled": [os.path.basename(c[-1]) for c, _ in procs], "relinked": bool(relinked),
+                  "library": os.path.relpath(out, os.path.dirname(_HERE))}
     return out
+
+
+last_build: dict = {}
 
 
 _lib = None

@@ -712,6 +712,8 @@ int slab_rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* 
     if (int rc = make_problem(hc, ndim, shape, true, p)) return rc;
     if (int rc = set_slab(p, halo, 0)) return rc;
     if (!traj || !P || T_steps < 0) return PERCNN_PI_EINVAL;
+    // the exchange sends `halo` INTERIOR planes per side: a thinner slab would forward halo planes as if they were data
+    if (p.n0 < halo) return PERCNN_PI_EINVAL;
     auto st = static_cast<hipStream_t>(stream);
     const int k = halo / 2;
     const int64_t n = p.n0;
@@ -759,11 +761,19 @@ int slab_rollout_bwd_impl(const T* traj, const T* g_traj, T* adj, double* param_
     if (int rc = make_problem(hc, ndim, shape, true, p)) return rc;
     if (int rc = set_slab(p, halo, halo - 2)) return rc;
     if (!traj || !g_traj || !adj || !param_grad || !P || T_steps < 0) return PERCNN_PI_EINVAL;
+    if (p.n0 < 2) return PERCNN_PI_EINVAL;                  // the adjoint exchange sends 2 interior planes per side
     Workspace w;
     if (!carve(ws, ws_bytes, p, sizeof(T), w)) return PERCNN_PI_EWORKSPACE;
     auto st = static_cast<hipStream_t>(stream);
     const int64_t n = p.n0;
     const size_t plane = (size_t)(p.n1 * p.W), ss = (size_t)(n + 2 * halo) * plane, frame = 2 * ss;
+    // frame 0 of `adj` is returned to the caller as dL/dh0 (padded layout): its halo planes are never written by the
+    // sweep (no exchange for frame 0), so define them here -- zeros, as the portable orchestration returns
+    for (int s = 0; s < 2; ++s) {
+        if (hipError_t e = hipMemsetAsync(adj + (size_t)s * ss, 0, (size_t)halo * plane * sizeof(T), st)) return (int)e;
+        if (hipError_t e = hipMemsetAsync(adj + (size_t)s * ss + (size_t)(halo + n) * plane, 0,
+                                          (size_t)halo * plane * sizeof(T), st)) return (int)e;
+    }
     // adj[T] interior = dL/dtraj[T] interior
     for (int s = 0; s < 2; ++s) {
         const size_t o = (size_t)T_steps * frame + (size_t)s * ss + (size_t)halo * plane;

@@ -452,21 +452,42 @@ class PiRolloutFunction(torch.autograd.Function):
         return g_h0[None], pg.to(P.dtype), None
 
 
-def _assemble_frame_grads(grads, frames, traj):
-    """dL/dtraj from the per-frame gradients autograd hands back.  Zero-copy when they are the consecutive slices
-    of one buffer (what ``torch.cat(tuple(outputs))`` followed by any dense loss produces: CatBackward narrows its
-    incoming gradient); otherwise the frames that carry a gradient are copied and the rest is masked out."""
+def _dense_prefix_view(grads, traj):
+    """The T+1 per-frame gradients as ONE [T+1,2,*S] view if they are consecutive slices of one buffer, else None."""
     T1 = traj.shape[0]
-    g0 = grads[0] if grads else None
-    if len(frames) == T1 and tuple(frames) == tuple(range(T1)) and all(g is not None for g in grads) and g0.is_contiguous():
-        step_bytes = traj[0].numel() * traj.element_size()
-        base = g0.data_ptr()
-        st = g0.untyped_storage()
-        room = st.nbytes() - (base - st.data_ptr())
-        if (room >= T1 * step_bytes and g0.dtype == traj.dtype and
-                all(g.is_contiguous() and g.dtype == traj.dtype and g.data_ptr() == base + k * step_bytes
-                    and g.untyped_storage().data_ptr() == st.data_ptr() for k, g in enumerate(grads))):
-            return torch.as_strided(g0, traj.shape, traj.stride(), g0.storage_offset()), None
+    g0 = grads[0]
+    if any(g is None for g in grads) or not g0.is_contiguous() or g0.dtype != traj.dtype:
+        return None
+    step_bytes = traj[0].numel() * traj.element_size()
+    base = g0.data_ptr()
+    st = g0.untyped_storage()
+    room = st.nbytes() - (base - st.data_ptr())
+    if room < T1 * step_bytes:
+        return None
+    if not all(g.is_contiguous() and g.dtype == traj.dtype and g.data_ptr() == base + k * step_bytes
+               and g.untyped_storage().data_ptr() == st.data_ptr() for k, g in enumerate(grads)):
+        return None
+    return torch.as_strided(g0, traj.shape, traj.stride(), g0.storage_offset())
+
+
+def _assemble_frame_grads(grads, frames, traj):
+    """dL/dtraj from the per-frame gradients autograd hands back.  ``frames`` = the dense list 0..T (what
+    ``torch.cat(tuple(outputs))`` followed by any dense loss produces: CatBackward narrows its incoming gradient, so
+    the per-frame gradients are consecutive slices of one buffer -> zero-copy view), optionally FOLLOWED by extra
+    frames (``RCNN.forward`` returns ``second_last_state`` as one more output): extras without a gradient cost
+    nothing, extras with one cost a single copy of the dense part.  Anything else: the frames that carry a gradient
+    are copied and the rest is masked out of the sweep."""
+    T1 = traj.shape[0]
+    if len(frames) >= T1 and tuple(frames[:T1]) == tuple(range(T1)):
+        view = _dense_prefix_view(grads[:T1], traj)
+        if view is not None:
+            extras = [(k, g) for k, g in zip(frames[T1:], grads[T1:]) if g is not None]
+            if not extras:
+                return view, None
+            g_traj = view.clone()                              # autograd owns `view`: never accumulate into it
+            for k, g in extras:
+                g_traj[k].add_(g[0])
+            return g_traj, None
     g_traj = torch.empty_like(traj)
     mask = [False] * T1
     for k, g in zip(frames, grads):

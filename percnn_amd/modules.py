@@ -35,6 +35,24 @@ class RCNNCell(nn.Module):
 
     diffusion='sigmoid' -> coefficient mu_up*sigmoid(CA|CB) (train_2drd.py:115-116);
     diffusion='raw'     -> coefficient DA|DB                 (percnn_LO_eqn.py:107-108).
+
+    reaction='factored' evaluates the six 1x1 branches, their Hadamard product and the 1x1 aggregation per point in
+    the reference's operation order (train_2drd.py:115-116).  reaction='poly' (default) evaluates the SAME cubic from
+    its 2 x 10 monomial coefficients c_m (contracted in float64 on the device, Horner form) -- ~4x fewer operations at
+    Hc = 8, but a different rounding: monomials that cancel each other (e.g. (u - a)^3 with |a| >> |u - a|) cancel
+    exactly in the factored form and only to rounding in the expanded one.
+
+    WHEN 'factored' IS REQUIRED.  The per-step rounding noise of the expanded form, relative to the state, is
+    eps * A with the amplification
+
+        A = dt * max_s sum_m |c_m^s| * phi_m(|u|max, |v|max) / max(|u|max, |v|max)        (``poly_amplification``)
+
+    Measured (tests/test_host_logic.py::test_poly_conditioning_rule, stable cubic with roots at a = 0 ... 50, 100
+    steps): state rel-L2 of 'poly' vs a float64 run = 0.6 * eps * A (A = 170 -> 6e-6, A = 4000 -> 1.3e-4) while
+    'factored' stays at the 1.6e-7 float32 noise floor for every A.  Rule: keep 'poly' while A <= 10 in float32
+    (<= 6e-7 extra, inside the reference's own fp32-vs-fp64 spread of 4e-7 over 1000 steps); use
+    reaction='factored' beyond -- always for A >= 100.  float64: A <= 1e4.  The shipped checkpoints sit at
+    A = 1.04 (2D GS), 0.39 (3D GS), 0.06 (lambda-omega) for states in [0, 1].
     """
 
     def __init__(self, ndim: int = 2, hidden_channels: int = 8, dx: float = 0.01, dt: float = 0.5,
@@ -106,16 +124,34 @@ class RCNNCell(nn.Module):
     def param_block(self) -> torch.Tensor:
         self._validate_stencil()
         w = self.W_laplace.weight
-        if self._dt_cache is None or self._dt_cache.device != w.device or self._dt_cache.dtype != w.dtype:
-            self._dt_cache = torch.tensor([self.dt], dtype=w.dtype, device=w.device)
+        # the reference reads self.dt every step (train_2drd.py:117): the cached device scalar is keyed on its value too
+        key = (float(self.dt), w.device, w.dtype)
+        if self._dt_cache is None or self._dt_cache[0] != key:
+            self._dt_cache = (key, torch.tensor([self.dt], dtype=w.dtype, device=w.device))
         cu, cv = self.coefficients()
         branch = []
         for s in ("u", "v"):
             for k in (1, 2, 3, 4):
                 m = getattr(self, f"Wh{k}_{s}")
                 branch += [m.weight, m.bias]
-        P = F_pi.pack_params(self._dt_cache, cu, cv, w, branch)
+        P = F_pi.pack_params(self._dt_cache[1], cu, cv, w, branch)
         return F_pi.contract_block(P) if self.reaction == "poly" else P
+
+    def poly_amplification(self, u_max: float = 1.0, v_max: float = 1.0) -> float:
+        """A of the class docstring for states bounded by |u| <= u_max, |v| <= v_max: how much larger the rounding
+        noise of reaction='poly' is than the rounding of the state update itself.  Host-side diagnostic (one
+        device-to-host copy); see the rule in the class docstring."""
+        with torch.no_grad():
+            keep, self.reaction = self.reaction, "factored"
+            try:
+                P = self.param_block().detach().to("cpu", torch.float64)
+            finally:
+                self.reaction = keep
+            Q = F_pi.contract_block(P)
+        u, v = float(u_max), float(v_max)
+        phi = torch.tensor([1, u, v, u * u, u * v, v * v, u ** 3, u * u * v, u * v * v, v ** 3], dtype=torch.float64)
+        a = (Q[16:36].abs().reshape(2, 10) * phi).sum(1).max()
+        return float(abs(self.dt) * a / max(u, v))
 
     # -- reference interface -------------------------------------------------------------------
     def forward(self, h):

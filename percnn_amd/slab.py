@@ -137,6 +137,8 @@ class RcclHaloExchanger(HaloExchanger):
     ``torch.distributed`` group.  Falls back to the parent class for CPU tensors / world size 1 without
     ``force_p2p``."""
 
+    # ncclDataType_t (nccl.h): ncclFloat32 = 7, ncclFloat64 = 8 -- unchanged since NCCL 2.0; the loaded library's
+    # version is checked in __init__ (ncclGetVersion) so an incompatible major version fails here, not in a kernel
     _DT = {torch.float32: 7, torch.float64: 8}
 
     def __init__(self, group=None, force_p2p: bool = False):
@@ -146,6 +148,13 @@ class RcclHaloExchanger(HaloExchanger):
         self._ct = ctypes
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         self._nccl = ctypes.CDLL(path)
+        ver = ctypes.c_int(0)
+        self._check(self._nccl.ncclGetVersion(ctypes.byref(ver)), "ncclGetVersion")
+        self.nccl_version = ver.value
+        major = ver.value // 10000 if ver.value >= 10000 else ver.value // 1000      # 2.x.y encodes as 2xxyy (>= 2.9) or 2xyy
+        if major != 2:
+            raise RuntimeError(f"percnn_amd: librccl reports NCCL version code {ver.value}; the ncclDataType_t values "
+                               "used here are those of NCCL 2.x")
 
         class UniqueId(ctypes.Structure):
             _fields_ = [("internal", ctypes.c_byte * 128)]
@@ -166,7 +175,14 @@ class RcclHaloExchanger(HaloExchanger):
 
     def _check(self, rc, what):
         if rc != 0:
-            raise RuntimeError(f"percnn_amd: {what} failed with ncclResult_t {rc}")
+            msg = ""
+            try:
+                f = self._nccl.ncclGetErrorString
+                f.restype, f.argtypes = self._ct.c_char_p, [self._ct.c_int]
+                msg = f" ({f(rc).decode()})"
+            except Exception:
+                pass
+            raise RuntimeError(f"percnn_amd: {what} failed with ncclResult_t {rc}{msg} on rank {self.rank}/{self.world}")
 
     def exchange(self, slab: torch.Tensor, halo: int, width: Optional[int] = None) -> None:
         if not slab.is_cuda or (self.world == 1 and not self.force_p2p):
@@ -234,14 +250,61 @@ class RcclHaloExchanger(HaloExchanger):
             self._comm = None
 
 
+_exchangers: dict = {}
+
+
+def _all_ranks_agree(ok: bool, group) -> bool:
+    """True iff `ok` on EVERY rank of the group (one tiny all-reduce): a set-up that succeeded on some ranks only must
+    not leave the ranks on different transports -- the first exchange would hang."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return ok
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item())
+
+
 def make_exchanger(group=None, prefer_rccl: bool = True, force_p2p: bool = False) -> HaloExchanger:
-    """RCCL-direct exchanger on GPU jobs when it can be set up, else the torch.distributed one."""
+    """ONE exchanger per (group, device, transport) for the life of the process: RCCL-direct on GPU jobs when the
+    communicator comes up on every rank, else the torch.distributed one.  (A fresh ``ncclCommInitRank`` per training
+    iteration would leak a communicator each time; cached instances are closed at interpreter exit.)"""
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    key = (id(group) if group is not None else None, dev, bool(prefer_rccl), bool(force_p2p))
+    ex = _exchangers.get(key)
+    if ex is not None:
+        return ex
+    ex = None
     if prefer_rccl and torch.cuda.is_available():
+        err = None
         try:
-            return RcclHaloExchanger(group, force_p2p)
-        except Exception:                       # missing symbols / init failure: keep the portable path
-            pass
-    return HaloExchanger(group, force_p2p)
+            ex = RcclHaloExchanger(group, force_p2p)
+        except Exception as e:                  # missing symbols / init failure: keep the portable path -- on ALL ranks
+            err = e
+        if not _all_ranks_agree(ex is not None, group):
+            if ex is not None:
+                ex.close()
+            ex = None
+            import warnings
+            warnings.warn(f"percnn_amd: RCCL halo ring not available on every rank ({err!r}); "
+                          "using torch.distributed point-to-point")
+    if ex is None:
+        ex = HaloExchanger(group, force_p2p)
+    _exchangers[key] = ex
+    return ex
+
+
+def close_exchangers() -> None:
+    for ex in list(_exchangers.values()):
+        if hasattr(ex, "close"):
+            try:
+                ex.close()
+            except Exception:
+                pass
+    _exchangers.clear()
+
+
+import atexit
+atexit.register(close_exchangers)
 
 
 def slab_rollout_fwd_(traj: torch.Tensor, P: torch.Tensor, ex: HaloExchanger, halo: int,

@@ -258,6 +258,19 @@ def test_slab_rollout_single_rank_equals_rollout(fam, halo, hip_device):
     for n, p in cell.named_parameters():
         if p.grad is not None:
             assert rel_l2(p.grad.cpu().numpy(), ref_grads[n].cpu().numpy()) < tol, n
+    # dL/dh0 in the padded layout: interior == the plain rollout's, halo planes exactly zero on the native path
+    # (they used to be uninitialised device memory)
+    for poison in (float("nan"), 1e30):
+        junk = [torch.full((n,), poison, device=hip_device) for n in (1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 22)]
+        del junk                                                        # dirty the allocator's free blocks
+        lo = slab.scatter_slab(h0[0], 0, 1, halo).requires_grad_(True)
+        tr = slab.slab_rollout(lo, cell.param_block().detach(), T, halo=halo)
+        (tr[:, :, halo:halo + n0] * gt).sum().backward()
+        assert torch.isfinite(lo.grad).all()
+        assert float(lo.grad[:, :halo].abs().max()) == 0.0 and float(lo.grad[:, halo + n0:].abs().max()) == 0.0
+    h1 = h0.clone().requires_grad_(True)
+    (pa.pi_rollout(h1, cell.param_block().detach(), T) * gt).sum().backward()
+    assert torch.equal(lo.grad[:, halo:halo + n0], h1.grad[0])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -292,6 +305,112 @@ def test_full_size_rollout_vs_reference_subsample(fam, shape, reaction, hip_devi
         assert rel_l2(got[sub].cpu().numpy(), z[f"sub/{t}"][0]) < tol, f"t={t}"
         assert abs(float(torch.linalg.vector_norm(got.double())) - float(z[f"l2/{t}"])) < tol * float(z[f"l2/{t}"])
         assert torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("reaction", ["factored", "poly"])
+@pytest.mark.parametrize("fam,shape", [("gs2d", (512, 512)), ("gs3d", (128, 128, 128)), ("lo2d", (512, 512))])
+def test_full_size_gradients_vs_reference(fam, shape, reaction, hip_device):
+    """The backward the reference triggers at train_2drd.py:407 / train_3drd.py:408 / percnn_LO_eqn.py:373, at the
+    BASELINE grid sizes: the imported reference's own autograd run (tools/make_golden.py --biggrad; 512^2 x 100,
+    128^3 x 20, lambda-omega 512^2 x 20 steps) -- both losses, every parameter gradient, dL/dh0 (every 8th point + norm)."""
+    import percnn_amd as pa
+    from oracle import restatement as R
+    fn = [f for f in os.listdir(GOLDEN) if f.startswith(fam + "_biggrad_")]
+    if not fn:
+        pytest.skip("biggrad golden absent")
+    z = np.load(os.path.join(GOLDEN, fn[0]))
+    sd = {k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}
+    cell = {"gs2d": pa.gs2d_cell, "gs3d": pa.gs3d_cell, "lo2d": pa.lo2d_cell}[fam](reaction=reaction)
+    cell.load_state_dict(sd)
+    cell.to(hip_device)
+    steps, stride_t, ndim = int(z["steps"]), int(z["stride_t"]), len(shape)
+    sub = (slice(None), slice(None)) + (slice(None, None, 8),) * ndim
+    tol_t, tol_g = (1e-5, 2e-5) if fam != "lo2d" else (1e-12, 1e-10)
+    names = [n for n, p in cell.named_parameters() if p.requires_grad]
+    params = [p for n, p in cell.named_parameters() if p.requires_grad]
+    for lname in ("meansq", "data"):
+        h0 = (R.lo_initial_state(shape[0]) if fam == "lo2d" else R.gs_initial_state(shape, seed=0)).to(hip_device)
+        h0.requires_grad_(True)
+        model = pa.RCNN(cell, step=steps, effective_step=list(range(steps)), init_state=h0)
+        outs, _ = model()                                   # the reference's call pattern: list of frames + cat
+        traj = torch.cat(tuple(outs), dim=0)
+        assert rel_l2(traj[-1:].detach()[sub].cpu().numpy(), z["sub_last"]) < tol_t
+        loss = (traj ** 2).mean() if lname == "meansq" else data_loss(traj, stride_t, ndim)
+        ref_loss = float(z[f"loss_{lname}"])
+        assert abs(loss.item() - ref_loss) <= 1e-5 * abs(ref_loss)
+        grads = torch.autograd.grad(loss, params + [h0])
+        allm = np.concatenate([g.cpu().numpy().ravel() for g in grads[:-1]])
+        allr = np.concatenate([z[f"grad_{lname}/{n}"].ravel() for n in names])
+        assert allm.size in (164, 44, 84)
+        assert rel_l2(allm, allr) < tol_g, lname
+        for n, g in zip(names, grads[:-1]):
+            assert rel_l2(g.cpu().numpy(), z[f"grad_{lname}/{n}"]) < 10 * tol_g, (lname, n)
+        gh = grads[-1]
+        assert rel_l2(gh[sub].cpu().numpy(), z[f"grad_{lname}_h0_sub"]) < tol_g
+        l2 = float(z[f"grad_{lname}_h0_l2"])
+        assert abs(float(torch.linalg.vector_norm(gh.double())) - l2) < tol_g * l2
+
+
+@pytest.mark.parametrize("a", [0.0, 2.0, 10.0, 50.0])
+def test_poly_conditioning_rule_on_the_kernels(a, hip_device):
+    """The rule of RCNNCell's docstring on the HIP kernels themselves: poly vs factored kernel after 100 steps on the
+    stable cubic well of tests/test_host_logic.py (ill-conditioned expansion for large a), both against a float64
+    factored run; RCNNCell.poly_amplification predicts the loss of the pre-contracted form."""
+    import percnn_amd as pa
+    from percnn_amd import functional as Fp
+    from test_host_logic import _cubic_well_block
+    P32 = _cubic_well_block(a, 1.0, 0.1).astype(np.float32)
+    Pd = dev_t(P32, hip_device)
+    Qd = Fp.contract_block(Pd)
+    h0 = (a + np.random.RandomState(0).uniform(-1, 1, (2, 48, 48))).astype(np.float32)
+    T = 100
+
+    def run(block, dtype):
+        traj = torch.empty((T + 1, 2, 48, 48), dtype=dtype, device=hip_device)
+        traj[0] = dev_t(h0, hip_device).to(dtype)
+        pa.rollout_fwd_(traj, block.to(dtype).contiguous())
+        return traj[-1].cpu().numpy()
+
+    t64 = run(Pd, torch.float64)
+    e_fact, e_poly = rel_l2(run(Pd, torch.float32), t64), rel_l2(run(Qd, torch.float32), t64)
+    hm = float(np.abs(t64).max())
+    Q64 = Fp.contract_block(Pd.double()).cpu().numpy()
+    phi = np.array([1, hm, hm, hm * hm, hm * hm, hm * hm, hm ** 3, hm ** 3, hm ** 3, hm ** 3])
+    A = 0.1 * max(float((np.abs(Q64[16 + 10 * s:26 + 10 * s]) * phi).sum()) for s in range(2)) / hm
+    eps = 2.0 ** -24
+    assert e_fact < 5e-7, (a, e_fact)
+    assert e_poly < max(5e-7, 2.5 * eps * A), (a, A, e_poly)
+    if A <= 10:
+        assert e_poly < 1e-6 and rel_l2(run(Qd, torch.float32), run(Pd, torch.float32)) < 1e-6
+
+
+def test_headline_backward_512x512x1000_vs_c_oracle(hip_device):
+    """The bench headline itself (BASELINE configs[1]: 512^2, T = 1000, float32 poly block, dense dL/dtraj): the fused
+    tile sweep against the plain-C oracle's hand-derived adjoint over the whole horizon -- dL/dh0 bit-identical, the 36
+    packed gradients to reduction round-off.  (~20 s of host time for the scalar C oracle.)"""
+    import percnn_amd as pa
+    z = _big("gs2d")
+    from oracle import pi_oracle as O
+    from oracle import restatement as R
+    sd = {k[6:]: z[k] for k in z.files if k.startswith("param/")}
+    oc = R.gs2d_cell()
+    oc.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    cu, cv = [c.detach().numpy() for c in oc.coefficients()]
+    P = O.pack_poly(sd, oc.dt, cu, cv, np.float32)
+    T, shape = 1000, (512, 512)
+    h0 = R.gs_initial_state(shape, seed=0)[0].numpy()
+    traj = torch.empty((T + 1, 2) + shape, device=hip_device)
+    traj[0] = dev_t(h0, hip_device)
+    Pd = dev_t(P, hip_device)
+    pa.rollout_fwd_(traj, Pd)
+    traj_o = O.poly_rollout_fwd(h0, P, T)
+    assert np.array_equal(traj.cpu().numpy(), traj_o)
+    gen = torch.Generator(device=hip_device).manual_seed(1234)
+    gd = torch.randn(traj.shape, device=hip_device, generator=gen) * (2.0 / traj.numel())      # bench.py's dL/dtraj
+    g0, pg = pa.rollout_bwd(traj, gd, Pd)
+    g0_o, pg_o = O.poly_rollout_bwd(traj_o, gd.cpu().numpy(), P)
+    assert np.array_equal(g0.cpu().numpy(), g0_o)
+    assert rel_l2(pg.cpu().numpy(), pg_o) < 5e-5
 
 
 @pytest.mark.parametrize("shape,hc,dtype", [((512, 512), 8, np.float32), ((128, 128, 128), 2, np.float32),

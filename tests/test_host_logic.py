@@ -55,6 +55,10 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.percnn_pi_step_fwd_f64(1, 2, 3, 4, 2, bad, None) == -1
     assert L.percnn_pi_rollout_fwd_f32(1, 2, 8, 2, shape, -1, None) == -1
     assert L.percnn_pi_step_bwd_f32(1, 2, None, 3, 4, None, 0, 5, 8, 2, shape, None) == -2   # no workspace
+    # native slab rollouts: a slab thinner than the exchange width would forward halo planes as data
+    thin = (ctypes.c_int64 * 2)(2, 8)
+    assert L.percnn_pi_slab_rollout_fwd_f32(1, 2, 8, 2, thin, 4, 3, None, 0, None) == -1
+    assert L.percnn_pi_slab_rollout_fwd_f32(1, 2, 8, 2, thin, 2, 0, None, 0, None) == 0       # T = 0: nothing to do
     # Stage-1 block (include/percnn_pi_stage1.h)
     assert L.percnn_pi_s1_param_count() == 5042 == percnn_amd.stage1.NP
     assert L.percnn_pi_s1_step_fwd_f32(None, None, None, shape, None) == -1
@@ -236,6 +240,105 @@ def test_frame_gradient_assembly_zero_copy_and_masked():
     g, mask = Fp._assemble_frame_grads(gr, frames, traj)
     assert mask == [True, False, False, False, True, True]
     assert float(g[0].mean()) == 1.0 and float(g[5].mean()) == 3.0 and float(g[4].mean()) == 4.5
+    # what RCNN.forward really produces for step >= 2: the dense list FOLLOWED by second_last_state (frame T-1).
+    # Extra frame unused (gradient None) -> still the zero-copy view; extra frame used -> one copy, summed, autograd's
+    # buffer left untouched
+    frames = tuple(range(6)) + (4,)
+    g, mask = Fp._assemble_frame_grads(grads + (None,), frames, traj)
+    assert mask is None and g.data_ptr() == dense.data_ptr()
+    before = dense.clone()
+    g, mask = Fp._assemble_frame_grads(grads + (torch.full((1, 2, 4, 4), 0.25),), frames, traj)
+    assert mask is None and g.data_ptr() != dense.data_ptr() and torch.equal(dense, before)
+    assert torch.equal(g[4], dense[4] + 0.25) and torch.equal(g[:4], dense[:4]) and torch.equal(g[5], dense[5])
+
+
+def test_dt_change_after_first_use_is_honoured():
+    """The reference reads self.dt at every step (train_2drd.py:117); the cached device scalar must follow it."""
+    import percnn_amd as pa
+    cell = pa.gs2d_cell(2, reaction="factored")
+    assert float(cell.param_block()[0]) == 0.5
+    cell.dt = 0.25
+    assert float(cell.param_block()[0]) == 0.25
+    cell.reaction = "poly"
+    cell.dt = 0.125
+    assert float(cell.param_block()[0]) == 0.125
+
+
+def _cubic_well_block(a, k, dt, hc=8):
+    """Stable, deliberately ill-conditioned block: r_s = -k (x_s - a)^3 - k (x_s - a)(x_o - a)^2 (gradient flow of a
+    quartic well centred at a).  The factored form subtracts a BEFORE multiplying; the expanded cubic cancels
+    monomials of size a^3 against each other."""
+    P = np.zeros(16 + 2 * (10 * hc + 1))
+    P[0], P[1], P[2], P[3] = dt, 0.02, 0.01, -5.0
+    P[4:8] = P[8:12] = (-1 / 12, 4 / 3, 4 / 3, -1 / 12)
+    for s in range(2):
+        W = P[16 + s * (10 * hc + 1):16 + (s + 1) * (10 * hc + 1)]
+        me, ot = s, 1 - s
+        for kk in range(3):
+            W[3 * kk + me], W[3 * kk + 2] = 1.0, -a
+        W[9] = -k
+        c1 = W[10:20]
+        c1[0 + me], c1[2] = 1.0, -a
+        c1[3 + ot], c1[5] = 1.0, -a
+        c1[6 + ot], c1[8] = 1.0, -a
+        c1[9] = -k
+    return P
+
+
+@pytest.mark.parametrize("a", [0.0, 2.0, 10.0, 50.0])
+def test_poly_conditioning_rule(a):
+    """Evidence for the rule in RCNNCell's docstring (when reaction='factored' is required): on a stable cubic whose
+    monomials cancel, the pre-contracted evaluation loses 0.6 * eps * A of relative state accuracy (A =
+    poly_amplification) while the factored evaluation stays at the float32 noise floor.  Runs on the plain-C oracle,
+    whose per-point arithmetic the HIP kernels reproduce bit for bit (tests/test_hip_parity.py)."""
+    from oracle import pi_oracle as O
+    from percnn_amd import functional as Fp
+    from util import rel_l2
+    P32 = _cubic_well_block(a, 1.0, 0.1).astype(np.float32)
+    P64 = P32.astype(np.float64)
+    Q32 = Fp.contract_block(torch.tensor(P32)).numpy()
+    Q64 = Fp.contract_block(torch.tensor(P64)).numpy()
+    h0 = (a + np.random.RandomState(0).uniform(-1, 1, (2, 48, 48))).astype(np.float32)
+    T = 100
+    t64 = O.rollout_fwd(h0.astype(np.float64), P64, 8, T)
+    tf = O.rollout_fwd(h0, P32, 8, T)
+    tp = O.poly_rollout_fwd(h0, Q32, T)
+    hm = float(np.abs(t64).max())
+    phi = np.array([1, hm, hm, hm * hm, hm * hm, hm * hm, hm ** 3, hm ** 3, hm ** 3, hm ** 3])
+    A = 0.1 * max(float((np.abs(Q64[16 + 10 * s:26 + 10 * s]) * phi).sum()) for s in range(2)) / hm
+    eps = 2.0 ** -24
+    e_fact, e_poly = rel_l2(tf[-1], t64[-1]), rel_l2(tp[-1], t64[-1])
+    assert e_fact < 5e-7, (a, e_fact)                          # factored: noise floor whatever the conditioning
+    assert e_poly < max(5e-7, 2.5 * eps * A), (a, A, e_poly)   # poly: predicted by the amplification
+    if A >= 100:
+        assert e_poly > 0.1 * eps * A and e_poly > 5 * e_fact  # ... and the prediction is tight: the rule is needed
+    if A <= 10:
+        assert e_poly < 1e-6
+
+
+def test_shipped_checkpoints_are_inside_the_poly_rule():
+    """The default reaction='poly' is justified for the weights the reference ships: A ~ 1 or below for states in [0, 1]."""
+    import percnn_amd as pa
+    for f, mk, bound in (("gs2d_ckpt_64x64.npz", pa.gs2d_cell, 2.0), ("gs3d_ckpt_16x16x16.npz", pa.gs3d_cell, 1.0),
+                         ("lo2d_ckpt_64x64.npz", pa.lo2d_cell, 0.2)):
+        g = Golden(os.path.join(GOLDEN, f))
+        cell = mk()
+        cell.load_state_dict({k: torch.tensor(v) for k, v in g.sd.items()})
+        A = cell.poly_amplification(1.0, 1.0)
+        assert 0 < A < bound, (f, A)
+        keep = cell.reaction
+        assert cell.reaction == keep == "poly"
+
+
+def test_exchanger_is_cached_per_group_and_device():
+    """slab_rollout(ex=None) must not create a communicator per call (one exchanger per process / group / transport)."""
+    from percnn_amd import slab
+    a, b = slab.make_exchanger(), slab.make_exchanger()
+    assert a is b
+    c = slab.make_exchanger(force_p2p=True)
+    assert c is not a and c is slab.make_exchanger(force_p2p=True)
+    slab.close_exchangers()
+    assert slab.make_exchanger() is not a
 
 
 def test_3d_upscaler_contraction_path_equals_stock_layers():

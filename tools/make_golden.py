@@ -3,6 +3,7 @@
 
     python tools/make_golden.py            # all small cases  -> tests/golden/*.npz
     python tools/make_golden.py --big      # + 512^2 x1000 and 128^3 x500 statistics (minutes)
+    python tools/make_golden.py --biggrad  # + reference GRADIENTS at 512^2 (T=100), 128^3 (T=20), lambda-omega 512^2 (T=100)
 
 The reference lives read-only at /root/reference and never travels to the GPU box; only
 the data written here (inputs + expected outputs) is committed.  Every case also asserts
@@ -238,6 +239,39 @@ def big_case(case, mod, shape, checkpoints):
     print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
 
 
+def biggrad_case(case, mod, shape, steps, stride_t):
+    """Reference forward + autograd backward at the BASELINE grid size (shorter horizon: the reference's tape is
+    ~80 MB per 512^2 step): both losses, every parameter gradient, an every-8th-point subsample of dL/dh0 and of the
+    last frame.  This is the backward the reference triggers at 2dgs:407 / 3dgs:408 / lo:373, at full spatial size."""
+    import time
+    state, _ = ckpt_cell_state(case)
+    rc = ref_cell(mod, case)
+    rc.load_state_dict(state)
+    ndim = len(shape)
+    sub = (slice(None), slice(None)) + (slice(None, None, 8),) * ndim
+    rec = {"h0_seed": 0, "steps": steps, "stride_t": stride_t}
+    for k, v in rc.state_dict().items():
+        rec["param/" + k] = v.numpy()
+    t0 = time.time()
+    h0 = initial_state(case, shape).requires_grad_(True)
+    tr = run_traj(rc, h0, steps)
+    print(f"   forward {steps} steps ({time.time()-t0:.0f}s)")
+    rec["sub_last"] = tr[-1:].detach()[sub].numpy()
+    rec["l2_last"] = float(torch.linalg.vector_norm(tr[-1].detach().double()))
+    for lname, lf in (("meansq", lambda x: (x ** 2).mean()), ("data", lambda x: data_loss(x, stride_t, ndim))):
+        loss = lf(tr)
+        g, gh = grads_of(loss, rc, h0)
+        rec[f"loss_{lname}"] = loss.item()
+        for n in g:
+            rec[f"grad_{lname}/{n}"] = g[n].numpy()
+        rec[f"grad_{lname}_h0_sub"] = gh[sub].numpy()
+        rec[f"grad_{lname}_h0_l2"] = float(torch.linalg.vector_norm(gh.double()))
+        print(f"   loss {lname} = {loss.item():.9g}, backward done ({time.time()-t0:.0f}s)")
+    fn = os.path.join(OUT, f"{case}_biggrad_{'x'.join(map(str, shape))}.npz")
+    np.savez_compressed(fn, **rec)
+    print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
+
+
 def stage3_lo_case(mod):
     """the Stage-3 physics-based lambda-omega cell (13 trainable scalars, Euler)."""
     from oracle import restatement as R
@@ -369,9 +403,17 @@ def stage1_case(mod, case):
         print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
 
 
-def run_case(case, big):
+def run_case(case, big, biggrad=False):
     mod = import_reference(case)
     torch.set_num_threads(8)
+    if biggrad:
+        if case == "gs2d":
+            biggrad_case(case, mod, (512, 512), 100, 20)
+        elif case == "gs3d":
+            biggrad_case(case, mod, (128, 128, 128), 20, 5)
+        elif case == "lo2d":
+            biggrad_case(case, mod, (512, 512), 100, 20)
+        return
     if case in ("bur1", "lo1"):
         if not big:
             stage1_case(mod, case)
@@ -400,6 +442,8 @@ def run_case(case, big):
         small_case(case, mod, "ckpt", state, (64, 64), 200, [1, 2, 10, 50, 200], 20)
         if case == "gs2d":
             small_case(case, mod, "ckpt", state, (24, 40), 10, [1, 2, 10], 5)   # non-square
+            # BASELINE configs[0]: the reference's own training configuration (2dgs:597-636: 100^2 grid, 200 steps)
+            small_case(case, mod, "ckpt", state, (100, 100), 200, [1, 20, 200], 20)
     else:
         small_case(case, mod, "ckpt", state, (16, 16, 16), 50, [1, 2, 10, 50], 5)
         small_case(case, mod, "fresh", None, (16, 16, 16), 10, [1, 2, 10], 5)
@@ -412,11 +456,13 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--case", choices=list(SCRIPTS))
     ap.add_argument("--big", action="store_true")
+    ap.add_argument("--biggrad", action="store_true", help="full-size reference gradients (512^2 x100, 128^3 x20, lo 512^2 x100)")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     if a.case:
-        run_case(a.case, a.big)
+        run_case(a.case, a.big, a.biggrad)
     else:
-        for c in SCRIPTS:
-            cmd = [sys.executable, os.path.abspath(__file__), "--case", c] + (["--big"] if a.big else [])
+        for c in (("gs2d", "gs3d", "lo2d") if a.biggrad else SCRIPTS):
+            cmd = [sys.executable, os.path.abspath(__file__), "--case", c] + (["--big"] if a.big else []) + \
+                  (["--biggrad"] if a.biggrad else [])
             subprocess.check_call(cmd)
