@@ -15,8 +15,11 @@
  *     [2][*S]; `shape` lists the spatial extents slowest-first (2D: {H, W}; 3D: {D, H, W}).
  *   - Periodic boundaries on every axis (2dgs:108-109, 3dgs:125-127); every extent >= 2.
  *   - Asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream); no host
- *     synchronisation and no allocation inside, hence hipGraph-capturable.  Re-entrant; no
- *     global state except the tuning options below (percnn_pi_set_option) and an internal side stream + events.
+ *     synchronisation and no allocation inside, hence hipGraph-capturable.  Re-entrant: the only
+ *     process-wide mutable state is the table of tuning DEFAULTS (percnn_pi_set_option), copied once, under a
+ *     lock, at the entry of every call; the *_opt entry points overlay per-call overrides on that copy, so
+ *     concurrent calls (threads, models) with different options do not interact.  (Plus a lazily created
+ *     internal side stream + events per device, used by the "overlap" schedules only.)
  *   - Output buffers must not alias inputs.
  *   - Return value: 0 on success, otherwise a hipError_t cast to int, or one of the negative
  *     PERCNN_PI_E* codes for argument errors.  No C++ exceptions cross this boundary.
@@ -90,7 +93,8 @@ size_t percnn_pi_bwd_workspace_bytes(int hc, int ndim, const int64_t *shape, int
  * (T+1 frames of [2][*S]) + per-workgroup gradient partials. */
 size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *shape, int T, int elem_size);
 
-/* Tuning / diagnostic options (process-wide).  Every setting computes the same values (state fields bit-identical,
+/* Tuning / diagnostic options: process-wide DEFAULTS (see the *_opt entry points at the end of this header for per-call
+ * overrides).  Every setting computes the same values (state fields bit-identical,
  * gradient sums to reduction round-off); defaults are what measured fastest on MI355X:
  *   "block"        workgroup size of the per-step direct kernels (64..256, multiple of 64; default 256)
  *   "vec"          1 = one point per lane instead of 16 bytes per lane
@@ -283,6 +287,35 @@ int percnn_pi_residual_bwd_f32(const float *traj, const float *g_resid, float *g
                                int ndim, const int64_t *shape, int nframes, void *stream);
 int percnn_pi_residual_bwd_f64(const double *traj, const double *g_resid, double *g_state, const double *params,
                                int ndim, const int64_t *shape, int nframes, void *stream);
+
+/* ---- per-call tuning overrides -----------------------------------------------------------------------------------
+ * The four calls above that training / inference loops issue, with an `options` string "key=value,key=value" (keys of
+ * percnn_pi_set_option; NULL or "" = the process defaults).  The overrides apply to THIS call only and are never
+ * written back, so two models (or two threads) can run with different settings.  Returns PERCNN_PI_EINVAL for a
+ * malformed string, an unknown key or a bad value.  Same reference calls as their namesakes: RCNNCell.forward
+ * (2dgs:105-121), its autograd backward (2dgs:407), RCNN.forward's loop (2dgs:162-190) and its backward. */
+int percnn_pi_step_fwd_opt_f32(const float *h, float *out, const float *params, int hc, int ndim,
+                               const int64_t *shape, const char *options, void *stream);
+int percnn_pi_step_fwd_opt_f64(const double *h, double *out, const double *params, int hc, int ndim,
+                               const int64_t *shape, const char *options, void *stream);
+int percnn_pi_step_bwd_opt_f32(const float *h, const float *g_out, const float *g_inject, float *g_in,
+                               double *param_grad, void *workspace, size_t workspace_bytes, const float *params,
+                               int hc, int ndim, const int64_t *shape, const char *options, void *stream);
+int percnn_pi_step_bwd_opt_f64(const double *h, const double *g_out, const double *g_inject, double *g_in,
+                               double *param_grad, void *workspace, size_t workspace_bytes, const double *params,
+                               int hc, int ndim, const int64_t *shape, const char *options, void *stream);
+int percnn_pi_rollout_fwd_opt_f32(float *traj, const float *params, int hc, int ndim, const int64_t *shape,
+                                  int T, const char *options, void *stream);
+int percnn_pi_rollout_fwd_opt_f64(double *traj, const double *params, int hc, int ndim, const int64_t *shape,
+                                  int T, const char *options, void *stream);
+int percnn_pi_rollout_bwd_opt_f32(const float *traj, const float *g_traj, const unsigned char *frame_mask,
+                                  float *g_h0, double *param_grad, void *workspace, size_t workspace_bytes,
+                                  const float *params, int hc, int ndim, const int64_t *shape, int T,
+                                  const char *options, void *stream);
+int percnn_pi_rollout_bwd_opt_f64(const double *traj, const double *g_traj, const unsigned char *frame_mask,
+                                  double *g_h0, double *param_grad, void *workspace, size_t workspace_bytes,
+                                  const double *params, int hc, int ndim, const int64_t *shape, int T,
+                                  const char *options, void *stream);
 
 #ifdef __cplusplus
 }

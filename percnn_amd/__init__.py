@@ -7,7 +7,8 @@ update, their adjoint, and the T-step rollout -- as hand-written HIP kernels beh
 
 Layout:  ``csrc/`` HIP kernels + the C-ABI translation units (pi_abi.hip: base block, slabs, physics residual;
 pi_s1_abi.hip: Stage-1 block on the matrix cores; pi_up3d_abi.hip: 3D IC-generator contraction) ->
-``libpercnn_pi.so``;  ``_lib`` ctypes binding + build;  ``functional`` autograd front-end;  ``modules`` the reference's
+``libpercnn_pi.so``;  ``_lib`` ctypes binding + build;  ``ops`` the registered ``torch.ops.percnn.*`` operators;
+``functional`` raw calls + autograd front-end;  ``modules`` the reference's
 module interface;  ``stage1`` the Stage-1 cell;  ``slab`` multi-GPU slab decomposition;  ``physics`` physics-residual
 loss;  ``synthetic`` initial states for benchmarks / tests.
 """
@@ -16,6 +17,7 @@ from .functional import (pi_step, pi_rollout, pack_params, contract_block, param
                          step_fwd, step_bwd, PiStepFunction, PiRolloutFunction)
 from .modules import RCNNCell, RCNN, Upscaler, Stage3LambdaOmegaCell, Stage3BurgersCell, gs2d_cell, gs3d_cell, lo2d_cell, laplace_stencil  # noqa: F401
 
+from . import ops  # noqa: F401  (registers torch.ops.percnn.*)
 from . import slab, synthetic, physics, stage1  # noqa: F401
 from .stage1 import Stage1Cell  # noqa: F401
 

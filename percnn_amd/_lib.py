@@ -29,7 +29,8 @@ EXPORTS = [
 ] + [f"percnn_pi_{op}_{suf}" for suf in ("f32", "f64")
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
                 "slab_step_fwd_range", "slab_step_bwd_range", "slab_rollout_fwd", "slab_rollout_bwd", "residual_fwd",
-                "residual_bwd", "contract_fwd", "contract_bwd")] + [
+                "residual_bwd", "contract_fwd", "contract_bwd", "step_fwd_opt", "step_bwd_opt", "rollout_fwd_opt",
+                "rollout_bwd_opt")] + [
     "percnn_pi_s1_param_count", "percnn_pi_s1_step_fwd_f32", "percnn_pi_s1_rollout_fwd_f32",
     "percnn_pi_s1_rollout_bwd_workspace_bytes", "percnn_pi_s1_rollout_bwd_f32", "percnn_pi_s1_set_option",
     "percnn_pi_conv3d_k5c8_f32", "percnn_pi_conv3d_k5c8_wgrad_workspace_bytes", "percnn_pi_conv3d_k5c8_wgrad_f32",
@@ -131,6 +132,15 @@ def lib() -> ctypes.CDLL:
         f.restype, f.argtypes = ci, [vp, vp, ci, ci, i64p, ci, vp]
         f = getattr(L, f"percnn_pi_rollout_bwd_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, ctypes.c_char_p, vp, vp, vp, sz, vp, ci, ci, i64p, ci, vp]
+        cs = ctypes.c_char_p
+        f = getattr(L, f"percnn_pi_step_fwd_opt_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, vp, ci, ci, i64p, cs, vp]
+        f = getattr(L, f"percnn_pi_step_bwd_opt_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, vp, vp, vp, vp, sz, vp, ci, ci, i64p, cs, vp]
+        f = getattr(L, f"percnn_pi_rollout_fwd_opt_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, ci, ci, i64p, ci, cs, vp]
+        f = getattr(L, f"percnn_pi_rollout_bwd_opt_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, cs, vp, vp, vp, sz, vp, ci, ci, i64p, ci, cs, vp]
     L.percnn_pi_s1_param_count.restype = sz
     L.percnn_pi_s1_param_count.argtypes = []
     L.percnn_pi_s1_step_fwd_f32.restype, L.percnn_pi_s1_step_fwd_f32.argtypes = ci, [vp, vp, vp, i64p, vp]
@@ -167,4 +177,15 @@ def shape_arg(shape):
 
 
 def set_option(key: str, value: int) -> None:
+    """Process-wide DEFAULT of a tuning option (include/percnn_pi.h); per-call overrides: the ``options`` argument of
+    ``functional.rollout_fwd_/rollout_bwd/step_fwd/step_bwd`` and of the ``torch.ops.percnn`` operators."""
     check(lib().percnn_pi_set_option(key.encode(), int(value)), f"set_option({key}={value})")
+
+
+def options_arg(options) -> bytes | None:
+    """dict / "k=v,k=v" string / None -> the `options` C string of the *_opt entry points"""
+    if not options:
+        return None
+    if isinstance(options, str):
+        return options.encode()
+    return ",".join(f"{k}={int(v)}" for k, v in options.items()).encode()

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "../../include/percnn_pi.h"
 #include "pi_kernels.h"
@@ -42,7 +44,13 @@ struct Options {
     int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
                             // small grid is spread over all CUs instead of being packed onto a few
 };
-Options g_opt;
+// The ONLY process-wide mutable state of the library: the table of tuning defaults.  Every entry point copies it once,
+// under the lock, into its Problem (p.opt), overlays the call's own overrides ("key=value,..." of the *_opt entry
+// points) and reads nothing else afterwards -- concurrent calls with different options do not interact.
+Options g_defaults;
+std::mutex g_defaults_mu;
+int apply_option(Options& o, const char* key, long value);
+int apply_overrides(Options& o, const char* spec);
 
 template <typename F>
 hipError_t allow_lds(F* f, size_t bytes)
@@ -88,10 +96,16 @@ struct Problem {
     int halo = 2;       // slab layout: planes present on each side of axis 0 (even, >= 2)
     int skip = 0;       // slab layout: outermost planes per side that this call neither reads nor writes
     int lo = -1, hi = -1;   // slab layout, plane-range calls: padded plane indices [lo, hi) this call computes
+    Options opt;            // this call's tuning options: process defaults at entry + per-call overrides
 };
 
-int make_problem(int hc, int ndim, const int64_t* shape, bool slab, Problem& p)
+int make_problem(int hc, int ndim, const int64_t* shape, bool slab, Problem& p, const char* overrides = nullptr)
 {
+    {
+        std::lock_guard<std::mutex> lk(g_defaults_mu);
+        p.opt = g_defaults;
+    }
+    if (int rc = apply_overrides(p.opt, overrides)) return rc;
     if (!shape || (ndim != 2 && ndim != 3) || hc < -1 || hc > 64) return PERCNN_PI_EINVAL;   // hc == 0: poly, -1: advective
     if (hc == -1 && slab) return PERCNN_PI_EINVAL;
     for (int a = 0; a < ndim; ++a)
@@ -154,7 +168,7 @@ template <typename T>
 int pick_vec(const Problem& p, std::initializer_list<const void*> ptrs)
 {
     constexpr int V = pi::vec_width<T>::value;
-    if (g_opt.vec == 1) return 1;
+    if (p.opt.vec == 1) return 1;
     if (p.W % V) return 1;
     for (const void* q : ptrs)
         if (q && (reinterpret_cast<uintptr_t>(q) % 16)) return 1;
@@ -168,20 +182,20 @@ hipError_t launch_fwd(const T* h, T* out, const T* P, const Problem& p, hipStrea
     Geom g = make_geom(p);
     set_fastdiv(g, VEC);
     const long nchunks = (long)g.rows * (g.W / VEC);
-    const int block = g_opt.block;
+    const int block = p.opt.block;
     const unsigned grid = (unsigned)((nchunks + block - 1) / block);
     if (nchunks <= 0) return hipSuccess;
     auto* k = pi::pi_fwd_kernel<T, NDIM, HC, VEC>;
-    if (hipError_t e = allow_lds(k, (size_t)g_opt.lds_pad)) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(block), (size_t)g_opt.lds_pad, st, h, out, P, g, p.hc);
+    if (hipError_t e = allow_lds(k, (size_t)p.opt.lds_pad)) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(block), (size_t)p.opt.lds_pad, st, h, out, P, g, p.hc);
     return hipGetLastError();
 }
 
 unsigned bwd_grid(const Problem& p, int vec)
 {
     const long nchunks = (long)make_geom(p).rows * (p.W / vec);
-    long need = (nchunks + g_opt.block - 1) / g_opt.block;
-    if (g_opt.bwd_cpl > 1 && need >= 512L * g_opt.bwd_cpl) need = (need + g_opt.bwd_cpl - 1) / g_opt.bwd_cpl;   // chunks per lane
+    long need = (nchunks + p.opt.block - 1) / p.opt.block;
+    if (p.opt.bwd_cpl > 1 && need >= 512L * p.opt.bwd_cpl) need = (need + p.opt.bwd_cpl - 1) / p.opt.bwd_cpl;   // chunks per lane
     return (unsigned)(need < MAX_BWD_BLOCKS ? need : MAX_BWD_BLOCKS);
 }
 
@@ -191,10 +205,10 @@ hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* parti
 {
     Geom g = make_geom(p);
     set_fastdiv(g, VEC);
-    const int block = g_opt.block;
+    const int block = p.opt.block;
     const unsigned grid = bwd_grid(p, VEC);
     const size_t lds = align_up((size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T), 16) +
-                       (size_t)(block / pi::WAVE) * 2 * sizeof(double) + (size_t)g_opt.lds_pad;
+                       (size_t)(block / pi::WAVE) * 2 * sizeof(double) + (size_t)p.opt.lds_pad;
     auto* k = pi::pi_bwd_kernel<T, NDIM, HC, VEC, WGRAD>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, st, h, G, inj, Gp, partials, P, g, p.hc);
@@ -221,7 +235,7 @@ hipError_t launch_wgrad(const T* traj, const T* adj, double* partials, const T* 
 {
     const long total = (long)(t_hi - t_lo) * (p.n / VEC);
     long nb = (total + 256L * 16 - 1) / (256L * 16);          // >= 16 chunks per lane before adding blocks
-    if (nb > g_opt.wgrad_blocks) nb = g_opt.wgrad_blocks;
+    if (nb > p.opt.wgrad_blocks) nb = p.opt.wgrad_blocks;
     if (nb < 1) nb = 1;
     *rows_out = (unsigned)(2 * nb);
     if (p.hc == 0) {                                           // pre-contracted mode: coefficient moments
@@ -301,17 +315,17 @@ constexpr int STREAM_TY = 4;
 template <typename T>
 int stream3d_vec(const Problem& p, std::initializer_list<const void*> ptrs)
 {
-    if (!g_opt.stream3d || p.ndim != 3) return 0;
+    if (!p.opt.stream3d || p.ndim != 3) return 0;
     // measured on MI355X: the plane-streaming kernels win from ~4M points per rank upwards (256^3: 4.1 vs
     // 2.7 TB/s forward); at 128^3 there are too few waves to cover their per-plane barrier chain.
     // Rows as wide as a full 16-B/lane wave (W = 256 fp32 -- the 32 x 256^2 slabs of the 8-GPU 256^3 problem) win
     // from ~2M points already (slab rollout 69 -> 63 us per step).
     // (plane-range calls are judged by the whole local slab -- the range in between the faces is most of it -- except
     // the few-plane faces themselves, which are not worth a z-march)
-    if (p.lo >= 0 && p.hi - p.lo < 8 && g_opt.stream3d == 1) return 0;
+    if (p.lo >= 0 && p.hi - p.lo < 8 && p.opt.stream3d == 1) return 0;
     const int64_t pts = (p.n0 + (p.slab ? 2 * p.halo : 0)) * p.n1 * p.W;
     const bool full_width = p.W == (int64_t)pi::WAVE * pi::vec_width<T>::value;
-    if (g_opt.stream3d == 1 && pts < ((int64_t)(full_width ? 2 : 3) << 20)) return 0;
+    if (p.opt.stream3d == 1 && pts < ((int64_t)(full_width ? 2 : 3) << 20)) return 0;
     if (p.hc != 0 && p.hc != 2 && p.hc != 4 && p.hc != 8) return 0;
     if (p.n1 % STREAM_TY) return 0;
     int vec = 0;
@@ -325,7 +339,7 @@ int stream3d_vec(const Problem& p, std::initializer_list<const void*> ptrs)
 
 inline int stream3d_zc(const Problem& p, const Geom& g, bool adj)
 {
-    int zc = adj ? 2 * g_opt.zc : g_opt.zc;               // the heavier adjoint body amortises its prologue over more planes
+    int zc = adj ? 2 * p.opt.zc : p.opt.zc;               // the heavier adjoint body amortises its prologue over more planes
     const long ytiles = p.n1 / STREAM_TY;
     while ((long)((g.n0 + zc - 1) / zc) * ytiles > MAX_BWD_BLOCKS) zc *= 2;
     return zc;
@@ -406,8 +420,8 @@ constexpr int TILE_B = 32;
 int tile_by_for(const Problem& p)
 {
     if (p.hc != 0) return TILE_B;
-    if (g_opt.tile_by == 16 || g_opt.tile_by == 32) return g_opt.tile_by;
-    if (g_opt.tile_k != 4 || g_opt.tile_nt != 512) return TILE_B;
+    if (p.opt.tile_by == 16 || p.opt.tile_by == 32) return p.opt.tile_by;
+    if (p.opt.tile_k != 4 || p.opt.tile_nt != 512) return TILE_B;
     const int64_t tiles32 = ((p.n0 + TILE_B - 1) / TILE_B) * ((p.W + TILE_B - 1) / TILE_B);
     return tiles32 <= 128 ? 16 : TILE_B;
 }
@@ -415,7 +429,7 @@ int tile_by_for(const Problem& p)
 template <typename T>
 bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs)
 {
-    if (!g_opt.tile || g_opt.vec == 1 || p.ndim != 2 || p.slab) return false;
+    if (!p.opt.tile || p.opt.vec == 1 || p.ndim != 2 || p.slab) return false;
     if (p.hc != 0 && p.hc != 2 && p.hc != 4 && p.hc != 8) return false;
     // ragged grids (e.g. the reference's 100^2) run with partial edge tiles; the window must not wrap onto itself
     auto fits = [](int64_t n) { return (n + TILE_B - 1) / TILE_B * TILE_B + 16 <= 2 * n; };   // one wrap per window coordinate
@@ -426,7 +440,7 @@ bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs)
     if (((p.n0 + by - 1) / by) * ((p.W + TILE_B - 1) / TILE_B) > MAX_BWD_BLOCKS) return false;
     // temporal blocking pays while launches are latency-bound; from ~1 M points the halo ring's redundant traffic
     // costs more than the launches it saves (measured: profiles/r01_size_sweep.txt), tile = 2 forces the tile path
-    if (g_opt.tile == 1 && p.n >= (1 << 20)) return false;
+    if (p.opt.tile == 1 && p.n >= (1 << 20)) return false;
     for (const void* q : ptrs)
         if (q && (reinterpret_cast<uintptr_t>(q) % 16)) return false;
     return true;
@@ -438,7 +452,7 @@ pi::TileGeom make_tile_geom(const Problem& p, int by)
 {
     const int tiles_x = (int)((p.W + TILE_B - 1) / TILE_B), tiles_y = (int)((p.n0 + by - 1) / by);
     pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, tiles_x, 0, 0, 0};
-    if (!g_opt.tile_xcd) return g;
+    if (!p.opt.tile_xcd) return g;
     int best = -1;
     for (int rx : {1, 2, 4, 8}) {
         const int ry = pi::NXCD / rx;
@@ -456,7 +470,7 @@ hipError_t launch_fwd_tile(T* frame_t, const T* P, const Problem& p, hipStream_t
     using TL = pi::Tile<K, TILE_B, BY>;
     const pi::TileGeom g = make_tile_geom(p, BY);
     const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
-    const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + 32 /* lds_pad0/1 */ + (size_t)g_opt.lds_pad;
+    const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + 32 /* lds_pad0/1 */ + (size_t)p.opt.lds_pad;
     auto* k = pi::pi_fwd2d_tile_kernel<T, HC, K, TILE_B, BY, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, frame_t, (long)(2 * p.n), P, g);
@@ -470,7 +484,7 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
     using TL = pi::Tile<K, TILE_B, BY>;
     const pi::TileGeom g = make_tile_geom(p, BY);
     const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
-    const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + 32 /* lds_pad0/1 */ + (size_t)g_opt.lds_pad;
+    const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + 32 /* lds_pad0/1 */ + (size_t)p.opt.lds_pad;
     auto* k = pi::pi_adj2d_tile_kernel<T, HC, K, TILE_B, BY, NT, MOM>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, hframe_t, gframe_t, aframe_t, (long)(2 * p.n), inj_mask, g_h0,
@@ -480,13 +494,13 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
 
 #define PI_TILE_VARIANTS(CALL, HC)                                              \
     do {                                                                        \
-        if (g_opt.tile_k == 2) return CALL(HC, 2, 256);                         \
+        if (p.opt.tile_k == 2) return CALL(HC, 2, 256);                         \
         if constexpr (HC == pi::POLY) {                                         \
-            if (g_opt.tile_k == 8) return CALL(HC, 8, 1024);                    \
-            if (g_opt.tile_nt == 1024) return CALL(HC, 4, 1024);                \
+            if (p.opt.tile_k == 8) return CALL(HC, 8, 1024);                    \
+            if (p.opt.tile_nt == 1024) return CALL(HC, 4, 1024);                \
             if (tile_by_for(p) == 16) return CALL(HC, 4, 320, 16);              \
         }                                                                       \
-        if (g_opt.tile_nt == 256) return CALL(HC, 4, 256);                      \
+        if (p.opt.tile_nt == 256) return CALL(HC, 4, 256);                      \
         return CALL(HC, 4, 512);                                                \
     } while (0)
 #define PI_TILE_DISPATCH(CALL)                                                  \
@@ -514,8 +528,8 @@ bool tile_fuse_ok(const Problem& p)
     // measured on MI355X (backward us per step, split -> fused): 384^2 3.37 -> 3.20, 512^2 3.90 -> 3.29, 1000^2 13.4 -> 11.3;
     // in the 16-row-tile regime (<= 128 tiles of 32x32, e.g. the reference's 100^2) the extra VALU work sits on the one
     // critical workgroup chain and loses (2.26 -> 2.66), so it keeps the split schedule
-    return g_opt.tile_fuse && !g_opt.skip_wgrad && sizeof(T) == 4 && p.hc == 0 && g_opt.tile_k == 4 &&
-           g_opt.tile_nt == 512 && tile_by_for(p) == TILE_B;
+    return p.opt.tile_fuse && !p.opt.skip_wgrad && sizeof(T) == 4 && p.hc == 0 && p.opt.tile_k == 4 &&
+           p.opt.tile_nt == 512 && tile_by_for(p) == TILE_B;
 }
 
 template <typename T>
@@ -594,10 +608,10 @@ int slab_step_fwd_range_impl(const T* h, T* out, const T* P, int hc, int ndim, c
 
 template <typename T>
 int step_fwd_impl(const T* h, T* out, const T* P, int hc, int ndim, const int64_t* shape, void* stream, bool slab,
-                  int halo = 2, int skip = 0)
+                  int halo = 2, int skip = 0, const char* options = nullptr)
 {
     Problem p;
-    if (int rc = make_problem(hc, ndim, shape, slab, p)) return rc;
+    if (int rc = make_problem(hc, ndim, shape, slab, p, options)) return rc;
     if (slab) if (int rc = set_slab(p, halo, skip)) return rc;
     if (!h || !out || !P || h == out) return PERCNN_PI_EINVAL;
     return (int)step_fwd<T>(h, out, P, p, static_cast<hipStream_t>(stream));
@@ -606,10 +620,10 @@ int step_fwd_impl(const T* h, T* out, const T* P, int hc, int ndim, const int64_
 template <typename T>
 int step_bwd_impl(const T* h, const T* g_out, const T* g_inj, T* g_in, double* param_grad, void* ws, size_t ws_bytes,
                   const T* P, int hc, int ndim, const int64_t* shape, void* stream, bool slab, int halo = 2,
-                  int flags = 0, int lo = -1, int hi = -1)
+                  int flags = 0, int lo = -1, int hi = -1, const char* options = nullptr)
 {
     Problem p;
-    if (int rc = make_problem(hc, ndim, shape, slab, p)) return rc;
+    if (int rc = make_problem(hc, ndim, shape, slab, p, options)) return rc;
     if (slab) {
         if (lo >= 0) { if (int rc = set_slab_range(p, halo, lo, hi)) return rc; }
         else if (int rc = set_slab(p, halo, halo - 2)) return rc;     // adjoint: interior planes only
@@ -647,7 +661,7 @@ int slab_wgrad_impl(const T* traj, const T* adj, double* param_grad, void* ws, s
     if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
     unsigned rows = 0;
     const Geom g = make_geom(p);
-    const bool vec_ok = (p.W % pi::vec_width<T>::value == 0) && g_opt.vec != 1 &&
+    const bool vec_ok = (p.W % pi::vec_width<T>::value == 0) && p.opt.vec != 1 &&
                         (reinterpret_cast<uintptr_t>(traj) % 16 == 0) && (reinterpret_cast<uintptr_t>(adj) % 16 == 0);
     hipError_t e = vec_ok ? launch_wgrad<T, pi::vec_width<T>::value>(traj, adj, w.partials, P, p, 0, T_steps, &rows, st)
                           : launch_wgrad<T, 1>(traj, adj, w.partials, P, p, 0, T_steps, &rows, st);
@@ -785,7 +799,7 @@ int slab_rollout_bwd_impl(const T* traj, const T* g_traj, T* adj, double* param_
     SideStream* side = overlap && n >= 4 ? side_stream() : nullptr;
     hipEvent_t pending = nullptr;
     // float32 poly mode: the 20 coefficient moments are reduced inside the sweep launches (no slab_wgrad pass)
-    const bool fuse = hc == 0 && sizeof(T) == 4 && g_opt.fuse_wgrad != 0;
+    const bool fuse = hc == 0 && sizeof(T) == 4 && p.opt.fuse_wgrad != 0;
     auto sweep = [&](int t, int lo, int hi) -> int {        // adjoint planes [lo, hi) of frame t-1 from frame t
         Problem q = p;
         if (int rc = set_slab_range(q, halo, lo, hi)) return rc;
@@ -818,16 +832,17 @@ int slab_rollout_bwd_impl(const T* traj, const T* g_traj, T* adj, double* param_
 }
 
 template <typename T>
-int rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* shape, int T_steps, void* stream)
+int rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* shape, int T_steps, void* stream,
+                     const char* options = nullptr)
 {
     Problem p;
-    if (int rc = make_problem(hc, ndim, shape, false, p)) return rc;
+    if (int rc = make_problem(hc, ndim, shape, false, p, options)) return rc;
     if (!traj || !P || T_steps < 0) return PERCNN_PI_EINVAL;
     auto st = static_cast<hipStream_t>(stream);
     const size_t frame = (size_t)2 * p.n;
     int t = 0;
     if (tile_eligible<T>(p, {traj})) {
-        const int K = (g_opt.tile_k == 8 && p.hc != 0) ? 4 : g_opt.tile_k;
+        const int K = (p.opt.tile_k == 8 && p.hc != 0) ? 4 : p.opt.tile_k;
         for (; t + K <= T_steps; t += K)
             if (hipError_t e = fwd_tile<T>(traj + (size_t)t * frame, P, p, st)) return (int)e;
     }
@@ -843,10 +858,11 @@ size_t rollout_workspace_bytes(const Problem& p, int T_steps, int elem)
 
 template <typename T>
 int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, T* g_h0, double* param_grad, void* ws,
-                     size_t ws_bytes, const T* P, int hc, int ndim, const int64_t* shape, int T_steps, void* stream)
+                     size_t ws_bytes, const T* P, int hc, int ndim, const int64_t* shape, int T_steps, void* stream,
+                     const char* options = nullptr)
 {
     Problem p;
-    if (int rc = make_problem(hc, ndim, shape, false, p)) return rc;
+    if (int rc = make_problem(hc, ndim, shape, false, p, options)) return rc;
     if (!traj || !g_traj || !g_h0 || !param_grad || !P || T_steps < 0) return PERCNN_PI_EINVAL;
     if (!ws || ws_bytes < rollout_workspace_bytes(p, T_steps, sizeof(T)) || (reinterpret_cast<uintptr_t>(ws) % 16))
         return PERCNN_PI_EWORKSPACE;
@@ -875,7 +891,7 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     // 1) sequential reverse sweep: adjoint states (+ diffusion-coefficient gradients), with
     // 2) the time-parallel branch-gradient reduction of every finished chunk of steps running UNDER it on a side
     //    stream (the sweep is latency-bound, the reduction HBM-bound); partial rows are disjoint columns.
-    const bool vec_ok = (p.n % pi::vec_width<T>::value == 0) && g_opt.vec != 1 &&
+    const bool vec_ok = (p.n % pi::vec_width<T>::value == 0) && p.opt.vec != 1 &&
                         (reinterpret_cast<uintptr_t>(traj) % 16 == 0);
     // fused gradient reduction only where the per-step direct kernels sweep EVERY step (no tile launches, no plane
     // streaming): the other kernel families have no fused flavour
@@ -884,24 +900,24 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     const bool direct_sweep = !tile_eligible<T>(p, {traj, g_traj, g_h0, adj}) &&
                               (f32poly || !stream3d_vec<T>(p, {traj, g_traj, g_h0, adj}));
     const bool tile_fused = !direct_sweep && tile_eligible<T>(p, {traj, g_traj, g_h0, adj}) && tile_fuse_ok<T>(p);
-    const bool fuse = tile_fused || (direct_sweep && !g_opt.skip_wgrad && hc != -1 &&
-                                     (g_opt.fuse_wgrad == 1 || (g_opt.fuse_wgrad == 2 && f32poly)));
+    const bool fuse = tile_fused || (direct_sweep && !p.opt.skip_wgrad && hc != -1 &&
+                                     (p.opt.fuse_wgrad == 1 || (p.opt.fuse_wgrad == 2 && f32poly)));
     unsigned rows = 0, wrows = 0;
     auto reduce_range = [&](int lo, int hi, hipStream_t s2) -> hipError_t {      // steps (lo, hi]
-        if (hi <= lo || g_opt.skip_wgrad || fuse) return hipSuccess;
+        if (hi <= lo || p.opt.skip_wgrad || fuse) return hipSuccess;
         unsigned r = 0;
         hipError_t e = vec_ok ? launch_wgrad<T, pi::vec_width<T>::value>(traj, adj, w.partials, P, p, lo, hi, &r, s2)
                               : launch_wgrad<T, 1>(traj, adj, w.partials, P, p, lo, hi, &r, s2);
         if (r > wrows) wrows = r;
         return e;
     };
-    SideStream* ss = (g_opt.overlap && !g_opt.skip_wgrad && !fuse && t_top >= 2 * g_opt.overlap_chunk)
+    SideStream* ss = (p.opt.overlap && !p.opt.skip_wgrad && !fuse && t_top >= 2 * p.opt.overlap_chunk)
                          ? side_stream() : nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (ss && (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) ss = nullptr;
     int reduced_above = t_top;                       // steps (reduced_above, t_top] are already handed to the reduction
     auto hand_over = [&](int t_done) -> hipError_t { // adj frames > t_done ... are final: reduce steps (t_done, reduced_above]
-        if (!ss || reduced_above - t_done < g_opt.overlap_chunk) return hipSuccess;
+        if (!ss || reduced_above - t_done < p.opt.overlap_chunk) return hipSuccess;
         hipEvent_t ev = ss->ev[ss->next++ % 8];
         if (hipError_t e = hipEventRecord(ev, st)) return e;
         if (hipError_t e = hipStreamWaitEvent(ss->stream, ev, 0)) return e;
@@ -916,7 +932,7 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     }
     int t_cur = t_top;
     if (tile_eligible<T>(p, {traj, g_traj, g_h0, adj})) {
-        const int K = (g_opt.tile_k == 8 && p.hc != 0) ? 4 : g_opt.tile_k;
+        const int K = (p.opt.tile_k == 8 && p.hc != 0) ? 4 : p.opt.tile_k;
         {
             const int by = tile_by_for(p);
             rows = (unsigned)(((p.n0 + by - 1) / by) * ((p.W + TILE_B - 1) / TILE_B));
@@ -942,7 +958,7 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
         if (r2 > rows) rows = r2;
         if (hipError_t e2 = hand_over(t - 1)) return (int)e2;
     }
-    if (g_opt.skip_wgrad || hc == -1 || fuse)
+    if (p.opt.skip_wgrad || hc == -1 || fuse)
         return (int)finish_grads(w, rows, hc, param_grad, st);
     if (ss) {
         // remaining steps (0, reduced_above] on the side stream too (ordered behind the earlier chunks), then join
@@ -985,6 +1001,106 @@ int residual_impl(const T* traj, const T* G, T* out, const T* Q, int ndim, const
 }
 
 }  // namespace
+
+namespace {
+
+int apply_option(Options& o, const char* key, long value)
+{
+    if (!key) return PERCNN_PI_EINVAL;
+    if (!std::strcmp(key, "vec")) {
+        if (value != 0 && value != 1) return PERCNN_PI_EINVAL;
+        o.vec = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "tile")) {                       // 0 = never, 1 = size heuristic, 2 = whenever eligible
+        if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
+        o.tile = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "tile_xcd")) { o.tile_xcd = value != 0; return 0; }
+    if (!std::strcmp(key, "tile_by")) {
+        if (value != 0 && value != 16 && value != 32) return PERCNN_PI_EINVAL;
+        o.tile_by = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "skip_wgrad")) { o.skip_wgrad = value != 0; return 0; }
+    if (!std::strcmp(key, "fuse_wgrad")) {
+        if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
+        o.fuse_wgrad = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "overlap")) { o.overlap = value != 0; return 0; }
+    if (!std::strcmp(key, "overlap_chunk")) {
+        if (value < 1 || value > (1 << 20)) return PERCNN_PI_EINVAL;
+        o.overlap_chunk = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "tile_fuse")) { o.tile_fuse = value != 0; return 0; }
+    if (!std::strcmp(key, "bwd_cpl")) {
+        if (value < 1 || value > 16) return PERCNN_PI_EINVAL;
+        o.bwd_cpl = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "stream3d")) {                         // 0 = never, 1 = size heuristic, 2 = whenever eligible
+        if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
+        o.stream3d = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "zc")) {
+        if (value < 1 || value > 1024) return PERCNN_PI_EINVAL;
+        o.zc = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "lds_pad")) {
+        if (value < 0 || value > 80 * 1024 || value % 16) return PERCNN_PI_EINVAL;
+        o.lds_pad = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "tile_k")) {
+        if (value != 2 && value != 4 && value != 8) return PERCNN_PI_EINVAL;   // 8: poly mode only (else 4)
+        o.tile_k = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "tile_nt")) {
+        if (value != 256 && value != 512 && value != 1024) return PERCNN_PI_EINVAL;   // 1024: poly mode only
+        o.tile_nt = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "wgrad_blocks")) {
+        if (value < 1 || value > MAX_BWD_BLOCKS / 2) return PERCNN_PI_EINVAL;
+        o.wgrad_blocks = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "block")) {
+        if (value < 64 || value > 256 || value % 64) return PERCNN_PI_EINVAL;
+        o.block = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "graph")) return value == 0 ? 0 : PERCNN_PI_EINVAL;   // reserved
+    return PERCNN_PI_EINVAL;
+}
+
+// "key=value,key=value" (whitespace-free); empty / NULL = no overrides
+int apply_overrides(Options& o, const char* spec)
+{
+    if (!spec) return 0;
+    char key[32];
+    while (*spec) {
+        const char* eq = std::strchr(spec, '=');
+        if (!eq || eq == spec || (size_t)(eq - spec) >= sizeof(key)) return PERCNN_PI_EINVAL;
+        std::memcpy(key, spec, (size_t)(eq - spec));
+        key[eq - spec] = 0;
+        char* end = nullptr;
+        const long v = std::strtol(eq + 1, &end, 10);
+        if (end == eq + 1 || (*end && *end != ',')) return PERCNN_PI_EINVAL;
+        if (int rc = apply_option(o, key, v)) return rc;
+        spec = *end ? end + 1 : end;
+    }
+    return 0;
+}
+
+}  // namespace
+
 
 // ---- exported symbols ---------------------------------------------------------------------------
 extern "C" {
@@ -1039,78 +1155,8 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t* sh
 
 int percnn_pi_set_option(const char* key, long value)
 {
-    if (!key) return PERCNN_PI_EINVAL;
-    if (!std::strcmp(key, "vec")) {
-        if (value != 0 && value != 1) return PERCNN_PI_EINVAL;
-        g_opt.vec = (int)value;
-        return 0;
-    }
-    if (!std::strcmp(key, "tile")) {                       // 0 = never, 1 = size heuristic, 2 = whenever eligible
-        if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
-        g_opt.tile = (int)value;
-        return 0;
-    }
-    if (!std::strcmp(key, "tile_xcd")) { g_opt.tile_xcd = value != 0; return 0; }
-    if (!std::strcmp(key, "tile_by")) {
-        if (value != 0 && value != 16 && value != 32) return PERCNN_PI_EINVAL;
-        g_opt.tile_by = (int)value;
-        return 0;
-    }
-    if (!std::strcmp(key, "skip_wgrad")) { g_opt.skip_wgrad = value != 0; return 0; }
-    if (!std::strcmp(key, "fuse_wgrad")) {
-        if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
-        g_opt.fuse_wgrad = (int)value;
-        return 0;
-    }
-    if (!std::strcmp(key, "overlap")) { g_opt.overlap = value != 0; return 0; }
-    if (!std::strcmp(key, "overlap_chunk")) {
-        if (value < 1 || value > (1 << 20)) return PERCNN_PI_EINVAL;
-        g_opt.overlap_chunk = (int)value;
-        return 0;
-    }
-    if (!std::strcmp(key, "tile_fuse")) { g_opt.tile_fuse = value != 0; return 0; }
-    if (!std::strcmp(key, "bwd_cpl")) {
-        if (value < 1 || value > 16) return PERCNN_PI_EINVAL;
-        g_opt.bwd_cpl = (int)value;
-        return 0;
-    }
-    if (!std::strcmp(key, "stream3d")) {                         // 0 = never, 1 = size heuristic, 2 = whenever eligible
-        if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
-        g_opt.stream3d = (int)value;
-        return 0;
-    }
-    if (!std::strcmp(key, "zc")) {
-        if (value < 1 || value > 1024) return PERCNN_PI_EINVAL;
-        g_opt.zc = (int)value;
-        return 0;
-    }
-    if (!std::strcmp(key, "lds_pad")) {
-        if (value < 0 || value > 80 * 1024 || value % 16) return PERCNN_PI_EINVAL;
-        g_opt.lds_pad = (int)value;
-        return 0;
-    }
-    if (!std::strcmp(key, "tile_k")) {
-        if (value != 2 && value != 4 && value != 8) return PERCNN_PI_EINVAL;   // 8: poly mode only (else 4)
-        g_opt.tile_k = (int)value;
-        return 0;
-    }
-    if (!std::strcmp(key, "tile_nt")) {
-        if (value != 256 && value != 512 && value != 1024) return PERCNN_PI_EINVAL;   // 1024: poly mode only
-        g_opt.tile_nt = (int)value;
-        return 0;
-    }
-    if (!std::strcmp(key, "wgrad_blocks")) {
-        if (value < 1 || value > MAX_BWD_BLOCKS / 2) return PERCNN_PI_EINVAL;
-        g_opt.wgrad_blocks = (int)value;
-        return 0;
-    }
-    if (!std::strcmp(key, "block")) {
-        if (value < 64 || value > 256 || value % 64) return PERCNN_PI_EINVAL;
-        g_opt.block = (int)value;
-        return 0;
-    }
-    if (!std::strcmp(key, "graph")) return value == 0 ? 0 : PERCNN_PI_EINVAL;   // reserved
-    return PERCNN_PI_EINVAL;
+    std::lock_guard<std::mutex> lk(g_defaults_mu);
+    return apply_option(g_defaults, key, value);
 }
 
 #define PI_EXPORT(SUF, T)                                                                                           \
@@ -1160,7 +1206,25 @@ int percnn_pi_set_option(const char* key, long value)
                                     double* param_grad, void* workspace, size_t workspace_bytes, const T* params,  \
                                     int hc, int ndim, const int64_t* shape, int T_steps, void* stream)              \
     { return rollout_bwd_impl<T>(traj, g_traj, frame_mask, g_h0, param_grad, workspace, workspace_bytes, params,   \
-                                 hc, ndim, shape, T_steps, stream); }
+                                 hc, ndim, shape, T_steps, stream); }                                               \
+    /* the same four calls with per-call tuning overrides ("key=value,..."; NULL / "" = process defaults) */        \
+    int percnn_pi_step_fwd_opt_##SUF(const T* h, T* out, const T* params, int hc, int ndim, const int64_t* shape,  \
+                                     const char* options, void* stream)                                             \
+    { return step_fwd_impl<T>(h, out, params, hc, ndim, shape, stream, false, 2, 0, options); }                     \
+    int percnn_pi_step_bwd_opt_##SUF(const T* h, const T* g_out, const T* g_inject, T* g_in, double* param_grad,   \
+                                     void* workspace, size_t workspace_bytes, const T* params, int hc, int ndim,   \
+                                     const int64_t* shape, const char* options, void* stream)                       \
+    { return step_bwd_impl<T>(h, g_out, g_inject, g_in, param_grad, workspace, workspace_bytes, params, hc, ndim,  \
+                              shape, stream, false, 2, 0, -1, -1, options); }                                       \
+    int percnn_pi_rollout_fwd_opt_##SUF(T* traj, const T* params, int hc, int ndim, const int64_t* shape,          \
+                                        int T_steps, const char* options, void* stream)                             \
+    { return rollout_fwd_impl<T>(traj, params, hc, ndim, shape, T_steps, stream, options); }                        \
+    int percnn_pi_rollout_bwd_opt_##SUF(const T* traj, const T* g_traj, const unsigned char* frame_mask, T* g_h0,  \
+                                        double* param_grad, void* workspace, size_t workspace_bytes,               \
+                                        const T* params, int hc, int ndim, const int64_t* shape, int T_steps,      \
+                                        const char* options, void* stream)                                          \
+    { return rollout_bwd_impl<T>(traj, g_traj, frame_mask, g_h0, param_grad, workspace, workspace_bytes, params,   \
+                                 hc, ndim, shape, T_steps, stream, options); }
 
 PI_EXPORT(f32, float)
 PI_EXPORT(f64, double)

@@ -251,21 +251,22 @@ def rollout_workspace(hc: int, shape: Sequence[int], T: int, dtype, device) -> t
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
-def rollout_fwd_(traj: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
-    """In place: traj[0] holds the initial state; frames 1..T are written."""
+def rollout_fwd_(traj: torch.Tensor, P: torch.Tensor, options=None) -> torch.Tensor:
+    """In place: traj[0] holds the initial state; frames 1..T are written.
+    options: per-call tuning overrides (dict or "key=value,..."; keys of include/percnn_pi.h:percnn_pi_set_option)."""
     _require(traj, "traj"); _require(P, "params", traj.dtype)
     T = traj.shape[0] - 1
     shape = traj.shape[2:]
-    f = getattr(_lib.lib(), "percnn_pi_rollout_fwd_" + _SUF[traj.dtype])
+    f = getattr(_lib.lib(), "percnn_pi_rollout_fwd_opt_" + _SUF[traj.dtype])
     with torch.cuda.device(traj.device):
-        _lib.check(f(traj.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape), T, _stream()),
-                   "rollout_fwd")
+        _lib.check(f(traj.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape), T,
+                     _lib.options_arg(options), _stream()), "rollout_fwd")
     return traj
 
 
 def rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor,
-                frame_mask: Optional[Sequence[bool]] = None, ws: Optional[torch.Tensor] = None):
-    """-> (dL/dh0 [2,*S], dL/dparams double[np])"""
+                frame_mask: Optional[Sequence[bool]] = None, ws: Optional[torch.Tensor] = None, options=None):
+    """-> (dL/dh0 [2,*S], dL/dparams double[np]);  options: per-call tuning overrides (see rollout_fwd_)"""
     _require(traj, "traj"); _require(g_traj, "g_traj", traj.dtype); _require(P, "params", traj.dtype)
     T = traj.shape[0] - 1
     shape = traj.shape[2:]
@@ -278,15 +279,16 @@ def rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor,
     if frame_mask is not None:
         assert len(frame_mask) == T + 1
         mask = bytes(bytearray(1 if m else 0 for m in frame_mask))
-    f = getattr(_lib.lib(), "percnn_pi_rollout_bwd_" + _SUF[traj.dtype])
+    f = getattr(_lib.lib(), "percnn_pi_rollout_bwd_opt_" + _SUF[traj.dtype])
     with torch.cuda.device(traj.device):
         _lib.check(f(traj.data_ptr(), g_traj.data_ptr(), mask, g_h0.data_ptr(), pg.data_ptr(), ws.data_ptr(),
-                     ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), T, _stream()), "rollout_bwd")
+                     ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), T, _lib.options_arg(options),
+                     _stream()), "rollout_bwd")
     return g_h0, pg
 
 
 def step_fwd(h: torch.Tensor, P: torch.Tensor, out: Optional[torch.Tensor] = None, slab: bool = False,
-             halo: int = 2, skip: int = 0, planes: Optional[Sequence[int]] = None):
+             halo: int = 2, skip: int = 0, planes: Optional[Sequence[int]] = None, options=None):
     """h: [2,*S] -> next state.  slab=True: h is a local slab [2, n0+2*halo, ...] (see include/percnn_pi.h);
     planes=(lo, hi): only those padded planes of the output are computed (communication overlap)."""
     _require(h, "h"); _require(P, "params", h.dtype)
@@ -307,8 +309,9 @@ def step_fwd(h: torch.Tensor, P: torch.Tensor, out: Optional[torch.Tensor] = Non
             rc = f(h.data_ptr(), out.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape), halo,
                    skip, _stream())
         else:
-            f = getattr(L, "percnn_pi_step_fwd_" + _SUF[h.dtype])
-            rc = f(h.data_ptr(), out.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape), _stream())
+            f = getattr(L, "percnn_pi_step_fwd_opt_" + _SUF[h.dtype])
+            rc = f(h.data_ptr(), out.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape),
+                   _lib.options_arg(options), _stream())
     _lib.check(rc, "step_fwd")
     return out
 
@@ -316,7 +319,7 @@ def step_fwd(h: torch.Tensor, P: torch.Tensor, out: Optional[torch.Tensor] = Non
 def step_bwd(h: torch.Tensor, g_out: torch.Tensor, P: torch.Tensor, g_inject: Optional[torch.Tensor] = None,
              g_in: Optional[torch.Tensor] = None, param_grad: Optional[torch.Tensor] = None, slab: bool = False,
              halo: int = 2, ws: Optional[torch.Tensor] = None, sweep_only: bool = False,
-             planes: Optional[Sequence[int]] = None, no_reset: bool = False, no_finish: bool = False):
+             planes: Optional[Sequence[int]] = None, no_reset: bool = False, no_finish: bool = False, options=None):
     """-> (dL/dh, param_grad double[np] (accumulated if given)).  sweep_only (slab): adjoint state and
     diffusion-coefficient gradients only; the branch gradients come from ``slab_wgrad`` afterwards.
     planes=(lo, hi) (slab): only those padded planes of dL/dh are computed; no_reset / no_finish: the launch shares
@@ -349,9 +352,9 @@ def step_bwd(h: torch.Tensor, g_out: torch.Tensor, P: torch.Tensor, g_inject: Op
                    ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), halo, 1 if sweep_only else 0,
                    _stream())
         else:
-            f = getattr(L, "percnn_pi_step_bwd_" + _SUF[h.dtype])
+            f = getattr(L, "percnn_pi_step_bwd_opt_" + _SUF[h.dtype])
             rc = f(h.data_ptr(), g_out.data_ptr(), inj, g_in.data_ptr(), param_grad.data_ptr(), ws.data_ptr(),
-                   ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), _stream())
+                   ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), _lib.options_arg(options), _stream())
     _lib.check(rc, "step_bwd")
     return g_in, param_grad
 
@@ -607,14 +610,24 @@ class PiRolloutObserveFunction(torch.autograd.Function):
         return g_h0[None], pg.to(P.dtype), None, None, None
 
 
-def pi_rollout_observe(h0: torch.Tensor, P: torch.Tensor, steps: int, t_idx: Sequence[int], strides: Sequence[int]):
-    """-> (pred [len(t_idx), 2, ceil(S/stride)...], traj [steps+1, 2, *S] detached)"""
-    return PiRolloutObserveFunction.apply(h0, P, int(steps), tuple(t_idx), tuple(strides))
+def _options_str(options) -> str:
+    b = _lib.options_arg(options)
+    return b.decode() if b else ""
 
 
-def pi_step(h: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
-    return PiStepFunction.apply(h, P)
+def pi_rollout_observe(h0: torch.Tensor, P: torch.Tensor, steps: int, t_idx: Sequence[int], strides: Sequence[int],
+                       options=None):
+    """-> (pred [len(t_idx), 2, ceil(S/stride)...], traj [steps+1, 2, *S] detached);  torch.ops.percnn.pi_rollout_observe"""
+    pred, traj = torch.ops.percnn.pi_rollout_observe(h0, P, int(steps), [int(t) for t in t_idx],
+                                                     [int(s) for s in strides], _options_str(options))
+    return pred, traj.detach()
 
 
-def pi_rollout(h0: torch.Tensor, P: torch.Tensor, steps: int) -> torch.Tensor:
-    return PiRolloutFunction.apply(h0, P, int(steps))
+def pi_step(h: torch.Tensor, P: torch.Tensor, options=None) -> torch.Tensor:
+    """One fused Pi-block step through the registered operator ``torch.ops.percnn.pi_step`` (percnn_amd/ops.py)."""
+    return torch.ops.percnn.pi_step(h, P, _options_str(options))
+
+
+def pi_rollout(h0: torch.Tensor, P: torch.Tensor, steps: int, options=None) -> torch.Tensor:
+    """T fused steps -> trajectory [T+1,2,*S] through ``torch.ops.percnn.pi_rollout``."""
+    return torch.ops.percnn.pi_rollout(h0, P, int(steps), _options_str(options))

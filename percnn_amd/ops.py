@@ -1,0 +1,187 @@
+"""PyTorch-ROCm custom operators of the Pi-block hot path: ``torch.ops.percnn.*``.
+
+north_star / SURVEY 8(b): the existing PeRCNN modules reach the fused kernels through registered operators with
+autograd support, as a drop-in for the per-step ATen sequence of ``RCNNCell.forward``
+(DataDrivenModeling/2d_gs_rd/train_2drd.py:105-121) at the call sites ``train_2drd.py:393`` (``model()``) and
+``train_2drd.py:407`` (``loss.backward()``).  Registered with ``torch.library.custom_op`` on top of the C-ABI
+(``include/percnn_pi.h``) -- the dispatcher sees real schemas, FakeTensor / meta implementations and autograd formulas,
+so the operators pass ``torch.library.opcheck`` and trace under ``torch.compile(fullgraph=True)``:
+
+    percnn::pi_step(Tensor h, Tensor params, str options="") -> Tensor
+    percnn::pi_step_backward(Tensor h, Tensor params, Tensor g_out, str options="") -> (Tensor, Tensor)
+    percnn::pi_rollout(Tensor h0, Tensor params, int steps, str options="") -> Tensor
+    percnn::pi_rollout_backward(Tensor traj, Tensor params, Tensor g_traj, str options="") -> (Tensor, Tensor)
+    percnn::pi_rollout_observe(Tensor h0, Tensor params, int steps, int[] t_idx, int[] strides, str options="")
+            -> (Tensor pred, Tensor traj)
+    percnn::pi_rollout_observe_backward(Tensor traj, Tensor params, Tensor g_pred, int[] t_idx, int[] strides,
+            str options="") -> (Tensor, Tensor)
+
+``params`` is the packed parameter block of ``include/percnn_pi.h`` (factored, pre-contracted or advective; the kind is
+encoded in its length); ``options`` carries per-call tuning overrides ("key=value,...", the keys of
+``percnn_pi_set_option``) -- nothing process-wide is touched.  Every operator fails loudly on CPU tensors: there is no
+CPU path.
+
+``pi_rollout_frames`` (the reference's list-of-frames return, train_2drd.py:187-188) is NOT a registered operator: its
+outputs are T+1 views of ONE trajectory buffer by design, and operators registered with the dispatcher may not return
+tensors that alias each other; it stays a ``torch.autograd.Function`` (``functional.PiRolloutFramesFunction``) over the
+same C-ABI calls.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+
+from . import functional as F_pi
+
+_lib_ns = "percnn"
+
+
+def _opts(options: str):
+    return options if options else None
+
+
+# ------------------------------------------------------------------------------------------------
+# one step
+# ------------------------------------------------------------------------------------------------
+@torch.library.custom_op(f"{_lib_ns}::pi_step", mutates_args=())
+def pi_step(h: torch.Tensor, params: torch.Tensor, options: str = "") -> torch.Tensor:
+    F_pi._check_state(h)
+    h, params = h.contiguous(), params.contiguous()
+    return F_pi.step_fwd(h[0], params, options=_opts(options))[None]
+
+
+@pi_step.register_fake
+def _(h, params, options=""):
+    return torch.empty_like(h, memory_format=torch.contiguous_format)
+
+
+@torch.library.custom_op(f"{_lib_ns}::pi_step_backward", mutates_args=())
+def pi_step_backward(h: torch.Tensor, params: torch.Tensor, g_out: torch.Tensor,
+                     options: str = "") -> Tuple[torch.Tensor, torch.Tensor]:
+    h, params, g_out = h.contiguous(), params.contiguous(), g_out.contiguous()
+    g_in, pg = F_pi.step_bwd(h[0], g_out[0], params, options=_opts(options))
+    return g_in[None], pg.to(params.dtype)
+
+
+@pi_step_backward.register_fake
+def _(h, params, g_out, options=""):
+    return torch.empty_like(h, memory_format=torch.contiguous_format), torch.empty_like(params)
+
+
+def _step_setup(ctx, inputs, output):
+    h, params, options = inputs
+    ctx.save_for_backward(h, params)
+    ctx.options = options
+
+
+def _step_bwd(ctx, g):
+    h, params = ctx.saved_tensors
+    g_in, g_p = torch.ops.percnn.pi_step_backward(h, params, g, ctx.options)
+    return g_in, g_p, None
+
+
+pi_step.register_autograd(_step_bwd, setup_context=_step_setup)
+
+
+# ------------------------------------------------------------------------------------------------
+# T-step rollout -> whole trajectory
+# ------------------------------------------------------------------------------------------------
+@torch.library.custom_op(f"{_lib_ns}::pi_rollout", mutates_args=())
+def pi_rollout(h0: torch.Tensor, params: torch.Tensor, steps: int, options: str = "") -> torch.Tensor:
+    F_pi._check_state(h0)
+    params = params.contiguous()
+    traj = torch.empty((steps + 1,) + tuple(h0.shape[1:]), dtype=h0.dtype, device=h0.device)
+    traj[0].copy_(h0[0])
+    return F_pi.rollout_fwd_(traj, params, options=_opts(options))
+
+
+@pi_rollout.register_fake
+def _(h0, params, steps, options=""):
+    return h0.new_empty((steps + 1,) + tuple(h0.shape[1:]))
+
+
+@torch.library.custom_op(f"{_lib_ns}::pi_rollout_backward", mutates_args=())
+def pi_rollout_backward(traj: torch.Tensor, params: torch.Tensor, g_traj: torch.Tensor,
+                        options: str = "") -> Tuple[torch.Tensor, torch.Tensor]:
+    g_h0, pg = F_pi.rollout_bwd(traj, g_traj.contiguous(), params.contiguous(), options=_opts(options))
+    return g_h0[None], pg.to(params.dtype)
+
+
+@pi_rollout_backward.register_fake
+def _(traj, params, g_traj, options=""):
+    return traj.new_empty((1,) + tuple(traj.shape[1:])), torch.empty_like(params)
+
+
+def _rollout_setup(ctx, inputs, output):
+    _h0, params, _steps, options = inputs
+    ctx.save_for_backward(output, params)
+    ctx.options = options
+
+
+def _rollout_bwd(ctx, g_traj):
+    traj, params = ctx.saved_tensors
+    g_h0, g_p = torch.ops.percnn.pi_rollout_backward(traj, params, g_traj, ctx.options)
+    return g_h0, g_p, None, None
+
+
+pi_rollout.register_autograd(_rollout_bwd, setup_context=_rollout_setup)
+
+
+# ------------------------------------------------------------------------------------------------
+# rollout + observation operator (what the reference's data loss looks at: output[0:-1:20, :, ::4, ::4],
+# train_2drd.py:397; [:-1:15, :, ::2, ::2, ::2], train_3drd.py:403)
+# ------------------------------------------------------------------------------------------------
+def _sub(strides):
+    return (slice(None),) + tuple(slice(None, None, int(s)) for s in strides)
+
+
+@torch.library.custom_op(f"{_lib_ns}::pi_rollout_observe", mutates_args=())
+def pi_rollout_observe(h0: torch.Tensor, params: torch.Tensor, steps: int, t_idx: List[int], strides: List[int],
+                       options: str = "") -> Tuple[torch.Tensor, torch.Tensor]:
+    F_pi._check_state(h0)
+    params = params.contiguous()
+    traj = torch.empty((steps + 1,) + tuple(h0.shape[1:]), dtype=h0.dtype, device=h0.device)
+    traj[0].copy_(h0[0])
+    F_pi.rollout_fwd_(traj, params, options=_opts(options))
+    pred = F_pi._observe(traj, tuple(int(t) % (steps + 1) for t in t_idx), _sub(strides))
+    return pred, traj
+
+
+@pi_rollout_observe.register_fake
+def _(h0, params, steps, t_idx, strides, options=""):
+    spatial = [(n + s - 1) // s for n, s in zip(h0.shape[2:], strides)]
+    return (h0.new_empty((len(t_idx), h0.shape[1]) + tuple(spatial)),
+            h0.new_empty((steps + 1,) + tuple(h0.shape[1:])))
+
+
+@torch.library.custom_op(f"{_lib_ns}::pi_rollout_observe_backward", mutates_args=())
+def pi_rollout_observe_backward(traj: torch.Tensor, params: torch.Tensor, g_pred: torch.Tensor, t_idx: List[int],
+                                strides: List[int], options: str = "") -> Tuple[torch.Tensor, torch.Tensor]:
+    steps = traj.shape[0] - 1
+    g_traj = torch.empty_like(traj)                    # never initialised as a whole: unobserved frames are masked
+    mask = F_pi._scatter_observed(g_traj, tuple(int(t) % (steps + 1) for t in t_idx), _sub(strides), g_pred)
+    g_h0, pg = F_pi.rollout_bwd(traj, g_traj, params.contiguous(), frame_mask=mask, options=_opts(options))
+    return g_h0[None], pg.to(params.dtype)
+
+
+@pi_rollout_observe_backward.register_fake
+def _(traj, params, g_pred, t_idx, strides, options=""):
+    return traj.new_empty((1,) + tuple(traj.shape[1:])), torch.empty_like(params)
+
+
+def _observe_setup(ctx, inputs, output):
+    _h0, params, _steps, t_idx, strides, options = inputs
+    _pred, traj = output
+    ctx.save_for_backward(traj, params)
+    ctx.t_idx, ctx.strides, ctx.options = list(t_idx), list(strides), options
+
+
+def _observe_bwd(ctx, g_pred, _g_traj_unused):
+    traj, params = ctx.saved_tensors
+    g_h0, g_p = torch.ops.percnn.pi_rollout_observe_backward(traj, params, g_pred.contiguous(), ctx.t_idx, ctx.strides,
+                                                             ctx.options)
+    return g_h0, g_p, None, None, None, None
+
+
+pi_rollout_observe.register_autograd(_observe_bwd, setup_context=_observe_setup)

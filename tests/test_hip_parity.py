@@ -342,16 +342,34 @@ def test_full_size_gradients_vs_reference(fam, shape, reaction, hip_device):
         allm = np.concatenate([g.cpu().numpy().ravel() for g in grads[:-1]])
         allr = np.concatenate([z[f"grad_{lname}/{n}"].ravel() for n in names])
         assert allm.size in (164, 44, 84)
-        assert rel_l2(allm, allr) < tol_g, lname
+        # float32 families carry the float64 twin's gradients as the yardstick: the float32 reference sums 262 144+
+        # terms per step in float32 (its Wh4 bias gradient is off by 1e-4 at 512^2 x 100), so the bar is
+        #   (i) within TOL_GRAD of the exact (float64) gradients, and
+        #  (ii) as close to the reference as the reference itself is to the exact ones
+        has64 = f"grad64_{lname}/{names[0]}" in z.files
+        if has64:
+            all64 = np.concatenate([z[f"grad64_{lname}/{n}"].ravel() for n in names])
+            e_ref = rel_l2(allr, all64)
+            assert rel_l2(allm, all64) < tol_g, (lname, rel_l2(allm, all64), e_ref)
+            assert rel_l2(allm, allr) < max(tol_g, 2 * e_ref), (lname, rel_l2(allm, allr), e_ref)
+        else:
+            assert rel_l2(allm, allr) < tol_g, lname
         for n, g in zip(names, grads[:-1]):
-            assert rel_l2(g.cpu().numpy(), z[f"grad_{lname}/{n}"]) < 10 * tol_g, (lname, n)
+            got, ref = g.cpu().numpy(), z[f"grad_{lname}/{n}"]
+            if has64:
+                t64 = z[f"grad64_{lname}/{n}"]
+                assert rel_l2(got, t64) < 10 * tol_g, (lname, n, rel_l2(got, t64), rel_l2(ref, t64))
+                assert rel_l2(got, ref) < max(10 * tol_g, 2 * rel_l2(ref, t64)), (lname, n)
+            else:
+                assert rel_l2(got, ref) < 10 * tol_g, (lname, n)
         gh = grads[-1]
         assert rel_l2(gh[sub].cpu().numpy(), z[f"grad_{lname}_h0_sub"]) < tol_g
         l2 = float(z[f"grad_{lname}_h0_l2"])
         assert abs(float(torch.linalg.vector_norm(gh.double())) - l2) < tol_g * l2
+        if has64:
+            assert rel_l2(gh[sub].cpu().numpy(), z[f"grad64_{lname}_h0_sub"]) < tol_g
 
 
-@pytest.mark.parametrize("a", [0.0, 2.0, 10.0, 50.0])
 def test_poly_conditioning_rule_on_the_kernels(a, hip_device):
     """The rule of RCNNCell's docstring on the HIP kernels themselves: poly vs factored kernel after 100 steps on the
     stable cubic well of tests/test_host_logic.py (ill-conditioned expansion for large a), both against a float64
@@ -1064,6 +1082,98 @@ def test_tile_sweep_with_fused_moments(shape, T, hip_device):
             assert rel_l2(pg.cpu().numpy(), pg_o) < 5e-5, (fuse, mask is not None)
             res[fuse] = pg.cpu().numpy()
         assert rel_l2(res[1], res[0]) < 2e-5
+
+
+@pytest.mark.parametrize("dtype,ndim,hc", [(torch.float32, 2, 0), (torch.float64, 2, 4), (torch.float32, 3, 2)])
+def test_registered_operators_pass_opcheck(dtype, ndim, hc, hip_device):
+    """torch.library.opcheck on HIP tensors: schema, autograd registration, FakeTensor and AOT-dispatch consistency of
+    percnn::pi_step / pi_rollout / pi_rollout_observe and their backward operators."""
+    import percnn_amd  # noqa: F401
+    from torch.library import opcheck
+    shape = (16, 32) if ndim == 2 else (8, 8, 64)
+    npd = np.float32 if dtype == torch.float32 else np.float64
+    P = dev_t(random_block(hc, ndim, npd, 3, scale=0.3), hip_device)
+    rs = np.random.RandomState(0)
+    h = dev_t(rs.uniform(0, 1, (1, 2) + shape).astype(npd), hip_device)
+    g = dev_t(rs.uniform(-1, 1, (1, 2) + shape).astype(npd), hip_device)
+    ns = torch.ops.percnn
+    hr, Pr = h.clone().requires_grad_(True), P.clone().requires_grad_(True)
+    opcheck(ns.pi_step.default, (hr, Pr))
+    opcheck(ns.pi_step.default, (hr, Pr), {"options": "vec=1"})
+    opcheck(ns.pi_step_backward.default, (h, P, g))
+    opcheck(ns.pi_rollout.default, (hr, Pr, 5))
+    traj = ns.pi_rollout(h, P, 5)
+    opcheck(ns.pi_rollout_backward.default, (traj, P, torch.randn_like(traj)))
+    opcheck(ns.pi_rollout_observe.default, (hr, Pr, 6, [0, 2, 4], [4] * ndim))
+    pred, traj6 = ns.pi_rollout_observe(h, P, 6, [0, 2, 4], [4] * ndim)
+    opcheck(ns.pi_rollout_observe_backward.default, (traj6, P, torch.randn_like(pred), [0, 2, 4], [4] * ndim))
+    # per-call options reach the kernels and change nothing but the schedule
+    assert torch.equal(ns.pi_rollout(h, P, 5, "tile=0,vec=1"), traj)
+
+
+def test_torch_compile_fullgraph_of_the_module_rollout(hip_device):
+    """RCNN.trajectory() + loss under torch.compile(fullgraph=True): the operators trace (no graph break), and the
+    compiled forward / backward equal the eager ones."""
+    import percnn_amd as pa
+    g = Golden(os.path.join(GOLDEN, "gs2d_ckpt_32x32.npz"))
+    cell = g.product_cell(hip_device)
+    h0 = dev_t(g.h0, hip_device)
+    model = pa.RCNN(cell, step=12, effective_step=list(range(12)), init_state=h0)
+
+    def loss_fn():
+        traj = model.trajectory()
+        return (traj ** 2).mean() + data_loss(traj, 4, 2)
+
+    eager = loss_fn()
+    ge = torch.autograd.grad(eager, [p for p in cell.parameters() if p.requires_grad])
+    torch._dynamo.reset()
+    compiled = torch.compile(loss_fn, fullgraph=True, backend="aot_eager")
+    lc = compiled()
+    gc = torch.autograd.grad(lc, [p for p in cell.parameters() if p.requires_grad])
+    assert abs(lc.item() - eager.item()) <= 1e-6 * abs(eager.item())
+    for a, b in zip(gc, ge):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+    # the default (inductor) backend needs a working Triton for the loss arithmetic: exercised when it is available
+    try:
+        torch._dynamo.reset()
+        li = torch.compile(loss_fn, fullgraph=True)()
+        assert abs(li.item() - eager.item()) <= 1e-5 * abs(eager.item())
+    except AssertionError:
+        raise
+    except Exception as e:                                           # toolchain problem of the box, not of the operators
+        print("inductor backend unavailable here:", repr(e)[:200])
+
+
+def test_per_call_options_do_not_touch_process_defaults(hip_device):
+    """Two call sites with different tuning options interleaved (+ one on another thread): each sees its own schedule,
+    the process defaults are untouched -- there is no shared mutable options state to race on."""
+    import threading
+    import percnn_amd as pa
+    rs = np.random.RandomState(2)
+    P = dev_t(random_block(0, 2, np.float32, 5, scale=0.3), hip_device)
+    traj = torch.empty((9, 2, 96, 128), device=hip_device)
+    traj[0] = dev_t(rs.uniform(0.2, 0.8, (2, 96, 128)).astype(np.float32), hip_device)
+    ref = pa.rollout_fwd_(traj.clone(), P)
+    gt = torch.randn_like(ref)
+    g0_ref, pg_ref = pa.rollout_bwd(ref, gt, P)
+    out = {}
+
+    def other_thread():
+        out["t"] = pa.rollout_bwd(ref, gt, P, options={"skip_wgrad": 1, "tile": 0})
+
+    th = threading.Thread(target=other_thread)
+    th.start()
+    a = pa.rollout_fwd_(traj.clone(), P, options="tile=0")
+    b = pa.rollout_fwd_(traj.clone(), P, options={"tile_k": 2})
+    g0_a, pg_a = pa.rollout_bwd(ref, gt, P)                             # defaults: the full gradients
+    th.join()
+    assert torch.equal(a, ref) and torch.equal(b, ref)
+    assert torch.equal(g0_a, g0_ref) and torch.equal(pg_a, pg_ref)
+    g0_t, pg_t = out["t"]
+    assert torch.equal(g0_t, g0_ref)
+    assert float(pg_t[16:].abs().max()) == 0.0 and float(pg_ref[16:].abs().max()) > 0     # sweep only: no branch sums
+    with pytest.raises(RuntimeError):
+        pa.rollout_fwd_(traj.clone(), P, options="tile_k=3")
 
 
 def test_reference_style_training_loop_example(hip_device):

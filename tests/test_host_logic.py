@@ -55,6 +55,14 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.percnn_pi_step_fwd_f64(1, 2, 3, 4, 2, bad, None) == -1
     assert L.percnn_pi_rollout_fwd_f32(1, 2, 8, 2, shape, -1, None) == -1
     assert L.percnn_pi_step_bwd_f32(1, 2, None, 3, 4, None, 0, 5, 8, 2, shape, None) == -2   # no workspace
+    # per-call option strings are validated before anything else
+    assert L.percnn_pi_rollout_fwd_opt_f32(1, 2, 8, 2, shape, 0, b"tile_k=4,skip_wgrad=1", None) == 0     # T = 0
+    for bad in (b"nonsense=1", b"tile_k=3", b"tile_k", b"=4", b"tile_k=4;tile=0", b"tile_k=x"):
+        assert L.percnn_pi_rollout_fwd_opt_f32(1, 2, 8, 2, shape, 0, bad, None) == -1, bad
+        assert L.percnn_pi_step_fwd_opt_f64(1, 2, 3, 4, 2, shape, bad, None) == -1, bad
+    # ... and never leak into the process defaults: a later call without overrides still sees tile_k = 4
+    assert L.percnn_pi_rollout_fwd_opt_f32(1, 2, 8, 2, shape, 0, b"tile_k=2", None) == 0
+    assert L.percnn_pi_set_option(b"tile_k", 4) == 0
     # native slab rollouts: a slab thinner than the exchange width would forward halo planes as data
     thin = (ctypes.c_int64 * 2)(2, 8)
     assert L.percnn_pi_slab_rollout_fwd_f32(1, 2, 8, 2, thin, 4, 3, None, 0, None) == -1
@@ -328,6 +336,30 @@ def test_shipped_checkpoints_are_inside_the_poly_rule():
         assert 0 < A < bound, (f, A)
         keep = cell.reaction
         assert cell.reaction == keep == "poly"
+
+
+def test_operators_are_registered_with_schemas_and_fake_impls():
+    """torch.ops.percnn.*: schemas as documented, FakeTensor propagation without a device, loud failure on CPU tensors."""
+    import percnn_amd  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    ns = torch.ops.percnn
+    assert str(ns.pi_step.default._schema) == 'percnn::pi_step(Tensor h, Tensor params, str options="") -> Tensor'
+    assert "SymInt steps" in str(ns.pi_rollout.default._schema)
+    for name in ("pi_step_backward", "pi_rollout_backward", "pi_rollout_observe", "pi_rollout_observe_backward"):
+        assert hasattr(ns, name)
+    with FakeTensorMode():
+        h = torch.empty(1, 2, 16, 24, device="cuda")
+        P = torch.empty(36, device="cuda")
+        assert ns.pi_step(h, P).shape == h.shape
+        assert ns.pi_rollout(h, P, 7).shape == (8, 2, 16, 24)
+        pred, traj = ns.pi_rollout_observe(h, P, 20, [0, 5, 10, 15], [4, 4])
+        assert pred.shape == (4, 2, 4, 6) and traj.shape == (21, 2, 16, 24)
+        g0, gp = ns.pi_rollout_backward(traj, P, traj)
+        assert g0.shape == (1, 2, 16, 24) and gp.shape == P.shape
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ns.pi_step(torch.zeros(1, 2, 8, 8), torch.zeros(36))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ns.pi_rollout(torch.zeros(1, 2, 8, 8), torch.zeros(36), 3)
 
 
 def test_exchanger_is_cached_per_group_and_device():

@@ -267,6 +267,27 @@ def biggrad_case(case, mod, shape, steps, stride_t):
         rec[f"grad_{lname}_h0_sub"] = gh[sub].numpy()
         rec[f"grad_{lname}_h0_l2"] = float(torch.linalg.vector_norm(gh.double()))
         print(f"   loss {lname} = {loss.item():.9g}, backward done ({time.time()-t0:.0f}s)")
+    del tr, loss, g, gh
+    if h0.dtype == torch.float32:
+        # float64 twin of the same cell (same float32-rounded weights and stencil taps, upcast): the yardstick that says
+        # how far the float32 reference's OWN gradients are from the exact ones (its per-step bias / weight reductions
+        # sum 262 144+ terms in float32)
+        import copy
+        oc = oracle_cell(case)
+        oc.load_state_dict(rc.state_dict())
+        oc = copy.deepcopy(oc).double()
+        h64 = initial_state(case, shape).double().requires_grad_(True)
+        t64 = run_traj(oc, h64, steps)
+        for lname, lf in (("meansq", lambda x: (x ** 2).mean()), ("data", lambda x: data_loss(x, stride_t, ndim))):
+            g64, gh64 = grads_of(lf(t64), oc, h64)
+            worst = 0.0
+            for n in g64:
+                rec[f"grad64_{lname}/{n}"] = g64[n].numpy()
+                ref = torch.tensor(rec[f"grad_{lname}/{n}"]).double()
+                worst = max(worst, ((ref - g64[n]).norm() / g64[n].norm()).item())
+            rec[f"grad64_{lname}_h0_sub"] = gh64[sub].numpy()
+            print(f"   float64 twin, loss {lname}: worst per-tensor rel-L2 of the float32 reference's parameter "
+                  f"gradients = {worst:.2e} ({time.time()-t0:.0f}s)")
     fn = os.path.join(OUT, f"{case}_biggrad_{'x'.join(map(str, shape))}.npz")
     np.savez_compressed(fn, **rec)
     print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
