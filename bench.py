@@ -71,9 +71,10 @@ def initial_state(family, shape):
     return S.lo_initial_state(shape[0]) if family == "lo2d" else S.gs_initial_state(shape, seed=0)
 
 
-def cpu_baseline(family, sd, shape, budget_s=15.0):
-    """The oracle's torch restatement (stock F.conv + cat padding + autograd; proven bit-identical
-    to the imported reference in the build container) timed on this box's host cores."""
+def cpu_baseline(family, sd, shape, budget_s=15.0, threads=None, extra_counts=True):
+    """The oracle's torch restatement (stock F.conv + cat padding + autograd; proven bit-identical to the imported
+    reference in the build container) timed on this box's host cores -- SURVEY 8(d): thread count stated, the all-cores
+    and the single-thread figures reported next to the best one, medians of repeated runs."""
     from oracle import restatement as R
     cell = {"gs2d": R.gs2d_cell, "gs3d": R.gs3d_cell, "lo2d": R.lo2d_cell}[family]()
     cell.load_state_dict(sd)
@@ -85,25 +86,53 @@ def cpu_baseline(family, sd, shape, budget_s=15.0):
         (traj ** 2).mean().backward()
         return time.perf_counter() - t0
 
-    # pick the thread count that is actually fastest on this host (all cores is NOT: oneDNN's
-    # small single-image convolutions oversubscribe badly on 100+ core boxes)
     ncpu = os.cpu_count() or 1
-    best = None
-    for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
+    probes = {}
+    if threads is None:
+        # the thread count that is actually fastest on this host (all cores is NOT: oneDNN's small single-image
+        # convolutions oversubscribe badly on 100+ core boxes)
+        best = None
+        for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+            torch.set_num_threads(th)
+            run(1)                                # warm-up (oneDNN primitive creation)
+            t1 = run(2) / 2
+            probes[th] = 1.0 / t1
+            if best is None or t1 < best[1]:
+                best = (th, t1)
+            if t1 > 4 * best[1]:
+                break
+        threads, t_probe = best
+    else:
+        torch.set_num_threads(threads)
+        run(1)
+        t_probe = run(1)
+    torch.set_num_threads(threads)
+    reps = 5
+    n = int(max(2, min(40, budget_s / reps / max(t_probe, 1e-6))))
+    times = sorted(run(n) for _ in range(reps))
+    med = times[reps // 2]
+    out = {"value": n / med, "unit": "steps/s", "cores": threads, "kind": "port", "host_cpus": ncpu,
+           "statistic": f"median of {reps} runs", "min_max": [n / times[-1], n / times[0]],
+           "sample": f"{reps} x {n}-step fwd+bwd rollouts of the same {'x'.join(map(str, shape))} problem, "
+                     f"torch {torch.__version__} CPU ({threads} threads), loss=mean(traj^2)",
+           "probe_steps_per_s_by_threads": probes}
+
+    def bounded(th, label):
+        # one warm-up step; if that alone is slow the single cold step IS the figure (keeps the bench within minutes)
         torch.set_num_threads(th)
-        run(1)                                # warm-up (oneDNN primitive creation)
-        t1 = run(2) / 2
-        if best is None or t1 < best[1]:
-            best = (th, t1)
-        if t1 > 4 * best[1]:
-            break
-    cores, t_probe = best
-    torch.set_num_threads(cores)
-    n = int(max(4, min(200, budget_s / max(t_probe, 1e-6))))
-    t = run(n)
-    return {"value": n / t, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n}-step fwd+bwd rollout of the same {'x'.join(map(str, shape))} problem, "
-                      f"torch {torch.__version__} CPU ({torch.get_num_threads()} threads), loss=mean(traj^2)"}
+        t_w = run(1)
+        if t_w > 8.0:
+            return {"value": 1.0 / t_w, "threads": th, "sample": "1 cold fwd+bwd step (no warm-up: > 8 s per step)"}
+        k = int(max(1, min(10, 3.0 / max(t_w, 1e-6))))
+        ts = sorted(run(k) for _ in range(3))
+        return {"value": k / ts[1], "threads": th, "sample": f"median of 3 x {k}-step fwd+bwd rollouts"}
+
+    if extra_counts:
+        out["threads_1"] = bounded(1, "1")
+        out["threads_all"] = bounded(ncpu, "all") if ncpu != threads else {"value": out["value"], "threads": ncpu,
+                                                                         "sample": "same as the headline figure"}
+        torch.set_num_threads(threads)
+    return out
 
 
 def ensure_library(local_rank):
@@ -124,11 +153,185 @@ def ensure_library(local_rank):
         time.sleep(1.0)
 
 
+def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, opts, T=0):
+    """Time `steps` rollout passes (T Pi-block time steps forward + the full backward each) of workload `name`.
+    Returns the measurement as a dict (value, ms_per_step, per-kernel roofline, ...) and the live tensors for add-ons."""
+    family, shape, hc, dtype, T_def, golden = WORKLOADS[name]
+    T = T or T_def
+    sd = load_params(golden)
+    cell = make_cell(family, sd, dev, reaction)
+    with torch.no_grad():
+        P = cell.param_block().contiguous()
+    npts = int(np.prod(shape))
+    esz = dtype.itemsize
+    traj = torch.empty((T + 1, 2) + shape, dtype=dtype, device=dev)
+    traj[0] = initial_state(family, shape)[0].to(dev)
+    # dense synthetic loss gradient, resident before the timed region (what autograd hands the op
+    # for L = mean(traj^2) has this shape and density)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    gtraj = torch.randn(traj.shape, dtype=dtype, device=dev, generator=gen) * (2.0 / traj.numel())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+
+    def one_pass(e=None):
+        if e: e[0].record()
+        with torch.no_grad():
+            Pc = cell.param_block().contiguous()     # parameter packing / contraction is part of every pass
+        pa.rollout_fwd_(traj, Pc)
+        if e: e[1].record()
+        g0, pg = pa.rollout_bwd(traj, gtraj, Pc)
+        if e: e[2].record()
+        return g0, pg
+
+    for _ in range(warmup):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        g0, pg = one_pass(ev[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert torch.isfinite(g0).all() and torch.isfinite(pg).all() and torch.isfinite(traj[-1]).all()
+
+    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    value = world * steps * T / elapsed
+
+    # ---- per-kernel roofline, measured live with HIP events on the launch stream ------------------
+    # The backward is two kernels where the schedule is split: the sequential adjoint sweep and ONE time-parallel
+    # gradient reduction.  The sweep is timed alone through a PER-CALL option (no process-wide state is touched).
+    reps = max(1, min(steps, 20))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    pa.rollout_bwd(traj, gtraj, P, options={"skip_wgrad": 1})
+    e0.record()
+    for _ in range(reps):
+        pa.rollout_bwd(traj, gtraj, P, options={"skip_wgrad": 1})
+    e1.record()
+    torch.cuda.synchronize()
+    sweep_ms = e0.elapsed_time(e1) / reps
+    red_ms = max(bwd_ms - sweep_ms, 1e-6)
+
+    tiled = len(shape) == 2 and npts < (1 << 20) and opts.get("tile", "1") != "0"   # ragged grids included
+    K = int(opts.get("tile_k", 4)) if tiled else 1
+    poly = reaction == "poly"
+    # algorithmic bytes per point and time step (SURVEY 8d): fwd read+write state = 2*C*s;
+    # sweep read h, adj, dL/dout + write adj = 4*C*s; gradient reduction read h + adj = 2*C*s
+    # (the factored Hc=8 reduction streams h once per species: 3*C*s)
+    Cs = 2 * esz
+    red_bytes_pt = 2 * Cs if (poly or hc <= 4) else 3 * Cs
+    # float32 poly mode on the direct-kernel path: the gradient reduction is fused into the sweep launches (no separate
+    # pass); the sweep-only timing above then only serves as a lower bound of that kernel
+    fused = (not tiled) and poly and dtype == torch.float32 and opts.get("fuse_wgrad", "2") != "0" and \
+        not (len(shape) == 3 and shape[-1] == 256 and npts >= (2 << 20) and opts.get("stream3d", "1") != "0")
+    # 2D tile path, pre-contracted blocks, 32x32 tiles (> 128 of them): the tile sweep reduces the moments itself as well
+    # (library option tile_fuse, default on) and keeps only every K-th adjoint frame
+    tiles32 = ((shape[0] + 31) // 32) * ((shape[1] + 31) // 32) if len(shape) == 2 else 0
+    tile_fused = tiled and poly and K == 4 and tiles32 > 128 and dtype in FUSED_TILE_DTYPES and \
+        opts.get("tile_fuse", "1") != "0" and opts.get("tile_by", "0") != "16" and opts.get("tile_nt", "512") == "512"
+    fused = fused or tile_fused
+    if fused:
+        sweep_ms, red_ms = bwd_ms, 1e-6
+    clock = "HIP events on the launch stream, this run (fwd / bwd phases of every pass; sweep alone via options=skip_wgrad)"
+    kernels = [
+        {"kernel": ("pi_fwd2d_tile_kernel" if tiled else "pi_fwd_kernel"), "launches_per_pass": T // K,
+         "algorithmic_bytes_per_launch": 2 * Cs * npts * K, "avg_launch_us": fwd_ms * 1e3 / (T / K)},
+        {"kernel": (("pi_adj2d_tile_kernel<sweep+moments>" if tile_fused else "pi_adj2d_tile_kernel") if tiled
+                    else ("pi_bwd_kernel<sweep+moments>" if fused else "pi_bwd_kernel<sweep>")),
+         "launches_per_pass": T // K,
+         "algorithmic_bytes_per_launch": 4 * Cs * npts * K, "avg_launch_us": sweep_ms * 1e3 / (T / K)},
+        {"kernel": ("pi_moments_kernel" if poly else "pi_wgrad_kernel"), "launches_per_pass": 1,
+         "algorithmic_bytes_per_launch": red_bytes_pt * npts * T, "avg_launch_us": red_ms * 1e3},
+    ]
+    if fused:
+        kernels.pop()                                   # no separate reduction launch
+    for k in kernels:
+        k["achieved"] = k["algorithmic_bytes_per_launch"] / (k["avg_launch_us"] * 1e-6) / 1e9
+        k["frac"] = k["achieved"] / HBM_PEAK_GBS
+        k["share_of_pass"] = k["avg_launch_us"] * k["launches_per_pass"] / ((fwd_ms + bwd_ms) * 1e3)
+        k["clock"] = "hip_events"
+    dom = max(kernels, key=lambda k: k["share_of_pass"])
+    traffic, traffic_source = None, None
+    tfile = os.path.join(ROOT, "profiles", f"traffic_{name}.json")
+    if os.path.exists(tfile):
+        traffic = json.load(open(tfile)).get(dom["kernel"].split("<")[0])
+        traffic_source = (f"profiles/traffic_{name}.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, "
+                          "collected in separate passes on MI355X and committed (not re-measured in this run)")
+    res = {
+        "value": value, "unit": "steps/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "timed_region_s": elapsed,
+        "dtype": "f32" if dtype == torch.float32 else "f64",
+        "config": {"workload": f"{name}: {family} {'x'.join(map(str, shape))}, 2 species, Hc={hc}, "
+                               f"T={T} forward+backward rollout per step, dense dL/dtraj",
+                   "reaction": reaction,
+                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (no collective)",
+                   "points": npts, "T": T, "time_steps_per_launch": K},
+        "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
+                     "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                     "avg_launch_us": dom["avg_launch_us"], "clock": clock, "all_kernels": kernels},
+        "fwd_us_per_time_step": fwd_ms * 1e3 / T, "bwd_us_per_time_step": bwd_ms * 1e3 / T,
+        "fwd_only_steps_per_sec": T / (fwd_ms * 1e-3),
+    }
+    live = {"cell": cell, "family": family, "traj": traj, "gtraj": gtraj, "P": P, "T": T, "fwd_ms": fwd_ms, "sd": sd,
+            "shape": shape, "esz": esz, "npts": npts}
+    return res, live
+
+
+FUSED_TILE_DTYPES = (torch.float32,)          # dtypes whose 2D tile sweep has the fused-moments flavour
+
+
+def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
+    """What a user of the reference's interface pays per training iteration (SURVEY 8b call sites train_2drd.py:393-407):
+    (a) ``outputs, _ = model(); torch.cat(outputs); loss; loss.backward()`` -- the list-of-frames path, dense loss;
+    (b) ``model.observe(slice(0, -1, 20), 4)`` + the reference's strided data loss + backward."""
+    cell = make_cell(family, sd, dev, reaction)
+    h0 = initial_state(family, shape).to(dev).requires_grad_(True)
+    model = pa.RCNN(cell, step=T, effective_step=list(range(T)), init_state=h0)
+    params = [p for p in cell.parameters() if p.requires_grad]
+
+    def it_list():
+        outs, _ = model()
+        traj = torch.cat(tuple(outs), dim=0)
+        loss = (traj ** 2).mean()
+        torch.autograd.grad(loss, params + [h0])
+
+    def it_observe():
+        pred = model.observe(slice(0, -1, 20), 4)
+        loss = ((pred - 0.5) ** 2).mean()
+        torch.autograd.grad(loss, params + [h0])
+
+    out = {}
+    for key, fn in (("list_cat_dense_loss_ms", it_list), ("observe_strided_loss_ms", it_observe)):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[key] = {"gpu_ms": e0.elapsed_time(e1) / reps, "wall_ms": (time.perf_counter() - t0) / reps * 1e3}
+    out["what"] = (f"one training iteration through the drop-in modules at {'x'.join(map(str, shape))} x T={T}: RCNN.forward() "
+                   "+ torch.cat + mean(traj^2) + backward, and RCNN.observe(0:-1:20, ::4) + MSE + backward "
+                   "(forward, loss, full backward incl. parameter gradients; wall = host clock around the same loop)")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)       # 200 passes x ~5 ms: a timed region of >= 1 s
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="gs2d_512", choices=list(WORKLOADS) + list(STAGE1))
     ap.add_argument("--T", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,6 +341,7 @@ def main():
     ap.add_argument("--slab-extra", action="store_true", help="also time the slab-sharded 3D path at N=1")
     ap.add_argument("--no-extras", action="store_true",
                     help="headline measurement only (profiling runs: keeps per-kernel averages free of the add-on passes)")
+    ap.add_argument("--no-also", action="store_true", help="skip the second half of the BASELINE metric (3D-GS 128^3)")
     ap.add_argument("--slab-timeout", type=float, default=240.0)
     ap.add_argument("--slab-child", action="store_true", help=argparse.SUPPRESS)   # see slab_extra_isolated
     a = ap.parse_args()
@@ -161,6 +365,10 @@ def main():
             res = slab_extra(dev, dist, rank, world)
         except Exception as e:
             res = {"error": repr(e)[:300]}
+        try:
+            pa.slab.close_exchangers()
+        except Exception:
+            pass
         if dist is not None:
             dist.destroy_process_group()
         flush_c_stdio()
@@ -170,144 +378,55 @@ def main():
         return stage1_main(a, pa, dev, dist, rank, world)
     for kv in a.opt:
         k, v = kv.split("=")
-        pa.set_option(k, int(v))
-    family, shape, hc, dtype, T_def, golden = WORKLOADS[a.workload]
-    T = a.T or T_def
-    sd = load_params(golden)
-    cell = make_cell(family, sd, dev, a.reaction)
-    with torch.no_grad():
-        P = cell.param_block().contiguous()
-    npts = int(np.prod(shape))
-    esz = dtype.itemsize
-    traj = torch.empty((T + 1, 2) + shape, dtype=dtype, device=dev)
-    traj[0] = initial_state(family, shape)[0].to(dev)
-    # dense synthetic loss gradient, resident before the timed region (what autograd hands the op
-    # for L = mean(traj^2) has this shape and density)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    gtraj = torch.randn(traj.shape, dtype=dtype, device=dev, generator=gen) * (2.0 / traj.numel())
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
-
-    def one_pass(e=None):
-        if e: e[0].record()
-        with torch.no_grad():
-            Pc = cell.param_block().contiguous()     # parameter packing / contraction is part of every pass
-        pa.rollout_fwd_(traj, Pc)
-        if e: e[1].record()
-        g0, pg = pa.rollout_bwd(traj, gtraj, Pc)
-        if e: e[2].record()
-        return g0, pg
-
-    for _ in range(a.warmup):
-        one_pass()
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        g0, pg = one_pass(ev[k])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
-    assert torch.isfinite(g0).all() and torch.isfinite(pg).all() and torch.isfinite(traj[-1]).all()
-
-    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-    total_steps = world * a.steps * T
-    value = total_steps / elapsed
-
-    # ---- per-kernel roofline, measured live with HIP events on the launch stream ------------------
-    # The backward is two kernels: the sequential adjoint sweep and ONE time-parallel gradient
-    # reduction.  Time the sweep alone (library diagnostic option) so each kernel gets its own line.
-    pa.set_option("skip_wgrad", 1)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    pa.rollout_bwd(traj, gtraj, P)
-    e0.record()
-    for _ in range(a.steps):
-        pa.rollout_bwd(traj, gtraj, P)
-    e1.record()
-    torch.cuda.synchronize()
-    pa.set_option("skip_wgrad", 0)
-    sweep_ms = e0.elapsed_time(e1) / a.steps
-    red_ms = max(bwd_ms - sweep_ms, 1e-6)
-
+        pa.set_option(k, int(v))                      # the CLI's explicit process-wide defaults for this run
     opts = dict(kv.split("=") for kv in a.opt)
-    tiled = len(shape) == 2 and int(np.prod(shape)) < (1 << 20) and opts.get("tile", "1") != "0"   # ragged grids included
-    K = int(opts.get("tile_k", 4)) if tiled else 1
-    poly = a.reaction == "poly"
-    # algorithmic bytes per point and time step: fwd read+write state = 2*C*s;
-    # sweep read h, adj, dL/dout + write adj = 4*C*s; gradient reduction read h + adj = 2*C*s
-    # (the factored Hc=8 reduction streams h once per species: 3*C*s)
-    Cs = 2 * esz
-    red_bytes_pt = 2 * Cs if (poly or hc <= 4) else 3 * Cs
-    # float32 poly mode on the direct-kernel path: the gradient reduction is fused into the sweep launches (no separate
-    # pass); the sweep-only timing above then only serves as a lower bound of that kernel
-    fused = (not tiled) and poly and dtype == torch.float32 and opts.get("fuse_wgrad", "2") != "0" and \
-        not (len(shape) == 3 and shape[-1] == 256 and npts >= (2 << 20) and opts.get("stream3d", "1") != "0")
-    # 2D tile path, float32 poly, 32x32 tiles (> 128 of them): the tile sweep reduces the moments itself as well
-    # (library option tile_fuse, default on) and keeps only every K-th adjoint frame
-    tiles32 = ((shape[0] + 31) // 32) * ((shape[1] + 31) // 32) if len(shape) == 2 else 0
-    tile_fused = tiled and poly and dtype == torch.float32 and K == 4 and tiles32 > 128 and \
-        opts.get("tile_fuse", "1") != "0" and opts.get("tile_by", "0") != "16" and opts.get("tile_nt", "512") == "512"
-    fused = fused or tile_fused
-    if fused:
-        sweep_ms, red_ms = bwd_ms, 1e-6
-    kernels = [
-        {"kernel": ("pi_fwd2d_tile_kernel" if tiled else "pi_fwd_kernel"), "launches_per_pass": T // K,
-         "algorithmic_bytes_per_launch": 2 * Cs * npts * K, "avg_launch_us": fwd_ms * 1e3 / (T / K)},
-        {"kernel": (("pi_adj2d_tile_kernel<sweep+moments>" if tile_fused else "pi_adj2d_tile_kernel") if tiled
-                    else ("pi_bwd_kernel<sweep+moments>" if fused else "pi_bwd_kernel<sweep>")),
-         "launches_per_pass": T // K,
-         "algorithmic_bytes_per_launch": 4 * Cs * npts * K, "avg_launch_us": sweep_ms * 1e3 / (T / K)},
-        {"kernel": ("pi_moments_kernel" if poly else "pi_wgrad_kernel"), "launches_per_pass": 1,
-         "algorithmic_bytes_per_launch": red_bytes_pt * npts * T, "avg_launch_us": red_ms * 1e3},
-    ]
-    if fused:
-        kernels.pop()                                   # no separate reduction launch
-    for k in kernels:
-        k["achieved"] = k["algorithmic_bytes_per_launch"] / (k["avg_launch_us"] * 1e-6) / 1e9
-        k["frac"] = k["achieved"] / HBM_PEAK_GBS
-        k["share_of_pass"] = k["avg_launch_us"] * k["launches_per_pass"] / ((fwd_ms + bwd_ms) * 1e3)
-    dom = max(kernels, key=lambda k: k["share_of_pass"])
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", f"traffic_{a.workload}.json")
-    if os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get(dom["kernel"].split("<")[0])
 
-    out = {
-        "metric": "pi_block_rollout_fwd_bwd_steps_per_sec", "value": value, "unit": "steps/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
-        "config": {"workload": f"{a.workload}: {family} {'x'.join(map(str, shape))}, 2 species, Hc={hc}, "
-                               f"T={T} forward+backward rollout per step, dense dL/dtraj",
-                   "reaction": a.reaction,
-                   "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (no collective)",
-                   "points": npts, "T": T, "time_steps_per_launch": K},
-        "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": dom["frac"], "traffic": traffic,
-                     "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                     "avg_launch_us": dom["avg_launch_us"], "all_kernels": kernels},
-        "fwd_us_per_time_step": fwd_ms * 1e3 / T, "bwd_us_per_time_step": bwd_ms * 1e3 / T,
-        "fwd_only_steps_per_sec": T / (fwd_ms * 1e-3),
-    }
+    res, live = measure_workload(pa, dev, dist, rank, world, a.workload, a.steps, a.warmup, a.reaction, opts, a.T)
+    out = {"metric": "pi_block_rollout_fwd_bwd_steps_per_sec", "value": res["value"], "unit": "steps/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
+           "config": res["config"], "roofline": res["roofline"], "timed_region_s": res["timed_region_s"],
+           "fwd_us_per_time_step": res["fwd_us_per_time_step"], "bwd_us_per_time_step": res["bwd_us_per_time_step"],
+           "fwd_only_steps_per_sec": res["fwd_only_steps_per_sec"]}
+    family, sd, shape, T = live["family"], live["sd"], live["shape"], live["T"]
+    cpu_threads = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(family, sd, shape)
+        cpu_threads = out["cpu_baseline"]["cores"]
     if world == 1 and not a.no_extras:
         try:
-            out["physics_residual"] = physics_extra(pa, cell, family, traj, esz, npts)
+            out["physics_residual"] = physics_extra(pa, live["cell"], family, live["traj"], live["esz"], live["npts"])
         except Exception as e:                       # an add-on measurement must never cost the headline line
             out["physics_residual"] = {"error": repr(e)[:200]}
         try:
-            out["strided_data_loss"] = strided_loss_extra(pa, traj, gtraj, P, T, fwd_ms, a.steps)
+            out["strided_data_loss"] = strided_loss_extra(pa, live["traj"], live["gtraj"], live["P"], T, live["fwd_ms"],
+                                                          min(a.steps, 10))
         except Exception as e:
             out["strided_data_loss"] = {"error": repr(e)[:200]}
+    del live, res
+    torch.cuda.empty_cache()
+    if world == 1 and not a.no_extras:
+        try:
+            out["module_path"] = module_path_extra(pa, family, sd, shape, T, dev, a.reaction)
+        except Exception as e:
+            out["module_path"] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
+
+    # ---- the other half of BASELINE.json's metric ("2D-GS 512^2 & 3D-GS 128^3") in the same line --------------------
+    if a.workload == "gs2d_512" and not a.no_also and not a.T:
+        try:
+            n3 = max(3, a.steps // 4)
+            r3, l3 = measure_workload(pa, dev, dist, rank, world, "gs3d_128", n3, max(1, a.warmup // 2), a.reaction, opts)
+            also = {k: r3[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "timed_region_s", "dtype", "config",
+                                       "roofline", "fwd_us_per_time_step", "bwd_us_per_time_step")}
+            if rank == 0 and world == 1 and not a.no_cpu_baseline:
+                also["cpu_baseline"] = cpu_baseline("gs3d", l3["sd"], l3["shape"], budget_s=8.0, threads=cpu_threads,
+                                                    extra_counts=False)
+            del r3, l3
+            torch.cuda.empty_cache()
+            out["also"] = {"gs3d_128": also}
+        except Exception as e:
+            out["also"] = {"gs3d_128": {"error": repr(e)[:300]}}
 
     # N > 1: additionally time the spatially sharded path (slab decomposition + RCCL halo exchange over
     # xGMI) on the configs[4]-shaped problem, weak-scaled: 32 planes of 256^2 per rank (256^3 at N = 8).
@@ -329,7 +448,6 @@ def main():
                 os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            del traj, gtraj
             torch.cuda.empty_cache()
             if dist is not None:                     # own process per rank: a fault in there cannot cost the line above
                 out["slab_3d"] = slab_extra_isolated(a, dev, dist, rank, world, local_rank)

@@ -119,9 +119,28 @@ def _contraction_tensor(device) -> torch.Tensor:
     return _k_cache[key]
 
 
+def contract_fwd_hip(P: torch.Tensor) -> torch.Tensor:
+    """one launch (csrc/pi_contract.h): factored block on a HIP device -> 36-entry polynomial block"""
+    _require(P, "params")
+    Q = torch.empty(NPOLY, dtype=P.dtype, device=P.device)
+    f = getattr(_lib.lib(), "percnn_pi_contract_fwd_" + _SUF[P.dtype])
+    with torch.cuda.device(P.device):
+        _lib.check(f(P.data_ptr(), _hc_of(P), Q.data_ptr(), _stream()), "contract_fwd")
+    return Q
+
+
+def contract_bwd_hip(P: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    _require(P, "params"); _require(g, "g_poly", P.dtype)
+    gP = torch.empty_like(P)
+    f = getattr(_lib.lib(), "percnn_pi_contract_bwd_" + _SUF[P.dtype])
+    with torch.cuda.device(P.device):
+        _lib.check(f(P.data_ptr(), _hc_of(P), g.data_ptr(), gP.data_ptr(), _stream()), "contract_bwd")
+    return gP
+
+
 class _ContractFunction(torch.autograd.Function):
-    """contract_block with a hand-written chain rule.  The einsum + autograd version cost ~80 tiny kernels per training
-    iteration (1.2 ms on MI355X, 20 % of a 512^2 x 1000 iteration); this one needs ~25."""
+    """contract_block on CPU tensors (host-side tools, tests) with a hand-written chain rule in plain torch ops; HIP
+    tensors go through the registered operator ``torch.ops.percnn.contract_block`` instead (one launch each way)."""
 
     @staticmethod
     def _factors(P):
@@ -135,14 +154,6 @@ class _ContractFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, P):
-        if P.is_cuda:                                      # one launch (csrc/pi_contract.h) instead of ~25
-            P = P.contiguous()
-            Q = torch.empty(NPOLY, dtype=P.dtype, device=P.device)
-            f = getattr(_lib.lib(), "percnn_pi_contract_fwd_" + _SUF[P.dtype])
-            with torch.cuda.device(P.device):
-                _lib.check(f(P.data_ptr(), _hc_of(P), Q.data_ptr(), _stream()), "contract_fwd")
-            ctx.save_for_backward(P)
-            return Q
         K, _e0 = _contraction_tensor(P.device)
         hc, B, L1, L2, L3, w4, T12, T = _ContractFunction._factors(P)
         S = (T * w4[:, :, None, None, None]).sum(1).reshape(2, 27)        # sum over the hidden channels
@@ -154,13 +165,6 @@ class _ContractFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (P,) = ctx.saved_tensors
-        if P.is_cuda:
-            g = g.contiguous()
-            gP = torch.empty_like(P)
-            f = getattr(_lib.lib(), "percnn_pi_contract_bwd_" + _SUF[P.dtype])
-            with torch.cuda.device(P.device):
-                _lib.check(f(P.data_ptr(), _hc_of(P), g.data_ptr(), gP.data_ptr(), _stream()), "contract_bwd")
-            return gP
         K, _e0 = _contraction_tensor(P.device)
         hc, B, L1, L2, L3, w4, T12, T = _ContractFunction._factors(P)
         gc = g[16:].to(torch.float64).reshape(2, 10)
@@ -184,6 +188,8 @@ def contract_block(P: torch.Tensor) -> torch.Tensor:
     L_k[j] = (Wh_k.weight[j,0], Wh_k.weight[j,1], Wh_k.bias[j]) -- the same expansion the reference
     prints symbolically (train_3drd.py:442-468).  Evaluated in float64, rounded once to the compute
     dtype.  The backward is the exact multilinear chain rule dL/dc -> dL/dWh* (hand-written, float64)."""
+    if P.is_cuda:
+        return torch.ops.percnn.contract_block(P)
     return _ContractFunction.apply(P)
 
 

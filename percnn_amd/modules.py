@@ -122,19 +122,25 @@ class RCNNCell(nn.Module):
             self._stencil_checked_version = key
 
     def param_block(self) -> torch.Tensor:
-        self._validate_stencil()
         w = self.W_laplace.weight
-        # the reference reads self.dt every step (train_2drd.py:117): the cached device scalar is keyed on its value too
-        key = (float(self.dt), w.device, w.dtype)
-        if self._dt_cache is None or self._dt_cache[0] != key:
-            self._dt_cache = (key, torch.tensor([self.dt], dtype=w.dtype, device=w.device))
+        if torch.compiler.is_compiling():
+            # traced by torch.compile: no host-side checks / caches inside the graph (the stencil was validated by the
+            # eager call that preceded compilation or is validated by the first eager use)
+            dt_t = torch.tensor([self.dt], dtype=w.dtype, device=w.device)
+        else:
+            self._validate_stencil()
+            # the reference reads self.dt every step (train_2drd.py:117): the cached device scalar is keyed on its value
+            key = (float(self.dt), w.device, w.dtype)
+            if self._dt_cache is None or self._dt_cache[0] != key:
+                self._dt_cache = (key, torch.tensor([self.dt], dtype=w.dtype, device=w.device))
+            dt_t = self._dt_cache[1]
         cu, cv = self.coefficients()
         branch = []
         for s in ("u", "v"):
             for k in (1, 2, 3, 4):
                 m = getattr(self, f"Wh{k}_{s}")
                 branch += [m.weight, m.bias]
-        P = F_pi.pack_params(self._dt_cache[1], cu, cv, w, branch)
+        P = F_pi.pack_params(dt_t, cu, cv, w, branch)
         return F_pi.contract_block(P) if self.reaction == "poly" else P
 
     def poly_amplification(self, u_max: float = 1.0, v_max: float = 1.0) -> float:

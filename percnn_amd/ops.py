@@ -7,6 +7,7 @@ autograd support, as a drop-in for the per-step ATen sequence of ``RCNNCell.forw
 (``include/percnn_pi.h``) -- the dispatcher sees real schemas, FakeTensor / meta implementations and autograd formulas,
 so the operators pass ``torch.library.opcheck`` and trace under ``torch.compile(fullgraph=True)``:
 
+    percnn::contract_block(Tensor params) -> Tensor          (+ contract_block_backward)
     percnn::pi_step(Tensor h, Tensor params, str options="") -> Tensor
     percnn::pi_step_backward(Tensor h, Tensor params, Tensor g_out, str options="") -> (Tensor, Tensor)
     percnn::pi_rollout(Tensor h0, Tensor params, int steps, str options="") -> Tensor
@@ -39,6 +40,41 @@ _lib_ns = "percnn"
 
 def _opts(options: str):
     return options if options else None
+
+
+# ------------------------------------------------------------------------------------------------
+# factored block -> pre-contracted polynomial block (device-side contraction, csrc/pi_contract.h)
+# ------------------------------------------------------------------------------------------------
+@torch.library.custom_op(f"{_lib_ns}::contract_block", mutates_args=())
+def contract_block(params: torch.Tensor) -> torch.Tensor:
+    return F_pi.contract_fwd_hip(params.contiguous())
+
+
+@contract_block.register_fake
+def _(params):
+    return params.new_empty((F_pi.NPOLY,))
+
+
+@torch.library.custom_op(f"{_lib_ns}::contract_block_backward", mutates_args=())
+def contract_block_backward(params: torch.Tensor, g_poly: torch.Tensor) -> torch.Tensor:
+    return F_pi.contract_bwd_hip(params.contiguous(), g_poly.contiguous())
+
+
+@contract_block_backward.register_fake
+def _(params, g_poly):
+    return torch.empty_like(params)
+
+
+def _contract_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0])
+
+
+def _contract_bwd(ctx, g):
+    (params,) = ctx.saved_tensors
+    return torch.ops.percnn.contract_block_backward(params, g)
+
+
+contract_block.register_autograd(_contract_bwd, setup_context=_contract_setup)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -370,6 +370,7 @@ def test_full_size_gradients_vs_reference(fam, shape, reaction, hip_device):
             assert rel_l2(gh[sub].cpu().numpy(), z[f"grad64_{lname}_h0_sub"]) < tol_g
 
 
+@pytest.mark.parametrize("a", [0.0, 2.0, 10.0, 50.0])
 def test_poly_conditioning_rule_on_the_kernels(a, hip_device):
     """The rule of RCNNCell's docstring on the HIP kernels themselves: poly vs factored kernel after 100 steps on the
     stable cubic well of tests/test_host_logic.py (ill-conditioned expansion for large a), both against a float64
