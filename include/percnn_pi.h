@@ -111,6 +111,9 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *                  / plane-streaming kernels
  *   "tile_fuse"    1 (default): the float32 pre-contracted tile sweep with 32x32 tiles reduces the 20 coefficient
  *                  moments itself and stores only every K-th adjoint frame (no separate moments pass); 0: split schedule
+ *   "l2_tile_kb"   direct 3D kernels: the rows of a plane are processed in y-tiles of this many KiB (both species; default
+ *                  128, 0 = whole planes) and the workgroups march along axis 0 tile by tile, so the five planes a tile's
+ *                  stencil reads stay in the XCD's L2 when whole planes do not fit (e.g. 384^3)
  *   "bwd_cpl"      direct adjoint kernel: 16-byte chunks per lane (1..16, default 2) once >= 512 workgroups remain
  *   "overlap", "overlap_chunk"  run the time-parallel gradient pass of finished chunks on a side stream under the sweep
  *   "skip_wgrad"   diagnostics: adjoint sweep only, parameter gradients of the branches come back as zeros

@@ -41,6 +41,11 @@ struct Options {
     int skip_wgrad = 0;     // diagnostics: rollout_bwd runs the adjoint sweep only (bench uses it to time the sweep alone)
     int tile_xcd = 1;       // XCD-aware block -> tile map of the 2D tile kernels (0 = identity)
     int tile_by = 0;        // tile height of the 2D tile kernels: 32, 16, or 0 = by grid size (see tile_by_for)
+    int fwd_blocks = 0;     // direct forward kernel: grid cap (0 = none; measured: a bounded persistent grid loses, 384^3 376 -> 416 us)
+    int xcd_window = 0;     // direct forward kernel: XCD-contiguous block remap inside windows of this many blocks (0 = whole grid)
+    int block_small = 1;    // direct kernels: 64-thread workgroups while 256-thread ones would leave CUs idle (small grids)
+    int l2_tile_kb = 128;   // direct 3D kernels: y-tile of a plane (both species, KiB) whose five stencil planes stay in the L2
+                            // (0 = whole planes, the pre-round-2 order): see set_blockmap
     int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
                             // small grid is spread over all CUs instead of being packed onto a few
 };
@@ -130,7 +135,7 @@ pi::FastDiv make_fastdiv(unsigned d)
     return f;
 }
 
-// chunk-id decomposition of the direct kernels without integer division (vec = points per lane of this launch)
+// chunk-id decomposition of the time-parallel / residual / advective kernels without integer division (vec = points per lane)
 void set_fastdiv(Geom& g, int vec)
 {
     const long nchunks = (long)g.rows * (g.W / vec);
@@ -139,10 +144,66 @@ void set_fastdiv(Geom& g, int vec)
     g.dn1 = make_fastdiv((unsigned)g.n1);
 }
 
+// block-uniform decomposition of the direct step kernels (pi_kernels.h "Direct step kernels, addressing"): lanes along x
+// = the power of two that wastes the fewest lanes on this row length; false if the grid is outside what 32-bit byte
+// offsets / 31-bit block ids address (2D: the whole local field + 4 rows, 3D: one plane, must stay below 4 GiB)
+bool set_blockmap(Geom& g, int ndim, int vec, int block, size_t elem, int l2_tile_bytes = 128 * 1024)
+{
+    const long cpr = g.W / vec;
+    int lxs;
+    if (cpr <= 64) {
+        lxs = 2;
+        while ((1L << lxs) < cpr) ++lxs;
+    } else {
+        lxs = 6;
+        double best = 0.0;
+        for (int c = 6; c >= 4; --c) {
+            const long lx = 1L << c;
+            const double eff = (double)cpr / (double)(((cpr + lx - 1) / lx) * lx);
+            if (eff > best + 1e-9) { best = eff; lxs = c; }
+        }
+    }
+    while ((1 << lxs) > block) --lxs;
+    const long lx = 1L << lxs, rpb = block >> lxs;
+    const long nrow = ndim == 3 ? g.n1 : g.n0;
+    g.lxs = lxs;
+    g.nxb = (int)((cpr + lx - 1) / lx);
+    g.nrg = (int)((nrow + rpb - 1) / rpb);
+    const long nblk = (long)g.nxb * g.nrg * (ndim == 3 ? g.n0 : 1);
+    const unsigned long long span = (unsigned long long)(ndim == 3 ? (long)g.n1 : (long)g.n0 + 4) * g.W * elem;
+    if (nblk <= 0 || nblk >= (1L << 31) || span >= (1ull << 32)) return false;
+    g.nblk = (unsigned)nblk;
+    g.dnxb = make_fastdiv((unsigned)g.nxb);
+    g.dnrg = make_fastdiv((unsigned)g.nrg);
+    // 3D y-tiling for L2 residency (Geom::rgt): a tile's plane section, both species, is held to ~128 KiB so that the four
+    // neighbour planes of everything in flight on an XCD (~2 MiB) fit its 4 MiB L2 next to the streams themselves
+    g.rgt = 0; g.nlast = 0; g.per_tile = 0;
+    // (only where whole planes do not fit anyway: four neighbour planes x two species above ~1.5 MiB; measured on
+    // MI355X: 384^3 backward 726 -> 513 us, 256^3 171 -> 148 us per step, 192^3 -- 1.2 MB of neighbour planes -- loses 3-8 %)
+    if (ndim == 3 && l2_tile_bytes > 0 && 8L * g.n1 * g.W * (long)elem > (3L << 19)) {
+        const long tile_rows = (long)l2_tile_bytes / (2 * (long)g.W * (long)elem);
+        long rgt = tile_rows / rpb;
+        if (rgt < 1) rgt = 1;
+        if (rgt < g.nrg && (long)rgt * g.n0 < (1L << 31)) {
+            const long ntile = (g.nrg + rgt - 1) / rgt;
+            g.rgt = (int)rgt;
+            g.nlast = (int)(g.nrg - (ntile - 1) * rgt);
+            g.per_tile = (unsigned)(rgt * g.n0);
+            g.dper = make_fastdiv(g.per_tile);
+            g.drgt = make_fastdiv((unsigned)g.rgt);
+            g.dlast = make_fastdiv((unsigned)g.nlast);
+        }
+    }
+    return true;
+}
+
 Geom make_geom(const Problem& p)
 {
     Geom g;
     g.fastdiv = 0; g.dcpr = pi::FastDiv{0u, 0u}; g.dn1 = pi::FastDiv{0u, 0u};
+    g.lxs = 0; g.nxb = g.nrg = 0; g.nblk = 0; g.dnxb = pi::FastDiv{0u, 0u}; g.dnrg = pi::FastDiv{0u, 0u};
+    g.rgt = g.nlast = 0; g.per_tile = 0; g.dper = g.drgt = g.dlast = pi::FastDiv{0u, 0u};
+    g.xwin = 0;
     g.n0 = (int)p.n0; g.n1 = (int)p.n1; g.W = (int)p.W;
     g.rows = (int)(p.n0 * p.n1);
     g.s0 = (long)(p.n1 * p.W);
@@ -175,26 +236,36 @@ int pick_vec(const Problem& p, std::initializer_list<const void*> ptrs)
     return V;
 }
 
+// workgroup size of the direct kernels: the "block" option, or 128 threads while 256-thread workgroups would leave
+// CUs idle (a 48^3 grid is 108 workgroups of 256 threads on 256 CUs)
+int direct_block(const Problem& p, const Geom& g, int vec)
+{
+    const long chunks = (long)g.rows * (g.W / vec);
+    if (p.opt.block_small && p.opt.block == 256 && chunks < 1024L * 256) return 128;   // measured 48^3 .. 96^3: +0-10 %
+    return p.opt.block;
+}
+
 // ---- kernel instantiation dispatch ------------------------------------------------------------
 template <typename T, int NDIM, int HC, int VEC>
 hipError_t launch_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
 {
     Geom g = make_geom(p);
-    set_fastdiv(g, VEC);
-    const long nchunks = (long)g.rows * (g.W / VEC);
-    const int block = p.opt.block;
-    const unsigned grid = (unsigned)((nchunks + block - 1) / block);
-    if (nchunks <= 0) return hipSuccess;
+    const int block = direct_block(p, g, VEC);
+    if (g.rows <= 0) return hipSuccess;
+    if (!set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024)) return hipErrorInvalidValue;
+    const unsigned grid = (p.opt.fwd_blocks > 0 && g.nblk > (unsigned)p.opt.fwd_blocks) ? (unsigned)p.opt.fwd_blocks : g.nblk;
+    g.xwin = (unsigned)p.opt.xcd_window;
     auto* k = pi::pi_fwd_kernel<T, NDIM, HC, VEC>;
     if (hipError_t e = allow_lds(k, (size_t)p.opt.lds_pad)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), (size_t)p.opt.lds_pad, st, h, out, P, g, p.hc);
     return hipGetLastError();
 }
 
-unsigned bwd_grid(const Problem& p, int vec)
+unsigned bwd_grid(const Problem& p, int vec, size_t elem)
 {
-    const long nchunks = (long)make_geom(p).rows * (p.W / vec);
-    long need = (nchunks + p.opt.block - 1) / p.opt.block;
+    Geom g = make_geom(p);
+    if (g.rows <= 0 || !set_blockmap(g, p.ndim, vec, direct_block(p, g, vec), elem, p.opt.l2_tile_kb * 1024)) return 0;
+    long need = g.nblk;
     if (p.opt.bwd_cpl > 1 && need >= 512L * p.opt.bwd_cpl) need = (need + p.opt.bwd_cpl - 1) / p.opt.bwd_cpl;   // chunks per lane
     return (unsigned)(need < MAX_BWD_BLOCKS ? need : MAX_BWD_BLOCKS);
 }
@@ -204,9 +275,10 @@ hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* parti
                       const Problem& p, hipStream_t st)
 {
     Geom g = make_geom(p);
-    set_fastdiv(g, VEC);
-    const int block = p.opt.block;
-    const unsigned grid = bwd_grid(p, VEC);
+    const int block = direct_block(p, g, VEC);
+    const unsigned grid = bwd_grid(p, VEC, sizeof(T));
+    if (g.rows <= 0) return hipSuccess;
+    if (!grid || !set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024)) return hipErrorInvalidValue;
     const size_t lds = align_up((size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T), 16) +
                        (size_t)(block / pi::WAVE) * 2 * sizeof(double) + (size_t)p.opt.lds_pad;
     auto* k = pi::pi_bwd_kernel<T, NDIM, HC, VEC, WGRAD>;
@@ -404,7 +476,7 @@ hipError_t step_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partial
         if (const int sv = stream3d_vec<T>(p, {h, G, inj, Gp}))
             return stream3d<T, true>(sv, G, Gp, h, inj, partials, P, p, st, grid_out, WGRAD ? 1 : 0);
     const int vec = pick_vec<T>(p, {h, G, inj, Gp});
-    if (grid_out) *grid_out = bwd_grid(p, vec);
+    if (grid_out) *grid_out = bwd_grid(p, vec, sizeof(T));
 #define CALL_BWD(NDIM, HC, VEC) launch_bwd<T, NDIM, HC, VEC, WGRAD>(h, G, inj, Gp, partials, P, p, st)
     PI_DISPATCH(CALL_BWD);
 #undef CALL_BWD
@@ -1049,6 +1121,22 @@ int apply_option(Options& o, const char* key, long value)
     if (!std::strcmp(key, "zc")) {
         if (value < 1 || value > 1024) return PERCNN_PI_EINVAL;
         o.zc = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "fwd_blocks")) {
+        if (value < 0 || value > (1 << 24)) return PERCNN_PI_EINVAL;
+        o.fwd_blocks = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "xcd_window")) {
+        if (value < 0 || value > (1 << 24) || value % 8) return PERCNN_PI_EINVAL;
+        o.xcd_window = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "block_small")) { o.block_small = value != 0; return 0; }
+    if (!std::strcmp(key, "l2_tile_kb")) {
+        if (value < 0 || value > 16384) return PERCNN_PI_EINVAL;
+        o.l2_tile_kb = (int)value;
         return 0;
     }
     if (!std::strcmp(key, "lds_pad")) {

@@ -21,6 +21,20 @@ struct Geom {
     int wrap0;          // 1: axis 0 periodic; 0: two halo planes present on each side (slab)
     FastDiv dcpr, dn1;  // chunk id -> (row, chunk in row) and row -> (plane, row in plane) without integer division;
     int fastdiv;        // set by the launcher when the chunk count is < 2^31 (else the 64-bit path below is used)
+    // block-uniform decomposition of the direct step kernels (pi_fwd_kernel / pi_bwd_kernel): a workgroup covers
+    // (blockDim >> lxs) rows x (1 << lxs) 16-byte chunks of ONE plane, so plane / row-group / x-block come from
+    // blockIdx by scalar arithmetic and a lane only adds its (row, chunk) inside the block
+    int lxs;            // log2 of the lanes along x
+    int nxb, nrg;       // x-blocks per row; row groups per plane (3D) or per grid (2D)
+    unsigned nblk;      // virtual blocks = nxb * nrg * (3D: n0)
+    FastDiv dnxb, dnrg;
+    // 3D, planes too large for the L2: the rows of a plane are cut into y-tiles of `rgt` row groups and the block order is
+    // (y-tile, plane, row group in tile, x block), so that the five planes a tile's stencil touches stay resident in the
+    // XCD's L2 while the blocks march along axis 0 (rgt == 0: one tile = the whole plane)
+    int rgt, nlast;     // row groups per full tile / in the last tile
+    unsigned per_tile;  // rgt * n0
+    FastDiv dper, drgt, dlast;
+    unsigned xwin;      // forward kernel: XCD-contiguous remap inside windows of this many blocks (0 = the whole grid)
 };
 
 // radius-2 star: lap[i] = c0*f(x) + sum_axes sum_t w[axis][t] * f(x + FLIP*offs[t]); FLIP=-1 is the adjoint
@@ -110,6 +124,174 @@ __device__ __forceinline__ void chunk_coords(const Geom& g, long cid, int cpr, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Direct step kernels, addressing.
+//
+// The first version of these kernels decomposed a flat chunk id per lane (two integer divisions), kept 64-bit
+// element offsets per neighbour and re-derived every wrap per lane: the 3D forward kernel executed ~295 VALU
+// instructions per wave of which ~80 were floating point (ISA count: 38 v_lshl_add_u64, 25 v_mul_lo_u32, 17
+// v_mad_u64_u32, 54 v_cndmask ...), i.e. at 128^3 it was bound by INTEGER issue (2.4 M VALU instructions per launch
+// = 5.9 us of the 8.5 us kernel body), not by memory.  Here
+//   * the plane (3D) / row group / x block of a workgroup are scalar (SALU) functions of blockIdx,
+//   * plane neighbours are scalar base pointers (+- s0 in SGPRs), both species share every vector offset,
+//   * a lane owns ONE 32-bit byte offset inside the plane; row neighbours are that offset +- k*W with one
+//     compare/select for the periodic wrap; loads are `global_load v, v_off, s[base]` (scalar base + 32-bit offset).
+// Arithmetic and its order are unchanged (bit-identical results).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int N>
+__device__ __forceinline__ Pack<T, N> ldb(const char* __restrict__ base, unsigned byteoff)
+{
+    return *reinterpret_cast<const Pack<T, N>*>(base + byteoff);
+}
+template <typename T, int N>
+__device__ __forceinline__ void stb(char* __restrict__ base, unsigned byteoff, const Pack<T, N>& x)
+{
+    *reinterpret_cast<Pack<T, N>*>(base + byteoff) = x;
+}
+
+// what a lane knows about its chunk: everything but `eb`, `row`, `x0` is wave-uniform
+struct Lane {
+    int i0;            // plane (3D; uniform), 0 in 2D
+    int row;           // row inside the plane (3D: axis 1) or the grid (2D: axis 0)
+    int x0;            // first point of the chunk
+    unsigned eb;       // byte offset of the chunk relative to the plane base (3D) / biased field base (2D)
+    bool valid;
+};
+
+// block id -> uniform (plane, row group, x block); lane -> (row, chunk).  Invalid lanes are clamped onto the last
+// valid chunk (their loads stay in bounds, callers mask their results).
+template <typename T, int NDIM, int VEC>
+__device__ __forceinline__ Lane locate(const Geom& g, unsigned vb)
+{
+    const unsigned t = g.dnxb.div(vb);
+    const unsigned xb = vb - t * (unsigned)g.nxb;
+    unsigned rg = t, pl = 0;
+    if constexpr (NDIM == 3) {
+        if (g.rgt == 0) {
+            pl = g.dnrg.div(t);
+            rg = t - pl * (unsigned)g.nrg;
+        } else {
+            const unsigned yt = g.dper.div(t);                       // all tiles before the last one are full
+            const unsigned r = t - yt * g.per_tile;
+            const bool last = (yt + 1u) * (unsigned)g.rgt >= (unsigned)g.nrg;
+            pl = last ? g.dlast.div(r) : g.drgt.div(r);
+            rg = yt * (unsigned)g.rgt + (r - pl * (unsigned)(last ? g.nlast : g.rgt));
+        }
+    }
+    const int lx = 1 << g.lxs;
+    const int xi = (int)threadIdx.x & (lx - 1), ri = (int)threadIdx.x >> g.lxs;
+    const int cpr = g.W / VEC;
+    const int nrow = NDIM == 3 ? g.n1 : g.n0;
+    int chunk = (int)xb * lx + xi;
+    int row = (int)rg * ((int)blockDim.x >> g.lxs) + ri;
+    Lane L;
+    L.valid = chunk < cpr && row < nrow;
+    chunk = min(chunk, cpr - 1);
+    row = min(row, nrow - 1);
+    L.i0 = (int)pl;
+    L.row = row;
+    L.x0 = chunk * VEC;
+    // 2D: bias of two rows keeps the offsets of rows -2, -1 (slab layout: halo rows below the first computed one)
+    // non-negative in unsigned arithmetic; the callers subtract it from the scalar base
+    const unsigned bias = NDIM == 2 ? 2u * (unsigned)g.W : 0u;
+    L.eb = ((unsigned)row * (unsigned)g.W + (unsigned)L.x0 + bias) * (unsigned)sizeof(T);
+    return L;
+}
+
+// Pin a wave-uniform pointer into an SGPR pair.  Without it LLVM reassociates  base + delta*s0 + zext(offset)  into a
+// per-lane 64-bit multiply-add (v_mad_u64_u32 + a VGPR-pair address) for every plane neighbour.
+__device__ __forceinline__ const char* sgpr_ptr(const char* p)
+{
+    asm("" : "+s"(p));
+    return p;
+}
+
+// scalar base of species plane set `f` (already offset to species / first computed plane) for this block
+template <typename T, int NDIM>
+__device__ __forceinline__ const char* plane_base(const T* f, const Geom& g, int i0)
+{
+    if constexpr (NDIM == 3) return sgpr_ptr(reinterpret_cast<const char*>(f + (long)i0 * g.s0));
+    else return sgpr_ptr(reinterpret_cast<const char*>(f) - (size_t)2 * g.W * sizeof(T));
+}
+
+// radius-2 star of the lane's VEC points; pb = plane_base(field).  Tap order as pi::star: centre, axis 0, (axis 1,) x.
+template <typename T, int NDIM, int VEC, int FLIP>
+__device__ __forceinline__ void star2(const char* __restrict__ pb, const T* __restrict__ P, const Geom& g, const Lane& L,
+                                      const Pack<T, VEC>& c, T (&lap)[VEC])
+{
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) lap[i] = P[P_C0] * c.v[i];
+    const unsigned Wb = (unsigned)g.W * (unsigned)sizeof(T);
+    if constexpr (NDIM == 3) {
+        // axis 0: neighbouring planes -- scalar pointers, the lane's offset is unchanged
+        const long s0b = g.s0 * (long)sizeof(T);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = FLIP * (t < 2 ? t - 2 : t - 1);
+            int j0 = L.i0 + k;
+            if (g.wrap0) j0 = wrap_near(j0, g.n0);
+#if defined(PI_EXPERIMENT) && PI_EXPERIMENT >= 1      // timing experiments only (wrong results): no plane-neighbour loads
+            const Pack<T, VEC> nb = c;
+            (void)s0b; (void)j0;
+#else
+            const Pack<T, VEC> nb = ldb<T, VEC>(sgpr_ptr(pb + (long)(j0 - L.i0) * s0b), L.eb);
+#endif
+            const T w = P[P_TAPS + t];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) lap[i] = fma_(w, nb.v[i], lap[i]);
+        }
+    }
+    {
+        // rows: axis 1 of a 3D plane (always periodic) or axis 0 of a 2D grid (periodic unless slab layout)
+        const int nrow = NDIM == 3 ? g.n1 : g.n0;
+        const bool wrap = NDIM == 3 ? true : (g.wrap0 != 0);
+        const unsigned span = (unsigned)nrow * Wb;
+        constexpr int TB = NDIM == 3 ? P_TAPS + 4 : P_TAPS;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = FLIP * (t < 2 ? t - 2 : t - 1);
+            const int jr = L.row + k;
+            unsigned off = L.eb + (unsigned)(k * (int)Wb);
+            if (wrap) off += jr < 0 ? span : (jr >= nrow ? 0u - span : 0u);
+#if defined(PI_EXPERIMENT) && PI_EXPERIMENT >= 2      // ... and no row-neighbour loads either
+            const Pack<T, VEC> nb = c;
+            (void)off;
+#else
+            const Pack<T, VEC> nb = ldb<T, VEC>(pb, off);
+#endif
+            const T w = P[TB + t];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) lap[i] = fma_(w, nb.v[i], lap[i]);
+        }
+    }
+    // fastest axis: window x0-2 .. x0+VEC+1 of the lane's own row
+    T win[VEC + 4];
+    const unsigned rowb = L.eb - (unsigned)L.x0 * (unsigned)sizeof(T);
+    if constexpr (VEC == 1) {
+        win[0] = ldb<T, 1>(pb, rowb + (unsigned)wrap_near(L.x0 - 2, g.W) * (unsigned)sizeof(T)).v[0];
+        win[1] = ldb<T, 1>(pb, rowb + (unsigned)wrap_near(L.x0 - 1, g.W) * (unsigned)sizeof(T)).v[0];
+        win[3] = ldb<T, 1>(pb, rowb + (unsigned)wrap_near(L.x0 + 1, g.W) * (unsigned)sizeof(T)).v[0];
+        win[4] = ldb<T, 1>(pb, rowb + (unsigned)wrap_near(L.x0 + 2, g.W) * (unsigned)sizeof(T)).v[0];
+    } else {
+        const int xl = L.x0 >= 2 ? L.x0 - 2 : L.x0 - 2 + g.W;
+        const int xr = L.x0 + VEC < g.W ? L.x0 + VEC : L.x0 + VEC - g.W;
+        const Pack<T, 2> l = ldb<T, 2>(pb, rowb + (unsigned)xl * (unsigned)sizeof(T));
+        const Pack<T, 2> r = ldb<T, 2>(pb, rowb + (unsigned)xr * (unsigned)sizeof(T));
+        win[0] = l.v[0]; win[1] = l.v[1];
+        win[VEC + 2] = r.v[0]; win[VEC + 3] = r.v[1];
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) win[2 + i] = c.v[i];
+    constexpr int TX = P_TAPS + 4 * (NDIM - 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = FLIP * (t < 2 ? t - 2 : t - 1);
+        const T w = P[TX + t];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) lap[i] = fma_(w, win[2 + i + k], lap[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward: out = h + dt * (coef * Lap(h) + Wh4(Wh1(h) * Wh2(h) * Wh3(h)))
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NDIM, int HC, int VEC>
@@ -117,62 +299,69 @@ __global__ void __launch_bounds__(256)
 pi_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict__ P, Geom g, int hc_rt)
 {
     const int hc = HC > 0 ? HC : hc_rt;      // unused when HC == POLY
-    const int cpr = g.W / VEC;
-    const long nchunks = (long)g.rows * cpr;
-    const long cid = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    if (cid >= nchunks) return;
-    int i0, i1, x0;
-    long e;
-    chunk_coords<NDIM>(g, cid, cpr, VEC, i0, i1, x0, e);
+    // one virtual block (plane, row group, x block) per workgroup, or -- large grids -- a bounded grid of workgroups
+    // that walk the virtual blocks in order (the launcher caps the grid: a quarter of a million 1024-point workgroups
+    // run at the dispatcher's pace, not the memory system's)
+    unsigned first = xcd_remap(blockIdx.x, gridDim.x);
+    if (g.xwin) {                                   // all XCDs inside one window of the grid at a time (see launch_fwd)
+        const unsigned base = blockIdx.x / g.xwin * g.xwin;
+        const unsigned len = min(g.xwin, gridDim.x - base);
+        first = base + xcd_remap(blockIdx.x - base, len);
+    }
+    for (unsigned vb = first; vb < g.nblk; vb += gridDim.x) {
+        const Lane L = locate<T, NDIM, VEC>(g, vb);
+        if (!L.valid) continue;
 
-    const T* hu = h + g.off;
-    const T* hv = h + g.ss + g.off;
-    const Pack<T, VEC> cu = ld<T, VEC>(hu + e), cv = ld<T, VEC>(hv + e);
-    T lap[2][VEC];
-    star<T, NDIM, VEC, +1>(hu, P, g, i0, i1, x0, e, cu, lap[0]);
-    star<T, NDIM, VEC, +1>(hv, P, g, i0, i1, x0, e, cv, lap[1]);
+        const char* pu = plane_base<T, NDIM>(h + g.off, g, L.i0);
+        const char* pv = plane_base<T, NDIM>(h + g.ss + g.off, g, L.i0);
+        const Pack<T, VEC> cu = ldb<T, VEC>(pu, L.eb), cv = ldb<T, VEC>(pv, L.eb);
+        T lap[2][VEC];
+        star2<T, NDIM, VEC, +1>(pu, P, g, L, cu, lap[0]);
+        star2<T, NDIM, VEC, +1>(pv, P, g, L, cv, lap[1]);
 
-    const T dt = P[P_DT];
-    // The species / hidden-channel loops stay ROLLED on purpose: a fully unrolled body is several KiB
-    // of straight-line code that every wave executes exactly once, and at one wave per SIMD the
-    // kernel then runs at instruction-fetch speed (measured ~16 cycles per VALU op).  The rolled
-    // body is ~40 instructions, I$-resident, with next channel's 10 scalars prefetched into SGPRs.
+        const T dt = P[P_DT];
+        // The species / hidden-channel loops stay ROLLED on purpose: a fully unrolled body is several KiB
+        // of straight-line code that every wave executes exactly once, and at one wave per SIMD the
+        // kernel then runs at instruction-fetch speed (measured ~16 cycles per VALU op).  The rolled
+        // body is ~40 instructions, I$-resident, with next channel's 10 scalars prefetched into SGPRs.
 #pragma clang loop unroll(disable)
-    for (int s = 0; s < 2; ++s) {
-        T rr[VEC];
-        if constexpr (HC == POLY) {
-            const T* c = P + P_W + 10 * s;
+        for (int s = 0; s < 2; ++s) {
+            T rr[VEC];
+            if constexpr (HC == POLY) {
+                const T* c = P + P_W + 10 * s;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) rr[i] = poly_r(c, cu.v[i], cv.v[i]);
-        } else {
-            const T* W = P + P_W + s * species_block(hc);
+                for (int i = 0; i < VEC; ++i) rr[i] = poly_r(c, cu.v[i], cv.v[i]);
+            } else {
+                const T* W = P + P_W + s * species_block(hc);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) rr[i] = W[10 * hc];
-            W10<T> nx = load_w10(W);
+                for (int i = 0; i < VEC; ++i) rr[i] = W[10 * hc];
+                W10<T> nx = load_w10(W);
 #pragma clang loop unroll(disable)
-            for (int j = 0; j < hc; ++j) {
-                const W10<T> c = nx;
-                if (j + 1 < hc) nx = load_w10(W + 10 * (j + 1));
+                for (int j = 0; j < hc; ++j) {
+                    const W10<T> c = nx;
+                    if (j + 1 < hc) nx = load_w10(W + 10 * (j + 1));
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    const T a1 = fma_(c.w[0], cu.v[i], fma_(c.w[1], cv.v[i], c.w[2]));
-                    const T a2 = fma_(c.w[3], cu.v[i], fma_(c.w[4], cv.v[i], c.w[5]));
-                    const T a3 = fma_(c.w[6], cu.v[i], fma_(c.w[7], cv.v[i], c.w[8]));
-                    rr[i] = fma_(c.w[9], (a1 * a2) * a3, rr[i]);
+                    for (int i = 0; i < VEC; ++i) {
+                        const T a1 = fma_(c.w[0], cu.v[i], fma_(c.w[1], cv.v[i], c.w[2]));
+                        const T a2 = fma_(c.w[3], cu.v[i], fma_(c.w[4], cv.v[i], c.w[5]));
+                        const T a3 = fma_(c.w[6], cu.v[i], fma_(c.w[7], cv.v[i], c.w[8]));
+                        rr[i] = fma_(c.w[9], (a1 * a2) * a3, rr[i]);
+                    }
                 }
             }
-        }
-        const T coef = P[P_COEF + s];
-        Pack<T, VEC> o;
+            const T coef = P[P_COEF + s];
+            Pack<T, VEC> o;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const T hs = s == 0 ? cu.v[i] : cv.v[i];
-            const T lp = s == 0 ? lap[0][i] : lap[1][i];
-            const T res = coef * lp + rr[i];            // two roundings (train_2drd.py:115)
-            const T inc = res * dt;                     // two roundings (train_2drd.py:117)
-            o.v[i] = hs + inc;
+            for (int i = 0; i < VEC; ++i) {
+                const T hs = s == 0 ? cu.v[i] : cv.v[i];
+                const T lp = s == 0 ? lap[0][i] : lap[1][i];
+                const T res = coef * lp + rr[i];            // two roundings (train_2drd.py:115)
+                const T inc = res * dt;                     // two roundings (train_2drd.py:117)
+                o.v[i] = hs + inc;
+            }
+            char* po = const_cast<char*>(plane_base<T, NDIM>(out + s * g.ss + g.off, g, L.i0));
+            stb<T, VEC>(po, L.eb, o);
         }
-        st<T, VEC>(out + s * g.ss + g.off + e, o);
     }
 }
 
@@ -200,15 +389,17 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
     double* redc = reinterpret_cast<double*>(smem_raw + ((size_t)nwaves * np * sizeof(T) + 15) / 16 * 16);   // [nwaves][2]
     for (int i = threadIdx.x; i < nwaves * np; i += blockDim.x) red[i] = T(0);
     if (threadIdx.x < 2 * nwaves) redc[threadIdx.x] = 0.0;
+    // running partial of this workgroup's row: requested NOW, needed at the very end (a dependent load -> add -> store
+    // in the tail of every launch otherwise; same fix as in the tile sweep)
+    auto carries_grad = [&](int idx) {
+        if (idx >= np || idx == P_DT || (idx >= P_C0 && idx < P_W)) return false;   // dt, frozen stencil: no gradient
+        return WGRAD || idx < P_W;                                                  // sweep-only flavour: coefficients only
+    };
+    double* const prow = partials + (long)blockIdx.x * np;
+    const double pold = carries_grad((int)threadIdx.x) ? prow[threadIdx.x] : 0.0;
     __syncthreads();
 
-    const int cpr = g.W / VEC;
-    const long nchunks = (long)g.rows * cpr;
     const T dt = P[P_DT];
-    const long stride = (long)gridDim.x * blockDim.x;
-    const long first = (long)xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    // every wave runs the same number of iterations (wave-level reductions inside)
-    const long iters = (nchunks + stride - 1) / stride;
 
     double lane_c[2] = {0.0, 0.0};
     // poly mode with fused gradients: the 20 coefficient moments stay in registers over all chunks of the lane and are
@@ -222,19 +413,20 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
             for (int m = 0; m < 10; ++m) macc[s][m] = T(0);
     }
 
-    for (long it = 0; it < iters; ++it) {
-        const long cid_raw = first + it * stride;
-        const bool valid = cid_raw < nchunks;
-        const long cid = valid ? cid_raw : nchunks - 1;
-        int i0, i1, x0;
-        long e;
-        chunk_coords<NDIM>(g, cid, cpr, VEC, i0, i1, x0, e);
-
-        const Pack<T, VEC> u = ld<T, VEC>(h + g.off + e), v = ld<T, VEC>(h + g.ss + g.off + e);
-        Pack<T, VEC> gc[2] = {ld<T, VEC>(G + g.off + e), ld<T, VEC>(G + g.ss + g.off + e)};
+    // virtual blocks (plane, row group, x block) of this workgroup: block-uniform trip count (wave-level reductions
+    // inside need whole waves, which a uniform loop guarantees); addressing as in the forward kernel
+    for (unsigned vb = xcd_remap(blockIdx.x, gridDim.x); vb < g.nblk; vb += gridDim.x) {
+        const Lane L = locate<T, NDIM, VEC>(g, vb);
+        const bool valid = L.valid;
+        const char* phu = plane_base<T, NDIM>(h + g.off, g, L.i0);
+        const char* phv = plane_base<T, NDIM>(h + g.ss + g.off, g, L.i0);
+        const char* pgu = plane_base<T, NDIM>(G + g.off, g, L.i0);
+        const char* pgv = plane_base<T, NDIM>(G + g.ss + g.off, g, L.i0);
+        const Pack<T, VEC> u = ldb<T, VEC>(phu, L.eb), v = ldb<T, VEC>(phv, L.eb);
+        Pack<T, VEC> gc[2] = {ldb<T, VEC>(pgu, L.eb), ldb<T, VEC>(pgv, L.eb)};
         T dl[2][VEC];
-        star<T, NDIM, VEC, -1>(G + g.off, P, g, i0, i1, x0, e, gc[0], dl[0]);
-        star<T, NDIM, VEC, -1>(G + g.ss + g.off, P, g, i0, i1, x0, e, gc[1], dl[1]);
+        star2<T, NDIM, VEC, -1>(pgu, P, g, L, gc[0], dl[0]);
+        star2<T, NDIM, VEC, -1>(pgv, P, g, L, gc[1], dl[1]);
         const T live = valid ? T(1) : T(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -356,12 +548,13 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
                 ov.v[i] = gc[1].v[i] + tv;
             }
             if (inj) {
-                const Pack<T, VEC> ju = ld<T, VEC>(inj + g.off + e), jv = ld<T, VEC>(inj + g.ss + g.off + e);
+                const Pack<T, VEC> ju = ldb<T, VEC>(plane_base<T, NDIM>(inj + g.off, g, L.i0), L.eb);
+                const Pack<T, VEC> jv = ldb<T, VEC>(plane_base<T, NDIM>(inj + g.ss + g.off, g, L.i0), L.eb);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) { ou.v[i] += ju.v[i]; ov.v[i] += jv.v[i]; }
             }
-            st<T, VEC>(Gp + g.off + e, ou);
-            st<T, VEC>(Gp + g.ss + g.off + e, ov);
+            stb<T, VEC>(const_cast<char*>(plane_base<T, NDIM>(Gp + g.off, g, L.i0)), L.eb, ou);
+            stb<T, VEC>(const_cast<char*>(plane_base<T, NDIM>(Gp + g.ss + g.off, g, L.i0)), L.eb, ov);
         }
     }
 
@@ -383,14 +576,13 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < np; idx += blockDim.x) {
-        if (idx == P_DT || (idx >= P_C0 && idx < P_W)) continue;   // dt and the frozen stencil carry no gradient
-        if (!WGRAD && idx >= P_W) break;                           // sweep-only flavour: coefficients only
+        if (!carries_grad(idx)) continue;
         double s = 0.0;
         if (idx == P_COEF || idx == P_COEF + 1)
             for (int w = 0; w < nwaves; ++w) s += redc[w * 2 + idx - P_COEF];
         else
             for (int w = 0; w < nwaves; ++w) s += (double)red[w * np + idx];
-        partials[(long)blockIdx.x * np + idx] += s;
+        prow[idx] = (idx == (int)threadIdx.x ? pold : prow[idx]) + s;
     }
 }
 
