@@ -110,7 +110,8 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *                  0 never, 1 wherever a fused flavour exists, 2 (default) float32 pre-contracted blocks on the direct
  *                  / plane-streaming kernels
  *   "tile_fuse"    1 (default): the float32 pre-contracted tile sweep with 32x32 tiles reduces the 20 coefficient
- *                  moments itself and stores only every K-th adjoint frame (no separate moments pass); 0: split schedule
+ *                  moments itself and stores only every K-th adjoint frame (no separate moments pass); 0: split schedule;
+ *                  2: float64 blocks too (register-bound there: measured slower than the split schedule)
  *   "l2_tile_kb"   direct 3D kernels: the rows of a plane are processed in y-tiles of this many KiB (both species; default
  *                  128, 0 = whole planes) and the workgroups march along axis 0 tile by tile, so the five planes a tile's
  *                  stencil reads stay in the XCD's L2 when whole planes do not fit (e.g. 384^3)

@@ -396,8 +396,11 @@ int stream3d_vec(const Problem& p, std::initializer_list<const void*> ptrs)
     // the few-plane faces themselves, which are not worth a z-march)
     if (p.lo >= 0 && p.hi - p.lo < 8 && p.opt.stream3d == 1) return 0;
     const int64_t pts = (p.n0 + (p.slab ? 2 * p.halo : 0)) * p.n1 * p.W;
-    const bool full_width = p.W == (int64_t)pi::WAVE * pi::vec_width<T>::value;
-    if (p.opt.stream3d == 1 && pts < ((int64_t)(full_width ? 2 : 3) << 20)) return 0;
+    // Round 2 (direct kernels with scalar plane addressing + L2 y-tiling): a z-march only pays with enough planes per
+    // workgroup chain -- the 32-plane slabs of the 8-GPU 256^3 problem now run faster on the direct kernels (47.9 vs
+    // 58.7 us per fwd+bwd step, profiles/r02_slab_n1.txt); the whole 256^3 domain still prefers streaming forward
+    // (66 vs 101 us) and ties backward (143 vs 147 us)
+    if (p.opt.stream3d == 1 && (pts < ((int64_t)3 << 20) || p.n0 < 64)) return 0;
     if (p.hc != 0 && p.hc != 2 && p.hc != 4 && p.hc != 8) return 0;
     if (p.n1 % STREAM_TY) return 0;
     int vec = 0;
@@ -600,19 +603,20 @@ bool tile_fuse_ok(const Problem& p)
     // measured on MI355X (backward us per step, split -> fused): 384^2 3.37 -> 3.20, 512^2 3.90 -> 3.29, 1000^2 13.4 -> 11.3;
     // in the 16-row-tile regime (<= 128 tiles of 32x32, e.g. the reference's 100^2) the extra VALU work sits on the one
     // critical workgroup chain and loses (2.26 -> 2.66), so it keeps the split schedule
-    return p.opt.tile_fuse && !p.opt.skip_wgrad && sizeof(T) == 4 && p.hc == 0 && p.opt.tile_k == 4 &&
-           p.opt.tile_nt == 512 && tile_by_for(p) == TILE_B;
+    // float64 (lambda-omega): the flavour exists (scalar accumulators, moments after the stores, no operand pipeline) but
+    // still needs more than the 256 registers of a 512-thread workgroup -- 57 spilled doubles -- and LOSES: 512^2 backward
+    // 5.98 -> 9.13 us per step on MI355X (profiles/r02_fp64_fused_tile_sweep.txt); opt-in only (tile_fuse = 2)
+    return p.opt.tile_fuse && (sizeof(T) == 4 || p.opt.tile_fuse == 2) && !p.opt.skip_wgrad && p.hc == 0 &&
+           p.opt.tile_k == 4 && p.opt.tile_nt == 512 && tile_by_for(p) == TILE_B;
 }
 
 template <typename T>
 hipError_t adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, unsigned inj_mask, T* g_h0, int steps_to_zero,
                     double* partials, const T* P, const Problem& p, hipStream_t st)
 {
-    if constexpr (sizeof(T) == 4) {
-        if (tile_fuse_ok<T>(p))
-            return launch_adj_tile<T, pi::POLY, 4, 512, TILE_B, true>(hframe_t, gframe_t, aframe_t, inj_mask, g_h0,
-                                                                      steps_to_zero, partials, P, p, st);
-    }
+    if (tile_fuse_ok<T>(p))
+        return launch_adj_tile<T, pi::POLY, 4, 512, TILE_B, true>(hframe_t, gframe_t, aframe_t, inj_mask, g_h0,
+                                                                  steps_to_zero, partials, P, p, st);
 #define CALL_AT(HC, K, NT, ...) \
     launch_adj_tile<T, HC, K, NT, ##__VA_ARGS__>(hframe_t, gframe_t, aframe_t, inj_mask, g_h0, steps_to_zero, partials, P, p, st)
     PI_TILE_DISPATCH(CALL_AT);
@@ -1107,7 +1111,11 @@ int apply_option(Options& o, const char* key, long value)
         o.overlap_chunk = (int)value;
         return 0;
     }
-    if (!std::strcmp(key, "tile_fuse")) { o.tile_fuse = value != 0; return 0; }
+    if (!std::strcmp(key, "tile_fuse")) {                        // 0 split, 1 fused for float32 (default), 2 fused for float64 too
+        if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
+        o.tile_fuse = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "bwd_cpl")) {
         if (value < 1 || value > 16) return PERCNN_PI_EINVAL;
         o.bwd_cpl = (int)value;

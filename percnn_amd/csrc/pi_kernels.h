@@ -35,6 +35,8 @@ struct Geom {
     unsigned per_tile;  // rgt * n0
     FastDiv dper, drgt, dlast;
     unsigned xwin;      // forward kernel: XCD-contiguous remap inside windows of this many blocks (0 = the whole grid)
+    int rz;             // 3D: consecutive planes one workgroup pass computes (plane neighbours shared in registers); the
+                        // "planes" of the block decomposition above are groups of rz planes
 };
 
 // radius-2 star: lap[i] = c0*f(x) + sum_axes sum_t w[axis][t] * f(x + FLIP*offs[t]); FLIP=-1 is the adjoint
@@ -187,7 +189,7 @@ __device__ __forceinline__ Lane locate(const Geom& g, unsigned vb)
     L.valid = chunk < cpr && row < nrow;
     chunk = min(chunk, cpr - 1);
     row = min(row, nrow - 1);
-    L.i0 = (int)pl;
+    L.i0 = NDIM == 3 ? (int)pl * g.rz : 0;          // first plane of the group
     L.row = row;
     L.x0 = chunk * VEC;
     // 2D: bias of two rows keeps the offsets of rows -2, -1 (slab layout: halo rows below the first computed one)
@@ -213,33 +215,12 @@ __device__ __forceinline__ const char* plane_base(const T* f, const Geom& g, int
     else return sgpr_ptr(reinterpret_cast<const char*>(f) - (size_t)2 * g.W * sizeof(T));
 }
 
-// radius-2 star of the lane's VEC points; pb = plane_base(field).  Tap order as pi::star: centre, axis 0, (axis 1,) x.
+// in-plane part of the radius-2 star (rows, then the fastest axis) accumulated onto `lap`; pb = base of the plane
 template <typename T, int NDIM, int VEC, int FLIP>
-__device__ __forceinline__ void star2(const char* __restrict__ pb, const T* __restrict__ P, const Geom& g, const Lane& L,
-                                      const Pack<T, VEC>& c, T (&lap)[VEC])
+__device__ __forceinline__ void star2_inplane(const char* __restrict__ pb, const T* __restrict__ P, const Geom& g,
+                                              const Lane& L, const Pack<T, VEC>& c, T (&lap)[VEC])
 {
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) lap[i] = P[P_C0] * c.v[i];
     const unsigned Wb = (unsigned)g.W * (unsigned)sizeof(T);
-    if constexpr (NDIM == 3) {
-        // axis 0: neighbouring planes -- scalar pointers, the lane's offset is unchanged
-        const long s0b = g.s0 * (long)sizeof(T);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int k = FLIP * (t < 2 ? t - 2 : t - 1);
-            int j0 = L.i0 + k;
-            if (g.wrap0) j0 = wrap_near(j0, g.n0);
-#if defined(PI_EXPERIMENT) && PI_EXPERIMENT >= 1      // timing experiments only (wrong results): no plane-neighbour loads
-            const Pack<T, VEC> nb = c;
-            (void)s0b; (void)j0;
-#else
-            const Pack<T, VEC> nb = ldb<T, VEC>(sgpr_ptr(pb + (long)(j0 - L.i0) * s0b), L.eb);
-#endif
-            const T w = P[P_TAPS + t];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) lap[i] = fma_(w, nb.v[i], lap[i]);
-        }
-    }
     {
         // rows: axis 1 of a 3D plane (always periodic) or axis 0 of a 2D grid (periodic unless slab layout)
         const int nrow = NDIM == 3 ? g.n1 : g.n0;
@@ -252,7 +233,7 @@ __device__ __forceinline__ void star2(const char* __restrict__ pb, const T* __re
             const int jr = L.row + k;
             unsigned off = L.eb + (unsigned)(k * (int)Wb);
             if (wrap) off += jr < 0 ? span : (jr >= nrow ? 0u - span : 0u);
-#if defined(PI_EXPERIMENT) && PI_EXPERIMENT >= 2      // ... and no row-neighbour loads either
+#if defined(PI_EXPERIMENT) && PI_EXPERIMENT >= 2      // timing experiments only (wrong results): no row-neighbour loads
             const Pack<T, VEC> nb = c;
             (void)off;
 #else
@@ -291,76 +272,134 @@ __device__ __forceinline__ void star2(const char* __restrict__ pb, const T* __re
     }
 }
 
+// The lane's chunk in planes i0-2 .. i0+RZ+1 of one species (3D): the register window the RZ output planes of a
+// workgroup pass share -- RZ + 4 plane loads (scalar base pointers) instead of 5 * RZ.  fs = species base + g.off.
+template <typename T, int VEC, int RZ>
+struct PlaneWindow {
+    Pack<T, VEC> w[RZ + 4];
+    __device__ __forceinline__ void load(const T* fs, const Geom& g, const Lane& L)
+    {
+#pragma unroll
+        for (int j = 0; j < RZ + 4; ++j) {
+            int jz = L.i0 - 2 + j;
+            if (g.wrap0) jz = jz < 0 ? jz + g.n0 : (jz >= g.n0 ? jz - g.n0 : jz);
+            else jz = min(jz, g.n0 + 1);                   // slab layout: two halo planes beyond the computed range exist
+            if (RZ > 1 && g.wrap0 && jz >= g.n0) jz -= g.n0;   // partial last group of a grid with fewer than RZ + 2 planes
+#if defined(PI_EXPERIMENT) && PI_EXPERIMENT >= 1      // timing experiments only (wrong results): no plane-neighbour loads
+            if (j < 2 || j >= RZ + 2) { w[j] = Pack<T, VEC>{}; continue; }
+#endif
+            w[j] = ldb<T, VEC>(sgpr_ptr(reinterpret_cast<const char*>(fs + (long)jz * g.s0)), L.eb);
+        }
+    }
+    // centre + axis-0 taps of output plane j (0 <= j < RZ): the first five terms of the star, in pi::star's order
+    template <int FLIP>
+    __device__ __forceinline__ void planes(int j, const T* __restrict__ P, T (&lap)[VEC]) const
+    {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) lap[i] = P[P_C0] * w[j + 2].v[i];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = FLIP * (t < 2 ? t - 2 : t - 1);
+            const T wt = P[P_TAPS + t];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) lap[i] = fma_(wt, w[j + 2 + k].v[i], lap[i]);
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // forward: out = h + dt * (coef * Lap(h) + Wh4(Wh1(h) * Wh2(h) * Wh3(h)))
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NDIM, int HC, int VEC>
+template <typename T, int NDIM, int HC, int VEC, int RZ = 1>
 __global__ void __launch_bounds__(256)
 pi_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict__ P, Geom g, int hc_rt)
 {
+    static_assert(NDIM == 3 || RZ == 1, "plane blocking is a 3D notion");
     const int hc = HC > 0 ? HC : hc_rt;      // unused when HC == POLY
-    // one virtual block (plane, row group, x block) per workgroup, or -- large grids -- a bounded grid of workgroups
-    // that walk the virtual blocks in order (the launcher caps the grid: a quarter of a million 1024-point workgroups
-    // run at the dispatcher's pace, not the memory system's)
+    // one virtual block (plane group, row group, x block) per workgroup, or -- option fwd_blocks -- a bounded grid of
+    // workgroups that walk the virtual blocks in order (measured slower: 384^3 376 -> 416 us)
     unsigned first = xcd_remap(blockIdx.x, gridDim.x);
     if (g.xwin) {                                   // all XCDs inside one window of the grid at a time (see launch_fwd)
         const unsigned base = blockIdx.x / g.xwin * g.xwin;
         const unsigned len = min(g.xwin, gridDim.x - base);
         first = base + xcd_remap(blockIdx.x - base, len);
     }
+    const T dt = P[P_DT];
     for (unsigned vb = first; vb < g.nblk; vb += gridDim.x) {
         const Lane L = locate<T, NDIM, VEC>(g, vb);
         if (!L.valid) continue;
-
-        const char* pu = plane_base<T, NDIM>(h + g.off, g, L.i0);
-        const char* pv = plane_base<T, NDIM>(h + g.ss + g.off, g, L.i0);
-        const Pack<T, VEC> cu = ldb<T, VEC>(pu, L.eb), cv = ldb<T, VEC>(pv, L.eb);
-        T lap[2][VEC];
-        star2<T, NDIM, VEC, +1>(pu, P, g, L, cu, lap[0]);
-        star2<T, NDIM, VEC, +1>(pv, P, g, L, cv, lap[1]);
-
-        const T dt = P[P_DT];
-        // The species / hidden-channel loops stay ROLLED on purpose: a fully unrolled body is several KiB
-        // of straight-line code that every wave executes exactly once, and at one wave per SIMD the
-        // kernel then runs at instruction-fetch speed (measured ~16 cycles per VALU op).  The rolled
-        // body is ~40 instructions, I$-resident, with next channel's 10 scalars prefetched into SGPRs.
-#pragma clang loop unroll(disable)
-        for (int s = 0; s < 2; ++s) {
-            T rr[VEC];
-            if constexpr (HC == POLY) {
-                const T* c = P + P_W + 10 * s;
+        const T* hs[2] = {h + g.off, h + g.ss + g.off};
+        // 3D: the lane's chunk in planes i0-2 .. i0+RZ+1, both species, requested up front (RZ + 4 loads per species
+        // serve RZ output planes)
+        PlaneWindow<T, VEC, NDIM == 3 ? RZ : 1> win[2];
+        if constexpr (NDIM == 3) {
+            win[0].load(hs[0], g, L);
+            win[1].load(hs[1], g, L);
+        }
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) rr[i] = poly_r(c, cu.v[i], cv.v[i]);
+        for (int j = 0; j < RZ; ++j) {
+            const int iz = L.i0 + j;
+            if (NDIM == 3 && iz >= g.n0) break;          // partial last plane group (block-uniform)
+            const char* pu = plane_base<T, NDIM>(hs[0], g, iz);
+            const char* pv = plane_base<T, NDIM>(hs[1], g, iz);
+            Pack<T, VEC> cu, cv;
+            T lap[2][VEC];
+            if constexpr (NDIM == 3) {
+                cu = win[0].w[j + 2];
+                cv = win[1].w[j + 2];
+                win[0].template planes<+1>(j, P, lap[0]);
+                win[1].template planes<+1>(j, P, lap[1]);
             } else {
-                const T* W = P + P_W + s * species_block(hc);
+                cu = ldb<T, VEC>(pu, L.eb);
+                cv = ldb<T, VEC>(pv, L.eb);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) rr[i] = W[10 * hc];
-                W10<T> nx = load_w10(W);
+                for (int i = 0; i < VEC; ++i) { lap[0][i] = P[P_C0] * cu.v[i]; lap[1][i] = P[P_C0] * cv.v[i]; }
+            }
+            star2_inplane<T, NDIM, VEC, +1>(pu, P, g, L, cu, lap[0]);
+            star2_inplane<T, NDIM, VEC, +1>(pv, P, g, L, cv, lap[1]);
+
+            // The species / hidden-channel loops stay ROLLED on purpose: a fully unrolled body is several KiB
+            // of straight-line code that every wave executes exactly once, and at one wave per SIMD the
+            // kernel then runs at instruction-fetch speed (measured ~16 cycles per VALU op).  The rolled
+            // body is ~40 instructions, I$-resident, with next channel's 10 scalars prefetched into SGPRs.
 #pragma clang loop unroll(disable)
-                for (int j = 0; j < hc; ++j) {
-                    const W10<T> c = nx;
-                    if (j + 1 < hc) nx = load_w10(W + 10 * (j + 1));
+            for (int s = 0; s < 2; ++s) {
+                T rr[VEC];
+                if constexpr (HC == POLY) {
+                    const T* c = P + P_W + 10 * s;
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) {
-                        const T a1 = fma_(c.w[0], cu.v[i], fma_(c.w[1], cv.v[i], c.w[2]));
-                        const T a2 = fma_(c.w[3], cu.v[i], fma_(c.w[4], cv.v[i], c.w[5]));
-                        const T a3 = fma_(c.w[6], cu.v[i], fma_(c.w[7], cv.v[i], c.w[8]));
-                        rr[i] = fma_(c.w[9], (a1 * a2) * a3, rr[i]);
+                    for (int i = 0; i < VEC; ++i) rr[i] = poly_r(c, cu.v[i], cv.v[i]);
+                } else {
+                    const T* W = P + P_W + s * species_block(hc);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) rr[i] = W[10 * hc];
+                    W10<T> nx = load_w10(W);
+#pragma clang loop unroll(disable)
+                    for (int jj = 0; jj < hc; ++jj) {
+                        const W10<T> c = nx;
+                        if (jj + 1 < hc) nx = load_w10(W + 10 * (jj + 1));
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            const T a1 = fma_(c.w[0], cu.v[i], fma_(c.w[1], cv.v[i], c.w[2]));
+                            const T a2 = fma_(c.w[3], cu.v[i], fma_(c.w[4], cv.v[i], c.w[5]));
+                            const T a3 = fma_(c.w[6], cu.v[i], fma_(c.w[7], cv.v[i], c.w[8]));
+                            rr[i] = fma_(c.w[9], (a1 * a2) * a3, rr[i]);
+                        }
                     }
                 }
-            }
-            const T coef = P[P_COEF + s];
-            Pack<T, VEC> o;
+                const T coef = P[P_COEF + s];
+                Pack<T, VEC> o;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                const T hs = s == 0 ? cu.v[i] : cv.v[i];
-                const T lp = s == 0 ? lap[0][i] : lap[1][i];
-                const T res = coef * lp + rr[i];            // two roundings (train_2drd.py:115)
-                const T inc = res * dt;                     // two roundings (train_2drd.py:117)
-                o.v[i] = hs + inc;
+                for (int i = 0; i < VEC; ++i) {
+                    const T hv = s == 0 ? cu.v[i] : cv.v[i];
+                    const T lp = s == 0 ? lap[0][i] : lap[1][i];
+                    const T res = coef * lp + rr[i];            // two roundings (train_2drd.py:115)
+                    const T inc = res * dt;                     // two roundings (train_2drd.py:117)
+                    o.v[i] = hv + inc;
+                }
+                char* po = const_cast<char*>(plane_base<T, NDIM>(out + s * g.ss + g.off, g, iz));
+                stb<T, VEC>(po, L.eb, o);
             }
-            char* po = const_cast<char*>(plane_base<T, NDIM>(out + s * g.ss + g.off, g, L.i0));
-            stb<T, VEC>(po, L.eb, o);
         }
     }
 }

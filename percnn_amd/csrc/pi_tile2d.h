@@ -420,7 +420,17 @@ __device__ __forceinline__ void adj_load_ops(StripOps<T>& o, int q, const T* __r
 // HBM latency of the trajectory / loss-gradient frames overlaps the window load and earlier sub-steps.
 // MOM (float32 poly mode): the 20 coefficient moments  sum_x dt*adj_t[s]*phi_m(h_{t-1})  of the OWNED points are carried in
 // registers (2-vectors, summed at the end of the launch) -- no adjoint trajectory, no separate moments pass.
-template <typename T, bool MOM> struct TileMoments { V2<T> a[MOM ? 2 : 1][MOM ? 10 : 1]; };
+// float32: 2-vector accumulators (v_pk_fma_f32); float64: scalar ones -- 40 instead of 80 VGPRs, what lets the 512-thread
+// lambda-omega sweep carry them inside its 256-register budget (together with PRE = false, see the kernel)
+template <typename T> struct MomAcc { using type = V2<T>; };
+template <> struct MomAcc<double> { using type = double; };
+template <typename T, bool MOM> struct TileMoments { typename MomAcc<T>::type a[MOM ? 2 : 1][MOM ? 10 : 1]; };
+__device__ __forceinline__ void mom_add(V2<float>& a, V2<float> g, V2<float> phi) { a = vfma(g, phi, a); }
+__device__ __forceinline__ void mom_add(double& a, V2<double> g, V2<double> phi) { a = fma_(g.x, phi.x, fma_(g.y, phi.y, a)); }
+__device__ __forceinline__ void mom_add1(V2<float>& a, V2<float> g) { a += g; }
+__device__ __forceinline__ void mom_add1(double& a, V2<double> g) { a += g.x + g.y; }
+__device__ __forceinline__ float mom_total(V2<float> a) { return a.x + a.y; }
+__device__ __forceinline__ double mom_total(double a) { return a; }
 
 template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE, bool MOM>
 __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict__ hfr, const T* __restrict__ gfr,
@@ -483,16 +493,16 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
                     poly_dr_v(c, U[h], V[h], ru, rv);
                     du[h] = vfma(gr, ru, du[h]);
                     dv[h] = vfma(gr, rv, dv[h]);
-                    if constexpr (MOM) {
-                        V2<T> (&a)[10] = mom.a[s];
+                    if constexpr (MOM && sizeof(T) == 4) {
+                        auto& a = mom.a[s];
                         const V2<T> gm = gr * own[h];
                         const V2<T> uu = U[h], vv = V[h];
                         const V2<T> u2 = uu * uu, uv = uu * vv, v2 = vv * vv;
-                        a[0] += gm;
-                        a[1] = vfma(gm, uu, a[1]); a[2] = vfma(gm, vv, a[2]);
-                        a[3] = vfma(gm, u2, a[3]); a[4] = vfma(gm, uv, a[4]); a[5] = vfma(gm, v2, a[5]);
-                        a[6] = vfma(gm, u2 * uu, a[6]); a[7] = vfma(gm, u2 * vv, a[7]);
-                        a[8] = vfma(gm, uu * v2, a[8]); a[9] = vfma(gm, v2 * vv, a[9]);
+                        mom_add1(a[0], gm);
+                        mom_add(a[1], gm, uu); mom_add(a[2], gm, vv);
+                        mom_add(a[3], gm, u2); mom_add(a[4], gm, uv); mom_add(a[5], gm, v2);
+                        mom_add(a[6], gm, u2 * uu); mom_add(a[7], gm, u2 * vv);
+                        mom_add(a[8], gm, uu * v2); mom_add(a[9], gm, v2 * vv);
                     }
                 }
             }
@@ -532,6 +542,25 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
             }
             stv2(nxt + off + 2 * h, ou);
             stv2(nxt + TL::PLANE + off + 2 * h, ov);
+        }
+        if constexpr (MOM && sizeof(T) == 8) {
+            // float64: the moments come LAST, half a strip at a time -- the stencil / Jacobian temporaries are dead by
+            // now, so the 20 accumulators (40 registers) fit the 256-register budget of the 512-thread workgroup
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const V2<T> uu = U[h], vv = V[h];
+                const V2<T> u2 = uu * uu, uv = uu * vv, v2 = vv * vv;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    auto& a = mom.a[s];
+                    const V2<T> gm = (gc[s][h] * dtv) * own[h];
+                    mom_add1(a[0], gm);
+                    mom_add(a[1], gm, uu); mom_add(a[2], gm, vv);
+                    mom_add(a[3], gm, u2); mom_add(a[4], gm, uv); mom_add(a[5], gm, v2);
+                    mom_add(a[6], gm, u2 * uu); mom_add(a[7], gm, u2 * vv);
+                    mom_add(a[8], gm, uu * v2); mom_add(a[9], gm, v2 * vv);
+                }
+            }
         }
     }
 }
@@ -580,7 +609,9 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
     using TL = Tile<K, BX, BY>;
     // Operand pipeline: one sub-step ahead (2 x 16 VGPRs).  Requesting ALL sub-steps' operands at kernel start was
     // measured slower (17.6 vs 15.5 us per K=4 launch: 64 extra VGPRs, requests queued ahead of the window load).
-    constexpr bool PRE = PI_TILE_ADJ_PIPE && TL::region_n(0) / 4 <= NT;
+    // (the float64 fused-moments flavour gives the operand pipeline's 32 registers to its 20 accumulators: with both it
+    // needs ~270 of the 256 registers a 512-thread workgroup can have and spills -- 20 -> 47 us per launch, measured)
+    constexpr bool PRE = PI_TILE_ADJ_PIPE && TL::region_n(0) / 4 <= NT && !(MOM && sizeof(T) == 8);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* b0 = reinterpret_cast<T*>(smem_raw) + lds_pad0<T>::value;
     T* b1 = reinterpret_cast<T*>(smem_raw) + 2 * TL::PLANE + lds_pad1<T>::value;
@@ -591,7 +622,7 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
     wl.issue(aframe_t, g, ty0, tx0);                       // adjoint window first, then the operands of sub-step 0
     // running diffusion-coefficient partial of this tile: requested now, needed at the very end (was a dependent
     // load -> add -> store at the end of every launch: 1 us)
-    static_assert(!MOM || (HC == POLY && sizeof(T) == 4), "fused moments: float32 poly mode");
+    static_assert(!MOM || HC == POLY, "fused moments: pre-contracted blocks");
     // slots of the partial row this thread updates at the end: threads 0,1 the two coefficient sums, MOM: threads
     // 2..21 the 20 moments (row layout of the direct kernels: P_W + 10*s + m)
     const int slot = threadIdx.x < 2 ? P_COEF + (int)threadIdx.x : P_W + (int)threadIdx.x - 2;
@@ -611,7 +642,7 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int m = 0; m < 10; ++m) mom.a[s][m] = vs(T(0));
+            for (int m = 0; m < 10; ++m) mom.a[s][m] = typename MomAcc<T>::type{};
     }
     adj_substeps<T, HC, K, BX, BY, NT, 0, PRE, MOM>(b0, b1, hframe_t, gframe_t, aframe_t, frame_stride, inj_mask, g_h0,
                                                     steps_to_zero, g, ty0, tx0, P, acc_c, ops0, mom);
@@ -631,7 +662,7 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int m = 0; m < 10; ++m) {
-                const T r = wave_sum_to_last(mom.a[s][m].x + mom.a[s][m].y);
+                const T r = wave_sum_to_last(mom_total(mom.a[s][m]));
                 if (lane == REDUCE_LANE) red[wave * NRED + 2 + 10 * s + m] = (double)r;
             }
     }
