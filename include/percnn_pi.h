@@ -112,6 +112,10 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *   "tile_fuse"    1 (default): the float32 pre-contracted tile sweep with 32x32 tiles reduces the 20 coefficient
  *                  moments itself and stores only every K-th adjoint frame (no separate moments pass); 0: split schedule;
  *                  2: float64 blocks too (register-bound there: measured slower than the split schedule)
+ *   "rz"           direct 3D kernels, pre-contracted blocks: consecutive planes per workgroup pass that share their plane
+ *                  neighbours in registers (1, 2, 4; default 0 = by grid size: large grids 4 forward / 2 backward)
+ *   "block_small"  1 (default): 128-thread workgroups for the direct kernels on grids below ~1 M points
+ *   "fwd_blocks", "xcd_window"   forward direct kernel: bounded persistent grid / windowed XCD remap (measured: no gain; off)
  *   "l2_tile_kb"   direct 3D kernels: the rows of a plane are processed in y-tiles of this many KiB (both species; default
  *                  128, 0 = whole planes) and the workgroups march along axis 0 tile by tile, so the five planes a tile's
  *                  stencil reads stay in the XCD's L2 when whole planes do not fit (e.g. 384^3)

@@ -44,6 +44,8 @@ struct Options {
     int fwd_blocks = 0;     // direct forward kernel: grid cap (0 = none; measured: a bounded persistent grid loses, 384^3 376 -> 416 us)
     int xcd_window = 0;     // direct forward kernel: XCD-contiguous block remap inside windows of this many blocks (0 = whole grid)
     int block_small = 1;    // direct kernels: 64-thread workgroups while 256-thread ones would leave CUs idle (small grids)
+    int rz = 0;             // direct 3D kernels, pre-contracted blocks: planes per workgroup pass sharing their plane neighbours in
+                            // registers (1, 2, 4; 0 = by size, see direct_rz)
     int l2_tile_kb = 128;   // direct 3D kernels: y-tile of a plane (both species, KiB) whose five stencil planes stay in the L2
                             // (0 = whole planes, the pre-round-2 order): see set_blockmap
     int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
@@ -147,7 +149,7 @@ void set_fastdiv(Geom& g, int vec)
 // block-uniform decomposition of the direct step kernels (pi_kernels.h "Direct step kernels, addressing"): lanes along x
 // = the power of two that wastes the fewest lanes on this row length; false if the grid is outside what 32-bit byte
 // offsets / 31-bit block ids address (2D: the whole local field + 4 rows, 3D: one plane, must stay below 4 GiB)
-bool set_blockmap(Geom& g, int ndim, int vec, int block, size_t elem, int l2_tile_bytes = 128 * 1024)
+bool set_blockmap(Geom& g, int ndim, int vec, int block, size_t elem, int l2_tile_bytes = 128 * 1024, int rz = 1)
 {
     const long cpr = g.W / vec;
     int lxs;
@@ -169,7 +171,9 @@ bool set_blockmap(Geom& g, int ndim, int vec, int block, size_t elem, int l2_til
     g.lxs = lxs;
     g.nxb = (int)((cpr + lx - 1) / lx);
     g.nrg = (int)((nrow + rpb - 1) / rpb);
-    const long nblk = (long)g.nxb * g.nrg * (ndim == 3 ? g.n0 : 1);
+    g.rz = ndim == 3 ? rz : 1;
+    const long ngroups = ndim == 3 ? (g.n0 + g.rz - 1) / g.rz : 1;          // plane groups of rz planes
+    const long nblk = (long)g.nxb * g.nrg * ngroups;
     const unsigned long long span = (unsigned long long)(ndim == 3 ? (long)g.n1 : (long)g.n0 + 4) * g.W * elem;
     if (nblk <= 0 || nblk >= (1L << 31) || span >= (1ull << 32)) return false;
     g.nblk = (unsigned)nblk;
@@ -184,11 +188,11 @@ bool set_blockmap(Geom& g, int ndim, int vec, int block, size_t elem, int l2_til
         const long tile_rows = (long)l2_tile_bytes / (2 * (long)g.W * (long)elem);
         long rgt = tile_rows / rpb;
         if (rgt < 1) rgt = 1;
-        if (rgt < g.nrg && (long)rgt * g.n0 < (1L << 31)) {
+        if (rgt < g.nrg && (long)rgt * ngroups < (1L << 31)) {
             const long ntile = (g.nrg + rgt - 1) / rgt;
             g.rgt = (int)rgt;
             g.nlast = (int)(g.nrg - (ntile - 1) * rgt);
-            g.per_tile = (unsigned)(rgt * g.n0);
+            g.per_tile = (unsigned)(rgt * ngroups);
             g.dper = make_fastdiv(g.per_tile);
             g.drgt = make_fastdiv((unsigned)g.rgt);
             g.dlast = make_fastdiv((unsigned)g.nlast);
@@ -203,7 +207,7 @@ Geom make_geom(const Problem& p)
     g.fastdiv = 0; g.dcpr = pi::FastDiv{0u, 0u}; g.dn1 = pi::FastDiv{0u, 0u};
     g.lxs = 0; g.nxb = g.nrg = 0; g.nblk = 0; g.dnxb = pi::FastDiv{0u, 0u}; g.dnrg = pi::FastDiv{0u, 0u};
     g.rgt = g.nlast = 0; g.per_tile = 0; g.dper = g.drgt = g.dlast = pi::FastDiv{0u, 0u};
-    g.xwin = 0;
+    g.xwin = 0; g.rz = 1;
     g.n0 = (int)p.n0; g.n1 = (int)p.n1; g.W = (int)p.W;
     g.rows = (int)(p.n0 * p.n1);
     g.s0 = (long)(p.n1 * p.W);
@@ -246,42 +250,58 @@ int direct_block(const Problem& p, const Geom& g, int vec)
 }
 
 // ---- kernel instantiation dispatch ------------------------------------------------------------
-template <typename T, int NDIM, int HC, int VEC>
+// planes per workgroup pass of the direct 3D kernels (the RZ > 1 flavours exist for pre-contracted blocks on 16-byte lanes)
+// Measured on MI355X (profiles/r02_direct_kernel_option_sweeps.txt, us per step rz = 1 / 2 / 4): forward 384^3 363 / 312 /
+// 283, 256^3 101 / 84 / 81, 128^3 12.3 / 11.1 / 11.8, 96^3 8.0 / 8.6 / 9.5, 48^3 4.7 / 5.5 / 7.0; backward 384^3 533 /
+// 482 / 529, 256^3 152 / 141 / 153, 128^3 21.9 / 24.2 / 21.9, 96^3 15.8 / 15.0 / 17.8 -- sharing plane neighbours pays
+// once the grid no longer fits the caches; small grids need the workgroups more than the reuse.
+template <typename T>
+int direct_rz(const Problem& p, int vec, bool adjoint)
+{
+    if (p.ndim != 3 || p.hc != 0 || vec != pi::vec_width<T>::value) return 1;
+    if (p.opt.rz) return p.opt.rz;
+    const int64_t pts = (int64_t)make_geom(p).rows * p.W;
+    if (adjoint) return pts >= ((int64_t)8 << 20) ? 2 : 1;
+    return pts >= ((int64_t)8 << 20) ? 4 : (pts >= ((int64_t)3 << 19) ? 2 : 1);
+}
+
+template <typename T, int NDIM, int HC, int VEC, int RZ = 1>
 hipError_t launch_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
 {
     Geom g = make_geom(p);
     const int block = direct_block(p, g, VEC);
     if (g.rows <= 0) return hipSuccess;
-    if (!set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024)) return hipErrorInvalidValue;
+    if (!set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ)) return hipErrorInvalidValue;
     const unsigned grid = (p.opt.fwd_blocks > 0 && g.nblk > (unsigned)p.opt.fwd_blocks) ? (unsigned)p.opt.fwd_blocks : g.nblk;
     g.xwin = (unsigned)p.opt.xcd_window;
-    auto* k = pi::pi_fwd_kernel<T, NDIM, HC, VEC>;
+    auto* k = pi::pi_fwd_kernel<T, NDIM, HC, VEC, RZ>;
     if (hipError_t e = allow_lds(k, (size_t)p.opt.lds_pad)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), (size_t)p.opt.lds_pad, st, h, out, P, g, p.hc);
     return hipGetLastError();
 }
 
-unsigned bwd_grid(const Problem& p, int vec, size_t elem)
+unsigned bwd_grid(const Problem& p, int vec, size_t elem, int rz)
 {
     Geom g = make_geom(p);
-    if (g.rows <= 0 || !set_blockmap(g, p.ndim, vec, direct_block(p, g, vec), elem, p.opt.l2_tile_kb * 1024)) return 0;
+    if (g.rows <= 0 || !set_blockmap(g, p.ndim, vec, direct_block(p, g, vec), elem, p.opt.l2_tile_kb * 1024, rz)) return 0;
     long need = g.nblk;
-    if (p.opt.bwd_cpl > 1 && need >= 512L * p.opt.bwd_cpl) need = (need + p.opt.bwd_cpl - 1) / p.opt.bwd_cpl;   // chunks per lane
+    const int cpl = rz > 1 ? (p.opt.bwd_cpl + rz - 1) / rz : p.opt.bwd_cpl;     // a pass already covers rz chunks per lane
+    if (cpl > 1 && need >= 512L * cpl) need = (need + cpl - 1) / cpl;            // chunks per lane
     return (unsigned)(need < MAX_BWD_BLOCKS ? need : MAX_BWD_BLOCKS);
 }
 
-template <typename T, int NDIM, int HC, int VEC, bool WGRAD>
+template <typename T, int NDIM, int HC, int VEC, bool WGRAD, int RZ = 1>
 hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partials, const T* P,
                       const Problem& p, hipStream_t st)
 {
     Geom g = make_geom(p);
     const int block = direct_block(p, g, VEC);
-    const unsigned grid = bwd_grid(p, VEC, sizeof(T));
+    const unsigned grid = bwd_grid(p, VEC, sizeof(T), RZ);
     if (g.rows <= 0) return hipSuccess;
-    if (!grid || !set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024)) return hipErrorInvalidValue;
+    if (!grid || !set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ)) return hipErrorInvalidValue;
     const size_t lds = align_up((size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T), 16) +
                        (size_t)(block / pi::WAVE) * 2 * sizeof(double) + (size_t)p.opt.lds_pad;
-    auto* k = pi::pi_bwd_kernel<T, NDIM, HC, VEC, WGRAD>;
+    auto* k = pi::pi_bwd_kernel<T, NDIM, HC, VEC, WGRAD, RZ>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, st, h, G, inj, Gp, partials, P, g, p.hc);
     return hipGetLastError();
@@ -462,6 +482,12 @@ hipError_t step_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_
     if (const int sv = stream3d_vec<T>(p, {h, out}))
         return stream3d<T, false>(sv, h, out, nullptr, nullptr, nullptr, P, p, st, nullptr);
     const int vec = pick_vec<T>(p, {h, out});
+    {
+        constexpr int V = pi::vec_width<T>::value;
+        const int rz = direct_rz<T>(p, vec, false);
+        if (rz == 2) return launch_fwd<T, 3, pi::POLY, V, 2>(h, out, P, p, st);
+        if (rz == 4) return launch_fwd<T, 3, pi::POLY, V, 4>(h, out, P, p, st);
+    }
 #define CALL_FWD(NDIM, HC, VEC) launch_fwd<T, NDIM, HC, VEC>(h, out, P, p, st)
     PI_DISPATCH(CALL_FWD);
 #undef CALL_FWD
@@ -479,7 +505,13 @@ hipError_t step_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partial
         if (const int sv = stream3d_vec<T>(p, {h, G, inj, Gp}))
             return stream3d<T, true>(sv, G, Gp, h, inj, partials, P, p, st, grid_out, WGRAD ? 1 : 0);
     const int vec = pick_vec<T>(p, {h, G, inj, Gp});
-    if (grid_out) *grid_out = bwd_grid(p, vec, sizeof(T));
+    const int rz = direct_rz<T>(p, vec, true);
+    if (grid_out) *grid_out = bwd_grid(p, vec, sizeof(T), rz);
+    {
+        constexpr int V = pi::vec_width<T>::value;
+        if (rz == 2) return launch_bwd<T, 3, pi::POLY, V, WGRAD, 2>(h, G, inj, Gp, partials, P, p, st);
+        if (rz == 4) return launch_bwd<T, 3, pi::POLY, V, WGRAD, 4>(h, G, inj, Gp, partials, P, p, st);
+    }
 #define CALL_BWD(NDIM, HC, VEC) launch_bwd<T, NDIM, HC, VEC, WGRAD>(h, G, inj, Gp, partials, P, p, st)
     PI_DISPATCH(CALL_BWD);
 #undef CALL_BWD
@@ -1142,6 +1174,11 @@ int apply_option(Options& o, const char* key, long value)
         return 0;
     }
     if (!std::strcmp(key, "block_small")) { o.block_small = value != 0; return 0; }
+    if (!std::strcmp(key, "rz")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return PERCNN_PI_EINVAL;
+        o.rz = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "l2_tile_kb")) {
         if (value < 0 || value > 16384) return PERCNN_PI_EINVAL;
         o.l2_tile_kb = (int)value;

@@ -412,7 +412,7 @@ pi_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict_
 // Gradient of the diffusion coefficient uses sum_x g*Lap(h) == sum_x LapT(g)*h, so the forward
 // Laplacian is never recomputed.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NDIM, int HC, int VEC, bool WGRAD>
+template <typename T, int NDIM, int HC, int VEC, bool WGRAD, int RZ = 1>
 __global__ void __launch_bounds__(256)
 pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restrict__ inj, T* __restrict__ Gp,
               double* __restrict__ partials, const T* __restrict__ P, Geom g, int hc_rt)
@@ -457,15 +457,36 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
     for (unsigned vb = xcd_remap(blockIdx.x, gridDim.x); vb < g.nblk; vb += gridDim.x) {
         const Lane L = locate<T, NDIM, VEC>(g, vb);
         const bool valid = L.valid;
-        const char* phu = plane_base<T, NDIM>(h + g.off, g, L.i0);
-        const char* phv = plane_base<T, NDIM>(h + g.ss + g.off, g, L.i0);
-        const char* pgu = plane_base<T, NDIM>(G + g.off, g, L.i0);
-        const char* pgv = plane_base<T, NDIM>(G + g.ss + g.off, g, L.i0);
+        // 3D: the adjoint state of planes i0-2 .. i0+RZ+1 in registers, shared by the RZ output planes of this pass
+        PlaneWindow<T, VEC, NDIM == 3 ? RZ : 1> win[2];
+        if constexpr (NDIM == 3) {
+            win[0].load(G + g.off, g, L);
+            win[1].load(G + g.ss + g.off, g, L);
+        }
+#pragma unroll
+        for (int jz = 0; jz < RZ; ++jz) {
+        const int iz = L.i0 + jz;
+        if (NDIM == 3 && iz >= g.n0) break;              // partial last plane group (block-uniform)
+        const char* phu = plane_base<T, NDIM>(h + g.off, g, iz);
+        const char* phv = plane_base<T, NDIM>(h + g.ss + g.off, g, iz);
+        const char* pgu = plane_base<T, NDIM>(G + g.off, g, iz);
+        const char* pgv = plane_base<T, NDIM>(G + g.ss + g.off, g, iz);
         const Pack<T, VEC> u = ldb<T, VEC>(phu, L.eb), v = ldb<T, VEC>(phv, L.eb);
-        Pack<T, VEC> gc[2] = {ldb<T, VEC>(pgu, L.eb), ldb<T, VEC>(pgv, L.eb)};
+        Pack<T, VEC> gc[2];
         T dl[2][VEC];
-        star2<T, NDIM, VEC, -1>(pgu, P, g, L, gc[0], dl[0]);
-        star2<T, NDIM, VEC, -1>(pgv, P, g, L, gc[1], dl[1]);
+        if constexpr (NDIM == 3) {
+            gc[0] = win[0].w[jz + 2];
+            gc[1] = win[1].w[jz + 2];
+            win[0].template planes<-1>(jz, P, dl[0]);
+            win[1].template planes<-1>(jz, P, dl[1]);
+        } else {
+            gc[0] = ldb<T, VEC>(pgu, L.eb);
+            gc[1] = ldb<T, VEC>(pgv, L.eb);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { dl[0][i] = P[P_C0] * gc[0].v[i]; dl[1][i] = P[P_C0] * gc[1].v[i]; }
+        }
+        star2_inplane<T, NDIM, VEC, -1>(pgu, P, g, L, gc[0], dl[0]);
+        star2_inplane<T, NDIM, VEC, -1>(pgv, P, g, L, gc[1], dl[1]);
         const T live = valid ? T(1) : T(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -587,14 +608,15 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
                 ov.v[i] = gc[1].v[i] + tv;
             }
             if (inj) {
-                const Pack<T, VEC> ju = ldb<T, VEC>(plane_base<T, NDIM>(inj + g.off, g, L.i0), L.eb);
-                const Pack<T, VEC> jv = ldb<T, VEC>(plane_base<T, NDIM>(inj + g.ss + g.off, g, L.i0), L.eb);
+                const Pack<T, VEC> ju = ldb<T, VEC>(plane_base<T, NDIM>(inj + g.off, g, iz), L.eb);
+                const Pack<T, VEC> jv = ldb<T, VEC>(plane_base<T, NDIM>(inj + g.ss + g.off, g, iz), L.eb);
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) { ou.v[i] += ju.v[i]; ov.v[i] += jv.v[i]; }
             }
-            stb<T, VEC>(const_cast<char*>(plane_base<T, NDIM>(Gp + g.off, g, L.i0)), L.eb, ou);
-            stb<T, VEC>(const_cast<char*>(plane_base<T, NDIM>(Gp + g.ss + g.off, g, L.i0)), L.eb, ov);
+            stb<T, VEC>(const_cast<char*>(plane_base<T, NDIM>(Gp + g.off, g, iz)), L.eb, ou);
+            stb<T, VEC>(const_cast<char*>(plane_base<T, NDIM>(Gp + g.ss + g.off, g, iz)), L.eb, ov);
         }
+        }   // planes of the group
     }
 
     if constexpr (!WGRAD || LANE_MOM) {
