@@ -29,6 +29,35 @@ __device__ __forceinline__ Pack<T, N> ld(const T* p) { return *reinterpret_cast<
 template <typename T, int N>
 __device__ __forceinline__ void st(T* p, const Pack<T, N>& x) { *reinterpret_cast<Pack<T, N>*>(p) = x; }
 
+// Write-through (sc1, agent scope) 16-byte store for the frames the 2D tile kernels write.  Those frames are consumed by the
+// NEXT launch (all XCDs) or much later by the backward, never again by the launch that wrote them, and a dependent kernel
+// boundary costs + (dirty bytes / ~6 TB/s) for the L2 write-back at kernel end (MI355X_MICROARCH.md, row "boundary": a K = 4
+// forward launch leaves 8 MiB dirty).  Written through while the kernel still computes, that drain is off the boundary:
+// measured on MI355X 512^2 forward 2.00 -> 1.84 us per step, lambda-omega 512^2 fp64 3.0 -> 2.78, 2048^2 16.3 -> 15.4
+// (profiles/r02_write_through_stores.txt); the direct 3D kernels do not gain (128^3 11.3 -> 11.7) and keep plain stores.
+// The compiler only emits sc1 on <= 8-byte atomic stores (two 8-byte sc1 stores per lane were measured SLOWER than plain
+// stores: 512^2 forward 2.28 us), hence inline asm; the s_nop covers the gfx9 hazard "VMEM store of more than 64 bits
+// followed by a write of its data VGPRs", which the hazard recogniser cannot see through inline asm (without it: corrupted
+// frames -- caught by the parity tests).  PI_WT_STORES = 0 restores plain stores.
+#ifndef PI_WT_STORES
+#define PI_WT_STORES 1
+#endif
+template <typename T, int N>
+__device__ __forceinline__ void st_frame_wt(T* p, const Pack<T, N>& x)
+{
+#if PI_WT_STORES
+    if constexpr (sizeof(T) * N == 16) {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        const v4u v = __builtin_bit_cast(v4u, x);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    } else {
+        *reinterpret_cast<Pack<T, N>*>(p) = x;
+    }
+#else
+    *reinterpret_cast<Pack<T, N>*>(p) = x;
+#endif
+}
+
 // Explicit fused multiply-add; the translation unit is built with -ffp-contract=off so every
 // other a*b+c keeps its two roundings (the reference rounds `coef*lap + react` and `h + res*dt`
 // separately -- train_2drd.py:115-118).

@@ -146,7 +146,7 @@ __device__ __forceinline__ void tile_store(const T* buf, T* __restrict__ dst, co
         } else {
             p = ld<T, VEC>(src);
         }
-        st<T, VEC>(dst + s * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC, p);
+        st_frame_wt<T, VEC>(dst + s * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC, p);
     }
 }
 
