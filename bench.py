@@ -304,13 +304,18 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
         loss = (traj ** 2).mean()
         torch.autograd.grad(loss, params + [h0])
 
+    def it_traj():
+        loss = (model.trajectory() ** 2).mean()
+        torch.autograd.grad(loss, params + [h0])
+
     def it_observe():
         pred = model.observe(slice(0, -1, 20), 4)
         loss = ((pred - 0.5) ** 2).mean()
         torch.autograd.grad(loss, params + [h0])
 
     out = {}
-    for key, fn in (("list_cat_dense_loss_ms", it_list), ("observe_strided_loss_ms", it_observe)):
+    for key, fn in (("list_cat_dense_loss_ms", it_list), ("trajectory_dense_loss_ms", it_traj),
+                    ("observe_strided_loss_ms", it_observe)):
         fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
@@ -322,7 +327,8 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
         torch.cuda.synchronize()
         out[key] = {"gpu_ms": e0.elapsed_time(e1) / reps, "wall_ms": (time.perf_counter() - t0) / reps * 1e3}
     out["what"] = (f"one training iteration through the drop-in modules at {'x'.join(map(str, shape))} x T={T}: RCNN.forward() "
-                   "+ torch.cat + mean(traj^2) + backward, and RCNN.observe(0:-1:20, ::4) + MSE + backward "
+                   "+ torch.cat + mean(traj^2) + backward; RCNN.trajectory() (torch.ops.percnn.pi_rollout, no list / cat) + the same loss; "
+                   "RCNN.observe(0:-1:20, ::4) + MSE + backward "
                    "(forward, loss, full backward incl. parameter gradients; wall = host clock around the same loop)")
     return out
 
