@@ -118,7 +118,8 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *   "fwd_blocks", "xcd_window"   forward direct kernel: bounded persistent grid / windowed XCD remap (measured: no gain; off)
  *   "l2_tile_kb"   direct 3D kernels: the rows of a plane are processed in y-tiles of this many KiB (both species; default
  *                  128, 0 = whole planes) and the workgroups march along axis 0 tile by tile, so the five planes a tile's
- *                  stencil reads stay in the XCD's L2 when whole planes do not fit (e.g. 384^3)
+ *                  stencil reads stay in the XCD's L2 when whole planes do not fit (e.g. 384^3); "l2_tile_min_kb" (default
+ *                  1536) = size of four neighbour planes x two species from which the tiling is applied
  *   "bwd_cpl"      direct adjoint kernel: 16-byte chunks per lane (1..16, default 2) once >= 512 workgroups remain
  *   "overlap", "overlap_chunk"  run the time-parallel gradient pass of finished chunks on a side stream under the sweep
  *   "skip_wgrad"   diagnostics: adjoint sweep only, parameter gradients of the branches come back as zeros

@@ -48,6 +48,7 @@ struct Options {
                             // registers (1, 2, 4; 0 = by size, see direct_rz)
     int l2_tile_kb = 128;   // direct 3D kernels: y-tile of a plane (both species, KiB) whose five stencil planes stay in the L2
                             // (0 = whole planes, the pre-round-2 order): see set_blockmap
+    int l2_tile_min_kb = 1536;  // ... applied once four neighbour planes x two species exceed this many KiB (0: always; tests)
     int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
                             // small grid is spread over all CUs instead of being packed onto a few
 };
@@ -149,7 +150,8 @@ void set_fastdiv(Geom& g, int vec)
 // block-uniform decomposition of the direct step kernels (pi_kernels.h "Direct step kernels, addressing"): lanes along x
 // = the power of two that wastes the fewest lanes on this row length; false if the grid is outside what 32-bit byte
 // offsets / 31-bit block ids address (2D: the whole local field + 4 rows, 3D: one plane, must stay below 4 GiB)
-bool set_blockmap(Geom& g, int ndim, int vec, int block, size_t elem, int l2_tile_bytes = 128 * 1024, int rz = 1)
+bool set_blockmap(Geom& g, int ndim, int vec, int block, size_t elem, int l2_tile_bytes = 128 * 1024, int rz = 1,
+                  long l2_tile_min_bytes = 3L << 19)
 {
     const long cpr = g.W / vec;
     int lxs;
@@ -184,7 +186,7 @@ bool set_blockmap(Geom& g, int ndim, int vec, int block, size_t elem, int l2_til
     g.rgt = 0; g.nlast = 0; g.per_tile = 0;
     // (only where whole planes do not fit anyway: four neighbour planes x two species above ~1.5 MiB; measured on
     // MI355X: 384^3 backward 726 -> 513 us, 256^3 171 -> 148 us per step, 192^3 -- 1.2 MB of neighbour planes -- loses 3-8 %)
-    if (ndim == 3 && l2_tile_bytes > 0 && 8L * g.n1 * g.W * (long)elem > (3L << 19)) {
+    if (ndim == 3 && l2_tile_bytes > 0 && 8L * g.n1 * g.W * (long)elem > l2_tile_min_bytes) {
         const long tile_rows = (long)l2_tile_bytes / (2 * (long)g.W * (long)elem);
         long rgt = tile_rows / rpb;
         if (rgt < 1) rgt = 1;
@@ -271,7 +273,7 @@ hipError_t launch_fwd(const T* h, T* out, const T* P, const Problem& p, hipStrea
     Geom g = make_geom(p);
     const int block = direct_block(p, g, VEC);
     if (g.rows <= 0) return hipSuccess;
-    if (!set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ)) return hipErrorInvalidValue;
+    if (!set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024)) return hipErrorInvalidValue;
     const unsigned grid = (p.opt.fwd_blocks > 0 && g.nblk > (unsigned)p.opt.fwd_blocks) ? (unsigned)p.opt.fwd_blocks : g.nblk;
     g.xwin = (unsigned)p.opt.xcd_window;
     auto* k = pi::pi_fwd_kernel<T, NDIM, HC, VEC, RZ>;
@@ -283,7 +285,7 @@ hipError_t launch_fwd(const T* h, T* out, const T* P, const Problem& p, hipStrea
 unsigned bwd_grid(const Problem& p, int vec, size_t elem, int rz)
 {
     Geom g = make_geom(p);
-    if (g.rows <= 0 || !set_blockmap(g, p.ndim, vec, direct_block(p, g, vec), elem, p.opt.l2_tile_kb * 1024, rz)) return 0;
+    if (g.rows <= 0 || !set_blockmap(g, p.ndim, vec, direct_block(p, g, vec), elem, p.opt.l2_tile_kb * 1024, rz, (long)p.opt.l2_tile_min_kb * 1024)) return 0;
     long need = g.nblk;
     const int cpl = rz > 1 ? (p.opt.bwd_cpl + rz - 1) / rz : p.opt.bwd_cpl;     // a pass already covers rz chunks per lane
     if (cpl > 1 && need >= 512L * cpl) need = (need + cpl - 1) / cpl;            // chunks per lane
@@ -298,7 +300,7 @@ hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* parti
     const int block = direct_block(p, g, VEC);
     const unsigned grid = bwd_grid(p, VEC, sizeof(T), RZ);
     if (g.rows <= 0) return hipSuccess;
-    if (!grid || !set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ)) return hipErrorInvalidValue;
+    if (!grid || !set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024)) return hipErrorInvalidValue;
     const size_t lds = align_up((size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T), 16) +
                        (size_t)(block / pi::WAVE) * 2 * sizeof(double) + (size_t)p.opt.lds_pad;
     auto* k = pi::pi_bwd_kernel<T, NDIM, HC, VEC, WGRAD, RZ>;
@@ -1177,6 +1179,11 @@ int apply_option(Options& o, const char* key, long value)
     if (!std::strcmp(key, "rz")) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return PERCNN_PI_EINVAL;
         o.rz = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "l2_tile_min_kb")) {
+        if (value < 0 || value > (1 << 22)) return PERCNN_PI_EINVAL;
+        o.l2_tile_min_kb = (int)value;
         return 0;
     }
     if (!std::strcmp(key, "l2_tile_kb")) {

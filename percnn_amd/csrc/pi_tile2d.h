@@ -27,8 +27,11 @@ namespace pi {
 // debug build only: per-workgroup s_memtime stamps {start, window loaded, after each sub-step (compute, store issued), end}
 __device__ long long pi_tile_stamps[4096 * 16];
 #define PI_STAMP(i) do { if (threadIdx.x == 0) pi_tile_stamps[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+// slot 14 keeps the END stamp of the previous launch of this block id: start - max(previous ends) = the launch boundary
+#define PI_STAMP_PREV() do { if (threadIdx.x == 0) pi_tile_stamps[blockIdx.x * 16 + 14] = pi_tile_stamps[blockIdx.x * 16 + 15]; } while (0)
 #else
 #define PI_STAMP(i) do { } while (0)
+#define PI_STAMP_PREV() do { } while (0)
 #endif
 
 template <int K, int BX, int BY>
@@ -371,6 +374,7 @@ pi_fwd2d_tile_kernel(T* __restrict__ frames /* frame t; t+1..t+K are written */,
     T* b1 = reinterpret_cast<T*>(smem_raw) + 2 * TL::PLANE + lds_pad1<T>::value;
     const int tile = tile_of_block(blockIdx.x, g);
     const int ty0 = (tile / g.tiles_x) * BY, tx0 = (tile % g.tiles_x) * BX;
+    PI_STAMP_PREV();
     PI_STAMP(0);
     tile_load<T, K, BX, BY, NT>(frames, g, ty0, tx0, b0);
     __syncthreads();
@@ -617,6 +621,7 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
     T* b1 = reinterpret_cast<T*>(smem_raw) + 2 * TL::PLANE + lds_pad1<T>::value;
     const int tile = tile_of_block(blockIdx.x, g);
     const int ty0 = (tile / g.tiles_x) * BY, tx0 = (tile % g.tiles_x) * BX;
+    PI_STAMP_PREV();
     PI_STAMP(0);
     WindowLoader<T, K, BX, BY, NT> wl;
     wl.issue(aframe_t, g, ty0, tx0);                       // adjoint window first, then the operands of sub-step 0

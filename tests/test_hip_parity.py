@@ -646,6 +646,79 @@ def test_stream3d_bitwise(opts, shape, dtype, hc, hip_device):
             pa.set_option(k, v)
 
 
+@pytest.mark.parametrize("opts", ["rz=1", "rz=2", "rz=4", "rz=4,l2_tile_kb=1,l2_tile_min_kb=0", "rz=2,l2_tile_kb=8,l2_tile_min_kb=0,block=64",
+                                  "rz=1,l2_tile_kb=4,l2_tile_min_kb=0,block=128",
+                                  "rz=2,fwd_blocks=8,bwd_cpl=1", "rz=4,xcd_window=16,bwd_cpl=4", "block_small=0,rz=2", "vec=1"])
+@pytest.mark.parametrize("shape,dtype", [((9, 12, 64), np.float32), ((6, 33, 40), np.float32), ((3, 8, 16), np.float32),
+                                         ((17, 20, 132), np.float32), ((10, 24, 48), np.float64), ((2, 6, 8), np.float64)])
+def test_direct_kernel_variants_bitwise(opts, shape, dtype, hip_device):
+    """Round-2 direct step kernels: block-uniform addressing, plane blocking (rz, incl. partial last plane groups and grids
+    with fewer planes than the register window), L2 y-tiling forced onto small grids (l2_tile_kb = 1 -> several tiles with a
+    ragged last one), workgroup sizes, bounded grids, windowed XCD remap -- every combination bit-identical to the C oracle
+    (state, adjoint state, masked frames), through per-call options; periodic rollout + slab layout (axis 0 not wrapped)."""
+    import percnn_amd as pa
+    T = 3
+    rs = np.random.RandomState(23)
+    P = random_block(0, 3, dtype, 29, scale=0.3)
+    h0 = rs.uniform(0, 1, (2,) + shape).astype(dtype)
+    gt = rs.uniform(-1, 1, (T + 1, 2) + shape).astype(dtype)
+    ref = o_rollout_fwd(h0, P, T)
+    g0_ref, pg_ref = o_rollout_bwd(ref, gt, P)
+    o = "stream3d=0," + opts
+    Pd = dev_t(P, hip_device)
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.from_numpy(h0).dtype, device=hip_device)
+    traj[0] = dev_t(h0, hip_device)
+    pa.rollout_fwd_(traj, Pd, options=o)
+    assert np.array_equal(traj.cpu().numpy(), ref)
+    g0, pg = pa.rollout_bwd(traj, dev_t(gt, hip_device), Pd, options=o)
+    assert np.array_equal(g0.cpu().numpy(), g0_ref)
+    assert rel_l2(pg.cpu().numpy(), pg_ref) < (2e-5 if dtype == np.float32 else 1e-12)
+    g0s, pgs = pa.rollout_bwd(traj, dev_t(gt, hip_device), Pd, options=o + ",fuse_wgrad=0")     # sweep + separate reduction
+    assert np.array_equal(g0s.cpu().numpy(), g0_ref)
+    assert rel_l2(pgs.cpu().numpy(), pg_ref) < (2e-5 if dtype == np.float32 else 1e-12)
+    mask = [True, False, True, False]
+    g = gt.copy(); g[1] = 0; g[3] = 0
+    g0m_ref, _ = o_rollout_bwd(ref, g, P)
+    g0m, _ = pa.rollout_bwd(traj, dev_t(g, hip_device), Pd, frame_mask=mask, options=o)
+    assert np.array_equal(g0m.cpu().numpy(), g0m_ref)
+    # one step forward + adjoint through the step entry points (odd plane counts: partial plane groups)
+    out = pa.step_fwd(dev_t(h0, hip_device), Pd, options=o)
+    assert np.array_equal(out.cpu().numpy(), o_step_fwd(h0, P))
+    gi, _ = pa.step_bwd(dev_t(h0, hip_device), dev_t(gt[1], hip_device), Pd, options=o)
+    assert np.array_equal(gi.cpu().numpy(), o_step_bwd(h0, gt[1], None, P)[0])
+
+
+@pytest.mark.parametrize("rz", [1, 2, 4])
+@pytest.mark.parametrize("shape,halo", [((12, 8, 64), 4), ((7, 12, 40), 2)])
+def test_slab_layout_with_plane_blocking(rz, shape, halo, hip_device):
+    """Slab layout (axis 0 not wrapped, halo planes in memory) under every plane-group size: the skip-schedule forward and the
+    adjoint of the slab entry points equal the periodic kernels on the same data (process default option: the slab entry
+    points take no per-call options)."""
+    import percnn_amd as pa
+    rs = np.random.RandomState(31)
+    P = dev_t(random_block(0, 3, np.float32, 5, scale=0.3), hip_device)
+    n0 = shape[0]
+    h = torch.tensor(rs.uniform(0, 1, (2,) + shape).astype(np.float32), device=hip_device)
+    G = torch.tensor(rs.uniform(-1, 1, (2,) + shape).astype(np.float32), device=hip_device)
+
+    def padded(x):
+        return torch.cat([x[:, n0 - halo:], x, x[:, :halo]], dim=1).contiguous()
+
+    ref = pa.step_fwd(h, P, options="stream3d=0,rz=1")
+    gref, _ = pa.step_bwd(h, G, P, options="stream3d=0,rz=1")
+    pa.set_option("rz", rz)
+    pa.set_option("stream3d", 0)
+    try:
+        out = pa.step_fwd(padded(h), P, slab=True, halo=halo, skip=0)
+        # skip = 0 computes planes [2, n0 + 2*halo - 2): compare the interior
+        assert torch.equal(out[:, halo:halo + n0], ref)
+        gi, _ = pa.step_bwd(padded(h), padded(G), P, slab=True, halo=halo)
+        assert torch.equal(gi[:, halo:halo + n0], gref)
+    finally:
+        pa.set_option("rz", 0)
+        pa.set_option("stream3d", 1)
+
+
 # ---------------------------------------------------------------------------------------------
 # configs[4] at full size on ONE GPU: 256^3 cut into 8 slabs of 32 planes ("virtual ranks"), halos
 # copied between neighbours exactly as the ring exchange does, wide halo (2 steps per exchange).

@@ -1,6 +1,7 @@
 """Debug aid: per-phase device timestamps of pi_fwd2d_tile_kernel (needs the -DPI_TILE_TIMING build)."""
 import ctypes, os, sys
-os.environ["PERCNN_PI_LIB"] = os.path.join(os.path.dirname(__file__), "..", "percnn_amd", "csrc", "libpercnn_pi_dbg.so")
+os.environ["PERCNN_PI_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "percnn_amd", "csrc",
+                                           sys.argv[1] if len(sys.argv) > 1 else "libpercnn_pi_dbg.so")
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
 import percnn_amd as pa
@@ -27,6 +28,8 @@ for reaction in ("poly",):
         print(f"{reaction} NT={nt}: last launch, us since first block start (median over 256 blocks | max)")
         for i in [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15]:
             print(f"   {names[i]:7s} median {np.median(rel[:, i]):7.2f}  min {rel[:, i].min():7.2f}  max {rel[:, i].max():7.2f}")
+        print(f"   launch boundary: first start of this launch - last end of the previous one = {(st[:, 0].min() - st[:, 14].max()) / 100.0:.2f} us; "
+              f"launch period (end - previous end, median) = {np.median(st[:, 15] - st[:, 14]) / 100.0:.2f} us")
         # adjoint sweep (sweep only)
         g = torch.randn_like(traj) * 1e-6
         pa.set_option("skip_wgrad", 1)
@@ -41,3 +44,5 @@ for reaction in ("poly",):
         print(f"{reaction} NT={nt}: ADJOINT last launch")
         for i in list(range(14)) + [15]:
             print(f"   {an[i]:7s} median {np.median(rel[:, i]):7.2f}  min {rel[:, i].min():7.2f}  max {rel[:, i].max():7.2f}")
+        print(f"   launch boundary: {(st[:, 0].min() - st[:, 14].max()) / 100.0:.2f} us; launch period (median) = "
+              f"{np.median(st[:, 15] - st[:, 14]) / 100.0:.2f} us")
