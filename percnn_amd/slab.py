@@ -95,6 +95,25 @@ class HaloExchanger:
         if bufs is None:
             bufs = self._bufs[key] = [torch.empty(top.shape, dtype=slab.dtype, device=slab.device) for _ in range(4)]
         send_bot, send_top, recv_lo, recv_hi = bufs
+        if slab.is_cuda and dist.get_backend(self.group) == "gloo":
+            # gloo moves host memory only: stage the faces through pinned buffers (portable fallback for HIP tensors when
+            # no RCCL ring is available -- e.g. several ranks sharing one GPU, which RCCL refuses; tests/test_slab_dist_gpu.py)
+            hk = ("host",) + key
+            hb = self._bufs.get(hk)
+            if hb is None:
+                hb = self._bufs[hk] = [torch.empty(top.shape, dtype=slab.dtype).pin_memory() for _ in range(4)]
+            hb[0].copy_(bot, non_blocking=True)
+            hb[1].copy_(top, non_blocking=True)
+            torch.cuda.current_stream(slab.device).synchronize()
+            ops = [dist.P2POp(dist.isend, hb[0], self._global(self.next), self.group, tag=0),
+                   dist.P2POp(dist.isend, hb[1], self._global(self.prev), self.group, tag=1),
+                   dist.P2POp(dist.irecv, hb[2], self._global(self.prev), self.group, tag=0),
+                   dist.P2POp(dist.irecv, hb[3], self._global(self.next), self.group, tag=1)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            lo_halo.copy_(hb[2], non_blocking=True)
+            hi_halo.copy_(hb[3], non_blocking=True)
+            return
         send_bot.copy_(bot)
         send_top.copy_(top)
         # order matters when prev == next (world 2): first message to a peer is my *bottom* face,
@@ -121,7 +140,12 @@ class HaloExchanger:
 
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
 
