@@ -302,7 +302,9 @@ hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* parti
     if (g.rows <= 0) return hipSuccess;
     if (!grid || !set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024)) return hipErrorInvalidValue;
     const size_t lds = align_up((size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T), 16) +
-                       (size_t)(block / pi::WAVE) * 2 * sizeof(double) + (size_t)p.opt.lds_pad;
+                       (size_t)(block / pi::WAVE) * 2 * sizeof(double) +
+                       ((WGRAD && HC == pi::POLY) ? (size_t)20 * (block + 8) * sizeof(T) : 0) +   // moment transpose scratch
+                       (size_t)p.opt.lds_pad;
     auto* k = pi::pi_bwd_kernel<T, NDIM, HC, VEC, WGRAD, RZ>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, st, h, G, inj, Gp, partials, P, g, p.hc);
@@ -593,7 +595,13 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
     using TL = pi::Tile<K, TILE_B, BY>;
     const pi::TileGeom g = make_tile_geom(p, BY);
     const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
-    const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + 32 /* lds_pad0/1 */ + (size_t)p.opt.lds_pad;
+    size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + 32 /* lds_pad0/1 */;
+    if (MOM) {                                  // the tail reduction's scratch (pi_tile2d.h): doubles, then [20][NT + 16] values
+        const size_t tail = (size_t)(2 * (NT / pi::WAVE) + 20 + 20 * (NT / pi::WAVE)) * sizeof(double) +
+                            (size_t)20 * (NT + 16) * sizeof(T);
+        if (tail > lds) lds = tail;
+    }
+    lds += (size_t)p.opt.lds_pad;
     auto* k = pi::pi_adj2d_tile_kernel<T, HC, K, TILE_B, BY, NT, MOM>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, hframe_t, gframe_t, aframe_t, (long)(2 * p.n), inj_mask, g_h0,

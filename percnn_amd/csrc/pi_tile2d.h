@@ -656,25 +656,65 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
     lds_barrier();
     double* red = reinterpret_cast<double*>(smem_raw);     // state buffers are dead now
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-    constexpr int NRED = MOM ? 22 : 2;                     // per wave: 2 coefficient sums (+ 20 moments)
+    constexpr int NW = NT / WAVE;
+    // red[0 .. 2*NW): per-wave coefficient sums; MOM (float32): red[2*NW .. 2*NW + 20): block totals of the moments;
+    // float scratch [20][NT + 16] behind them
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const double r = wave_sum_to_last(acc_c[s]);
-        if (lane == REDUCE_LANE) red[wave * NRED + s] = r;
+        if (lane == REDUCE_LANE) red[wave * 2 + s] = r;
     }
-    if constexpr (MOM) {
+    constexpr bool MOM_LDS = MOM && sizeof(T) == 4;        // moments through an LDS transpose (see below)
+    if constexpr (MOM_LDS) {
+        // Block-wide sums of the 20 per-thread moments through an LDS transpose: every thread writes its 20 values, then
+        // 16 lanes per moment add NT/16 values each and fold with four DPP steps.  All 8 waves of all 256 workgroups reach
+        // this tail at the same time, so its instruction count is exposed in full: the earlier 20 six-step DPP wave
+        // reductions per wave cost ~1 us of a 12.6 us launch (same finding as in pi_bwd_kernel, where removing the
+        // reduction in a timing experiment gained 1.6 us at 128^3).
+        constexpr int RS = NT + 16;                        // + 16 floats per row: 4 rows cover all 64 banks
+        T* scr = reinterpret_cast<T*>(red + 2 * NW + 20);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int m = 0; m < 10; ++m) scr[(10 * s + m) * RS + (int)threadIdx.x] = mom_total(mom.a[s][m]);
+        lds_barrier();
+        if (threadIdx.x < 320) {                           // five whole waves: 20 moments x 16 lanes
+            const int mm = (int)threadIdx.x >> 4, part = (int)threadIdx.x & 15;
+            const T* row = scr + mm * RS + part;
+            T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+#pragma unroll
+            for (int k = 0; k < NT; k += 128) {
+                const T v0 = row[k], v1 = row[k + 16], v2 = row[k + 32], v3 = row[k + 48];
+                const T v4 = row[k + 64], v5 = row[k + 80], v6 = row[k + 96], v7 = row[k + 112];
+                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+                a0 += v4; a1 += v5; a2 += v6; a3 += v7;
+            }
+            T a = (a0 + a1) + (a2 + a3);
+            a += dpp_mov<0x111, 0xF>(a);                   // row_shr:1, :2, :4, :8 -> lane 15 of each row of 16
+            a += dpp_mov<0x112, 0xF>(a);
+            a += dpp_mov<0x114, 0xF>(a);
+            a += dpp_mov<0x118, 0xF>(a);
+            if (part == 15) red[2 * NW + mm] = (double)a;
+        }
+    } else if constexpr (MOM) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int m = 0; m < 10; ++m) {
                 const T r = wave_sum_to_last(mom_total(mom.a[s][m]));
-                if (lane == REDUCE_LANE) red[wave * NRED + 2 + 10 * s + m] = (double)r;
+                if (lane == REDUCE_LANE) red[2 * NW + 20 + wave * 20 + 10 * s + m] = (double)r;
             }
     }
     lds_barrier();
     if (has_slot) {
         double sum = 0.0;
-        for (int w = 0; w < NT / WAVE; ++w) sum += red[w * NRED + threadIdx.x];
+        if (threadIdx.x < 2) {
+            for (int w = 0; w < NW; ++w) sum += red[w * 2 + threadIdx.x];
+        } else if constexpr (MOM_LDS) {
+            sum = red[2 * NW + threadIdx.x - 2];
+        } else if constexpr (MOM) {
+            for (int w = 0; w < NW; ++w) sum += red[2 * NW + 20 + w * 20 + threadIdx.x - 2];
+        }
         *pslot = pold + sum;
     }
     PI_STAMP(15);
