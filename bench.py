@@ -220,8 +220,12 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
     sweep_ms = e0.elapsed_time(e1) / reps
     red_ms = max(bwd_ms - sweep_ms, 1e-6)
 
-    tiled = len(shape) == 2 and npts < (1 << 20) and opts.get("tile", "1") != "0"   # ragged grids included
+    # the library's switch points (pi_abi.hip: tile_eligible): forward tiles below 3 M points, sweep tiles below 1.25 M
+    tile_opt = opts.get("tile", "1")
+    tiled_fwd = len(shape) == 2 and tile_opt != "0" and (npts < (3 << 20) or tile_opt == "2")
+    tiled = len(shape) == 2 and tile_opt != "0" and (npts < (5 << 18) or tile_opt == "2")   # the sweep (ragged grids included)
     K = int(opts.get("tile_k", 4)) if tiled else 1
+    Kf = int(opts.get("tile_k", 4)) if tiled_fwd else 1
     poly = reaction == "poly"
     # algorithmic bytes per point and time step: fwd read+write state = 2*C*s;
     # sweep read h, adj, dL/dout + write adj = 4*C*s; gradient reduction read h + adj = 2*C*s
@@ -242,8 +246,8 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
         sweep_ms, red_ms = bwd_ms, 1e-6
     clock = "HIP events on the launch stream, this run (fwd / bwd phases of every pass; sweep alone via options=skip_wgrad)"
     kernels = [
-        {"kernel": ("pi_fwd2d_tile_kernel" if tiled else "pi_fwd_kernel"), "launches_per_pass": T // K,
-         "algorithmic_bytes_per_launch": 2 * Cs * npts * K, "avg_launch_us": fwd_ms * 1e3 / (T / K)},
+        {"kernel": ("pi_fwd2d_tile_kernel" if tiled_fwd else "pi_fwd_kernel"), "launches_per_pass": T // Kf,
+         "algorithmic_bytes_per_launch": 2 * Cs * npts * Kf, "avg_launch_us": fwd_ms * 1e3 / (T / Kf)},
         {"kernel": (("pi_adj2d_tile_kernel<sweep+moments>" if tile_fused else "pi_adj2d_tile_kernel") if tiled
                     else ("pi_bwd_kernel<sweep+moments>" if fused else "pi_bwd_kernel<sweep>")),
          "launches_per_pass": T // K,

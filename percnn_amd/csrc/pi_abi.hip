@@ -538,7 +538,7 @@ int tile_by_for(const Problem& p)
 }
 
 template <typename T>
-bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs)
+bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs, bool adjoint)
 {
     if (!p.opt.tile || p.opt.vec == 1 || p.ndim != 2 || p.slab) return false;
     if (p.hc != 0 && p.hc != 2 && p.hc != 4 && p.hc != 8) return false;
@@ -549,9 +549,12 @@ bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs)
     // direct kernels take over (4096^2 = 16384 tiles)
     const int64_t by = tile_by_for(p);
     if (((p.n0 + by - 1) / by) * ((p.W + TILE_B - 1) / TILE_B) > MAX_BWD_BLOCKS) return false;
-    // temporal blocking pays while launches are latency-bound; from ~1 M points the halo ring's redundant traffic
-    // costs more than the launches it saves (measured: profiles/r01_size_sweep.txt), tile = 2 forces the tile path
-    if (p.opt.tile == 1 && p.n >= (1 << 20)) return false;
+    // temporal blocking pays while launches are latency-bound; beyond, the halo ring's redundant traffic costs more than
+    // the launches it saves.  Round 2 (write-through frame stores, cheaper tails; profiles/r02_direct_kernel_option_sweeps.txt,
+    // us per step tiles / direct): forward 1024^2 4.5 / 6.4, 1536^2 8.6 / 9.9, 2048^2 14.4 / 14.9; backward 1024^2 11.0 / 12.2,
+    // 1280^2 18.0 / 16.4, 2048^2 41.3 / 31.1 -> the forward keeps tiles below 3 M points, the sweep below 1.25 M
+    // (tile = 2 forces the tile path)
+    if (p.opt.tile == 1 && p.n >= (adjoint ? (5 << 18) : (3 << 20))) return false;
     for (const void* q : ptrs)
         if (q && (reinterpret_cast<uintptr_t>(q) % 16)) return false;
     return true;
@@ -959,7 +962,7 @@ int rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* shape
     auto st = static_cast<hipStream_t>(stream);
     const size_t frame = (size_t)2 * p.n;
     int t = 0;
-    if (tile_eligible<T>(p, {traj})) {
+    if (tile_eligible<T>(p, {traj}, false)) {
         const int K = (p.opt.tile_k == 8 && p.hc != 0) ? 4 : p.opt.tile_k;
         for (; t + K <= T_steps; t += K)
             if (hipError_t e = fwd_tile<T>(traj + (size_t)t * frame, P, p, st)) return (int)e;
@@ -1015,9 +1018,9 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     // streaming): the other kernel families have no fused flavour
     // (the streaming kernel's fused flavour exists for float32 poly mode)
     const bool f32poly = hc == 0 && sizeof(T) == 4;
-    const bool direct_sweep = !tile_eligible<T>(p, {traj, g_traj, g_h0, adj}) &&
+    const bool direct_sweep = !tile_eligible<T>(p, {traj, g_traj, g_h0, adj}, true) &&
                               (f32poly || !stream3d_vec<T>(p, {traj, g_traj, g_h0, adj}));
-    const bool tile_fused = !direct_sweep && tile_eligible<T>(p, {traj, g_traj, g_h0, adj}) && tile_fuse_ok<T>(p);
+    const bool tile_fused = !direct_sweep && tile_eligible<T>(p, {traj, g_traj, g_h0, adj}, true) && tile_fuse_ok<T>(p);
     const bool fuse = tile_fused || (direct_sweep && !p.opt.skip_wgrad && hc != -1 &&
                                      (p.opt.fuse_wgrad == 1 || (p.opt.fuse_wgrad == 2 && f32poly)));
     unsigned rows = 0, wrows = 0;
@@ -1049,7 +1052,7 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
         if (hipError_t e = hipStreamWaitEvent(ss->stream, ev, 0)) return (int)e;
     }
     int t_cur = t_top;
-    if (tile_eligible<T>(p, {traj, g_traj, g_h0, adj})) {
+    if (tile_eligible<T>(p, {traj, g_traj, g_h0, adj}, true)) {
         const int K = (p.opt.tile_k == 8 && p.hc != 0) ? 4 : p.opt.tile_k;
         {
             const int by = tile_by_for(p);
