@@ -252,12 +252,26 @@ def test_slab_rollout_single_rank_equals_rollout(fam, halo, hip_device):
     inner = trajs[:, :, halo:halo + n0]
     assert torch.equal(inner, traj.detach())
     (inner * gt).sum().backward()
-    # two different fp32 reduction orders (per-step fused kernel vs sweep + time-parallel reduction); for a
-    # random dL/dtraj the diffusion-coefficient gradient is a heavily cancelling sum, hence the loose bound
-    tol = 5e-4 if g.dtype == np.float32 else 1e-11
-    for n, p in cell.named_parameters():
-        if p.grad is not None:
-            assert rel_l2(p.grad.cpu().numpy(), ref_grads[n].cpu().numpy()) < tol, n
+    # two different fp32 reduction orders (fused tile sweep vs per-step slab kernels); for a random dL/dtraj the
+    # diffusion-coefficient gradient is a heavily cancelling sum.  Yardstick: the same rollout in
+    # float64 -- the slab path must be as close to it as the plain path is (not merely within a loose bound of each other).
+    slab_grads = {n: p.grad.clone() for n, p in cell.named_parameters() if p.grad is not None}
+    if g.dtype == np.float32:
+        import copy
+        cell64 = copy.deepcopy(cell).double()
+        cell64.zero_grad()
+        (pa.pi_rollout(h0.double(), cell64.param_block(), T) * gt.double()).sum().backward()
+        for n, p in cell64.named_parameters():
+            if p.grad is None:
+                continue
+            t64 = p.grad.cpu().numpy()
+            e_plain = rel_l2(ref_grads[n].cpu().numpy(), t64)
+            e_slab = rel_l2(slab_grads[n].cpu().numpy(), t64)
+            assert e_slab <= 3.0 * e_plain + 2e-6, (n, e_slab, e_plain)
+            assert e_slab < 5e-4, (n, e_slab)
+    else:
+        for n in slab_grads:
+            assert rel_l2(slab_grads[n].cpu().numpy(), ref_grads[n].cpu().numpy()) < 1e-11, n
     # dL/dh0 in the padded layout: interior == the plain rollout's, halo planes exactly zero on the native path
     # (they used to be uninitialised device memory)
     for poison in (float("nan"), 1e30):
@@ -826,18 +840,30 @@ def test_physics_loss_vs_reference(fn, hip_device):
     out = traj_cpu.to(hip_device).requires_grad_(True)
     loss = physics.physics_loss(out, Q)
     ref = float(g.z["phy_loss"])
-    # fp32: the residual is a difference of O(1e-2..1) terms that nearly cancel; reference and kernel round
-    # the Laplacian differently (conv/dx^2 vs pre-scaled taps), so the scalar agrees to ~1e-3 relative
-    tol_v = 2e-3 if g.dtype == np.float32 else 1e-7      # converged lambda-omega model: loss ~1e-14 is pure round-off
-    assert abs(loss.item() - ref) <= tol_v * abs(ref), (loss.item(), ref)
     loss.backward()
     oc = traj_cpu.clone().requires_grad_(True)
     lo = R.physics_loss_reference(oc, g.family, g.dx, g.dt)
     lo.backward()
-    assert abs(loss.item() - lo.item()) <= tol_v * abs(lo.item())
-    # converged lambda-omega checkpoint: the residual itself is ~1e-8 (loss 8e-16), i.e. pure cancellation
-    tol_g = 2e-3 if g.dtype == np.float32 else 1e-6
-    assert rel_l2(out.grad.cpu().numpy(), oc.grad.numpy()) < tol_g
+    if g.dtype == np.float32:
+        # Yardstick: the same formula in float64 on the same float32 trajectory.  Measured on MI355X
+        # (tools/physics_spread.py): value |ours - f64| <= 2e-6 where the float32 reference itself is <= 5e-7 off; gradient
+        # rel-L2 vs f64 8e-6 .. 8e-5 = 1.8-2.3x the reference's own 5e-6 .. 4.5e-5 (kernel and reference round the
+        # Laplacian differently: pre-scaled taps vs conv / dx^2).  The old bound here was 2e-3.
+        o64 = traj_cpu.double().requires_grad_(True)
+        l64 = R.physics_loss_reference(o64, g.family, g.dx, g.dt)
+        l64.backward()
+        assert abs(loss.item() - l64.item()) <= 5e-6 * abs(l64.item()), (loss.item(), l64.item())
+        assert abs(loss.item() - ref) <= 5e-6 * abs(ref), (loss.item(), ref)
+        assert abs(loss.item() - lo.item()) <= 5e-6 * abs(lo.item())
+        e_ref = rel_l2(oc.grad.numpy(), o64.grad.numpy())
+        e_ours = rel_l2(out.grad.cpu().numpy(), o64.grad.numpy())
+        assert e_ours <= 3.0 * e_ref + 1e-6, (e_ours, e_ref)
+        assert e_ours < 2e-4
+    else:
+        # converged lambda-omega checkpoint: the residual itself is ~1e-8 (loss 8e-16), i.e. pure cancellation
+        assert abs(loss.item() - ref) <= 1e-7 * abs(ref), (loss.item(), ref)
+        assert abs(loss.item() - lo.item()) <= 1e-7 * abs(lo.item())
+        assert rel_l2(out.grad.cpu().numpy(), oc.grad.numpy()) < 1e-6
     # plain periodic mean (no duplicated first row/column) is a different, slightly smaller weighting
     plain = physics.physics_loss(out.detach(), Q, reference_weighting=False)
     assert torch.isfinite(plain) and plain.item() > 0
