@@ -55,6 +55,11 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.percnn_pi_step_fwd_f64(1, 2, 3, 4, 2, bad, None) == -1
     assert L.percnn_pi_rollout_fwd_f32(1, 2, 8, 2, shape, -1, None) == -1
     assert L.percnn_pi_step_bwd_f32(1, 2, None, 3, 4, None, 0, 5, 8, 2, shape, None) == -2   # no workspace
+    # 32-bit addressing limit of the direct kernels: a 2D field beyond 4 GiB per species is refused
+    # before any launch (hipErrorInvalidValue = 1), it is not silently mis-addressed
+    huge = (ctypes.c_int64 * 2)(70000, 70000)
+    assert L.percnn_pi_step_fwd_f32(16, 32, 48, 0, 2, huge, None) == 1
+    assert L.percnn_pi_step_fwd_opt_f32(16, 32, 48, 0, 2, huge, b"tile=0", None) == 1
     # per-call option strings are validated before anything else
     assert L.percnn_pi_rollout_fwd_opt_f32(1, 2, 8, 2, shape, 0, b"tile_k=4,skip_wgrad=1", None) == 0     # T = 0
     for bad in (b"nonsense=1", b"tile_k=3", b"tile_k", b"=4", b"tile_k=4;tile=0", b"tile_k=x"):
