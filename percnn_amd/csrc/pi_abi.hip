@@ -1261,6 +1261,10 @@ int percnn_pi_debug_stamps(long long* host_out, int n)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pi::pi_tile_stamps), (size_t)n * sizeof(long long));
 }
+int percnn_pi_debug_wave_stamps(long long* host_out, int n)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pi::pi_tile_wave_stamps), (size_t)n * sizeof(long long));
+}
 #endif
 
 int percnn_pi_abi_version(void) { return PERCNN_PI_ABI_VERSION; }

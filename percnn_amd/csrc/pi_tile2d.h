@@ -22,11 +22,18 @@ namespace pi {
 #ifndef PI_TILE_ADJ_PIPE
 #define PI_TILE_ADJ_PIPE 1
 #endif
+#ifndef PI_PIN_MOMENTS
+#define PI_PIN_MOMENTS 1
+#endif
+
 
 #ifdef PI_TILE_TIMING
 // debug build only: per-workgroup s_memtime stamps {start, window loaded, after each sub-step (compute, store issued), end}
 __device__ long long pi_tile_stamps[4096 * 16];
-#define PI_STAMP(i) do { if (threadIdx.x == 0) pi_tile_stamps[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+__device__ long long pi_tile_wave_stamps[256 * 16 * 16];      // [block < 256][wave < 16][slot]: per-wave view of the same stamps
+#define PI_STAMP(i) do { if (threadIdx.x == 0) pi_tile_stamps[blockIdx.x * 16 + (i)] = wall_clock64();                      \
+                         if (threadIdx.x % 64 == 0 && blockIdx.x < 256)                                                      \
+                             pi_tile_wave_stamps[(blockIdx.x * 16 + threadIdx.x / 64) * 16 + (i)] = wall_clock64(); } while (0)
 // slot 14 keeps the END stamp of the previous launch of this block id: start - max(previous ends) = the launch boundary
 #define PI_STAMP_PREV() do { if (threadIdx.x == 0) pi_tile_stamps[blockIdx.x * 16 + 14] = pi_tile_stamps[blockIdx.x * 16 + 15]; } while (0)
 #else
@@ -293,7 +300,12 @@ __device__ __forceinline__ void fwd_substep(T* cur, T* nxt, const T* __restrict_
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
         int idx = threadIdx.x + q * NT;
-        if (idx >= RN4) idx = RN4 - 1;                     // tail lanes redo the last strip (identical values)
+        // Waves with no strip left in this (shrinking) region skip it: they share a SIMD with a working wave and the
+        // sub-steps are VALU-issue-bound (per-wave timeline: the second wave of a SIMD finishes 0.45 us after the first),
+        // so a wave that merely repeats the last strip doubles that SIMD's work.  Sub-step K-1 of a 32 x 32 tile with 512
+        // threads is exactly four waves of strips -> one working wave per SIMD.
+        if (((int)threadIdx.x & ~(WAVE - 1)) + q * NT >= RN4) continue;
+        if (idx >= RN4) idx = RN4 - 1;                     // tail lanes of a partial wave redo the last strip (identical values)
         const int ry = idx / RW4, rc = idx - ry * RW4;
         const int off = (ry + O) * TL::LX + 4 * rc + O;
         T u[4], v[4], lap[2][4];
@@ -405,17 +417,35 @@ __device__ __forceinline__ void adj_load_ops(StripOps<T>& o, int q, const T* __r
     // two 8/16-byte pieces per row: the strip may straddle the periodic wrap
     const int gy = wrap1(ty0 - 2 * K + ly, g.H);
     const int gx0 = wrap1(tx0 - 2 * K + lx, g.W), gx1 = wrap1(tx0 - 2 * K + lx + 2, g.W);
-    const long e0 = (long)gy * g.W + gx0, e1 = (long)gy * g.W + gx1;
-    const Pack<T, 2> a = ld<T, 2>(hfr + e0), b = ld<T, 2>(hfr + e1);
-    const Pack<T, 2> c = ld<T, 2>(hfr + g.ss + e0), d = ld<T, 2>(hfr + g.ss + e1);
+    // The sub-steps are VALU-issue-bound (two waves per SIMD: the per-wave timeline shows waves 4-7 finishing 0.45 us after
+    // waves 0-3 in every sub-step), so the operand addressing was A/B-measured on one box (us per step, 512^2 backward):
+    // scalar frame bases + 32-bit byte offsets (`global_load v, v_off, s[base]`) vs per-lane 64-bit addresses --
+    // float64 5.80 -> 5.56, float32 2.96 -> 3.06 (fused) / 3.51 -> 3.68 (split): kept for float64 only.
+    Pack<T, 2> a, b, c, d, a2, b2, c2, d2;
+    // (the loss-gradient loads are unconditional -- a frame without gradient re-reads the state frame, the values are ignored:
+    // with the loads in a branch the compiler cannot count the outstanding requests and makes the window commit wait for
+    // these HBM-cold operands too, s_waitcnt vmcnt(4) instead of vmcnt(8): +1.5 us per launch on the device timeline)
+    const T* gsrc = gfr ? gfr : hfr;
+    if constexpr (sizeof(T) == 8) {
+        const unsigned e0 = ((unsigned)gy * (unsigned)g.W + (unsigned)gx0) * (unsigned)sizeof(T);
+        const unsigned e1 = ((unsigned)gy * (unsigned)g.W + (unsigned)gx1) * (unsigned)sizeof(T);
+        const char* hu = reinterpret_cast<const char*>(hfr);
+        const char* hv = reinterpret_cast<const char*>(hfr + g.ss);
+        const char* ju = reinterpret_cast<const char*>(gsrc);
+        const char* jv = reinterpret_cast<const char*>(gsrc + g.ss);
+        a = *reinterpret_cast<const Pack<T, 2>*>(hu + e0); b = *reinterpret_cast<const Pack<T, 2>*>(hu + e1);
+        c = *reinterpret_cast<const Pack<T, 2>*>(hv + e0); d = *reinterpret_cast<const Pack<T, 2>*>(hv + e1);
+        a2 = *reinterpret_cast<const Pack<T, 2>*>(ju + e0); b2 = *reinterpret_cast<const Pack<T, 2>*>(ju + e1);
+        c2 = *reinterpret_cast<const Pack<T, 2>*>(jv + e0); d2 = *reinterpret_cast<const Pack<T, 2>*>(jv + e1);
+    } else {
+        const long e0 = (long)gy * g.W + gx0, e1 = (long)gy * g.W + gx1;
+        a = ld<T, 2>(hfr + e0); b = ld<T, 2>(hfr + e1);
+        c = ld<T, 2>(hfr + g.ss + e0); d = ld<T, 2>(hfr + g.ss + e1);
+        a2 = ld<T, 2>(gsrc + e0); b2 = ld<T, 2>(gsrc + e1);
+        c2 = ld<T, 2>(gsrc + g.ss + e0); d2 = ld<T, 2>(gsrc + g.ss + e1);
+    }
     o.u[0] = a.v[0]; o.u[1] = a.v[1]; o.u[2] = b.v[0]; o.u[3] = b.v[1];
     o.v[0] = c.v[0]; o.v[1] = c.v[1]; o.v[2] = d.v[0]; o.v[3] = d.v[1];
-    // Unconditional (a frame without gradient re-reads the state frame; the values are ignored): with the loads in a
-    // branch the compiler cannot count the outstanding requests and makes the window commit wait for these
-    // HBM-cold operands too (s_waitcnt vmcnt(4) instead of vmcnt(8): +1.5 us per launch on the device timeline).
-    const T* gsrc = gfr ? gfr : hfr;
-    const Pack<T, 2> a2 = ld<T, 2>(gsrc + e0), b2 = ld<T, 2>(gsrc + e1);
-    const Pack<T, 2> c2 = ld<T, 2>(gsrc + g.ss + e0), d2 = ld<T, 2>(gsrc + g.ss + e1);
     o.ju[0] = a2.v[0]; o.ju[1] = a2.v[1]; o.ju[2] = b2.v[0]; o.ju[3] = b2.v[1];
     o.jv[0] = c2.v[0]; o.jv[1] = c2.v[1]; o.jv[2] = d2.v[0]; o.jv[3] = d2.v[1];
 }
@@ -456,6 +486,9 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
         const int off = ly * TL::LX + lx;
         StripOps<T> lo;
         if constexpr (!PRE) adj_load_ops<T, K, BX, BY, NT, M>(lo, q, hfr, gfr, g, ty0, tx0);
+        // whole waves beyond the region skip the strip (see fwd_substep); their operand loads above stay unconditional --
+        // loads inside a branch would cost the compiler its count of outstanding requests
+        if (((int)threadIdx.x & ~(WAVE - 1)) + q * NT >= RN4) continue;
         const StripOps<T>& op = PRE ? pre : lo;
         const T (&u)[4] = op.u;
         const T (&v)[4] = op.v;
@@ -465,25 +498,31 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
         V2<T> gc[2][2], dl[2][2];                          // [species][half of the strip]
         lds_star4v<T, TL::LX, -1>(cur, ly, lx, P, gc[0], dl[0]);
         lds_star4v<T, TL::LX, -1>(cur + TL::PLANE, ly, lx, P, gc[1], dl[1]);
-        const bool rowin = live && ly >= 2 * K && ly < 2 * K + BY && ty0 + ly - 2 * K < g.H;
+        // owned, in-grid points: one unsigned compare per coordinate against the tile's owned extent (edge tiles of a
+        // ragged grid own less) -- the sub-step is issue-bound, the three-compare form cost 16 VALU per strip
+        const unsigned own_ny = (unsigned)min(BY, g.H - ty0), own_nx = (unsigned)min(BX, g.W - tx0);
+        const bool rowin = live && (unsigned)(ly - 2 * K) < own_ny;
         const V2<T> dtv = vs(dt);
         V2<T> own[2];                                      // 1 for owned, in-grid points, else 0 (MOM only)
+        V2<T> cs[2] = {vs(T(0)), vs(T(0))};                 // this strip's owned part of sum_x dt*LapT(a)*h, per species
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             dl[0][h] *= dtv;
             dl[1][h] *= dtv;
-            const V2<T> mu = dl[0][h] * U[h], mv = dl[1][h] * V[h];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int i = 2 * h + e;
-                const bool mine = rowin && lx + i >= 2 * K && lx + i < 2 * K + BX && tx0 + lx + i - 2 * K < g.W;
-                if (mine) {                                // owned, in-grid points only
-                    acc_c[0] += (double)mu[e];
-                    acc_c[1] += (double)mv[e];
-                }
-                own[h][e] = mine ? T(1) : T(0);
+                const bool mine = rowin && (unsigned)(lx + i - 2 * K) < own_nx;
+                own[h][e] = mine ? T(1) : T(0);            // owned, in-grid points only
             }
+            // the four products of a strip are added in the compute type, the strip sum goes to the fp64 accumulator (was:
+            // every product converted and added in fp64 -- 16 half-rate instructions per strip in an issue-bound loop; the
+            // products themselves are already rounded to the compute type, so the sum loses nothing that matters)
+            cs[0] = vfma(dl[0][h] * U[h], own[h], cs[0]);
+            cs[1] = vfma(dl[1][h] * V[h], own[h], cs[1]);
         }
+        acc_c[0] += (double)(cs[0].x + cs[0].y);
+        acc_c[1] += (double)(cs[1].x + cs[1].y);
         V2<T> du[2] = {vs(T(0)), vs(T(0))}, dv[2] = {vs(T(0)), vs(T(0))};
         if constexpr (HC == POLY) {
             // unrolled over the species: the 20 coefficients become loop-invariant scalar loads
@@ -589,6 +628,18 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
     }
     adj_substep<T, HC, K, BX, BY, NT, M, PRE, MOM>(cur, nxt, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g,
                                                    ty0, tx0, P, acc_c, ops, mom);
+#if PI_PIN_MOMENTS
+    // Pin this sub-step's moment accumulation HERE.  Left alone, the scheduler sinks the moment FMAs of all four sub-steps
+    // (they depend on no LDS traffic) behind the last barrier -- 350 VALU instructions in the tail of the launch, where all
+    // 256 workgroups execute them at the same time with nothing to overlap; inside the sub-step they fill LDS-latency and
+    // barrier bubbles of the two waves that share a SIMD.
+    if constexpr (MOM && sizeof(T) == 4) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int m = 0; m < 10; ++m) asm volatile("" : "+v"(mom.a[s][m]));
+    }
+#endif
     PI_STAMP(2 + 3 * M);
     lds_barrier();
     PI_STAMP(3 + 3 * M);

@@ -46,3 +46,13 @@ for reaction in ("poly",):
             print(f"   {an[i]:7s} median {np.median(rel[:, i]):7.2f}  min {rel[:, i].min():7.2f}  max {rel[:, i].max():7.2f}")
         print(f"   launch boundary: {(st[:, 0].min() - st[:, 14].max()) / 100.0:.2f} us; launch period (median) = "
               f"{np.median(st[:, 15] - st[:, 14]) / 100.0:.2f} us")
+        # per-wave view: when does each of the 8 waves finish the compute phase of every sub-step (relative to its block's start)?
+        wb = (ctypes.c_longlong * (256 * 16 * 16))()
+        L.percnn_pi_debug_wave_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        assert L.percnn_pi_debug_wave_stamps(wb, 256 * 16 * 16) == 0
+        ws = np.array(wb, dtype=np.int64).reshape(256, 16, 16)[:, :nt // 64]
+        wrel = (ws - ws[:, :, 0:1].min(axis=1, keepdims=True)) / 100.0
+        print("   per-wave medians over the 256 workgroups (us since the block's first wave started): window | comp0 barr0 | comp1 barr1 | comp2 barr2 | comp3 barr3 | end")
+        for w in range(nt // 64):
+            r = np.median(wrel[:, w], axis=0)
+            print(f"     wave {w}: {r[1]:5.2f} | {r[2]:5.2f} {r[3]:5.2f} | {r[5]:5.2f} {r[6]:5.2f} | {r[8]:5.2f} {r[9]:5.2f} | {r[11]:5.2f} {r[12]:5.2f} | {r[15]:5.2f}")
