@@ -404,9 +404,11 @@ pi_fwd2d_tile_kernel(T* __restrict__ frames /* frame t; t+1..t+K are written */,
 // pointwise operands (state h_{t-1-M}, injected dL/dout_{t-1-M}) of one 4-point strip
 template <typename T> struct StripOps { T u[4], v[4], ju[4], jv[4]; };
 
-template <typename T, int K, int BX, int BY, int NT, int M>
-__device__ __forceinline__ void adj_load_ops(StripOps<T>& o, int q, const T* __restrict__ hfr, const T* __restrict__ gfr,
-                                             const TileGeom& g, int ty0, int tx0)
+// element offsets (inside one species plane) of the two halves of the strip a lane owns in sub-step M
+struct StripAddr { long e0, e1; };
+
+template <int K, int BX, int BY, int NT, int M>
+__device__ __forceinline__ StripAddr strip_addr(int q, const TileGeom& g, int ty0, int tx0)
 {
     using TL = Tile<K, BX, BY>;
     constexpr int RW4 = TL::region_w(M) / 4, RN4 = TL::region_n(M) / 4, O = 2 * (M + 1);
@@ -417,6 +419,23 @@ __device__ __forceinline__ void adj_load_ops(StripOps<T>& o, int q, const T* __r
     // two 8/16-byte pieces per row: the strip may straddle the periodic wrap
     const int gy = wrap1(ty0 - 2 * K + ly, g.H);
     const int gx0 = wrap1(tx0 - 2 * K + lx, g.W), gx1 = wrap1(tx0 - 2 * K + lx + 2, g.W);
+    return StripAddr{(long)gy * g.W + gx0, (long)gy * g.W + gx1};
+}
+
+template <int K, int BX, int BY, int NT, int M>
+__device__ __forceinline__ void strip_addr_table(StripAddr (&sa)[K], const TileGeom& g, int ty0, int tx0)
+{
+    sa[M] = strip_addr<K, BX, BY, NT, M>(0, g, ty0, tx0);
+    asm volatile("" : "+v"(sa[M].e0), "+v"(sa[M].e1));      // computed HERE (kernel prologue), not where it is consumed
+    if constexpr (M + 1 < K) strip_addr_table<K, BX, BY, NT, M + 1>(sa, g, ty0, tx0);
+}
+
+// sa: the strip's offsets if they were computed ahead (kernel prologue), else nullptr
+template <typename T, int K, int BX, int BY, int NT, int M>
+__device__ __forceinline__ void adj_load_ops(StripOps<T>& o, int q, const T* __restrict__ hfr, const T* __restrict__ gfr,
+                                             const TileGeom& g, int ty0, int tx0, const StripAddr* sa = nullptr)
+{
+    const StripAddr A = sa ? *sa : strip_addr<K, BX, BY, NT, M>(q, g, ty0, tx0);
     // The sub-steps are VALU-issue-bound (two waves per SIMD: the per-wave timeline shows waves 4-7 finishing 0.45 us after
     // waves 0-3 in every sub-step), so the operand addressing was A/B-measured on one box (us per step, 512^2 backward):
     // scalar frame bases + 32-bit byte offsets (`global_load v, v_off, s[base]`) vs per-lane 64-bit addresses --
@@ -427,8 +446,7 @@ __device__ __forceinline__ void adj_load_ops(StripOps<T>& o, int q, const T* __r
     // these HBM-cold operands too, s_waitcnt vmcnt(4) instead of vmcnt(8): +1.5 us per launch on the device timeline)
     const T* gsrc = gfr ? gfr : hfr;
     if constexpr (sizeof(T) == 8) {
-        const unsigned e0 = ((unsigned)gy * (unsigned)g.W + (unsigned)gx0) * (unsigned)sizeof(T);
-        const unsigned e1 = ((unsigned)gy * (unsigned)g.W + (unsigned)gx1) * (unsigned)sizeof(T);
+        const unsigned e0 = (unsigned)A.e0 * (unsigned)sizeof(T), e1 = (unsigned)A.e1 * (unsigned)sizeof(T);
         const char* hu = reinterpret_cast<const char*>(hfr);
         const char* hv = reinterpret_cast<const char*>(hfr + g.ss);
         const char* ju = reinterpret_cast<const char*>(gsrc);
@@ -438,7 +456,7 @@ __device__ __forceinline__ void adj_load_ops(StripOps<T>& o, int q, const T* __r
         a2 = *reinterpret_cast<const Pack<T, 2>*>(ju + e0); b2 = *reinterpret_cast<const Pack<T, 2>*>(ju + e1);
         c2 = *reinterpret_cast<const Pack<T, 2>*>(jv + e0); d2 = *reinterpret_cast<const Pack<T, 2>*>(jv + e1);
     } else {
-        const long e0 = (long)gy * g.W + gx0, e1 = (long)gy * g.W + gx1;
+        const long e0 = A.e0, e1 = A.e1;
         a = ld<T, 2>(hfr + e0); b = ld<T, 2>(hfr + e1);
         c = ld<T, 2>(hfr + g.ss + e0); d = ld<T, 2>(hfr + g.ss + e1);
         a2 = ld<T, 2>(gsrc + e0); b2 = ld<T, 2>(gsrc + e1);
@@ -615,7 +633,7 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
                                              T* __restrict__ abase, long frame_stride, unsigned inj_mask,
                                              T* __restrict__ g_h0, int steps_to_zero, const TileGeom& g, int ty0,
                                              int tx0, const T* __restrict__ P, double (&acc_c)[2],
-                                             const StripOps<T>& ops, TileMoments<T, MOM>& mom)
+                                             const StripOps<T>& ops, TileMoments<T, MOM>& mom, const StripAddr (&sa)[K])
 {
     T* cur = (M & 1) ? b1 : b0;
     T* nxt = (M & 1) ? b0 : b1;
@@ -624,7 +642,7 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
     if constexpr (PRE && M + 1 < K) {
         const long fn = -(long)(M + 2) * frame_stride;
         adj_load_ops<T, K, BX, BY, NT, M + 1>(ahead, 0, hbase + fn, (inj_mask >> (M + 1)) & 1u ? gbase + fn : nullptr, g,
-                                              ty0, tx0);
+                                              ty0, tx0, &sa[M + 1]);
     }
     adj_substep<T, HC, K, BX, BY, NT, M, PRE, MOM>(cur, nxt, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g,
                                                    ty0, tx0, P, acc_c, ops, mom);
@@ -652,7 +670,7 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
     PI_STAMP(4 + 3 * M);
     if constexpr (M + 1 < K)
         adj_substeps<T, HC, K, BX, BY, NT, M + 1, PRE, MOM>(b0, b1, hbase, gbase, abase, frame_stride, inj_mask, g_h0,
-                                                            steps_to_zero, g, ty0, tx0, P, acc_c, ahead, mom);
+                                                            steps_to_zero, g, ty0, tx0, P, acc_c, ahead, mom, sa);
 }
 
 template <typename T, int HC, int K, int BX, int BY, int NT, bool MOM = false>
@@ -686,9 +704,15 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
     double* pslot = partials + (long)blockIdx.x * np + (has_slot ? slot : P_COEF);
     const double pold = has_slot ? *pslot : 0.0;
     StripOps<T> ops0;
-    if constexpr (PRE)
+    // The strip offsets of ALL sub-steps are computed here, in the shadow of the window load (the VALU is idle for ~1 us),
+    // and pinned: inside the issue-bound sub-steps the wraps, 64-bit multiplies and shifts of the next strip's operand
+    // addresses were ~45 of ~290 VALU instructions per wave and sub-step.
+    StripAddr sa[K];
+    if constexpr (PRE) {
+        strip_addr_table<K, BX, BY, NT, 0>(sa, g, ty0, tx0);
         adj_load_ops<T, K, BX, BY, NT, 0>(ops0, 0, hframe_t - frame_stride, inj_mask & 1u ? gframe_t - frame_stride : nullptr,
-                                          g, ty0, tx0);
+                                          g, ty0, tx0, &sa[0]);
+    }
     wl.commit(b0);
     lds_barrier();                                         // LDS only: the operand loads stay in flight
     PI_STAMP(1);
@@ -701,7 +725,7 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
             for (int m = 0; m < 10; ++m) mom.a[s][m] = typename MomAcc<T>::type{};
     }
     adj_substeps<T, HC, K, BX, BY, NT, 0, PRE, MOM>(b0, b1, hframe_t, gframe_t, aframe_t, frame_stride, inj_mask, g_h0,
-                                                    steps_to_zero, g, ty0, tx0, P, acc_c, ops0, mom);
+                                                    steps_to_zero, g, ty0, tx0, P, acc_c, ops0, mom, sa);
     // diffusion-coefficient gradients of this tile over the K sub-steps: one reduction per launch
     // (LDS-only barriers: the last frame's global stores need not drain first)
     lds_barrier();
