@@ -102,7 +102,8 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *   "tile"         2D temporally blocked kernels: 0 never, 1 (default) below 1 M points, 2 whenever the shape allows
  *   "tile_k"       time steps per tile launch: 2, 4 (default), 8 (pre-contracted blocks only)
  *   "tile_nt"      threads per tile workgroup: 256, 512 (default), 1024
- *   "tile_by"      tile height: 16, 32, 0 (default) = 16 when 32x32 tiles would leave more than half the CUs idle
+ *   "tile_by"      tile height: 8, 16, 32, 0 (default) = 8 while 32x8 tiles fit one per CU, 16 while 32x32 tiles would leave
+ *                  more than half the CUs idle, else 32
  *   "tile_xcd"     1 (default) = XCD-aware block -> tile map
  *   "stream3d"     3D plane-streaming kernels: 0 never, 1 (default) by size, 2 whenever W == 64 * lanes' vector width
  *   "zc"           planes per workgroup of the plane-streaming kernels (default 8; the adjoint uses twice that)

@@ -528,13 +528,18 @@ constexpr int TILE_B = 32;
 // Tile height of the poly-mode tile kernels.  32x32 tiles give a 512^2 grid exactly one workgroup per CU; smaller grids
 // leave CUs idle and the launch time is the dependent chain of ONE workgroup, so they get 32x16 tiles (twice the
 // workgroups, shorter chain): measured 243 k vs 208 k steps/s on the reference's 100^2 grid, 135 k vs 171 k at 512^2.
+// Round 2: the sub-steps are VALU-issue-bound, so what counts is waves per SIMD -- 32x8 tiles with 256 threads are ONE wave
+// per SIMD (a 32x16 tile's 308 strips need five waves, i.e. two on one SIMD): while they fit one per CU (<= 256 tiles)
+// they win everywhere, 100^2 310 k -> 337 k steps/s, 256^2 279 k -> 304 k, lambda-omega 256^2 194 k -> 220 k; 320^2
+// (400 tiles) loses 8 %.
 int tile_by_for(const Problem& p)
 {
     if (p.hc != 0) return TILE_B;
-    if (p.opt.tile_by == 16 || p.opt.tile_by == 32) return p.opt.tile_by;
+    if (p.opt.tile_by == 8 || p.opt.tile_by == 16 || p.opt.tile_by == 32) return p.opt.tile_by;
     if (p.opt.tile_k != 4 || p.opt.tile_nt != 512) return TILE_B;
     const int64_t tiles32 = ((p.n0 + TILE_B - 1) / TILE_B) * ((p.W + TILE_B - 1) / TILE_B);
-    return tiles32 <= 128 ? 16 : TILE_B;
+    const int64_t tiles8 = ((p.n0 + 7) / 8) * ((p.W + TILE_B - 1) / TILE_B);
+    return tiles8 <= 256 ? 8 : (tiles32 <= 128 ? 16 : TILE_B);
 }
 
 template <typename T>
@@ -619,6 +624,7 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
             if (p.opt.tile_k == 8) return CALL(HC, 8, 1024);                    \
             if (p.opt.tile_nt == 1024) return CALL(HC, 4, 1024);                \
             if (tile_by_for(p) == 16) return CALL(HC, 4, 320, 16);              \
+            if (tile_by_for(p) == 8) return CALL(HC, 4, 256, 8);                \
         }                                                                       \
         if (p.opt.tile_nt == 256) return CALL(HC, 4, 256);                      \
         return CALL(HC, 4, 512);                                                \
@@ -1140,7 +1146,7 @@ int apply_option(Options& o, const char* key, long value)
     }
     if (!std::strcmp(key, "tile_xcd")) { o.tile_xcd = value != 0; return 0; }
     if (!std::strcmp(key, "tile_by")) {
-        if (value != 0 && value != 16 && value != 32) return PERCNN_PI_EINVAL;
+        if (value != 0 && value != 8 && value != 16 && value != 32) return PERCNN_PI_EINVAL;
         o.tile_by = (int)value;
         return 0;
     }

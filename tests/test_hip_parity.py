@@ -585,7 +585,7 @@ def test_rccl_halo_exchange_to_self(hip_device):
 # temporally blocked 2D kernels: every variant must stay bit-identical to the oracle
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opts", [{"tile": 0}, {"tile_xcd": 0}, {"tile_k": 2}, {"tile_k": 4, "tile_nt": 256},
-                                  {"tile_k": 4, "tile_nt": 512}, {"tile_k": 4, "tile_nt": 1024}, {"tile_k": 8}, {"tile_by": 16}, {"tile_by": 32}, {"vec": 1}])
+                                  {"tile_k": 4, "tile_nt": 512}, {"tile_k": 4, "tile_nt": 1024}, {"tile_k": 8}, {"tile_by": 8}, {"tile_by": 16}, {"tile_by": 32}, {"vec": 1}])
 @pytest.mark.parametrize("dtype,hc", [(np.float32, 8), (np.float32, 2), (np.float64, 4), (np.float32, 0),
                                       (np.float64, 0)])
 @pytest.mark.parametrize("shape", [(64, 96), (40, 100), (128, 256)])
