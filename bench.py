@@ -375,6 +375,12 @@ def main():
             res = slab_extra(dev, dist, rank, world)
         except Exception as e:
             res = {"error": repr(e)[:300]}
+        if dist is not None and "error" not in res and not int(os.environ.get("PERCNN_NO_PEER", "0")):
+            # second transport, same problem: peer mailboxes (xGMI load/store + epoch flags) instead of RCCL calls
+            try:
+                res["peer_mailbox"] = slab_extra(dev, dist, rank, world, transport="peer")
+            except Exception as e:
+                res["peer_mailbox"] = {"error": repr(e)[:300]}
         try:
             pa.slab.close_exchangers()
         except Exception:
@@ -691,21 +697,20 @@ def slab_extra_isolated(a, dev, dist, rank, world, local_rank):
     return json.loads(lines[-1])
 
 
-def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=5):
-    """3D Gray-Scott, Hc=2, fp32: global grid (32*world) x 256 x 256 sharded into slabs along axis 0."""
+def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=5, transport=None):
+    """3D Gray-Scott, Hc=2, fp32: global grid (32*world) x 256 x 256 sharded into slabs along axis 0.  The forward state
+    of every rank is checked bit for bit against the single-domain rollout of the whole grid (computed on every rank)."""
     import percnn_amd as pa
     from percnn_amd import slab, synthetic
     sd = load_params(WORKLOADS["gs3d_128"][5])
     cell = make_cell("gs3d", sd, dev)
     with torch.no_grad():
         P = cell.param_block().contiguous()
-    ex = slab.make_exchanger(force_p2p=bool(int(os.environ.get("PERCNN_FORCE_P2P", "0"))))
+    ex = slab.make_exchanger(force_p2p=bool(int(os.environ.get("PERCNN_FORCE_P2P", "0"))), transport=transport)
     full_shape = (planes * world, hw, hw)
-    lo = planes * rank
-    g = torch.Generator().manual_seed(0)
+    blocks = [synthetic.gs_initial_state((planes, hw, hw), seed=r)[0] for r in range(world)]
     local = torch.zeros((2, planes + 2 * halo, hw, hw), device=dev)
-    blockv = synthetic.gs_initial_state((planes, hw, hw), seed=rank)[0]
-    local[:, halo:halo + planes] = blockv.to(dev)
+    local[:, halo:halo + planes] = blocks[rank].to(dev)
     traj = torch.zeros((T + 1,) + tuple(local.shape), device=dev)
     traj[0] = local
     gtraj = torch.randn(traj.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(rank)) / traj.numel()
@@ -740,13 +745,26 @@ def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=5):
         times.append(e)
     el = float(np.median(times)) * reps
     assert torch.isfinite(pg).all() and torch.isfinite(traj[-1][:, halo:-halo]).all()
-    return {"workload": f"gs3d {'x'.join(map(str, full_shape))} sharded into {world} slabs of {planes} planes, Hc=2, "
-                        f"T={T} fwd+bwd, forward halo {halo} (={halo // 2} steps per exchange), adjoint sweep "
-                        f"exchanges 2 planes per step; native C loop (one call per rollout), overlap={int(overlap)}; "
-                        f"exchanger={type(ex).__name__}",
-            "steps_per_sec_fwd_bwd": reps * T / el, "ms_per_time_step_fwd_bwd": el / (reps * T) * 1e3,
-            "points_per_rank": planes * hw * hw, "global_points": planes * world * hw * hw,
-            "halo_bytes_per_exchange_per_direction": 2 * halo * hw * hw * 4}
+    # verification: the whole grid as ONE periodic domain on this GPU, same kernels -> my planes must match exactly
+    ref = torch.empty((T + 1, 2) + full_shape, device=dev)
+    ref[0] = torch.cat([b.to(dev) for b in blocks], dim=1)
+    pa.rollout_fwd_(ref, P)
+    same = torch.equal(ref[:, :, planes * rank:planes * (rank + 1)], traj[:, :, halo:halo + planes])
+    del ref
+    ok = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
+    if dist is not None:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    out = {"workload": f"gs3d {'x'.join(map(str, full_shape))} sharded into {world} slabs of {planes} planes, Hc=2, "
+                       f"T={T} fwd+bwd, forward halo {halo} (={halo // 2} steps per exchange), adjoint sweep "
+                       f"exchanges 2 planes per step; native C loop (one call per rollout), overlap={int(overlap)}; "
+                       f"exchanger={type(ex).__name__}",
+           "steps_per_sec_fwd_bwd": reps * T / el, "ms_per_time_step_fwd_bwd": el / (reps * T) * 1e3,
+           "forward_state_equals_single_domain_rollout": bool(ok.item()),
+           "points_per_rank": planes * hw * hw, "global_points": planes * world * hw * hw,
+           "halo_bytes_per_exchange_per_direction": 2 * halo * hw * hw * 4}
+    if hasattr(ex, "status"):
+        out["timed_out_exchange"] = ex.status()
+    return out
 
 
 if __name__ == "__main__":

@@ -221,11 +221,28 @@ int percnn_pi_conv3d_k5c8_wgrad_f32(const float* in, const float* g_out, float* 
 /* ---- native slab rollouts (multi-GPU): the whole T-step loop, halo exchanges included, in ONE call ---------------
  * The ring is described by plain function pointers so that the library needs no link-time dependency on RCCL: the host
  * side passes the addresses of ncclGroupStart / ncclGroupEnd / ncclSend / ncclRecv of the librccl it already uses
- * (percnn_amd.slab does this with ctypes for the librccl PyTorch loaded) plus its communicator and neighbour ranks.
+ * (percnn_amd.slab does this with ctypes for the librccl PyTorch loaded) plus its communicator and neighbour ranks --
+ * or a percnn_pi_peer_ring (below), in which case the library needs nothing from RCCL at all.
  * ring == NULL: single rank, the periodic wrap is done with device-to-device copies.
  * overlap != 0: the step that produces a frame about to be exchanged computes the two faces first, the exchange runs
  * on an internal side stream (ordered by events) while the planes in between are computed.
  * Layout: local padded trajectories [T+1][2][n0_local + 2*halo][...]; shape = local interior shape. */
+/* Second transport: PEER MAILBOXES (csrc/pi_peer.h).  xGMI peers are load/store addressable, so a face can travel as plain
+ * stores into a mailbox that lives in the neighbour's fine-grained device memory, announced by an epoch flag -- two small
+ * kernels per exchange on the compute stream instead of one ncclGroup call (~19-25 us each on MI355X).  Every rank
+ * allocates one mailbox (percnn_pi_peer_box_alloc), exports its hipIpc handle, maps the mailboxes of its two ring
+ * neighbours (percnn_pi_peer_box_open; a rank that is its own neighbour passes its own mailbox) and fills this struct;
+ * the library advances `epoch` by one per exchange -- all ranks of a ring must issue the same sequence of exchanges.
+ * slot_bytes >= 2 species x width planes of the widest exchange (rounded up to 16 B per species). */
+typedef struct percnn_pi_peer_ring {
+    void* my_box;               /* this rank's mailbox */
+    void* prev_box;             /* mapped mailbox of the previous / next rank on the ring */
+    void* next_box;
+    size_t slot_bytes;          /* the capacity all three mailboxes were allocated with */
+    uint64_t epoch;             /* exchanges issued so far (in/out) */
+    uint64_t timeout_ticks;     /* bounded wait of a take, in 10 ns ticks; 0 = default (5 s) */
+} percnn_pi_peer_ring;
+
 typedef struct percnn_pi_halo_ring {
     void* comm;                 /* ncclComm_t */
     int prev, next;             /* neighbour ranks on the ring (periodic) */
@@ -234,7 +251,21 @@ typedef struct percnn_pi_halo_ring {
     int (*group_end)(void);
     int (*send)(const void* buf, size_t count, int dtype, int peer, void* comm, void* stream);
     int (*recv)(void* buf, size_t count, int dtype, int peer, void* comm, void* stream);
+    percnn_pi_peer_ring* peer;  /* non-NULL: exchange through the peer mailboxes, the RCCL members above are not used */
 } percnn_pi_halo_ring;
+
+size_t percnn_pi_peer_box_bytes(size_t slot_bytes);                 /* size of a mailbox allocation */
+int percnn_pi_peer_box_alloc(void** box, size_t slot_bytes);        /* fine-grained device memory on the current device, zeroed */
+int percnn_pi_peer_box_free(void* box);
+int percnn_pi_peer_box_export(void* box, void* handle64);           /* hipIpcMemHandle_t (64 bytes) of a mailbox */
+int percnn_pi_peer_box_open(const void* handle64, void** mapped);   /* map a neighbour's mailbox (another process) */
+int percnn_pi_peer_box_close(void* mapped);
+int percnn_pi_peer_box_status(const void* box, uint64_t* error_epoch, void* stream);   /* synchronises `stream`; 0 = no take timed out */
+/* one ring exchange of `width` planes per side of a local slab [2][n0 + 2*halo][...] (shape = local interior shape) */
+int percnn_pi_peer_exchange_f32(float* slab, int ndim, const int64_t* shape, int halo, int width,
+                                percnn_pi_peer_ring* ring, void* stream);
+int percnn_pi_peer_exchange_f64(double* slab, int ndim, const int64_t* shape, int halo, int width,
+                                percnn_pi_peer_ring* ring, void* stream);
 
 size_t percnn_pi_halo_ring_bytes(void);   /* sizeof(percnn_pi_halo_ring) of the library build: bindings check their layout */
 int percnn_pi_slab_rollout_fwd_f32(float* traj, const float* params, int hc, int ndim, const int64_t* shape, int halo,

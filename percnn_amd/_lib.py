@@ -18,7 +18,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 _INC = os.path.join("..", "..", "include")
 # translation unit -> headers it depends on (all under csrc/ unless a path is given)
 SOURCES = {
-    "pi_abi.hip": ["pi_kernels.h", "pi_tile2d.h", "pi_stream3d.h", "pi_adv.h", "pi_contract.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h")],
+    "pi_abi.hip": ["pi_kernels.h", "pi_tile2d.h", "pi_stream3d.h", "pi_adv.h", "pi_contract.h", "pi_peer.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h")],
     "pi_s1_abi.hip": ["pi_s1.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h"), os.path.join(_INC, "percnn_pi_stage1.h")],
     "pi_up3d_abi.hip": ["pi_up3d.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h")],
 }
@@ -26,6 +26,9 @@ SOURCES = {
 EXPORTS = [
     "percnn_pi_abi_version", "percnn_pi_param_count", "percnn_pi_bwd_workspace_bytes",
     "percnn_pi_rollout_bwd_workspace_bytes", "percnn_pi_set_option", "percnn_pi_halo_ring_bytes",
+    "percnn_pi_peer_box_bytes", "percnn_pi_peer_box_alloc", "percnn_pi_peer_box_free", "percnn_pi_peer_box_export",
+    "percnn_pi_peer_box_open", "percnn_pi_peer_box_close", "percnn_pi_peer_box_status",
+    "percnn_pi_peer_exchange_f32", "percnn_pi_peer_exchange_f64",
 ] + [f"percnn_pi_{op}_{suf}" for suf in ("f32", "f64")
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
                 "slab_step_fwd_range", "slab_step_bwd_range", "slab_rollout_fwd", "slab_rollout_bwd", "residual_fwd",
@@ -101,6 +104,18 @@ def lib() -> ctypes.CDLL:
     L.percnn_pi_halo_ring_bytes.restype, L.percnn_pi_halo_ring_bytes.argtypes = sz, []
     if L.percnn_pi_halo_ring_bytes() != ctypes.sizeof(HaloRing):
         raise RuntimeError("percnn_amd: percnn_pi_halo_ring layout differs between the python binding and libpercnn_pi.so")
+    vpp = ctypes.POINTER(ctypes.c_void_p)
+    L.percnn_pi_peer_box_bytes.restype, L.percnn_pi_peer_box_bytes.argtypes = sz, [sz]
+    L.percnn_pi_peer_box_alloc.restype, L.percnn_pi_peer_box_alloc.argtypes = ci, [vpp, sz]
+    L.percnn_pi_peer_box_free.restype, L.percnn_pi_peer_box_free.argtypes = ci, [vp]
+    L.percnn_pi_peer_box_export.restype, L.percnn_pi_peer_box_export.argtypes = ci, [vp, vp]
+    L.percnn_pi_peer_box_open.restype, L.percnn_pi_peer_box_open.argtypes = ci, [vp, vpp]
+    L.percnn_pi_peer_box_close.restype, L.percnn_pi_peer_box_close.argtypes = ci, [vp]
+    L.percnn_pi_peer_box_status.restype = ci
+    L.percnn_pi_peer_box_status.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), vp]
+    for suf in ("f32", "f64"):
+        f = getattr(L, f"percnn_pi_peer_exchange_{suf}")
+        f.restype, f.argtypes = ci, [vp, ci, i64p, ci, ci, ctypes.POINTER(PeerRing), vp]
     for suf in ("f32", "f64"):
         f = getattr(L, f"percnn_pi_contract_fwd_{suf}")
         f.restype, f.argtypes = ci, [vp, ci, vp, vp]
@@ -158,12 +173,19 @@ def lib() -> ctypes.CDLL:
     return L
 
 
+class PeerRing(ctypes.Structure):
+    """percnn_pi_peer_ring of include/percnn_pi.h: this rank's mailbox, the mapped mailboxes of its ring neighbours"""
+    _fields_ = [("my_box", ctypes.c_void_p), ("prev_box", ctypes.c_void_p), ("next_box", ctypes.c_void_p),
+                ("slot_bytes", ctypes.c_size_t), ("epoch", ctypes.c_uint64), ("timeout_ticks", ctypes.c_uint64)]
+
+
 class HaloRing(ctypes.Structure):
-    """percnn_pi_halo_ring of include/percnn_pi.h: communicator, neighbours and the four RCCL entry points as addresses"""
+    """percnn_pi_halo_ring of include/percnn_pi.h: communicator, neighbours and the four RCCL entry points as addresses,
+    or (``peer`` set) the peer-mailbox transport"""
     _fields_ = [("comm", ctypes.c_void_p), ("prev", ctypes.c_int), ("next", ctypes.c_int),
                 ("dtype_f32", ctypes.c_int), ("dtype_f64", ctypes.c_int),
                 ("group_start", ctypes.c_void_p), ("group_end", ctypes.c_void_p),
-                ("send", ctypes.c_void_p), ("recv", ctypes.c_void_p)]
+                ("send", ctypes.c_void_p), ("recv", ctypes.c_void_p), ("peer", ctypes.POINTER(PeerRing))]
 
 
 def check(rc: int, what: str) -> None:

@@ -13,6 +13,7 @@
 #include "pi_tile2d.h"
 #include "pi_stream3d.h"
 #include "pi_contract.h"
+#include "pi_peer.h"
 #include "pi_adv.h"
 
 namespace {
@@ -801,10 +802,70 @@ template <typename T> int ring_dtype(const percnn_pi_halo_ring* r);
 template <> int ring_dtype<float>(const percnn_pi_halo_ring* r) { return r->dtype_f32; }
 template <> int ring_dtype<double>(const percnn_pi_halo_ring* r) { return r->dtype_f64; }
 
+// the same exchange through the peer mailboxes (pi_peer.h): put into the neighbours' slots, take from mine
+template <typename T>
+int peer_exchange(T* slab, const Problem& p, int width, percnn_pi_peer_ring* pr, hipStream_t st)
+{
+    if (!pr || !pr->my_box || !pr->prev_box || !pr->next_box || width < 1 || width > p.halo || width > p.n0)
+        return PERCNN_PI_EINVAL;
+    const size_t plane = (size_t)(p.n1 * p.W), bytes = (size_t)width * plane * sizeof(T);
+    const size_t ss = (size_t)(p.n0 + 2 * p.halo) * plane;
+    const size_t soff = pi::peer_round16(bytes);                 // species 1 inside a slot
+    if (2 * soff > pr->slot_bytes) return PERCNN_PI_EINVAL;
+    const int64_t n = p.n0, halo = p.halo;
+    auto at = [&](int s, int64_t pl) { return reinterpret_cast<char*>(slab + (size_t)s * ss + (size_t)pl * plane); };
+    const uint64_t epoch = ++pr->epoch;
+    const int parity = (int)(epoch & 1);
+    pi::PeerXfer put{}, take{};
+    // direction 0: my LAST interior planes -> the next rank (arrive there as "from prev", its lower halo);
+    // direction 1: my FIRST interior planes -> the prev rank (arrive as "from next", its upper halo)
+    char* to_next = pi::peer_slot(pr->next_box, pr->slot_bytes, parity, 0);
+    char* to_prev = pi::peer_slot(pr->prev_box, pr->slot_bytes, parity, 1);
+    char* from_prev = pi::peer_slot(pr->my_box, pr->slot_bytes, parity, 0);
+    char* from_next = pi::peer_slot(pr->my_box, pr->slot_bytes, parity, 1);
+    bool vec = bytes % 16 == 0;
+    for (int s = 0; s < 2; ++s) {
+        put.src[0][s] = at(s, halo + n - width); put.dst[0][s] = to_next + s * soff;
+        put.src[1][s] = at(s, halo);             put.dst[1][s] = to_prev + s * soff;
+        take.src[0][s] = from_prev + s * soff;   take.dst[0][s] = at(s, halo - width);
+        take.src[1][s] = from_next + s * soff;   take.dst[1][s] = at(s, halo + n);
+        for (int d = 0; d < 2; ++d)
+            vec = vec && reinterpret_cast<uintptr_t>(put.src[d][s]) % 16 == 0 && reinterpret_cast<uintptr_t>(take.dst[d][s]) % 16 == 0;
+    }
+    const size_t units = bytes / (vec ? 16 : 4);
+    const int bpd = (int)std::min<size_t>(256, std::max<size_t>(1, (units + 1023) / 1024));   // 4 units in flight per lane and species
+    put.bytes = take.bytes = bytes;
+    put.epoch = take.epoch = epoch;
+    put.blocks_per_dir = take.blocks_per_dir = bpd;
+    put.mine = take.mine = static_cast<pi::PeerBox*>(pr->my_box);
+    put.signal[0] = static_cast<pi::PeerBox*>(pr->next_box);
+    put.signal[1] = static_cast<pi::PeerBox*>(pr->prev_box);
+    const unsigned long long ticks = pr->timeout_ticks ? pr->timeout_ticks : 500000000ull;
+    if (vec) {
+        hipLaunchKernelGGL(pi::peer_put_kernel<true>, dim3(2 * bpd), dim3(256), 0, st, put);
+        hipLaunchKernelGGL(pi::peer_take_kernel<true>, dim3(2 * bpd), dim3(256), 0, st, take, ticks);
+    } else {
+        hipLaunchKernelGGL(pi::peer_put_kernel<false>, dim3(2 * bpd), dim3(256), 0, st, put);
+        hipLaunchKernelGGL(pi::peer_take_kernel<false>, dim3(2 * bpd), dim3(256), 0, st, take, ticks);
+    }
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int peer_exchange_impl(T* slab, int ndim, const int64_t* shape, int halo, int width, percnn_pi_peer_ring* ring, void* stream)
+{
+    Problem p;
+    if (int rc = make_problem(0, ndim, shape, true, p)) return rc;
+    if (halo < 1 || !slab) return PERCNN_PI_EINVAL;
+    p.halo = halo;
+    return peer_exchange<T>(slab, p, width, ring, static_cast<hipStream_t>(stream));
+}
+
 // faces of `slab` ([2][n0 + 2*halo][plane]) -> the neighbours' halo planes, `width` planes per side, on stream st
 template <typename T>
 int ring_exchange(T* slab, const Problem& p, int width, const percnn_pi_halo_ring* r, hipStream_t st)
 {
+    if (r && r->peer) return peer_exchange<T>(slab, p, width, r->peer, st);
     const size_t plane = (size_t)(p.n1 * p.W), cnt = (size_t)width * plane;
     const size_t ss = (size_t)(p.n0 + 2 * p.halo) * plane;
     const int64_t n = p.n0, halo = p.halo;
@@ -1275,6 +1336,53 @@ int percnn_pi_debug_wave_stamps(long long* host_out, int n)
 
 int percnn_pi_abi_version(void) { return PERCNN_PI_ABI_VERSION; }
 size_t percnn_pi_halo_ring_bytes(void) { return sizeof(percnn_pi_halo_ring); }
+
+// ---- peer mailboxes (pi_peer.h) ----
+size_t percnn_pi_peer_box_bytes(size_t slot_bytes) { return pi::peer_box_bytes(slot_bytes); }
+int percnn_pi_peer_box_alloc(void** box, size_t slot_bytes)
+{
+    if (!box || !slot_bytes) return PERCNN_PI_EINVAL;
+    const size_t total = pi::peer_box_bytes(slot_bytes);
+    // fine-grained: stores that arrive over xGMI bypass this device's L2, so its own reads must not be served from there
+    if (hipError_t e = hipExtMallocWithFlags(box, total, hipDeviceMallocFinegrained)) return (int)e;
+    if (hipError_t e = hipMemset(*box, 0, total)) return (int)e;
+    return (int)hipDeviceSynchronize();
+}
+int percnn_pi_peer_box_free(void* box) { return box ? (int)hipFree(box) : 0; }
+int percnn_pi_peer_box_export(void* box, void* handle64)
+{
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t");
+    if (!box || !handle64) return PERCNN_PI_EINVAL;
+    hipIpcMemHandle_t h;
+    if (hipError_t e = hipIpcGetMemHandle(&h, box)) return (int)e;
+    std::memcpy(handle64, &h, sizeof(h));
+    return 0;
+}
+int percnn_pi_peer_box_open(const void* handle64, void** mapped)
+{
+    if (!handle64 || !mapped) return PERCNN_PI_EINVAL;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle64, sizeof(h));
+    return (int)hipIpcOpenMemHandle(mapped, h, hipIpcMemLazyEnablePeerAccess);
+}
+int percnn_pi_peer_box_close(void* mapped) { return mapped ? (int)hipIpcCloseMemHandle(mapped) : 0; }
+int percnn_pi_peer_box_status(const void* box, uint64_t* error_epoch, void* stream)
+{
+    if (!box || !error_epoch) return PERCNN_PI_EINVAL;
+    auto st = static_cast<hipStream_t>(stream);
+    unsigned long long e = 0;
+    if (hipError_t rc = hipMemcpyAsync(&e, &static_cast<const pi::PeerBox*>(box)->error[0], sizeof(e), hipMemcpyDeviceToHost, st))
+        return (int)rc;
+    if (hipError_t rc = hipStreamSynchronize(st)) return (int)rc;
+    *error_epoch = e;
+    return 0;
+}
+int percnn_pi_peer_exchange_f32(float* slab, int ndim, const int64_t* shape, int halo, int width, percnn_pi_peer_ring* ring,
+                                void* stream)
+{ return peer_exchange_impl<float>(slab, ndim, shape, halo, width, ring, stream); }
+int percnn_pi_peer_exchange_f64(double* slab, int ndim, const int64_t* shape, int halo, int width, percnn_pi_peer_ring* ring,
+                                void* stream)
+{ return peer_exchange_impl<double>(slab, ndim, shape, halo, width, ring, stream); }
 
 size_t percnn_pi_param_count(int hc) { return hc < -1 ? 0 : (size_t)pi::nparams(hc); }
 

@@ -132,6 +132,10 @@ class HaloExchanger:
         this exchanger, and the ``percnn_pi_halo_ring*`` to pass (None = single rank, local periodic wrap)."""
         return (self.world == 1 and not self.force_p2p), None
 
+    def prepare(self, slab: torch.Tensor, halo: int) -> None:
+        """Collective hook called once per slab rollout before any exchange of ``slab``-shaped arrays (width <= halo):
+        transports that own buffers size them here.  Nothing to do for message passing."""
+
     def exchange_async(self, slab: torch.Tensor, halo: int, width: Optional[int] = None):
         """Portable exchanger: the exchange completes before returning (the overlapped orchestration stays valid,
         it just does not overlap)."""
@@ -274,6 +278,153 @@ class RcclHaloExchanger(HaloExchanger):
             self._comm = None
 
 
+class PeerHaloExchanger(HaloExchanger):
+    """Ring exchange through PEER MAILBOXES (``csrc/pi_peer.h``, ``percnn_pi_peer_*`` of the C-ABI): the faces travel as
+    plain stores over xGMI into a mailbox in the neighbour's fine-grained device memory, announced by an epoch flag --
+    a put and a take kernel per exchange on the compute stream, no RCCL call, no host wait.  All ranks must run on ONE
+    node (the mailboxes are shared through hipIpc handles, gathered once over the ``torch.distributed`` group -- any
+    backend, the data path never touches it).  Falls back to the parent class for CPU tensors / world size 1 without
+    ``force_p2p``.
+
+    Validated here with several processes sharing one MI355X (``tests/test_slab_dist_gpu.py``) and against itself on one
+    rank; it has not run across two physical GPUs yet, so ``make_exchanger`` only picks it on request
+    (``transport="peer"`` / ``PERCNN_SLAB_TRANSPORT=peer``)."""
+
+    def __init__(self, group=None, force_p2p: bool = False, slot_bytes: int = 1 << 20):
+        super().__init__(group, force_p2p)
+        import ctypes
+        from . import _lib
+        self._ct, self._L = ctypes, _lib
+        self._peer = None            # _lib.PeerRing
+        self._ring = None            # _lib.HaloRing pointing at it
+        self._mapped = []            # mailboxes of other processes this rank has open
+        self._side = None
+        self._ensure(int(slot_bytes))
+
+    # -- mailbox management (collective) ------------------------------------------------------------------------
+    def _ensure(self, slot_bytes: int) -> None:
+        if self._peer is not None and slot_bytes <= self._peer.slot_bytes:
+            return
+        import socket
+        ct, L = self._ct, self._L.lib()
+        self._release()
+        slot_bytes = (int(slot_bytes) + (1 << 20) - 1) & ~((1 << 20) - 1)
+        box = ct.c_void_p()
+        self._L.check(L.percnn_pi_peer_box_alloc(ct.byref(box), slot_bytes), "peer_box_alloc")
+        handle = (ct.c_char * 64)()
+        self._L.check(L.percnn_pi_peer_box_export(box, handle), "peer_box_export")
+        mine = (socket.gethostname(), bytes(handle.raw), slot_bytes)
+        infos = [mine]
+        if self.world > 1:
+            infos = [None] * self.world
+            dist.all_gather_object(infos, mine, group=self.group)
+        if any(i[0] != mine[0] for i in infos):
+            L.percnn_pi_peer_box_free(box)
+            raise RuntimeError("percnn_amd: the peer-mailbox transport needs all ranks of the ring on one node")
+        if any(i[2] != slot_bytes for i in infos):
+            L.percnn_pi_peer_box_free(box)
+            raise RuntimeError("percnn_amd: ranks disagree on the mailbox size (are the slabs shaped alike?)")
+
+        def mapped(r):
+            if r == self.rank:
+                return box.value
+            m = ct.c_void_p()
+            self._L.check(L.percnn_pi_peer_box_open(ct.c_char_p(infos[r][1]), ct.byref(m)), f"peer_box_open(rank {r})")
+            self._mapped.append(m.value)
+            return m.value
+
+        err = None
+        try:
+            prev_box = mapped(self.prev)
+            next_box = prev_box if self.next == self.prev else mapped(self.next)
+        except Exception as e:                      # keep the collectives below aligned across ranks, then report
+            err = e
+        if err is not None:
+            if self.world > 1:
+                dist.barrier(group=self.group)
+            for m in self._mapped:
+                L.percnn_pi_peer_box_close(m)
+            self._mapped = []
+            L.percnn_pi_peer_box_free(box)
+            raise err
+        self._box = box.value
+        self._peer = self._L.PeerRing(box.value, prev_box, next_box, slot_bytes, 0, 0)
+        self._ring = self._L.HaloRing(None, self.prev, self.next, 0, 0, None, None, None, None, ct.pointer(self._peer))
+        if self.world > 1:
+            dist.barrier(group=self.group)          # nobody frees / re-sizes before everybody has mapped
+
+    def _release(self) -> None:
+        if self._peer is None:
+            return
+        L = self._L.lib()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if self.world > 1:
+            try:
+                dist.barrier(group=self.group)      # the neighbours may still be writing into / reading from it
+            except Exception:
+                pass
+        for m in self._mapped:
+            L.percnn_pi_peer_box_close(m)
+        self._mapped = []
+        L.percnn_pi_peer_box_free(self._box)
+        self._peer = self._ring = self._box = None
+
+    def prepare(self, slab: torch.Tensor, halo: int) -> None:
+        if slab.is_cuda and not (self.world == 1 and not self.force_p2p):
+            per_species = halo * slab[0, 0].numel() * slab.element_size()
+            self._ensure(2 * ((per_species + 15) & ~15))
+
+    def status(self) -> int:
+        """0, or the number of the first exchange whose take timed out (synchronises the current stream)."""
+        if self._peer is None:
+            return 0
+        e = self._ct.c_uint64(0)
+        st = self._ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._L.check(self._L.lib().percnn_pi_peer_box_status(self._box, self._ct.byref(e), st), "peer_box_status")
+        return int(e.value)
+
+    # -- exchanges -------------------------------------------------------------------------------------------------
+    def exchange(self, slab: torch.Tensor, halo: int, width: Optional[int] = None) -> None:
+        if not slab.is_cuda or (self.world == 1 and not self.force_p2p):
+            return super().exchange(slab, halo, width)
+        width = halo if width is None else width
+        n = slab.shape[1] - 2 * halo
+        if width > n:
+            raise ValueError("halo wider than the neighbour's interior")
+        assert slab.is_contiguous()
+        self.prepare(slab, halo)
+        ct = self._ct
+        shape = [n] + list(slab.shape[2:])
+        f = getattr(self._L.lib(), "percnn_pi_peer_exchange_" + ("f32" if slab.dtype == torch.float32 else "f64"))
+        st = ct.c_void_p(torch.cuda.current_stream(slab.device).cuda_stream)
+        self._L.check(f(ct.c_void_p(slab.data_ptr()), len(shape), self._L.shape_arg(shape), int(halo), int(width),
+                        ct.byref(self._peer), st), "peer_exchange")
+
+    def native_ring(self):
+        if self.world == 1 and not self.force_p2p:
+            return True, None
+        return True, self._ct.byref(self._ring)
+
+    def exchange_async(self, slab: torch.Tensor, halo: int, width: Optional[int] = None):
+        if not slab.is_cuda or (self.world == 1 and not self.force_p2p):
+            super().exchange(slab, halo, width)
+            return _Done()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=slab.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(slab.device))
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            self.exchange(slab, halo, width)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        return _StreamDone(done)
+
+    def close(self):
+        self._release()
+
+
 _exchangers: dict = {}
 
 
@@ -288,17 +439,43 @@ def _all_ranks_agree(ok: bool, group) -> bool:
     return bool(flag.item())
 
 
-def make_exchanger(group=None, prefer_rccl: bool = True, force_p2p: bool = False) -> HaloExchanger:
-    """ONE exchanger per (group, device, transport) for the life of the process: RCCL-direct on GPU jobs when the
-    communicator comes up on every rank, else the torch.distributed one.  (A fresh ``ncclCommInitRank`` per training
-    iteration would leak a communicator each time; cached instances are closed at interpreter exit.)"""
+def make_exchanger(group=None, prefer_rccl: bool = True, force_p2p: bool = False,
+                   transport: Optional[str] = None) -> HaloExchanger:
+    """ONE exchanger per (group, device, transport) for the life of the process.  ``transport`` (default: environment
+    variable ``PERCNN_SLAB_TRANSPORT``, else "auto"):
+
+    * "auto"  RCCL-direct on GPU jobs when the communicator comes up on every rank, else ``torch.distributed``;
+    * "peer"  peer mailboxes over xGMI load/store (``PeerHaloExchanger``) when every rank can set them up, else "auto";
+    * "rccl" / "dist"  as named ("dist" = ``prefer_rccl=False``).
+
+    (A fresh ``ncclCommInitRank`` / mailbox per training iteration would leak one each time; cached instances are closed
+    at interpreter exit.)"""
+    import os
+    import warnings
+    transport = (transport or os.environ.get("PERCNN_SLAB_TRANSPORT", "auto")).lower()
+    if transport not in ("auto", "peer", "rccl", "dist"):
+        raise ValueError(f"unknown slab transport {transport!r}")
+    if transport == "dist":
+        prefer_rccl = False
     dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
-    key = (id(group) if group is not None else None, dev, bool(prefer_rccl), bool(force_p2p))
+    key = (id(group) if group is not None else None, dev, bool(prefer_rccl), bool(force_p2p), transport == "peer")
     ex = _exchangers.get(key)
     if ex is not None:
         return ex
     ex = None
-    if prefer_rccl and torch.cuda.is_available():
+    if transport == "peer" and torch.cuda.is_available():
+        err = None
+        try:
+            ex = PeerHaloExchanger(group, force_p2p)
+        except Exception as e:
+            err = e
+        if not _all_ranks_agree(ex is not None, group):
+            if ex is not None:
+                ex.close()
+            ex = None
+            warnings.warn(f"percnn_amd: peer-mailbox halo ring not available on every rank ({err!r}); using RCCL / "
+                          "torch.distributed")
+    if ex is None and prefer_rccl and torch.cuda.is_available():
         err = None
         try:
             ex = RcclHaloExchanger(group, force_p2p)
@@ -308,7 +485,6 @@ def make_exchanger(group=None, prefer_rccl: bool = True, force_p2p: bool = False
             if ex is not None:
                 ex.close()
             ex = None
-            import warnings
             warnings.warn(f"percnn_amd: RCCL halo ring not available on every rank ({err!r}); "
                           "using torch.distributed point-to-point")
     if ex is None:
@@ -348,6 +524,7 @@ def slab_rollout_fwd_(traj: torch.Tensor, P: torch.Tensor, ex: HaloExchanger, ha
     the un-split schedule (``tests/test_slab_dist_cpu.py`` runs both on gloo, ``tests/test_hip_parity.py`` on RCCL)."""
     if halo < 2 or halo % 2:
         raise ValueError("halo must be even and >= 2")
+    ex.prepare(traj[0], halo)
     if step_fwd is F_pi.step_fwd and traj.is_cuda:
         usable, ring = ex.native_ring()
         if usable:                                    # the whole loop in one C call (no per-step host work)
@@ -389,6 +566,7 @@ def slab_rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor, 
 
     overlap: every step first computes the two 2-plane faces of the new adjoint state, starts their exchange
     (``ex.exchange_async``) and computes the planes in between while they travel."""
+    ex.prepare(traj[0], halo)
     if step_bwd is F_pi.step_bwd and wgrad is F_pi.slab_wgrad and traj.is_cuda:
         usable, ring = ex.native_ring()
         if usable:

@@ -582,6 +582,75 @@ def test_rccl_halo_exchange_to_self(hip_device):
 
 
 # ---------------------------------------------------------------------------------------------
+# peer-mailbox transport on one rank: put / take through the rank's own mailbox must equal the local wrap
+# ---------------------------------------------------------------------------------------------
+def test_peer_mailbox_exchange_to_self(hip_device):
+    import ctypes
+    from percnn_amd import slab, _lib
+    px = slab.PeerHaloExchanger(force_p2p=True, slot_bytes=4096)
+    try:
+        # (10, 6, 8): 16-byte vector path; (9, 3, 5) / (12, 7): odd plane sizes -> element path, unaligned species stride
+        for shape in ((10, 6, 8), (9, 3, 5), (12, 7), (64, 32, 64)):
+            for halo, width in ((2, 2), (4, 4), (6, 2)):
+                for dtype in (torch.float32, torch.float64):
+                    n = shape[0]
+                    a = torch.rand((2, n + 2 * halo) + shape[1:], device=hip_device, dtype=dtype)
+                    b = a.clone()
+                    slab.HaloExchanger().exchange(a, halo, width)                 # local copies
+                    px.exchange(b, halo, width)                                   # put + take through the mailbox
+                    torch.cuda.synchronize()
+                    assert torch.equal(a, b), (shape, halo, width, dtype)
+        assert px.status() == 0 and px._peer.epoch == 4 * 3 * 2
+        # whole slab rollouts: native C loop, Python orchestration, faces-first schedule -- all equal to the local wrap
+        for ndim, shape, halo, hc in ((3, (24, 16, 64), 4, 2), (2, (40, 64), 2, 2), (3, (16, 8, 256), 4, 0)):
+            P = dev_t(random_block(hc, ndim, np.float32, 3, scale=0.3), hip_device)
+            T = 7
+            h0 = torch.rand((2,) + shape, device=hip_device)
+            res = []
+
+            class PyLoop(slab.PeerHaloExchanger):
+                def native_ring(self):
+                    return False, None
+            py = PyLoop(force_p2p=True)
+            for ex, overlap in ((slab.HaloExchanger(), False), (px, False), (px, True), (py, True)):
+                local = slab.scatter_slab(h0, 0, 1, halo)
+                traj = torch.zeros((T + 1,) + tuple(local.shape), device=hip_device)
+                traj[0] = local
+                slab.slab_rollout_fwd_(traj, P, ex, halo, overlap=overlap)
+                gt = torch.randn(traj.shape, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(1))
+                g0, pg = slab.slab_rollout_bwd(traj, gt, P, ex, halo, overlap=overlap)
+                torch.cuda.synchronize()
+                res.append((traj[:, :, halo:-halo].clone(), g0[:, halo:-halo].clone(), pg.clone()))
+            py.close()
+            for r in res[1:]:
+                assert torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1])
+                assert rel_l2(r[2].cpu().numpy(), res[0][2].cpu().numpy()) < 2e-5
+        assert px.status() == 0
+        # a neighbour that never delivers: the take gives up after its (here: 1 ms) bound, records the exchange number
+        # and every later take returns at once -- no hang
+        L = _lib.lib()
+        silent = ctypes.c_void_p()
+        _lib.check(L.percnn_pi_peer_box_alloc(ctypes.byref(silent), 1 << 20), "alloc")
+        ring = _lib.PeerRing(px._box, silent.value, silent.value, px._peer.slot_bytes, 1000000, 100000)
+        c = torch.rand((2, 14, 6, 8), device=hip_device)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(3):
+            _lib.check(L.percnn_pi_peer_exchange_f32(ctypes.c_void_p(c.data_ptr()), 3, _lib.shape_arg((10, 6, 8)), 2, 2,
+                                                     ctypes.byref(ring), st), "exchange")
+        torch.cuda.synchronize()
+        assert px.status() == 1000001 and ring.epoch == 1000003
+        L.percnn_pi_peer_box_free(silent)
+        # capacity check: a face that does not fit the slots is refused, not truncated
+        big = torch.rand((2, 40, 64, 64), device=hip_device)
+        small = _lib.PeerRing(px._box, px._box, px._box, 4096, 0, 0)
+        rc = L.percnn_pi_peer_exchange_f32(ctypes.c_void_p(big.data_ptr()), 3, _lib.shape_arg((36, 64, 64)), 2, 2,
+                                           ctypes.byref(small), st)
+        assert rc == -1 and small.epoch == 0
+    finally:
+        px.close()
+
+
+# ---------------------------------------------------------------------------------------------
 # temporally blocked 2D kernels: every variant must stay bit-identical to the oracle
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opts", [{"tile": 0}, {"tile_xcd": 0}, {"tile_k": 2}, {"tile_k": 4, "tile_nt": 256},

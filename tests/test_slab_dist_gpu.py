@@ -1,7 +1,9 @@
 """GPU, multi-process: the N > 1 slab path with the REAL HIP slab kernels -- world_size 2 and 3 on ONE MI355X.
 
 RCCL refuses several ranks on one device, and the build box has one GPU per call, so the ranks share cuda:0 and the ring
-exchange runs through the portable ``HaloExchanger`` (gloo; faces staged through pinned host buffers).  What is exercised
+exchange runs through the portable ``HaloExchanger`` (gloo; faces staged through pinned host buffers) or through the
+PEER-MAILBOX transport (``PeerHaloExchanger``: hipIpc-mapped mailboxes of the other processes, put / take kernels, epoch
+flags -- the very code path of a multi-GPU node, here with every "peer" on the same device).  What is exercised
 on hardware here, for the first time with more than one process: slab scatter, the skip-schedule forward with wide halos,
 the adjoint sweep with 2-plane exchanges, fused moments in the slab sweep, the gradient all-reduce -- against the
 single-domain rollout of the same kernels (state and dL/dh0 bit-identical, parameter gradients to reduction round-off)."""
@@ -27,7 +29,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, shape, halo, T, hc, dtype_name, overlap, q):
+def _worker(rank, world, port, shape, halo, T, hc, dtype_name, overlap, transport, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -50,8 +52,9 @@ def _worker(rank, world, port, shape, halo, T, hc, dtype_name, overlap, q):
         g_ref = torch.tensor(rs.uniform(-1, 1, tuple(traj_ref.shape)).astype(dtype), device=dev)
         g0_ref, pg_ref = pa.rollout_bwd(traj_ref, g_ref, P)
 
-        ex = slab.make_exchanger(prefer_rccl=False)
-        assert type(ex) is slab.HaloExchanger and (ex.rank, ex.world) == (rank, world)
+        ex = slab.make_exchanger(prefer_rccl=False, transport=transport)
+        want = slab.PeerHaloExchanger if transport == "peer" else slab.HaloExchanger
+        assert type(ex) is want and (ex.rank, ex.world) == (rank, world)
         lo, hi = slab.split_extent(shape[0], world)[rank]
         n = hi - lo
         local0 = slab.scatter_slab(h0, rank, world, halo)
@@ -69,22 +72,40 @@ def _worker(rank, world, port, shape, halo, T, hc, dtype_name, overlap, q):
         out = slab.slab_rollout(loc, P, T, halo=halo, ex=ex)
         (out[:, :, halo:halo + n] * g_ref[:, :, lo:hi]).sum().backward()
         ok_auto = bool(torch.equal(loc.grad[:, halo:halo + n], g0_ref[:, lo:hi]))
+        if transport == "peer":
+            ok_auto = ok_auto and ex.status() == 0            # no take ever timed out
+            # the Python orchestration (one exchange call per step) over the same mailboxes
+            class PyLoop(type(ex)):
+                def native_ring(self):
+                    return False, None
+            ex.__class__ = PyLoop
+            traj2 = torch.zeros_like(traj)
+            traj2[0] = local0
+            slab.slab_rollout_fwd_(traj2, P, ex, halo, overlap=overlap)
+            g0b, pgb = slab.slab_rollout_bwd(traj2, g_local, P, ex, halo, overlap=overlap)
+            ok_fwd = ok_fwd and bool(torch.equal(traj2[:, :, halo:halo + n], traj_ref[:, :, lo:hi]))
+            ok_g0 = ok_g0 and bool(torch.equal(g0b[:, halo:halo + n], g0_ref[:, lo:hi])) and ex.status() == 0
         q.put((rank, ok_fwd, ok_g0, err_pg, ok_auto))
     finally:
+        try:
+            slab.close_exchangers()
+        except Exception:
+            pass
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("transport", ["dist", "peer"])
 @pytest.mark.parametrize("world,shape,halo,T,hc,dtype,overlap", [
     (2, (16, 12, 64), 4, 5, 0, "float32", False),       # 3D, wide halo (2 steps per exchange), fused moments in the sweep
     (2, (16, 12, 64), 4, 5, 0, "float32", True),        # faces first + asynchronous exchange + planes in between
     (3, (20, 8, 16), 2, 4, 2, "float32", False),        # uneven split (7,7,6), factored block: sweep + slab_wgrad
     (2, (24, 40), 4, 6, 0, "float64", False),           # 2D slabs, float64
 ])
-def test_multi_process_slab_rollout_on_one_gpu(world, shape, halo, T, hc, dtype, overlap, hip_device):
+def test_multi_process_slab_rollout_on_one_gpu(world, shape, halo, T, hc, dtype, overlap, transport, hip_device):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, halo, T, hc, dtype, overlap, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, halo, T, hc, dtype, overlap, transport, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
