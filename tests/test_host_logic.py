@@ -378,6 +378,33 @@ def test_exchanger_is_cached_per_group_and_device():
     assert slab.make_exchanger() is not a
 
 
+def test_slab_transport_selection(monkeypatch):
+    """transport names are validated; without a HIP device the peer-mailbox / RCCL transports are never attempted and the
+    portable exchanger is what every name resolves to; the environment variable is the default of the argument."""
+    import ctypes
+    from percnn_amd import slab, _lib
+    slab.close_exchangers()
+    with pytest.raises(ValueError, match="unknown slab transport"):
+        slab.make_exchanger(transport="carrier-pigeon")
+    if not torch.cuda.is_available():
+        for name in ("auto", "peer", "rccl", "dist"):
+            assert type(slab.make_exchanger(transport=name)) is slab.HaloExchanger
+        monkeypatch.setenv("PERCNN_SLAB_TRANSPORT", "smoke-signals")
+        with pytest.raises(ValueError):
+            slab.make_exchanger()
+        monkeypatch.setenv("PERCNN_SLAB_TRANSPORT", "peer")
+        assert type(slab.make_exchanger()) is slab.HaloExchanger
+    slab.close_exchangers()
+    # the ctypes mirrors of the two ring structs have the C layout (the library checks percnn_pi_halo_ring itself)
+    assert ctypes.sizeof(_lib.PeerRing) == 3 * ctypes.sizeof(ctypes.c_void_p) + ctypes.sizeof(ctypes.c_size_t) + 16
+    L = _lib.lib()
+    assert L.percnn_pi_peer_box_bytes(1) == 4096 + 4 * 4096 and L.percnn_pi_peer_box_bytes(4097) == 4096 + 4 * 8192
+    # argument errors surface as return codes before any HIP call
+    assert L.percnn_pi_peer_box_alloc(None, 4096) == -1 and L.percnn_pi_peer_box_export(None, None) == -1
+    assert L.percnn_pi_peer_box_open(None, None) == -1
+    assert L.percnn_pi_peer_exchange_f32(None, 3, _lib.shape_arg((8, 8, 8)), 2, 2, None, None) == -1
+
+
 def test_3d_upscaler_contraction_path_equals_stock_layers():
     """The 3D IC generator evaluates its transposed convolutions as matmuls (MIOpen's ConvTranspose3d is 15x slower on
     MI355X); values and all gradients must equal the stock torch.nn layers it holds (train_3drd.py:41-56)."""
