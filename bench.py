@@ -375,10 +375,11 @@ def main():
             res = slab_extra(dev, dist, rank, world)
         except Exception as e:
             res = {"error": repr(e)[:300]}
-        if dist is not None and "error" not in res and not int(os.environ.get("PERCNN_NO_PEER", "0")):
+        if "error" not in res and not int(os.environ.get("PERCNN_NO_PEER", "0")):
             # second transport, same problem: peer mailboxes (xGMI load/store + epoch flags) instead of RCCL calls
+            # (one rank: put / take through the rank's own mailbox)
             try:
-                res["peer_mailbox"] = slab_extra(dev, dist, rank, world, transport="peer")
+                res["peer_mailbox"] = slab_extra(dev, dist, rank, world, transport="peer", force_p2p=True)
             except Exception as e:
                 res["peer_mailbox"] = {"error": repr(e)[:300]}
         try:
@@ -456,7 +457,7 @@ def main():
                 flush_c_stdio()                              # RCCL's version banner sits in the C stdio buffer
                 print(json.dumps(out), flush=True)           # -> the JSON line is the last line on stdout
 
-    if world > 1 or a.slab_extra:
+    if world > 1 or a.slab_extra or not a.no_extras:
         def watchdog():
             if not printed.wait(a.slab_timeout + 60.0):
                 out["slab_3d"] = {"error": f"timed out after {a.slab_timeout + 60.0}s"}
@@ -465,10 +466,8 @@ def main():
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             torch.cuda.empty_cache()
-            if dist is not None:                     # own process per rank: a fault in there cannot cost the line above
-                out["slab_3d"] = slab_extra_isolated(a, dev, dist, rank, world, local_rank)
-            else:
-                out["slab_3d"] = slab_extra(dev, dist, rank, world)
+            # own process per rank: a fault in there cannot cost the line above
+            out["slab_3d"] = slab_extra_isolated(a, dev, dist, rank, world, local_rank)
         except Exception as e:                       # keep the headline number whatever happens here
             out["slab_3d"] = {"error": repr(e)[:300]}
     if dist is not None:
@@ -671,15 +670,20 @@ def slab_extra_isolated(a, dev, dist, rank, world, local_rank):
     function addresses to the native loop, and a crash or stall in there must not take the headline line with it."""
     import socket
     import subprocess
-    port = torch.zeros(1, dtype=torch.int64, device=dev)
-    if rank == 0:
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port[0] = so.getsockname()[1]
-    if world > 1:
-        dist.broadcast(port, 0)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(port.item())), RANK=str(rank),
-               WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank))
+    if dist is None:                                 # plain `python bench.py`: one rank, no process group in the child either
+        env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
+        for k in ("MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+    else:
+        port = torch.zeros(1, dtype=torch.int64, device=dev)
+        if rank == 0:
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port[0] = so.getsockname()[1]
+        if world > 1:
+            dist.broadcast(port, 0)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(port.item())), RANK=str(rank),
+                   WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank))
     for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RESTART_COUNT",
               "TORCHELASTIC_MAX_RESTARTS", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME"):
         env.pop(k, None)                             # plain env:// rendezvous on the new port
@@ -697,7 +701,7 @@ def slab_extra_isolated(a, dev, dist, rank, world, local_rank):
     return json.loads(lines[-1])
 
 
-def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=5, transport=None):
+def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=5, transport=None, force_p2p=None):
     """3D Gray-Scott, Hc=2, fp32: global grid (32*world) x 256 x 256 sharded into slabs along axis 0.  The forward state
     of every rank is checked bit for bit against the single-domain rollout of the whole grid (computed on every rank)."""
     import percnn_amd as pa
@@ -706,7 +710,9 @@ def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=5, 
     cell = make_cell("gs3d", sd, dev)
     with torch.no_grad():
         P = cell.param_block().contiguous()
-    ex = slab.make_exchanger(force_p2p=bool(int(os.environ.get("PERCNN_FORCE_P2P", "0"))), transport=transport)
+    if force_p2p is None:
+        force_p2p = bool(int(os.environ.get("PERCNN_FORCE_P2P", "0")))
+    ex = slab.make_exchanger(force_p2p=force_p2p, transport=transport)
     full_shape = (planes * world, hw, hw)
     blocks = [synthetic.gs_initial_state((planes, hw, hw), seed=r)[0] for r in range(world)]
     local = torch.zeros((2, planes + 2 * halo, hw, hw), device=dev)
@@ -759,6 +765,11 @@ def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=5, 
                        f"exchanges 2 planes per step; native C loop (one call per rollout), overlap={int(overlap)}; "
                        f"exchanger={type(ex).__name__}",
            "steps_per_sec_fwd_bwd": reps * T / el, "ms_per_time_step_fwd_bwd": el / (reps * T) * 1e3,
+           "exchange": ("periodic wrap by device copies (one rank, no transport involved)" if world == 1 and not force_p2p
+                        else {"PeerHaloExchanger": "peer mailboxes: put / take kernels + epoch flags (csrc/pi_peer.h)",
+                              "RcclHaloExchanger": "ncclSend / ncclRecv groups issued by the native loop",
+                              "HaloExchanger": "torch.distributed point-to-point"}[type(ex).__name__]
+                        + (" -- to the rank itself" if world == 1 else "")),
            "forward_state_equals_single_domain_rollout": bool(ok.item()),
            "points_per_rank": planes * hw * hw, "global_points": planes * world * hw * hw,
            "halo_bytes_per_exchange_per_direction": 2 * halo * hw * hw * 4}
