@@ -50,6 +50,8 @@ struct Options {
     int l2_tile_kb = 128;   // direct 3D kernels: y-tile of a plane (both species, KiB) whose five stencil planes stay in the L2
                             // (0 = whole planes, the pre-round-2 order): see set_blockmap
     int l2_tile_min_kb = 1536;  // ... applied once four neighbour planes x two species exceed this many KiB (0: always; tests)
+    int lane_x = 0;         // direct kernels: log2 of the lanes along x per row segment (2..6), 0 = fewest idle lanes (set_blockmap),
+                            // -1 = the pre-round-2 rule (next power of two >= chunks per row)
     int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
                             // small grid is spread over all CUs instead of being packed onto a few
 };
@@ -152,19 +154,42 @@ void set_fastdiv(Geom& g, int vec)
 // = the power of two that wastes the fewest lanes on this row length; false if the grid is outside what 32-bit byte
 // offsets / 31-bit block ids address (2D: the whole local field + 4 rows, 3D: one plane, must stay below 4 GiB)
 bool set_blockmap(Geom& g, int ndim, int vec, int block, size_t elem, int l2_tile_bytes = 128 * 1024, int rz = 1,
-                  long l2_tile_min_bytes = 3L << 19)
+                  long l2_tile_min_bytes = 3L << 19, int lane_x = 0)
 {
     const long cpr = g.W / vec;
-    int lxs;
-    if (cpr <= 64) {
-        lxs = 2;
-        while ((1L << lxs) < cpr) ++lxs;
+    // lanes along x: 2^lxs consecutive chunks of a row per wave row-segment.  A row of cpr chunks is covered by
+    // ceil(cpr / 2^lxs) segments, so a width that is not a power of two leaves lanes idle (cpr = 48 on 64 lanes: 25 %; the
+    // reference's 48^3: 12 chunks on 16 lanes).  Pick the power of two with the most useful lanes, weighted by what a
+    // narrower contiguous segment costs (fitted to 96^3 .. 224^3 on MI355X, profiles/r02_lanes_along_x.txt: 128-byte
+    // segments run at ~0.8 of 1 KiB ones, 256 / 512-byte ones at ~0.95): 160^3 13.8 k -> 17.0 k, 192^3 8.4 k -> 10.6 k steps/s.
+    static const double seg_weight[5] = {0.70, 0.82, 0.95, 0.95, 1.0};     // 2^lxs = 4, 8, 16, 32, 64 chunks of 16 bytes
+    int lxs = 2;
+    if (lane_x >= 2 && lane_x <= 6) {
+        lxs = lane_x;                                     // tuning aid / A-B tests
+    } else if (lane_x == -1) {                            // the pre-round-2 rule
+        if (cpr <= 64) { while ((1L << lxs) < cpr) ++lxs; }
+        else {
+            lxs = 6;
+            double best = 0.0;
+            for (int c = 6; c >= 4; --c) {
+                const long lx = 1L << c;
+                const double eff = (double)cpr / (double)(((cpr + lx - 1) / lx) * lx);
+                if (eff > best + 1e-9) { best = eff; lxs = c; }
+            }
+        }
     } else {
-        lxs = 6;
+        const long rows = ndim == 3 ? g.n1 : g.n0;
         double best = 0.0;
-        for (int c = 6; c >= 4; --c) {
-            const long lx = 1L << c;
-            const double eff = (double)cpr / (double)(((cpr + lx - 1) / lx) * lx);
+        for (int c = 6; c >= 2; --c) {
+            const long lx = 1L << c, rb = block >> c;     // rb rows of lx chunks per workgroup
+            if (lx > block) continue;
+            double eff = (double)cpr / (double)(((cpr + lx - 1) / lx) * lx) *
+                         (double)rows / (double)(((rows + rb - 1) / rb) * rb);
+            eff *= seg_weight[c - 2];
+            // a row pitch that is not a multiple of 128 bytes leaves the segments straddling cache lines: S bytes touch
+            // (S + 128) / 128 lines on average instead of S / 128 (200^3 with 128-byte segments: forward 39 -> 66 us)
+            const long seg = lx * 16;
+            if (((long)g.W * (long)elem) % 128 != 0) eff *= (double)seg / (double)(seg + 128);
             if (eff > best + 1e-9) { best = eff; lxs = c; }
         }
     }
@@ -274,7 +299,7 @@ hipError_t launch_fwd(const T* h, T* out, const T* P, const Problem& p, hipStrea
     Geom g = make_geom(p);
     const int block = direct_block(p, g, VEC);
     if (g.rows <= 0) return hipSuccess;
-    if (!set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024)) return hipErrorInvalidValue;
+    if (!set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024, p.opt.lane_x)) return hipErrorInvalidValue;
     const unsigned grid = (p.opt.fwd_blocks > 0 && g.nblk > (unsigned)p.opt.fwd_blocks) ? (unsigned)p.opt.fwd_blocks : g.nblk;
     g.xwin = (unsigned)p.opt.xcd_window;
     auto* k = pi::pi_fwd_kernel<T, NDIM, HC, VEC, RZ>;
@@ -286,7 +311,7 @@ hipError_t launch_fwd(const T* h, T* out, const T* P, const Problem& p, hipStrea
 unsigned bwd_grid(const Problem& p, int vec, size_t elem, int rz)
 {
     Geom g = make_geom(p);
-    if (g.rows <= 0 || !set_blockmap(g, p.ndim, vec, direct_block(p, g, vec), elem, p.opt.l2_tile_kb * 1024, rz, (long)p.opt.l2_tile_min_kb * 1024)) return 0;
+    if (g.rows <= 0 || !set_blockmap(g, p.ndim, vec, direct_block(p, g, vec), elem, p.opt.l2_tile_kb * 1024, rz, (long)p.opt.l2_tile_min_kb * 1024, p.opt.lane_x)) return 0;
     long need = g.nblk;
     const int cpl = rz > 1 ? (p.opt.bwd_cpl + rz - 1) / rz : p.opt.bwd_cpl;     // a pass already covers rz chunks per lane
     if (cpl > 1 && need >= 512L * cpl) need = (need + cpl - 1) / cpl;            // chunks per lane
@@ -301,7 +326,7 @@ hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* parti
     const int block = direct_block(p, g, VEC);
     const unsigned grid = bwd_grid(p, VEC, sizeof(T), RZ);
     if (g.rows <= 0) return hipSuccess;
-    if (!grid || !set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024)) return hipErrorInvalidValue;
+    if (!grid || !set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024, p.opt.lane_x)) return hipErrorInvalidValue;
     const size_t lds = align_up((size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T), 16) +
                        (size_t)(block / pi::WAVE) * 2 * sizeof(double) +
                        ((WGRAD && HC == pi::POLY) ? (size_t)20 * (block + 8) * sizeof(T) : 0) +   // moment transpose scratch
@@ -1254,6 +1279,11 @@ int apply_option(Options& o, const char* key, long value)
         return 0;
     }
     if (!std::strcmp(key, "block_small")) { o.block_small = value != 0; return 0; }
+    if (!std::strcmp(key, "lane_x")) {
+        if (value != 0 && value != -1 && (value < 2 || value > 6)) return PERCNN_PI_EINVAL;
+        o.lane_x = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "rz")) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return PERCNN_PI_EINVAL;
         o.rz = (int)value;
