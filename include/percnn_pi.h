@@ -116,9 +116,10 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *   "rz"           direct 3D kernels, pre-contracted blocks: consecutive planes per workgroup pass that share their plane
  *                  neighbours in registers (1, 2, 4; default 0 = by grid size: large grids 4 forward / 2 backward)
  *   "block_small"  1 (default): 128-thread workgroups for the direct kernels on grids below ~1 M points
- *   "lane_x"       direct kernels: log2 of the 16-byte chunks a wave takes from one row (2..6); default 0 = the width with
- *                  the most useful lanes, weighted by segment length and row-pitch alignment (rows that are not a power of
- *                  two wide: 160^3 +26 %, 192^3 +27 %); -1 = the earlier rule (next power of two >= chunks per row)
+ *   "lane_x"       direct kernels: log2 of the 16-byte chunks a wave takes from one row (2..6), or 7 = flat (a workgroup
+ *                  takes consecutive chunks of the plane across row ends); default 0 = the decomposition with the most
+ *                  useful lanes, weighted by segment length and row-pitch alignment (grids that are not a power of two
+ *                  wide: 48^3 +14 %, 144^3 .. 200^3 +20-30 %); -1 = the earlier rule (next power of two >= chunks per row)
  *   "fwd_blocks", "xcd_window"   forward direct kernel: bounded persistent grid / windowed XCD remap (measured: no gain; off)
  *   "l2_tile_kb"   direct 3D kernels: the rows of a plane are processed in y-tiles of this many KiB (both species; default
  *                  128, 0 = whole planes) and the workgroups march along axis 0 tile by tile, so the five planes a tile's

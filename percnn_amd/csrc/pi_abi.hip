@@ -164,6 +164,7 @@ bool set_blockmap(Geom& g, int ndim, int vec, int block, size_t elem, int l2_til
     // segments run at ~0.8 of 1 KiB ones, 256 / 512-byte ones at ~0.95): 160^3 13.8 k -> 17.0 k, 192^3 8.4 k -> 10.6 k steps/s.
     static const double seg_weight[5] = {0.70, 0.82, 0.95, 0.95, 1.0};     // 2^lxs = 4, 8, 16, 32, 64 chunks of 16 bytes
     int lxs = 2;
+    double best_pow2 = 1.0;                               // score of the chosen power of two (forced / old rule: never flat)
     if (lane_x >= 2 && lane_x <= 6) {
         lxs = lane_x;                                     // tuning aid / A-B tests
     } else if (lane_x == -1) {                            // the pre-round-2 rule
@@ -192,13 +193,30 @@ bool set_blockmap(Geom& g, int ndim, int vec, int block, size_t elem, int l2_til
             if (((long)g.W * (long)elem) % 128 != 0) eff *= (double)seg / (double)(seg + 128);
             if (eff > best + 1e-9) { best = eff; lxs = c; }
         }
+        best_pow2 = best;
     }
     while ((1 << lxs) > block) --lxs;
-    const long lx = 1L << lxs, rpb = block >> lxs;
     const long nrow = ndim == 3 ? g.n1 : g.n0;
-    g.lxs = lxs;
-    g.nxb = (int)((cpr + lx - 1) / lx);
-    g.nrg = (int)((nrow + rpb - 1) / rpb);
+    // ... or none of them: consecutive chunks of the plane across row ends (`flat`; one multiply-shift per lane, rows follow
+    // each other in memory so a wave still moves 1 KiB pieces) -- taken where the best power of two leaves > ~10 % idle
+    bool flat = lane_x == 7;
+    if (lane_x == 0 && nrow * cpr < (1L << 31)) {
+        const long total = nrow * cpr, nb = (total + block - 1) / block;
+        double eff = 0.97 * (double)total / (double)(nb * block);
+        if (((long)g.W * (long)elem) % 128 != 0) eff *= 1024.0 / (1024.0 + 128.0);
+        // (not with four planes per pass: 208^3 forward 41 -> 51 us, 240^3 65 -> 69 us when forced, while the two-plane
+        // adjoint of the same grids gains 7 %)
+        // and only below 8 M points, where the kernels are latency-bound and idle lanes are what costs: beyond that the
+        // outcome follows the DRAM access pattern instead (same-box A/B: 288^3 +10 %, 224^3 -3 %, 352^3 -5 %)
+        const long npts = (long)g.n0 * g.n1 * g.W;
+        flat = eff > best_pow2 + 0.08 && rz <= 2 && npts < (8L << 20);
+    }
+    if (flat && nrow * cpr >= (1L << 31)) return false;
+    const long lx = flat ? block : 1L << lxs, rpb = flat ? 1 : block >> lxs;
+    g.lxs = flat ? -1 : lxs;
+    g.nxb = flat ? 1 : (int)((cpr + lx - 1) / lx);
+    g.nrg = flat ? (int)((nrow * cpr + block - 1) / block) : (int)((nrow + rpb - 1) / rpb);
+    if (flat) g.dcpr = make_fastdiv((unsigned)cpr);
     g.rz = ndim == 3 ? rz : 1;
     const long ngroups = ndim == 3 ? (g.n0 + g.rz - 1) / g.rz : 1;          // plane groups of rz planes
     const long nblk = (long)g.nxb * g.nrg * ngroups;
@@ -214,7 +232,7 @@ bool set_blockmap(Geom& g, int ndim, int vec, int block, size_t elem, int l2_til
     // MI355X: 384^3 backward 726 -> 513 us, 256^3 171 -> 148 us per step, 192^3 -- 1.2 MB of neighbour planes -- loses 3-8 %)
     if (ndim == 3 && l2_tile_bytes > 0 && 8L * g.n1 * g.W * (long)elem > l2_tile_min_bytes) {
         const long tile_rows = (long)l2_tile_bytes / (2 * (long)g.W * (long)elem);
-        long rgt = tile_rows / rpb;
+        long rgt = flat ? (long)l2_tile_bytes / (2 * (long)block * vec * (long)elem) : tile_rows / rpb;
         if (rgt < 1) rgt = 1;
         if (rgt < g.nrg && (long)rgt * ngroups < (1L << 31)) {
             const long ntile = (g.nrg + rgt - 1) / rgt;
@@ -1280,7 +1298,7 @@ int apply_option(Options& o, const char* key, long value)
     }
     if (!std::strcmp(key, "block_small")) { o.block_small = value != 0; return 0; }
     if (!std::strcmp(key, "lane_x")) {
-        if (value != 0 && value != -1 && (value < 2 || value > 6)) return PERCNN_PI_EINVAL;
+        if (value != 0 && value != -1 && (value < 2 || value > 7)) return PERCNN_PI_EINVAL;     // 7 = flat
         o.lane_x = (int)value;
         return 0;
     }

@@ -118,10 +118,13 @@ struct FastDiv {
 
 // XCD-aware block remap: hand each XCD (private 4 MiB L2) a contiguous range of the grid so the
 // axis-0 neighbours of a block's rows are served by the same L2.  Pure speed; any mapping is correct.
+// Any block count: XCD x (the blocks with bid % 8 == x) gets the contiguous range starting at x*q + min(x, r), q = n / 8,
+// r = n % 8 -- the first r XCDs hold one block more.  (Was: identity unless n % 8 == 0, which cost a 1800^2 grid with a
+// block count of 3165 a quarter of its speed against 3600 blocks.)
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks)
 {
-    if (nblocks % NXCD) return bid;
-    return (bid % NXCD) * (nblocks / NXCD) + bid / NXCD;
+    const unsigned q = nblocks / NXCD, r = nblocks % NXCD, x = bid % NXCD;
+    return x * q + min(x, r) + bid / NXCD;
 }
 
 // ---- wave-level sum (all 64 lanes) -----------------------------------------------------------

@@ -24,7 +24,7 @@ struct Geom {
     // block-uniform decomposition of the direct step kernels (pi_fwd_kernel / pi_bwd_kernel): a workgroup covers
     // (blockDim >> lxs) rows x (1 << lxs) 16-byte chunks of ONE plane, so plane / row-group / x-block come from
     // blockIdx by scalar arithmetic and a lane only adds its (row, chunk) inside the block
-    int lxs;            // log2 of the lanes along x
+    int lxs;            // log2 of the lanes along x; -1: flat (consecutive chunks of the plane, row = chunk / chunks per row)
     int nxb, nrg;       // x-blocks per row; row groups per plane (3D) or per grid (2D)
     unsigned nblk;      // virtual blocks = nxb * nrg * (3D: n0)
     FastDiv dnxb, dnrg;
@@ -179,16 +179,30 @@ __device__ __forceinline__ Lane locate(const Geom& g, unsigned vb)
             rg = yt * (unsigned)g.rgt + (r - pl * (unsigned)(last ? g.nlast : g.rgt));
         }
     }
-    const int lx = 1 << g.lxs;
-    const int xi = (int)threadIdx.x & (lx - 1), ri = (int)threadIdx.x >> g.lxs;
     const int cpr = g.W / VEC;
     const int nrow = NDIM == 3 ? g.n1 : g.n0;
-    int chunk = (int)xb * lx + xi;
-    int row = (int)rg * ((int)blockDim.x >> g.lxs) + ri;
+    int chunk, row;
     Lane L;
-    L.valid = chunk < cpr && row < nrow;
-    chunk = min(chunk, cpr - 1);
-    row = min(row, nrow - 1);
+    if (g.lxs < 0) {
+        // flat decomposition (widths that no power of two of lanes covers well): the workgroup takes blockDim consecutive
+        // chunks of the plane, rows follow each other in memory, so a wave still reads 1 KiB contiguous pieces; the lane
+        // finds its row with one multiply-shift
+        const unsigned total = (unsigned)nrow * (unsigned)cpr;
+        unsigned idx = rg * blockDim.x + threadIdx.x;
+        L.valid = idx < total;
+        idx = min(idx, total - 1u);
+        const unsigned r = g.dcpr.div(idx);
+        row = (int)r;
+        chunk = (int)(idx - r * (unsigned)cpr);
+    } else {
+        const int lx = 1 << g.lxs;
+        const int xi = (int)threadIdx.x & (lx - 1), ri = (int)threadIdx.x >> g.lxs;
+        chunk = (int)xb * lx + xi;
+        row = (int)rg * ((int)blockDim.x >> g.lxs) + ri;
+        L.valid = chunk < cpr && row < nrow;
+        chunk = min(chunk, cpr - 1);
+        row = min(row, nrow - 1);
+    }
     L.i0 = NDIM == 3 ? (int)pl * g.rz : 0;          // first plane of the group
     L.row = row;
     L.x0 = chunk * VEC;
