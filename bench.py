@@ -32,6 +32,7 @@ WORKLOADS = {
     "gs2d_512": ("gs2d", (512, 512), 8, torch.float32, 1000, "gs2d_big_512x512.npz"),
     "gs2d_100": ("gs2d", (100, 100), 8, torch.float32, 200, "gs2d_big_512x512.npz"),   # BASELINE configs[0]: the reference's own grid / horizon
     "gs3d_128": ("gs3d", (128, 128, 128), 2, torch.float32, 500, "gs3d_big_128x128x128.npz"),
+    "gs3d_48": ("gs3d", (48, 48, 48), 2, torch.float32, 300, "gs3d_big_128x128x128.npz"),   # the reference's own 3D grid / horizon (3dgs:497-536)
     "lo2d_512": ("lo2d", (512, 512), 4, torch.float64, 400, "lo2d_big_512x512.npz"),
 }
 # Stage-1 Pi-block (5x5 conv branches 2 -> 16 on the matrix cores): name -> (family, shape, T, golden)

@@ -8,7 +8,7 @@ O=$R/gpurun_out
 cd /tmp
 # the driver's command first: default bench line (headline + also + cpu baselines + module path)
 (timeout 900 python $R/bench.py 2>&1 | tail -1) > $O/${ROUND}_final_bench_default.json
-for wl in gs3d_128 lo2d_512 gs2d_100 bur1_100 lo1_100; do
+for wl in gs3d_128 lo2d_512 gs2d_100 gs3d_48 bur1_100 lo1_100; do
   (timeout 900 python $R/bench.py --workload $wl --no-also 2>&1 | tail -1) > $O/${ROUND}_final_bench_$wl.json
 done
 for wl in gs2d_512 gs3d_128 lo2d_512 gs2d_100; do
