@@ -306,8 +306,22 @@ int direct_rz(const Problem& p, int vec, bool adjoint)
 {
     if (p.ndim != 3 || p.hc != 0 || vec != pi::vec_width<T>::value) return 1;
     if (p.opt.rz) return p.opt.rz;
-    const int64_t pts = (int64_t)make_geom(p).rows * p.W;
-    if (adjoint) return pts >= ((int64_t)8 << 20) ? 2 : 1;
+    Geom g = make_geom(p);
+    const int64_t pts = (int64_t)g.rows * p.W;
+    if (adjoint) {
+        // Two planes per pass save two of eleven neighbour loads per output but halve the workgroups.  Measured on MI355X
+        // (profiles/r02_adjoint_rz.txt): they win from ~0.4 M points on (80^3 .. 112^3 -7 %, 144^3 -12 %, 160^3 / 192^3
+        // -5 %) -- except where one plane per pass is exactly one full resident round of the chip (2048 threads per CU:
+        // 120..128 x 128^2, 32 x 256^2: +8 % with two planes); one block more than that round and a plane per pass needs a
+        // second round (130 x 126 x 128: 25.8 vs 23.3 us).
+        if (pts >= ((int64_t)8 << 20)) return 2;
+        if (pts < ((int64_t)3 << 17)) return 1;
+        const int block = direct_block(p, g, vec);
+        if (!set_blockmap(g, p.ndim, vec, block, sizeof(T), p.opt.l2_tile_kb * 1024, 1, (long)p.opt.l2_tile_min_kb * 1024,
+                          p.opt.lane_x)) return 1;
+        const int64_t threads = (int64_t)g.nblk * block, round = (int64_t)256 * 2048;
+        return (threads <= round && threads > round - round / 8) ? 1 : 2;
+    }
     return pts >= ((int64_t)8 << 20) ? 4 : (pts >= ((int64_t)3 << 19) ? 2 : 1);
 }
 
