@@ -773,6 +773,44 @@ def test_direct_kernel_variants_bitwise(opts, shape, dtype, hip_device):
     assert np.array_equal(gi.cpu().numpy(), o_step_bwd(h0, gt[1], None, P)[0])
 
 
+@pytest.mark.parametrize("lane_x", [-1, 0, 2, 3, 5, 6, 7])
+@pytest.mark.parametrize("shape,dtype,hc", [((40, 100), np.float32, 0), ((33, 72), np.float32, 8), ((64, 96), np.float64, 0),
+                                            ((9, 12), np.float64, 4), ((50, 36), np.float32, 0)])
+def test_direct_2d_lane_modes_bitwise(lane_x, shape, dtype, hc, hip_device):
+    """2D grids on the direct kernels (tile = 0) under every lane decomposition -- power-of-two row segments of all widths,
+    the flat decomposition (lane_x = 7: consecutive chunks across row ends, rows = axis 0 here), the fitted default and the
+    earlier rule: state, adjoint state bit-identical to the C oracle; also as a slab (axis 0 not wrapped)."""
+    import percnn_amd as pa
+    from percnn_amd import slab
+    T = 5
+    rs = np.random.RandomState(31)
+    P = random_block(hc, 2, dtype, 37, scale=0.3)
+    h0 = rs.uniform(0, 1, (2,) + shape).astype(dtype)
+    gt = rs.uniform(-1, 1, (T + 1, 2) + shape).astype(dtype)
+    ref = o_rollout_fwd(h0, P, T)
+    g0_ref, pg_ref = o_rollout_bwd(ref, gt, P)
+    o = f"tile=0,lane_x={lane_x}"
+    Pd = dev_t(P, hip_device)
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.from_numpy(h0).dtype, device=hip_device)
+    traj[0] = dev_t(h0, hip_device)
+    pa.rollout_fwd_(traj, Pd, options=o)
+    assert np.array_equal(traj.cpu().numpy(), ref)
+    g0, pg = pa.rollout_bwd(traj, dev_t(gt, hip_device), Pd, options=o)
+    assert np.array_equal(g0.cpu().numpy(), g0_ref)
+    assert rel_l2(pg.cpu().numpy(), pg_ref) < (2e-5 if dtype == np.float32 else 1e-12)
+    # slab layout through the process-wide default (the slab entry points take no option string)
+    pa.set_option("lane_x", lane_x)
+    try:
+        halo = 2
+        local = slab.scatter_slab(dev_t(h0, hip_device), 0, 1, halo)
+        ltraj = torch.zeros((T + 1,) + tuple(local.shape), dtype=local.dtype, device=hip_device)
+        ltraj[0] = local
+        slab.slab_rollout_fwd_(ltraj, Pd, slab.HaloExchanger(), halo)
+        assert np.array_equal(ltraj[:, :, halo:-halo].cpu().numpy(), ref)
+    finally:
+        pa.set_option("lane_x", 0)
+
+
 @pytest.mark.parametrize("rz", [1, 2, 4])
 @pytest.mark.parametrize("shape,halo", [((12, 8, 64), 4), ((7, 12, 40), 2)])
 def test_slab_layout_with_plane_blocking(rz, shape, halo, hip_device):
