@@ -291,7 +291,7 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
     return res, live
 
 
-FUSED_TILE_DTYPES = (torch.float32,)   # dtypes whose 2D tile sweep runs the fused-moments flavour by default (float64: measured slower, opt-in)
+FUSED_TILE_DTYPES = (torch.float32, torch.float64)   # dtypes whose 2D tile sweep runs the fused-moments flavour by default
 
 
 def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):

@@ -110,9 +110,9 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *   "fuse_wgrad"   parameter gradients reduced inside the sweep launches instead of one time-parallel pass:
  *                  0 never, 1 wherever a fused flavour exists, 2 (default) float32 pre-contracted blocks on the direct
  *                  / plane-streaming kernels
- *   "tile_fuse"    1 (default): the float32 pre-contracted tile sweep with 32x32 tiles reduces the 20 coefficient
- *                  moments itself and stores only every K-th adjoint frame (no separate moments pass); 0: split schedule;
- *                  2: float64 blocks too (register-bound there: measured slower than the split schedule)
+ *   "tile_fuse"    1 (default): the pre-contracted tile sweep with 32x32 tiles reduces the 20 coefficient moments itself
+ *                  and stores only every K-th adjoint frame (no separate moments pass; float32: register accumulators,
+ *                  float64: per-lane accumulators in LDS updated with ds_add_f64); 0: split schedule
  *   "rz"           direct 3D kernels, pre-contracted blocks: consecutive planes per workgroup pass that share their plane
  *                  neighbours in registers (1, 2, 4; default 0 = by grid size: large grids 4 forward / 2 backward)
  *   "block_small"  1 (default): 128-thread workgroups for the direct kernels on grids below ~1 M points

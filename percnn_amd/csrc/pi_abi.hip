@@ -662,11 +662,13 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
     const pi::TileGeom g = make_tile_geom(p, BY);
     const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
     size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + 32 /* lds_pad0/1 */;
-    if (MOM) {                                  // the tail reduction's scratch (pi_tile2d.h): doubles, then [20][NT + 16] values
+    if (MOM && sizeof(T) == 4) {                // the tail reduction's scratch (pi_tile2d.h): doubles, then [20][NT + 16] values
         const size_t tail = (size_t)(2 * (NT / pi::WAVE) + 20 + 20 * (NT / pi::WAVE)) * sizeof(double) +
                             (size_t)20 * (NT + 16) * sizeof(T);
         if (tail > lds) lds = tail;
     }
+    if (MOM && sizeof(T) == 8)                  // float64: [20][NT] per-lane moment accumulators behind the state buffers
+        lds = pi::tile_state_bytes<T, K, TILE_B, BY>() + (size_t)20 * NT * sizeof(double);
     lds += (size_t)p.opt.lds_pad;
     auto* k = pi::pi_adj2d_tile_kernel<T, HC, K, TILE_B, BY, NT, MOM>;
     if (hipError_t e = allow_lds(k, lds)) return e;
@@ -712,10 +714,11 @@ bool tile_fuse_ok(const Problem& p)
     // measured on MI355X (backward us per step, split -> fused): 384^2 3.37 -> 3.20, 512^2 3.90 -> 3.29, 1000^2 13.4 -> 11.3;
     // in the 16-row-tile regime (<= 128 tiles of 32x32, e.g. the reference's 100^2) the extra VALU work sits on the one
     // critical workgroup chain and loses (2.26 -> 2.66), so it keeps the split schedule
-    // float64 (lambda-omega): the flavour exists (scalar accumulators, moments after the stores, no operand pipeline) but
-    // still needs more than the 256 registers of a 512-thread workgroup -- 57 spilled doubles -- and LOSES: 512^2 backward
-    // 5.98 -> 9.13 us per step on MI355X (profiles/r02_fp64_fused_tile_sweep.txt); opt-in only (tile_fuse = 2)
-    return p.opt.tile_fuse && (sizeof(T) == 4 || p.opt.tile_fuse == 2) && !p.opt.skip_wgrad && p.hc == 0 &&
+    // float64 (lambda-omega): the per-lane moment sums live in LDS and are updated with ds_add_f64 (pi_tile2d.h) -- a register
+    // flavour needed more than the 256 registers of a 512-thread workgroup (57 spilled doubles, 5.98 -> 9.13 us per step,
+    // profiles/r02_fp64_fused_tile_sweep.txt); with LDS accumulators: 186 VGPRs, no scratch, lambda-omega 512^2 backward
+    // 5.45 -> 4.48 us per step, 1024^2 19.1 -> 15.9 (profiles/r02_fp64_fused_lds_accumulators.txt)
+    return p.opt.tile_fuse && !p.opt.skip_wgrad && p.hc == 0 &&
            p.opt.tile_k == 4 && p.opt.tile_nt == 512 && tile_by_for(p) == TILE_B;
 }
 

@@ -51,6 +51,19 @@ struct Tile {
     static constexpr int region_n(int m) { return region_w(m) * region_h(m); }
 };
 
+// bytes of the two ping-pong state buffers (both species) incl. their alignment pads, rounded up to 16
+template <typename T, int K, int BX, int BY>
+__host__ __device__ constexpr size_t tile_state_bytes()
+{
+    return ((size_t)4 * Tile<K, BX, BY>::PLANE * sizeof(T) + 32 + 15) / 16 * 16;
+}
+
+// LDS add without a return value (`ds_add_f64`): the caller is the only lane that touches the address
+__device__ __forceinline__ void lds_add_f64(double* p, double v)
+{
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 struct TileGeom {
     int H, W;          // grid
     long ss;           // species stride = H*W
@@ -487,7 +500,8 @@ __device__ __forceinline__ double mom_total(double a) { return a; }
 template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE, bool MOM>
 __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict__ hfr, const T* __restrict__ gfr,
                                             const TileGeom& g, int ty0, int tx0, const T* __restrict__ P,
-                                            double (&acc_c)[2], const StripOps<T>& pre, TileMoments<T, MOM>& mom)
+                                            double (&acc_c)[2], const StripOps<T>& pre, TileMoments<T, MOM>& mom,
+                                            double* lacc = nullptr)
 {
     using TL = Tile<K, BX, BY>;
     constexpr int RW4 = TL::region_w(M) / 4, RN4 = TL::region_n(M) / 4, O = 2 * (M + 1);
@@ -605,21 +619,27 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
             stv2(nxt + TL::PLANE + off + 2 * h, ov);
         }
         if constexpr (MOM && sizeof(T) == 8) {
-            // float64: the moments come LAST, half a strip at a time -- the stencil / Jacobian temporaries are dead by
-            // now, so the 20 accumulators (40 registers) fit the 256-register budget of the 512-thread workgroup
+            // float64: 20 more accumulators (40 registers) do not fit next to the operand pipeline in the 256 registers of a
+            // 512-thread workgroup (the register flavour spilled 57 doubles: 5.98 -> 9.13 us per step).  Each lane keeps its
+            // 20 sums in LDS instead -- slot [moment][thread], touched by that lane only -- and adds to them with
+            // `ds_add_f64` (no return value, nothing to wait for): the LDS pipe does the accumulation, the VALU only the
+            // products, and the layout is already the transposed one the tail reduction reads.  Moments LAST, half a strip
+            // at a time: the stencil / Jacobian temporaries are dead by now.
+            double* slot = lacc + (int)threadIdx.x;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const V2<T> uu = U[h], vv = V[h];
                 const V2<T> u2 = uu * uu, uv = uu * vv, v2 = vv * vv;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    auto& a = mom.a[s];
                     const V2<T> gm = (gc[s][h] * dtv) * own[h];
-                    mom_add1(a[0], gm);
-                    mom_add(a[1], gm, uu); mom_add(a[2], gm, vv);
-                    mom_add(a[3], gm, u2); mom_add(a[4], gm, uv); mom_add(a[5], gm, v2);
-                    mom_add(a[6], gm, u2 * uu); mom_add(a[7], gm, u2 * vv);
-                    mom_add(a[8], gm, uu * v2); mom_add(a[9], gm, v2 * vv);
+                    double* a = slot + 10 * s * NT;
+                    auto add = [&](int m, V2<T> phi) { lds_add_f64(a + m * NT, fma_(gm.x, phi.x, gm.y * phi.y)); };
+                    lds_add_f64(a, gm.x + gm.y);
+                    add(1, uu); add(2, vv);
+                    add(3, u2); add(4, uv); add(5, v2);
+                    add(6, u2 * uu); add(7, u2 * vv);
+                    add(8, uu * v2); add(9, v2 * vv);
                 }
             }
         }
@@ -633,7 +653,8 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
                                              T* __restrict__ abase, long frame_stride, unsigned inj_mask,
                                              T* __restrict__ g_h0, int steps_to_zero, const TileGeom& g, int ty0,
                                              int tx0, const T* __restrict__ P, double (&acc_c)[2],
-                                             const StripOps<T>& ops, TileMoments<T, MOM>& mom, const StripAddr (&sa)[K])
+                                             const StripOps<T>& ops, TileMoments<T, MOM>& mom, const StripAddr (&sa)[K],
+                                             double* lacc = nullptr)
 {
     T* cur = (M & 1) ? b1 : b0;
     T* nxt = (M & 1) ? b0 : b1;
@@ -645,7 +666,7 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
                                               ty0, tx0, &sa[M + 1]);
     }
     adj_substep<T, HC, K, BX, BY, NT, M, PRE, MOM>(cur, nxt, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g,
-                                                   ty0, tx0, P, acc_c, ops, mom);
+                                                   ty0, tx0, P, acc_c, ops, mom, lacc);
 #if PI_PIN_MOMENTS
     // Pin this sub-step's moment accumulation HERE.  Left alone, the scheduler sinks the moment FMAs of all four sub-steps
     // (they depend on no LDS traffic) behind the last barrier -- 350 VALU instructions in the tail of the launch, where all
@@ -670,7 +691,7 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
     PI_STAMP(4 + 3 * M);
     if constexpr (M + 1 < K)
         adj_substeps<T, HC, K, BX, BY, NT, M + 1, PRE, MOM>(b0, b1, hbase, gbase, abase, frame_stride, inj_mask, g_h0,
-                                                            steps_to_zero, g, ty0, tx0, P, acc_c, ahead, mom, sa);
+                                                            steps_to_zero, g, ty0, tx0, P, acc_c, ahead, mom, sa, lacc);
 }
 
 template <typename T, int HC, int K, int BX, int BY, int NT, bool MOM = false>
@@ -684,16 +705,23 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
     // measured slower (17.6 vs 15.5 us per K=4 launch: 64 extra VGPRs, requests queued ahead of the window load).
     // (the float64 fused-moments flavour gives the operand pipeline's 32 registers to its 20 accumulators: with both it
     // needs ~270 of the 256 registers a 512-thread workgroup can have and spills -- 20 -> 47 us per launch, measured)
-    constexpr bool PRE = PI_TILE_ADJ_PIPE && TL::region_n(0) / 4 <= NT && !(MOM && sizeof(T) == 8);
+    constexpr bool PRE = PI_TILE_ADJ_PIPE && TL::region_n(0) / 4 <= NT;
+    constexpr bool MOM_LACC = MOM && sizeof(T) == 8;       // float64: per-lane moment accumulators in LDS (adj_substep)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* b0 = reinterpret_cast<T*>(smem_raw) + lds_pad0<T>::value;
     T* b1 = reinterpret_cast<T*>(smem_raw) + 2 * TL::PLANE + lds_pad1<T>::value;
     const int tile = tile_of_block(blockIdx.x, g);
     const int ty0 = (tile / g.tiles_x) * BY, tx0 = (tile % g.tiles_x) * BX;
+    // [20][NT] doubles behind the state buffers (not aliased: they live through all sub-steps)
+    double* lacc = MOM_LACC ? reinterpret_cast<double*>(smem_raw + tile_state_bytes<T, K, BX, BY>()) : nullptr;
     PI_STAMP_PREV();
     PI_STAMP(0);
     WindowLoader<T, K, BX, BY, NT> wl;
     wl.issue(aframe_t, g, ty0, tx0);                       // adjoint window first, then the operands of sub-step 0
+    if constexpr (MOM_LACC) {
+#pragma unroll
+        for (int m = 0; m < 20; ++m) lacc[m * NT + (int)threadIdx.x] = 0.0;
+    }
     // running diffusion-coefficient partial of this tile: requested now, needed at the very end (was a dependent
     // load -> add -> store at the end of every launch: 1 us)
     static_assert(!MOM || HC == POLY, "fused moments: pre-contracted blocks");
@@ -725,7 +753,7 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
             for (int m = 0; m < 10; ++m) mom.a[s][m] = typename MomAcc<T>::type{};
     }
     adj_substeps<T, HC, K, BX, BY, NT, 0, PRE, MOM>(b0, b1, hframe_t, gframe_t, aframe_t, frame_stride, inj_mask, g_h0,
-                                                    steps_to_zero, g, ty0, tx0, P, acc_c, ops0, mom, sa);
+                                                    steps_to_zero, g, ty0, tx0, P, acc_c, ops0, mom, sa, lacc);
     // diffusion-coefficient gradients of this tile over the K sub-steps: one reduction per launch
     // (LDS-only barriers: the last frame's global stores need not drain first)
     lds_barrier();
@@ -771,24 +799,33 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
             a += dpp_mov<0x118, 0xF>(a);
             if (part == 15) red[2 * NW + mm] = (double)a;
         }
-    } else if constexpr (MOM) {
+    } else if constexpr (MOM_LACC) {
+        // the per-lane sums already sit transposed in LDS ([moment][thread], complete: the barrier above waited for the
+        // LDS adds): 16 lanes per moment add NT/16 of them each and fold with four DPP steps
+        if (threadIdx.x < 320) {
+            const int mm = (int)threadIdx.x >> 4, part = (int)threadIdx.x & 15;
+            const double* row = lacc + mm * NT + part;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int m = 0; m < 10; ++m) {
-                const T r = wave_sum_to_last(mom_total(mom.a[s][m]));
-                if (lane == REDUCE_LANE) red[2 * NW + 20 + wave * 20 + 10 * s + m] = (double)r;
+            for (int k = 0; k < NT; k += 64) {
+                const double v0 = row[k], v1 = row[k + 16], v2 = row[k + 32], v3 = row[k + 48];
+                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
             }
+            double a = (a0 + a1) + (a2 + a3);
+            a += dpp_mov<0x111, 0xF>(a);
+            a += dpp_mov<0x112, 0xF>(a);
+            a += dpp_mov<0x114, 0xF>(a);
+            a += dpp_mov<0x118, 0xF>(a);
+            if (part == 15) red[2 * NW + mm] = a;
+        }
     }
     lds_barrier();
     if (has_slot) {
         double sum = 0.0;
         if (threadIdx.x < 2) {
             for (int w = 0; w < NW; ++w) sum += red[w * 2 + threadIdx.x];
-        } else if constexpr (MOM_LDS) {
-            sum = red[2 * NW + threadIdx.x - 2];
         } else if constexpr (MOM) {
-            for (int w = 0; w < NW; ++w) sum += red[2 * NW + 20 + w * 20 + threadIdx.x - 2];
+            sum = red[2 * NW + threadIdx.x - 2];
         }
         *pslot = pold + sum;
     }

@@ -1264,7 +1264,7 @@ def test_contraction_kernel_equals_host_expansion(hc, dtype, hip_device):
 @pytest.mark.parametrize("shape,T", [((512, 512), 6), ((500, 520), 9), ((512, 512), 8)])
 def test_tile_sweep_with_fused_moments(shape, T, dtype, hip_device):
     """tile_fuse: the pre-contracted tile sweep reduces the 20 coefficient moments itself and stores only the hand-over
-    adjoint frames (float32: default; float64: opt-in flavour tile_fuse = 2).  dL/dh0 bit-identical to the split schedule
+    adjoint frames (float32: register accumulators; float64: per-lane LDS accumulators, ds_add_f64).  dL/dh0 bit-identical to the split schedule
     and to the C oracle, parameter gradients to reduction round-off; ragged grid, T not a multiple of K (direct fused
     kernel finishes), and a sparse frame mask.  Options are passed per call."""
     import percnn_amd as pa
@@ -1284,12 +1284,12 @@ def test_tile_sweep_with_fused_moments(shape, T, dtype, hip_device):
         g0_o, pg_o = o_rollout_bwd(traj_o, gm, P)
         gd = dev_t(g if mask is None else np.where(np.array(mask)[:, None, None, None], g, np.nan).astype(dtype), hip_device)
         res = {}
-        for fuse in (0, 2):
+        for fuse in (0, 1):
             g0, pg = pa.rollout_bwd(traj, gd, Pd, frame_mask=mask, options={"tile_fuse": fuse})
             assert np.array_equal(g0.cpu().numpy(), g0_o), (fuse, mask is not None)
             assert rel_l2(pg.cpu().numpy(), pg_o) < tol[0], (fuse, mask is not None)
             res[fuse] = pg.cpu().numpy()
-        assert rel_l2(res[2], res[0]) < tol[1]
+        assert rel_l2(res[1], res[0]) < tol[1]
 
 
 @pytest.mark.parametrize("dtype,ndim,hc", [(torch.float32, 2, 0), (torch.float64, 2, 4), (torch.float32, 3, 2)])
