@@ -4,7 +4,7 @@ tools/gpu_final_profiles.sh wrote (rocprofv3 --kernel-trace --pmc FETCH_SIZE / W
 values are KiB per launch).  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams."""
 import json, re, sys, os
 
-src = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01_final_pmc_fetch_write_summary.txt"
+src = sys.argv[1] if len(sys.argv) > 1 else sorted(f for f in __import__("glob").glob("profiles/r*_final_pmc_fetch_write_summary.txt"))[-1]   # newest round
 rows = {}
 for line in open(src):
     m = re.match(r"(\S+) T=(\d+) \| (\w+) \| n=(\d+) avg=([\d.]+).*\| (?:void )?pi::(\w+)(<[^(]*>)?", line)
