@@ -235,8 +235,11 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
     red_bytes_pt = 2 * Cs if (poly or hc <= 4) else 3 * Cs
     # float32 poly mode on the direct-kernel path: the gradient reduction is fused into the sweep launches (no separate
     # pass); the sweep-only timing above then only serves as a lower bound of that kernel
-    fused = (not tiled) and poly and dtype == torch.float32 and opts.get("fuse_wgrad", "2") != "0" and \
-        not (len(shape) == 3 and shape[-1] == 256 and npts >= (2 << 20) and opts.get("stream3d", "1") != "0")
+    # (float64 too, except where the plane-streaming kernels run: their fused flavour is float32 only)
+    streamed = len(shape) == 3 and shape[-1] in (64, 128, 256) and shape[0] >= 64 and npts >= (3 << 20) and \
+        opts.get("stream3d", "1") != "0"
+    fused = (not tiled) and poly and opts.get("fuse_wgrad", "2") != "0" and \
+        not (streamed and (dtype != torch.float32 or shape[-1] == 256))
     # 2D tile path, pre-contracted blocks, 32x32 tiles (> 128 of them): the tile sweep reduces the moments itself as well
     # (library option tile_fuse, default on) and keeps only every K-th adjoint frame
     tiles32 = ((shape[0] + 31) // 32) * ((shape[1] + 31) // 32) if len(shape) == 2 else 0
