@@ -1457,7 +1457,7 @@ size_t percnn_pi_param_count(int hc) { return hc < -1 ? 0 : (size_t)pi::nparams(
     int percnn_pi_contract_fwd_##SUF(const T* params, int hc, T* poly, void* stream)                                   \
     {                                                                                                                   \
         if (!params || !poly || hc < 1) return PERCNN_PI_EINVAL;                                                        \
-        hipLaunchKernelGGL((pi::pi_contract_fwd_kernel<T>), dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),    \
+        hipLaunchKernelGGL((pi::pi_contract_fwd_kernel<T>), dim3(1), dim3(128), 0, static_cast<hipStream_t>(stream),    \
                            params, hc, poly);                                                                           \
         return (int)hipGetLastError();                                                                                  \
     }                                                                                                                   \

@@ -22,34 +22,58 @@ __device__ __forceinline__ int mono_of(int a, int b, int c)
 constexpr int CONTRACT_LDS_HC = 64;                       // widest block staged in LDS (wider ones read global memory)
 
 template <typename T>
-__global__ void __launch_bounds__(64) pi_contract_fwd_kernel(const T* __restrict__ Pg, int hc, T* __restrict__ Q)
+__global__ void __launch_bounds__(128) pi_contract_fwd_kernel(const T* __restrict__ Pg, int hc, T* __restrict__ Q)
 {
     // the whole block comes in with ONE round trip (the per-channel loop below otherwise pays a cold ~2 us load per
     // hidden channel: 20 us at Hc = 8)
     __shared__ T stage[P_W + 2 * (10 * CONTRACT_LDS_HC + 1)];
+    // per (species, channel): its ten monomial sums, computed by ONE thread each in parallel (was: twenty threads walking all
+    // channels and all 27 index triples each -- 13 us of dependent float64 arithmetic per launch at Hc = 8, 4 % of a
+    // 100^2 x 200-step training iteration); the sums over the channels keep their order, results are bit-identical
+    __shared__ double mono[2 * CONTRACT_LDS_HC][10];
     const int t = threadIdx.x;
     const bool staged = hc <= CONTRACT_LDS_HC;
     if (staged) {
-        for (int i = t; i < nparams(hc); i += 64) stage[i] = Pg[i];
+        for (int i = t; i < nparams(hc); i += blockDim.x) stage[i] = Pg[i];
         __syncthreads();
     }
     const T* P = staged ? stage : Pg;
     if (t < P_W) Q[t] = P[t];
-    if (t >= 20) return;
-    const int s = t / 10, m = t % 10;
-    const T* B = P + P_W + s * species_block(hc);
-    double acc = 0.0;
-    for (int j = 0; j < hc; ++j) {
-        const T* w = B + 10 * j;
-        double sj = 0.0;
+    auto channel_sums = [&](const T* w, double (&sj)[10]) {
+#pragma unroll
+        for (int m = 0; m < 10; ++m) sj[m] = 0.0;
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    if (mono_of(a, b, c) == m) sj += ((double)w[a] * (double)w[3 + b]) * (double)w[6 + c];
-        acc += (double)w[9] * sj;
+                    sj[mono_of(a, b, c)] += ((double)w[a] * (double)w[3 + b]) * (double)w[6 + c];
+    };
+    if (staged) {
+        for (int idx = t; idx < 2 * hc; idx += blockDim.x) {
+            const int s = idx / hc, j = idx - s * hc;
+            double sj[10];
+            channel_sums(P + P_W + s * species_block(hc) + 10 * j, sj);
+#pragma unroll
+            for (int m = 0; m < 10; ++m) mono[idx][m] = sj[m];
+        }
+        __syncthreads();
+    }
+    if (t >= 20) return;
+    const int s = t / 10, m = t % 10;
+    const T* B = P + P_W + s * species_block(hc);
+    double acc = 0.0;
+    for (int j = 0; j < hc; ++j) {
+        double sjm;
+        if (staged) {
+            sjm = mono[s * hc + j][m];
+        } else {
+            double sj[10];
+            channel_sums(B + 10 * j, sj);
+            sjm = sj[m];
+        }
+        acc += (double)B[10 * j + 9] * sjm;
     }
     if (m == 0) acc += (double)B[10 * hc];
     Q[P_W + t] = (T)acc;
