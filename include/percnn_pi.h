@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define PERCNN_PI_ABI_VERSION 1
+#define PERCNN_PI_ABI_VERSION 2   /* 2: percnn_pi_halo_ring gained `peer`; percnn_pi_peer_*, *_opt entry points */
 
 #define PERCNN_PI_SWEEP_ONLY 1    /* flags of percnn_pi_slab_step_bwd_*: adjoint state + diffusion-coefficient
                                    * gradients only; branch gradients come from percnn_pi_slab_wgrad_* later */

@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("PERCNN_PI_LIB", os.path.join(CSRC, "libpercnn_pi.so"))
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 _INC = os.path.join("..", "..", "include")

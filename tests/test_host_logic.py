@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 16
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/*.h but not exported"
-    assert percnn_amd.lib().percnn_pi_abi_version() == 1
+    assert percnn_amd.lib().percnn_pi_abi_version() == 2
     for hc in (2, 4, 8, 16):
         assert percnn_amd.lib().percnn_pi_param_count(hc) == 16 + 2 * (10 * hc + 1) == percnn_amd.param_count(hc)
     assert percnn_amd.lib().percnn_pi_param_count(0) == 36          # pre-contracted polynomial block
