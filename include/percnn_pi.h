@@ -85,6 +85,31 @@ int percnn_pi_contract_fwd_f64(const double *params, int hc, double *poly, void 
 int percnn_pi_contract_bwd_f32(const float *params, int hc, const float *g_poly, float *g_params, void *stream);
 int percnn_pi_contract_bwd_f64(const double *params, int hc, const double *g_poly, double *g_params, void *stream);
 
+
+/* ---- parameter packing in one launch (replaces the tensor-op assembly of RCNNCell's parameters) ----------------------
+ * The reference keeps its parameters as 18 trainable tensors + the frozen stencil (RCNNCell.__init__, train_2drd.py:46-90).
+ * percnn_pi_pack_fwd_* gathers them into the packed block of this header -- `contract` != 0: into its pre-contracted
+ * 36-entry form (== percnn_pi_contract_fwd_* of the factored block, bit for bit) -- with ONE single-workgroup launch;
+ * percnn_pi_pack_bwd_* maps dL/d(block) back onto the 18 tensors (contraction chain rule, sigmoid derivative).
+ *   c[0], c[1]   CA, CB when `sigmoid` (coefficient = mu_up * sigmoid(C), train_2drd.py:115), else the raw DA, DB
+ *   w            W_laplace.weight, 5^ndim taps (frozen in the reference: no gradient is produced for it)
+ *   branch[16]   Wh1_u.weight, Wh1_u.bias, Wh2_u.weight, ..., Wh4_u.bias, then the same eight tensors of species v
+ * All pointers are device pointers to contiguous tensors of the entry point's element type; in `grads` NULL slots are
+ * skipped and `w` is ignored. */
+typedef struct percnn_pi_param_ptrs {
+    const void* c[2];
+    const void* w;
+    const void* branch[16];
+} percnn_pi_param_ptrs;
+int percnn_pi_pack_fwd_f32(const percnn_pi_param_ptrs* params, int hc, int ndim, double dt, double mu_up, int sigmoid,
+                           int contract, float* block, void* stream);
+int percnn_pi_pack_fwd_f64(const percnn_pi_param_ptrs* params, int hc, int ndim, double dt, double mu_up, int sigmoid,
+                           int contract, double* block, void* stream);
+int percnn_pi_pack_bwd_f32(const percnn_pi_param_ptrs* params, const percnn_pi_param_ptrs* grads, int hc, int ndim, double dt,
+                           double mu_up, int sigmoid, int contract, const float* g_block, void* stream);
+int percnn_pi_pack_bwd_f64(const percnn_pi_param_ptrs* params, const percnn_pi_param_ptrs* grads, int hc, int ndim, double dt,
+                           double mu_up, int sigmoid, int contract, const double* g_block, void* stream);
+
 /* Bytes of scratch the backward entry points need for a grid of this shape
  * (two adjoint ping-pong states + per-workgroup gradient partials). elem_size = 4 or 8. */
 size_t percnn_pi_bwd_workspace_bytes(int hc, int ndim, const int64_t *shape, int elem_size);

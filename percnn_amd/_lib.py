@@ -29,6 +29,7 @@ EXPORTS = [
     "percnn_pi_peer_box_bytes", "percnn_pi_peer_box_alloc", "percnn_pi_peer_box_free", "percnn_pi_peer_box_export",
     "percnn_pi_peer_box_open", "percnn_pi_peer_box_close", "percnn_pi_peer_box_status",
     "percnn_pi_peer_exchange_f32", "percnn_pi_peer_exchange_f64",
+    "percnn_pi_pack_fwd_f32", "percnn_pi_pack_fwd_f64", "percnn_pi_pack_bwd_f32", "percnn_pi_pack_bwd_f64",
 ] + [f"percnn_pi_{op}_{suf}" for suf in ("f32", "f64")
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
                 "slab_step_fwd_range", "slab_step_bwd_range", "slab_rollout_fwd", "slab_rollout_bwd", "residual_fwd",
@@ -113,6 +114,12 @@ def lib() -> ctypes.CDLL:
     L.percnn_pi_peer_box_close.restype, L.percnn_pi_peer_box_close.argtypes = ci, [vp]
     L.percnn_pi_peer_box_status.restype = ci
     L.percnn_pi_peer_box_status.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), vp]
+    cd = ctypes.c_double
+    for suf in ("f32", "f64"):
+        f = getattr(L, f"percnn_pi_pack_fwd_{suf}")
+        f.restype, f.argtypes = ci, [ctypes.POINTER(ParamPtrs), ci, ci, cd, cd, ci, ci, vp, vp]
+        f = getattr(L, f"percnn_pi_pack_bwd_{suf}")
+        f.restype, f.argtypes = ci, [ctypes.POINTER(ParamPtrs), ctypes.POINTER(ParamPtrs), ci, ci, cd, cd, ci, ci, vp, vp]
     for suf in ("f32", "f64"):
         f = getattr(L, f"percnn_pi_peer_exchange_{suf}")
         f.restype, f.argtypes = ci, [vp, ci, i64p, ci, ci, ctypes.POINTER(PeerRing), vp]
@@ -171,6 +178,11 @@ def lib() -> ctypes.CDLL:
     L.percnn_pi_s1_rollout_bwd_f32.argtypes = [vp, vp, ctypes.c_char_p, vp, vp, vp, sz, vp, i64p, ci, vp]
     _lib = L
     return L
+
+
+class ParamPtrs(ctypes.Structure):
+    """percnn_pi_param_ptrs of include/percnn_pi.h: device pointers of the reference's parameter tensors"""
+    _fields_ = [("c", ctypes.c_void_p * 2), ("w", ctypes.c_void_p), ("branch", ctypes.c_void_p * 16)]
 
 
 class PeerRing(ctypes.Structure):

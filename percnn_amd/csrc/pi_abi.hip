@@ -1472,6 +1472,46 @@ PI_CONTRACT(f32, float)
 PI_CONTRACT(f64, double)
 #undef PI_CONTRACT
 
+namespace {
+bool pack_ptrs(const percnn_pi_param_ptrs* in, bool need_all, pi::PackPtrs& out)
+{
+    static_assert(sizeof(percnn_pi_param_ptrs) == sizeof(pi::PackPtrs), "pointer tables");
+    if (!in) return false;
+    out.c[0] = in->c[0]; out.c[1] = in->c[1]; out.w = in->w;
+    for (int i = 0; i < 16; ++i) out.br[i] = in->branch[i];
+    if (!need_all) return true;
+    if (!out.c[0] || !out.c[1] || !out.w) return false;
+    for (int i = 0; i < 16; ++i) if (!out.br[i]) return false;
+    return true;
+}
+}  // namespace
+
+#define PI_PACK(SUF, T)                                                                                                 \
+    int percnn_pi_pack_fwd_##SUF(const percnn_pi_param_ptrs* params, int hc, int ndim, double dt, double mu_up,         \
+                                 int sigmoid, int contract, T* block, void* stream)                                     \
+    {                                                                                                                   \
+        pi::PackPtrs pp;                                                                                                \
+        if (!pack_ptrs(params, true, pp) || !block || hc < 1 || hc > pi::CONTRACT_LDS_HC || (ndim != 2 && ndim != 3))  \
+            return PERCNN_PI_EINVAL;                                                                                    \
+        hipLaunchKernelGGL((pi::pi_pack_fwd_kernel<T>), dim3(1), dim3(128), 0, static_cast<hipStream_t>(stream), pp, hc, \
+                           ndim, dt, mu_up, sigmoid, contract, block);                                                  \
+        return (int)hipGetLastError();                                                                                  \
+    }                                                                                                                   \
+    int percnn_pi_pack_bwd_##SUF(const percnn_pi_param_ptrs* params, const percnn_pi_param_ptrs* grads, int hc, int ndim, \
+                                 double dt, double mu_up, int sigmoid, int contract, const T* g_block, void* stream)    \
+    {                                                                                                                   \
+        pi::PackPtrs pp, gp;                                                                                            \
+        if (!pack_ptrs(params, true, pp) || !pack_ptrs(grads, false, gp) || !g_block || hc < 1 ||                       \
+            hc > pi::CONTRACT_LDS_HC || (ndim != 2 && ndim != 3))                                                       \
+            return PERCNN_PI_EINVAL;                                                                                    \
+        hipLaunchKernelGGL((pi::pi_pack_bwd_kernel<T>), dim3(1), dim3(128), 0, static_cast<hipStream_t>(stream), pp, gp, \
+                           hc, ndim, dt, mu_up, sigmoid, contract, g_block);                                            \
+        return (int)hipGetLastError();                                                                                  \
+    }
+PI_PACK(f32, float)
+PI_PACK(f64, double)
+#undef PI_PACK
+
 size_t percnn_pi_bwd_workspace_bytes(int hc, int ndim, const int64_t* shape, int elem_size)
 {
     Problem p;

@@ -93,6 +93,85 @@ def pack_params(dt: torch.Tensor, coef_u: torch.Tensor, coef_v: torch.Tensor, w_
 
 
 # ------------------------------------------------------------------------------------------------
+# the same assembly (+ contraction) in ONE launch: percnn_pi_pack_fwd/bwd_* (csrc/pi_contract.h)
+# ------------------------------------------------------------------------------------------------
+def _param_ptrs(tensors: Sequence[Optional[torch.Tensor]]):
+    """tensors = [c_u, c_v, W_laplace.weight, Wh1_u.w, Wh1_u.b, ..., Wh4_v.b] (19) -> percnn_pi_param_ptrs"""
+    pp = _lib.ParamPtrs()
+    ptr = [None if t is None else t.data_ptr() for t in tensors]
+    pp.c[0], pp.c[1], pp.w = ptr[0], ptr[1], ptr[2]
+    for i in range(16):
+        pp.branch[i] = ptr[3 + i]
+    return pp
+
+
+def _check_pack_inputs(tensors):
+    if len(tensors) != 19:
+        raise ValueError("pack_block expects [c_u, c_v, W_laplace.weight, 16 branch tensors]")
+    t0 = tensors[2]
+    if not t0.is_cuda:
+        raise RuntimeError("percnn_amd: pack_block has no CPU path (use functional.pack_params)")
+    for t in tensors:
+        if t.device != t0.device or t.dtype != t0.dtype or not t.is_contiguous():
+            raise ValueError("pack_block: tensors must be contiguous and share device and dtype")
+
+
+def pack_fwd_hip(tensors, hc: int, ndim: int, dt: float, mu_up: float, sigmoid: bool, contract: bool) -> torch.Tensor:
+    _check_pack_inputs(tensors)
+    w = tensors[2]
+    out = torch.empty(NPOLY if contract else param_count(hc), dtype=w.dtype, device=w.device)
+    f = getattr(_lib.lib(), "percnn_pi_pack_fwd_" + _SUF[w.dtype])
+    with torch.cuda.device(w.device):
+        _lib.check(f(ctypes.byref(_param_ptrs(tensors)), hc, ndim, float(dt), float(mu_up), int(sigmoid), int(contract),
+                     out.data_ptr(), _stream()), "pack_fwd")
+    return out
+
+
+def pack_bwd_hip(tensors, g_block: torch.Tensor, hc: int, ndim: int, dt: float, mu_up: float, sigmoid: bool,
+                 contract: bool, one_buffer: bool = False):
+    """-> gradients of the 18 trainable tensors, in the order of ``tensors`` without W_laplace.weight.
+    one_buffer: the gradients are views of ONE allocation (eager autograd path; outputs of a registered operator must
+    not share storage, so ``torch.ops.percnn.pack_block_backward`` allocates them one by one)"""
+    _check_pack_inputs(tensors)
+    w = tensors[2]
+    g_block = g_block.contiguous()
+    if one_buffer:                   # 18 allocator round trips are a third of the host time of this call otherwise
+        train = [t for i, t in enumerate(tensors) if i != 2]
+        flat = torch.empty(sum(t.numel() for t in train), dtype=w.dtype, device=w.device)
+        grads, o = [], 0
+        for t in train:
+            grads.append(flat[o:o + t.numel()].view(t.shape))
+            o += t.numel()
+    else:
+        grads = [torch.empty_like(t) for i, t in enumerate(tensors) if i != 2]
+    gptr = grads[:2] + [None] + grads[2:]
+    f = getattr(_lib.lib(), "percnn_pi_pack_bwd_" + _SUF[w.dtype])
+    with torch.cuda.device(w.device):
+        _lib.check(f(ctypes.byref(_param_ptrs(tensors)), ctypes.byref(_param_ptrs(gptr)), hc, ndim, float(dt), float(mu_up),
+                     int(sigmoid), int(contract), g_block.data_ptr(), _stream()), "pack_bwd")
+    return grads
+
+
+class PackBlockFunction(torch.autograd.Function):
+    """Eager-mode front of the two pack kernels: ``apply(meta, *tensors)`` with meta = (hc, ndim, dt, mu_up, sigmoid,
+    contract).  A plain autograd.Function on purpose -- measured on the MI355X box's host (tools/pack_time.py), per call
+    without / with backward: stock tensor ops 86 / 550 us, the registered operator (torch.ops.percnn.pack_block, what
+    torch.compile traces) 38 / 480-840 us, this 21 / 320 us: with one small launch each way the dispatcher's Python
+    layers are what is left to pay."""
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        ctx.meta = meta
+        ctx.save_for_backward(*tensors)
+        return pack_fwd_hip(tensors, *meta)
+
+    @staticmethod
+    def backward(ctx, g):
+        gr = pack_bwd_hip(ctx.saved_tensors, g, *ctx.meta, one_buffer=True)
+        return (None, gr[0], gr[1], None, *gr[2:])
+
+
+# ------------------------------------------------------------------------------------------------
 # pre-contracted ("poly") reaction: Wh4(Wh1(h)*Wh2(h)*Wh3(h)) as a cubic in (u, v)
 # ------------------------------------------------------------------------------------------------
 NPOLY = 36

@@ -121,8 +121,30 @@ class RCNNCell(nn.Module):
             F_pi.check_star_stencil(w)
             self._stencil_checked_version = key
 
+    def _pack_tensors(self):
+        c = (self.CA, self.CB) if self.diffusion == "sigmoid" else (self.DA, self.DB)
+        out = [c[0], c[1], self.W_laplace.weight]
+        for s in ("u", "v"):
+            for k in (1, 2, 3, 4):
+                m = getattr(self, f"Wh{k}_{s}")
+                out += [m.weight, m.bias]
+        return out
+
     def param_block(self) -> torch.Tensor:
         w = self.W_laplace.weight
+        if w.is_cuda and not w.requires_grad:
+            # one launch each way (torch.ops.percnn.pack_block): the tensor-op assembly below costs 79 us per call on
+            # MI355X without autograd and 540 us forward + backward with it -- as much as a 200-step rollout at 100^2
+            if not torch.compiler.is_compiling():
+                self._validate_stencil()
+            tensors = self._pack_tensors()
+            if all(t.is_contiguous() for t in tensors):
+                meta = (self.hidden_channels, self.ndim, float(self.dt),
+                        float(self.mu_up) if self.diffusion == "sigmoid" else 0.0, self.diffusion == "sigmoid",
+                        self.reaction == "poly")
+                if torch.compiler.is_compiling():            # the registered operator is what a graph can hold
+                    return torch.ops.percnn.pack_block(tensors, *meta)
+                return F_pi.PackBlockFunction.apply(meta, *tensors)
         if torch.compiler.is_compiling():
             # traced by torch.compile: no host-side checks / caches inside the graph (the stencil was validated by the
             # eager call that preceded compilation or is validated by the first eager use)

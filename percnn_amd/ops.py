@@ -8,6 +8,8 @@ autograd support, as a drop-in for the per-step ATen sequence of ``RCNNCell.forw
 so the operators pass ``torch.library.opcheck`` and trace under ``torch.compile(fullgraph=True)``:
 
     percnn::contract_block(Tensor params) -> Tensor          (+ contract_block_backward)
+    percnn::pack_block(Tensor[] tensors, int hc, int ndim, float dt, float mu_up, bool sigmoid, bool contract) -> Tensor
+            (+ pack_block_backward -> Tensor[]): the reference's 19 parameter tensors -> the block, one launch each way
     percnn::pi_step(Tensor h, Tensor params, str options="") -> Tensor
     percnn::pi_step_backward(Tensor h, Tensor params, Tensor g_out, str options="") -> (Tensor, Tensor)
     percnn::pi_rollout(Tensor h0, Tensor params, int steps, str options="") -> Tensor
@@ -75,6 +77,48 @@ def _contract_bwd(ctx, g):
 
 
 contract_block.register_autograd(_contract_bwd, setup_context=_contract_setup)
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's parameter tensors -> packed (optionally pre-contracted) block, one launch each way
+# (csrc/pi_contract.h: pi_pack_fwd_kernel / pi_pack_bwd_kernel; RCNNCell.param_block)
+#   tensors = [CA|DA, CB|DB, W_laplace.weight, Wh1_u.weight, Wh1_u.bias, ..., Wh4_u.bias, Wh1_v.weight, ..., Wh4_v.bias]
+# ------------------------------------------------------------------------------------------------
+@torch.library.custom_op(f"{_lib_ns}::pack_block", mutates_args=())
+def pack_block(tensors: List[torch.Tensor], hc: int, ndim: int, dt: float, mu_up: float, sigmoid: bool,
+               contract: bool) -> torch.Tensor:
+    return F_pi.pack_fwd_hip(tensors, hc, ndim, dt, mu_up, sigmoid, contract)
+
+
+@pack_block.register_fake
+def _(tensors, hc, ndim, dt, mu_up, sigmoid, contract):
+    return tensors[2].new_empty((F_pi.NPOLY if contract else F_pi.param_count(hc),))
+
+
+@torch.library.custom_op(f"{_lib_ns}::pack_block_backward", mutates_args=())
+def pack_block_backward(tensors: List[torch.Tensor], g_block: torch.Tensor, hc: int, ndim: int, dt: float, mu_up: float,
+                        sigmoid: bool, contract: bool) -> List[torch.Tensor]:
+    return F_pi.pack_bwd_hip(tensors, g_block, hc, ndim, dt, mu_up, sigmoid, contract)
+
+
+@pack_block_backward.register_fake
+def _(tensors, g_block, hc, ndim, dt, mu_up, sigmoid, contract):
+    return [torch.empty_like(t) for i, t in enumerate(tensors) if i != 2]
+
+
+def _pack_setup(ctx, inputs, output):
+    tensors, hc, ndim, dt, mu_up, sigmoid, contract = inputs
+    ctx.save_for_backward(*tensors)
+    ctx.meta = (hc, ndim, dt, mu_up, sigmoid, contract)
+
+
+def _pack_bwd(ctx, g):
+    tensors = list(ctx.saved_tensors)
+    grads = torch.ops.percnn.pack_block_backward(tensors, g.contiguous(), *ctx.meta)
+    return [grads[0], grads[1], None] + list(grads[2:]), None, None, None, None, None, None
+
+
+pack_block.register_autograd(_pack_bwd, setup_context=_pack_setup)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1292,6 +1292,60 @@ def test_tile_sweep_with_fused_moments(shape, T, dtype, hip_device):
         assert rel_l2(res[1], res[0]) < tol[1]
 
 
+@pytest.mark.parametrize("maker,reaction", [("gs2d_cell", "poly"), ("gs2d_cell", "factored"), ("gs3d_cell", "poly"),
+                                            ("lo2d_cell", "poly"), ("lo2d_cell", "factored")])
+def test_fused_parameter_packing_equals_tensor_op_assembly(maker, reaction, hip_device):
+    """torch.ops.percnn.pack_block (one launch forward, one backward) against the stock tensor-op assembly it replaces in
+    RCNNCell.param_block (sigmoid, mul, cat, index_select, contraction): the block entry for entry (the two sigmoid
+    coefficients to one rounding of the parameter dtype, everything else exactly), the gradients of all 18 trainable
+    tensors to round-off, none for the frozen stencil; opcheck of the operator."""
+    import percnn_amd as pa
+    from percnn_amd import functional as F_pi
+    from torch.library import opcheck
+    torch.manual_seed(3)
+    cell = getattr(pa, maker)(reaction=reaction).to(hip_device)
+    with torch.no_grad():
+        for m in cell.filter_list:
+            m.bias.uniform_(-0.3, 0.3)                      # the initialiser zeroes the biases
+            m.weight.mul_(10.0)
+    w = cell.W_laplace.weight
+    dt_t = torch.tensor([cell.dt], dtype=w.dtype, device=w.device)
+    cu, cv = cell.coefficients()
+    branch = []
+    for sname in ("u", "v"):
+        for k in (1, 2, 3, 4):
+            m = getattr(cell, f"Wh{k}_{sname}")
+            branch += [m.weight, m.bias]
+    P_ref = F_pi.pack_params(dt_t, cu, cv, w, branch)
+    if reaction == "poly":
+        P_ref = F_pi.contract_block(P_ref)
+    P = cell.param_block()                                   # the fused operator on a HIP device
+    assert P.shape == P_ref.shape and P.grad_fn is not None
+    eps = torch.finfo(w.dtype).eps
+    a, b = P.detach().cpu(), P_ref.detach().cpu()
+    assert torch.equal(a[3:], b[3:]) and a[0] == b[0]
+    assert ((a[1:3] - b[1:3]).abs() <= 2 * eps * b[1:3].abs()).all()
+    gsel = torch.randn(P.shape, dtype=w.dtype, device=w.device, generator=torch.Generator(device=w.device).manual_seed(5))
+    params = [p for p in cell.parameters() if p.requires_grad]
+    g_new = torch.autograd.grad((P * gsel).sum(), params)
+    g_old = torch.autograd.grad((P_ref * gsel).sum(), params)
+    assert len(g_new) == 18
+    for x, y in zip(g_new, g_old):
+        assert x.shape == y.shape
+        assert (x - y).abs().max() <= 8 * eps * max(y.abs().max().item(), 1e-30), (x - y).abs().max()
+    assert not w.requires_grad
+    tensors = cell._pack_tensors()
+    args = (tensors, cell.hidden_channels, cell.ndim, float(cell.dt), float(cell.mu_up or 0.0), cell.diffusion == "sigmoid",
+            reaction == "poly")
+    opcheck(torch.ops.percnn.pack_block, args)
+    # the rollout through the modules is unchanged by the new packing (same block -> same kernels)
+    h0 = torch.rand((1, 2) + (16,) * cell.ndim, dtype=w.dtype, device=w.device)
+    with torch.no_grad():
+        t1 = pa.RCNN(cell, step=4, effective_step=list(range(4)), init_state=h0).trajectory()
+        t2 = F_pi.pi_rollout(h0, P_ref.detach(), 4)
+    assert torch.allclose(t1, t2, rtol=1e-6 if w.dtype == torch.float32 else 1e-13, atol=0)
+
+
 @pytest.mark.parametrize("dtype,ndim,hc", [(torch.float32, 2, 0), (torch.float64, 2, 4), (torch.float32, 3, 2)])
 def test_registered_operators_pass_opcheck(dtype, ndim, hc, hip_device):
     """torch.library.opcheck on HIP tensors: schema, autograd registration, FakeTensor and AOT-dispatch consistency of
