@@ -283,6 +283,11 @@ typedef struct percnn_pi_halo_ring {
     percnn_pi_peer_ring* peer;  /* non-NULL: exchange through the peer mailboxes, the RCCL members above are not used */
 } percnn_pi_halo_ring;
 
+/* diagnostics (host only, no device work): the block decomposition the direct kernels would use for `shape` under `options`
+ * ("key=value,..." or NULL): out[6] = {log2 lanes along x (-1 = flat), x blocks per row, row groups per plane, virtual blocks,
+ * planes per pass of the adjoint, workgroup size} */
+int percnn_pi_debug_blockmap(int ndim, const int64_t* shape, int elem_size, const char* options, int* out);
+
 size_t percnn_pi_peer_box_bytes(size_t slot_bytes);                 /* size of a mailbox allocation */
 int percnn_pi_peer_box_alloc(void** box, size_t slot_bytes);        /* fine-grained device memory on the current device, zeroed */
 int percnn_pi_peer_box_free(void* box);

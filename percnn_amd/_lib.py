@@ -30,6 +30,7 @@ EXPORTS = [
     "percnn_pi_peer_box_open", "percnn_pi_peer_box_close", "percnn_pi_peer_box_status",
     "percnn_pi_peer_exchange_f32", "percnn_pi_peer_exchange_f64",
     "percnn_pi_pack_fwd_f32", "percnn_pi_pack_fwd_f64", "percnn_pi_pack_bwd_f32", "percnn_pi_pack_bwd_f64",
+    "percnn_pi_debug_blockmap",
 ] + [f"percnn_pi_{op}_{suf}" for suf in ("f32", "f64")
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
                 "slab_step_fwd_range", "slab_step_bwd_range", "slab_rollout_fwd", "slab_rollout_bwd", "residual_fwd",
@@ -114,6 +115,8 @@ def lib() -> ctypes.CDLL:
     L.percnn_pi_peer_box_close.restype, L.percnn_pi_peer_box_close.argtypes = ci, [vp]
     L.percnn_pi_peer_box_status.restype = ci
     L.percnn_pi_peer_box_status.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), vp]
+    L.percnn_pi_debug_blockmap.restype = ci
+    L.percnn_pi_debug_blockmap.argtypes = [ci, i64p, ci, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     cd = ctypes.c_double
     for suf in ("f32", "f64"):
         f = getattr(L, f"percnn_pi_pack_fwd_{suf}")

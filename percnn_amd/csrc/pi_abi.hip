@@ -1451,6 +1451,23 @@ int percnn_pi_peer_exchange_f64(double* slab, int ndim, const int64_t* shape, in
                                 void* stream)
 { return peer_exchange_impl<double>(slab, ndim, shape, halo, width, ring, stream); }
 
+// Host-only view of the direct kernels' block decomposition (set_blockmap / direct_rz) for a shape -- what tests/
+// test_host_logic.py checks without a GPU: out = {lxs (-1 = flat), nxb, nrg, nblk, rz chosen for the adjoint, block}.
+int percnn_pi_debug_blockmap(int ndim, const int64_t* shape, int elem_size, const char* options, int* out)
+{
+    Problem p;
+    if (int rc = make_problem(0, ndim, shape, false, p, options)) return rc;
+    if (!out || (elem_size != 4 && elem_size != 8)) return PERCNN_PI_EINVAL;
+    const int vec = (p.W % (16 / elem_size) == 0 && p.opt.vec != 1) ? 16 / elem_size : 1;
+    Geom g = make_geom(p);
+    const int block = direct_block(p, g, vec);
+    const int rz = elem_size == 4 ? direct_rz<float>(p, vec, true) : direct_rz<double>(p, vec, true);
+    if (!set_blockmap(g, p.ndim, vec, block, (size_t)elem_size, p.opt.l2_tile_kb * 1024, rz, (long)p.opt.l2_tile_min_kb * 1024,
+                      p.opt.lane_x)) return PERCNN_PI_EINVAL;
+    out[0] = g.lxs; out[1] = g.nxb; out[2] = g.nrg; out[3] = (int)g.nblk; out[4] = rz; out[5] = block;
+    return 0;
+}
+
 size_t percnn_pi_param_count(int hc) { return hc < -1 ? 0 : (size_t)pi::nparams(hc); }
 
 #define PI_CONTRACT(SUF, T)                                                                                             \

@@ -405,6 +405,58 @@ def test_slab_transport_selection(monkeypatch):
     assert L.percnn_pi_peer_exchange_f32(None, 3, _lib.shape_arg((8, 8, 8)), 2, 2, None, None) == -1
 
 
+def test_direct_kernel_block_decomposition_rules():
+    """Host logic of the direct kernels' lane decomposition (set_blockmap) and of the adjoint's planes per pass (direct_rz),
+    through the diagnostic entry point -- no device work: every chunk of every row is covered, the fitted rule never
+    leaves more lanes idle than the earlier one (beyond its segment-length weights), power-of-two widths keep the
+    decomposition the BASELINE sizes were measured with, the flat decomposition appears exactly where stated."""
+    import ctypes
+    from percnn_amd import _lib
+    L = _lib.lib()
+
+    def bm(shape, elem=4, options=None):
+        out = (ctypes.c_int * 6)()
+        rc = L.percnn_pi_debug_blockmap(len(shape), _lib.shape_arg(shape), elem, options.encode() if options else None, out)
+        assert rc == 0, (shape, rc)
+        return dict(lxs=out[0], nxb=out[1], nrg=out[2], nblk=out[3], rz=out[4], block=out[5])
+
+    rs = np.random.RandomState(0)
+    shapes = [(48,) * 3, (96,) * 3, (100,) * 3, (128,) * 3, (144,) * 3, (160,) * 3, (192,) * 3, (200,) * 3, (208,) * 3,
+              (224,) * 3, (256,) * 3, (384,) * 3, (32, 256, 256), (1800, 1800), (2048, 2048), (100, 100), (7, 12, 40)]
+    shapes += [tuple(int(v) for v in rs.randint(2, 200, 3)) for _ in range(40)] + [tuple(int(v) for v in rs.randint(2, 3000, 2)) for _ in range(20)]
+    for shape in shapes:
+        for elem in (4, 8):
+            vecw = 16 // elem
+            vec = vecw if shape[-1] % vecw == 0 else 1
+            cpr = shape[-1] // vec
+            rows = shape[1] if len(shape) == 3 else shape[0]
+            planes = shape[0] if len(shape) == 3 else 1
+            new, old = bm(shape, elem), bm(shape, elem, "lane_x=-1")
+            for d in (new, old):
+                groups = -(-planes // d["rz"]) if len(shape) == 3 else 1
+                if d["lxs"] < 0:                                        # flat: consecutive chunks of the plane
+                    assert d["nxb"] == 1 and d["nrg"] * d["block"] >= rows * cpr > (d["nrg"] - 1) * d["block"]
+                else:
+                    lx, rb = 1 << d["lxs"], d["block"] >> d["lxs"]
+                    assert 2 <= d["lxs"] <= 6 and lx <= d["block"]
+                    assert d["nxb"] * lx >= cpr > (d["nxb"] - 1) * lx and d["nrg"] * rb >= rows > (d["nrg"] - 1) * rb
+                assert d["nblk"] == d["nxb"] * d["nrg"] * groups
+            assert old["lxs"] >= 2                                       # the earlier rule never goes flat
+            # useful lanes: the fitted rule trades at most its segment weights (>= 0.70 / 1.0) against the earlier one
+            eff = lambda d: (planes * rows * cpr) / (d["nblk"] * d["block"] * d["rz"])
+            assert eff(new) >= 0.69 * eff(old) - 1e-9, (shape, elem, new, old)
+            npts = int(np.prod(shape))
+            if new["lxs"] < 0:
+                assert npts < (8 << 20) and new["rz"] <= 2 and eff(new) > eff(bm(shape, elem, "lane_x=6")) + 0.05
+            assert new["rz"] in (1, 2) and (new["rz"] == 1 or npts >= (3 << 17))
+    for shape in ((128,) * 3, (256,) * 3, (32, 256, 256), (2048, 2048), (512, 512)):       # the sizes the profiles were taken at
+        assert bm(shape)["lxs"] == bm(shape, 4, "lane_x=-1")["lxs"]
+    assert bm((128,) * 3)["rz"] == 1 and bm((32, 256, 256))["rz"] == 1                      # exactly one resident round
+    assert bm((144,) * 3)["rz"] == 2 and bm((96,) * 3)["rz"] == 2 and bm((64,) * 3)["rz"] == 1 and bm((256,) * 3)["rz"] == 2
+    assert bm((192,) * 3)["lxs"] == 4 and bm((160,) * 3)["lxs"] == -1 and bm((144,) * 3)["lxs"] == -1 and bm((48,) * 3)["lxs"] == -1
+    assert bm((192,) * 3, 4, "lane_x=7")["lxs"] == -1 and bm((192,) * 3, 4, "lane_x=5")["lxs"] == 5
+
+
 def test_3d_upscaler_contraction_path_equals_stock_layers():
     """The 3D IC generator evaluates its transposed convolutions as matmuls (MIOpen's ConvTranspose3d is 15x slower on
     MI355X); values and all gradients must equal the stock torch.nn layers it holds (train_3drd.py:41-56)."""
