@@ -141,6 +141,8 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *   "rz"           direct 3D kernels, pre-contracted blocks: consecutive planes per workgroup pass that share their plane
  *                  neighbours in registers (1, 2, 4; default 0 = by grid size: large grids 4 forward / 2 backward)
  *   "block_small"  1 (default): 128-thread workgroups for the direct kernels on grids below ~1 M points
+ *   "slab_wide_adjoint"  1: the native slab backward over an RCCL ring exchanges once per two adjoint steps (default 0:
+ *                  measured slower, an ncclGroup costs per operation)
  *   "lane_x"       direct kernels: log2 of the 16-byte chunks a wave takes from one row (2..6), or 7 = flat (a workgroup
  *                  takes consecutive chunks of the plane across row ends); default 0 = the decomposition with the most
  *                  useful lanes, weighted by segment length and row-pitch alignment (grids that are not a power of two
@@ -307,7 +309,9 @@ int percnn_pi_slab_rollout_fwd_f32(float* traj, const float* params, int hc, int
 int percnn_pi_slab_rollout_fwd_f64(double* traj, const double* params, int hc, int ndim, const int64_t* shape, int halo,
                                    int T_steps, const percnn_pi_halo_ring* ring, int overlap, void* stream);
 /* adj: caller-provided local adjoint trajectory (same layout as traj, contents irrelevant on entry; adj[0] holds
- * dL/d(frame 0) on return); g_traj: dL/dtraj in the same padded layout (halo planes ignored); param_grad: double[np],
+ * dL/d(frame 0) on return); g_traj: dL/dtraj in the same padded layout (halo planes ignored; only with option "slab_wide_adjoint" = 1 -- one
+ * exchange per two adjoint steps over an RCCL ring, halo >= 4 -- they serve as receive buffers and hold the neighbours'
+ * values on return); param_grad: double[np],
  * ACCUMULATED (local sums of this rank; the caller all-reduces them); workspace: percnn_pi_bwd_workspace_bytes(). */
 int percnn_pi_slab_rollout_bwd_f32(const float* traj, const float* g_traj, float* adj, double* param_grad,
                                    void* workspace, size_t workspace_bytes, const float* params, int hc, int ndim,

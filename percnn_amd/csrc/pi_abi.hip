@@ -50,6 +50,11 @@ struct Options {
     int l2_tile_kb = 128;   // direct 3D kernels: y-tile of a plane (both species, KiB) whose five stencil planes stay in the L2
                             // (0 = whole planes, the pre-round-2 order): see set_blockmap
     int l2_tile_min_kb = 1536;  // ... applied once four neighbour planes x two species exceed this many KiB (0: always; tests)
+    int slab_wide_adjoint = 0;  // native slab backward over RCCL: one exchange per TWO adjoint steps (4 adjoint planes + 2 dL/dtraj
+                            // planes per side in one group call), the 2-plane strips next to the faces recomputed locally.
+                            // Built for VERDICT r1 #3, measured SLOWER on MI355X (RCCL to self, 32 x 256^2 slab: 74.0 -> 79.6 us
+                            // per fwd+bwd step): an ncclGroup costs per operation (~3 us each of its 8 sends / receives), not per
+                            // call, so 16 operations every second step save nothing and the two strip launches come on top
     int lane_x = 0;         // direct kernels: log2 of the lanes along x per row segment (2..6), 0 = fewest idle lanes (set_blockmap),
                             // -1 = the pre-round-2 rule (next power of two >= chunks per row)
     int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
@@ -921,11 +926,16 @@ int peer_exchange_impl(T* slab, int ndim, const int64_t* shape, int halo, int wi
     return peer_exchange<T>(slab, p, width, ring, static_cast<hipStream_t>(stream));
 }
 
-// faces of `slab` ([2][n0 + 2*halo][plane]) -> the neighbours' halo planes, `width` planes per side, on stream st
+// faces of `slab` ([2][n0 + 2*halo][plane]) -> the neighbours' halo planes, `width` planes per side, on stream st;
+// slab2 / width2: a second array of the same layout exchanged in the SAME ncclGroup (one call's latency for both)
 template <typename T>
-int ring_exchange(T* slab, const Problem& p, int width, const percnn_pi_halo_ring* r, hipStream_t st)
+int ring_exchange(T* slab, const Problem& p, int width, const percnn_pi_halo_ring* r, hipStream_t st, T* slab2 = nullptr,
+                  int width2 = 0)
 {
-    if (r && r->peer) return peer_exchange<T>(slab, p, width, r->peer, st);
+    if (r && r->peer) {
+        if (int rc = peer_exchange<T>(slab, p, width, r->peer, st)) return rc;
+        return slab2 ? peer_exchange<T>(slab2, p, width2, r->peer, st) : 0;
+    }
     const size_t plane = (size_t)(p.n1 * p.W), cnt = (size_t)width * plane;
     const size_t ss = (size_t)(p.n0 + 2 * p.halo) * plane;
     const int64_t n = p.n0, halo = p.halo;
@@ -937,18 +947,24 @@ int ring_exchange(T* slab, const Problem& p, int width, const percnn_pi_halo_rin
             if (hipError_t e = hipMemcpyAsync(at(s, halo + n), at(s, halo), cnt * sizeof(T), hipMemcpyDeviceToDevice, st))
                 return (int)e;
         }
-        return 0;
+        return slab2 ? ring_exchange<T>(slab2, p, width2, r, st) : 0;
     }
     const int dt = ring_dtype<T>(r);
     if (int rc = r->group_start()) return rc;
     // per peer, sends and receives pair up in issue order (matters when prev == next: 2 ranks)
-    for (int s = 0; s < 2; ++s) {
-        if (int rc = r->send(at(s, halo + n - width), cnt, dt, r->next, r->comm, st)) return rc;
-        if (int rc = r->send(at(s, halo), cnt, dt, r->prev, r->comm, st)) return rc;
-    }
-    for (int s = 0; s < 2; ++s) {
-        if (int rc = r->recv(at(s, halo - width), cnt, dt, r->prev, r->comm, st)) return rc;
-        if (int rc = r->recv(at(s, halo + n), cnt, dt, r->next, r->comm, st)) return rc;
+    for (int pass = 0; pass < (slab2 ? 2 : 1); ++pass) {
+        T* base = pass ? slab2 : slab;
+        const int wd = pass ? width2 : width;
+        const size_t c = (size_t)wd * plane;
+        auto a2 = [&](int s, int64_t pl) { return base + (size_t)s * ss + (size_t)pl * plane; };
+        for (int s = 0; s < 2; ++s) {
+            if (int rc = r->send(a2(s, halo + n - wd), c, dt, r->next, r->comm, st)) return rc;
+            if (int rc = r->send(a2(s, halo), c, dt, r->prev, r->comm, st)) return rc;
+        }
+        for (int s = 0; s < 2; ++s) {
+            if (int rc = r->recv(a2(s, halo - wd), c, dt, r->prev, r->comm, st)) return rc;
+            if (int rc = r->recv(a2(s, halo + n), c, dt, r->next, r->comm, st)) return rc;
+        }
     }
     return r->group_end();
 }
@@ -1048,7 +1064,7 @@ int slab_rollout_bwd_impl(const T* traj, const T* g_traj, T* adj, double* param_
     hipEvent_t pending = nullptr;
     // float32 poly mode: the 20 coefficient moments are reduced inside the sweep launches (no slab_wgrad pass)
     const bool fuse = hc == 0 && sizeof(T) == 4 && p.opt.fuse_wgrad != 0;
-    auto sweep = [&](int t, int lo, int hi) -> int {        // adjoint planes [lo, hi) of frame t-1 from frame t
+    auto sweep = [&](int t, int lo, int hi, bool strip = false) -> int {   // adjoint planes [lo, hi) of frame t-1 from frame t
         Problem q = p;
         if (int rc = set_slab_range(q, halo, lo, hi)) return rc;
         unsigned grid = 0;
@@ -1056,10 +1072,30 @@ int slab_rollout_bwd_impl(const T* traj, const T* g_traj, T* adj, double* param_
         const T* gf = adj + (size_t)t * frame;
         const T* jf = g_traj + (size_t)(t - 1) * frame;
         T* of = adj + (size_t)(t - 1) * frame;
+        // strips outside the interior (wide-halo blocks below) belong to the neighbour's sums: their partial rows go to a
+        // scratch area nobody reads
+        if (strip) return (int)step_bwd<T, false>(hf, gf, jf, of, static_cast<double*>(w.adj[0]), P, q, st, &grid);
         return fuse ? (int)step_bwd<T, true>(hf, gf, jf, of, w.partials, P, q, st, &grid)
                     : (int)step_bwd<T, false>(hf, gf, jf, of, w.partials, P, q, st, &grid);
     };
+    // Wide-halo adjoint over RCCL (option slab_wide_adjoint, off: measured slower, see Options): TWO adjoint steps share one
+    // exchange: 4 planes of adj[t] and 2 planes of dL/dtraj[t-1] per side travel together, adj[t-1] is then also computed on the two
+    // planes next to each face (two small launches; the trajectory halos are at least 2 planes valid in every frame the
+    // forward wrote), and step t-1 -> t-2 needs no exchange.  The halo planes of g_traj are used as receive buffers.
+    // Not with the peer mailboxes (their per-exchange cost is two small launches already), not in overlap mode.
+    const bool wide = ring && !ring->peer && !side && p.opt.slab_wide_adjoint && halo >= 4 && n >= 4 &&
+                      (size_t)2 * p.n * sizeof(T) >= w.partials_bytes;
+    T* g_mut = const_cast<T*>(g_traj);
     for (int t = T_steps; t >= 1; --t) {
+        if (wide && t >= 2) {
+            if (int rc = ring_exchange<T>(adj + (size_t)t * frame, p, 4, ring, st, g_mut + (size_t)(t - 1) * frame, 2)) return rc;
+            if (int rc = sweep(t, halo - 2, halo, true)) return rc;
+            if (int rc = sweep(t, halo + (int)n, halo + (int)n + 2, true)) return rc;
+            if (int rc = sweep(t, halo, halo + (int)n)) return rc;
+            --t;                                           // adj[t-1] now has 2 valid halo planes per side
+            if (int rc = sweep(t, halo, halo + (int)n)) return rc;
+            continue;
+        }
         if (pending) {
             if (hipError_t e = hipStreamWaitEvent(st, pending, 0)) return (int)e;
             pending = nullptr;
@@ -1316,6 +1352,7 @@ int apply_option(Options& o, const char* key, long value)
         return 0;
     }
     if (!std::strcmp(key, "block_small")) { o.block_small = value != 0; return 0; }
+    if (!std::strcmp(key, "slab_wide_adjoint")) { o.slab_wide_adjoint = value != 0; return 0; }
     if (!std::strcmp(key, "lane_x")) {
         if (value != 0 && value != -1 && (value < 2 || value > 7)) return PERCNN_PI_EINVAL;     // 7 = flat
         o.lane_x = (int)value;

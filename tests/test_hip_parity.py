@@ -566,7 +566,12 @@ def test_rccl_halo_exchange_to_self(hip_device):
                 def native_ring(self):
                     return False, None
             for ex, overlap in ((slab.HaloExchanger(), False), (slab.RcclHaloExchanger(force_p2p=True), True),
-                                (slab.RcclHaloExchanger(force_p2p=True), False), (PyLoop(force_p2p=True), True)):
+                                (slab.RcclHaloExchanger(force_p2p=True), False), (PyLoop(force_p2p=True), True),
+                                (slab.RcclHaloExchanger(force_p2p=True), "wide")):
+                wide = overlap == "wide"                    # option slab_wide_adjoint: one exchange per two adjoint steps
+                overlap = False if wide else overlap
+                import percnn_amd as _pa
+                _pa.set_option("slab_wide_adjoint", 1 if wide else 0)
                 local = slab.scatter_slab(h0, 0, 1, halo)
                 traj = torch.zeros((T + 1,) + tuple(local.shape), device=hip_device)
                 traj[0] = local
@@ -575,6 +580,7 @@ def test_rccl_halo_exchange_to_self(hip_device):
                 g0, pg = slab.slab_rollout_bwd(traj, gt, P, ex, halo, overlap=overlap)
                 torch.cuda.synchronize()
                 res.append((traj[:, :, halo:-halo].clone(), g0[:, halo:-halo].clone(), pg.clone()))
+                _pa.set_option("slab_wide_adjoint", 0)
                 if hasattr(ex, "close"):
                     ex.close()
             for r in res[1:]:
