@@ -283,6 +283,9 @@ typedef struct percnn_pi_halo_ring {
     int (*send)(const void* buf, size_t count, int dtype, int peer, void* comm, void* stream);
     int (*recv)(void* buf, size_t count, int dtype, int peer, void* comm, void* stream);
     percnn_pi_peer_ring* peer;  /* non-NULL: exchange through the peer mailboxes, the RCCL members above are not used */
+    void* stage;                /* optional device scratch of stage_bytes for the RCCL path: both species of a face are packed into */
+    size_t stage_bytes;         /* ONE message per direction (2 sends + 2 receives per exchange instead of 4 + 4); needs
+                                 * 8 x width x plane elements; NULL / too small: per-species messages straight from the slab */
 } percnn_pi_halo_ring;
 
 /* diagnostics (host only, no device work): the block decomposition the direct kernels would use for `shape` under `options`

@@ -200,7 +200,8 @@ class HaloRing(ctypes.Structure):
     _fields_ = [("comm", ctypes.c_void_p), ("prev", ctypes.c_int), ("next", ctypes.c_int),
                 ("dtype_f32", ctypes.c_int), ("dtype_f64", ctypes.c_int),
                 ("group_start", ctypes.c_void_p), ("group_end", ctypes.c_void_p),
-                ("send", ctypes.c_void_p), ("recv", ctypes.c_void_p), ("peer", ctypes.POINTER(PeerRing))]
+                ("send", ctypes.c_void_p), ("recv", ctypes.c_void_p), ("peer", ctypes.POINTER(PeerRing)),
+                ("stage", ctypes.c_void_p), ("stage_bytes", ctypes.c_size_t)]
 
 
 def check(rc: int, what: str) -> None:

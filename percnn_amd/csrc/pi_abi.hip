@@ -950,6 +950,35 @@ int ring_exchange(T* slab, const Problem& p, int width, const percnn_pi_halo_rin
         return slab2 ? ring_exchange<T>(slab2, p, width2, r, st) : 0;
     }
     const int dt = ring_dtype<T>(r);
+    if (!slab2 && r->stage && (size_t)8 * cnt * sizeof(T) <= r->stage_bytes) {
+        // packed faces: [to next | to prev | from prev | from next], both species each
+        char* stg = static_cast<char*>(r->stage);
+        const size_t fb = cnt * sizeof(T), msg = 2 * fb;
+        pi::PeerXfer pk{}, un{};
+        bool vec = fb % 16 == 0 && reinterpret_cast<uintptr_t>(stg) % 16 == 0;
+        for (int s = 0; s < 2; ++s) {
+            pk.src[0][s] = reinterpret_cast<const char*>(at(s, halo + n - width)); pk.dst[0][s] = stg + s * fb;
+            pk.src[1][s] = reinterpret_cast<const char*>(at(s, halo));             pk.dst[1][s] = stg + msg + s * fb;
+            un.src[0][s] = stg + 2 * msg + s * fb;  un.dst[0][s] = reinterpret_cast<char*>(at(s, halo - width));
+            un.src[1][s] = stg + 3 * msg + s * fb;  un.dst[1][s] = reinterpret_cast<char*>(at(s, halo + n));
+            for (int d = 0; d < 2; ++d)
+                vec = vec && reinterpret_cast<uintptr_t>(pk.src[d][s]) % 16 == 0 && reinterpret_cast<uintptr_t>(un.dst[d][s]) % 16 == 0;
+        }
+        const size_t units = fb / (vec ? 16 : 4);
+        pk.bytes = un.bytes = fb;
+        pk.blocks_per_dir = un.blocks_per_dir = (int)std::min<size_t>(256, std::max<size_t>(1, (units + 1023) / 1024));
+        if (vec) hipLaunchKernelGGL(pi::face_copy_kernel<true>, dim3(2 * pk.blocks_per_dir), dim3(256), 0, st, pk);
+        else hipLaunchKernelGGL(pi::face_copy_kernel<false>, dim3(2 * pk.blocks_per_dir), dim3(256), 0, st, pk);
+        if (int rc = r->group_start()) return rc;
+        if (int rc = r->send(stg, 2 * cnt, dt, r->next, r->comm, st)) return rc;
+        if (int rc = r->send(stg + msg, 2 * cnt, dt, r->prev, r->comm, st)) return rc;
+        if (int rc = r->recv(stg + 2 * msg, 2 * cnt, dt, r->prev, r->comm, st)) return rc;
+        if (int rc = r->recv(stg + 3 * msg, 2 * cnt, dt, r->next, r->comm, st)) return rc;
+        if (int rc = r->group_end()) return rc;
+        if (vec) hipLaunchKernelGGL(pi::face_copy_kernel<true>, dim3(2 * un.blocks_per_dir), dim3(256), 0, st, un);
+        else hipLaunchKernelGGL(pi::face_copy_kernel<false>, dim3(2 * un.blocks_per_dir), dim3(256), 0, st, un);
+        return (int)hipGetLastError();
+    }
     if (int rc = r->group_start()) return rc;
     // per peer, sends and receives pair up in issue order (matters when prev == next: 2 ranks)
     for (int pass = 0; pass < (slab2 ? 2 : 1); ++pass) {

@@ -82,6 +82,16 @@ __global__ void __launch_bounds__(256) peer_put_kernel(PeerXfer x)
     }
 }
 
+// the same segmented copy without any signalling: packs the faces of both species into one staging message per direction
+// (and unpacks the received ones) for the RCCL ring -- an ncclGroup costs per operation (~3 us each on MI355X), so 2 sends +
+// 2 receives of packed faces beat 4 + 4 of per-species planes even with the two copy launches
+template <bool VEC>
+__global__ void __launch_bounds__(256) face_copy_kernel(PeerXfer x)
+{
+    const int dir = (int)blockIdx.x / x.blocks_per_dir, lb = (int)blockIdx.x % x.blocks_per_dir;
+    for (int s = 0; s < 2; ++s) peer_copy<VEC>(x.src[dir][s], x.dst[dir][s], x.bytes, lb, x.blocks_per_dir);
+}
+
 template <bool VEC>
 __global__ void __launch_bounds__(256) peer_take_kernel(PeerXfer x, unsigned long long timeout_ticks)
 {

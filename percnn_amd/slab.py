@@ -251,8 +251,23 @@ class RcclHaloExchanger(HaloExchanger):
             from . import _lib
             self._ring = _lib.HaloRing(self._comm.value, self.prev, self.next, self._DT[torch.float32],
                                        self._DT[torch.float64], addr(N.ncclGroupStart), addr(N.ncclGroupEnd),
-                                       addr(N.ncclSend), addr(N.ncclRecv))
+                                       addr(N.ncclSend), addr(N.ncclRecv), None, None, 0)
+        st = getattr(self, "_stage", None)               # packed-face staging (prepare): 2 + 2 operations per exchange
+        self._ring.stage = st.data_ptr() if st is not None else None
+        self._ring.stage_bytes = st.numel() if st is not None else 0
         return True, self._ct.byref(self._ring)
+
+    def prepare(self, slab: torch.Tensor, halo: int) -> None:
+        """staging for the packed exchange of the native loops: four messages of both species' faces (to next / to prev /
+        from prev / from next); an ncclGroup costs per operation, so 2 + 2 packed ones beat 4 + 4 per-species ones"""
+        import os
+        if not slab.is_cuda or (self.world == 1 and not self.force_p2p) or int(os.environ.get("PERCNN_SLAB_NO_PACK", "0")):
+            self._stage = None
+            return
+        need = 8 * halo * slab[0, 0].numel() * slab.element_size()
+        st = getattr(self, "_stage", None)
+        if st is None or st.numel() < need or st.device != slab.device:
+            self._stage = torch.empty(need, dtype=torch.uint8, device=slab.device)
 
     def exchange_async(self, slab: torch.Tensor, halo: int, width: Optional[int] = None):
         """The same exchange on a side stream, ordered after everything enqueued so far on the current stream; the
@@ -349,7 +364,7 @@ class PeerHaloExchanger(HaloExchanger):
             raise err
         self._box = box.value
         self._peer = self._L.PeerRing(box.value, prev_box, next_box, slot_bytes, 0, 0)
-        self._ring = self._L.HaloRing(None, self.prev, self.next, 0, 0, None, None, None, None, ct.pointer(self._peer))
+        self._ring = self._L.HaloRing(None, self.prev, self.next, 0, 0, None, None, None, None, ct.pointer(self._peer), None, 0)
         if self.world > 1:
             dist.barrier(group=self.group)          # nobody frees / re-sizes before everybody has mapped
 
