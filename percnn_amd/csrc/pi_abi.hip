@@ -940,13 +940,21 @@ int ring_exchange(T* slab, const Problem& p, int width, const percnn_pi_halo_rin
     const size_t ss = (size_t)(p.n0 + 2 * p.halo) * plane;
     const int64_t n = p.n0, halo = p.halo;
     auto at = [&](int s, int64_t pl) { return slab + (size_t)s * ss + (size_t)pl * plane; };
-    if (!r) {                                              // single rank: periodic wrap by device-to-device copies
+    if (!r) {                                              // single rank: periodic wrap, ONE copy launch for the four faces
+        pi::PeerXfer cp{};                                 // (was four hipMemcpyAsync: 48.2 -> 44 us per fwd+bwd step on the 32 x 256^2 slab)
+        const size_t fb = cnt * sizeof(T);
+        bool vec = fb % 16 == 0;
         for (int s = 0; s < 2; ++s) {
-            if (hipError_t e = hipMemcpyAsync(at(s, halo - width), at(s, halo + n - width), cnt * sizeof(T),
-                                              hipMemcpyDeviceToDevice, st)) return (int)e;
-            if (hipError_t e = hipMemcpyAsync(at(s, halo + n), at(s, halo), cnt * sizeof(T), hipMemcpyDeviceToDevice, st))
-                return (int)e;
+            cp.src[0][s] = reinterpret_cast<const char*>(at(s, halo + n - width)); cp.dst[0][s] = reinterpret_cast<char*>(at(s, halo - width));
+            cp.src[1][s] = reinterpret_cast<const char*>(at(s, halo));             cp.dst[1][s] = reinterpret_cast<char*>(at(s, halo + n));
+            for (int d = 0; d < 2; ++d)
+                vec = vec && reinterpret_cast<uintptr_t>(cp.src[d][s]) % 16 == 0 && reinterpret_cast<uintptr_t>(cp.dst[d][s]) % 16 == 0;
         }
+        cp.bytes = fb;
+        cp.blocks_per_dir = (int)std::min<size_t>(256, std::max<size_t>(1, (fb / (vec ? 16 : 4) + 1023) / 1024));
+        if (vec) hipLaunchKernelGGL(pi::face_copy_kernel<true>, dim3(2 * cp.blocks_per_dir), dim3(256), 0, st, cp);
+        else hipLaunchKernelGGL(pi::face_copy_kernel<false>, dim3(2 * cp.blocks_per_dir), dim3(256), 0, st, cp);
+        if (hipError_t e = hipGetLastError()) return (int)e;
         return slab2 ? ring_exchange<T>(slab2, p, width2, r, st) : 0;
     }
     const int dt = ring_dtype<T>(r);
