@@ -57,6 +57,8 @@ struct Options {
                             // call, so 16 operations every second step save nothing and the two strip launches come on top
     int lane_x = 0;         // direct kernels: log2 of the lanes along x per row segment (2..6), 0 = fewest idle lanes (set_blockmap),
                             // -1 = the pre-round-2 rule (next power of two >= chunks per row)
+    int lds_win = 1;        // direct 3D kernels: in-plane stencil neighbours from an LDS row window (pi::RowWindow) instead of
+                            // L1 / L2 gathers: 0 never, 1 where it measured faster (lds_win_for), 2 whenever the shape allows
     int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
                             // small grid is spread over all CUs instead of being packed onto a few
 };
@@ -259,6 +261,7 @@ Geom make_geom(const Problem& p)
     g.lxs = 0; g.nxb = g.nrg = 0; g.nblk = 0; g.dnxb = pi::FastDiv{0u, 0u}; g.dnrg = pi::FastDiv{0u, 0u};
     g.rgt = g.nlast = 0; g.per_tile = 0; g.dper = g.drgt = g.dlast = pi::FastDiv{0u, 0u};
     g.xwin = 0; g.rz = 1;
+    g.lw_nwin = 0; g.lw_base = 0; g.d4cpr = pi::FastDiv{0u, 0u};
     g.n0 = (int)p.n0; g.n1 = (int)p.n1; g.W = (int)p.W;
     g.rows = (int)(p.n0 * p.n1);
     g.s0 = (long)(p.n1 * p.W);
@@ -300,6 +303,25 @@ int direct_block(const Problem& p, const Geom& g, int vec)
     return p.opt.block;
 }
 
+// LDS row window of the direct 3D kernels (pi::RowWindow): usable when a workgroup pass owns a contiguous chunk range of
+// the plane (one x block per row, or flat mode) and the four halo rows are no more than one fetch per lane, plane and
+// species; fills Geom::lw_* (lds_base = bytes of dynamic LDS in front of the windows) and returns the window bytes, 0 = off
+size_t lds_win_setup(const Problem& p, Geom& g, int ndim, int vec, int block, size_t elem, int rz, size_t lds_base)
+{
+    g.lw_nwin = 0;
+    if (!p.opt.lds_win || ndim != 3 || (size_t)vec * elem != 16) return 0;
+    if (g.lxs >= 0 && g.nxb != 1) return 0;
+    const long cpr = g.W / vec;
+    if (4 * cpr > block || g.n1 < 2) return 0;
+    const long nown = g.lxs < 0 ? block : (long)(block >> g.lxs) * cpr;
+    const size_t bytes = (size_t)(2 * rz) * (size_t)(nown + 4 * cpr) * 16;
+    if (lds_base + bytes > 160 * 1024) return 0;
+    g.lw_nwin = (unsigned)(nown + 4 * cpr);
+    g.lw_base = (unsigned)lds_base;
+    g.d4cpr = make_fastdiv((unsigned)(4 * cpr));
+    return bytes;
+}
+
 // ---- kernel instantiation dispatch ------------------------------------------------------------
 // planes per workgroup pass of the direct 3D kernels (the RZ > 1 flavours exist for pre-contracted blocks on 16-byte lanes)
 // Measured on MI355X (profiles/r02_direct_kernel_option_sweeps.txt, us per step rz = 1 / 2 / 4): forward 384^3 363 / 312 /
@@ -339,6 +361,15 @@ hipError_t launch_fwd(const T* h, T* out, const T* P, const Problem& p, hipStrea
     if (!set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024, p.opt.lane_x)) return hipErrorInvalidValue;
     const unsigned grid = (p.opt.fwd_blocks > 0 && g.nblk > (unsigned)p.opt.fwd_blocks) ? (unsigned)p.opt.fwd_blocks : g.nblk;
     g.xwin = (unsigned)p.opt.xcd_window;
+    if constexpr (NDIM == 3 && VEC * sizeof(T) == 16) {
+        if (const size_t wbytes = lds_win_setup(p, g, NDIM, VEC, block, sizeof(T), RZ, 0)) {
+            auto* k = pi::pi_fwd_kernel<T, NDIM, HC, VEC, RZ, true>;
+            const size_t lds = wbytes + (size_t)p.opt.lds_pad;
+            if (hipError_t e = allow_lds(k, lds)) return e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, st, h, out, P, g, p.hc);
+            return hipGetLastError();
+        }
+    }
     auto* k = pi::pi_fwd_kernel<T, NDIM, HC, VEC, RZ>;
     if (hipError_t e = allow_lds(k, (size_t)p.opt.lds_pad)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), (size_t)p.opt.lds_pad, st, h, out, P, g, p.hc);
@@ -364,10 +395,20 @@ hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* parti
     const unsigned grid = bwd_grid(p, VEC, sizeof(T), RZ);
     if (g.rows <= 0) return hipSuccess;
     if (!grid || !set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024, p.opt.lane_x)) return hipErrorInvalidValue;
-    const size_t lds = align_up((size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T), 16) +
-                       (size_t)(block / pi::WAVE) * 2 * sizeof(double) +
-                       ((WGRAD && HC == pi::POLY) ? (size_t)20 * (block + 8) * sizeof(T) : 0) +   // moment transpose scratch
-                       (size_t)p.opt.lds_pad;
+    const size_t lds_head = align_up((size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T), 16) +
+                            (size_t)(block / pi::WAVE) * 2 * sizeof(double);
+    const size_t scratch = (WGRAD && HC == pi::POLY) ? (size_t)20 * (block + 8) * sizeof(T) : 0;   // moment transpose scratch
+    if constexpr (NDIM == 3 && VEC * sizeof(T) == 16) {
+        // the row windows overlay the moment scratch (used after the last pass only)
+        if (const size_t wbytes = lds_win_setup(p, g, NDIM, VEC, block, sizeof(T), RZ, lds_head)) {
+            auto* k = pi::pi_bwd_kernel<T, NDIM, HC, VEC, WGRAD, RZ, true>;
+            const size_t lds = lds_head + (wbytes > scratch ? wbytes : scratch) + (size_t)p.opt.lds_pad;
+            if (hipError_t e = allow_lds(k, lds)) return e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, st, h, G, inj, Gp, partials, P, g, p.hc);
+            return hipGetLastError();
+        }
+    }
+    const size_t lds = lds_head + scratch + (size_t)p.opt.lds_pad;
     auto* k = pi::pi_bwd_kernel<T, NDIM, HC, VEC, WGRAD, RZ>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, st, h, G, inj, Gp, partials, P, g, p.hc);
@@ -1408,6 +1449,11 @@ int apply_option(Options& o, const char* key, long value)
     if (!std::strcmp(key, "l2_tile_kb")) {
         if (value < 0 || value > 16384) return PERCNN_PI_EINVAL;
         o.l2_tile_kb = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "lds_win")) {                          // 0 = never, 1 = size heuristic, 2 = whenever eligible
+        if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
+        o.lds_win = (int)value;
         return 0;
     }
     if (!std::strcmp(key, "lds_pad")) {

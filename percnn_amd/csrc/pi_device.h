@@ -114,6 +114,9 @@ __device__ __forceinline__ int wrap_near(int i, int n) { return i < 0 ? i + n : 
 struct FastDiv {
     unsigned m, s;
     __device__ __forceinline__ unsigned div(unsigned x) const { return m ? (__umulhi(x, m) >> s) : x; }
+    // d >= 2 known: no test of m (a wave-uniform test becomes a scalar branch, i.e. a basic-block boundary that keeps the
+    // scheduler from batching the loads on either side of it)
+    __device__ __forceinline__ unsigned div_nz(unsigned x) const { return __umulhi(x, m) >> s; }
 };
 
 // XCD-aware block remap: hand each XCD (private 4 MiB L2) a contiguous range of the grid so the

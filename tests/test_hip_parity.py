@@ -745,7 +745,11 @@ def test_stream3d_bitwise(opts, shape, dtype, hc, hip_device):
                                   "rz=1,l2_tile_kb=4,l2_tile_min_kb=0,block=128",
                                   "rz=2,fwd_blocks=8,bwd_cpl=1", "rz=4,xcd_window=16,bwd_cpl=4", "block_small=0,rz=2", "vec=1",
                                   "lane_x=2", "lane_x=3,rz=2", "lane_x=6,block=64", "lane_x=-1", "lane_x=7", "lane_x=7,rz=2,block=64",
-                                  "lane_x=7,rz=4,l2_tile_kb=1,l2_tile_min_kb=0"])
+                                  "lane_x=7,rz=4,l2_tile_kb=1,l2_tile_min_kb=0",
+                                  # LDS row window (round 3) off / forced, with every decomposition it rides on
+                                  "lds_win=0,rz=1", "lds_win=0,rz=2", "lds_win=2,rz=1", "lds_win=2,rz=2,bwd_cpl=1", "lds_win=2,rz=4",
+                                  "lds_win=2,rz=2,lane_x=7", "lds_win=2,rz=1,lane_x=7,block=128", "lds_win=2,rz=2,block=128,bwd_cpl=4",
+                                  "lds_win=2,rz=4,lane_x=7,l2_tile_kb=1,l2_tile_min_kb=0", "lds_win=2,rz=2,fwd_blocks=8"])
 @pytest.mark.parametrize("shape,dtype", [((9, 12, 64), np.float32), ((6, 33, 40), np.float32), ((3, 8, 16), np.float32),
                                          ((17, 20, 132), np.float32), ((10, 24, 48), np.float64), ((2, 6, 8), np.float64)])
 def test_direct_kernel_variants_bitwise(opts, shape, dtype, hip_device):
