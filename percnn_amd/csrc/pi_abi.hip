@@ -12,6 +12,7 @@
 #include "pi_kernels.h"
 #include "pi_tile2d.h"
 #include "pi_stream3d.h"
+#include "pi_brick3d.h"
 #include "pi_contract.h"
 #include "pi_peer.h"
 #include "pi_adv.h"
@@ -57,8 +58,11 @@ struct Options {
                             // call, so 16 operations every second step save nothing and the two strip launches come on top
     int lane_x = 0;         // direct kernels: log2 of the lanes along x per row segment (2..6), 0 = fewest idle lanes (set_blockmap),
                             // -1 = the pre-round-2 rule (next power of two >= chunks per row)
-    int lds_win = 1;        // direct 3D kernels: in-plane stencil neighbours from an LDS row window (pi::RowWindow) instead of
-                            // L1 / L2 gathers: 0 never, 1 where it measured faster (lds_win_for), 2 whenever the shape allows
+    int brick3d = 1;        // 3D: brick kernels (pi_brick3d.h) for one-step launches where the shape allows: 0 never, 1 by
+                            // size (brick_ok), 2 whenever eligible
+    int brick_rz = 0;       // planes per brick (1, 2, 4; 0 = by size)
+    int brick_wgs = 0;      // adjoint brick kernel: resident workgroups per CU that walk the bricks (0 = 4 / 2 by planes per brick)
+    int brick_wt = 1;       // brick kernels store their output frame write-through (BrickGeom::wt)
     int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
                             // small grid is spread over all CUs instead of being packed onto a few
 };
@@ -261,7 +265,6 @@ Geom make_geom(const Problem& p)
     g.lxs = 0; g.nxb = g.nrg = 0; g.nblk = 0; g.dnxb = pi::FastDiv{0u, 0u}; g.dnrg = pi::FastDiv{0u, 0u};
     g.rgt = g.nlast = 0; g.per_tile = 0; g.dper = g.drgt = g.dlast = pi::FastDiv{0u, 0u};
     g.xwin = 0; g.rz = 1;
-    g.lw_nwin = 0; g.lw_base = 0; g.d4cpr = pi::FastDiv{0u, 0u};
     g.n0 = (int)p.n0; g.n1 = (int)p.n1; g.W = (int)p.W;
     g.rows = (int)(p.n0 * p.n1);
     g.s0 = (long)(p.n1 * p.W);
@@ -303,25 +306,6 @@ int direct_block(const Problem& p, const Geom& g, int vec)
     return p.opt.block;
 }
 
-// LDS row window of the direct 3D kernels (pi::RowWindow): usable when a workgroup pass owns a contiguous chunk range of
-// the plane (one x block per row, or flat mode) and the four halo rows are no more than one fetch per lane, plane and
-// species; fills Geom::lw_* (lds_base = bytes of dynamic LDS in front of the windows) and returns the window bytes, 0 = off
-size_t lds_win_setup(const Problem& p, Geom& g, int ndim, int vec, int block, size_t elem, int rz, size_t lds_base)
-{
-    g.lw_nwin = 0;
-    if (!p.opt.lds_win || ndim != 3 || (size_t)vec * elem != 16) return 0;
-    if (g.lxs >= 0 && g.nxb != 1) return 0;
-    const long cpr = g.W / vec;
-    if (4 * cpr > block || g.n1 < 2) return 0;
-    const long nown = g.lxs < 0 ? block : (long)(block >> g.lxs) * cpr;
-    const size_t bytes = (size_t)(2 * rz) * (size_t)(nown + 4 * cpr) * 16;
-    if (lds_base + bytes > 160 * 1024) return 0;
-    g.lw_nwin = (unsigned)(nown + 4 * cpr);
-    g.lw_base = (unsigned)lds_base;
-    g.d4cpr = make_fastdiv((unsigned)(4 * cpr));
-    return bytes;
-}
-
 // ---- kernel instantiation dispatch ------------------------------------------------------------
 // planes per workgroup pass of the direct 3D kernels (the RZ > 1 flavours exist for pre-contracted blocks on 16-byte lanes)
 // Measured on MI355X (profiles/r02_direct_kernel_option_sweeps.txt, us per step rz = 1 / 2 / 4): forward 384^3 363 / 312 /
@@ -361,15 +345,6 @@ hipError_t launch_fwd(const T* h, T* out, const T* P, const Problem& p, hipStrea
     if (!set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024, p.opt.lane_x)) return hipErrorInvalidValue;
     const unsigned grid = (p.opt.fwd_blocks > 0 && g.nblk > (unsigned)p.opt.fwd_blocks) ? (unsigned)p.opt.fwd_blocks : g.nblk;
     g.xwin = (unsigned)p.opt.xcd_window;
-    if constexpr (NDIM == 3 && VEC * sizeof(T) == 16) {
-        if (const size_t wbytes = lds_win_setup(p, g, NDIM, VEC, block, sizeof(T), RZ, 0)) {
-            auto* k = pi::pi_fwd_kernel<T, NDIM, HC, VEC, RZ, true>;
-            const size_t lds = wbytes + (size_t)p.opt.lds_pad;
-            if (hipError_t e = allow_lds(k, lds)) return e;
-            hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, st, h, out, P, g, p.hc);
-            return hipGetLastError();
-        }
-    }
     auto* k = pi::pi_fwd_kernel<T, NDIM, HC, VEC, RZ>;
     if (hipError_t e = allow_lds(k, (size_t)p.opt.lds_pad)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), (size_t)p.opt.lds_pad, st, h, out, P, g, p.hc);
@@ -395,20 +370,10 @@ hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* parti
     const unsigned grid = bwd_grid(p, VEC, sizeof(T), RZ);
     if (g.rows <= 0) return hipSuccess;
     if (!grid || !set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024, p.opt.lane_x)) return hipErrorInvalidValue;
-    const size_t lds_head = align_up((size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T), 16) +
-                            (size_t)(block / pi::WAVE) * 2 * sizeof(double);
-    const size_t scratch = (WGRAD && HC == pi::POLY) ? (size_t)20 * (block + 8) * sizeof(T) : 0;   // moment transpose scratch
-    if constexpr (NDIM == 3 && VEC * sizeof(T) == 16) {
-        // the row windows overlay the moment scratch (used after the last pass only)
-        if (const size_t wbytes = lds_win_setup(p, g, NDIM, VEC, block, sizeof(T), RZ, lds_head)) {
-            auto* k = pi::pi_bwd_kernel<T, NDIM, HC, VEC, WGRAD, RZ, true>;
-            const size_t lds = lds_head + (wbytes > scratch ? wbytes : scratch) + (size_t)p.opt.lds_pad;
-            if (hipError_t e = allow_lds(k, lds)) return e;
-            hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, st, h, G, inj, Gp, partials, P, g, p.hc);
-            return hipGetLastError();
-        }
-    }
-    const size_t lds = lds_head + scratch + (size_t)p.opt.lds_pad;
+    const size_t lds = align_up((size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T), 16) +
+                       (size_t)(block / pi::WAVE) * 2 * sizeof(double) +
+                       ((WGRAD && HC == pi::POLY) ? (size_t)20 * (block + 8) * sizeof(T) : 0) +   // moment transpose scratch
+                       (size_t)p.opt.lds_pad;
     auto* k = pi::pi_bwd_kernel<T, NDIM, HC, VEC, WGRAD, RZ>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, st, h, G, inj, Gp, partials, P, g, p.hc);
@@ -513,9 +478,14 @@ constexpr int STREAM_TY = 4;
 
 // VEC such that one wave spans a full row (W == 64*VEC), 0 if the shape does not qualify
 template <typename T>
-int stream3d_vec(const Problem& p, std::initializer_list<const void*> ptrs)
+int stream3d_vec(const Problem& p, std::initializer_list<const void*> ptrs, bool adjoint)
 {
     if (!p.opt.stream3d || p.ndim != 3) return 0;
+    // Round 3 (brick kernels, pi_brick3d.h): the z-march keeps the forward step from ~8 M points on (256^3: 63.8 vs 68.0 us);
+    // below that and for every adjoint step the bricks are faster (64 x 256^2: 17.2 + 37.5 vs 19.1 + 39.6 us, 256^3 adjoint
+    // 139.8 vs 144.2) -- which also retires the streaming adjoint's register spills
+    if (p.opt.stream3d == 1 && p.opt.brick3d && (adjoint || (p.n0 + (p.slab ? 2 * p.halo : 0)) * p.n1 * p.W < ((int64_t)1 << 23)))
+        return 0;
     // measured on MI355X: the plane-streaming kernels win from ~4M points per rank upwards (256^3: 4.1 vs
     // 2.7 TB/s forward); at 128^3 there are too few waves to cover their per-plane barrier chain.
     // Rows as wide as a full 16-B/lane wave (W = 256 fp32 -- the 32 x 256^2 slabs of the 8-GPU 256^3 problem) win
@@ -583,13 +553,137 @@ hipError_t stream3d(int vec, const T* f, T* out, const T* h, const T* inj, doubl
 #undef CALL_S3
 }
 
+// ---- 3D brick kernels (pi_brick3d.h) --------------------------------------------------------------
+// rows of up to 64 sixteen-byte chunks, planes below 4 GiB; returns planes per brick, 0 = not this path
+template <typename T>
+int brick_rz_for(const Problem& p, int vec, bool adjoint)
+{
+    if (!p.opt.brick3d || p.ndim != 3 || p.hc < 0 || (size_t)vec * sizeof(T) != 16) return 0;
+    const int64_t cpr = p.W / vec;
+    if (cpr > pi::BRICK_CPR_MAX || p.n1 < 2 || p.n1 * p.W * (int64_t)sizeof(T) >= (int64_t(1) << 32)) return 0;
+    // planes per brick (profiles/r03_brick_sweeps.txt): sharing plane neighbours pays in the forward kernel from ~2 M points on
+    // (128^3: 8.8 -> 8.4 us, 200^3: 33 -> 30); the adjoint keeps one plane (more workgroups in flight beats the reuse: 144^3 25.4 vs
+    // 26.1 us, 200^3 59.3 vs 60.9; 128^3 ties); small grids need the workgroups (48^3: 99 k vs 89 k steps/s)
+    // (beyond ~12 M points the adjoint is DRAM-bound and takes two planes as well: 256^3 172 -> 140 us)
+    int rz = p.opt.brick_rz ? p.opt.brick_rz : (p.n >= (adjoint ? (int64_t(3) << 22) : (int64_t(1) << 21)) ? 2 : 1);
+    if (rz > 1 && p.hc != 0) rz = 1;                        // the multi-plane flavours exist for pre-contracted blocks
+    return rz;
+}
+
+pi::BrickGeom make_brick_geom(const Problem& p, int vec, int rz)
+{
+    const Geom g = make_geom(p);
+    pi::BrickGeom b;
+    b.n0 = g.n0; b.n1 = g.n1; b.cpr = g.W / vec; b.total = b.n1 * b.cpr;
+    b.nrg = (b.total + pi::BRICK_NT - 1) / pi::BRICK_NT;
+    b.nblk = (unsigned)((long)b.nrg * ((g.n0 + rz - 1) / rz));
+    b.wrap0 = g.wrap0; b.s0 = g.s0; b.ss = g.ss; b.off = g.off;
+    b.dnrg = make_fastdiv((unsigned)b.nrg); b.dcpr = make_fastdiv((unsigned)b.cpr);
+    b.nseg = (4 * b.cpr + 63) / 64; b.ntask = 2 * rz * b.nseg; b.dnseg = make_fastdiv((unsigned)b.nseg);
+    b.wt = p.opt.brick_wt;
+    return b;
+}
+
+template <typename T, int HC, int RZ>
+hipError_t launch_brick_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const pi::BrickGeom b = make_brick_geom(p, VEC, RZ);
+    if (b.n0 <= 0) return hipSuccess;
+    const size_t lds = (size_t)2 * RZ * pi::BRICK_WB + (size_t)p.opt.lds_pad;
+    auto* k = pi::pi_fwd3d_brick_kernel<T, HC, RZ>;
+    if (hipError_t e = allow_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(b.nblk), dim3(pi::BRICK_NT), lds, st, h, out, P, b, p.hc);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t brick_fwd(int rz, const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
+{
+    if (p.hc == 0) {
+        if (rz == 4) return launch_brick_fwd<T, pi::POLY, 4>(h, out, P, p, st);
+        if (rz == 2) return launch_brick_fwd<T, pi::POLY, 2>(h, out, P, p, st);
+        return launch_brick_fwd<T, pi::POLY, 1>(h, out, P, p, st);
+    }
+    switch (p.hc) {
+        case 2:  return launch_brick_fwd<T, 2, 1>(h, out, P, p, st);
+        case 4:  return launch_brick_fwd<T, 4, 1>(h, out, P, p, st);
+        case 8:  return launch_brick_fwd<T, 8, 1>(h, out, P, p, st);
+        default: return launch_brick_fwd<T, 0, 1>(h, out, P, p, st);
+    }
+}
+
+// The adjoint brick kernel pays a per-workgroup tail (block reduction of the 22 sums, ~1.4 us of a 5 us pass at 128^3): a
+// grid of what is resident at once (4 workgroups per CU with one-plane bricks, 2 with more) walks the bricks instead, every
+// workgroup the same number of them where the count allows.  Probe (128^3, us per adjoint step): 2048 one-brick workgroups
+// 17.4, 1024 two-brick ones 17.2, 768 (uneven) 17.8; two-plane bricks 1024 / 512 workgroups 18.1 / 17.0.
+unsigned brick_bwd_grid(const Problem& p, int vec, int rz)
+{
+    const pi::BrickGeom b = make_brick_geom(p, vec, rz);
+    static int cu_count[16] = {};                           // per device, asked once (benign race: same value)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
+        if (!cu_count[dev]) {
+            int n = 0;
+            cu_count[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        }
+        cus = cu_count[dev];
+    }
+    const int per_cu = p.opt.brick_wgs ? p.opt.brick_wgs : (rz == 1 ? 4 : 2);
+    unsigned cap = (unsigned)(cus * per_cu);
+    if (cap > (unsigned)MAX_BWD_BLOCKS) cap = MAX_BWD_BLOCKS;
+    if (b.nblk <= cap) return b.nblk;
+    // ... while that is at most two bricks each: a workgroup takes its bricks one after the other, nothing of the next one is
+    // in flight while it computes (200^3, one-plane bricks: 4000 two-brick workgroups 59.3 us per step, 1000 eight-brick ones 69.6)
+    if (!p.opt.brick_wgs && b.nblk > 2 * cap) cap = MAX_BWD_BLOCKS;
+    const unsigned k = (b.nblk + cap - 1) / cap;            // bricks per workgroup
+    return (b.nblk + k - 1) / k;
+}
+
+template <typename T, int HC, int RZ, bool MOM>
+hipError_t launch_brick_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partials, const T* P, const Problem& p,
+                            hipStream_t st)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const pi::BrickGeom b = make_brick_geom(p, VEC, RZ);
+    if (b.n0 <= 0) return hipSuccess;
+    const unsigned grid = brick_bwd_grid(p, VEC, RZ);
+    const size_t head = (size_t)(pi::BRICK_NT / pi::WAVE) * 2 * sizeof(double);
+    const size_t windows = (size_t)2 * RZ * pi::BRICK_WB, scratch = MOM ? (size_t)(32 + 20 * (pi::BRICK_NT + 8)) * sizeof(T) : 0;
+    const size_t lds = head + (windows > scratch ? windows : scratch) + (size_t)p.opt.lds_pad;
+    auto* k = pi::pi_adj3d_brick_kernel<T, HC, RZ, MOM>;
+    if (hipError_t e = allow_lds(k, lds)) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(pi::BRICK_NT), lds, st, h, G, inj, Gp, partials, P, b, p.hc);
+    return hipGetLastError();
+}
+
+// mom: all gradients of a pre-contracted block in the sweep launch; else adjoint state + diffusion-coefficient sums
+template <typename T>
+hipError_t brick_bwd(int rz, bool mom, const T* h, const T* G, const T* inj, T* Gp, double* partials, const T* P,
+                     const Problem& p, hipStream_t st)
+{
+#define CALL_BB(HC, RZ, MOM) launch_brick_bwd<T, HC, RZ, MOM>(h, G, inj, Gp, partials, P, p, st)
+    if (p.hc == 0) {
+        if (mom) return rz == 4 ? CALL_BB(pi::POLY, 4, true) : (rz == 2 ? CALL_BB(pi::POLY, 2, true) : CALL_BB(pi::POLY, 1, true));
+        return rz == 4 ? CALL_BB(pi::POLY, 4, false) : (rz == 2 ? CALL_BB(pi::POLY, 2, false) : CALL_BB(pi::POLY, 1, false));
+    }
+    switch (p.hc) {
+        case 2:  return CALL_BB(2, 1, false);
+        case 4:  return CALL_BB(4, 1, false);
+        case 8:  return CALL_BB(8, 1, false);
+        default: return CALL_BB(0, 1, false);
+    }
+#undef CALL_BB
+}
+
 template <typename T>
 hipError_t step_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
 {
     if (p.hc == -1) return adv_fwd<T>(h, out, P, p, st);
-    if (const int sv = stream3d_vec<T>(p, {h, out}))
+    if (const int sv = stream3d_vec<T>(p, {h, out}, false))
         return stream3d<T, false>(sv, h, out, nullptr, nullptr, nullptr, P, p, st, nullptr);
     const int vec = pick_vec<T>(p, {h, out});
+    if (const int brz = brick_rz_for<T>(p, vec, false)) return brick_fwd<T>(brz, h, out, P, p, st);
     {
         constexpr int V = pi::vec_width<T>::value;
         const int rz = direct_rz<T>(p, vec, false);
@@ -610,9 +704,14 @@ hipError_t step_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partial
 {
     if (p.hc == -1) return adv_bwd<T>(h, G, inj, Gp, partials, P, p, st, grid_out);   // always fused (tiny grids)
     if (!WGRAD || (p.hc == 0 && sizeof(T) == 4))            // fused flavour of the streaming kernel: float32 poly mode only
-        if (const int sv = stream3d_vec<T>(p, {h, G, inj, Gp}))
+        if (const int sv = stream3d_vec<T>(p, {h, G, inj, Gp}, true))
             return stream3d<T, true>(sv, G, Gp, h, inj, partials, P, p, st, grid_out, WGRAD ? 1 : 0);
     const int vec = pick_vec<T>(p, {h, G, inj, Gp});
+    if (!WGRAD || p.hc == 0)                                  // factored blocks with all gradients in the launch: direct kernel
+        if (const int brz = brick_rz_for<T>(p, vec, true)) {
+            if (grid_out) *grid_out = brick_bwd_grid(p, vec, brz);
+            return brick_bwd<T>(brz, WGRAD, h, G, inj, Gp, partials, P, p, st);
+        }
     const int rz = direct_rz<T>(p, vec, true);
     if (grid_out) *grid_out = bwd_grid(p, vec, sizeof(T), rz);
     {
@@ -1260,7 +1359,7 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     // (the streaming kernel's fused flavour exists for float32 poly mode)
     const bool f32poly = hc == 0 && sizeof(T) == 4;
     const bool direct_sweep = !tile_eligible<T>(p, {traj, g_traj, g_h0, adj}, true) &&
-                              (f32poly || !stream3d_vec<T>(p, {traj, g_traj, g_h0, adj}));
+                              (f32poly || !stream3d_vec<T>(p, {traj, g_traj, g_h0, adj}, true));
     const bool tile_fused = !direct_sweep && tile_eligible<T>(p, {traj, g_traj, g_h0, adj}, true) && tile_fuse_ok<T>(p);
     // (float64 pre-contracted blocks too since round 2: per-lane double accumulators; lambda-omega beyond the tile regime,
     // backward per step 1200^2 29.0 -> 25.1 us, 2048^2 71.5 -> 60.4, 3072^2 187 -> 143 -- no pi_moments_kernel pass)
@@ -1451,9 +1550,20 @@ int apply_option(Options& o, const char* key, long value)
         o.l2_tile_kb = (int)value;
         return 0;
     }
-    if (!std::strcmp(key, "lds_win")) {                          // 0 = never, 1 = size heuristic, 2 = whenever eligible
+    if (!std::strcmp(key, "brick3d")) {                          // 0 = never, 1 = size heuristic, 2 = whenever eligible
         if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
-        o.lds_win = (int)value;
+        o.brick3d = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "brick_wt")) { o.brick_wt = value != 0; return 0; }
+    if (!std::strcmp(key, "brick_wgs")) {
+        if (value < 0 || value > 16) return PERCNN_PI_EINVAL;
+        o.brick_wgs = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "brick_rz")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return PERCNN_PI_EINVAL;
+        o.brick_rz = (int)value;
         return 0;
     }
     if (!std::strcmp(key, "lds_pad")) {

@@ -1,0 +1,460 @@
+// pi_brick3d.h -- "brick" step kernels for 3D grids (forward and adjoint): one launch = one time step, built around what the
+// device timeline of the direct kernels showed at 128^3 (tools/ubench/step3d_probe.hip, DESIGN.md "Brick kernels"):
+//   * the load phase is bound by the bytes REQUESTED through the vector L1 (~64 B/clk per CU), not by what reaches the
+//     L2: a pass that asks for every stencil neighbour separately spends 2.3 us just issuing its loads;
+//   * the compute phase is bound by VALU ISSUE (~2 ns per instruction and SIMD whatever its type), and two thirds of the
+//     instructions of the generic direct kernels were integer overhead (per-lane 64-bit addresses, wraps, spilled SGPRs).
+// So: a workgroup of 256 lanes owns a BRICK = 256 consecutive 16-byte chunks of RZ consecutive planes (whole rows at the
+// usual widths; any width works, rows follow each other in memory);
+//   * z neighbours: the lane's own chunk in planes i0-2 .. i0+RZ+1, RZ + 4 loads per species with SCALAR plane bases and
+//     ONE 32-bit lane offset (no per-lane address arithmetic at all);
+//   * y / x neighbours: LDS.  Per (plane, species) the brick's chunks plus two rows of chunks before and after them (the
+//     periodic wrap of the plane resolved when they are staged) sit in one window of fixed stride, so every neighbour is a
+//     ds_read at lane address + immediate; the four halo rows are fetched by whole waves (wave-uniform task -> scalar
+//     base, lane = chunk), at most 2 * RZ requests per lane;
+//   * ONE barrier per pass; stores with scalar bases.
+// Requests per lane and pass: 2 * (RZ + 4) + <= 2 * RZ  (RZ = 2: 14-16, against 36 in the direct kernel), VALU
+// instructions per pass roughly halved.  Arithmetic and its order are those of pi::star / pi_fwd_kernel / pi_bwd_kernel:
+// results are bit-identical (tests/test_hip_parity.py::test_brick3d_bitwise).
+#pragma once
+#include "pi_device.h"
+#include "pi_kernels.h"
+
+namespace pi {
+
+constexpr int BRICK_NT = 256;                        // lanes per workgroup = own chunks per plane of a brick
+constexpr int BRICK_CPR_MAX = 64;                    // rows of up to 64 chunks (W <= 256 float32 / 128 float64)
+constexpr int BRICK_WCH = BRICK_NT + 4 * BRICK_CPR_MAX;   // chunks per LDS window (fixed stride -> immediate offsets)
+constexpr int BRICK_WB = BRICK_WCH * 16;             // 8 KiB per (plane, species)
+
+struct BrickGeom {
+    int n0, n1;            // planes this call computes, rows per plane
+    int cpr, total;        // chunks per row, per plane
+    int nrg;               // bricks per plane group = ceil(total / 256)
+    unsigned nblk;         // nrg * ceil(n0 / RZ)
+    int wrap0;             // 1: axis 0 periodic, 0: slab layout (two halo planes on either side of the computed range)
+    long s0, ss, off;      // plane stride, species stride, first computed point (elements), as in Geom
+    FastDiv dnrg, dcpr;
+    int nseg, ntask;       // halo segments of 64 chunks per (plane, species) = ceil(4 cpr / 64); ntask = 2 * RZ * nseg
+    FastDiv dnseg;
+    int wt;                // 1: the output frame is stored write-through (sc1).  Plain stores leave the whole frame dirty in the
+                           // L2s and the kernel boundary then waits for its write-back (16 MiB at 128^3: ~1.5 us of a 9.4 us
+                           // step, tools/ubench/step3d_probe.hip); written through, that traffic overlaps the waves still
+                           // loading / computing.  (The direct kernels of round 2 did not gain from it: their boundary was
+                           // hidden behind a longer body.)
+};
+
+// what a lane of a brick knows: `eb`, `lo`, row-neighbour / x-halo LDS addresses are per lane, the rest is wave-uniform
+template <typename T, int RZ>
+struct Brick {
+    static constexpr int VEC = 16 / (int)sizeof(T);
+    static constexpr int MH = 2 * RZ;                // halo tasks per wave: 2 RZ nseg / 4 waves, nseg <= 4
+    int i0, cb, nown;                                // first plane of the group; first own chunk of the plane; how many
+    bool valid;
+    unsigned eb;                                     // byte offset of the lane's chunk inside a plane
+    unsigned lo, ym2, ym1, yp1, yp2, xl, xr;         // LDS byte addresses (window 0): own chunk, row neighbours, x-halo pairs
+    Pack<T, VEC> hreg[MH];
+    unsigned hoff[MH];
+
+    __device__ __forceinline__ void locate(const BrickGeom& g, unsigned vb, unsigned lds_base)
+    {
+        const unsigned pg = g.dnrg.div(vb), rg = vb - pg * (unsigned)g.nrg;
+        i0 = (int)pg * RZ;
+        cb = (int)rg * BRICK_NT;
+        nown = min(BRICK_NT, g.total - cb);
+        const int tid = (int)threadIdx.x;
+        valid = tid < nown;
+        const int own = min(tid, nown - 1);                            // idle lanes shadow the last chunk (never stored)
+        const unsigned idx = (unsigned)(cb + own);
+        eb = idx * 16u;
+        const unsigned row = g.dcpr.div(idx), xc = idx - row * (unsigned)g.cpr;
+        const unsigned Wb = (unsigned)g.cpr * 16u;
+        lo = lds_base + (unsigned)(2 * g.cpr + own) * 16u;
+        ym2 = lo - 2u * Wb; ym1 = lo - Wb; yp1 = lo + Wb; yp2 = lo + 2u * Wb;
+        xl = xc > 0u ? lo - 2u * (unsigned)sizeof(T) : lo + Wb - 2u * (unsigned)sizeof(T);
+        xr = xc + 1u < (unsigned)g.cpr ? lo + 16u : lo + 16u - Wb;
+    }
+
+    // the four halo rows of every (plane, species) of the brick: whole waves take 64-chunk segments
+    __device__ __forceinline__ void request_halo(const T* __restrict__ f, const BrickGeom& g, unsigned lds_base)
+    {
+        const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+        const int cpr = g.cpr;
+#pragma unroll
+        for (int m = 0; m < MH; ++m) {
+            const int task = wave + 4 * m;
+            hoff[m] = ~0u;
+            if (task < g.ntask) {                                      // wave-uniform
+                const int c = (int)g.dnseg.div((unsigned)task), sg = task - c * g.nseg;    // c = 2 * plane + species
+                int hidx = sg * 64 + lane;
+                const bool ok = hidx < 4 * cpr;
+                hidx = min(hidx, 4 * cpr - 1);
+                const int wp = hidx + (hidx >= 2 * cpr ? nown : 0);    // chunk of the window
+                int pc = cb - 2 * cpr + wp;                            // chunk of the plane, periodic
+                pc += pc < 0 ? g.total : (pc >= g.total ? -g.total : 0);
+                const int pl = min(i0 + (c >> 1), g.n0 - 1);           // partial last group: stay inside the field
+                const char* base = sgpr_ptr(reinterpret_cast<const char*>(f + ((c & 1) ? g.ss : 0L) + g.off + (long)pl * g.s0));
+                hreg[m] = ldb<T, VEC>(base, (unsigned)pc * 16u);
+                hoff[m] = ok ? lds_base + (unsigned)c * (unsigned)BRICK_WB + (unsigned)wp * 16u : ~0u;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void commit(unsigned char* smem, const PlaneWindow<T, VEC, RZ> (&win)[2]) const
+    {
+#pragma unroll
+        for (int j = 0; j < RZ; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                *reinterpret_cast<Pack<T, VEC>*>(smem + lo + (2 * j + s) * BRICK_WB) = win[s].w[j + 2];
+#pragma unroll
+        for (int m = 0; m < MH; ++m)
+            if (hoff[m] != ~0u) *reinterpret_cast<Pack<T, VEC>*>(smem + hoff[m]) = hreg[m];
+    }
+
+    // rows, then the fastest axis, onto `lap` (pi::star2_inplane's order); window c = 2 * plane + species
+    template <int FLIP>
+    __device__ __forceinline__ void inplane(const unsigned char* smem, int c, const T* __restrict__ P,
+                                            const Pack<T, VEC>& ctr, T (&lap)[VEC]) const
+    {
+        const unsigned yo[4] = {FLIP > 0 ? ym2 : yp2, FLIP > 0 ? ym1 : yp1, FLIP > 0 ? yp1 : ym1, FLIP > 0 ? yp2 : ym2};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const Pack<T, VEC> nb = *reinterpret_cast<const Pack<T, VEC>*>(smem + yo[t] + c * BRICK_WB);
+            const T w = P[P_TAPS + 4 + t];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) lap[i] = fma_(w, nb.v[i], lap[i]);
+        }
+        T win[VEC + 4];
+        const Pack<T, 2> l = *reinterpret_cast<const Pack<T, 2>*>(smem + xl + c * BRICK_WB);
+        const Pack<T, 2> r = *reinterpret_cast<const Pack<T, 2>*>(smem + xr + c * BRICK_WB);
+        win[0] = l.v[0]; win[1] = l.v[1];
+        win[VEC + 2] = r.v[0]; win[VEC + 3] = r.v[1];
+        Pack<T, VEC> cc = ctr;
+        keep_in_regs(cc);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) win[2 + i] = cc.v[i];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = FLIP * (t < 2 ? t - 2 : t - 1);
+            const T w = P[P_TAPS + 8 + t];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) lap[i] = fma_(w, win[2 + i + k], lap[i]);
+        }
+    }
+};
+
+// the window of plane neighbours reads Geom; the brick kernels carry the few fields it needs
+__device__ __forceinline__ Geom brick_as_geom(const BrickGeom& b)
+{
+    Geom g;
+    g.n0 = b.n0; g.wrap0 = b.wrap0; g.s0 = b.s0;
+    return g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: out = h + dt * (coef * Lap(h) + react(h))      (one brick per workgroup: gridDim.x == g.nblk)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int HC, int RZ>
+__global__ void __launch_bounds__(BRICK_NT)
+pi_fwd3d_brick_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict__ P, BrickGeom g, int hc_rt)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int hc = HC > 0 ? HC : hc_rt;
+    PI_STAMP3(0);
+    Brick<T, RZ> B;
+    B.locate(g, xcd_remap(blockIdx.x, gridDim.x), 0u);
+    Lane L;
+    L.i0 = B.i0; L.eb = B.eb;
+    Geom gg = brick_as_geom(g);
+    const T* hs[2] = {h + g.off, h + g.ss + g.off};
+    PlaneWindow<T, VEC, RZ> win[2];
+    win[0].load(hs[0], gg, L);
+    win[1].load(hs[1], gg, L);
+    B.request_halo(h, g, 0u);
+    PI_STAMP3(1);
+    B.commit(smem_raw, win);
+    PI_STAMP3(2);
+    lds_barrier();
+    PI_STAMP3(3);
+    const T dt = P[P_DT];
+#pragma unroll
+    for (int j = 0; j < RZ; ++j) {
+        const int iz = B.i0 + j;
+        if (iz >= g.n0) break;                               // partial last plane group (block-uniform)
+        const Pack<T, VEC> cu = win[0].w[j + 2], cv = win[1].w[j + 2];
+        T lap[2][VEC];
+        win[0].template planes<+1>(j, P, lap[0]);
+        win[1].template planes<+1>(j, P, lap[1]);
+        B.template inplane<+1>(smem_raw, 2 * j, P, cu, lap[0]);
+        B.template inplane<+1>(smem_raw, 2 * j + 1, P, cv, lap[1]);
+#pragma clang loop unroll(disable)
+        for (int s = 0; s < 2; ++s) {
+            T rr[VEC];
+            if constexpr (HC == POLY) {
+                const T* c = P + P_W + 10 * s;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) rr[i] = poly_r(c, cu.v[i], cv.v[i]);
+            } else {
+                const T* W = P + P_W + s * species_block(hc);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) rr[i] = W[10 * hc];
+                W10<T> nx = load_w10(W);
+#pragma clang loop unroll(disable)
+                for (int jj = 0; jj < hc; ++jj) {
+                    const W10<T> c = nx;
+                    if (jj + 1 < hc) nx = load_w10(W + 10 * (jj + 1));
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const T a1 = fma_(c.w[0], cu.v[i], fma_(c.w[1], cv.v[i], c.w[2]));
+                        const T a2 = fma_(c.w[3], cu.v[i], fma_(c.w[4], cv.v[i], c.w[5]));
+                        const T a3 = fma_(c.w[6], cu.v[i], fma_(c.w[7], cv.v[i], c.w[8]));
+                        rr[i] = fma_(c.w[9], (a1 * a2) * a3, rr[i]);
+                    }
+                }
+            }
+            const T coef = P[P_COEF + s];
+            Pack<T, VEC> o;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const T hv = s == 0 ? cu.v[i] : cv.v[i];
+                const T lp = s == 0 ? lap[0][i] : lap[1][i];
+                const T res = coef * lp + rr[i];            // two roundings (train_3drd.py:133-134)
+                const T inc = res * dt;
+                o.v[i] = hv + inc;
+            }
+            char* po = const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(out + s * g.ss + g.off + (long)iz * g.s0)));
+            if (B.valid) {
+                if (g.wt) stb_wt<T, VEC>(po, B.eb, o);      // wave-uniform choice
+                else stb<T, VEC>(po, B.eb, o);
+            }
+        }
+        PI_STAMP3(4 + (j > 0));
+    }
+    PI_STAMP3(7);
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoint of one step (see pi_bwd_kernel): Gp = G + coef*dt*LapT(G) + dt*J_react(h)^T G (+ inj), diffusion-coefficient
+// sums always, and -- MOM, pre-contracted blocks -- the 20 coefficient moments carried per lane over all bricks of the
+// workgroup and reduced once per launch.  partials: one row of np doubles per workgroup (owner-block read-modify-write).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int HC, int RZ, bool MOM>
+__global__ void __launch_bounds__(BRICK_NT, RZ == 1 ? 4 : 2)     // one-plane bricks: four workgroups per CU (<= 128 VGPRs)
+pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restrict__ inj, T* __restrict__ Gp,
+                      double* __restrict__ partials, const T* __restrict__ P, BrickGeom g, int hc_rt)
+{
+    static_assert(!MOM || HC == POLY, "fused moments are those of the pre-contracted block");
+    constexpr int VEC = 16 / (int)sizeof(T), NT = BRICK_NT, NW = NT / WAVE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int hc = HC == POLY ? 0 : (HC > 0 ? HC : hc_rt);
+    const int np = nparams(hc);
+    // LDS: [NW][2] coefficient sums (double) | windows, overlaid after the last pass by the moment transpose scratch
+    double* redc = reinterpret_cast<double*>(smem_raw);
+    constexpr unsigned WIN0 = NW * 2 * sizeof(double);
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    // this workgroup's partial row: requested now, needed at the very end
+    auto slot_of = [&](int k) { return k < 2 ? P_COEF + k : P_W + k - 2; };
+    double* const prow = partials + (long)blockIdx.x * np;
+    const int nsum = MOM ? 22 : 2;
+    const double pold = (int)threadIdx.x < nsum ? prow[slot_of((int)threadIdx.x)] : 0.0;
+
+    const T dt = P[P_DT];
+    double lane_c[2] = {0.0, 0.0};
+    T macc[MOM ? 2 : 1][MOM ? 10 : 1];
+    if constexpr (MOM) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int m = 0; m < 10; ++m) macc[s][m] = T(0);
+    }
+    Geom gg = brick_as_geom(g);
+    bool staged = false;
+    PI_STAMP3(0);
+    for (unsigned vb = xcd_remap(blockIdx.x, gridDim.x); vb < g.nblk; vb += gridDim.x) {
+        Brick<T, RZ> B;
+        B.locate(g, vb, WIN0);
+        Lane L;
+        L.i0 = B.i0; L.eb = B.eb;
+        PlaneWindow<T, VEC, RZ> win[2];
+        win[0].load(G + g.off, gg, L);
+        win[1].load(G + g.ss + g.off, gg, L);
+        B.request_halo(G, g, WIN0);
+        // pointwise operands of all planes of the pass: requested with the window, before the barrier (HBM-cold)
+        Pack<T, VEC> hu[RZ], hv[RZ], ju[RZ], jv[RZ];
+#pragma unroll
+        for (int j = 0; j < RZ; ++j) {
+            const int iz = min(B.i0 + j, g.n0 - 1);
+            hu[j] = ldb<T, VEC>(sgpr_ptr(reinterpret_cast<const char*>(h + g.off + (long)iz * g.s0)), B.eb);
+            hv[j] = ldb<T, VEC>(sgpr_ptr(reinterpret_cast<const char*>(h + g.ss + g.off + (long)iz * g.s0)), B.eb);
+            if (inj) {
+                ju[j] = ldb<T, VEC>(sgpr_ptr(reinterpret_cast<const char*>(inj + g.off + (long)iz * g.s0)), B.eb);
+                jv[j] = ldb<T, VEC>(sgpr_ptr(reinterpret_cast<const char*>(inj + g.ss + g.off + (long)iz * g.s0)), B.eb);
+            }
+        }
+        PI_STAMP3(1);
+        if (staged) lds_barrier();                           // a further brick of this workgroup: the last one's reads are done
+        B.commit(smem_raw, win);
+        PI_STAMP3(2);
+        lds_barrier();
+        PI_STAMP3(3);
+        staged = true;
+        const T live = B.valid ? T(1) : T(0);
+#pragma unroll
+        for (int j = 0; j < RZ; ++j) {
+            const int iz = B.i0 + j;
+            if (iz >= g.n0) break;
+            const Pack<T, VEC> u = hu[j], v = hv[j];
+            Pack<T, VEC> gc[2] = {win[0].w[j + 2], win[1].w[j + 2]};
+            T dl[2][VEC];
+            win[0].template planes<-1>(j, P, dl[0]);
+            win[1].template planes<-1>(j, P, dl[1]);
+            B.template inplane<-1>(smem_raw, 2 * j, P, gc[0], dl[0]);
+            B.template inplane<-1>(smem_raw, 2 * j + 1, P, gc[1], dl[1]);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    dl[s][i] = (dl[s][i] * dt) * live;
+                    gc[s].v[i] *= live;
+                }
+            T du[VEC], dv[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) du[i] = dv[i] = T(0);
+            if constexpr (HC == POLY) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const T* c = P + P_W + 10 * s;
+                    const Pack<T, VEC>& hs = s == 0 ? u : v;
+                    double acc_c = 0.0;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        const T gr = gc[s].v[i] * dt;
+                        acc_c += (double)(dl[s][i] * hs.v[i]);
+                        T ru, rv;
+                        poly_dr(c, u.v[i], v.v[i], ru, rv);
+                        du[i] = fma_(gr, ru, du[i]);
+                        dv[i] = fma_(gr, rv, dv[i]);
+                        if constexpr (MOM) {
+                            T (&acc)[10] = macc[s];
+                            const T uu = u.v[i], vv = v.v[i];
+                            const T u2 = uu * uu, uv = uu * vv, v2 = vv * vv;
+                            acc[0] += gr;
+                            acc[1] = fma_(gr, uu, acc[1]); acc[2] = fma_(gr, vv, acc[2]);
+                            acc[3] = fma_(gr, u2, acc[3]); acc[4] = fma_(gr, uv, acc[4]); acc[5] = fma_(gr, v2, acc[5]);
+                            acc[6] = fma_(gr, u2 * uu, acc[6]); acc[7] = fma_(gr, u2 * vv, acc[7]);
+                            acc[8] = fma_(gr, uu * v2, acc[8]); acc[9] = fma_(gr, v2 * vv, acc[9]);
+                        }
+                    }
+                    lane_c[s] += acc_c;
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const T* W = P + P_W + s * species_block(hc);
+                    const Pack<T, VEC>& hs = s == 0 ? u : v;
+                    T gr[VEC];
+                    double acc_c = 0.0;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        gr[i] = gc[s].v[i] * dt;
+                        acc_c += (double)(dl[s][i] * hs.v[i]);
+                    }
+                    lane_c[s] += acc_c;
+                    W10<T> nx = load_w10(W);
+#pragma clang loop unroll(disable)
+                    for (int jj = 0; jj < hc; ++jj) {
+                        const W10<T> c = nx;
+                        if (jj + 1 < hc) nx = load_w10(W + 10 * (jj + 1));
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) {
+                            const T a1 = fma_(c.w[0], u.v[i], fma_(c.w[1], v.v[i], c.w[2]));
+                            const T a2 = fma_(c.w[3], u.v[i], fma_(c.w[4], v.v[i], c.w[5]));
+                            const T a3 = fma_(c.w[6], u.v[i], fma_(c.w[7], v.v[i], c.w[8]));
+                            const T p12 = a1 * a2;
+                            const T gw = gr[i] * c.w[9];
+                            const T q1 = gw * (a2 * a3), q2 = gw * (a1 * a3), q3 = gw * p12;
+                            du[i] = fma_(q1, c.w[0], fma_(q2, c.w[3], fma_(q3, c.w[6], du[i])));
+                            dv[i] = fma_(q1, c.w[1], fma_(q2, c.w[4], fma_(q3, c.w[7], dv[i])));
+                        }
+                    }
+                }
+            }
+            Pack<T, VEC> ou, ov;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const T tu = P[P_COEF + 0] * dl[0][i] + du[i];
+                const T tv = P[P_COEF + 1] * dl[1][i] + dv[i];
+                ou.v[i] = gc[0].v[i] + tu;
+                ov.v[i] = gc[1].v[i] + tv;
+            }
+            if (inj) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { ou.v[i] += ju[j].v[i]; ov.v[i] += jv[j].v[i]; }
+            }
+            if (B.valid) {
+                char* pu = const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(Gp + g.off + (long)iz * g.s0)));
+                char* pv = const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(Gp + g.ss + g.off + (long)iz * g.s0)));
+                if (g.wt) { stb_wt<T, VEC>(pu, B.eb, ou); stb_wt<T, VEC>(pv, B.eb, ov); }
+                else { stb<T, VEC>(pu, B.eb, ou); stb<T, VEC>(pv, B.eb, ov); }
+            }
+            PI_STAMP3(4 + (j > 0));
+        }
+    }
+    PI_STAMP3(6);
+
+    // ---- per-launch reductions --------------------------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const double r = wave_sum_to_last(lane_c[s]);
+        if (lane == REDUCE_LANE) redc[wave * 2 + s] = r;
+    }
+    T* mred = reinterpret_cast<T*>(smem_raw + WIN0);                      // [20] block sums of the moments, then scratch
+    if constexpr (MOM) {
+        // LDS transpose (see pi_bwd_kernel): every thread writes its 20 values, 8 lanes per moment add NT / 8 of them
+        constexpr int RS = NT + 8;
+        T* scr = mred + 32;
+        lds_barrier();                                                   // the scratch overlays the windows
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int m = 0; m < 10; ++m) scr[(10 * s + m) * RS + (int)threadIdx.x] = macc[s][m];
+        __syncthreads();
+        {
+            const int task = (int)threadIdx.x;                           // NT = 256 >= 160 tasks: one trip
+            const int mm = min(task, 159) >> 3, part = task & 7;
+            T a = T(0);
+            if (task < 160) {
+                T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+                const T* row = scr + mm * RS + part;
+#pragma unroll
+                for (int k = 0; k < NT; k += 64) {
+                    const T v0 = row[k], v1 = row[k + 8], v2 = row[k + 16], v3 = row[k + 24];
+                    const T v4 = row[k + 32], v5 = row[k + 40], v6 = row[k + 48], v7 = row[k + 56];
+                    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+                    a0 += v4; a1 += v5; a2 += v6; a3 += v7;
+                }
+                a = (a0 + a1) + (a2 + a3);
+            }
+            a += dpp_mov<0x111, 0xF>(a);
+            a += dpp_mov<0x112, 0xF>(a);
+            a += dpp_mov<0x114, 0xF>(a);
+            if (task < 160 && part == 7) mred[mm] = a;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nsum) {
+        double s = 0.0;
+        if (threadIdx.x < 2) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += redc[w * 2 + threadIdx.x];
+        } else {
+            s = (double)mred[threadIdx.x - 2];
+        }
+        prow[slot_of((int)threadIdx.x)] = pold + s;
+    }
+    PI_STAMP3(7);
+}
+
+}  // namespace pi

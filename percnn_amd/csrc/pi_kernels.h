@@ -46,10 +46,6 @@ struct Geom {
     unsigned xwin;      // forward kernel: XCD-contiguous remap inside windows of this many blocks (0 = the whole grid)
     int rz;             // 3D: consecutive planes one workgroup pass computes (plane neighbours shared in registers); the
                         // "planes" of the block decomposition above are groups of rz planes
-    // 3D, LDS row window (RowWindow below): the in-plane neighbours of a workgroup pass come from LDS
-    unsigned lw_nwin;   // 16-byte chunks per (plane, species) window = chunks of a full block + 4 rows of halo; 0 = off
-    unsigned lw_base;   // byte offset of the windows inside the kernel's dynamic LDS
-    FastDiv d4cpr;      // halo tuple id -> (plane-species, chunk of the 4 halo rows)
 };
 
 // radius-2 star: lap[i] = c0*f(x) + sum_axes sum_t w[axis][t] * f(x + FLIP*offs[t]); FLIP=-1 is the adjoint
@@ -181,8 +177,6 @@ struct Lane {
     int x0;            // first point of the chunk
     unsigned eb;       // byte offset of the chunk relative to the plane base (3D) / biased field base (2D)
     bool valid;
-    unsigned cb, nown; // block-uniform: first chunk of the plane this workgroup owns, and how many (contiguous; row mode
-                       // with one x block, or flat mode) -- the LDS row window is built around [cb, cb + nown)
 };
 
 // block id -> uniform (plane, row group, x block); lane -> (row, chunk).  Invalid lanes are clamped onto the last
@@ -220,8 +214,6 @@ __device__ __forceinline__ Lane locate(const Geom& g, unsigned vb)
         const unsigned r = g.dcpr.div(idx);
         row = (int)r;
         chunk = (int)(idx - r * (unsigned)cpr);
-        L.cb = rg * blockDim.x;
-        L.nown = min(blockDim.x, total - L.cb);
     } else {
         const int lx = 1 << g.lxs;
         const int xi = (int)threadIdx.x & (lx - 1), ri = (int)threadIdx.x >> g.lxs;
@@ -231,8 +223,6 @@ __device__ __forceinline__ Lane locate(const Geom& g, unsigned vb)
         L.valid = chunk < cpr && row < nrow;
         chunk = min(chunk, cpr - 1);
         row = min(row, nrow - 1);
-        L.cb = rg * (unsigned)(rpb * cpr);
-        L.nown = (unsigned)(min(rpb, nrow - (int)rg * rpb) * cpr);
     }
     L.i0 = NDIM == 3 ? (int)pl * g.rz : 0;          // first plane of the group
     L.row = row;
@@ -253,6 +243,16 @@ __device__ __forceinline__ void keep_in_regs(Pack<T, N>& c)
 {
 #pragma unroll
     for (int i = 0; i < N; ++i) asm("" : "+v"(c.v[i]));
+}
+
+// write-through (sc1) 16-byte store, scalar base + 32-bit lane offset; see st_frame_wt for what it buys and for the s_nop
+template <typename T, int N>
+__device__ __forceinline__ void stb_wt(char* base, unsigned byteoff, const Pack<T, N>& x)
+{
+    static_assert(sizeof(Pack<T, N>) == 16, "16-byte lanes");
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_bit_cast(v4u, x);
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(byteoff), "v"(v), "s"(base) : "memory");
 }
 
 // Pin a wave-uniform pointer into an SGPR pair.  Without it LLVM reassociates  base + delta*s0 + zext(offset)  into a
@@ -372,114 +372,13 @@ struct PlaneWindow {
 };
 
 // ---------------------------------------------------------------------------------------------
-// LDS row window (3D direct kernels, option lds_win): the in-plane half of the star out of LDS.
-//
-// The direct 3D kernels gathered the four row neighbours (16-byte loads) and the x halo (two 8-byte loads) of every
-// species and output plane through the vector L1 / L2: 6 of the 9 memory requests per species and output at RZ = 2, and
-// timing experiments put 1.65 us of the 10.6 us forward launch at 128^3 on them (DESIGN.md "What bounds 128^3").  A
-// workgroup pass owns a contiguous range [cb, cb + nown) of 16-byte chunks of RZ planes (whole rows, or `flat` mode); per
-// (plane, species) it stages that range plus two rows of chunks on either side -- the rows above and below, periodic in
-// the plane -- into LDS: the own chunks come out of the register window of plane neighbours (already loaded), the 4 * cpr
-// halo chunks are fetched once per workgroup, spread over all lanes (2 * RZ loads per lane at most).  Every in-plane
-// neighbour is then an LDS read at a fixed offset from the lane's own chunk: +- k rows = +- k * row pitch (the wrap was
-// resolved at staging), the x halo = the 8 bytes (16 in float64) before / after the chunk, or the other end of the row.
-// Global requests per species and output: (RZ + 4) / RZ + <= 1 instead of (RZ + 4) / RZ + 6.  Arithmetic and order are
-// those of star2_inplane (bit-identical results).
-// ---------------------------------------------------------------------------------------------
-template <typename T, int VEC, int RZ>
-struct RowWindow {
-    static constexpr int MH = 2 * RZ;     // halo fetches per lane: RZ planes x 2 species x 4 * cpr chunks <= MH * blockDim
-    Pack<T, VEC> hreg[MH];
-    unsigned hoff[MH];                    // LDS byte offset of hreg[m], ~0u: none
-    unsigned lo;                          // byte offset of the lane's own chunk inside a window
-    unsigned wbytes;                      // bytes per (plane, species) window
-    int Wb, xl, xr;                       // row pitch; offsets of the left / right x-halo pair relative to the own chunk
-
-    // f = field base (species 0), i.e. h or G
-    __device__ __forceinline__ void request(const T* __restrict__ f, const Geom& g, const Lane& L)
-    {
-        const unsigned cpr = (unsigned)(g.W / VEC), nh = 4u * cpr, ntup = (unsigned)(2 * RZ) * nh;
-        const int total = g.n1 * (int)cpr;
-        wbytes = g.lw_nwin * 16u;
-        Wb = (int)cpr * 16;
-        lo = (2u * cpr + (unsigned)L.row * cpr + (unsigned)(L.x0 / VEC) - L.cb) * 16u;
-        xl = L.x0 >= 2 ? -2 * (int)sizeof(T) : Wb - 2 * (int)sizeof(T);
-        xr = L.x0 + VEC < g.W ? VEC * (int)sizeof(T) : VEC * (int)sizeof(T) - Wb;
-        const T* src[MH];
-#pragma unroll
-        for (int m = 0; m < MH; ++m) {
-            unsigned id = threadIdx.x + (unsigned)m * blockDim.x;
-            const bool ok = id < ntup;
-            id = min(id, ntup - 1u);
-            const unsigned ps = g.d4cpr.div_nz(id), hidx = id - ps * nh;       // ps = 2 * plane of the group + species
-            const unsigned wp = hidx + (hidx >= 2u * cpr ? L.nown : 0u);       // chunk of the window
-            int pc = (int)L.cb - 2 * (int)cpr + (int)wp;                       // chunk of the plane, periodic in the plane
-            pc += pc < 0 ? total : (pc >= total ? -total : 0);
-            const int pl = min(L.i0 + (int)(ps >> 1), g.n0 - 1);               // partial last plane group: stay in bounds
-            src[m] = f + (ps & 1u ? g.ss : 0L) + g.off + (long)pl * g.s0 + (long)pc * VEC;
-            hoff[m] = ok ? (ps * g.lw_nwin + wp) * 16u : ~0u;
-        }
-#pragma unroll
-        for (int m = 0; m < MH; ++m) hreg[m] = ld<T, VEC>(src[m]);             // all addresses first, then the loads back to back
-    }
-    // own chunks of the RZ centre planes (register window) + the halo chunks -> LDS
-    __device__ __forceinline__ void commit(unsigned char* lds, const PlaneWindow<T, VEC, RZ> (&win)[2]) const
-    {
-#pragma unroll
-        for (int j = 0; j < RZ; ++j)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-                *reinterpret_cast<Pack<T, VEC>*>(lds + (unsigned)(2 * j + s) * wbytes + lo) = win[s].w[j + 2];
-#pragma unroll
-        for (int m = 0; m < MH; ++m)
-            if (hoff[m] != ~0u) *reinterpret_cast<Pack<T, VEC>*>(lds + hoff[m]) = hreg[m];
-    }
-    // rows, then the fastest axis, accumulated onto `lap` in star2_inplane's order; plane j of the group, species s
-    template <int FLIP>
-    __device__ __forceinline__ void inplane(const unsigned char* lds, int j, int s, const T* __restrict__ P,
-                                            const Pack<T, VEC>& c, T (&lap)[VEC]) const
-    {
-        const unsigned char* own = lds + (unsigned)(2 * j + s) * wbytes + lo;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int k = FLIP * (t < 2 ? t - 2 : t - 1);
-            const Pack<T, VEC> nb = *reinterpret_cast<const Pack<T, VEC>*>(own + k * Wb);
-            const T w = P[P_TAPS + 4 + t];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) lap[i] = fma_(w, nb.v[i], lap[i]);
-        }
-        static_assert(VEC >= 2, "the LDS row window serves 16-byte lanes");
-        T win[VEC + 4];
-        const Pack<T, 2> l = *reinterpret_cast<const Pack<T, 2>*>(own + xl);
-        const Pack<T, 2> r = *reinterpret_cast<const Pack<T, 2>*>(own + xr);
-        win[0] = l.v[0]; win[1] = l.v[1];
-        win[VEC + 2] = r.v[0]; win[VEC + 3] = r.v[1];
-        Pack<T, VEC> cc = c;
-        keep_in_regs(cc);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) win[2 + i] = cc.v[i];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int k = FLIP * (t < 2 ? t - 2 : t - 1);
-            const T w = P[P_TAPS + 8 + t];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) lap[i] = fma_(w, win[2 + i + k], lap[i]);
-        }
-    }
-};
-
-// ---------------------------------------------------------------------------------------------
 // forward: out = h + dt * (coef * Lap(h) + Wh4(Wh1(h) * Wh2(h) * Wh3(h)))
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NDIM, int HC, int VEC, int RZ = 1, bool LW = false>
+template <typename T, int NDIM, int HC, int VEC, int RZ = 1>
 __global__ void __launch_bounds__(256)
 pi_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict__ P, Geom g, int hc_rt)
 {
     static_assert(NDIM == 3 || RZ == 1, "plane blocking is a 3D notion");
-    static_assert(NDIM == 3 || !LW, "the LDS row window is a 3D notion");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned char* const lwin = smem_raw + (LW ? g.lw_base : 0u);
-    bool staged = false;
     const int hc = HC > 0 ? HC : hc_rt;      // unused when HC == POLY
     // one virtual block (plane group, row group, x block) per workgroup, or -- option fwd_blocks -- a bounded grid of
     // workgroups that walk the virtual blocks in order (measured slower: 384^3 376 -> 416 us)
@@ -493,9 +392,7 @@ pi_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict_
     PI_STAMP3(0);
     for (unsigned vb = first; vb < g.nblk; vb += gridDim.x) {
         const Lane L = locate<T, NDIM, VEC>(g, vb);
-        if constexpr (!LW) {
-            if (!L.valid) continue;
-        }
+        if (!L.valid) continue;
         const T* hs[2] = {h + g.off, h + g.ss + g.off};
         // 3D: the lane's chunk in planes i0-2 .. i0+RZ+1, both species, requested up front (RZ + 4 loads per species
         // serve RZ output planes)
@@ -503,18 +400,6 @@ pi_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict_
         if constexpr (NDIM == 3) {
             win[0].load(hs[0], g, L);
             win[1].load(hs[1], g, L);
-        }
-        // LDS row window: halo rows requested with the plane window, everything committed once, ONE barrier per pass
-        RowWindow<T, VEC, NDIM == 3 ? RZ : 1> rw;
-        if constexpr (LW) {
-            rw.request(h, g, L);
-            PI_STAMP3(1);
-            if (staged) lds_barrier();                    // a further pass of this workgroup: the last one's reads are done
-            rw.commit(lwin, win);
-            PI_STAMP3(2);
-            lds_barrier();
-            PI_STAMP3(3);
-            staged = true;
         }
 #pragma unroll
         for (int j = 0; j < RZ; ++j) {
@@ -535,13 +420,8 @@ pi_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict_
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) { lap[0][i] = P[P_C0] * cu.v[i]; lap[1][i] = P[P_C0] * cv.v[i]; }
             }
-            if constexpr (LW) {
-                rw.template inplane<+1>(lwin, j, 0, P, cu, lap[0]);
-                rw.template inplane<+1>(lwin, j, 1, P, cv, lap[1]);
-            } else {
-                star2_inplane<T, NDIM, VEC, +1>(pu, P, g, L, cu, lap[0]);
-                star2_inplane<T, NDIM, VEC, +1>(pv, P, g, L, cv, lap[1]);
-            }
+            star2_inplane<T, NDIM, VEC, +1>(pu, P, g, L, cu, lap[0]);
+            star2_inplane<T, NDIM, VEC, +1>(pv, P, g, L, cv, lap[1]);
 
             // The species / hidden-channel loops stay ROLLED on purpose: a fully unrolled body is several KiB
             // of straight-line code that every wave executes exactly once, and at one wave per SIMD the
@@ -583,7 +463,7 @@ pi_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict_
                     o.v[i] = hv + inc;
                 }
                 char* po = const_cast<char*>(plane_base<T, NDIM>(out + s * g.ss + g.off, g, iz));
-                if (!LW || L.valid) stb<T, VEC>(po, L.eb, o);
+                stb<T, VEC>(po, L.eb, o);
             }
             PI_STAMP3(4 + (j > 0));
         }
@@ -599,16 +479,13 @@ pi_fwd_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict_
 // Gradient of the diffusion coefficient uses sum_x g*Lap(h) == sum_x LapT(g)*h, so the forward
 // Laplacian is never recomputed.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NDIM, int HC, int VEC, bool WGRAD, int RZ = 1, bool LW = false>
+template <typename T, int NDIM, int HC, int VEC, bool WGRAD, int RZ = 1>
 __global__ void __launch_bounds__(256)
 pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restrict__ inj, T* __restrict__ Gp,
               double* __restrict__ partials, const T* __restrict__ P, Geom g, int hc_rt)
 {
-    static_assert(NDIM == 3 || !LW, "the LDS row window is a 3D notion");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* red = reinterpret_cast<T*>(smem_raw);           // [nwaves][np] running sums of this block
-    unsigned char* const lwin = smem_raw + (LW ? g.lw_base : 0u);   // LDS row windows (share the moment scratch area)
-    bool staged = false;
 
     const int hc = HC == POLY ? 0 : (HC > 0 ? HC : hc_rt);
     const int np = nparams(hc);
@@ -653,14 +530,6 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
             win[0].load(G + g.off, g, L);
             win[1].load(G + g.ss + g.off, g, L);
         }
-        RowWindow<T, VEC, NDIM == 3 ? RZ : 1> rw;
-        if constexpr (LW) {
-            rw.request(G, g, L);
-            if (staged) lds_barrier();
-            rw.commit(lwin, win);
-            lds_barrier();
-            staged = true;
-        }
 #pragma unroll
         for (int jz = 0; jz < RZ; ++jz) {
         const int iz = L.i0 + jz;
@@ -683,13 +552,8 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { dl[0][i] = P[P_C0] * gc[0].v[i]; dl[1][i] = P[P_C0] * gc[1].v[i]; }
         }
-        if constexpr (LW) {
-            rw.template inplane<-1>(lwin, jz, 0, P, gc[0], dl[0]);
-            rw.template inplane<-1>(lwin, jz, 1, P, gc[1], dl[1]);
-        } else {
-            star2_inplane<T, NDIM, VEC, -1>(pgu, P, g, L, gc[0], dl[0]);
-            star2_inplane<T, NDIM, VEC, -1>(pgv, P, g, L, gc[1], dl[1]);
-        }
+        star2_inplane<T, NDIM, VEC, -1>(pgu, P, g, L, gc[0], dl[0]);
+        star2_inplane<T, NDIM, VEC, -1>(pgv, P, g, L, gc[1], dl[1]);
         const T live = valid ? T(1) : T(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -837,7 +701,6 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
         const int NT = (int)blockDim.x, RS = NT + 8;                 // row stride: + 8 floats -> 8 rows cover all banks
         T* scr = reinterpret_cast<T*>(smem_raw + (((size_t)nwaves * np * sizeof(T) + 15) / 16 * 16) +
                                       (size_t)nwaves * 2 * sizeof(double));
-        if constexpr (LW) lds_barrier();                             // the scratch area overlays the row windows
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll

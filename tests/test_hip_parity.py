@@ -745,11 +745,7 @@ def test_stream3d_bitwise(opts, shape, dtype, hc, hip_device):
                                   "rz=1,l2_tile_kb=4,l2_tile_min_kb=0,block=128",
                                   "rz=2,fwd_blocks=8,bwd_cpl=1", "rz=4,xcd_window=16,bwd_cpl=4", "block_small=0,rz=2", "vec=1",
                                   "lane_x=2", "lane_x=3,rz=2", "lane_x=6,block=64", "lane_x=-1", "lane_x=7", "lane_x=7,rz=2,block=64",
-                                  "lane_x=7,rz=4,l2_tile_kb=1,l2_tile_min_kb=0",
-                                  # LDS row window (round 3) off / forced, with every decomposition it rides on
-                                  "lds_win=0,rz=1", "lds_win=0,rz=2", "lds_win=2,rz=1", "lds_win=2,rz=2,bwd_cpl=1", "lds_win=2,rz=4",
-                                  "lds_win=2,rz=2,lane_x=7", "lds_win=2,rz=1,lane_x=7,block=128", "lds_win=2,rz=2,block=128,bwd_cpl=4",
-                                  "lds_win=2,rz=4,lane_x=7,l2_tile_kb=1,l2_tile_min_kb=0", "lds_win=2,rz=2,fwd_blocks=8"])
+                                  "lane_x=7,rz=4,l2_tile_kb=1,l2_tile_min_kb=0"])
 @pytest.mark.parametrize("shape,dtype", [((9, 12, 64), np.float32), ((6, 33, 40), np.float32), ((3, 8, 16), np.float32),
                                          ((17, 20, 132), np.float32), ((10, 24, 48), np.float64), ((2, 6, 8), np.float64)])
 def test_direct_kernel_variants_bitwise(opts, shape, dtype, hip_device):
@@ -765,7 +761,7 @@ def test_direct_kernel_variants_bitwise(opts, shape, dtype, hip_device):
     gt = rs.uniform(-1, 1, (T + 1, 2) + shape).astype(dtype)
     ref = o_rollout_fwd(h0, P, T)
     g0_ref, pg_ref = o_rollout_bwd(ref, gt, P)
-    o = "stream3d=0," + opts
+    o = "stream3d=0,brick3d=0," + opts              # (since round 3 the brick kernels take 3D grids by default: test_brick3d_bitwise)
     Pd = dev_t(P, hip_device)
     traj = torch.empty((T + 1, 2) + shape, dtype=torch.from_numpy(h0).dtype, device=hip_device)
     traj[0] = dev_t(h0, hip_device)
@@ -787,6 +783,52 @@ def test_direct_kernel_variants_bitwise(opts, shape, dtype, hip_device):
     assert np.array_equal(out.cpu().numpy(), o_step_fwd(h0, P))
     gi, _ = pa.step_bwd(dev_t(h0, hip_device), dev_t(gt[1], hip_device), Pd, options=o)
     assert np.array_equal(gi.cpu().numpy(), o_step_bwd(h0, gt[1], None, P)[0])
+
+
+@pytest.mark.parametrize("opts", ["brick3d=2,brick_rz=1", "brick3d=2,brick_rz=2", "brick3d=2,brick_rz=4", "brick3d=0"])
+@pytest.mark.parametrize("shape,dtype,hc", [((9, 12, 64), np.float32, 0), ((6, 33, 40), np.float32, 0), ((3, 8, 16), np.float32, 0),
+                                            ((17, 20, 132), np.float32, 0), ((5, 2, 256), np.float32, 0), ((4, 70, 100), np.float32, 0),
+                                            ((10, 24, 48), np.float64, 0), ((2, 6, 8), np.float64, 0), ((7, 5, 128), np.float64, 0),
+                                            ((9, 12, 64), np.float32, 2), ((6, 33, 40), np.float32, 8), ((5, 9, 24), np.float64, 4),
+                                            ((4, 7, 20), np.float32, 3)])
+def test_brick3d_bitwise(opts, shape, dtype, hc, hip_device):
+    """Round-3 brick kernels (pi_brick3d.h: z neighbours in a register window, y / x neighbours from LDS windows staged once per
+    workgroup, halo rows fetched by whole waves): forward, adjoint sweep with fused moments, sweep + separate reduction, masked
+    frames and the one-step entry points, bit-identical to the C oracle for 1 / 2 / 4 planes per brick (incl. partial last plane
+    groups, planes smaller than a brick, rows of 2 .. 64 chunks, ragged widths), float32 / float64, pre-contracted and factored
+    blocks; `brick3d=0` is the direct-kernel path on the same inputs."""
+    import percnn_amd as pa
+    T = 3
+    rs = np.random.RandomState(31)
+    P = random_block(hc, 3, dtype, 29, scale=0.3)
+    h0 = rs.uniform(0, 1, (2,) + shape).astype(dtype)
+    gt = rs.uniform(-1, 1, (T + 1, 2) + shape).astype(dtype)
+    ref = o_rollout_fwd(h0, P, T)
+    g0_ref, pg_ref = o_rollout_bwd(ref, gt, P)
+    o = "stream3d=0," + opts
+    Pd = dev_t(P, hip_device)
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.from_numpy(h0).dtype, device=hip_device)
+    traj[0] = dev_t(h0, hip_device)
+    pa.rollout_fwd_(traj, Pd, options=o)
+    assert np.array_equal(traj.cpu().numpy(), ref)
+    tol = 2e-5 if dtype == np.float32 else 1e-12
+    g0, pg = pa.rollout_bwd(traj, dev_t(gt, hip_device), Pd, options=o)
+    assert np.array_equal(g0.cpu().numpy(), g0_ref)
+    assert rel_l2(pg.cpu().numpy(), pg_ref) < tol
+    g0s, pgs = pa.rollout_bwd(traj, dev_t(gt, hip_device), Pd, options=o + ",fuse_wgrad=0")
+    assert np.array_equal(g0s.cpu().numpy(), g0_ref)
+    assert rel_l2(pgs.cpu().numpy(), pg_ref) < tol
+    mask = [True, False, True, False]
+    g = gt.copy(); g[1] = 0; g[3] = 0
+    g0m_ref, _ = o_rollout_bwd(ref, g, P)
+    g0m, _ = pa.rollout_bwd(traj, dev_t(g, hip_device), Pd, frame_mask=mask, options=o)
+    assert np.array_equal(g0m.cpu().numpy(), g0m_ref)
+    out = pa.step_fwd(dev_t(h0, hip_device), Pd, options=o)
+    assert np.array_equal(out.cpu().numpy(), ref[1])
+    gi, pgi = pa.step_bwd(dev_t(h0, hip_device), dev_t(gt[1], hip_device), Pd, options=o)
+    gi_ref, pgi_ref = o_step_bwd(h0, gt[1], None, P)
+    assert np.array_equal(gi.cpu().numpy(), gi_ref)
+    assert rel_l2(pgi.cpu().numpy(), pgi_ref) < tol
 
 
 @pytest.mark.parametrize("lane_x", [-1, 0, 2, 3, 5, 6, 7])
@@ -843,18 +885,23 @@ def test_slab_layout_with_plane_blocking(rz, shape, halo, hip_device):
     def padded(x):
         return torch.cat([x[:, n0 - halo:], x, x[:, :halo]], dim=1).contiguous()
 
-    ref = pa.step_fwd(h, P, options="stream3d=0,rz=1")
-    gref, _ = pa.step_bwd(h, G, P, options="stream3d=0,rz=1")
-    pa.set_option("rz", rz)
+    ref = pa.step_fwd(h, P, options="stream3d=0,brick3d=0,rz=1")
+    gref, _ = pa.step_bwd(h, G, P, options="stream3d=0,brick3d=0,rz=1")
     pa.set_option("stream3d", 0)
     try:
-        out = pa.step_fwd(padded(h), P, slab=True, halo=halo, skip=0)
-        # skip = 0 computes planes [2, n0 + 2*halo - 2): compare the interior
-        assert torch.equal(out[:, halo:halo + n0], ref)
-        gi, _ = pa.step_bwd(padded(h), padded(G), P, slab=True, halo=halo)
-        assert torch.equal(gi[:, halo:halo + n0], gref)
+        for brick in (0, 2):                          # direct kernels with `rz` planes per pass, then `rz`-plane bricks
+            pa.set_option("brick3d", brick)
+            pa.set_option("rz", rz)
+            pa.set_option("brick_rz", rz)
+            out = pa.step_fwd(padded(h), P, slab=True, halo=halo, skip=0)
+            # skip = 0 computes planes [2, n0 + 2*halo - 2): compare the interior
+            assert torch.equal(out[:, halo:halo + n0], ref), brick
+            gi, _ = pa.step_bwd(padded(h), padded(G), P, slab=True, halo=halo)
+            assert torch.equal(gi[:, halo:halo + n0], gref), brick
     finally:
         pa.set_option("rz", 0)
+        pa.set_option("brick_rz", 0)
+        pa.set_option("brick3d", 1)
         pa.set_option("stream3d", 1)
 
 
@@ -1241,12 +1288,21 @@ def test_direct_adjoint_kernel_chunks_per_lane(shape, hip_device):
             for cpl in (1, 2, 3):
                 pa.set_option("fuse_wgrad", fuse)
                 pa.set_option("bwd_cpl", cpl)
+                pa.set_option("brick3d", 0)
                 g0, pg = pa.rollout_bwd(traj, gd, Pd)
                 assert np.array_equal(g0.cpu().numpy(), g0_o), (fuse, cpl)
                 assert rel_l2(pg.cpu().numpy(), pg_o) < 5e-5, (fuse, cpl)
+                # the adjoint brick kernel with `cpl` resident workgroups per CU walking the bricks (several bricks each)
+                pa.set_option("brick3d", 2)
+                pa.set_option("brick_wgs", cpl)
+                g0, pg = pa.rollout_bwd(traj, gd, Pd)
+                assert np.array_equal(g0.cpu().numpy(), g0_o), (fuse, cpl, "brick")
+                assert rel_l2(pg.cpu().numpy(), pg_o) < 5e-5, (fuse, cpl, "brick")
     finally:
         pa.set_option("fuse_wgrad", 2)
         pa.set_option("bwd_cpl", 2)
+        pa.set_option("brick3d", 1)
+        pa.set_option("brick_wgs", 0)
         pa.set_option("stream3d", 1)
 
 
