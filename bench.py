@@ -221,40 +221,33 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
     sweep_ms = e0.elapsed_time(e1) / reps
     red_ms = max(bwd_ms - sweep_ms, 1e-6)
 
-    # the library's switch points (pi_abi.hip: tile_eligible): forward tiles below 3 M points, sweep tiles below 1.25 M
-    tile_opt = opts.get("tile", "1")
-    tiled_fwd = len(shape) == 2 and tile_opt != "0" and (npts < (3 << 20) or tile_opt == "2")
-    tiled = len(shape) == 2 and tile_opt != "0" and (npts < (5 << 18) or tile_opt == "2")   # the sweep (ragged grids included)
-    K = int(opts.get("tile_k", 4)) if tiled else 1
-    Kf = int(opts.get("tile_k", 4)) if tiled_fwd else 1
+    # which kernel families ran, asked from the library itself (percnn_pi_debug_plan: its own dispatch rules)
+    from percnn_amd import _lib as _pl
+    plan = _pl.rollout_plan(0 if reaction == "poly" else hc, shape, esz, ",".join(f"{k}={v}" for k, v in opts.items()) or None)
+    K, Kf = plan["bwd_steps_per_launch"], plan["fwd_steps_per_launch"]
+    tiled = plan["bwd"] == "tile2d"
     poly = reaction == "poly"
     # algorithmic bytes per point and time step: fwd read+write state = 2*C*s;
     # sweep read h, adj, dL/dout + write adj = 4*C*s; gradient reduction read h + adj = 2*C*s
     # (the factored Hc=8 reduction streams h once per species: 3*C*s)
     Cs = 2 * esz
     red_bytes_pt = 2 * Cs if (poly or hc <= 4) else 3 * Cs
-    # float32 poly mode on the direct-kernel path: the gradient reduction is fused into the sweep launches (no separate
-    # pass); the sweep-only timing above then only serves as a lower bound of that kernel
-    # (float64 too, except where the plane-streaming kernels run: their fused flavour is float32 only)
-    streamed = len(shape) == 3 and shape[-1] in (64, 128, 256) and shape[0] >= 64 and npts >= (3 << 20) and \
-        opts.get("stream3d", "1") != "0"
-    fused = (not tiled) and poly and opts.get("fuse_wgrad", "2") != "0" and \
-        not (streamed and (dtype != torch.float32 or shape[-1] == 256))
-    # 2D tile path, pre-contracted blocks, 32x32 tiles (> 128 of them): the tile sweep reduces the moments itself as well
-    # (library option tile_fuse, default on) and keeps only every K-th adjoint frame
-    tiles32 = ((shape[0] + 31) // 32) * ((shape[1] + 31) // 32) if len(shape) == 2 else 0
-    tile_fused = tiled and poly and K == 4 and tiles32 > 128 and dtype in FUSED_TILE_DTYPES and \
-        opts.get("tile_fuse", "1") != "0" and opts.get("tile_by", "0") != "16" and opts.get("tile_nt", "512") == "512"
-    fused = fused or tile_fused
+    # `fused`: the parameter gradients are reduced inside the sweep launches (no separate time-parallel pass); the
+    # sweep-only timing above then only serves as a lower bound of that kernel
+    fused = plan["fused_gradients"]
+    fwd_names = {"tile2d": "pi_fwd2d_tile_kernel", "stream3d": "pi_stream3d_kernel<fwd>", "brick3d": "pi_fwd3d_brick_kernel",
+                 "direct": "pi_fwd_kernel", "advective": "pi_adv_fwd_kernel"}
+    bwd_names = {"tile2d": "pi_adj2d_tile_kernel", "stream3d": "pi_stream3d_kernel<adj>", "brick3d": "pi_adj3d_brick_kernel",
+                 "direct": "pi_bwd_kernel", "advective": "pi_adv_bwd_kernel"}
+    fwd_kernel = fwd_names[plan["fwd"]]
+    bwd_kernel = bwd_names[plan["bwd"]] + (("<sweep+moments>" if fused else "") if tiled else ("<sweep+moments>" if fused else "<sweep>"))
     if fused:
         sweep_ms, red_ms = bwd_ms, 1e-6
     clock = "HIP events on the launch stream, this run (fwd / bwd phases of every pass; sweep alone via options=skip_wgrad)"
     kernels = [
-        {"kernel": ("pi_fwd2d_tile_kernel" if tiled_fwd else "pi_fwd_kernel"), "launches_per_pass": T // Kf,
+        {"kernel": fwd_kernel, "launches_per_pass": T // Kf,
          "algorithmic_bytes_per_launch": 2 * Cs * npts * Kf, "avg_launch_us": fwd_ms * 1e3 / (T / Kf)},
-        {"kernel": (("pi_adj2d_tile_kernel<sweep+moments>" if tile_fused else "pi_adj2d_tile_kernel") if tiled
-                    else ("pi_bwd_kernel<sweep+moments>" if fused else "pi_bwd_kernel<sweep>")),
-         "launches_per_pass": T // K,
+        {"kernel": bwd_kernel, "launches_per_pass": T // K,
          "algorithmic_bytes_per_launch": 4 * Cs * npts * K, "avg_launch_us": sweep_ms * 1e3 / (T / K)},
         {"kernel": ("pi_moments_kernel" if poly else "pi_wgrad_kernel"), "launches_per_pass": 1,
          "algorithmic_bytes_per_launch": red_bytes_pt * npts * T, "avg_launch_us": red_ms * 1e3},
@@ -281,7 +274,7 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
                                f"T={T} forward+backward rollout per step, dense dL/dtraj",
                    "reaction": reaction,
                    "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (no collective)",
-                   "points": npts, "T": T, "time_steps_per_launch": K},
+                   "points": npts, "T": T, "time_steps_per_launch": K, "kernel_plan": plan},
         "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
@@ -294,7 +287,6 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
     return res, live
 
 
-FUSED_TILE_DTYPES = (torch.float32, torch.float64)   # dtypes whose 2D tile sweep runs the fused-moments flavour by default
 
 
 def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
@@ -356,7 +348,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="headline measurement only (profiling runs: keeps per-kernel averages free of the add-on passes)")
     ap.add_argument("--no-also", action="store_true", help="skip the second half of the BASELINE metric (3D-GS 128^3)")
-    ap.add_argument("--slab-timeout", type=float, default=240.0)
+    ap.add_argument("--slab-timeout", type=float, default=420.0)
     ap.add_argument("--slab-child", action="store_true", help=argparse.SUPPRESS)   # see slab_extra_isolated
     a = ap.parse_args()
 
@@ -365,27 +357,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
-    dev = torch.device("cuda", local_rank)
+    # PERCNN_BENCH_ONE_GPU=1: every rank on cuda:0, gloo as the control plane (RCCL refuses two ranks on one device) -- how
+    # tests/test_slab_dist_gpu.py::test_bench_two_ranks_on_one_gpu proves the N > 1 control flow of this file on a 1-GPU box
+    one_gpu = bool(int(os.environ.get("PERCNN_BENCH_ONE_GPU", "0")))
+    dev = torch.device("cuda", 0 if one_gpu else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1 or "MASTER_ADDR" in os.environ:          # launched by torch.distributed.run
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     ensure_library(local_rank)
     import percnn_amd as pa
     if a.slab_child:
-        try:
-            res = slab_extra(dev, dist, rank, world)
-        except Exception as e:
-            res = {"error": repr(e)[:300]}
-        if "error" not in res and not int(os.environ.get("PERCNN_NO_PEER", "0")):
-            # second transport, same problem: peer mailboxes (xGMI load/store + epoch flags) instead of RCCL calls
-            # (one rank: put / take through the rank's own mailbox)
-            try:
-                res["peer_mailbox"] = slab_extra(dev, dist, rank, world, transport="peer", force_p2p=True)
-            except Exception as e:
-                res["peer_mailbox"] = {"error": repr(e)[:300]}
+        res = sharded_series(dev, dist, rank, world, one_gpu)
         try:
             pa.slab.close_exchangers()
         except Exception:
@@ -705,22 +693,32 @@ def slab_extra_isolated(a, dev, dist, rank, world, local_rank):
     return json.loads(lines[-1])
 
 
-def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=5, transport=None, force_p2p=None):
-    """3D Gray-Scott, Hc=2, fp32: global grid (32*world) x 256 x 256 sharded into slabs along axis 0.  The forward state
-    of every rank is checked bit for bit against the single-domain rollout of the whole grid (computed on every rank)."""
+def _all_max(dist, dev, x):
+    """max over ranks of a host float (gloo groups reduce on the host)"""
+    if dist is None or dist.get_world_size() == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sharded_rollout(dev, dist, rank, world, full_shape, T, halo, reps, transport, force_p2p, P, blocks_seed=0,
+                    breakdown=True):
+    """3D Gray-Scott, Hc=2, fp32: the global grid `full_shape` cut into `world` slabs along axis 0 (axis 0 must divide).
+    Times T-step forward + backward rollouts of the slab path (barrier on both sides, max over ranks, median of `reps`),
+    checks every rank's forward state bit for bit against the single-domain rollout of the whole grid, and -- breakdown --
+    splits the time per step into compute (the same local arrays with a local wrap instead of a transport), communication
+    (the rollout's exchanges alone) and what of it is exposed (total - compute)."""
     import percnn_amd as pa
     from percnn_amd import slab, synthetic
-    sd = load_params(WORKLOADS["gs3d_128"][5])
-    cell = make_cell("gs3d", sd, dev)
-    with torch.no_grad():
-        P = cell.param_block().contiguous()
-    if force_p2p is None:
-        force_p2p = bool(int(os.environ.get("PERCNN_FORCE_P2P", "0")))
+    planes = full_shape[0] // world
+    assert planes * world == full_shape[0] and planes >= halo
     ex = slab.make_exchanger(force_p2p=force_p2p, transport=transport)
-    full_shape = (planes * world, hw, hw)
-    blocks = [synthetic.gs_initial_state((planes, hw, hw), seed=r)[0] for r in range(world)]
-    local = torch.zeros((2, planes + 2 * halo, hw, hw), device=dev)
-    local[:, halo:halo + planes] = blocks[rank].to(dev)
+    local_wrap = world == 1 and not force_p2p
+    gen = torch.Generator().manual_seed(blocks_seed)
+    h_full = synthetic.gs_initial_state(full_shape, seed=blocks_seed)[0]
+    local = torch.zeros((2, planes + 2 * halo) + tuple(full_shape[1:]), device=dev)
+    local[:, halo:halo + planes] = h_full[:, planes * rank:planes * (rank + 1)].to(dev)
     traj = torch.zeros((T + 1,) + tuple(local.shape), device=dev)
     traj[0] = local
     gtraj = torch.randn(traj.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(rank)) / traj.numel()
@@ -732,53 +730,155 @@ def slab_extra(dev, dist, rank, world, planes=32, hw=256, T=40, halo=4, reps=5, 
 
     overlap = bool(int(os.environ.get("PERCNN_SLAB_OVERLAP", "0")))
 
-    def run():
-        slab.slab_rollout_fwd_(traj, P, ex, halo, overlap=overlap)
-        t1 = time.perf_counter()
-        g0, pg = slab.slab_rollout_bwd(traj, gtraj, P, ex, halo, overlap=overlap)
-        return t1, pg
+    def timed(fn, n):
+        fn()
+        fn()                                # second warm-up: lazily created RCCL channels / allocator blocks
+        ts = []
+        for _ in range(n):                  # every pass timed on its own (barrier on both sides, max over ranks); the median is
+            sync()                          # reported: one stray stall (first-use setup inside RCCL) used to dominate
+            s0 = time.perf_counter()
+            fn()
+            sync()
+            ts.append(_all_max(dist, dev, time.perf_counter() - s0))
+        return float(np.median(ts))
 
-    run()
-    run()                                   # second warm-up: lazily created RCCL channels / allocator blocks
-    sync()
-    times = []
-    for _ in range(reps):                   # every rollout pass timed on its own (barrier on both sides, max over ranks);
-        sync()                              # the median is reported: one stray stall (first-use setup inside RCCL) used to
-        s0 = time.perf_counter()            # dominate a single 10 ms timing window
-        t1, pg = run()
-        sync()
-        e = time.perf_counter() - s0
-        if dist is not None:
-            tt = torch.tensor([e], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            e = tt.item()
-        times.append(e)
-    el = float(np.median(times)) * reps
+    res = {}
+
+    def run(e=ex):
+        slab.slab_rollout_fwd_(traj, P, e, halo, overlap=overlap)
+        res["g"] = slab.slab_rollout_bwd(traj, gtraj, P, e, halo, overlap=overlap)
+
+    el = timed(run, reps)
+    pg = res["g"][1]
     assert torch.isfinite(pg).all() and torch.isfinite(traj[-1][:, halo:-halo]).all()
     # verification: the whole grid as ONE periodic domain on this GPU, same kernels -> my planes must match exactly
-    ref = torch.empty((T + 1, 2) + full_shape, device=dev)
-    ref[0] = torch.cat([b.to(dev) for b in blocks], dim=1)
+    ref = torch.empty((T + 1, 2) + tuple(full_shape), device=dev)
+    ref[0] = h_full.to(dev)
     pa.rollout_fwd_(ref, P)
     same = torch.equal(ref[:, :, planes * rank:planes * (rank + 1)], traj[:, :, halo:halo + planes])
     del ref
-    ok = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
+    ok = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev if (dist is None or dist.get_backend() == "nccl") else "cpu")
     if dist is not None:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    out = {"workload": f"gs3d {'x'.join(map(str, full_shape))} sharded into {world} slabs of {planes} planes, Hc=2, "
+    name = "none (one rank: periodic wrap by device copies)" if local_wrap else type(ex).__name__
+    out = {"workload": f"gs3d {'x'.join(map(str, full_shape))} cut into {world} slab(s) of {planes} planes, Hc=2, "
                        f"T={T} fwd+bwd, forward halo {halo} (={halo // 2} steps per exchange), adjoint sweep "
-                       f"exchanges 2 planes per step; native C loop (one call per rollout), overlap={int(overlap)}; "
-                       f"exchanger={type(ex).__name__}",
-           "steps_per_sec_fwd_bwd": reps * T / el, "ms_per_time_step_fwd_bwd": el / (reps * T) * 1e3,
-           "exchange": ("periodic wrap by device copies (one rank, no transport involved)" if world == 1 and not force_p2p
+                       f"exchanges 2 planes per step; native C loop (one call per rollout), overlap={int(overlap)}",
+           "transport": name,
+           "steps_per_sec_fwd_bwd": T / el, "us_per_time_step_fwd_bwd": el / T * 1e6,
+           "exchange": ("periodic wrap by device copies (one rank, no transport involved)" if local_wrap
                         else {"PeerHaloExchanger": "peer mailboxes: put / take kernels + epoch flags (csrc/pi_peer.h)",
                               "RcclHaloExchanger": "ncclSend / ncclRecv groups issued by the native loop",
                               "HaloExchanger": "torch.distributed point-to-point"}[type(ex).__name__]
                         + (" -- to the rank itself" if world == 1 else "")),
            "forward_state_equals_single_domain_rollout": bool(ok.item()),
-           "points_per_rank": planes * hw * hw, "global_points": planes * world * hw * hw,
-           "halo_bytes_per_exchange_per_direction": 2 * halo * hw * hw * 4}
+           "points_per_rank": planes * int(np.prod(full_shape[1:])), "global_points": int(np.prod(full_shape)),
+           "halo_bytes_per_exchange_per_direction": 2 * halo * int(np.prod(full_shape[1:])) * 4}
+    if breakdown and not local_wrap:
+        lw = slab.LocalWrapExchanger()
+        comp = timed(lambda: run(lw), max(2, reps // 2))
+        k = halo // 2
+        face = traj[0]
+
+        def exchanges():                     # the exchanges one fwd+bwd rollout issues, nothing else
+            for _ in range((T + k - 1) // k):
+                ex.exchange(face, halo, halo)
+            for _ in range(T):
+                ex.exchange(face, halo, 2)
+        comm = timed(exchanges, max(2, reps // 2))
+        slab.slab_rollout_fwd_(traj, P, ex, halo, overlap=overlap)      # frame 0's halos were overwritten by the loop above
+        out["per_time_step_us"] = {"total": el / T * 1e6, "compute_alone": comp / T * 1e6, "exchanges_alone": comm / T * 1e6,
+                                   "exposed": max(0.0, (el - comp) / T * 1e6)}
     if hasattr(ex, "status"):
         out["timed_out_exchange"] = ex.status()
+    del traj, gtraj
+    torch.cuda.empty_cache()
+    return out
+
+
+def single_domain_anchor(dev, full_shape, T, reps, P):
+    """N = 1 anchor of a strong-scaling series: the whole grid as ONE periodic domain (no slab layout, no exchange)."""
+    import percnn_amd as pa
+    from percnn_amd import synthetic
+    traj = torch.empty((T + 1, 2) + tuple(full_shape), device=dev)
+    traj[0] = synthetic.gs_initial_state(full_shape, seed=0)[0].to(dev)
+    g = torch.randn(traj.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) / traj.numel()
+    ts = []
+    for i in range(reps + 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pa.rollout_fwd_(traj, P)
+        pa.rollout_bwd(traj, g, P)
+        torch.cuda.synchronize()
+        if i >= 2:
+            ts.append(time.perf_counter() - t0)
+    el = float(np.median(ts))
+    del traj, g
+    torch.cuda.empty_cache()
+    return {"workload": f"gs3d {'x'.join(map(str, full_shape))} single-domain rollout (no slab layout), Hc=2, T={T} fwd+bwd",
+            "transport": "none (single domain)", "steps_per_sec_fwd_bwd": T / el, "us_per_time_step_fwd_bwd": el / T * 1e6,
+            "global_points": int(np.prod(full_shape))}
+
+
+def sharded_series(dev, dist, rank, world, one_gpu):
+    """What the slab child reports:
+      weak    -- configs[4]-shaped, 32 planes of 256^2 per rank (256^3 at N = 8), every usable transport;
+      strong  -- north_star's curve: FIXED global grids 256^3 (configs[4]) and 128^3 cut into N slabs, on the transport the
+                 start-up probe picked; N = 1 is the single-domain rollout.  The driver divides by its own N = 1 line."""
+    import percnn_amd as pa
+    from percnn_amd import slab
+    sd = load_params(WORKLOADS["gs3d_128"][5])
+    cell = make_cell("gs3d", sd, dev)
+    with torch.no_grad():
+        P = cell.param_block().contiguous()
+    force_p2p = bool(int(os.environ.get("PERCNN_FORCE_P2P", "0")))
+    small = bool(int(os.environ.get("PERCNN_BENCH_SMALL", "0")))          # test mode: tiny grids, same control flow
+    hw, planes, halo = (64, 8, 4) if small else (256, 32, 4)
+    Tw, reps = (6, 2) if small else (40, 5)
+    out = {}
+    # ---- transport: probe, do not guess (one-GPU mode has no RCCL between its ranks: torch.distributed / mailboxes)
+    cands = ("dist", "peer") if one_gpu else ("rccl", "peer")
+    picked, probe = "dist", {}
+    if world > 1 or force_p2p:
+        try:
+            sample = torch.rand((2, planes + 2 * halo, hw, hw), device=dev)
+            picked, probe = slab.probe_transport(sample, halo, candidates=cands, force_p2p=force_p2p)
+            del sample
+        except Exception as e:
+            probe = {"error": repr(e)[:300]}
+    out["transport_probe"] = probe
+
+    def guarded(fn):
+        try:
+            return fn()
+        except Exception as e:
+            return {"error": repr(e)[:300]}
+
+    # ---- weak scaling (the round-1/2 figure), on every candidate so that the line shows both
+    weak = {}
+    if world == 1 and not force_p2p:
+        weak["local_wrap"] = guarded(lambda: sharded_rollout(dev, dist, rank, world, (planes, hw, hw), Tw, halo, reps, "dist", False, P))
+        if not int(os.environ.get("PERCNN_NO_PEER", "0")):      # one rank: put / take through the rank's own mailbox
+            weak["peer_to_self"] = guarded(lambda: sharded_rollout(dev, dist, rank, world, (planes, hw, hw), Tw, halo, reps, "peer", True, P))
+    else:
+        for name in cands:
+            if probe.get(name, {}).get("usable_on_every_rank"):
+                weak[name] = guarded(lambda: sharded_rollout(dev, dist, rank, world, (planes * world, hw, hw), Tw, halo, reps,
+                                                             name, force_p2p, P))
+    out["weak_scaling"] = {"what": f"{planes} planes of {hw}^2 per rank", "by_transport": weak}
+    # ---- strong scaling: fixed global grids
+    strong = {}
+    for n3, T in (((32, 2) if small else (256, 10)), ((16, 2) if small else (128, 40))):
+        full = (n3, n3, n3)
+        key = f"{n3}^3"
+        if n3 % world or n3 // world < halo:
+            strong[key] = {"skipped": f"{n3} planes do not cut into {world} slabs of >= {halo}"}
+        elif world == 1 and not force_p2p:
+            strong[key] = guarded(lambda: single_domain_anchor(dev, full, T, 3, P))
+        else:
+            strong[key] = guarded(lambda: sharded_rollout(dev, dist, rank, world, full, T, halo, 3, picked, force_p2p, P))
+    out["strong_scaling"] = {"what": "fixed global grid cut into N slabs along axis 0; N = 1 = single-domain rollout",
+                             "transport": picked if (world > 1 or force_p2p) else "none", "by_grid": strong}
     return out
 
 

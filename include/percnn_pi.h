@@ -271,7 +271,10 @@ typedef struct percnn_pi_peer_ring {
     void* next_box;
     size_t slot_bytes;          /* the capacity all three mailboxes were allocated with */
     uint64_t epoch;             /* exchanges issued so far (in/out) */
-    uint64_t timeout_ticks;     /* bounded wait of a take, in 10 ns ticks; 0 = default (5 s) */
+    uint64_t timeout_ticks;     /* bounded wait of a take, in 10 ns ticks; 0 = default: PERCNN_PEER_TIMEOUT_S seconds
+                                 * (environment, default 300).  A take that times out records the exchange number in the
+                                 * mailbox (percnn_pi_peer_box_status) and fills its halo planes with NaNs; so does every
+                                 * later take of that mailbox. */
 } percnn_pi_peer_ring;
 
 typedef struct percnn_pi_halo_ring {
@@ -292,6 +295,11 @@ typedef struct percnn_pi_halo_ring {
  * ("key=value,..." or NULL): out[6] = {log2 lanes along x (-1 = flat), x blocks per row, row groups per plane, virtual blocks,
  * planes per pass of the adjoint, workgroup size} */
 int percnn_pi_debug_blockmap(int ndim, const int64_t* shape, int elem_size, const char* options, int* out);
+/* Host-only: which kernel family a rollout of this problem takes (the library's own dispatch rules, for 16-byte-aligned
+ * buffers).  out[8] = {forward family, adjoint family, 1 if the parameter gradients are reduced inside the sweep launches,
+ * time steps per forward launch, per adjoint launch, planes per pass forward, adjoint, 0}; families: 0 direct step kernels,
+ * 1 2D tile kernels, 2 3D plane streaming, 3 3D brick kernels, 4 advective block. */
+int percnn_pi_debug_plan(int hc, int ndim, const int64_t* shape, int elem_size, const char* options, int* out);
 
 size_t percnn_pi_peer_box_bytes(size_t slot_bytes);                 /* size of a mailbox allocation */
 int percnn_pi_peer_box_alloc(void** box, size_t slot_bytes);        /* fine-grained device memory on the current device, zeroed */

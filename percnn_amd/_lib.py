@@ -30,7 +30,7 @@ EXPORTS = [
     "percnn_pi_peer_box_open", "percnn_pi_peer_box_close", "percnn_pi_peer_box_status",
     "percnn_pi_peer_exchange_f32", "percnn_pi_peer_exchange_f64",
     "percnn_pi_pack_fwd_f32", "percnn_pi_pack_fwd_f64", "percnn_pi_pack_bwd_f32", "percnn_pi_pack_bwd_f64",
-    "percnn_pi_debug_blockmap",
+    "percnn_pi_debug_blockmap", "percnn_pi_debug_plan",
 ] + [f"percnn_pi_{op}_{suf}" for suf in ("f32", "f64")
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
                 "slab_step_fwd_range", "slab_step_bwd_range", "slab_rollout_fwd", "slab_rollout_bwd", "residual_fwd",
@@ -117,6 +117,8 @@ def lib() -> ctypes.CDLL:
     L.percnn_pi_peer_box_status.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), vp]
     L.percnn_pi_debug_blockmap.restype = ci
     L.percnn_pi_debug_blockmap.argtypes = [ci, i64p, ci, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    L.percnn_pi_debug_plan.restype = ci
+    L.percnn_pi_debug_plan.argtypes = [ci, ci, i64p, ci, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
     cd = ctypes.c_double
     for suf in ("f32", "f64"):
         f = getattr(L, f"percnn_pi_pack_fwd_{suf}")
@@ -212,6 +214,18 @@ def check(rc: int, what: str) -> None:
 
 def shape_arg(shape):
     return (ctypes.c_int64 * len(shape))(*[int(s) for s in shape])
+
+
+FAMILIES = {0: "direct", 1: "tile2d", 2: "stream3d", 3: "brick3d", 4: "advective"}
+
+
+def rollout_plan(hc: int, shape, elem_size: int, options=None) -> dict:
+    """Kernel families a rollout of this problem runs on (the library's own dispatch, ``percnn_pi_debug_plan``)."""
+    out = (ctypes.c_int * 8)()
+    check(lib().percnn_pi_debug_plan(int(hc), len(shape), shape_arg(shape), int(elem_size), options_arg(options), out),
+          "debug_plan")
+    return {"fwd": FAMILIES[out[0]], "bwd": FAMILIES[out[1]], "fused_gradients": bool(out[2]), "fwd_steps_per_launch": out[3],
+            "bwd_steps_per_launch": out[4], "fwd_planes_per_pass": out[5], "bwd_planes_per_pass": out[6]}
 
 
 def set_option(key: str, value: int) -> None:

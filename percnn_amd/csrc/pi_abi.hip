@@ -1008,6 +1008,22 @@ template <> int ring_dtype<float>(const percnn_pi_halo_ring* r) { return r->dtyp
 template <> int ring_dtype<double>(const percnn_pi_halo_ring* r) { return r->dtype_f64; }
 
 // the same exchange through the peer mailboxes (pi_peer.h): put into the neighbours' slots, take from mine
+// bounded wait of a take when the ring does not say: PERCNN_PEER_TIMEOUT_S seconds (default 300 -- a rank that compiles the
+// library, writes a checkpoint or loads data may arrive minutes late; the bound is there against DEAD neighbours), in 10 ns ticks
+unsigned long long peer_default_timeout_ticks()
+{
+    static const unsigned long long ticks = [] {
+        double s = 300.0;
+        if (const char* e = std::getenv("PERCNN_PEER_TIMEOUT_S")) {
+            char* end = nullptr;
+            const double v = std::strtod(e, &end);
+            if (end != e && v > 0.0) s = v;
+        }
+        return (unsigned long long)(s * 1e8);
+    }();
+    return ticks;
+}
+
 template <typename T>
 int peer_exchange(T* slab, const Problem& p, int width, percnn_pi_peer_ring* pr, hipStream_t st)
 {
@@ -1045,7 +1061,7 @@ int peer_exchange(T* slab, const Problem& p, int width, percnn_pi_peer_ring* pr,
     put.mine = take.mine = static_cast<pi::PeerBox*>(pr->my_box);
     put.signal[0] = static_cast<pi::PeerBox*>(pr->next_box);
     put.signal[1] = static_cast<pi::PeerBox*>(pr->prev_box);
-    const unsigned long long ticks = pr->timeout_ticks ? pr->timeout_ticks : 500000000ull;
+    const unsigned long long ticks = pr->timeout_ticks ? pr->timeout_ticks : peer_default_timeout_ticks();
     if (vec) {
         hipLaunchKernelGGL(pi::peer_put_kernel<true>, dim3(2 * bpd), dim3(256), 0, st, put);
         hipLaunchKernelGGL(pi::peer_take_kernel<true>, dim3(2 * bpd), dim3(256), 0, st, take, ticks);
@@ -1617,6 +1633,47 @@ int apply_overrides(Options& o, const char* spec)
 }  // namespace
 
 
+namespace {
+// Which kernel family a rollout of this problem runs on and how its backward is scheduled -- the library's own dispatch
+// rules, evaluated for 16-byte-aligned buffers (bench.py labels its roofline entries with it instead of mirroring the rules).
+// out = {forward family, adjoint family, gradients reduced inside the sweep launches (0 / 1), time steps per forward launch,
+//        per adjoint launch, planes per pass forward, adjoint, 0}; families: 0 direct, 1 2D tiles, 2 plane streaming, 3 3D bricks,
+//        4 advective block
+template <typename T>
+int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options, int* out)
+{
+    Problem p;
+    if (int rc = make_problem(hc, ndim, shape, false, p, options)) return rc;
+    const int vec = pick_vec<T>(p, {});
+    auto family = [&](bool adjoint, bool wgrad, int& planes) {
+        planes = 1;
+        if (p.hc == -1) return 4;
+        if (tile_eligible<T>(p, {}, adjoint)) return 1;
+        if (!adjoint || !wgrad || (p.hc == 0 && sizeof(T) == 4))
+            if (stream3d_vec<T>(p, {}, adjoint)) return 2;
+        if (!adjoint || !wgrad || p.hc == 0)
+            if (const int brz = brick_rz_for<T>(p, vec, adjoint)) { planes = brz; return 3; }
+        planes = direct_rz<T>(p, vec, adjoint);
+        return 0;
+    };
+    const bool f32poly = hc == 0 && sizeof(T) == 4;
+    const bool tiled_adj = tile_eligible<T>(p, {}, true);
+    const bool direct_sweep = !tiled_adj && (f32poly || !stream3d_vec<T>(p, {}, true));
+    const bool tile_fused = tiled_adj && tile_fuse_ok<T>(p);
+    const bool fuse = tile_fused || (direct_sweep && !p.opt.skip_wgrad && hc != -1 &&
+                                     (p.opt.fuse_wgrad == 1 || (p.opt.fuse_wgrad == 2 && hc == 0)));
+    const int K = (p.opt.tile_k == 8 && p.hc != 0) ? 4 : p.opt.tile_k;
+    out[0] = family(false, false, out[5]);
+    out[1] = family(true, fuse, out[6]);
+    out[2] = fuse ? 1 : 0;
+    out[3] = out[0] == 1 ? K : 1;
+    out[4] = out[1] == 1 ? K : 1;
+    out[7] = 0;
+    return 0;
+}
+
+}  // namespace
+
 // ---- exported symbols ---------------------------------------------------------------------------
 extern "C" {
 
@@ -1696,6 +1753,12 @@ int percnn_pi_debug_blockmap(int ndim, const int64_t* shape, int elem_size, cons
                       p.opt.lane_x)) return PERCNN_PI_EINVAL;
     out[0] = g.lxs; out[1] = g.nxb; out[2] = g.nrg; out[3] = (int)g.nblk; out[4] = rz; out[5] = block;
     return 0;
+}
+
+int percnn_pi_debug_plan(int hc, int ndim, const int64_t* shape, int elem_size, const char* options, int* out)
+{
+    if (!out || (elem_size != 4 && elem_size != 8)) return PERCNN_PI_EINVAL;
+    return elem_size == 4 ? debug_plan_impl<float>(hc, ndim, shape, options, out) : debug_plan_impl<double>(hc, ndim, shape, options, out);
 }
 
 size_t percnn_pi_param_count(int hc) { return hc < -1 ? 0 : (size_t)pi::nparams(hc); }

@@ -138,6 +138,11 @@ struct PackPtrs {
     const void* br[16];     // Wh1_u.weight, Wh1_u.bias, ..., Wh4_u.bias, Wh1_v.weight, ..., Wh4_v.bias
 };
 
+// forward value: ATen's own formula in the parameter dtype (1 / (1 + exp(-x)) in T, UnarySpecialOpsKernel.cu), so that the
+// one-launch packing gives the same diffusion coefficient as `mu_up * torch.sigmoid(CA)` on the device (the
+// float64 evaluation rounded to T could differ from it by one ulp); the derivative below stays in float64
+template <typename T>
+__device__ __forceinline__ T pack_sigmoid_t(T x) { return T(1) / (T(1) + exp(-x)); }
 template <typename T>
 __device__ __forceinline__ double pack_sigmoid(T x) { return 1.0 / (1.0 + exp(-(double)x)); }
 
@@ -150,7 +155,7 @@ __device__ __forceinline__ void pack_stage(const PackPtrs& pp, int hc, int ndim,
     if (t < 2) {
         const T x = *static_cast<const T*>(pp.c[t]);
         // the reference rounds the sigmoid to the parameter dtype and multiplies by the Python float in that dtype
-        stage[P_COEF + t] = sigmoid ? (T)((T)pack_sigmoid(x) * (T)mu_up) : x;
+        stage[P_COEF + t] = sigmoid ? (T)(pack_sigmoid_t(x) * (T)mu_up) : x;
     }
     if (t >= 32 && t < 32 + 13) {
         const T* w = static_cast<const T*>(pp.w);

@@ -109,9 +109,25 @@ __global__ void __launch_bounds__(256) peer_take_kernel(PeerXfer x, unsigned lon
             __builtin_amdgcn_s_sleep(2);
         }
     }
+    __shared__ int arrived;
+    if (threadIdx.x == 0)
+        arrived = __hip_atomic_load(&x.mine->flag[dir][0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= x.epoch;
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                // every wave: nothing older than the flag is read below
-    for (int s = 0; s < 2; ++s) peer_copy<VEC>(x.src[dir][s], x.dst[dir][s], x.bytes, lb, x.blocks_per_dir);
+    if (arrived) {
+        for (int s = 0; s < 2; ++s) peer_copy<VEC>(x.src[dir][s], x.dst[dir][s], x.bytes, lb, x.blocks_per_dir);
+    } else {
+        // timed out (now or in an earlier exchange: the error word is sticky): whatever sits in the slot is NOT this
+        // exchange's face.  Poison the halo planes instead of copying it, so that a late or dead neighbour shows up as
+        // NaNs in the very next step rather than as silently wrong halos (all-ones bit patterns are NaNs in float32 and
+        // float64 alike); the hosts' status checks report the exchange number.
+        const size_t words = x.bytes / 4, per = (words + (size_t)x.blocks_per_dir - 1) / (size_t)x.blocks_per_dir;
+        const size_t w0 = per * (size_t)lb, w1 = w0 + per < words ? w0 + per : words;
+        for (int s = 0; s < 2; ++s) {
+            unsigned* d = reinterpret_cast<unsigned*>(x.dst[dir][s]);
+            for (size_t i = w0 + threadIdx.x; i < w1; i += blockDim.x) d[i] = 0xffffffffu;
+        }
+    }
 }
 
 }  // namespace pi

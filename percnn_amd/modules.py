@@ -138,7 +138,9 @@ class RCNNCell(nn.Module):
             if not torch.compiler.is_compiling():
                 self._validate_stencil()
             tensors = self._pack_tensors()
-            if all(t.is_contiguous() for t in tensors):
+            # (anything the kernel's pointer table cannot describe -- views, mixed dtypes / devices -- takes the tensor-op
+            # assembly below instead of raising)
+            if all(t.is_contiguous() and t.dtype == w.dtype and t.device == w.device for t in tensors):
                 meta = (self.hidden_channels, self.ndim, float(self.dt),
                         float(self.mu_up) if self.diffusion == "sigmoid" else 0.0, self.diffusion == "sigmoid",
                         self.reaction == "poly")

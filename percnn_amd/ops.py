@@ -253,11 +253,19 @@ def _(traj, params, g_pred, t_idx, strides, options=""):
 def _observe_setup(ctx, inputs, output):
     _h0, params, _steps, t_idx, strides, options = inputs
     _pred, traj = output
+    ctx.mark_non_differentiable(traj)
+    ctx.set_materialize_grads(False)
     ctx.save_for_backward(traj, params)
     ctx.t_idx, ctx.strides, ctx.options = list(t_idx), list(strides), options
 
 
-def _observe_bwd(ctx, g_pred, _g_traj_unused):
+def _observe_bwd(ctx, g_pred, g_traj):
+    # `traj` is returned for inspection / logging only: the operator declares it non-differentiable (setup_context), and a
+    # gradient that reaches it nevertheless -- a caller that put a loss on the second output of the raw operator -- must
+    # not be dropped silently
+    if g_traj is not None:
+        raise RuntimeError("percnn::pi_rollout_observe: its `traj` output is not differentiable (a loss on the trajectory "
+                           "itself goes through percnn::pi_rollout, or through RCNN.trajectory())")
     traj, params = ctx.saved_tensors
     g_h0, g_p = torch.ops.percnn.pi_rollout_observe_backward(traj, params, g_pred.contiguous(), ctx.t_idx, ctx.strides,
                                                              ctx.options)

@@ -132,6 +132,11 @@ class HaloExchanger:
         this exchanger, and the ``percnn_pi_halo_ring*`` to pass (None = single rank, local periodic wrap)."""
         return (self.world == 1 and not self.force_p2p), None
 
+    def check(self) -> None:
+        """Raise if an exchange of this exchanger failed without an error code (peer mailboxes: a take that timed out).
+        Called once at the end of every slab rollout; a no-op for transports that report failures synchronously."""
+        return None
+
     def prepare(self, slab: torch.Tensor, halo: int) -> None:
         """Collective hook called once per slab rollout before any exchange of ``slab``-shaped arrays (width <= halo):
         transports that own buffers size them here.  Nothing to do for message passing."""
@@ -368,13 +373,13 @@ class PeerHaloExchanger(HaloExchanger):
         if self.world > 1:
             dist.barrier(group=self.group)          # nobody frees / re-sizes before everybody has mapped
 
-    def _release(self) -> None:
+    def _release(self, barrier: bool = True) -> None:
         if self._peer is None:
             return
         L = self._L.lib()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
-        if self.world > 1:
+        if self.world > 1 and barrier and dist.is_available() and dist.is_initialized():
             try:
                 dist.barrier(group=self.group)      # the neighbours may still be writing into / reading from it
             except Exception:
@@ -398,6 +403,14 @@ class PeerHaloExchanger(HaloExchanger):
         st = self._ct.c_void_p(torch.cuda.current_stream().cuda_stream)
         self._L.check(self._L.lib().percnn_pi_peer_box_status(self._box, self._ct.byref(e), st), "peer_box_status")
         return int(e.value)
+
+    def check(self) -> None:
+        """A take that timed out fills its halo planes with NaNs and records the exchange number; this turns that record
+        into an exception (one stream synchronisation -- the slab rollouts call it once per rollout, not per exchange)."""
+        e = self.status()
+        if e:
+            raise RuntimeError(f"percnn_amd: peer-mailbox halo exchange #{e} of rank {self.rank} timed out (a ring neighbour "
+                               f"did not deliver within PERCNN_PEER_TIMEOUT_S); halos from that exchange on are NaN")
 
     # -- exchanges -------------------------------------------------------------------------------------------------
     def exchange(self, slab: torch.Tensor, halo: int, width: Optional[int] = None) -> None:
@@ -436,11 +449,22 @@ class PeerHaloExchanger(HaloExchanger):
             done.record(self._side)
         return _StreamDone(done)
 
-    def close(self):
-        self._release()
+    def close(self, barrier: bool = True):
+        self._release(barrier)
 
 
-_exchangers: dict = {}
+_exchangers: dict = {}          # key -> (exchanger, the ProcessGroup object it was built on)
+
+
+def _group_object(group):
+    """The ProcessGroup an exchanger of `group` lives on (None: no torch.distributed job).  The cache keeps a reference to it
+    next to the exchanger: an `id()` alone can be handed to a NEW group once the old one is gone, and the default group is
+    a different object after destroy_process_group() + init_process_group()."""
+    if group is not None:
+        return group
+    if dist.is_available() and dist.is_initialized():
+        return dist.distributed_c10d._get_default_group()
+    return None
 
 
 def _all_ranks_agree(ok: bool, group) -> bool:
@@ -473,10 +497,19 @@ def make_exchanger(group=None, prefer_rccl: bool = True, force_p2p: bool = False
     if transport == "dist":
         prefer_rccl = False
     dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
-    key = (id(group) if group is not None else None, dev, bool(prefer_rccl), bool(force_p2p), transport == "peer")
-    ex = _exchangers.get(key)
-    if ex is not None:
-        return ex
+    pg = _group_object(group)
+    key = (id(pg) if pg is not None else None, dev, bool(prefer_rccl), bool(force_p2p), transport == "peer")
+    hit = _exchangers.get(key)
+    if hit is not None:
+        if hit[1] is pg:                       # same live group object: every rank takes this branch together
+            return hit[0]
+        # the group this exchanger was built on is gone (destroy_process_group + re-init, or its id was recycled):
+        # its communicator / mapped mailboxes belong to dead peers -- drop it without collectives and build a new one
+        del _exchangers[key]
+        try:
+            hit[0].close(barrier=False) if isinstance(hit[0], PeerHaloExchanger) else getattr(hit[0], "close", lambda: None)()
+        except Exception:
+            pass
     ex = None
     if transport == "peer" and torch.cuda.is_available():
         err = None
@@ -504,22 +537,96 @@ def make_exchanger(group=None, prefer_rccl: bool = True, force_p2p: bool = False
                           "using torch.distributed point-to-point")
     if ex is None:
         ex = HaloExchanger(group, force_p2p)
-    _exchangers[key] = ex
+    _exchangers[key] = (ex, pg)
     return ex
 
 
-def close_exchangers() -> None:
-    for ex in list(_exchangers.values()):
+class LocalWrapExchanger(HaloExchanger):
+    """No neighbours: every exchange wraps the slab onto itself with device copies, whatever process group is up.  What
+    ``bench.py`` uses to time the COMPUTE share of a sharded rollout (same local arrays, same kernels, no transport);
+    physically meaningful only for world size 1."""
+
+    def __init__(self):
+        self.group, self.force_p2p = None, False
+        self.rank, self.world, self.prev, self.next = 0, 1, 0, 0
+        self._bufs = {}
+
+    def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        return t
+
+
+def probe_transport(sample: torch.Tensor, halo: int, group=None, candidates=("rccl", "peer"), reps: int = 2,
+                    force_p2p: bool = False):
+    """Pick the halo transport by a start-up probe instead of by default (VERDICT r2 #2d): every candidate exchanges the
+    faces of ``sample`` (a local padded slab, left untouched) ``reps`` times at the two widths a rollout uses (``halo`` and
+    2 planes); a candidate counts only if its set-up works on EVERY rank and its halos equal, bit for bit, those of the
+    portable ``torch.distributed`` exchange of the same slab; the fastest one (max over ranks) wins.  Collective.
+    Returns (name, report) with name in ``candidates`` or "dist"."""
+    import time
+    ref = sample.clone()
+    HaloExchanger(group, force_p2p).exchange(ref, halo, halo)
+    report, best, best_t = {}, "dist", None
+    cuda = sample.is_cuda
+    for name in candidates:
+        entry = {}
+        try:
+            ex = make_exchanger(group, prefer_rccl=(name != "dist"), force_p2p=force_p2p, transport=name)
+            want = {"rccl": RcclHaloExchanger, "peer": PeerHaloExchanger, "dist": HaloExchanger}[name]
+            ok = type(ex) is want
+            if ok:
+                ex.prepare(sample, halo)
+                work = sample.clone()
+                ex.exchange(work, halo, halo)                       # also the warm-up (lazily created channels)
+                if cuda:
+                    torch.cuda.synchronize()
+                ok = bool(torch.equal(work, ref))
+                entry["halos_equal_portable_exchange"] = ok
+                ts = []
+                for _ in range(max(1, reps)):
+                    if cuda:
+                        torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    ex.exchange(work, halo, halo)
+                    ex.exchange(work, halo, 2)
+                    if cuda:
+                        torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                entry["us_per_exchange_pair"] = min(ts) * 1e6
+                ex.check()
+        except Exception as e:                                      # a transport that cannot come up here is not a candidate
+            ok = False
+            entry["error"] = repr(e)[:200]
+        ok = _all_ranks_agree(ok, group)
+        t = entry.get("us_per_exchange_pair", float("inf")) if ok else float("inf")
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dev = sample.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            tt = torch.tensor([t if t != float("inf") else 1e30], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
+            t = float(tt.item())
+        entry["usable_on_every_rank"] = bool(ok)
+        entry["max_over_ranks_us"] = None if t >= 1e29 else t
+        report[name] = entry
+        if ok and t < 1e29 and (best_t is None or t < best_t):
+            best, best_t = name, t
+    report["picked"] = best
+    return best, report
+
+
+def close_exchangers(barrier: bool = True) -> None:
+    """Close every cached exchanger.  Call it (on all ranks) BEFORE ``dist.destroy_process_group()``: the mailbox transport
+    synchronises its ranks once more so that nobody unmaps a mailbox a neighbour still writes to.  ``barrier=False`` (what
+    the interpreter-exit hook uses: peers may already be gone, a barrier would wait for its time-out) skips that."""
+    for ex, _ in list(_exchangers.values()):
         if hasattr(ex, "close"):
             try:
-                ex.close()
+                ex.close(barrier=barrier) if isinstance(ex, PeerHaloExchanger) else ex.close()
             except Exception:
                 pass
     _exchangers.clear()
 
 
 import atexit
-atexit.register(close_exchangers)
+atexit.register(close_exchangers, False)
 
 
 def slab_rollout_fwd_(traj: torch.Tensor, P: torch.Tensor, ex: HaloExchanger, halo: int,
@@ -543,7 +650,9 @@ def slab_rollout_fwd_(traj: torch.Tensor, P: torch.Tensor, ex: HaloExchanger, ha
     if step_fwd is F_pi.step_fwd and traj.is_cuda:
         usable, ring = ex.native_ring()
         if usable:                                    # the whole loop in one C call (no per-step host work)
-            return F_pi.slab_rollout_fwd_native_(traj, P, halo, ring, overlap and ring is not None)
+            F_pi.slab_rollout_fwd_native_(traj, P, halo, ring, overlap and ring is not None)
+            ex.check()
+            return traj
     T = traj.shape[0] - 1
     k = halo // 2
     n = traj.shape[2] - 2 * halo
@@ -565,6 +674,7 @@ def slab_rollout_fwd_(traj: torch.Tensor, P: torch.Tensor, ex: HaloExchanger, ha
                 step_fwd(traj[t], P, out=traj[t + 1], slab=True, halo=halo, planes=(2 * halo, n))
         else:
             step_fwd(traj[t], P, out=traj[t + 1], slab=True, halo=halo, skip=2 * m)
+    ex.check()
     return traj
 
 
@@ -586,6 +696,7 @@ def slab_rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor, 
         usable, ring = ex.native_ring()
         if usable:
             adj, pg = F_pi.slab_rollout_bwd_native(traj, g_traj, P, halo, ring, overlap and ring is not None)
+            ex.check()
             ex.all_reduce_sum_(pg)
             return adj[0], pg
     T = traj.shape[0] - 1
@@ -642,6 +753,7 @@ def slab_rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor, 
         g0 = adj[0]
     else:
         g0 = dst(1)
+    ex.check()
     ex.all_reduce_sum_(pg)
     return g0, pg
 

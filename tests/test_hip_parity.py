@@ -651,6 +651,10 @@ def test_peer_mailbox_exchange_to_self(hip_device):
                                                      ctypes.byref(ring), st), "exchange")
         torch.cuda.synchronize()
         assert px.status() == 1000001 and ring.epoch == 1000003
+        # ... and the halo planes it could not fill are poisoned, not stale: the interior is untouched
+        assert torch.isnan(c[:, :2]).all() and torch.isnan(c[:, 12:]).all() and torch.isfinite(c[:, 2:12]).all()
+        with pytest.raises(RuntimeError, match="timed out"):
+            px.check()
         L.percnn_pi_peer_box_free(silent)
         # capacity check: a face that does not fit the slots is refused, not truncated
         big = torch.rand((2, 40, 64, 64), device=hip_device)
@@ -1216,6 +1220,10 @@ def test_observe_equals_cat_and_slice(ndim, hip_device):
     g_obs = grads(torch.nn.functional.mse_loss(pred, truth))
     for a, b in zip(g_obs, g_ref):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+    # the raw operator: its trajectory output is declared non-differentiable (a loss on it can not be dropped silently)
+    t_idx = list(range(steps + 1))[tsl]
+    pred2, traj2 = torch.ops.percnn.pi_rollout_observe(h0, cell.param_block(), steps, t_idx, [stride] * ndim, "")
+    assert torch.equal(pred2, ref) and pred2.requires_grad and not traj2.requires_grad
 
 
 @pytest.mark.parametrize("shape", [(6, 5, 7), (16, 16, 64), (9, 33, 70)])

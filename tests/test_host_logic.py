@@ -457,6 +457,29 @@ def test_direct_kernel_block_decomposition_rules():
     assert bm((192,) * 3, 4, "lane_x=7")["lxs"] == -1 and bm((192,) * 3, 4, "lane_x=5")["lxs"] == 5
 
 
+def test_rollout_plan_follows_the_dispatch_rules():
+    """percnn_pi_debug_plan = the library's own answer to "which kernels would this rollout run on" (bench.py labels its
+    roofline entries with it): the BASELINE configs and the switch points documented in DESIGN.md."""
+    from percnn_amd import _lib
+    plan = _lib.rollout_plan
+    p = plan(0, (512, 512), 4)
+    assert p["fwd"] == "tile2d" and p["bwd"] == "tile2d" and p["fused_gradients"] and p["fwd_steps_per_launch"] == 4
+    p = plan(0, (128, 128, 128), 4)                       # 3D Gray-Scott 128^3: bricks, two planes forward, one adjoint
+    assert p == {"fwd": "brick3d", "bwd": "brick3d", "fused_gradients": True, "fwd_steps_per_launch": 1,
+                 "bwd_steps_per_launch": 1, "fwd_planes_per_pass": 2, "bwd_planes_per_pass": 1}
+    assert plan(0, (48, 48, 48), 4)["fwd_planes_per_pass"] == 1
+    p = plan(0, (256, 256, 256), 4)                       # forward keeps the z-march from 8 M points on, the adjoint takes bricks
+    assert p["fwd"] == "stream3d" and p["bwd"] == "brick3d" and p["bwd_planes_per_pass"] == 2
+    assert plan(0, (64, 256, 256), 4)["fwd"] == "brick3d"
+    assert plan(0, (384, 384, 384), 4)["fwd"] == "direct"                 # rows of 96 chunks: beyond the brick windows
+    assert plan(0, (128, 128, 128), 4, "brick3d=0")["fwd"] == "direct"
+    assert plan(2, (48, 48, 48), 4)["bwd"] == "brick3d" and not plan(2, (48, 48, 48), 4)["fused_gradients"]
+    assert plan(0, (30, 30, 30), 4)["fwd"] == "direct"                    # W % 4 != 0: 4-byte lanes
+    p = plan(0, (512, 512), 8)
+    assert p["fwd"] == "tile2d" and p["fused_gradients"]
+    assert plan(0, (2048, 2048), 4)["bwd"] == "direct" and plan(-1, (100, 100), 8)["fwd"] == "advective"
+
+
 def test_3d_upscaler_contraction_path_equals_stock_layers():
     """The 3D IC generator evaluates its transposed convolutions as matmuls (MIOpen's ConvTranspose3d is 15x slower on
     MI355X); values and all gradients must equal the stock torch.nn layers it holds (train_3drd.py:41-56)."""

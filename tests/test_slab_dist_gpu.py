@@ -51,6 +51,14 @@ def _worker(rank, world, port, shape, halo, T, hc, dtype_name, overlap, transpor
         pa.rollout_fwd_(traj_ref, P)
         g_ref = torch.tensor(rs.uniform(-1, 1, tuple(traj_ref.shape)).astype(dtype), device=dev)
         g0_ref, pg_ref = pa.rollout_bwd(traj_ref, g_ref, P)
+        # float64 yardstick for the float32 parameter gradients (two reduction orders of heavily cancelling sums): the same
+        # rollout in float64 is "exact" at this scale; the slab path may be as far from it as the plain path is
+        pg_exact = None
+        if dtype == np.float32:
+            P64, t64 = P.double(), torch.empty(traj_ref.shape, dtype=torch.float64, device=dev)
+            t64[0] = h0.double()
+            pa.rollout_fwd_(t64, P64)
+            _, pg_exact = pa.rollout_bwd(t64, g_ref.double(), P64)
 
         ex = slab.make_exchanger(prefer_rccl=False, transport=transport)
         want = slab.PeerHaloExchanger if transport == "peer" else slab.HaloExchanger
@@ -66,7 +74,11 @@ def _worker(rank, world, port, shape, halo, T, hc, dtype_name, overlap, transpor
         g_local[:, :, halo:halo + n] = g_ref[:, :, lo:hi]
         g0, pg = slab.slab_rollout_bwd(traj, g_local, P, ex, halo, overlap=overlap)
         ok_g0 = bool(torch.equal(g0[:, halo:halo + n], g0_ref[:, lo:hi]))
-        err_pg = float((pg - pg_ref).norm() / pg_ref.norm())
+        if pg_exact is None:
+            err_pg, err_plain = float((pg - pg_ref).norm() / pg_ref.norm()), 0.0
+        else:
+            err_pg = float((pg - pg_exact).norm() / pg_exact.norm())
+            err_plain = float((pg_ref - pg_exact).norm() / pg_exact.norm())
         # the autograd wrapper (what a training script calls) on the same split
         loc = local0.clone().requires_grad_(True)
         out = slab.slab_rollout(loc, P, T, halo=halo, ex=ex)
@@ -85,7 +97,7 @@ def _worker(rank, world, port, shape, halo, T, hc, dtype_name, overlap, transpor
             g0b, pgb = slab.slab_rollout_bwd(traj2, g_local, P, ex, halo, overlap=overlap)
             ok_fwd = ok_fwd and bool(torch.equal(traj2[:, :, halo:halo + n], traj_ref[:, :, lo:hi]))
             ok_g0 = ok_g0 and bool(torch.equal(g0b[:, halo:halo + n], g0_ref[:, lo:hi])) and ex.status() == 0
-        q.put((rank, ok_fwd, ok_g0, err_pg, ok_auto))
+        q.put((rank, ok_fwd, ok_g0, err_pg, ok_auto, err_plain))
     finally:
         try:
             slab.close_exchangers()
@@ -112,9 +124,45 @@ def test_multi_process_slab_rollout_on_one_gpu(world, shape, halo, T, hc, dtype,
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    tol = 5e-4 if dtype == "float32" else 1e-11                # two reduction orders of heavily cancelling sums
-    for rank, ok_fwd, ok_g0, err_pg, ok_auto in sorted(res):
+    for rank, ok_fwd, ok_g0, err_pg, ok_auto, err_plain in sorted(res):
+        # float32: measured against a float64 rollout of the same problem -- "as close to it as the single-domain path, within
+        # a factor of three" (was a flat 5e-4 against the plain path); float64: against the plain path
+        tol = 3.0 * err_plain + 2e-6 if dtype == "float32" else 1e-11
         assert ok_fwd, f"rank {rank}: forward interior differs from the single-domain rollout"
         assert ok_g0, f"rank {rank}: dL/dh0 interior differs"
         assert ok_auto, f"rank {rank}: autograd wrapper dL/dh0 differs"
         assert err_pg < tol, f"rank {rank}: all-reduced parameter gradient rel err {err_pg}"
+
+
+def test_bench_two_ranks_on_one_gpu(hip_device):
+    """bench.py --gpus 2, launched exactly as the driver launches it (python -m torch.distributed.run ...), with both ranks on
+    cuda:0 (PERCNN_BENCH_ONE_GPU: gloo as the control plane) and the sharded series on small grids (PERCNN_BENCH_SMALL): the
+    N > 1 control flow of the harness -- replicas of the headline, the isolated slab child per rank, the transport probe, the
+    weak- and strong-scaling series with their bit-identity checks, the watchdog, ONE JSON line from rank 0 -- runs end to
+    end before the driver's 8-GPU run does (VERDICT r2 #2b)."""
+    import json
+    import subprocess
+    env = dict(os.environ, PERCNN_BENCH_ONE_GPU="1", PERCNN_BENCH_SMALL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["also"]["gs3d_128"]["value"] > 0
+    sl = out["slab_3d"]
+    assert "error" not in sl, sl
+    assert sl["transport_probe"]["picked"] in ("dist", "peer")
+    weak = sl["weak_scaling"]["by_transport"]
+    assert set(weak) >= {"dist"} and all(w.get("forward_state_equals_single_domain_rollout") for w in weak.values()), weak
+    for w in weak.values():
+        b = w["per_time_step_us"]
+        assert b["total"] > 0 and b["compute_alone"] > 0 and b["exchanges_alone"] > 0
+    strong = sl["strong_scaling"]["by_grid"]
+    assert set(strong) == {"32^3", "16^3"}
+    for g in strong.values():
+        assert g.get("forward_state_equals_single_domain_rollout") is True and g["steps_per_sec_fwd_bwd"] > 0, g
