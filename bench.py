@@ -313,9 +313,13 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
         loss = ((pred - 0.5) ** 2).mean()
         torch.autograd.grad(loss, params + [h0])
 
+    def it_loss_mse():
+        loss = model.loss_mse()                          # mean(traj^2) inside the rollout's autograd node
+        torch.autograd.grad(loss, params + [h0])
+
     out = {}
     for key, fn in (("list_cat_dense_loss_ms", it_list), ("trajectory_dense_loss_ms", it_traj),
-                    ("observe_strided_loss_ms", it_observe)):
+                    ("loss_mse_dense_ms", it_loss_mse), ("observe_strided_loss_ms", it_observe)):
         fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
@@ -328,9 +332,42 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
         out[key] = {"gpu_ms": e0.elapsed_time(e1) / reps, "wall_ms": (time.perf_counter() - t0) / reps * 1e3}
     out["what"] = (f"one training iteration through the drop-in modules at {'x'.join(map(str, shape))} x T={T}: RCNN.forward() "
                    "+ torch.cat + mean(traj^2) + backward; RCNN.trajectory() (torch.ops.percnn.pi_rollout, no list / cat) + the same loss; "
+                   "RCNN.loss_mse() = the same dense loss as ONE autograd node with the rollout (gradient formed inside the sweep); "
                    "RCNN.observe(0:-1:20, ::4) + MSE + backward "
                    "(forward, loss, full backward incl. parameter gradients; wall = host clock around the same loop)")
     return out
+
+
+def lo2d_physics_path_extra(pa, dev, reaction, reps=3):
+    """The lambda-omega training iteration of the reference (percnn_LO_eqn.py:371-373: the loss IS the physics residual of
+    the rollout, no data term) through the drop-in modules at BASELINE configs[2]: 512^2, float64, T = 400 -- RCNN.trajectory()
+    -> physics_loss (one residual launch over all frames) -> backward (one residual-adjoint launch, then the sweep)."""
+    from percnn_amd import physics
+    family, shape, hc, dtype, T, golden = WORKLOADS["lo2d_512"]
+    cell = make_cell(family, load_params(golden), dev, reaction)
+    h0 = initial_state(family, shape).to(dev).requires_grad_(True)
+    model = pa.RCNN(cell, step=T, effective_step=list(range(T)), init_state=h0)
+    params = [p for p in cell.parameters() if p.requires_grad]
+    Q = physics.lambda_omega_block(cell, 0.1)
+
+    def it():
+        loss = physics.physics_loss(model.trajectory(), Q)
+        torch.autograd.grad(loss, params + [h0])
+        return loss
+
+    it()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        loss = it()
+    e1.record()
+    torch.cuda.synchronize()
+    return {"what": f"lambda-omega {shape[0]}x{shape[1]} float64, T={T}: RCNN.trajectory() + physics_loss + backward per iteration "
+                    "(the loss of percnn_LO_eqn.py:371-373, in the gradient path)",
+            "gpu_ms": e0.elapsed_time(e1) / reps, "wall_ms": (time.perf_counter() - t0) / reps * 1e3,
+            "time_steps_per_sec": T / (e0.elapsed_time(e1) / reps * 1e-3), "loss_value": float(loss)}
 
 
 def main():
@@ -412,6 +449,10 @@ def main():
                                                           min(a.steps, 10))
         except Exception as e:
             out["strided_data_loss"] = {"error": repr(e)[:200]}
+        try:
+            out["sqerr_loss_in_sweep"] = sqerr_extra(pa, live["traj"], live["P"], T, live["fwd_ms"], min(a.steps, 10))
+        except Exception as e:
+            out["sqerr_loss_in_sweep"] = {"error": repr(e)[:200]}
     del live, res
     torch.cuda.empty_cache()
     if world == 1 and not a.no_extras:
@@ -420,6 +461,12 @@ def main():
         except Exception as e:
             out["module_path"] = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
+        if a.workload == "gs2d_512" and not a.T:
+            try:
+                out["module_path"]["lo2d_512_physics_loss"] = lo2d_physics_path_extra(pa, dev, a.reaction)
+            except Exception as e:
+                out["module_path"]["lo2d_512_physics_loss"] = {"error": repr(e)[:200]}
+            torch.cuda.empty_cache()
 
     # ---- the other half of BASELINE.json's metric ("2D-GS 512^2 & 3D-GS 128^3") in the same line --------------------
     if a.workload == "gs2d_512" and not a.no_also and not a.T:
@@ -428,6 +475,11 @@ def main():
             r3, l3 = measure_workload(pa, dev, dist, rank, world, "gs3d_128", n3, max(1, a.warmup // 2), a.reaction, opts)
             also = {k: r3[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "timed_region_s", "dtype", "config",
                                        "roofline", "fwd_us_per_time_step", "bwd_us_per_time_step")}
+            if world == 1 and not a.no_extras:
+                try:
+                    also["sqerr_loss_in_sweep"] = sqerr_extra(pa, l3["traj"], l3["P"], l3["T"], l3["fwd_ms"], min(n3, 5))
+                except Exception as e:
+                    also["sqerr_loss_in_sweep"] = {"error": repr(e)[:200]}
             if rank == 0 and world == 1 and not a.no_cpu_baseline:
                 also["cpu_baseline"] = cpu_baseline("gs3d", l3["sd"], l3["shape"], budget_s=8.0, threads=cpu_threads,
                                                     extra_counts=False)
@@ -635,6 +687,31 @@ def physics_extra(pa, cell, family, traj, esz, npts):
     return {"frames": F, "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_GBps": b / tf / 1e9, "bwd_GBps": b / tb / 1e9,
             "fwd_frac_of_8TBps": b / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac_of_8TBps": b / tb / 1e9 / HBM_PEAK_GBS,
             "loss_value": float(physics.physics_loss(sub, Q))}
+
+
+def sqerr_extra(pa, traj, P, T, fwd_ms, reps):
+    """the same fwd+bwd rollout with the loss INSIDE the backward -- L = mean(traj^2) (SURVEY 8d's dense loss) is
+    reduced by one streaming pass and its gradient 2/N * h_t is formed by the sweep from the state it reads anyway: no dL/dtraj
+    buffer (2 GB at 512^2 x 1000), 24 instead of 32 algorithmic bytes per point and step in the sweep."""
+    from percnn_amd import functional as F_pi
+    w = 1.0 / traj.numel()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    F_pi.rollout_bwd_sqerr(traj, P, None, None, 2.0 * w)
+    loss = F_pi.traj_sqerr(traj, None, None, w)
+    ev[0].record()
+    for _ in range(reps):
+        loss = F_pi.traj_sqerr(traj, None, None, w)
+    ev[1].record()
+    for _ in range(reps):
+        g0, pg = F_pi.rollout_bwd_sqerr(traj, P, None, None, 2.0 * w)
+    ev[2].record()
+    torch.cuda.synchronize()
+    loss_ms, bwd_ms = ev[0].elapsed_time(ev[1]) / reps, ev[1].elapsed_time(ev[2]) / reps
+    assert torch.isfinite(g0).all() and torch.isfinite(pg).all() and torch.isfinite(loss)
+    return {"what": "L = mean(traj^2): loss value by one streaming pass, gradient formed inside the sweep (no dL/dtraj)",
+            "loss_pass_us_per_time_step": loss_ms * 1e3 / T, "bwd_us_per_time_step": bwd_ms * 1e3 / T,
+            "sweep_algorithmic_bytes_per_point_step": 3 * 2 * traj.element_size(),
+            "fwd_bwd_steps_per_sec": T / ((fwd_ms + loss_ms + bwd_ms) * 1e-3)}
 
 
 def strided_loss_extra(pa, traj, gtraj, P, T, fwd_ms, reps):

@@ -407,6 +407,33 @@ int percnn_pi_rollout_bwd_opt_f64(const double *traj, const double *g_traj, cons
                                   const double *params, int hc, int ndim, const int64_t *shape, int T,
                                   const char *options, void *stream);
 
+/* ---- squared-error losses differentiated INSIDE the sweep (round 3) -------------------------------------------------------
+ * Replaces, for the reference's dense squared-error losses (train_2drd.py:397-407 MSE against data; SURVEY 8d mean(traj^2)),
+ * the sequence  loss = f(torch.cat(outputs)) ; loss.backward()  -- which materialises dL/dtraj (as large as the trajectory)
+ * only for the sweep to read it back -- by a sweep that forms  dL/dh_t = a * (h_t - target_t)  from the state it loads anyway
+ * (24 instead of 32 bytes per point and step; no dL/dtraj buffer).
+ *   L = scale' * sum_{t : frame_mask[t]} sum_x (traj_t - target_t)^2 ,   a = 2 * scale' (pass scale = a), times *dev_scale
+ *   (device scalar of the compute type, nullable: the gradient autograd hands the loss -- no host synchronisation).
+ * target == NULL: target = 0 (mode 1: the sweep reads nothing extra).  frame_mask: HOST array of T_steps + 1 bytes, NULL =
+ * every frame.  Workspace, params, options, error codes as percnn_pi_rollout_bwd_opt_*; PERCNN_PI_EINVAL also for block
+ * kinds without the in-kernel form (advective blocks): materialise the gradient and call percnn_pi_rollout_bwd_* then. */
+int percnn_pi_rollout_bwd_sqerr_f32(const float *traj, const float *target, const unsigned char *frame_mask, double scale,
+                                    const float *dev_scale, float *g_h0, double *param_grad, void *workspace,
+                                    size_t workspace_bytes, const float *params, int hc, int ndim, const int64_t *shape,
+                                    int T_steps, const char *options, void *stream);
+int percnn_pi_rollout_bwd_sqerr_f64(const double *traj, const double *target, const unsigned char *frame_mask, double scale,
+                                    const double *dev_scale, double *g_h0, double *param_grad, void *workspace,
+                                    size_t workspace_bytes, const double *params, int hc, int ndim, const int64_t *shape,
+                                    int T_steps, const char *options, void *stream);
+/* The loss value itself: out[0] = scale * sum_{f < nframes : frame_mask[f]} sum_x (traj_f - target_f)^2 in ONE streaming
+ * pass (float64 accumulation); workspace >= 8 KiB, 8-byte aligned; at most 64 runs of consecutive selected frames. */
+int percnn_pi_traj_sqerr_f32(const float *traj, const float *target, const unsigned char *frame_mask, int nframes, int ndim,
+                             const int64_t *shape, double scale, float *out, void *workspace, size_t workspace_bytes,
+                             void *stream);
+int percnn_pi_traj_sqerr_f64(const double *traj, const double *target, const unsigned char *frame_mask, int nframes, int ndim,
+                             const int64_t *shape, double scale, double *out, void *workspace, size_t workspace_bytes,
+                             void *stream);
+
 #ifdef __cplusplus
 }
 #endif

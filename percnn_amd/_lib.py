@@ -35,7 +35,7 @@ EXPORTS = [
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
                 "slab_step_fwd_range", "slab_step_bwd_range", "slab_rollout_fwd", "slab_rollout_bwd", "residual_fwd",
                 "residual_bwd", "contract_fwd", "contract_bwd", "step_fwd_opt", "step_bwd_opt", "rollout_fwd_opt",
-                "rollout_bwd_opt")] + [
+                "rollout_bwd_opt", "rollout_bwd_sqerr", "traj_sqerr")] + [
     "percnn_pi_s1_param_count", "percnn_pi_s1_step_fwd_f32", "percnn_pi_s1_rollout_fwd_f32",
     "percnn_pi_s1_rollout_bwd_workspace_bytes", "percnn_pi_s1_rollout_bwd_f32", "percnn_pi_s1_set_option",
     "percnn_pi_conv3d_k5c8_f32", "percnn_pi_conv3d_k5c8_wgrad_workspace_bytes", "percnn_pi_conv3d_k5c8_wgrad_f32",
@@ -168,6 +168,10 @@ def lib() -> ctypes.CDLL:
         f.restype, f.argtypes = ci, [vp, vp, ci, ci, i64p, ci, cs, vp]
         f = getattr(L, f"percnn_pi_rollout_bwd_opt_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, cs, vp, vp, vp, sz, vp, ci, ci, i64p, ci, cs, vp]
+        f = getattr(L, f"percnn_pi_rollout_bwd_sqerr_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, cs, cd, vp, vp, vp, vp, sz, vp, ci, ci, i64p, ci, cs, vp]
+        f = getattr(L, f"percnn_pi_traj_sqerr_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, cs, ci, ci, i64p, cd, vp, vp, sz, vp]
     L.percnn_pi_s1_param_count.restype = sz
     L.percnn_pi_s1_param_count.argtypes = []
     L.percnn_pi_s1_step_fwd_f32.restype, L.percnn_pi_s1_step_fwd_f32.argtypes = ci, [vp, vp, vp, i64p, vp]

@@ -119,6 +119,7 @@ struct Problem {
     int skip = 0;       // slab layout: outermost planes per side that this call neither reads nor writes
     int lo = -1, hi = -1;   // slab layout, plane-range calls: padded plane indices [lo, hi) this call computes
     Options opt;            // this call's tuning options: process defaults at entry + per-call overrides
+    pi::LossInj loss{0.0, nullptr, 0};   // adjoint calls: what the injection pointer means (pi_device.h); mode 0 = dL/dout itself
 };
 
 int make_problem(int hc, int ndim, const int64_t* shape, bool slab, Problem& p, const char* overrides = nullptr)
@@ -265,6 +266,7 @@ Geom make_geom(const Problem& p)
     g.lxs = 0; g.nxb = g.nrg = 0; g.nblk = 0; g.dnxb = pi::FastDiv{0u, 0u}; g.dnrg = pi::FastDiv{0u, 0u};
     g.rgt = g.nlast = 0; g.per_tile = 0; g.dper = g.drgt = g.dlast = pi::FastDiv{0u, 0u};
     g.xwin = 0; g.rz = 1;
+    g.loss = p.loss;
     g.n0 = (int)p.n0; g.n1 = (int)p.n1; g.W = (int)p.W;
     g.rows = (int)(p.n0 * p.n1);
     g.s0 = (long)(p.n1 * p.W);
@@ -581,6 +583,7 @@ pi::BrickGeom make_brick_geom(const Problem& p, int vec, int rz)
     b.dnrg = make_fastdiv((unsigned)b.nrg); b.dcpr = make_fastdiv((unsigned)b.cpr);
     b.nseg = (4 * b.cpr + 63) / 64; b.ntask = 2 * rz * b.nseg; b.dnseg = make_fastdiv((unsigned)b.nseg);
     b.wt = p.opt.brick_wt;
+    b.loss = p.loss;
     return b;
 }
 
@@ -629,7 +632,7 @@ unsigned brick_bwd_grid(const Problem& p, int vec, int rz)
         }
         cus = cu_count[dev];
     }
-    const int per_cu = p.opt.brick_wgs ? p.opt.brick_wgs : (rz == 1 ? 4 : 2);
+    const int per_cu = p.opt.brick_wgs ? p.opt.brick_wgs : ((rz == 1 && p.hc == 0 && p.loss.mode != 2) ? 4 : (rz == 1 ? 3 : 2));
     unsigned cap = (unsigned)(cus * per_cu);
     if (cap > (unsigned)MAX_BWD_BLOCKS) cap = MAX_BWD_BLOCKS;
     if (b.nblk <= cap) return b.nblk;
@@ -651,6 +654,18 @@ hipError_t launch_brick_bwd(const T* h, const T* G, const T* inj, T* Gp, double*
     const size_t head = (size_t)(pi::BRICK_NT / pi::WAVE) * 2 * sizeof(double);
     const size_t windows = (size_t)2 * RZ * pi::BRICK_WB, scratch = MOM ? (size_t)(32 + 20 * (pi::BRICK_NT + 8)) * sizeof(T) : 0;
     const size_t lds = head + (windows > scratch ? windows : scratch) + (size_t)p.opt.lds_pad;
+    if (p.loss.mode == 1) {
+        auto* k = pi::pi_adj3d_brick_kernel<T, HC, RZ, MOM, 1>;
+        if (hipError_t e = allow_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(pi::BRICK_NT), lds, st, h, G, inj, Gp, partials, P, b, p.hc);
+        return hipGetLastError();
+    }
+    if (p.loss.mode == 2) {
+        auto* k = pi::pi_adj3d_brick_kernel<T, HC, RZ, MOM, 2>;
+        if (hipError_t e = allow_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(pi::BRICK_NT), lds, st, h, G, inj, Gp, partials, P, b, p.hc);
+        return hipGetLastError();
+    }
     auto* k = pi::pi_adj3d_brick_kernel<T, HC, RZ, MOM>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(pi::BRICK_NT), lds, st, h, G, inj, Gp, partials, P, b, p.hc);
@@ -773,7 +788,7 @@ bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs, bo
 pi::TileGeom make_tile_geom(const Problem& p, int by)
 {
     const int tiles_x = (int)((p.W + TILE_B - 1) / TILE_B), tiles_y = (int)((p.n0 + by - 1) / by);
-    pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, tiles_x, 0, 0, 0};
+    pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, tiles_x, 0, 0, 0, p.loss};
     if (!p.opt.tile_xcd) return g;
     int best = -1;
     for (int rx : {1, 2, 4, 8}) {
@@ -1336,11 +1351,20 @@ size_t rollout_workspace_bytes(const Problem& p, int T_steps, int elem)
 template <typename T>
 int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, T* g_h0, double* param_grad, void* ws,
                      size_t ws_bytes, const T* P, int hc, int ndim, const int64_t* shape, int T_steps, void* stream,
-                     const char* options = nullptr)
+                     const char* options = nullptr, const pi::LossInj* loss = nullptr)
 {
     Problem p;
     if (int rc = make_problem(hc, ndim, shape, false, p, options)) return rc;
+    // loss != nullptr: no dL/dtraj exists; `g_traj` is the TARGET trajectory (mode 2) or ignored (mode 1) and the sweep forms
+    // the gradient of frame t from the state it reads anyway (pi::LossInj); `mask` then selects the frames inside the loss
+    if (loss) {
+        if ((loss->mode != 1 && loss->mode != 2) || (loss->mode == 2 && !g_traj)) return PERCNN_PI_EINVAL;
+        p.loss = *loss;
+        if (p.loss.mode == 1) g_traj = traj;
+    }
     if (!traj || !g_traj || !g_h0 || !param_grad || !P || T_steps < 0) return PERCNN_PI_EINVAL;
+    // kernel families without the in-kernel form (advective blocks, a forced plane-streaming adjoint): the caller materialises
+    if (loss && (hc == -1 || stream3d_vec<T>(p, {traj, g_traj, g_h0}, true))) return PERCNN_PI_EINVAL;
     if (!ws || ws_bytes < rollout_workspace_bytes(p, T_steps, sizeof(T)) || (reinterpret_cast<uintptr_t>(ws) % 16))
         return PERCNN_PI_EWORKSPACE;
     auto st = static_cast<hipStream_t>(stream);
@@ -1356,14 +1380,27 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     // frames after the last one carrying gradient contribute nothing: start the sweep there
     int t_top = T_steps;
     while (t_top > 0 && !has(t_top)) --t_top;
+    // dL/dh of one frame that no later step injects (the top frame): a copy, or -- loss form -- a * (h - target)
+    auto top_frame = [&](int t, T* dst) -> hipError_t {
+        if (!loss)
+            return hipMemcpyAsync(dst, g_traj + (size_t)t * frame, frame_bytes, hipMemcpyDeviceToDevice, st);
+        const T* tg = p.loss.mode == 2 ? g_traj + (size_t)t * frame : nullptr;
+        const bool v16 = frame % pi::vec_width<T>::value == 0 && reinterpret_cast<uintptr_t>(traj) % 16 == 0 &&
+                         reinterpret_cast<uintptr_t>(dst) % 16 == 0 && (!tg || reinterpret_cast<uintptr_t>(g_traj) % 16 == 0) &&
+                         frame_bytes % 16 == 0;
+        const unsigned nb = (unsigned)std::min<size_t>(2048, (frame + 1023) / 1024);
+        if (v16) hipLaunchKernelGGL((pi::pi_loss_grad_kernel<T, pi::vec_width<T>::value>), dim3(nb), dim3(256), 0, st,
+                                    traj + (size_t)t * frame, tg, dst, (long)frame, p.loss);
+        else     hipLaunchKernelGGL((pi::pi_loss_grad_kernel<T, 1>), dim3(nb), dim3(256), 0, st,
+                                    traj + (size_t)t * frame, tg, dst, (long)frame, p.loss);
+        return hipGetLastError();
+    };
     if (t_top == 0) {
-        if (has(0)) return (int)hipMemcpyAsync(g_h0, g_traj, frame_bytes, hipMemcpyDeviceToDevice, st);
+        if (has(0)) return (int)top_frame(0, g_h0);
         return (int)hipMemsetAsync(g_h0, 0, frame_bytes, st);
     }
     if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
-    if (hipError_t e = hipMemcpyAsync(adj + (size_t)t_top * frame, g_traj + (size_t)t_top * frame, frame_bytes,
-                                      hipMemcpyDeviceToDevice, st))
-        return (int)e;
+    if (hipError_t e = top_frame(t_top, adj + (size_t)t_top * frame)) return (int)e;
 
     // 1) sequential reverse sweep: adjoint states (+ diffusion-coefficient gradients), with
     // 2) the time-parallel branch-gradient reduction of every finished chunk of steps running UNDER it on a side
@@ -1632,6 +1669,53 @@ int apply_overrides(Options& o, const char* spec)
 
 }  // namespace
 
+
+namespace {
+// loss value of the squared-error losses the sweep differentiates in place (pi::LossInj): scale * sum over the frames with
+// mask[f] != 0 of sum_x (traj - target)^2, written to out[0] (compute type).  ws: >= 1024 doubles.
+template <typename T>
+int sqerr_impl(const T* traj, const T* target, const unsigned char* mask, int nframes, int ndim, const int64_t* shape,
+               double scale, T* out, void* ws, size_t ws_bytes, void* stream)
+{
+    Problem p;
+    if (int rc = make_problem(0, ndim, shape, false, p)) return rc;
+    if (!traj || !out || nframes < 0) return PERCNN_PI_EINVAL;
+    constexpr unsigned NB = 1024;
+    if (!ws || ws_bytes < NB * sizeof(double) || reinterpret_cast<uintptr_t>(ws) % 8) return PERCNN_PI_EWORKSPACE;
+    auto st = static_cast<hipStream_t>(stream);
+    const long frame = 2 * p.n;
+    // the mask lives on the HOST (as in rollout_bwd); the kernel wants it on the device: pass it by value in 64-bit words
+    // would cap T; instead launch once per run of selected frames (runs are few: a slice, or everything)
+    double* partials = static_cast<double*>(ws);
+    if (hipError_t e = hipMemsetAsync(partials, 0, NB * sizeof(double), st)) return (int)e;
+    const bool v16 = frame % pi::vec_width<T>::value == 0 && reinterpret_cast<uintptr_t>(traj) % 16 == 0 &&
+                     (!target || reinterpret_cast<uintptr_t>(target) % 16 == 0) && (frame * sizeof(T)) % 16 == 0;
+    // runs of consecutive selected frames (a slice, or everything: one run); each gets an equal stripe of the partial slots
+    int nruns = 0;
+    for (int f = 0; f < nframes; ++f)
+        if ((!mask || mask[f]) && (f == 0 || (mask && !mask[f - 1]))) ++nruns;
+    if (nruns > 64) return PERCNN_PI_EINVAL;                  // pathological masks: the caller sums frame by frame
+    const unsigned nb = nruns ? NB / (unsigned)nruns : NB;
+    int f = 0, run = 0;
+    while (f < nframes) {
+        while (f < nframes && mask && !mask[f]) ++f;
+        int g = f;
+        while (g < nframes && (!mask || mask[g])) ++g;
+        if (g > f) {
+            double* dst = partials + (size_t)run++ * nb;
+            const T* tr = traj + (size_t)f * frame;
+            const T* tg = target ? target + (size_t)f * frame : nullptr;
+            if (v16) hipLaunchKernelGGL((pi::pi_sqerr_kernel<T, pi::vec_width<T>::value>), dim3(nb), dim3(256), 0, st, tr, tg,
+                                        (long)(g - f) * frame, dst);
+            else     hipLaunchKernelGGL((pi::pi_sqerr_kernel<T, 1>), dim3(nb), dim3(256), 0, st, tr, tg,
+                                        (long)(g - f) * frame, dst);
+        }
+        f = g;
+    }
+    hipLaunchKernelGGL((pi::pi_sqerr_finish_kernel<T>), dim3(1), dim3(64), 0, st, partials, (int)NB, scale, out);
+    return (int)hipGetLastError();
+}
+}  // namespace
 
 namespace {
 // Which kernel family a rollout of this problem runs on and how its backward is scheduled -- the library's own dispatch
@@ -1914,6 +1998,25 @@ int percnn_pi_set_option(const char* key, long value)
 
 PI_EXPORT(f32, float)
 PI_EXPORT(f64, double)
+
+// squared-error losses differentiated inside the sweep (include/percnn_pi.h)
+#define PI_EXPORT_LOSS(SUF, T)                                                                                      \
+    int percnn_pi_rollout_bwd_sqerr_##SUF(const T* traj, const T* target, const unsigned char* frame_mask, double scale, \
+                                          const T* dev_scale, T* g_h0, double* param_grad, void* workspace,        \
+                                          size_t workspace_bytes, const T* params, int hc, int ndim,               \
+                                          const int64_t* shape, int T_steps, const char* options, void* stream)    \
+    {                                                                                                               \
+        const pi::LossInj l{scale, dev_scale, target ? 2 : 1};                                                      \
+        return rollout_bwd_impl<T>(traj, target, frame_mask, g_h0, param_grad, workspace, workspace_bytes, params, \
+                                   hc, ndim, shape, T_steps, stream, options, &l);                                  \
+    }                                                                                                               \
+    int percnn_pi_traj_sqerr_##SUF(const T* traj, const T* target, const unsigned char* frame_mask, int nframes,   \
+                                   int ndim, const int64_t* shape, double scale, T* out, void* workspace,          \
+                                   size_t workspace_bytes, void* stream)                                            \
+    { return sqerr_impl<T>(traj, target, frame_mask, nframes, ndim, shape, scale, out, workspace, workspace_bytes, stream); }
+
+PI_EXPORT_LOSS(f32, float)
+PI_EXPORT_LOSS(f64, double)
 
 #define PI_EXPORT_RES(SUF, T)                                                                                       \
     int percnn_pi_residual_fwd_##SUF(const T* traj, T* resid, const T* params, int ndim, const int64_t* shape,     \

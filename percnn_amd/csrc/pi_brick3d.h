@@ -37,6 +37,7 @@ struct BrickGeom {
     FastDiv dnrg, dcpr;
     int nseg, ntask;       // halo segments of 64 chunks per (plane, species) = ceil(4 cpr / 64); ntask = 2 * RZ * nseg
     FastDiv dnseg;
+    LossInj loss;          // adjoint kernel: what the injection pointer means (pi_device.h)
     int wt;                // 1: the output frame is stored write-through (sc1).  Plain stores leave the whole frame dirty in the
                            // L2s and the kernel boundary then waits for its write-back (16 MiB at 128^3: ~1.5 us of a 9.4 us
                            // step, tools/ubench/step3d_probe.hip); written through, that traffic overlaps the waves still
@@ -240,8 +241,12 @@ pi_fwd3d_brick_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __r
 // sums always, and -- MOM, pre-contracted blocks -- the 20 coefficient moments carried per lane over all bricks of the
 // workgroup and reduced once per launch.  partials: one row of np doubles per workgroup (owner-block read-modify-write).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int HC, int RZ, bool MOM>
-__global__ void __launch_bounds__(BRICK_NT, RZ == 1 ? 4 : 2)     // one-plane bricks: four workgroups per CU (<= 128 VGPRs)
+// LOSS: the injected frame is a squared-error loss gradient formed here (pi::LossInj modes 1 / 2) instead of a materialised
+// dL/dout (a template parameter, not a run-time switch: the kernel sits at the edge of its 128-register budget and of the 102
+// SGPRs -- the generic form spilled)
+// (LOSS = pi::LossInj::mode, 0 / 1 / 2)
+template <typename T, int HC, int RZ, bool MOM, int LOSS = 0>
+__global__ void __launch_bounds__(BRICK_NT, (RZ == 1 && HC == POLY && LOSS != 2) ? 4 : 2)   // one-plane bricks of pre-contracted
 pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restrict__ inj, T* __restrict__ Gp,
                       double* __restrict__ partials, const T* __restrict__ P, BrickGeom g, int hc_rt)
 {
@@ -288,7 +293,7 @@ pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T*
             const int iz = min(B.i0 + j, g.n0 - 1);
             hu[j] = ldb<T, VEC>(sgpr_ptr(reinterpret_cast<const char*>(h + g.off + (long)iz * g.s0)), B.eb);
             hv[j] = ldb<T, VEC>(sgpr_ptr(reinterpret_cast<const char*>(h + g.ss + g.off + (long)iz * g.s0)), B.eb);
-            if (inj) {
+            if (LOSS != 1 && inj) {                          // LOSS mode 1: a function of the state, nothing more to read
                 ju[j] = ldb<T, VEC>(sgpr_ptr(reinterpret_cast<const char*>(inj + g.off + (long)iz * g.s0)), B.eb);
                 jv[j] = ldb<T, VEC>(sgpr_ptr(reinterpret_cast<const char*>(inj + g.ss + g.off + (long)iz * g.s0)), B.eb);
             }
@@ -390,8 +395,17 @@ pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T*
                 ov.v[i] = gc[1].v[i] + tv;
             }
             if (inj) {
+                if constexpr (LOSS != 0) {
+                    const T la = loss_factor<T>(g.loss);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) { ou.v[i] += ju[j].v[i]; ov.v[i] += jv[j].v[i]; }
+                    for (int i = 0; i < VEC; ++i) {
+                        ou.v[i] += la * (LOSS == 2 ? u.v[i] - ju[j].v[i] : u.v[i]);
+                        ov.v[i] += la * (LOSS == 2 ? v.v[i] - jv[j].v[i] : v.v[i]);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) { ou.v[i] += ju[j].v[i]; ov.v[i] += jv[j].v[i]; }
+                }
             }
             if (B.valid) {
                 char* pu = const_cast<char*>(sgpr_ptr(reinterpret_cast<const char*>(Gp + g.off + (long)iz * g.s0)));

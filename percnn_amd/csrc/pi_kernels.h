@@ -46,6 +46,7 @@ struct Geom {
     unsigned xwin;      // forward kernel: XCD-contiguous remap inside windows of this many blocks (0 = the whole grid)
     int rz;             // 3D: consecutive planes one workgroup pass computes (plane neighbours shared in registers); the
                         // "planes" of the block decomposition above are groups of rz planes
+    LossInj loss;       // adjoint kernels: what the injection pointer means (pi_device.h)
 };
 
 // radius-2 star: lap[i] = c0*f(x) + sum_axes sum_t w[axis][t] * f(x + FLIP*offs[t]); FLIP=-1 is the adjoint
@@ -675,10 +676,17 @@ pi_bwd_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restr
                 ov.v[i] = gc[1].v[i] + tv;
             }
             if (inj) {
-                const Pack<T, VEC> ju = ldb<T, VEC>(plane_base<T, NDIM>(inj + g.off, g, iz), L.eb);
-                const Pack<T, VEC> jv = ldb<T, VEC>(plane_base<T, NDIM>(inj + g.ss + g.off, g, iz), L.eb);
+                Pack<T, VEC> ju = u, jv = v;
+                if (g.loss.mode != 1) {                                  // mode 1 injects a function of the state alone
+                    ju = ldb<T, VEC>(plane_base<T, NDIM>(inj + g.off, g, iz), L.eb);
+                    jv = ldb<T, VEC>(plane_base<T, NDIM>(inj + g.ss + g.off, g, iz), L.eb);
+                }
+                const T la = g.loss.mode ? loss_factor<T>(g.loss) : T(0);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) { ou.v[i] += ju.v[i]; ov.v[i] += jv.v[i]; }
+                for (int i = 0; i < VEC; ++i) {
+                    ou.v[i] += loss_inject(g.loss.mode, la, u.v[i], ju.v[i]);
+                    ov.v[i] += loss_inject(g.loss.mode, la, v.v[i], jv.v[i]);
+                }
             }
             stb<T, VEC>(const_cast<char*>(plane_base<T, NDIM>(Gp + g.off, g, iz)), L.eb, ou);
             stb<T, VEC>(const_cast<char*>(plane_base<T, NDIM>(Gp + g.ss + g.off, g, iz)), L.eb, ov);
@@ -990,6 +998,90 @@ pi_residual_adj_kernel(const T* __restrict__ traj, const T* __restrict__ G, T* _
     }
     st<T, VEC>(out + (long)blockIdx.y * frame + e, ou);
     st<T, VEC>(out + (long)blockIdx.y * frame + g.ss + e, ov);
+}
+
+// ---------------------------------------------------------------------------------------------
+// squared-error losses over a trajectory without a materialised dL/dtraj (LossInj, pi_device.h)
+// ---------------------------------------------------------------------------------------------
+// one frame of the loss gradient: out = a * (h - target) (target == nullptr: a * h).  The sweep starts from it (frame T has
+// no later step that could inject it) and the fall-back paths materialise whole trajectories of it.  n = elements.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+pi_loss_grad_kernel(const T* __restrict__ h, const T* __restrict__ target, T* __restrict__ out, long n, LossInj l)
+{
+    const T a = loss_factor<T>(l);
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < n; i += (long)gridDim.x * blockDim.x * VEC) {
+        const Pack<T, VEC> x = ld<T, VEC>(h + i);
+        Pack<T, VEC> y = x;
+        if (target) {
+            const Pack<T, VEC> t = ld<T, VEC>(target + i);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) y.v[k] = x.v[k] - t.v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) y.v[k] = a * y.v[k];
+        st<T, VEC>(out + i, y);
+    }
+}
+
+// sum_x (h - target)^2 over `n` consecutive elements (a run of whole frames), one partial per workgroup (double).
+// Streaming: 4 (8 with a target) bytes per element, read once; four 16-byte loads in flight per lane and operand.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+pi_sqerr_kernel(const T* __restrict__ traj, const T* __restrict__ target, long n, double* __restrict__ partials)
+{
+    __shared__ double red[256 / WAVE];
+    double acc = 0.0;
+    const long nchunks = n / VEC, stride = (long)gridDim.x * blockDim.x;
+    long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; c + 3 * stride < nchunks; c += 4 * stride) {
+        Pack<T, VEC> x[4], t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = ld<T, VEC>(traj + (c + q * stride) * VEC);
+        if (target) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = ld<T, VEC>(target + (c + q * stride) * VEC);
+        }
+        T part = T(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const T d = target ? x[q].v[k] - t[q].v[k] : x[q].v[k];
+                part = fma_(d, d, part);
+            }
+        acc += (double)part;
+    }
+    for (; c < nchunks; c += stride) {
+        const Pack<T, VEC> x = ld<T, VEC>(traj + c * VEC);
+        T part = T(0);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const T d = target ? x.v[k] - target[c * VEC + k] : x.v[k];
+            part = fma_(d, d, part);
+        }
+        acc += (double)part;
+    }
+    acc = wave_sum_to_last(acc);
+    if (threadIdx.x % WAVE == REDUCE_LANE) red[threadIdx.x / WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 256 / WAVE; ++w) s += red[w];
+        partials[blockIdx.x] = s;
+    }
+}
+
+// loss = scale * sum of the partials, written in the compute type (one wave, fixed order)
+template <typename T>
+__global__ void __launch_bounds__(64)
+pi_sqerr_finish_kernel(const double* __restrict__ partials, int n, double scale, T* __restrict__ out)
+{
+    double s = 0.0;
+    for (int b = threadIdx.x; b < n; b += WAVE) s += partials[b];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, WAVE);
+    if (threadIdx.x == 0) out[0] = (T)(s * scale);
 }
 
 // param_grad[idx] += sum_b partials[b][idx]; one wave per parameter, fixed order -> deterministic

@@ -72,6 +72,7 @@ struct TileGeom {
     // rw x rh rectangle of tiles and the halo rings of neighbouring tiles are fetched from the fabric once per XCD
     // instead of once per tile (the sweep moved 1.7x its algorithmic bytes with the identity map).  rx == 0: identity.
     int rx, rw, rh;    // rectangles per row of rectangles, rectangle width / height in tiles
+    LossInj loss;      // adjoint kernel: what the frames behind `gframes` mean (pi_device.h; mode 1: gframes = the trajectory)
 };
 
 __device__ __forceinline__ int tile_of_block(int b, const TileGeom& g)
@@ -612,8 +613,14 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
             const V2<T> tv = cv * dl[1][h] + dv[h];
             V2<T> ou = gc[0][h] + tu, ov = gc[1][h] + tv;
             if (gfr) {
-                ou += V2<T>{ju[2 * h], ju[2 * h + 1]};
-                ov += V2<T>{jv[2 * h], jv[2 * h + 1]};
+                V2<T> iu = V2<T>{ju[2 * h], ju[2 * h + 1]}, iv = V2<T>{jv[2 * h], jv[2 * h + 1]};
+                if (g.loss.mode) {                         // wave-uniform: the loss gradient is formed here (pi_device.h)
+                    const V2<T> la = vs(loss_factor<T>(g.loss));
+                    iu = la * (g.loss.mode == 2 ? U[h] - iu : U[h]);
+                    iv = la * (g.loss.mode == 2 ? V[h] - iv : V[h]);
+                }
+                ou += iu;
+                ov += iv;
             }
             stv2(nxt + off + 2 * h, ou);
             stv2(nxt + TL::PLANE + off + 2 * h, ov);

@@ -372,6 +372,112 @@ def rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor,
     return g_h0, pg
 
 
+def _mask_bytes(frame_mask, n):
+    if frame_mask is None:
+        return None
+    assert len(frame_mask) == n
+    return bytes(bytearray(1 if m else 0 for m in frame_mask))
+
+
+def traj_sqerr(traj: torch.Tensor, target: Optional[torch.Tensor] = None, frame_mask: Optional[Sequence[bool]] = None,
+               scale: float = 1.0) -> torch.Tensor:
+    """scale * sum over the frames with frame_mask[t] of sum_x (traj_t - target_t)^2 as a 0-dim tensor of traj's dtype, in one
+    streaming pass (``percnn_pi_traj_sqerr_*``; target None = 0)."""
+    _require(traj, "traj")
+    if target is not None:
+        _require(target, "target", traj.dtype)
+        assert target.shape == traj.shape
+    out = torch.empty((), dtype=traj.dtype, device=traj.device)
+    ws = torch.empty(8192, dtype=torch.uint8, device=traj.device)
+    shape = traj.shape[2:]
+    f = getattr(_lib.lib(), "percnn_pi_traj_sqerr_" + _SUF[traj.dtype])
+    with torch.cuda.device(traj.device):
+        _lib.check(f(traj.data_ptr(), target.data_ptr() if target is not None else None, _mask_bytes(frame_mask, traj.shape[0]),
+                     traj.shape[0], len(shape), _lib.shape_arg(shape), float(scale), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                     _stream()), "traj_sqerr")
+    return out
+
+
+def rollout_bwd_sqerr(traj: torch.Tensor, P: torch.Tensor, target: Optional[torch.Tensor] = None,
+                      frame_mask: Optional[Sequence[bool]] = None, scale: float = 1.0,
+                      dev_scale: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None, options=None):
+    """Backward of  L = (scale / 2) * sum_{t in mask} sum_x (traj_t - target_t)^2  (times the device scalar ``dev_scale``)
+    WITHOUT a dL/dtraj buffer: the sweep forms  scale * (h_t - target_t)  from the state it reads anyway
+    (``percnn_pi_rollout_bwd_sqerr_*``).  -> (dL/dh0 [2,*S], dL/dparams double[np]).  Block kinds without the in-kernel form
+    (advective blocks) take the materialising route here."""
+    _require(traj, "traj"); _require(P, "params", traj.dtype)
+    if target is not None:
+        _require(target, "target", traj.dtype)
+        assert target.shape == traj.shape
+    if dev_scale is not None:
+        dev_scale = dev_scale.reshape(1).to(traj.dtype).contiguous()
+    T = traj.shape[0] - 1
+    shape = traj.shape[2:]
+    hc = _hc_of(P)
+    g_h0 = torch.empty_like(traj[0])
+    pg = torch.zeros(P.numel(), dtype=torch.float64, device=traj.device)
+    if ws is None:
+        ws = rollout_workspace(hc, shape, T, traj.dtype, traj.device)
+    f = getattr(_lib.lib(), "percnn_pi_rollout_bwd_sqerr_" + _SUF[traj.dtype])
+    with torch.cuda.device(traj.device):
+        rc = f(traj.data_ptr(), target.data_ptr() if target is not None else None, _mask_bytes(frame_mask, T + 1), float(scale),
+               dev_scale.data_ptr() if dev_scale is not None else None, g_h0.data_ptr(), pg.data_ptr(), ws.data_ptr(),
+               ws.numel(), P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), T, _lib.options_arg(options), _stream())
+    if rc == -1 and hc == -1:                                # advective block: materialise dL/dtraj, ordinary sweep
+        g = traj if target is None else traj - target
+        g = g * (float(scale) if dev_scale is None else float(scale) * dev_scale)
+        return rollout_bwd(traj, g, P, frame_mask=frame_mask, ws=ws, options=options)
+    _lib.check(rc, "rollout_bwd_sqerr")
+    return g_h0, pg
+
+
+class PiRolloutSqErrFunction(torch.autograd.Function):
+    """Rollout + squared-error loss as ONE autograd node:  loss = weight * sum_{t in frames} sum_x (h_t -
+    target_t)^2.  Forward = the fused rollout + one streaming reduction; backward = the sweep with the loss gradient formed
+    in-kernel -- no dL/dtraj, 24 (32 with a target) instead of 32 + 2 x 8 bytes per point and step.  Returns (loss, traj);
+    traj is not differentiable (inspection / validation only)."""
+
+    @staticmethod
+    def forward(ctx, h0, P, steps, target, frame_mask, weight, options):
+        _check_state(h0)
+        P = P.contiguous()
+        traj = torch.empty((steps + 1,) + tuple(h0.shape[1:]), dtype=h0.dtype, device=h0.device)
+        traj[0].copy_(h0[0])
+        rollout_fwd_(traj, P, options=options)
+        loss = traj_sqerr(traj, target, frame_mask, weight)
+        ctx.save_for_backward(traj, P) if target is None else ctx.save_for_backward(traj, P, target)
+        ctx.meta = (frame_mask, float(weight), options)
+        ctx.mark_non_differentiable(traj)
+        ctx.set_materialize_grads(False)
+        return loss, traj
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_traj):
+        saved = ctx.saved_tensors
+        traj, P = saved[0], saved[1]
+        target = saved[2] if len(saved) > 2 else None
+        frame_mask, weight, options = ctx.meta
+        g_h0, pg = rollout_bwd_sqerr(traj, P, target, frame_mask, 2.0 * weight, g_loss, options=options)
+        return g_h0[None], pg.to(P.dtype), None, None, None, None, None
+
+
+def pi_rollout_sqerr(h0: torch.Tensor, P: torch.Tensor, steps: int, target: Optional[torch.Tensor] = None,
+                     frames: Optional[Sequence[int]] = None, reduction: str = "mean", options=None):
+    """-> (loss, traj detached): ``mse_loss(traj[frames], target[frames], reduction)`` of the T-step rollout from h0 (target
+    None: ``(traj[frames] ** 2).mean()`` / ``.sum()``) as one autograd node.  frames: indices into the T+1 frames (default
+    all); target: [T+1, 2, *S] (frames outside `frames` are never read)."""
+    T1 = int(steps) + 1
+    sel = sorted(set(int(t) % T1 for t in frames)) if frames is not None else list(range(T1))
+    if not sel:
+        raise ValueError("pi_rollout_sqerr: no frame selected")
+    mask = None if len(sel) == T1 else [t in set(sel) for t in range(T1)]
+    n = len(sel) * int(h0[0].numel())
+    weight = {"mean": 1.0 / n, "sum": 1.0}[reduction]
+    if target is not None and tuple(target.shape) != (T1,) + tuple(h0.shape[1:]):
+        raise ValueError("target must have the trajectory's shape [steps + 1, 2, *S]")
+    return PiRolloutSqErrFunction.apply(h0, P, int(steps), target, mask, weight, options)
+
+
 def step_fwd(h: torch.Tensor, P: torch.Tensor, out: Optional[torch.Tensor] = None, slab: bool = False,
              halo: int = 2, skip: int = 0, planes: Optional[Sequence[int]] = None, options=None):
     """h: [2,*S] -> next state.  slab=True: h is a local slab [2, n0+2*halo, ...] (see include/percnn_pi.h);

@@ -538,6 +538,37 @@ class RCNN(nn.Module):
         self.last_trajectory = traj
         return pred
 
+    def loss_mse(self, target: Optional[torch.Tensor] = None, t_slice=slice(None), space_stride: int = 1,
+                 reduction: str = "mean") -> torch.Tensor:
+        """``F.mse_loss(torch.cat(self()[0])[t_slice][..., ::s, ::s], target, reduction)`` -- the reference's data loss
+        (train_2drd.py:397-401) -- with the rollout as ONE autograd node and no dL/dtraj:
+
+        * ``space_stride == 1`` (dense in space): ``target`` is None (then ``mean(traj[t_slice] ** 2)``, SURVEY 8d's loss) or
+          the full-trajectory tensor [step+1, 2, *S] of which the frames in ``t_slice`` are used; the sweep forms
+          ``2/N * (h_t - target_t)`` in-kernel from the state it reads anyway (``pi_rollout_sqerr``);
+        * ``space_stride > 1``: the observed sub-lattice through ``observe()`` (sparse injection), ``target`` shaped like
+          its result.
+
+        The full (detached) trajectory is kept in ``self.last_trajectory``."""
+        if space_stride != 1:
+            pred = self.observe(t_slice, space_stride)
+            t = torch.zeros_like(pred) if target is None else target
+            return torch.nn.functional.mse_loss(pred, t, reduction=reduction)
+        if self.effective_step != list(range(self.step)):
+            raise ValueError("loss_mse() indexes the dense output list: effective_step must be list(range(step))")
+        if hasattr(self.cell, "rollout"):
+            traj = self.trajectory()                        # cells with their own kernels: ordinary autograd on the trajectory
+            self.last_trajectory = traj.detach()
+            sel = traj[t_slice]
+            return torch.nn.functional.mse_loss(sel, torch.zeros_like(sel) if target is None else target[t_slice],
+                                                reduction=reduction)
+        if hasattr(self, "UpconvBlock"):
+            self.init_state = self.UpconvBlock(self.init_state_low)
+        frames = list(range(self.step + 1))[t_slice]
+        loss, traj = F_pi.pi_rollout_sqerr(self.init_state, self.cell.param_block(), self.step, target, frames, reduction)
+        self.last_trajectory = traj
+        return loss
+
     def forward(self):
         if hasattr(self, "UpconvBlock"):
             self.init_state = self.UpconvBlock(self.init_state_low)

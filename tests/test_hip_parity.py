@@ -1226,6 +1226,95 @@ def test_observe_equals_cat_and_slice(ndim, hip_device):
     assert torch.equal(pred2, ref) and pred2.requires_grad and not traj2.requires_grad
 
 
+@pytest.mark.parametrize("shape,dtype,hc,opts", [
+    ((64, 96), np.float32, 0, ""),                   # 2D tile sweep with fused moments
+    ((64, 96), np.float32, 0, "tile_fuse=0"),        # 2D tile sweep + separate moments pass
+    ((40, 100), np.float32, 8, ""),                  # factored block, ragged tiles
+    ((64, 64), np.float64, 0, ""),                   # float64 (LDS moment accumulators)
+    ((48, 72), np.float32, 0, "tile=0"),             # direct 2D adjoint kernel
+    ((12, 16, 64), np.float32, 0, ""),               # 3D bricks, fused moments
+    ((9, 12, 40), np.float32, 2, ""),                # 3D bricks, factored block: sweep + wgrad pass
+    ((10, 8, 32), np.float64, 0, "brick3d=0"),       # direct 3D adjoint kernel
+])
+@pytest.mark.parametrize("with_target", [False, True])
+def test_squared_error_loss_inside_the_sweep(shape, dtype, hc, opts, with_target, hip_device):
+    """L = w * sum_{t in frames} sum_x (h_t - target_t)^2 differentiated INSIDE the sweep (percnn_pi_rollout_bwd_
+    sqerr_*: the loss gradient is formed from the state the sweep reads anyway, no dL/dtraj buffer) equals the materialised
+    route -- dL/dh0 bit for bit (same values injected: one subtraction and one multiplication, separately rounded), parameter
+    gradients to reduction round-off -- for every sweep family, dense and sliced frame sets; the loss value equals torch's."""
+    import percnn_amd as pa
+    from percnn_amd import functional as F_pi
+    T = 9
+    rs = np.random.RandomState(7)
+    ndim = len(shape)
+    P = dev_t(random_block(hc, ndim, dtype, 13, scale=0.3), hip_device)
+    traj = torch.empty((T + 1, 2) + shape, dtype=P.dtype, device=hip_device)
+    traj[0] = dev_t(rs.uniform(0, 1, (2,) + shape).astype(dtype), hip_device)
+    o = opts or None
+    pa.rollout_fwd_(traj, P, options=o)
+    target = dev_t(rs.uniform(0, 1, traj.shape).astype(dtype), hip_device) if with_target else None
+    tol = 2e-5 if dtype == np.float32 else 1e-11
+    for frames in (None, list(range(0, T, 3)), [T], [0], [2, 3, 4, 7]):
+        mask = None if frames is None else [t in frames for t in range(T + 1)]
+        nsel = (T + 1) if frames is None else len(frames)
+        w = 1.0 / (nsel * traj[0].numel())
+        # loss value
+        sel = slice(None) if frames is None else frames
+        d = traj[sel] if target is None else traj[sel] - target[sel]
+        want = (d.double() ** 2).sum() * w
+        got = F_pi.traj_sqerr(traj, target, mask, w)
+        assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want)) + 1e-30, (frames, float(got), float(want))
+        # gradients: in-kernel form vs the same gradient materialised by tensor ops
+        a = torch.tensor(2.0 * w, dtype=P.dtype, device=hip_device)
+        g = (traj if target is None else traj - target) * a
+        g0_ref, pg_ref = pa.rollout_bwd(traj, g, P, frame_mask=mask, options=o)
+        g0, pg = F_pi.rollout_bwd_sqerr(traj, P, target, mask, 2.0 * w, options=o)
+        assert torch.equal(g0, g0_ref), frames
+        assert rel_l2(pg.cpu().numpy(), pg_ref.cpu().numpy()) < tol, frames
+        # the scalar autograd hands the loss, read from device memory
+        g0s, _ = F_pi.rollout_bwd_sqerr(traj, P, target, mask, 4.0 * w, dev_scale=torch.tensor(0.5, device=hip_device), options=o)
+        assert torch.equal(g0s, g0_ref)
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_module_loss_mse_equals_cat_and_mse(ndim, hip_device):
+    """RCNN.loss_mse(target, t_slice) == F.mse_loss(torch.cat(outputs)[t_slice], target[t_slice]) in value and in every
+    gradient (the reference's dense data loss, train_2drd.py:397-407), as ONE autograd node without a dL/dtraj."""
+    import percnn_amd as pa
+    from percnn_amd import synthetic
+    torch.manual_seed(0)
+    steps = 24
+    shape = (64, 64) if ndim == 2 else (12, 16, 64)
+    cell = (pa.gs2d_cell(8) if ndim == 2 else pa.gs3d_cell(2)).to(hip_device)
+    for p in cell.filter_list:
+        p.weight.data.mul_(20.0)
+    h0 = synthetic.gs_initial_state(shape, seed=0).to(hip_device).requires_grad_(True)
+    m = pa.RCNN(cell, step=steps, effective_step=list(range(steps)), init_state=h0)
+
+    def grads(loss):
+        cell.zero_grad(); h0.grad = None
+        loss.backward()
+        return [h0.grad.clone()] + [p.grad.clone() for p in cell.parameters() if p.grad is not None]
+
+    target = torch.rand((steps + 1, 2) + shape, device=hip_device)
+    for tsl, tgt in ((slice(None), None), (slice(None), target), (slice(0, -1, 5), target), (slice(3, 20), None)):
+        outs, _ = m()
+        full = torch.cat(tuple(outs), 0)[tsl]
+        ref = torch.nn.functional.mse_loss(full, torch.zeros_like(full) if tgt is None else tgt[tsl])
+        g_ref = grads(ref)
+        loss = m.loss_mse(tgt, tsl)
+        assert abs(float(loss) - float(ref)) < 2e-6 * abs(float(ref))
+        assert m.last_trajectory.shape[0] == steps + 1 and not m.last_trajectory.requires_grad
+        for a, b in zip(grads(loss), g_ref):
+            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
+    # strided in space: the observation operator carries it
+    l2 = m.loss_mse(None, slice(0, -1, 4), 4)
+    outs, _ = m()
+    sub = (slice(None), slice(None)) + (slice(None, None, 4),) * ndim
+    r2 = (torch.cat(tuple(outs), 0)[slice(0, -1, 4)][sub] ** 2).mean()
+    assert abs(float(l2) - float(r2)) < 2e-6 * abs(float(r2))
+
+
 @pytest.mark.parametrize("shape", [(6, 5, 7), (16, 16, 64), (9, 33, 70)])
 def test_3d_upscaler_hip_contraction_equals_stock_layers(shape, hip_device):
     """The 3D IC generator on a HIP device (layer 2 forward and input gradient through percnn_pi_conv3d_k5c8_f32) gives

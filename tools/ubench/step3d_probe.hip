@@ -41,11 +41,7 @@ static pi::Geom geom(int n0, int n1, int W, int block, int rz, bool lw)
     g.nblk = (unsigned)(g.nxb * g.nrg * ((n0 + rz - 1) / rz));
     g.dnxb = fastdiv(1); g.dnrg = fastdiv((unsigned)g.nrg); g.dcpr = fastdiv((unsigned)cpr); g.dn1 = fastdiv((unsigned)n1);
     g.fastdiv = 1;
-    if (lw) {
-        g.lw_nwin = (unsigned)(rpb * cpr + 4 * cpr);
-        g.lw_base = 0;
-        g.d4cpr = fastdiv((unsigned)(4 * cpr));
-    }
+    (void)lw;
     return g;
 }
 
@@ -69,11 +65,10 @@ static void launch_brick(const float* h, float* out, const float* P, const pi::B
     hipLaunchKernelGGL((pi::pi_fwd3d_brick_kernel<float, pi::POLY, RZ>), dim3(g.nblk), dim3(256), (size_t)2 * RZ * pi::BRICK_WB, st, h, out, P, g, 0);
 }
 
-template <int RZ, bool LW>
+template <int RZ>
 static void launch(const float* h, float* out, const float* P, const pi::Geom& g, int block, hipStream_t st)
 {
-    const size_t lds = LW ? (size_t)2 * RZ * g.lw_nwin * 16 : 0;
-    hipLaunchKernelGGL((pi::pi_fwd_kernel<float, 3, pi::POLY, 4, RZ, LW>), dim3(g.nblk), dim3(block), lds, st, h, out, P, g, 0);
+    hipLaunchKernelGGL((pi::pi_fwd_kernel<float, 3, pi::POLY, 4, RZ>), dim3(g.nblk), dim3(block), 0, st, h, out, P, g, 0);
 }
 
 static int gN0, gN1, gW;
@@ -87,9 +82,9 @@ static void run(const Variant& v, const float* h, float* out, const float* P, co
         if (v.rz == 4) launch_brick<4>(h, out, P, bg, st);
         return;
     }
-    if (v.rz == 1) { if (v.lw) launch<1, true>(h, out, P, g, v.block, st); else launch<1, false>(h, out, P, g, v.block, st); }
-    if (v.rz == 2) { if (v.lw) launch<2, true>(h, out, P, g, v.block, st); else launch<2, false>(h, out, P, g, v.block, st); }
-    if (v.rz == 4) { if (v.lw) launch<4, true>(h, out, P, g, v.block, st); else launch<4, false>(h, out, P, g, v.block, st); }
+    if (v.rz == 1) launch<1>(h, out, P, g, v.block, st);
+    if (v.rz == 2) launch<2>(h, out, P, g, v.block, st);
+    if (v.rz == 4) launch<4>(h, out, P, g, v.block, st);
 }
 
 int main(int argc, char** argv)
@@ -117,7 +112,6 @@ int main(int argc, char** argv)
     for (int i = 0; i < 20; ++i) hp[pi::P_W + i] = 0.01f * (float)((i * 7) % 11 - 5);
     CK(hipMemcpy(P, hp.data(), 64 * 4, hipMemcpyHostToDevice));
     std::vector<Variant> vars = {{"direct rz=1", 1, false, 256}, {"direct rz=2", 2, false, 256}, {"direct rz=4", 4, false, 256},
-                                 {"ldswin rz=1", 1, true, 256}, {"ldswin rz=2", 2, true, 256}, {"ldswin rz=4", 4, true, 256},
                                  {"brick rz=1", 1, false, 256, true}, {"brick rz=2", 2, false, 256, true}, {"brick rz=4", 4, false, 256, true},
                                  {"brick rz=1 wt", 1, false, 256, true, true}, {"brick rz=2 wt", 2, false, 256, true, true}};
     std::vector<float> first, cur(n);
