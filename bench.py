@@ -338,6 +338,46 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
     return out
 
 
+def cell_loop_extra(pa, dev, reaction):
+    """The reference's OWN step loop (train_2drd.py:169-188) with `cell(h)` swapped in -- what a maintainer
+    pays who keeps the loop instead of calling the fused rollout: per time step, forward loop alone (no_grad / recording)
+    and the whole training iteration (torch.cat + dense loss + backward + Adam step).  VERDICT r2 #4."""
+    from percnn_amd import synthetic
+    sd = load_params(WORKLOADS["gs2d_512"][5])
+    out = {"what": "for step in range(T): h, _ = cell(h) -- wall-clock us per time step (host-bound: the block is packed once "
+                   "per iteration and cached, each step is one autograd node + one launch)"}
+    for n, T in ((100, 200), (512, 100)):
+        cell = make_cell("gs2d", sd, dev, reaction)
+        h0 = synthetic.gs_initial_state((n, n), seed=0).to(dev)
+        opt = torch.optim.Adam(cell.parameters(), lr=1e-6)
+
+        def loop():
+            h, outs = h0, [h0]
+            for _ in range(T):
+                h, _ = cell(h)
+                outs.append(h)
+            return outs
+
+        def iteration():
+            opt.zero_grad(set_to_none=True)
+            ((torch.cat(loop(), 0) ** 2).mean()).backward()
+            opt.step()
+
+        def timeit(fn, k=5):
+            fn(); fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                fn()
+            torch.cuda.synchronize()
+            return 1e6 * (time.perf_counter() - t0) / k / T
+        with torch.no_grad():
+            t_ng = timeit(loop)
+        out[f"{n}x{n}_T{T}"] = {"forward_loop_no_grad_us_per_step": t_ng, "forward_loop_recording_us_per_step": timeit(loop),
+                                "training_iteration_us_per_step": timeit(iteration)}
+    return out
+
+
 def lo2d_physics_path_extra(pa, dev, reaction, reps=3):
     """The lambda-omega training iteration of the reference (percnn_LO_eqn.py:371-373: the loss IS the physics residual of
     the rollout, no data term) through the drop-in modules at BASELINE configs[2]: 512^2, float64, T = 400 -- RCNN.trajectory()
@@ -462,6 +502,10 @@ def main():
             out["module_path"] = {"error": repr(e)[:200]}
         torch.cuda.empty_cache()
         if a.workload == "gs2d_512" and not a.T:
+            try:
+                out["module_path"]["per_step_cell_loop"] = cell_loop_extra(pa, dev, a.reaction)
+            except Exception as e:
+                out["module_path"]["per_step_cell_loop"] = {"error": repr(e)[:200]}
             try:
                 out["module_path"]["lo2d_512_physics_loss"] = lo2d_physics_path_extra(pa, dev, a.reaction)
             except Exception as e:

@@ -216,8 +216,19 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"percnn_amd: {what} failed: {names.get(rc, 'hipError_t ' + str(rc))}")
 
 
+_shape_args: dict = {}
+
+
 def shape_arg(shape):
-    return (ctypes.c_int64 * len(shape))(*[int(s) for s in shape])
+    """int64 array of a grid shape for the C-ABI (cached per shape: the per-step entry points of a reference-style loop
+    build the same few arrays thousands of times; the arrays are never written to)"""
+    key = tuple(int(s) for s in shape)
+    a = _shape_args.get(key)
+    if a is None:
+        if len(_shape_args) > 256:
+            _shape_args.clear()
+        a = _shape_args[key] = (ctypes.c_int64 * len(key))(*key)
+    return a
 
 
 FAMILIES = {0: "direct", 1: "tile2d", 2: "stream3d", 3: "brick3d", 4: "advective"}

@@ -294,7 +294,12 @@ def check_star_stencil(w_laplace: torch.Tensor) -> None:
 # ------------------------------------------------------------------------------------------------
 # raw calls
 # ------------------------------------------------------------------------------------------------
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> ctypes.c_void_p:
+    if _raw_stream is not None:                       # the current stream's handle without building a Stream object (~0.2 vs ~2 us)
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -606,6 +611,20 @@ def _check_state(h: torch.Tensor) -> None:
         raise RuntimeError(f"percnn_amd: state must be [1,2,*S] (batch 1, two species), got {tuple(h.shape)}")
 
 
+def _step_fwd_lean(h: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
+    """step_fwd for the per-step call of a reference-style loop: same checks, no context manager / option parsing when the
+    tensors already live on the current device (the host side of a 100^2 step costs more than its 3 us kernel)."""
+    _require(h, "h"); _require(P, "params", h.dtype)
+    if h.device.index != torch.cuda.current_device():
+        return step_fwd(h[0], P)[None]
+    out = torch.empty_like(h)
+    shape = h.shape[2:]
+    f = getattr(_lib.lib(), "percnn_pi_step_fwd_opt_" + _SUF[h.dtype])
+    _lib.check(f(h.data_ptr(), out.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape), None, _stream()),
+               "step_fwd")
+    return out
+
+
 class PiStepFunction(torch.autograd.Function):
     """One fused step: replaces the ~30 ATen launches of RCNNCell.forward."""
 
@@ -614,9 +633,9 @@ class PiStepFunction(torch.autograd.Function):
         _check_state(h)
         h = h.contiguous()
         P = P.contiguous()
-        out = step_fwd(h[0], P)
+        out = _step_fwd_lean(h, P)
         ctx.save_for_backward(h, P)
-        return out[None]
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -815,8 +834,18 @@ def pi_rollout_observe(h0: torch.Tensor, P: torch.Tensor, steps: int, t_idx: Seq
 
 
 def pi_step(h: torch.Tensor, P: torch.Tensor, options=None) -> torch.Tensor:
-    """One fused Pi-block step through the registered operator ``torch.ops.percnn.pi_step`` (percnn_amd/ops.py)."""
-    return torch.ops.percnn.pi_step(h, P, _options_str(options))
+    """One fused Pi-block step.  Under ``torch.compile`` the registered operator ``torch.ops.percnn.pi_step`` (percnn_amd/
+    ops.py) is what the graph holds; in eager mode the plain ``autograd.Function`` does the same work without the
+    dispatcher's per-call cost -- this is the call a reference-style step loop makes T times per iteration."""
+    if torch.compiler.is_compiling() or options:
+        return torch.ops.percnn.pi_step(h, P, _options_str(options))
+    return PiStepFunction.apply(h, P)
+
+
+def pi_step_nograd(h: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
+    """One fused step without an autograd node (inference loops; the caller has checked that nothing records)."""
+    _check_state(h)
+    return _step_fwd_lean(h.contiguous(), P.contiguous())
 
 
 def pi_rollout(h0: torch.Tensor, P: torch.Tensor, steps: int, options=None) -> torch.Tensor:

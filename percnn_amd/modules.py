@@ -96,6 +96,7 @@ class RCNNCell(nn.Module):
         self.init_filter(self.filter_list, init_c, init)
         self._stencil_checked_version = None
         self._dt_cache = None
+        self._block_cache = None            # (key, packed block) of the last param_block() call, see _block_key
 
     def init_filter(self, filter_list, c, mode="xavier"):
         for f in filter_list:
@@ -122,15 +123,64 @@ class RCNNCell(nn.Module):
             self._stencil_checked_version = key
 
     def _pack_tensors(self):
-        c = (self.CA, self.CB) if self.diffusion == "sigmoid" else (self.DA, self.DB)
-        out = [c[0], c[1], self.W_laplace.weight]
+        """The 19 tensors of the block in packing order.  nn.Module attribute access costs ~1 us apiece (18 us for this list),
+        more than a 100^2 step kernel, and a reference-style loop asks once per time step: the list is kept together with
+        the `_parameters` dictionaries it was read from and only re-validated by identity (parameter surgery replaces the
+        dictionary entries; in-place updates keep them and show up in the version counters instead)."""
+        hit = self.__dict__.get("_pack_list")
+        if hit is not None:
+            tensors, src = hit
+            for (d, k), t in zip(src, tensors):
+                if d[k] is not t:
+                    break
+            else:
+                return tensors
+        names = ("CA", "CB") if self.diffusion == "sigmoid" else ("DA", "DB")
+        src = [(self._parameters, names[0]), (self._parameters, names[1]), (self.W_laplace._parameters, "weight")]
         for s in ("u", "v"):
             for k in (1, 2, 3, 4):
                 m = getattr(self, f"Wh{k}_{s}")
-                out += [m.weight, m.bias]
-        return out
+                src += [(m._parameters, "weight"), (m._parameters, "bias")]
+        tensors = [d[k] for d, k in src]
+        self.__dict__["_pack_list"] = (tensors, src)
+        return tensors
+
+    def _block_key(self, tensors):
+        """What a packed block depends on: every parameter's version counter and storage (optimizer.step(), load_state_dict,
+        .to(), parameter surgery), dt (the reference reads self.dt every step, train_2drd.py:117), the reaction mode and
+        whether autograd records."""
+        return (tuple(t._version for t in tensors), tensors[0].data_ptr(), tensors[2].data_ptr(), tensors[3].data_ptr(),
+                float(self.dt), self.reaction, self.diffusion, torch.is_grad_enabled())
 
     def param_block(self) -> torch.Tensor:
+        """The packed parameter block the kernels read.  A caller that keeps the reference's own step loop
+        (``for step in range(T): h, _ = cell(h)``, train_2drd.py:169-188) calls this once per time step; the block is
+        therefore cached until something it depends on changes (_block_key) or until a backward pass has run through it
+        (its autograd node is consumed then): one pack launch and ONE pack-backward per training iteration instead of T,
+        the per-step gradients accumulate on the shared block.  (20-55 us per call, 180-280 us with
+        backward, per STEP before.)"""
+        w = self.W_laplace.weight
+        if not torch.compiler.is_compiling():
+            tensors = self._pack_tensors()
+            key = self._block_key(tensors)
+            hit = self._block_cache
+            if hit is not None and hit[0] == key:
+                return hit[1]
+            P = self._param_block_uncached()
+            if P.requires_grad:
+                import weakref
+                me = weakref.ref(self)
+
+                def consumed(_g, me=me, P_id=id(P)):          # backward reached the block: its graph is gone after this pass
+                    cell = me()
+                    if cell is not None and cell._block_cache is not None and id(cell._block_cache[1]) == P_id:
+                        cell._block_cache = None
+                P.register_hook(consumed)
+            self._block_cache = (key, P)
+            return P
+        return self._param_block_uncached()
+
+    def _param_block_uncached(self) -> torch.Tensor:
         w = self.W_laplace.weight
         if w.is_cuda and not w.requires_grad:
             # one launch each way (torch.ops.percnn.pack_block): the tensor-op assembly below costs 79 us per call on
@@ -185,7 +235,11 @@ class RCNNCell(nn.Module):
 
     # -- reference interface -------------------------------------------------------------------
     def forward(self, h):
-        ch = F_pi.pi_step(h, self.param_block())
+        P = self.param_block()
+        if not torch.compiler.is_compiling() and not (torch.is_grad_enabled() and (h.requires_grad or P.requires_grad)):
+            ch = F_pi.pi_step_nograd(h, P)                 # nothing to record: straight to the kernel
+        else:
+            ch = F_pi.pi_step(h, P)
         return ch, ch
 
     def init_hidden_tensor(self, prev_state):

@@ -457,6 +457,46 @@ def test_direct_kernel_block_decomposition_rules():
     assert bm((192,) * 3, 4, "lane_x=7")["lxs"] == -1 and bm((192,) * 3, 4, "lane_x=5")["lxs"] == 5
 
 
+def test_param_block_cache_invalidation():
+    """RCNNCell.param_block() is cached for callers that keep the reference's per-step loop: the same block
+    object while nothing it depends on changes, a new one after a backward pass through it, optimizer.step(),
+    load_state_dict(), `cell.dt = ...`, a switch of grad mode or of the reaction mode."""
+    import percnn_amd as pa
+    torch.manual_seed(0)
+    for reaction in ("poly", "factored"):
+        cell = pa.RCNNCell(2, 4, reaction=reaction)
+        P1 = cell.param_block()
+        assert cell.param_block() is P1 and P1.requires_grad
+        P1.sum().backward()                                   # consumed: the graph behind P1 is gone
+        P2 = cell.param_block()
+        assert P2 is not P1 and torch.equal(P2, P1) and cell.param_block() is P2
+        opt = torch.optim.SGD(cell.parameters(), lr=0.1)
+        opt.step()                                            # parameters changed in place
+        P3 = cell.param_block()
+        assert P3 is not P2 and not torch.equal(P3, P2)
+        sd = {k: v.clone() for k, v in cell.state_dict().items()}
+        sd["CA"] = sd["CA"] + 1.0
+        cell.load_state_dict(sd)
+        P4 = cell.param_block()
+        assert P4 is not P3 and float(P4[1]) != float(P3[1])
+        cell.dt = 0.25                                        # the reference reads self.dt every step
+        P5 = cell.param_block()
+        assert P5 is not P4 and float(P5[0]) == 0.25
+        with torch.no_grad():
+            P6 = cell.param_block()
+            assert P6 is not P5 and not P6.requires_grad and cell.param_block() is P6
+        assert cell.param_block() is not P6 and cell.param_block().requires_grad
+        cell.reaction = "factored" if reaction == "poly" else "poly"
+        assert cell.param_block().numel() != P5.numel()
+        # gradients of several uses of ONE cached block accumulate on it: two "steps" == twice the gradient of one
+        cell.zero_grad()
+        (cell.param_block().sum() + cell.param_block().sum()).backward()
+        g2 = cell.Wh1_u.weight.grad.clone()
+        cell.zero_grad()
+        cell.param_block().sum().backward()
+        assert torch.allclose(g2, 2 * cell.Wh1_u.weight.grad)
+
+
 def test_rollout_plan_follows_the_dispatch_rules():
     """percnn_pi_debug_plan = the library's own answer to "which kernels would this rollout run on" (bench.py labels its
     roofline entries with it): the BASELINE configs and the switch points documented in DESIGN.md."""
