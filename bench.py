@@ -450,15 +450,17 @@ def main():
     ensure_library(local_rank)
     import percnn_amd as pa
     if a.slab_child:
-        res = sharded_series(dev, dist, rank, world, one_gpu)
+        def checkpoint(res):
+            flush_c_stdio()
+            print(json.dumps(res), flush=True)
+        res = sharded_series(dev, dist, rank, world, one_gpu, checkpoint)
         try:
             pa.slab.close_exchangers()
         except Exception:
             pass
         if dist is not None:
             dist.destroy_process_group()
-        flush_c_stdio()
-        print(json.dumps(res), flush=True)
+        checkpoint(res)
         return
     if a.workload in STAGE1:
         return stage1_main(a, pa, dev, dist, rank, world)
@@ -802,16 +804,25 @@ def slab_extra_isolated(a, dev, dist, rank, world, local_rank):
         env.pop(k, None)                             # plain env:// rendezvous on the new port
     child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--slab-child", "--gpus", str(a.gpus)], env=env,
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    timed_out = False
     try:
         so, se = child.communicate(timeout=a.slab_timeout)
     except subprocess.TimeoutExpired:
+        timed_out = True
         child.kill()
-        child.communicate()
-        return {"error": f"child timed out after {a.slab_timeout}s"}
-    lines = [l for l in so.splitlines() if l.startswith("{")]
-    if child.returncode != 0 or not lines:
-        return {"error": f"child exit code {child.returncode}", "stderr_tail": se[-300:]}
-    return json.loads(lines[-1])
+        so, se = child.communicate()
+    # the child prints a (growing) JSON line after every phase -- portable transport first, the experimental one last -- so
+    # that a stall or crash in a later phase costs only that phase
+    lines = [l for l in (so or "").splitlines() if l.startswith("{")]
+    if not lines:
+        return {"error": f"child timed out after {a.slab_timeout}s" if timed_out else f"child exit code {child.returncode}",
+                "stderr_tail": (se or "")[-300:]}
+    res = json.loads(lines[-1])
+    if timed_out or child.returncode != 0:
+        res["incomplete"] = (f"child timed out after {a.slab_timeout}s" if timed_out else f"child exit code {child.returncode}") + \
+                            "; phases completed before that are reported"
+        res["stderr_tail"] = (se or "")[-300:]
+    return res
 
 
 def _all_max(dist, dev, x):
@@ -941,11 +952,15 @@ def single_domain_anchor(dev, full_shape, T, reps, P):
             "global_points": int(np.prod(full_shape))}
 
 
-def sharded_series(dev, dist, rank, world, one_gpu):
+def sharded_series(dev, dist, rank, world, one_gpu, checkpoint=lambda res: None):
     """What the slab child reports:
       weak    -- configs[4]-shaped, 32 planes of 256^2 per rank (256^3 at N = 8), every usable transport;
-      strong  -- north_star's curve: FIXED global grids 256^3 (configs[4]) and 128^3 cut into N slabs, on the transport the
-                 start-up probe picked; N = 1 is the single-domain rollout.  The driver divides by its own N = 1 line."""
+      strong  -- north_star's curve: FIXED global grids 256^3 (configs[4]) and 128^3 cut into N slabs; N = 1 is the
+                 single-domain rollout.  The driver divides by its own N = 1 line.
+    Order: everything on the library's proven transport first (RCCL send / recv; torch.distributed in one-GPU mode), a JSON
+    line printed (`checkpoint`), THEN the peer mailboxes -- probed against the portable exchange bit for bit before they carry
+    a rollout -- and the strong series once more on them if the probe found them faster.  A fault in the second phase cannot
+    cost the first."""
     import percnn_amd as pa
     from percnn_amd import slab
     sd = load_params(WORKLOADS["gs3d_128"][5])
@@ -956,18 +971,13 @@ def sharded_series(dev, dist, rank, world, one_gpu):
     small = bool(int(os.environ.get("PERCNN_BENCH_SMALL", "0")))          # test mode: tiny grids, same control flow
     hw, planes, halo = (64, 8, 4) if small else (256, 32, 4)
     Tw, reps = (6, 2) if small else (40, 5)
-    out = {}
-    # ---- transport: probe, do not guess (one-GPU mode has no RCCL between its ranks: torch.distributed / mailboxes)
-    cands = ("dist", "peer") if one_gpu else ("rccl", "peer")
-    picked, probe = "dist", {}
-    if world > 1 or force_p2p:
-        try:
-            sample = torch.rand((2, planes + 2 * halo, hw, hw), device=dev)
-            picked, probe = slab.probe_transport(sample, halo, candidates=cands, force_p2p=force_p2p)
-            del sample
-        except Exception as e:
-            probe = {"error": repr(e)[:300]}
-    out["transport_probe"] = probe
+    grids = (((32, 2), (16, 2)) if small else ((256, 10), (128, 40)))
+    sharded = world > 1 or force_p2p
+    base = "dist" if one_gpu else "rccl"
+    out = {"transport_probe": {}, "weak_scaling": {"what": f"{planes} planes of {hw}^2 per rank", "by_transport": {}},
+           "strong_scaling": {"what": "fixed global grid cut into N slabs along axis 0; N = 1 = single-domain rollout",
+                              "transport": base if sharded else "none", "by_grid": {}}}
+    weak, strong = out["weak_scaling"]["by_transport"], out["strong_scaling"]["by_grid"]
 
     def guarded(fn):
         try:
@@ -975,31 +985,47 @@ def sharded_series(dev, dist, rank, world, one_gpu):
         except Exception as e:
             return {"error": repr(e)[:300]}
 
-    # ---- weak scaling (the round-1/2 figure), on every candidate so that the line shows both
-    weak = {}
-    if world == 1 and not force_p2p:
+    def strong_on(transport, dest):
+        for n3, T in grids:
+            full, key = (n3, n3, n3), f"{n3}^3"
+            if n3 % world or n3 // world < halo:
+                dest[key] = {"skipped": f"{n3} planes do not cut into {world} slabs of >= {halo}"}
+            elif not sharded:
+                dest[key] = guarded(lambda: single_domain_anchor(dev, full, T, 3, P))
+            else:
+                dest[key] = guarded(lambda: sharded_rollout(dev, dist, rank, world, full, T, halo, 3, transport, force_p2p, P))
+
+    # ---- phase 1: the proven transport
+    if not sharded:
         weak["local_wrap"] = guarded(lambda: sharded_rollout(dev, dist, rank, world, (planes, hw, hw), Tw, halo, reps, "dist", False, P))
-        if not int(os.environ.get("PERCNN_NO_PEER", "0")):      # one rank: put / take through the rank's own mailbox
-            weak["peer_to_self"] = guarded(lambda: sharded_rollout(dev, dist, rank, world, (planes, hw, hw), Tw, halo, reps, "peer", True, P))
     else:
-        for name in cands:
-            if probe.get(name, {}).get("usable_on_every_rank"):
-                weak[name] = guarded(lambda: sharded_rollout(dev, dist, rank, world, (planes * world, hw, hw), Tw, halo, reps,
-                                                             name, force_p2p, P))
-    out["weak_scaling"] = {"what": f"{planes} planes of {hw}^2 per rank", "by_transport": weak}
-    # ---- strong scaling: fixed global grids
-    strong = {}
-    for n3, T in (((32, 2) if small else (256, 10)), ((16, 2) if small else (128, 40))):
-        full = (n3, n3, n3)
-        key = f"{n3}^3"
-        if n3 % world or n3 // world < halo:
-            strong[key] = {"skipped": f"{n3} planes do not cut into {world} slabs of >= {halo}"}
-        elif world == 1 and not force_p2p:
-            strong[key] = guarded(lambda: single_domain_anchor(dev, full, T, 3, P))
-        else:
-            strong[key] = guarded(lambda: sharded_rollout(dev, dist, rank, world, full, T, halo, 3, picked, force_p2p, P))
-    out["strong_scaling"] = {"what": "fixed global grid cut into N slabs along axis 0; N = 1 = single-domain rollout",
-                             "transport": picked if (world > 1 or force_p2p) else "none", "by_grid": strong}
+        weak[base] = guarded(lambda: sharded_rollout(dev, dist, rank, world, (planes * world, hw, hw), Tw, halo, reps, base,
+                                                     force_p2p, P))
+    strong_on(base, strong)
+    checkpoint(out)
+    # ---- phase 2: peer mailboxes (xGMI load / store + epoch flags)
+    if int(os.environ.get("PERCNN_NO_PEER", "0")):
+        return out
+    if not sharded:                               # one rank: put / take through the rank's own mailbox
+        weak["peer_to_self"] = guarded(lambda: sharded_rollout(dev, dist, rank, world, (planes, hw, hw), Tw, halo, reps, "peer", True, P))
+        return out
+    picked, probe = base, {}
+    try:
+        sample = torch.rand((2, planes + 2 * halo, hw, hw), device=dev)
+        picked, probe = slab.probe_transport(sample, halo, candidates=(base, "peer"), force_p2p=force_p2p)
+        del sample
+    except Exception as e:
+        probe = {"error": repr(e)[:300]}
+    out["transport_probe"] = probe
+    checkpoint(out)
+    if probe.get("peer", {}).get("usable_on_every_rank"):
+        weak["peer"] = guarded(lambda: sharded_rollout(dev, dist, rank, world, (planes * world, hw, hw), Tw, halo, reps, "peer",
+                                                       force_p2p, P))
+        checkpoint(out)
+        if picked == "peer":
+            out["strong_scaling"]["by_grid_peer"] = {}
+            strong_on("peer", out["strong_scaling"]["by_grid_peer"])
+            out["strong_scaling"]["transport_picked_by_probe"] = "peer"
     return out
 
 

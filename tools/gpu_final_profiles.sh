@@ -1,6 +1,6 @@
 # Round-end evidence: bench lines, rocprofv3 kernel-trace summaries of the same commands, PMC traffic.
-#   ROUND=r02 bash tools/gpu_final_profiles.sh        (run on the GPU box, e.g. through gpurun)
-ROUND=${ROUND:-r02}
+#   ROUND=r03 bash tools/gpu_final_profiles.sh        (run on the GPU box, e.g. through gpurun)
+ROUND=${ROUND:-r03}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -31,5 +31,5 @@ timeout 900 python tools/size_sweep.py --out gpurun_out/${ROUND}_size_sweep.json
 for f in gpurun_out/${ROUND}_final_bench_[a-z0-9_]*.json; do case $f in *under_rocprof*) continue;; esac; echo $f; python -c "
 import json,sys
 d=json.loads(open('$f').read().strip().splitlines()[-1])
-print('  value %.0f steps/s  fwd %.2f us  bwd %.2f us'%(d['value'], d['fwd_us_per_time_step'], d['bwd_us_per_time_step']), ' dominant', d['roofline']['kernel'], 'frac %.3f'%d['roofline']['frac'], 'cpu', d.get('cpu_baseline',{}).get('value'), 'also', (d.get('also') or {}).get('gs3d_128',{}).get('value'), 'slab', (d.get('slab_3d') or {}).get('ms_per_time_step_fwd_bwd'))
+print('  value %.0f steps/s  fwd %.2f us  bwd %.2f us'%(d['value'], d['fwd_us_per_time_step'], d['bwd_us_per_time_step']), ' dominant', d['roofline']['kernel'], 'frac %.3f'%d['roofline']['frac'], 'cpu', d.get('cpu_baseline',{}).get('value'), 'also', (d.get('also') or {}).get('gs3d_128',{}).get('value'), 'slab', [(k, round(v.get('us_per_time_step_fwd_bwd', 0), 1)) for k, v in ((d.get('slab_3d') or {}).get('weak_scaling', {}).get('by_transport', {})).items() if isinstance(v, dict)])
 "; done

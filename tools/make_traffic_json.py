@@ -23,7 +23,8 @@ for wl, kernels in rows.items():
     for k, v in kernels.items():
         f, w = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
         out["detail"][k] = {"fetch_raw_bytes": f, "fetch_corrected_bytes": 2 * f, "write_bytes": w, "hbm_bytes_per_launch": 2 * f + w}
-        if k in ("pi_adj2d_tile_kernel", "pi_fwd2d_tile_kernel", "pi_fwd_kernel", "pi_bwd_kernel"):
+        if k in ("pi_adj2d_tile_kernel", "pi_fwd2d_tile_kernel", "pi_fwd_kernel", "pi_bwd_kernel", "pi_fwd3d_brick_kernel",
+                 "pi_adj3d_brick_kernel", "pi_stream3d_kernel"):
             out[k] = 2 * f + w
     out["pi_moments_kernel"] = None        # one launch per rollout: per-launch bytes depend on T
     json.dump(out, open(os.path.join("profiles", f"traffic_{wl}.json"), "w"), indent=1)
