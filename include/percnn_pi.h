@@ -68,6 +68,8 @@ extern "C" {
 
 #define PERCNN_PI_EINVAL   (-1)  /* bad ndim / hc / shape / NULL pointer          */
 #define PERCNN_PI_EWORKSPACE (-2) /* workspace smaller than *_workspace_bytes says */
+#define PERCNN_PI_ETOOLARGE (-3)  /* grid beyond the 32-bit byte offsets of the step kernels: a 2D field (+ 4 rows) or a 3D
+                                   * plane of 4 GiB or more per species (e.g. 32768^2 float32); nothing was launched */
 
 /* ABI version of the loaded library (== PERCNN_PI_ABI_VERSION it was built with). */
 int percnn_pi_abi_version(void);
@@ -297,7 +299,7 @@ typedef struct percnn_pi_halo_ring {
 int percnn_pi_debug_blockmap(int ndim, const int64_t* shape, int elem_size, const char* options, int* out);
 /* Host-only: which kernel family a rollout of this problem takes (the library's own dispatch rules, for 16-byte-aligned
  * buffers).  out[8] = {forward family, adjoint family, 1 if the parameter gradients are reduced inside the sweep launches,
- * time steps per forward launch, per adjoint launch, planes per pass forward, adjoint, 0}; families: 0 direct step kernels,
+ * time steps per forward launch, per adjoint launch, planes per pass forward, adjoint, lanes per brick workgroup or 0}; families: 0 direct step kernels,
  * 1 2D tile kernels, 2 3D plane streaming, 3 3D brick kernels, 4 advective block. */
 int percnn_pi_debug_plan(int hc, int ndim, const int64_t* shape, int elem_size, const char* options, int* out);
 

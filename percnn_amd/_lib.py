@@ -212,7 +212,8 @@ class HaloRing(ctypes.Structure):
 
 def check(rc: int, what: str) -> None:
     if rc != 0:
-        names = {-1: "invalid argument", -2: "workspace too small"}
+        names = {-1: "invalid argument", -2: "workspace too small",
+                 -3: "grid too large for the step kernels' 32-bit offsets (a 2D field or a 3D plane of >= 4 GiB per species)"}
         raise RuntimeError(f"percnn_amd: {what} failed: {names.get(rc, 'hipError_t ' + str(rc))}")
 
 
@@ -240,7 +241,8 @@ def rollout_plan(hc: int, shape, elem_size: int, options=None) -> dict:
     check(lib().percnn_pi_debug_plan(int(hc), len(shape), shape_arg(shape), int(elem_size), options_arg(options), out),
           "debug_plan")
     return {"fwd": FAMILIES[out[0]], "bwd": FAMILIES[out[1]], "fused_gradients": bool(out[2]), "fwd_steps_per_launch": out[3],
-            "bwd_steps_per_launch": out[4], "fwd_planes_per_pass": out[5], "bwd_planes_per_pass": out[6]}
+            "bwd_steps_per_launch": out[4], "fwd_planes_per_pass": out[5], "bwd_planes_per_pass": out[6],
+            "brick_lanes": out[7]}
 
 
 def set_option(key: str, value: int) -> None:

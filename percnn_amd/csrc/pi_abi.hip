@@ -61,6 +61,7 @@ struct Options {
     int brick3d = 1;        // 3D: brick kernels (pi_brick3d.h) for one-step launches where the shape allows: 0 never, 1 by
                             // size (brick_ok), 2 whenever eligible
     int brick_rz = 0;       // planes per brick (1, 2, 4; 0 = by size)
+    int brick_nt = 0;       // lanes per brick workgroup: 512 = the wide flavour (pre-contracted blocks; see brick_nt_for), else 256
     int brick_wgs = 0;      // adjoint brick kernel: resident workgroups per CU that walk the bricks (0 = 4 / 2 by planes per brick)
     int brick_wt = 1;       // brick kernels store their output frame write-through (BrickGeom::wt)
     int lds_pad = 0;        // extra dynamic LDS per workgroup (bytes): lowers workgroups/CU so that a
@@ -344,7 +345,8 @@ hipError_t launch_fwd(const T* h, T* out, const T* P, const Problem& p, hipStrea
     Geom g = make_geom(p);
     const int block = direct_block(p, g, VEC);
     if (g.rows <= 0) return hipSuccess;
-    if (!set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024, p.opt.lane_x)) return hipErrorInvalidValue;
+    if (!set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024, p.opt.lane_x))
+        return (hipError_t)PERCNN_PI_ETOOLARGE;              // 32-bit plane / field offsets (was an unspecific hipErrorInvalidValue)
     const unsigned grid = (p.opt.fwd_blocks > 0 && g.nblk > (unsigned)p.opt.fwd_blocks) ? (unsigned)p.opt.fwd_blocks : g.nblk;
     g.xwin = (unsigned)p.opt.xcd_window;
     auto* k = pi::pi_fwd_kernel<T, NDIM, HC, VEC, RZ>;
@@ -371,7 +373,8 @@ hipError_t launch_bwd(const T* h, const T* G, const T* inj, T* Gp, double* parti
     const int block = direct_block(p, g, VEC);
     const unsigned grid = bwd_grid(p, VEC, sizeof(T), RZ);
     if (g.rows <= 0) return hipSuccess;
-    if (!grid || !set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024, p.opt.lane_x)) return hipErrorInvalidValue;
+    if (!grid || !set_blockmap(g, NDIM, VEC, block, sizeof(T), p.opt.l2_tile_kb * 1024, RZ, (long)p.opt.l2_tile_min_kb * 1024, p.opt.lane_x))
+        return (hipError_t)PERCNN_PI_ETOOLARGE;
     const size_t lds = align_up((size_t)(block / pi::WAVE) * pi::nparams(p.hc) * sizeof(T), 16) +
                        (size_t)(block / pi::WAVE) * 2 * sizeof(double) +
                        ((WGRAD && HC == pi::POLY) ? (size_t)20 * (block + 8) * sizeof(T) : 0) +   // moment transpose scratch
@@ -572,12 +575,25 @@ int brick_rz_for(const Problem& p, int vec, bool adjoint)
     return rz;
 }
 
-pi::BrickGeom make_brick_geom(const Problem& p, int vec, int rz)
+// lanes per brick workgroup.  The four halo rows of a brick cost as many fetches as the brick owns chunks once a row is 64
+// chunks wide (W = 256 float32: 256^3, and the 32 x 256^2 slabs of its 8-GPU decomposition); 512 lanes halve that share.
+// (the 512-lane flavours exist for pre-contracted blocks and the plain injection form)
+// Measured (same-box A/B over 14 shapes, T = 12): 512 lanes win 2-6 % where their bricks fill exactly one or two resident rounds
+// (128^3, 32 x 256^2, 16 x 256^2) and lose 8-20 % wherever the coarser granule leaves a round partly empty (112^3, 144^3,
+// 64 x 256^2, the 256^3 adjoint); in the driver's 500-step 128^3 run the gain was inside the box-to-box spread (forward 8.40 ->
+// 7.84 us, adjoint 17.78 -> 18.29).  Not a default: option brick_nt = 512 selects them.
+int brick_nt_for(const Problem& p, int vec)
+{
+    (void)vec;
+    return (p.opt.brick_nt == 512 && p.hc == 0 && p.loss.mode == 0) ? 512 : 256;
+}
+
+pi::BrickGeom make_brick_geom(const Problem& p, int vec, int rz, int nt = pi::BRICK_NT)
 {
     const Geom g = make_geom(p);
     pi::BrickGeom b;
     b.n0 = g.n0; b.n1 = g.n1; b.cpr = g.W / vec; b.total = b.n1 * b.cpr;
-    b.nrg = (b.total + pi::BRICK_NT - 1) / pi::BRICK_NT;
+    b.nrg = (b.total + nt - 1) / nt;
     b.nblk = (unsigned)((long)b.nrg * ((g.n0 + rz - 1) / rz));
     b.wrap0 = g.wrap0; b.s0 = g.s0; b.ss = g.ss; b.off = g.off;
     b.dnrg = make_fastdiv((unsigned)b.nrg); b.dcpr = make_fastdiv((unsigned)b.cpr);
@@ -587,16 +603,16 @@ pi::BrickGeom make_brick_geom(const Problem& p, int vec, int rz)
     return b;
 }
 
-template <typename T, int HC, int RZ>
+template <typename T, int HC, int RZ, int NT = pi::BRICK_NT>
 hipError_t launch_brick_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
-    const pi::BrickGeom b = make_brick_geom(p, VEC, RZ);
+    const pi::BrickGeom b = make_brick_geom(p, VEC, RZ, NT);
     if (b.n0 <= 0) return hipSuccess;
-    const size_t lds = (size_t)2 * RZ * pi::BRICK_WB + (size_t)p.opt.lds_pad;
-    auto* k = pi::pi_fwd3d_brick_kernel<T, HC, RZ>;
+    const size_t lds = (size_t)2 * RZ * pi::brick_wb(NT) + (size_t)p.opt.lds_pad;
+    auto* k = pi::pi_fwd3d_brick_kernel<T, HC, RZ, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
-    hipLaunchKernelGGL(k, dim3(b.nblk), dim3(pi::BRICK_NT), lds, st, h, out, P, b, p.hc);
+    hipLaunchKernelGGL(k, dim3(b.nblk), dim3(NT), lds, st, h, out, P, b, p.hc);
     return hipGetLastError();
 }
 
@@ -604,6 +620,8 @@ template <typename T>
 hipError_t brick_fwd(int rz, const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
 {
     if (p.hc == 0) {
+        if (rz <= 2 && brick_nt_for(p, 16 / (int)sizeof(T)) == 512)
+            return rz == 2 ? launch_brick_fwd<T, pi::POLY, 2, 512>(h, out, P, p, st) : launch_brick_fwd<T, pi::POLY, 1, 512>(h, out, P, p, st);
         if (rz == 4) return launch_brick_fwd<T, pi::POLY, 4>(h, out, P, p, st);
         if (rz == 2) return launch_brick_fwd<T, pi::POLY, 2>(h, out, P, p, st);
         return launch_brick_fwd<T, pi::POLY, 1>(h, out, P, p, st);
@@ -622,7 +640,8 @@ hipError_t brick_fwd(int rz, const T* h, T* out, const T* P, const Problem& p, h
 // 17.4, 1024 two-brick ones 17.2, 768 (uneven) 17.8; two-plane bricks 1024 / 512 workgroups 18.1 / 17.0.
 unsigned brick_bwd_grid(const Problem& p, int vec, int rz)
 {
-    const pi::BrickGeom b = make_brick_geom(p, vec, rz);
+    const int nt = rz <= 2 ? brick_nt_for(p, vec) : 256;
+    const pi::BrickGeom b = make_brick_geom(p, vec, rz, nt);
     static int cu_count[16] = {};                           // per device, asked once (benign race: same value)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {
@@ -632,7 +651,8 @@ unsigned brick_bwd_grid(const Problem& p, int vec, int rz)
         }
         cus = cu_count[dev];
     }
-    const int per_cu = p.opt.brick_wgs ? p.opt.brick_wgs : ((rz == 1 && p.hc == 0 && p.loss.mode != 2) ? 4 : (rz == 1 ? 3 : 2));
+    int per_cu = p.opt.brick_wgs ? p.opt.brick_wgs : ((rz == 1 && p.hc == 0 && p.loss.mode != 2) ? 4 : (rz == 1 ? 3 : 2));
+    if (nt == 512 && !p.opt.brick_wgs) per_cu = (per_cu + 1) / 2;      // the same waves per CU in half as many workgroups
     unsigned cap = (unsigned)(cus * per_cu);
     if (cap > (unsigned)MAX_BWD_BLOCKS) cap = MAX_BWD_BLOCKS;
     if (b.nblk <= cap) return b.nblk;
@@ -643,17 +663,23 @@ unsigned brick_bwd_grid(const Problem& p, int vec, int rz)
     return (b.nblk + k - 1) / k;
 }
 
-template <typename T, int HC, int RZ, bool MOM>
+template <typename T, int HC, int RZ, bool MOM, int NT = pi::BRICK_NT>
 hipError_t launch_brick_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partials, const T* P, const Problem& p,
                             hipStream_t st)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
-    const pi::BrickGeom b = make_brick_geom(p, VEC, RZ);
+    const pi::BrickGeom b = make_brick_geom(p, VEC, RZ, NT);
     if (b.n0 <= 0) return hipSuccess;
     const unsigned grid = brick_bwd_grid(p, VEC, RZ);
-    const size_t head = (size_t)(pi::BRICK_NT / pi::WAVE) * 2 * sizeof(double);
-    const size_t windows = (size_t)2 * RZ * pi::BRICK_WB, scratch = MOM ? (size_t)(32 + 20 * (pi::BRICK_NT + 8)) * sizeof(T) : 0;
+    const size_t head = (size_t)(NT / pi::WAVE) * 2 * sizeof(double);
+    const size_t windows = (size_t)2 * RZ * pi::brick_wb(NT), scratch = MOM ? (size_t)(32 + 20 * (NT + 8)) * sizeof(T) : 0;
     const size_t lds = head + (windows > scratch ? windows : scratch) + (size_t)p.opt.lds_pad;
+    if constexpr (NT != pi::BRICK_NT) {
+        auto* k = pi::pi_adj3d_brick_kernel<T, HC, RZ, MOM, 0, NT>;
+        if (hipError_t e = allow_lds(k, lds)) return e;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, h, G, inj, Gp, partials, P, b, p.hc);
+        return hipGetLastError();
+    }
     if (p.loss.mode == 1) {
         auto* k = pi::pi_adj3d_brick_kernel<T, HC, RZ, MOM, 1>;
         if (hipError_t e = allow_lds(k, lds)) return e;
@@ -679,6 +705,12 @@ hipError_t brick_bwd(int rz, bool mom, const T* h, const T* G, const T* inj, T* 
 {
 #define CALL_BB(HC, RZ, MOM) launch_brick_bwd<T, HC, RZ, MOM>(h, G, inj, Gp, partials, P, p, st)
     if (p.hc == 0) {
+        if (rz <= 2 && brick_nt_for(p, 16 / (int)sizeof(T)) == 512) {
+#define CALL_BB5(RZ, MOM) launch_brick_bwd<T, pi::POLY, RZ, MOM, 512>(h, G, inj, Gp, partials, P, p, st)
+            if (mom) return rz == 2 ? CALL_BB5(2, true) : CALL_BB5(1, true);
+            return rz == 2 ? CALL_BB5(2, false) : CALL_BB5(1, false);
+#undef CALL_BB5
+        }
         if (mom) return rz == 4 ? CALL_BB(pi::POLY, 4, true) : (rz == 2 ? CALL_BB(pi::POLY, 2, true) : CALL_BB(pi::POLY, 1, true));
         return rz == 4 ? CALL_BB(pi::POLY, 4, false) : (rz == 2 ? CALL_BB(pi::POLY, 2, false) : CALL_BB(pi::POLY, 1, false));
     }
@@ -1609,6 +1641,11 @@ int apply_option(Options& o, const char* key, long value)
         return 0;
     }
     if (!std::strcmp(key, "brick_wt")) { o.brick_wt = value != 0; return 0; }
+    if (!std::strcmp(key, "brick_nt")) {
+        if (value != 0 && value != 256 && value != 512) return PERCNN_PI_EINVAL;
+        o.brick_nt = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "brick_wgs")) {
         if (value < 0 || value > 16) return PERCNN_PI_EINVAL;
         o.brick_wgs = (int)value;
@@ -1721,7 +1758,7 @@ namespace {
 // Which kernel family a rollout of this problem runs on and how its backward is scheduled -- the library's own dispatch
 // rules, evaluated for 16-byte-aligned buffers (bench.py labels its roofline entries with it instead of mirroring the rules).
 // out = {forward family, adjoint family, gradients reduced inside the sweep launches (0 / 1), time steps per forward launch,
-//        per adjoint launch, planes per pass forward, adjoint, 0}; families: 0 direct, 1 2D tiles, 2 plane streaming, 3 3D bricks,
+//        per adjoint launch, planes per pass forward, adjoint, lanes per brick workgroup (0: no bricks)}; families: 0 direct, 1 2D tiles, 2 plane streaming, 3 3D bricks,
 //        4 advective block
 template <typename T>
 int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options, int* out)
@@ -1752,7 +1789,7 @@ int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options,
     out[2] = fuse ? 1 : 0;
     out[3] = out[0] == 1 ? K : 1;
     out[4] = out[1] == 1 ? K : 1;
-    out[7] = 0;
+    out[7] = (out[0] == 3 || out[1] == 3) ? brick_nt_for(p, vec) : 0;     // lanes per brick workgroup
     return 0;
 }
 

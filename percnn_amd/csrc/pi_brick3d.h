@@ -22,15 +22,16 @@
 
 namespace pi {
 
-constexpr int BRICK_NT = 256;                        // lanes per workgroup = own chunks per plane of a brick
+constexpr int BRICK_NT = 256;                        // lanes per workgroup = own chunks per plane of a brick (NT = 512: wide rows)
 constexpr int BRICK_CPR_MAX = 64;                    // rows of up to 64 chunks (W <= 256 float32 / 128 float64)
-constexpr int BRICK_WCH = BRICK_NT + 4 * BRICK_CPR_MAX;   // chunks per LDS window (fixed stride -> immediate offsets)
-constexpr int BRICK_WB = BRICK_WCH * 16;             // 8 KiB per (plane, species)
+// chunks / bytes per LDS window (fixed stride -> immediate offsets): 8 KiB per (plane, species) with 256 lanes, 12 KiB with 512
+__host__ __device__ constexpr int brick_wb(int nt) { return (nt + 4 * BRICK_CPR_MAX) * 16; }
+constexpr int BRICK_WB = brick_wb(BRICK_NT);
 
 struct BrickGeom {
     int n0, n1;            // planes this call computes, rows per plane
     int cpr, total;        // chunks per row, per plane
-    int nrg;               // bricks per plane group = ceil(total / 256)
+    int nrg;               // bricks per plane group = ceil(total / lanes per workgroup)
     unsigned nblk;         // nrg * ceil(n0 / RZ)
     int wrap0;             // 1: axis 0 periodic, 0: slab layout (two halo planes on either side of the computed range)
     long s0, ss, off;      // plane stride, species stride, first computed point (elements), as in Geom
@@ -46,10 +47,15 @@ struct BrickGeom {
 };
 
 // what a lane of a brick knows: `eb`, `lo`, row-neighbour / x-halo LDS addresses are per lane, the rest is wave-uniform
-template <typename T, int RZ>
+// NT lanes per workgroup: 256, or 512 for rows of more than 32 chunks -- the halo is four ROWS, so a 256-lane brick of 64-chunk
+// rows (W = 256 float32: the 32 x 256^2 slabs of the 8-GPU 256^3 problem) fetches as many halo chunks as it owns; 512 lanes
+// halve that share
+template <typename T, int RZ, int NT = BRICK_NT>
 struct Brick {
     static constexpr int VEC = 16 / (int)sizeof(T);
-    static constexpr int MH = 2 * RZ;                // halo tasks per wave: 2 RZ nseg / 4 waves, nseg <= 4
+    static constexpr int NW = NT / 64;
+    static constexpr int WB = brick_wb(NT);
+    static constexpr int MH = (2 * RZ * 4 + NW - 1) / NW;   // halo tasks per wave: 2 RZ nseg / NW waves, nseg <= 4
     int i0, cb, nown;                                // first plane of the group; first own chunk of the plane; how many
     bool valid;
     unsigned eb;                                     // byte offset of the lane's chunk inside a plane
@@ -61,8 +67,8 @@ struct Brick {
     {
         const unsigned pg = g.dnrg.div(vb), rg = vb - pg * (unsigned)g.nrg;
         i0 = (int)pg * RZ;
-        cb = (int)rg * BRICK_NT;
-        nown = min(BRICK_NT, g.total - cb);
+        cb = (int)rg * NT;
+        nown = min(NT, g.total - cb);
         const int tid = (int)threadIdx.x;
         valid = tid < nown;
         const int own = min(tid, nown - 1);                            // idle lanes shadow the last chunk (never stored)
@@ -83,7 +89,7 @@ struct Brick {
         const int cpr = g.cpr;
 #pragma unroll
         for (int m = 0; m < MH; ++m) {
-            const int task = wave + 4 * m;
+            const int task = wave + NW * m;
             hoff[m] = ~0u;
             if (task < g.ntask) {                                      // wave-uniform
                 const int c = (int)g.dnseg.div((unsigned)task), sg = task - c * g.nseg;    // c = 2 * plane + species
@@ -96,7 +102,7 @@ struct Brick {
                 const int pl = min(i0 + (c >> 1), g.n0 - 1);           // partial last group: stay inside the field
                 const char* base = sgpr_ptr(reinterpret_cast<const char*>(f + ((c & 1) ? g.ss : 0L) + g.off + (long)pl * g.s0));
                 hreg[m] = ldb<T, VEC>(base, (unsigned)pc * 16u);
-                hoff[m] = ok ? lds_base + (unsigned)c * (unsigned)BRICK_WB + (unsigned)wp * 16u : ~0u;
+                hoff[m] = ok ? lds_base + (unsigned)c * (unsigned)WB + (unsigned)wp * 16u : ~0u;
             }
         }
     }
@@ -107,7 +113,7 @@ struct Brick {
         for (int j = 0; j < RZ; ++j)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
-                *reinterpret_cast<Pack<T, VEC>*>(smem + lo + (2 * j + s) * BRICK_WB) = win[s].w[j + 2];
+                *reinterpret_cast<Pack<T, VEC>*>(smem + lo + (2 * j + s) * WB) = win[s].w[j + 2];
 #pragma unroll
         for (int m = 0; m < MH; ++m)
             if (hoff[m] != ~0u) *reinterpret_cast<Pack<T, VEC>*>(smem + hoff[m]) = hreg[m];
@@ -121,14 +127,14 @@ struct Brick {
         const unsigned yo[4] = {FLIP > 0 ? ym2 : yp2, FLIP > 0 ? ym1 : yp1, FLIP > 0 ? yp1 : ym1, FLIP > 0 ? yp2 : ym2};
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const Pack<T, VEC> nb = *reinterpret_cast<const Pack<T, VEC>*>(smem + yo[t] + c * BRICK_WB);
+            const Pack<T, VEC> nb = *reinterpret_cast<const Pack<T, VEC>*>(smem + yo[t] + c * WB);
             const T w = P[P_TAPS + 4 + t];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) lap[i] = fma_(w, nb.v[i], lap[i]);
         }
         T win[VEC + 4];
-        const Pack<T, 2> l = *reinterpret_cast<const Pack<T, 2>*>(smem + xl + c * BRICK_WB);
-        const Pack<T, 2> r = *reinterpret_cast<const Pack<T, 2>*>(smem + xr + c * BRICK_WB);
+        const Pack<T, 2> l = *reinterpret_cast<const Pack<T, 2>*>(smem + xl + c * WB);
+        const Pack<T, 2> r = *reinterpret_cast<const Pack<T, 2>*>(smem + xr + c * WB);
         win[0] = l.v[0]; win[1] = l.v[1];
         win[VEC + 2] = r.v[0]; win[VEC + 3] = r.v[1];
         Pack<T, VEC> cc = ctr;
@@ -156,15 +162,15 @@ __device__ __forceinline__ Geom brick_as_geom(const BrickGeom& b)
 // ---------------------------------------------------------------------------------------------
 // forward: out = h + dt * (coef * Lap(h) + react(h))      (one brick per workgroup: gridDim.x == g.nblk)
 // ---------------------------------------------------------------------------------------------
-template <typename T, int HC, int RZ>
-__global__ void __launch_bounds__(BRICK_NT)
+template <typename T, int HC, int RZ, int NT = BRICK_NT>
+__global__ void __launch_bounds__(NT)
 pi_fwd3d_brick_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict__ P, BrickGeom g, int hc_rt)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int hc = HC > 0 ? HC : hc_rt;
     PI_STAMP3(0);
-    Brick<T, RZ> B;
+    Brick<T, RZ, NT> B;
     B.locate(g, xcd_remap(blockIdx.x, gridDim.x), 0u);
     Lane L;
     L.i0 = B.i0; L.eb = B.eb;
@@ -245,13 +251,13 @@ pi_fwd3d_brick_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __r
 // dL/dout (a template parameter, not a run-time switch: the kernel sits at the edge of its 128-register budget and of the 102
 // SGPRs -- the generic form spilled)
 // (LOSS = pi::LossInj::mode, 0 / 1 / 2)
-template <typename T, int HC, int RZ, bool MOM, int LOSS = 0>
-__global__ void __launch_bounds__(BRICK_NT, (RZ == 1 && HC == POLY && LOSS != 2) ? 4 : 2)   // one-plane bricks of pre-contracted
+template <typename T, int HC, int RZ, bool MOM, int LOSS = 0, int NT = BRICK_NT>
+__global__ void __launch_bounds__(NT, (RZ == 1 && HC == POLY && LOSS != 2) ? 4 : 2)   // one-plane bricks of pre-contracted
 pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restrict__ inj, T* __restrict__ Gp,
                       double* __restrict__ partials, const T* __restrict__ P, BrickGeom g, int hc_rt)
 {
     static_assert(!MOM || HC == POLY, "fused moments are those of the pre-contracted block");
-    constexpr int VEC = 16 / (int)sizeof(T), NT = BRICK_NT, NW = NT / WAVE;
+    constexpr int VEC = 16 / (int)sizeof(T), NW = NT / WAVE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int hc = HC == POLY ? 0 : (HC > 0 ? HC : hc_rt);
     const int np = nparams(hc);
@@ -278,7 +284,7 @@ pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T*
     bool staged = false;
     PI_STAMP3(0);
     for (unsigned vb = xcd_remap(blockIdx.x, gridDim.x); vb < g.nblk; vb += gridDim.x) {
-        Brick<T, RZ> B;
+        Brick<T, RZ, NT> B;
         B.locate(g, vb, WIN0);
         Lane L;
         L.i0 = B.i0; L.eb = B.eb;

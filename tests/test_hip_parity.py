@@ -789,7 +789,8 @@ def test_direct_kernel_variants_bitwise(opts, shape, dtype, hip_device):
     assert np.array_equal(gi.cpu().numpy(), o_step_bwd(h0, gt[1], None, P)[0])
 
 
-@pytest.mark.parametrize("opts", ["brick3d=2,brick_rz=1", "brick3d=2,brick_rz=2", "brick3d=2,brick_rz=4", "brick3d=0"])
+@pytest.mark.parametrize("opts", ["brick3d=2,brick_rz=1", "brick3d=2,brick_rz=2", "brick3d=2,brick_rz=4", "brick3d=0",
+                                  "brick3d=2,brick_rz=1,brick_nt=512", "brick3d=2,brick_rz=2,brick_nt=512,brick_wgs=1"])
 @pytest.mark.parametrize("shape,dtype,hc", [((9, 12, 64), np.float32, 0), ((6, 33, 40), np.float32, 0), ((3, 8, 16), np.float32, 0),
                                             ((17, 20, 132), np.float32, 0), ((5, 2, 256), np.float32, 0), ((4, 70, 100), np.float32, 0),
                                             ((10, 24, 48), np.float64, 0), ((2, 6, 8), np.float64, 0), ((7, 5, 128), np.float64, 0),

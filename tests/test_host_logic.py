@@ -56,10 +56,10 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.percnn_pi_rollout_fwd_f32(1, 2, 8, 2, shape, -1, None) == -1
     assert L.percnn_pi_step_bwd_f32(1, 2, None, 3, 4, None, 0, 5, 8, 2, shape, None) == -2   # no workspace
     # 32-bit addressing limit of the direct kernels: a 2D field beyond 4 GiB per species is refused
-    # before any launch (hipErrorInvalidValue = 1), it is not silently mis-addressed
+    # before any launch with its own code (PERCNN_PI_ETOOLARGE = -3; was hipErrorInvalidValue), it is not silently mis-addressed
     huge = (ctypes.c_int64 * 2)(70000, 70000)
-    assert L.percnn_pi_step_fwd_f32(16, 32, 48, 0, 2, huge, None) == 1
-    assert L.percnn_pi_step_fwd_opt_f32(16, 32, 48, 0, 2, huge, b"tile=0", None) == 1
+    assert L.percnn_pi_step_fwd_f32(16, 32, 48, 0, 2, huge, None) == -3
+    assert L.percnn_pi_step_fwd_opt_f32(16, 32, 48, 0, 2, huge, b"tile=0", None) == -3
     # per-call option strings are validated before anything else
     assert L.percnn_pi_rollout_fwd_opt_f32(1, 2, 8, 2, shape, 0, b"tile_k=4,skip_wgrad=1", None) == 0     # T = 0
     for bad in (b"nonsense=1", b"tile_k=3", b"tile_k", b"=4", b"tile_k=4;tile=0", b"tile_k=x"):
@@ -506,8 +506,9 @@ def test_rollout_plan_follows_the_dispatch_rules():
     assert p["fwd"] == "tile2d" and p["bwd"] == "tile2d" and p["fused_gradients"] and p["fwd_steps_per_launch"] == 4
     p = plan(0, (128, 128, 128), 4)                       # 3D Gray-Scott 128^3: bricks, two planes forward, one adjoint
     assert p == {"fwd": "brick3d", "bwd": "brick3d", "fused_gradients": True, "fwd_steps_per_launch": 1,
-                 "bwd_steps_per_launch": 1, "fwd_planes_per_pass": 2, "bwd_planes_per_pass": 1}
-    assert plan(0, (48, 48, 48), 4)["fwd_planes_per_pass"] == 1
+                 "bwd_steps_per_launch": 1, "fwd_planes_per_pass": 2, "bwd_planes_per_pass": 1, "brick_lanes": 256}
+    assert plan(0, (48, 48, 48), 4)["fwd_planes_per_pass"] == 1 and plan(0, (48, 48, 48), 4)["brick_lanes"] == 256
+    assert plan(0, (32, 256, 256), 4, "brick_nt=512")["brick_lanes"] == 512 and plan(0, (144, 144, 144), 4)["brick_lanes"] == 256
     p = plan(0, (256, 256, 256), 4)                       # forward keeps the z-march from 8 M points on, the adjoint takes bricks
     assert p["fwd"] == "stream3d" and p["bwd"] == "brick3d" and p["bwd_planes_per_pass"] == 2
     assert plan(0, (64, 256, 256), 4)["fwd"] == "brick3d"
