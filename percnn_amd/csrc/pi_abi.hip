@@ -61,6 +61,8 @@ struct Options {
     int brick3d = 1;        // 3D: brick kernels (pi_brick3d.h) for one-step launches where the shape allows: 0 never, 1 by
                             // size (brick_ok), 2 whenever eligible
     int brick_rz = 0;       // planes per brick (1, 2, 4; 0 = by size)
+    int brick_xcd = 1;      // brick kernels: XCD regions split in y as well as in z where the counts divide (BrickGeom::xny):
+                            // 0 never, 1 where it measured no worse (make_brick_geom), 2 always
     int brick_nt = 0;       // lanes per brick workgroup: 512 = the wide flavour (pre-contracted blocks; see brick_nt_for), else 256
     int brick_wgs = 0;      // adjoint brick kernel: resident workgroups per CU that walk the bricks (0 = 4 / 2 by planes per brick)
     int brick_wt = 1;       // brick kernels store their output frame write-through (BrickGeom::wt)
@@ -588,7 +590,7 @@ int brick_nt_for(const Problem& p, int vec)
     return (p.opt.brick_nt == 512 && p.hc == 0 && p.loss.mode == 0) ? 512 : 256;
 }
 
-pi::BrickGeom make_brick_geom(const Problem& p, int vec, int rz, int nt = pi::BRICK_NT)
+pi::BrickGeom make_brick_geom(const Problem& p, int vec, int rz, int nt = pi::BRICK_NT, bool adjoint = true)
 {
     const Geom g = make_geom(p);
     pi::BrickGeom b;
@@ -600,6 +602,28 @@ pi::BrickGeom make_brick_geom(const Problem& p, int vec, int rz, int nt = pi::BR
     b.nseg = (4 * b.cpr + 63) / 64; b.ntask = 2 * rz * b.nseg; b.dnseg = make_fastdiv((unsigned)b.nseg);
     b.wt = p.opt.brick_wt;
     b.loss = p.loss;
+    // XCD regions (BrickGeom::xny): split the brick rows of a plane group between 2 or 4 XCDs where the counts divide and the
+    // regions get closer to square in (planes, rows) -- fewer halo planes fetched by two L2s
+    b.xny = 0; b.xpg = 0; b.xrg = 0; b.dxrg = pi::FastDiv{0u, 0u};
+    const long npg = (g.n0 + rz - 1) / rz;
+    // Measured (gpurun_out -> profiles/r03_brick_xcd_regions.txt; PMC at 128^3: forward 37.9 -> 36.8 MB per launch = 1.10x the
+    // algorithmic bytes, adjoint 75.9 -> 71.0 MB = 1.06x): 128^3 34.2 -> 36.1 k steps/s, the 32 x 256^2 slab of the 8-GPU 256^3
+    // problem -- four planes per XCD before, as many halo planes as own ones -- 29.1 -> 34.5 k; neutral at 64^3 .. 160^3; the
+    // 256^3 FORWARD loses (66 -> 76 us) while its adjoint gains a little, hence: option 1 = everywhere but forward steps of
+    // 8 M points and more, 2 = everywhere
+    const bool split = p.opt.brick_xcd == 2 || (p.opt.brick_xcd == 1 && (adjoint || p.n < (int64_t(1) << 23)));
+    if (split && b.nblk % pi::NXCD == 0) {
+        double best = 4.0 * rz / (double)std::max<long>(1, (npg / pi::NXCD) * rz);     // halo share of the contiguous map: 4 planes / its planes
+        const long rows_per_brick = std::max<long>(1, nt / std::max(1, b.cpr));
+        for (int ny : {2, 4}) {
+            const int nz = pi::NXCD / ny;
+            if (npg % nz || b.nrg % ny) continue;
+            const double planes = (double)(npg / nz) * rz, rows = (double)(b.nrg / ny) * rows_per_brick;
+            const double share = 4.0 / planes + 4.0 / rows;
+            if (share < best - 1e-9) { best = share; b.xny = ny; b.xpg = (int)(npg / nz); b.xrg = b.nrg / ny; }
+        }
+        if (b.xny) b.dxrg = make_fastdiv((unsigned)b.xrg);
+    }
     return b;
 }
 
@@ -607,7 +631,7 @@ template <typename T, int HC, int RZ, int NT = pi::BRICK_NT>
 hipError_t launch_brick_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
-    const pi::BrickGeom b = make_brick_geom(p, VEC, RZ, NT);
+    const pi::BrickGeom b = make_brick_geom(p, VEC, RZ, NT, false);
     if (b.n0 <= 0) return hipSuccess;
     const size_t lds = (size_t)2 * RZ * pi::brick_wb(NT) + (size_t)p.opt.lds_pad;
     auto* k = pi::pi_fwd3d_brick_kernel<T, HC, RZ, NT>;
@@ -1641,6 +1665,11 @@ int apply_option(Options& o, const char* key, long value)
         return 0;
     }
     if (!std::strcmp(key, "brick_wt")) { o.brick_wt = value != 0; return 0; }
+    if (!std::strcmp(key, "brick_xcd")) {
+        if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
+        o.brick_xcd = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "brick_nt")) {
         if (value != 0 && value != 256 && value != 512) return PERCNN_PI_EINVAL;
         o.brick_nt = (int)value;

@@ -38,6 +38,12 @@ struct BrickGeom {
     FastDiv dnrg, dcpr;
     int nseg, ntask;       // halo segments of 64 chunks per (plane, species) = ceil(4 cpr / 64); ntask = 2 * RZ * nseg
     FastDiv dnseg;
+    // XCD regions: workgroup b runs on XCD b % 8 (private L2).  xny == 0: every XCD takes a contiguous range of bricks, i.e. a
+    // range of plane groups -- its two halo plane groups on either side are fetched by two L2s (128^3: 25 % of an XCD's reads).
+    // xny > 0: the 8 XCDs tile the (plane group, brick row) space as (8 / xny) x xny rectangles of xpg x xrg bricks: shorter in z,
+    // split in y -- 128^3: 32 planes x half a plane each, halo share 18.75 %.  Pure placement; any map is correct.
+    int xny, xpg, xrg;
+    FastDiv dxrg;
     LossInj loss;          // adjoint kernel: what the injection pointer means (pi_device.h)
     int wt;                // 1: the output frame is stored write-through (sc1).  Plain stores leave the whole frame dirty in the
                            // L2s and the kernel boundary then waits for its write-back (16 MiB at 128^3: ~1.5 us of a 9.4 us
@@ -63,9 +69,23 @@ struct Brick {
     Pack<T, VEC> hreg[MH];
     unsigned hoff[MH];
 
-    __device__ __forceinline__ void locate(const BrickGeom& g, unsigned vb, unsigned lds_base)
+    // r: raw brick id with r % 8 = the XCD it runs on (blockIdx.x, + multiples of a grid that is a multiple of 8)
+    __device__ __forceinline__ void locate(const BrickGeom& g, unsigned r, unsigned ngrid, unsigned lds_base)
     {
-        const unsigned pg = g.dnrg.div(vb), rg = vb - pg * (unsigned)g.nrg;
+        unsigned pg, rg;
+        if (g.xny > 0) {
+            const unsigned x = r % NXCD, i = r / NXCD;
+            const unsigned zx = x / (unsigned)g.xny, yx = x - zx * (unsigned)g.xny;
+            const unsigned pl = g.dxrg.div(i), rl = i - pl * (unsigned)g.xrg;
+            pg = zx * (unsigned)g.xpg + pl;
+            rg = yx * (unsigned)g.xrg + rl;
+        } else {
+            // contiguous range per XCD within the first `ngrid` ids, the same again for every further pass of a persistent grid
+            const unsigned pass = r / ngrid;
+            const unsigned vb = pass * ngrid + xcd_remap(r - pass * ngrid, min(ngrid, g.nblk - pass * ngrid));
+            pg = g.dnrg.div(vb);
+            rg = vb - pg * (unsigned)g.nrg;
+        }
         i0 = (int)pg * RZ;
         cb = (int)rg * NT;
         nown = min(NT, g.total - cb);
@@ -171,7 +191,7 @@ pi_fwd3d_brick_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __r
     const int hc = HC > 0 ? HC : hc_rt;
     PI_STAMP3(0);
     Brick<T, RZ, NT> B;
-    B.locate(g, xcd_remap(blockIdx.x, gridDim.x), 0u);
+    B.locate(g, blockIdx.x, gridDim.x, 0u);
     Lane L;
     L.i0 = B.i0; L.eb = B.eb;
     Geom gg = brick_as_geom(g);
@@ -283,9 +303,9 @@ pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T*
     Geom gg = brick_as_geom(g);
     bool staged = false;
     PI_STAMP3(0);
-    for (unsigned vb = xcd_remap(blockIdx.x, gridDim.x); vb < g.nblk; vb += gridDim.x) {
+    for (unsigned vb = blockIdx.x; vb < g.nblk; vb += gridDim.x) {
         Brick<T, RZ, NT> B;
-        B.locate(g, vb, WIN0);
+        B.locate(g, vb, gridDim.x, WIN0);
         Lane L;
         L.i0 = B.i0; L.eb = B.eb;
         PlaneWindow<T, VEC, RZ> win[2];

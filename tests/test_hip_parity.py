@@ -790,9 +790,11 @@ def test_direct_kernel_variants_bitwise(opts, shape, dtype, hip_device):
 
 
 @pytest.mark.parametrize("opts", ["brick3d=2,brick_rz=1", "brick3d=2,brick_rz=2", "brick3d=2,brick_rz=4", "brick3d=0",
-                                  "brick3d=2,brick_rz=1,brick_nt=512", "brick3d=2,brick_rz=2,brick_nt=512,brick_wgs=1"])
+                                  "brick3d=2,brick_rz=1,brick_nt=512", "brick3d=2,brick_rz=2,brick_nt=512,brick_wgs=1",
+                                  "brick3d=2,brick_rz=1,brick_xcd=0,brick_wgs=1"])
 @pytest.mark.parametrize("shape,dtype,hc", [((9, 12, 64), np.float32, 0), ((6, 33, 40), np.float32, 0), ((3, 8, 16), np.float32, 0),
                                             ((17, 20, 132), np.float32, 0), ((5, 2, 256), np.float32, 0), ((4, 70, 100), np.float32, 0),
+                                            ((8, 32, 64), np.float32, 0), ((16, 64, 32), np.float32, 0),   # XCD regions split in z and y
                                             ((10, 24, 48), np.float64, 0), ((2, 6, 8), np.float64, 0), ((7, 5, 128), np.float64, 0),
                                             ((9, 12, 64), np.float32, 2), ((6, 33, 40), np.float32, 8), ((5, 9, 24), np.float64, 4),
                                             ((4, 7, 20), np.float32, 3)])
