@@ -185,6 +185,13 @@ def lib() -> ctypes.CDLL:
     L.percnn_pi_s1_set_option.restype, L.percnn_pi_s1_set_option.argtypes = ci, [ctypes.c_char_p, ctypes.c_long]
     L.percnn_pi_s1_rollout_bwd_f32.restype = ci
     L.percnn_pi_s1_rollout_bwd_f32.argtypes = [vp, vp, ctypes.c_char_p, vp, vp, vp, sz, vp, i64p, ci, vp]
+    # process-wide tuning defaults from the environment ("key=value,..."; the keys of percnn_pi_set_option) -- what a launcher
+    # uses to A/B an option in worker processes it does not construct itself
+    spec = os.environ.get("PERCNN_PI_OPTIONS", "")
+    for kv in filter(None, spec.split(",")):
+        k, _, v = kv.partition("=")
+        if L.percnn_pi_set_option(k.strip().encode(), int(v)) != 0:
+            raise RuntimeError(f"percnn_amd: PERCNN_PI_OPTIONS: bad option {kv!r}")
     _lib = L
     return L
 

@@ -51,6 +51,9 @@ struct Options {
     int l2_tile_kb = 128;   // direct 3D kernels: y-tile of a plane (both species, KiB) whose five stencil planes stay in the L2
                             // (0 = whole planes, the pre-round-2 order): see set_blockmap
     int l2_tile_min_kb = 1536;  // ... applied once four neighbour planes x two species exceed this many KiB (0: always; tests)
+    int slab_put_blocks = 16; // ... workgroups per direction of that fused put (a multiple of 4)
+    int slab_fused_put = 1; // native slab rollouts over the peer mailboxes: the step kernel that writes a frame about to be exchanged
+                            // also carries its faces into the neighbours' mailboxes (pi_peer.h "put fused into the step kernel")
     int slab_wide_adjoint = 0;  // native slab backward over RCCL: one exchange per TWO adjoint steps (4 adjoint planes + 2 dL/dtraj
                             // planes per side in one group call), the 2-plane strips next to the faces recomputed locally.
                             // Built for VERDICT r1 #3, measured SLOWER on MI355X (RCCL to self, 32 x 256^2 slab: 74.0 -> 79.6 us
@@ -627,34 +630,67 @@ pi::BrickGeom make_brick_geom(const Problem& p, int vec, int rz, int nt = pi::BR
     return b;
 }
 
+// what a fused put (pi_peer.h) of a slab step needs besides the transfer itself: the two faces as plane ranges of the PADDED
+// local array; launch_brick_* turn them into the kernel's own plane numbering and count the bricks that hold them
+struct FusedPut {
+    pi::PeerXfer x;
+    bool vec16;
+    int face_lo[2], face_hi[2];          // padded plane indices [lo, hi) of the faces sent to next / prev
+    unsigned long long timeout_ticks;
+};
+
+template <int RZ>
+pi::PeerPutFused fused_put_args(const FusedPut* fp, const Problem& p, const pi::BrickGeom& b)
+{
+    pi::PeerPutFused f{};
+    if (!fp) return f;
+    f.x = fp->x;
+    f.vec16 = fp->vec16 ? 1 : 0;
+    f.timeout_ticks = fp->timeout_ticks;
+    // a few workgroups per direction: what they feed is one xGMI link (~64 GB/s each way), not HBM; 2 x blocks is a multiple
+    // of 8 (XCD placement of the bricks behind them)
+    f.x.blocks_per_dir = std::min(p.opt.slab_put_blocks, (fp->x.blocks_per_dir + 3) / 4 * 4);
+    f.nput = 2 * f.x.blocks_per_dir;
+    const int first = p.lo >= 0 ? p.lo : p.skip + 2;                     // padded index of the kernel's plane 0
+    for (int d = 0; d < 2; ++d) {
+        f.lo[d] = std::max(0, fp->face_lo[d] - first);
+        f.hi[d] = std::min(b.n0, fp->face_hi[d] - first);
+        const int groups = f.hi[d] > f.lo[d] ? (f.hi[d] - 1) / RZ - f.lo[d] / RZ + 1 : 0;
+        f.expect[d] = (unsigned)(groups * b.nrg);
+    }
+    return f;
+}
+
 template <typename T, int HC, int RZ, int NT = pi::BRICK_NT>
-hipError_t launch_brick_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
+hipError_t launch_brick_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_t st, const FusedPut* fp = nullptr)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
-    const pi::BrickGeom b = make_brick_geom(p, VEC, RZ, NT, false);
+    pi::BrickGeom b = make_brick_geom(p, VEC, RZ, NT, false);
     if (b.n0 <= 0) return hipSuccess;
     const size_t lds = (size_t)2 * RZ * pi::brick_wb(NT) + (size_t)p.opt.lds_pad;
+    const pi::PeerPutFused put = fused_put_args<RZ>(fp, p, b);
+    if (fp) b.wt = 1;                                                    // the put workgroups read what the bricks wrote THROUGH
     auto* k = pi::pi_fwd3d_brick_kernel<T, HC, RZ, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
-    hipLaunchKernelGGL(k, dim3(b.nblk), dim3(NT), lds, st, h, out, P, b, p.hc);
+    hipLaunchKernelGGL(k, dim3(b.nblk + (unsigned)put.nput), dim3(NT), lds, st, h, out, P, b, p.hc, put);
     return hipGetLastError();
 }
 
 template <typename T>
-hipError_t brick_fwd(int rz, const T* h, T* out, const T* P, const Problem& p, hipStream_t st)
+hipError_t brick_fwd(int rz, const T* h, T* out, const T* P, const Problem& p, hipStream_t st, const FusedPut* fp = nullptr)
 {
     if (p.hc == 0) {
         if (rz <= 2 && brick_nt_for(p, 16 / (int)sizeof(T)) == 512)
-            return rz == 2 ? launch_brick_fwd<T, pi::POLY, 2, 512>(h, out, P, p, st) : launch_brick_fwd<T, pi::POLY, 1, 512>(h, out, P, p, st);
-        if (rz == 4) return launch_brick_fwd<T, pi::POLY, 4>(h, out, P, p, st);
-        if (rz == 2) return launch_brick_fwd<T, pi::POLY, 2>(h, out, P, p, st);
-        return launch_brick_fwd<T, pi::POLY, 1>(h, out, P, p, st);
+            return rz == 2 ? launch_brick_fwd<T, pi::POLY, 2, 512>(h, out, P, p, st, fp) : launch_brick_fwd<T, pi::POLY, 1, 512>(h, out, P, p, st, fp);
+        if (rz == 4) return launch_brick_fwd<T, pi::POLY, 4>(h, out, P, p, st, fp);
+        if (rz == 2) return launch_brick_fwd<T, pi::POLY, 2>(h, out, P, p, st, fp);
+        return launch_brick_fwd<T, pi::POLY, 1>(h, out, P, p, st, fp);
     }
     switch (p.hc) {
-        case 2:  return launch_brick_fwd<T, 2, 1>(h, out, P, p, st);
-        case 4:  return launch_brick_fwd<T, 4, 1>(h, out, P, p, st);
-        case 8:  return launch_brick_fwd<T, 8, 1>(h, out, P, p, st);
-        default: return launch_brick_fwd<T, 0, 1>(h, out, P, p, st);
+        case 2:  return launch_brick_fwd<T, 2, 1>(h, out, P, p, st, fp);
+        case 4:  return launch_brick_fwd<T, 4, 1>(h, out, P, p, st, fp);
+        case 8:  return launch_brick_fwd<T, 8, 1>(h, out, P, p, st, fp);
+        default: return launch_brick_fwd<T, 0, 1>(h, out, P, p, st, fp);
     }
 }
 
@@ -664,6 +700,7 @@ hipError_t brick_fwd(int rz, const T* h, T* out, const T* P, const Problem& p, h
 // 17.4, 1024 two-brick ones 17.2, 768 (uneven) 17.8; two-plane bricks 1024 / 512 workgroups 18.1 / 17.0.
 unsigned brick_bwd_grid(const Problem& p, int vec, int rz)
 {
+    const int elem = 16 / vec;                              // bricks run on 16-byte lanes: 4 = float32, 8 = float64
     const int nt = rz <= 2 ? brick_nt_for(p, vec) : 256;
     const pi::BrickGeom b = make_brick_geom(p, vec, rz, nt);
     static int cu_count[16] = {};                           // per device, asked once (benign race: same value)
@@ -675,7 +712,9 @@ unsigned brick_bwd_grid(const Problem& p, int vec, int rz)
         }
         cus = cu_count[dev];
     }
-    int per_cu = p.opt.brick_wgs ? p.opt.brick_wgs : ((rz == 1 && p.hc == 0 && p.loss.mode != 2) ? 4 : (rz == 1 ? 3 : 2));
+
+    int per_cu = p.opt.brick_wgs ? p.opt.brick_wgs
+                                 : ((rz == 1 && p.hc == 0 && p.loss.mode != 2 && elem == 4) ? 4 : (rz == 1 ? 3 : 2));
     if (nt == 512 && !p.opt.brick_wgs) per_cu = (per_cu + 1) / 2;      // the same waves per CU in half as many workgroups
     unsigned cap = (unsigned)(cus * per_cu);
     if (cap > (unsigned)MAX_BWD_BLOCKS) cap = MAX_BWD_BLOCKS;
@@ -1095,8 +1134,10 @@ unsigned long long peer_default_timeout_ticks()
     return ticks;
 }
 
+// one exchange through the mailboxes, described but not launched: the put and the take of `width` face planes of `slab`
+// (advances the ring's exchange counter)
 template <typename T>
-int peer_exchange(T* slab, const Problem& p, int width, percnn_pi_peer_ring* pr, hipStream_t st)
+int peer_prepare(T* slab, const Problem& p, int width, percnn_pi_peer_ring* pr, pi::PeerXfer& put, pi::PeerXfer& take, bool& vec)
 {
     if (!pr || !pr->my_box || !pr->prev_box || !pr->next_box || width < 1 || width > p.halo || width > p.n0)
         return PERCNN_PI_EINVAL;
@@ -1108,14 +1149,15 @@ int peer_exchange(T* slab, const Problem& p, int width, percnn_pi_peer_ring* pr,
     auto at = [&](int s, int64_t pl) { return reinterpret_cast<char*>(slab + (size_t)s * ss + (size_t)pl * plane); };
     const uint64_t epoch = ++pr->epoch;
     const int parity = (int)(epoch & 1);
-    pi::PeerXfer put{}, take{};
+    put = pi::PeerXfer{};
+    take = pi::PeerXfer{};
     // direction 0: my LAST interior planes -> the next rank (arrive there as "from prev", its lower halo);
     // direction 1: my FIRST interior planes -> the prev rank (arrive as "from next", its upper halo)
     char* to_next = pi::peer_slot(pr->next_box, pr->slot_bytes, parity, 0);
     char* to_prev = pi::peer_slot(pr->prev_box, pr->slot_bytes, parity, 1);
     char* from_prev = pi::peer_slot(pr->my_box, pr->slot_bytes, parity, 0);
     char* from_next = pi::peer_slot(pr->my_box, pr->slot_bytes, parity, 1);
-    bool vec = bytes % 16 == 0;
+    vec = bytes % 16 == 0;
     for (int s = 0; s < 2; ++s) {
         put.src[0][s] = at(s, halo + n - width); put.dst[0][s] = to_next + s * soff;
         put.src[1][s] = at(s, halo);             put.dst[1][s] = to_prev + s * soff;
@@ -1132,15 +1174,30 @@ int peer_exchange(T* slab, const Problem& p, int width, percnn_pi_peer_ring* pr,
     put.mine = take.mine = static_cast<pi::PeerBox*>(pr->my_box);
     put.signal[0] = static_cast<pi::PeerBox*>(pr->next_box);
     put.signal[1] = static_cast<pi::PeerBox*>(pr->prev_box);
-    const unsigned long long ticks = pr->timeout_ticks ? pr->timeout_ticks : peer_default_timeout_ticks();
-    if (vec) {
-        hipLaunchKernelGGL(pi::peer_put_kernel<true>, dim3(2 * bpd), dim3(256), 0, st, put);
-        hipLaunchKernelGGL(pi::peer_take_kernel<true>, dim3(2 * bpd), dim3(256), 0, st, take, ticks);
-    } else {
-        hipLaunchKernelGGL(pi::peer_put_kernel<false>, dim3(2 * bpd), dim3(256), 0, st, put);
-        hipLaunchKernelGGL(pi::peer_take_kernel<false>, dim3(2 * bpd), dim3(256), 0, st, take, ticks);
-    }
+    return 0;
+}
+
+inline unsigned long long peer_ticks(const percnn_pi_peer_ring* pr)
+{
+    return pr->timeout_ticks ? pr->timeout_ticks : peer_default_timeout_ticks();
+}
+
+inline int peer_launch_take(const pi::PeerXfer& take, bool vec, const percnn_pi_peer_ring* pr, hipStream_t st)
+{
+    if (vec) hipLaunchKernelGGL(pi::peer_take_kernel<true>, dim3(2 * take.blocks_per_dir), dim3(256), 0, st, take, peer_ticks(pr));
+    else     hipLaunchKernelGGL(pi::peer_take_kernel<false>, dim3(2 * take.blocks_per_dir), dim3(256), 0, st, take, peer_ticks(pr));
     return (int)hipGetLastError();
+}
+
+template <typename T>
+int peer_exchange(T* slab, const Problem& p, int width, percnn_pi_peer_ring* pr, hipStream_t st)
+{
+    pi::PeerXfer put, take;
+    bool vec = false;
+    if (int rc = peer_prepare<T>(slab, p, width, pr, put, take, vec)) return rc;
+    if (vec) hipLaunchKernelGGL(pi::peer_put_kernel<true>, dim3(2 * put.blocks_per_dir), dim3(256), 0, st, put);
+    else     hipLaunchKernelGGL(pi::peer_put_kernel<false>, dim3(2 * put.blocks_per_dir), dim3(256), 0, st, put);
+    return peer_launch_take(take, vec, pr, st);
 }
 
 template <typename T>
@@ -1267,15 +1324,39 @@ int slab_rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* 
         if (int rc = set_slab_range(q, halo, lo, hi)) return rc;
         return (int)step_fwd<T>(in, out, P, q, st);
     };
+    // peer mailboxes + brick kernels: the step that writes a frame about to be exchanged puts its faces itself
+    const int vecw = pick_vec<T>(p, {traj, traj + frame});
+    const bool fuse_put = ring && ring->peer && p.opt.slab_fused_put && !side && (size_t)vecw * sizeof(T) == 16;
+    pi::PeerXfer take_pending{};
+    bool have_take = false, take_vec = false;
     for (int t = 0; t < T_steps; ++t) {
         T* cur = traj + (size_t)t * frame;
         T* nxt = cur + frame;
         const int m = t % k;
         if (m == 0) {
-            if (pending) {
+            if (have_take) {                                 // the put of this exchange rode on the previous step's launch
+                if (int rc = peer_launch_take(take_pending, take_vec, ring->peer, st)) return rc;
+                have_take = false;
+            } else if (pending) {
                 if (hipError_t e = hipStreamWaitEvent(st, pending, 0)) return (int)e;
                 pending = nullptr;
             } else if (int rc = ring_exchange<T>(cur, p, halo, ring, st)) return rc;
+        }
+        if (fuse_put && m == k - 1 && t + 1 < T_steps) {
+            Problem q = p;
+            if (int rc = set_slab(q, halo, 2 * m)) return rc;
+            const int brz = stream3d_vec<T>(q, {cur, nxt}, false) ? 0 : brick_rz_for<T>(q, vecw, false);   // step_fwd's own choice
+            if (brz) {
+                FusedPut fp{};
+                if (int rc = peer_prepare<T>(nxt, p, halo, ring->peer, fp.x, take_pending, take_vec)) return rc;
+                fp.vec16 = take_vec;
+                fp.timeout_ticks = peer_ticks(ring->peer);
+                fp.face_lo[0] = halo + (int)n - halo; fp.face_hi[0] = halo + (int)n;     // my LAST interior planes -> next
+                fp.face_lo[1] = halo;                 fp.face_hi[1] = 2 * halo;          // my FIRST interior planes -> prev
+                if (hipError_t e = brick_fwd<T>(brz, cur, nxt, P, q, st, &fp)) return (int)e;
+                have_take = true;
+                continue;
+            }
         }
         if (side && m == k - 1 && t + 1 < T_steps) {        // frame t+1 is exchanged next: faces first
             if (int rc = range(cur, nxt, halo, 2 * halo)) return rc;
@@ -1639,6 +1720,12 @@ int apply_option(Options& o, const char* key, long value)
     }
     if (!std::strcmp(key, "block_small")) { o.block_small = value != 0; return 0; }
     if (!std::strcmp(key, "slab_wide_adjoint")) { o.slab_wide_adjoint = value != 0; return 0; }
+    if (!std::strcmp(key, "slab_fused_put")) { o.slab_fused_put = value != 0; return 0; }
+    if (!std::strcmp(key, "slab_put_blocks")) {
+        if (value < 4 || value > 256 || value % 4) return PERCNN_PI_EINVAL;
+        o.slab_put_blocks = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "lane_x")) {
         if (value != 0 && value != -1 && (value < 2 || value > 7)) return PERCNN_PI_EINVAL;     // 7 = flat
         o.lane_x = (int)value;

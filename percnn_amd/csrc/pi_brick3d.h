@@ -19,6 +19,7 @@
 #pragma once
 #include "pi_device.h"
 #include "pi_kernels.h"
+#include "pi_peer.h"
 
 namespace pi {
 
@@ -76,7 +77,11 @@ struct Brick {
         if (g.xny > 0) {
             const unsigned x = r % NXCD, i = r / NXCD;
             const unsigned zx = x / (unsigned)g.xny, yx = x - zx * (unsigned)g.xny;
-            const unsigned pl = g.dxrg.div(i), rl = i - pl * (unsigned)g.xrg;
+            unsigned pl = g.dxrg.div(i);
+            const unsigned rl = i - pl * (unsigned)g.xrg;
+            // the regions of the upper half walk their planes from the top down: both ends of the plane range are computed
+            // FIRST -- in the slab layout those are the faces a fused put (pi_peer.h) is waiting for
+            if (2u * zx >= (unsigned)(NXCD / g.xny)) pl = (unsigned)g.xpg - 1u - pl;
             pg = zx * (unsigned)g.xpg + pl;
             rg = yx * (unsigned)g.xrg + rl;
         } else {
@@ -184,14 +189,22 @@ __device__ __forceinline__ Geom brick_as_geom(const BrickGeom& b)
 // ---------------------------------------------------------------------------------------------
 template <typename T, int HC, int RZ, int NT = BRICK_NT>
 __global__ void __launch_bounds__(NT)
-pi_fwd3d_brick_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict__ P, BrickGeom g, int hc_rt)
+pi_fwd3d_brick_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __restrict__ P, BrickGeom g, int hc_rt,
+                      PeerPutFused put)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // slab layout, peer-mailbox ring: the lowest `put.nput` workgroups carry the faces of the frame being written into the
+    // neighbours' mailboxes as soon as the bricks that hold them have stored them (pi_peer.h "put fused into the step kernel")
+    if (put.nput && (int)blockIdx.x < put.nput) {
+        if (put.vec16) peer_put_block<true>(put, (int)blockIdx.x);
+        else peer_put_block<false>(put, (int)blockIdx.x);
+        return;
+    }
     const int hc = HC > 0 ? HC : hc_rt;
     PI_STAMP3(0);
     Brick<T, RZ, NT> B;
-    B.locate(g, blockIdx.x, gridDim.x, 0u);
+    B.locate(g, blockIdx.x - (unsigned)put.nput, gridDim.x - (unsigned)put.nput, 0u);
     Lane L;
     L.i0 = B.i0; L.eb = B.eb;
     Geom gg = brick_as_geom(g);
@@ -259,6 +272,7 @@ pi_fwd3d_brick_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __r
         }
         PI_STAMP3(4 + (j > 0));
     }
+    if (put.nput) peer_face_stored(put, B.i0, min(B.i0 + RZ, g.n0));
     PI_STAMP3(7);
 }
 
@@ -272,10 +286,13 @@ pi_fwd3d_brick_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __r
 // SGPRs -- the generic form spilled)
 // (LOSS = pi::LossInj::mode, 0 / 1 / 2)
 template <typename T, int HC, int RZ, bool MOM, int LOSS = 0, int NT = BRICK_NT>
-__global__ void __launch_bounds__(NT, (RZ == 1 && HC == POLY && LOSS != 2) ? 4 : 2)   // one-plane bricks of pre-contracted
+__global__ void __launch_bounds__(NT, (RZ == 1 && HC == POLY && LOSS != 2 && sizeof(T) == 4) ? 4 : 2)   // one-plane bricks of pre-contracted float32
 pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restrict__ inj, T* __restrict__ Gp,
                       double* __restrict__ partials, const T* __restrict__ P, BrickGeom g, int hc_rt)
 {
+    // (no fused put here, unlike the forward kernel: measured on the 32 x 256^2 slab through the rank's own mailbox it bought
+    // 1.4 us per step where the forward's buys 4, and the extra kernel argument pushed three flavours of this kernel, which sits
+    // at its 128-VGPR / 102-SGPR edge, into scratch)
     static_assert(!MOM || HC == POLY, "fused moments are those of the pre-contracted block");
     constexpr int VEC = 16 / (int)sizeof(T), NW = NT / WAVE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

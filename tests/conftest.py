@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# a mailbox take that never gets its flag should fail a test in seconds, not after the production bound of 300 s
+os.environ.setdefault("PERCNN_PEER_TIMEOUT_S", "20")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

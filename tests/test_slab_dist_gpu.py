@@ -98,6 +98,9 @@ def _worker(rank, world, port, shape, halo, T, hc, dtype_name, overlap, transpor
             ok_fwd = ok_fwd and bool(torch.equal(traj2[:, :, halo:halo + n], traj_ref[:, :, lo:hi]))
             ok_g0 = ok_g0 and bool(torch.equal(g0b[:, halo:halo + n], g0_ref[:, lo:hi])) and ex.status() == 0
         q.put((rank, ok_fwd, ok_g0, err_pg, ok_auto, err_plain))
+    except Exception as e:                             # report instead of leaving the parent waiting for its queue time-out
+        q.put((rank, "error", repr(e)[:500]))
+        raise
     finally:
         try:
             slab.close_exchangers()
@@ -121,8 +124,11 @@ def test_multi_process_slab_rollout_on_one_gpu(world, shape, halo, T, hc, dtype,
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
+    errors = [r for r in res if len(r) == 3 and r[1] == "error"]
     for p in procs:
         p.join(timeout=120)
+    assert not errors, errors
+    for p in procs:
         assert p.exitcode == 0
     for rank, ok_fwd, ok_g0, err_pg, ok_auto, err_plain in sorted(res):
         # float32: measured against a float64 rollout of the same problem -- "as close to it as the single-domain path, within

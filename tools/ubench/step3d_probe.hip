@@ -62,7 +62,7 @@ static pi::BrickGeom brick_geom(int n0, int n1, int W, int rz)
 template <int RZ>
 static void launch_brick(const float* h, float* out, const float* P, const pi::BrickGeom& g, hipStream_t st)
 {
-    hipLaunchKernelGGL((pi::pi_fwd3d_brick_kernel<float, pi::POLY, RZ>), dim3(g.nblk), dim3(256), (size_t)2 * RZ * pi::BRICK_WB, st, h, out, P, g, 0);
+    hipLaunchKernelGGL((pi::pi_fwd3d_brick_kernel<float, pi::POLY, RZ>), dim3(g.nblk), dim3(256), (size_t)2 * RZ * pi::BRICK_WB, st, h, out, P, g, 0, pi::PeerPutFused{});
 }
 
 template <int RZ>
