@@ -139,3 +139,50 @@ def test_split_extent_and_scatter():
     assert loc.shape == (2, 9, 3) and torch.equal(loc[:, 2:7], full[:, 5:10]) and loc[:, :2].abs().sum() == 0
     with pytest.raises(ValueError):
         slab.scatter_slab(full, 0, 5, 4)
+
+
+def _probe_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        from percnn_amd import slab
+        out = []
+        for round_ in range(2):                             # two process groups in a row: the exchanger cache must follow
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            sample = torch.rand(2, 6 + 2 * 2, 4, 8, generator=torch.Generator().manual_seed(rank))
+            keep = sample.clone()
+            name, report = slab.probe_transport(sample, 2, candidates=("dist",))
+            ex = slab.make_exchanger(prefer_rccl=False, transport="dist")
+            again = slab.make_exchanger(prefer_rccl=False, transport="dist")
+            out.append((name, report["picked"], report["dist"]["usable_on_every_rank"],
+                        report["dist"]["halos_equal_portable_exchange"], bool(torch.equal(sample, keep)), ex is again, id(ex)))
+            work = sample.clone()
+            ex.exchange(work, 2, 2)                          # the cached exchanger works on THIS group
+            slab.close_exchangers()
+            dist.destroy_process_group()
+        q.put((rank, out))
+    except Exception as e:
+        q.put((rank, "error", repr(e)[:500]))
+        raise
+
+
+def test_transport_probe_and_exchanger_cache_across_process_groups():
+    """slab.probe_transport (start-up probe instead of a default, VERDICT r2 #2d) on a gloo ring of two: the portable
+    transport is usable on every rank, its halos equal the reference exchange, the sample is left untouched; and
+    make_exchanger's cache hands out ONE exchanger per live process group -- after destroy_process_group() + a new
+    init_process_group() a fresh one (it used to be keyed on id(group) / None for the life of the process)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    port = _free_port()
+    procs = [ctx.Process(target=_probe_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert not (len(r) == 3 and r[1] == "error"), r
+        rank, rounds = r
+        for name, picked, usable, equal, untouched, cached, _ in rounds:
+            assert name == picked == "dist" and usable and equal and untouched and cached
