@@ -4,7 +4,6 @@ single-domain plain-C oracle.  The compute kernel is replaced by the oracle's ra
 (injected explicitly; the product package itself has no CPU path), so what is tested here is
 exactly the orchestration that runs around the HIP slab kernels on a multi-GPU node."""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -16,12 +15,10 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _rendezvous():
+    """A fresh path for torch.distributed's file store: no TCP port to lose to another process between choosing and binding it."""
+    import tempfile
+    return os.path.join(tempfile.mkdtemp(prefix="percnn_rdzv_"), "store")
 
 
 def _random_block(hc, ndim, dtype, seed):
@@ -61,9 +58,8 @@ def _oracle_slab_steps(hc):
 
 def _worker(rank, world, port, shape, halo, T, hc, dtype_name, q):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         from percnn_amd import slab
         from oracle import pi_oracle as O
@@ -115,7 +111,7 @@ def _worker(rank, world, port, shape, halo, T, hc, dtype_name, q):
 def test_slab_rollout_matches_single_domain(world, shape, halo, T):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
+    port = _rendezvous()
     procs = [ctx.Process(target=_worker, args=(r, world, port, shape, halo, T, 3, "float64", q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -143,12 +139,11 @@ def test_split_extent_and_scatter():
 
 def _probe_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     try:
         from percnn_amd import slab
         out = []
         for round_ in range(2):                             # two process groups in a row: the exchanger cache must follow
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", init_method=f"file://{port}.{round_}", rank=rank, world_size=world)
             sample = torch.rand(2, 6 + 2 * 2, 4, 8, generator=torch.Generator().manual_seed(rank))
             keep = sample.clone()
             name, report = slab.probe_transport(sample, 2, candidates=("dist",))
@@ -174,7 +169,7 @@ def test_transport_probe_and_exchanger_cache_across_process_groups():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     world = 2
-    port = _free_port()
+    port = _rendezvous()
     procs = [ctx.Process(target=_probe_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()

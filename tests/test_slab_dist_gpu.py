@@ -32,8 +32,8 @@ def _free_port():
 def _worker(rank, world, port, shape, halo, T, hc, dtype_name, overlap, transport, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # file rendezvous (`port` is a fresh path): no TCP port to lose to another process between choosing and binding it
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         import percnn_amd as pa
         from percnn_amd import slab
@@ -119,7 +119,8 @@ def _worker(rank, world, port, shape, halo, T, hc, dtype_name, overlap, transpor
 def test_multi_process_slab_rollout_on_one_gpu(world, shape, halo, T, hc, dtype, overlap, transport, hip_device):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
+    import tempfile
+    port = os.path.join(tempfile.mkdtemp(prefix="percnn_rdzv_"), "store")
     procs = [ctx.Process(target=_worker, args=(r, world, port, shape, halo, T, hc, dtype, overlap, transport, q)) for r in range(world)]
     for p in procs:
         p.start()
