@@ -298,8 +298,9 @@ typedef struct percnn_pi_halo_ring {
  * planes per pass of the adjoint, workgroup size} */
 int percnn_pi_debug_blockmap(int ndim, const int64_t* shape, int elem_size, const char* options, int* out);
 /* Host-only: which kernel family a rollout of this problem takes (the library's own dispatch rules, for 16-byte-aligned
- * buffers).  out[8] = {forward family, adjoint family, 1 if the parameter gradients are reduced inside the sweep launches,
- * time steps per forward launch, per adjoint launch, planes per pass forward, adjoint, lanes per brick workgroup or 0}; families: 0 direct step kernels,
+ * buffers).  out[11] = {forward family, adjoint family, 1 if the parameter gradients are reduced inside the sweep launches,
+ * time steps per forward launch, per adjoint launch, planes per pass forward, adjoint, lanes per brick workgroup or 0,
+ * 2D tile width, tile height, lanes per tile workgroup (0: no tile kernels)}; families: 0 direct step kernels,
  * 1 2D tile kernels, 2 3D plane streaming, 3 3D brick kernels, 4 advective block. */
 int percnn_pi_debug_plan(int hc, int ndim, const int64_t* shape, int elem_size, const char* options, int* out);
 

@@ -43,6 +43,8 @@ struct Options {
     int skip_wgrad = 0;     // diagnostics: rollout_bwd runs the adjoint sweep only (bench uses it to time the sweep alone)
     int tile_xcd = 1;       // XCD-aware block -> tile map of the 2D tile kernels (0 = identity)
     int tile_by = 0;        // tile height of the 2D tile kernels: 32, 16, or 0 = by grid size (see tile_by_for)
+    int tile_wide = 3;      // float32 poly blocks: 3 = 32x40 / 40x40 tiles where they keep the grid in one round (tile_wide_for),
+                            // 0 = never, 1 / 2 = force 32x40 / 40x40
     int fwd_blocks = 0;     // direct forward kernel: grid cap (0 = none; measured: a bounded persistent grid loses, 384^3 376 -> 416 us)
     int xcd_window = 0;     // direct forward kernel: XCD-contiguous block remap inside windows of this many blocks (0 = whole grid)
     int block_small = 1;    // direct kernels: 64-thread workgroups while 256-thread ones would leave CUs idle (small grids)
@@ -855,18 +857,57 @@ int tile_by_for(const Problem& p)
     return tiles8 <= 256 ? 8 : (tiles32 <= 128 ? 16 : TILE_B);
 }
 
+// Wide tiles.  Past 512^2 the 32 x 32 tiles no longer fit one per CU (544^2 = 289 tiles on 256 CUs) and
+// the launch takes two rounds of a latency-bound workgroup chain: 512^2 218 k steps/s, 544^2 130 k.  Float32 poly blocks
+// therefore grow the TILE while that keeps the grid in one resident round: 32 x 40 tiles on 640 lanes (first sub-step's
+// region 44 x 52 = 572 strips), then 40 x 40 on 768 lanes (52 x 52 = 676 strips) -- one strip per lane either way, which is
+// what the sweep's operand pipeline is written for, and 10 / 12 waves at <= 168 registers (the fused-moments sweep holds
+// 164).  0: 32-wide tiles by tile_by_for; 1: 32 x 40 / 640; 2: 40 x 40 / 768.  Option tile_wide = 0 switches the rule off,
+// 1 / 2 force a shape (tests).  Float64 keeps 32 x 32: its fused sweep's [20][lanes] LDS accumulators do not fit next to a
+// larger window.
+template <typename T>
+int tile_wide_for(const Problem& p)
+{
+    if (sizeof(T) != 4 || p.hc != 0 || p.opt.tile_wide == 0 || p.opt.tile_k != 4 || p.opt.tile_nt != 512 || p.opt.tile_by != 0)
+        return 0;
+    if (p.opt.tile_wide == 1 || p.opt.tile_wide == 2) return p.opt.tile_wide;
+    auto tiles = [&](int64_t bx, int64_t by) { return ((p.n0 + by - 1) / by) * ((p.W + bx - 1) / bx); };
+    const int cus = 256;
+    if (tiles(32, 32) <= cus) return 0;
+    if (tiles(32, 40) <= cus) return 1;
+    if (tiles(40, 40) <= cus) return 2;
+    return 0;
+}
+
+struct TileShape { int bx, by, nt; };
+template <typename T>
+TileShape tile_shape_for(const Problem& p)
+{
+    switch (tile_wide_for<T>(p)) {
+        case 1: return {32, 40, 640};
+        case 2: return {40, 40, 768};
+        default: return {TILE_B, tile_by_for(p), 0};
+    }
+}
+template <typename T>
+int64_t tile_count(const Problem& p)
+{
+    const TileShape s = tile_shape_for<T>(p);
+    return ((p.n0 + s.by - 1) / s.by) * ((p.W + s.bx - 1) / s.bx);
+}
+
 template <typename T>
 bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs, bool adjoint)
 {
     if (!p.opt.tile || p.opt.vec == 1 || p.ndim != 2 || p.slab) return false;
     if (p.hc != 0 && p.hc != 2 && p.hc != 4 && p.hc != 8) return false;
     // ragged grids (e.g. the reference's 100^2) run with partial edge tiles; the window must not wrap onto itself
-    auto fits = [](int64_t n) { return (n + TILE_B - 1) / TILE_B * TILE_B + 16 <= 2 * n; };   // one wrap per window coordinate
-    if (p.W % pi::vec_width<T>::value || !fits(p.n0) || !fits(p.W)) return false;
+    const TileShape shp = tile_shape_for<T>(p);
+    auto fits = [](int64_t n, int64_t b) { return (n + b - 1) / b * b + 16 <= 2 * n; };        // one wrap per window coordinate
+    if (p.W % pi::vec_width<T>::value || !fits(p.n0, shp.by < TILE_B ? TILE_B : shp.by) || !fits(p.W, shp.bx)) return false;
     // the adjoint tile kernel owns one partial row per workgroup: beyond MAX_BWD_BLOCKS tiles the grid-stride
     // direct kernels take over (4096^2 = 16384 tiles)
-    const int64_t by = tile_by_for(p);
-    if (((p.n0 + by - 1) / by) * ((p.W + TILE_B - 1) / TILE_B) > MAX_BWD_BLOCKS) return false;
+    if (tile_count<T>(p) > MAX_BWD_BLOCKS) return false;
     // temporal blocking pays while launches are latency-bound; beyond, the halo ring's redundant traffic costs more than
     // the launches it saves.  Round 2 (write-through frame stores, cheaper tails; profiles/r02_direct_kernel_option_sweeps.txt,
     // us per step tiles / direct): forward 1024^2 4.5 / 6.4, 1536^2 8.6 / 9.9, 2048^2 14.4 / 14.9; backward 1024^2 11.0 / 12.2,
@@ -880,9 +921,9 @@ bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs, bo
 
 // XCD-aware tile map (pi::tile_of_block): split the tiles_y x tiles_x tile grid into 8 equal rectangles, as square as
 // possible; identity when the counts do not divide (ragged grids, small grids)
-pi::TileGeom make_tile_geom(const Problem& p, int by)
+pi::TileGeom make_tile_geom(const Problem& p, int by, int bx = TILE_B)
 {
-    const int tiles_x = (int)((p.W + TILE_B - 1) / TILE_B), tiles_y = (int)((p.n0 + by - 1) / by);
+    const int tiles_x = (int)((p.W + bx - 1) / bx), tiles_y = (int)((p.n0 + by - 1) / by);
     pi::TileGeom g{(int)p.n0, (int)p.W, (long)p.n, tiles_x, 0, 0, 0, p.loss};
     if (!p.opt.tile_xcd) return g;
     int best = -1;
@@ -896,25 +937,25 @@ pi::TileGeom make_tile_geom(const Problem& p, int by)
     return g;
 }
 
-template <typename T, int HC, int K, int NT, int BY = TILE_B>
+template <typename T, int HC, int K, int NT, int BY = TILE_B, int BX = TILE_B>
 hipError_t launch_fwd_tile(T* frame_t, const T* P, const Problem& p, hipStream_t st)
 {
-    using TL = pi::Tile<K, TILE_B, BY>;
-    const pi::TileGeom g = make_tile_geom(p, BY);
+    using TL = pi::Tile<K, BX, BY>;
+    const pi::TileGeom g = make_tile_geom(p, BY, BX);
     const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
     const size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + 32 /* lds_pad0/1 */ + (size_t)p.opt.lds_pad;
-    auto* k = pi::pi_fwd2d_tile_kernel<T, HC, K, TILE_B, BY, NT>;
+    auto* k = pi::pi_fwd2d_tile_kernel<T, HC, K, BX, BY, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, frame_t, (long)(2 * p.n), P, g);
     return hipGetLastError();
 }
 
-template <typename T, int HC, int K, int NT, int BY = TILE_B, bool MOM = false>
+template <typename T, int HC, int K, int NT, int BY = TILE_B, bool MOM = false, int BX = TILE_B>
 hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, unsigned inj_mask, T* g_h0,
                            int steps_to_zero, double* partials, const T* P, const Problem& p, hipStream_t st)
 {
-    using TL = pi::Tile<K, TILE_B, BY>;
-    const pi::TileGeom g = make_tile_geom(p, BY);
+    using TL = pi::Tile<K, BX, BY>;
+    const pi::TileGeom g = make_tile_geom(p, BY, BX);
     const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
     size_t lds = (size_t)4 * TL::PLANE * sizeof(T) + 32 /* lds_pad0/1 */;
     if (MOM && sizeof(T) == 4) {                // the tail reduction's scratch (pi_tile2d.h): doubles, then [20][NT + 16] values
@@ -923,9 +964,9 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
         if (tail > lds) lds = tail;
     }
     if (MOM && sizeof(T) == 8)                  // float64: [20][NT] per-lane moment accumulators behind the state buffers
-        lds = pi::tile_state_bytes<T, K, TILE_B, BY>() + (size_t)20 * NT * sizeof(double);
+        lds = pi::tile_state_bytes<T, K, BX, BY>() + (size_t)20 * NT * sizeof(double);
     lds += (size_t)p.opt.lds_pad;
-    auto* k = pi::pi_adj2d_tile_kernel<T, HC, K, TILE_B, BY, NT, MOM>;
+    auto* k = pi::pi_adj2d_tile_kernel<T, HC, K, BX, BY, NT, MOM>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, hframe_t, gframe_t, aframe_t, (long)(2 * p.n), inj_mask, g_h0,
                        steps_to_zero, partials, pi::nparams(p.hc), P, g);
@@ -957,6 +998,13 @@ hipError_t launch_adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, un
 template <typename T>
 hipError_t fwd_tile(T* frame_t, const T* P, const Problem& p, hipStream_t st)
 {
+    if constexpr (sizeof(T) == 4) {
+        switch (tile_wide_for<T>(p)) {
+            case 1: return launch_fwd_tile<T, pi::POLY, 4, 640, 40, 32>(frame_t, P, p, st);
+            case 2: return launch_fwd_tile<T, pi::POLY, 4, 768, 40, 40>(frame_t, P, p, st);
+            default: break;
+        }
+    }
 #define CALL_FT(HC, K, NT, ...) launch_fwd_tile<T, HC, K, NT, ##__VA_ARGS__>(frame_t, P, p, st)
     PI_TILE_DISPATCH(CALL_FT);
 #undef CALL_FT
@@ -974,13 +1022,24 @@ bool tile_fuse_ok(const Problem& p)
     // profiles/r02_fp64_fused_tile_sweep.txt); with LDS accumulators: 186 VGPRs, no scratch, lambda-omega 512^2 backward
     // 5.45 -> 4.48 us per step, 1024^2 19.1 -> 15.9 (profiles/r02_fp64_fused_lds_accumulators.txt)
     return p.opt.tile_fuse && !p.opt.skip_wgrad && p.hc == 0 &&
-           p.opt.tile_k == 4 && p.opt.tile_nt == 512 && tile_by_for(p) == TILE_B;
+           p.opt.tile_k == 4 && p.opt.tile_nt == 512 && (tile_by_for(p) == TILE_B || tile_wide_for<T>(p) != 0);
 }
 
 template <typename T>
 hipError_t adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, unsigned inj_mask, T* g_h0, int steps_to_zero,
                     double* partials, const T* P, const Problem& p, hipStream_t st)
 {
+    if constexpr (sizeof(T) == 4) {
+        const bool fused = tile_fuse_ok<T>(p);
+#define CALL_WIDE(NT, BY, BX, MOM) \
+    launch_adj_tile<T, pi::POLY, 4, NT, BY, MOM, BX>(hframe_t, gframe_t, aframe_t, inj_mask, g_h0, steps_to_zero, partials, P, p, st)
+        switch (tile_wide_for<T>(p)) {
+            case 1: return fused ? CALL_WIDE(640, 40, 32, true) : CALL_WIDE(640, 40, 32, false);
+            case 2: return fused ? CALL_WIDE(768, 40, 40, true) : CALL_WIDE(768, 40, 40, false);
+            default: break;
+        }
+#undef CALL_WIDE
+    }
     if (tile_fuse_ok<T>(p))
         return launch_adj_tile<T, pi::POLY, 4, 512, TILE_B, true>(hframe_t, gframe_t, aframe_t, inj_mask, g_h0,
                                                                   steps_to_zero, partials, P, p, st);
@@ -1586,10 +1645,7 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     int t_cur = t_top;
     if (tile_eligible<T>(p, {traj, g_traj, g_h0, adj}, true)) {
         const int K = (p.opt.tile_k == 8 && p.hc != 0) ? 4 : p.opt.tile_k;
-        {
-            const int by = tile_by_for(p);
-            rows = (unsigned)(((p.n0 + by - 1) / by) * ((p.W + TILE_B - 1) / TILE_B));
-        }
+        rows = (unsigned)tile_count<T>(p);
         for (; t_cur - K >= 0; t_cur -= K) {
             unsigned m = 0;
             for (int q = 0; q < K; ++q) if (has(t_cur - 1 - q)) m |= 1u << q;
@@ -1674,6 +1730,11 @@ int apply_option(Options& o, const char* key, long value)
     if (!std::strcmp(key, "tile_by")) {
         if (value != 0 && value != 8 && value != 16 && value != 32) return PERCNN_PI_EINVAL;
         o.tile_by = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "tile_wide")) {
+        if (value < 0 || value > 3) return PERCNN_PI_EINVAL;
+        o.tile_wide = (int)value;
         return 0;
     }
     if (!std::strcmp(key, "skip_wgrad")) { o.skip_wgrad = value != 0; return 0; }
@@ -1874,7 +1935,8 @@ namespace {
 // Which kernel family a rollout of this problem runs on and how its backward is scheduled -- the library's own dispatch
 // rules, evaluated for 16-byte-aligned buffers (bench.py labels its roofline entries with it instead of mirroring the rules).
 // out = {forward family, adjoint family, gradients reduced inside the sweep launches (0 / 1), time steps per forward launch,
-//        per adjoint launch, planes per pass forward, adjoint, lanes per brick workgroup (0: no bricks)}; families: 0 direct, 1 2D tiles, 2 plane streaming, 3 3D bricks,
+//        per adjoint launch, planes per pass forward, adjoint, lanes per brick workgroup (0: no bricks), 2D tile width,
+//        height, lanes per tile workgroup (0: no tiles)}; families: 0 direct, 1 2D tiles, 2 plane streaming, 3 3D bricks,
 //        4 advective block
 template <typename T>
 int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options, int* out)
@@ -1906,6 +1968,13 @@ int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options,
     out[3] = out[0] == 1 ? K : 1;
     out[4] = out[1] == 1 ? K : 1;
     out[7] = (out[0] == 3 || out[1] == 3) ? brick_nt_for(p, vec) : 0;     // lanes per brick workgroup
+    out[8] = out[9] = out[10] = 0;
+    if (out[0] == 1 || out[1] == 1) {                                      // 2D tiles: width, height, lanes per workgroup
+        const TileShape ts = tile_shape_for<T>(p);
+        out[8] = ts.bx; out[9] = ts.by;
+        out[10] = ts.nt ? ts.nt : (p.opt.tile_k == 2 ? 256 : (p.hc == 0 && p.opt.tile_k == 8) ? 1024 : (p.hc == 0 && p.opt.tile_nt == 1024) ? 1024 :
+                                   (p.hc == 0 && ts.by == 16) ? 320 : (p.hc == 0 && ts.by == 8) ? 256 : p.opt.tile_nt == 256 ? 256 : 512);
+    }
     return 0;
 }
 

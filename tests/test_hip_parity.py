@@ -670,13 +670,15 @@ def test_peer_mailbox_exchange_to_self(hip_device):
 # temporally blocked 2D kernels: every variant must stay bit-identical to the oracle
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opts", [{"tile": 0}, {"tile_xcd": 0}, {"tile_k": 2}, {"tile_k": 4, "tile_nt": 256},
-                                  {"tile_k": 4, "tile_nt": 512}, {"tile_k": 4, "tile_nt": 1024}, {"tile_k": 8}, {"tile_by": 8}, {"tile_by": 16}, {"tile_by": 32}, {"vec": 1}])
+                                  {"tile_k": 4, "tile_nt": 512}, {"tile_k": 4, "tile_nt": 1024}, {"tile_k": 8}, {"tile_by": 8}, {"tile_by": 16}, {"tile_by": 32}, {"vec": 1},
+                                  {"tile_wide": 1}, {"tile_wide": 2}])
 @pytest.mark.parametrize("dtype,hc", [(np.float32, 8), (np.float32, 2), (np.float64, 4), (np.float32, 0),
                                       (np.float64, 0)])
 @pytest.mark.parametrize("shape", [(64, 96), (40, 100), (128, 256)])
 def test_tile_variants_bitwise(opts, dtype, hc, shape, hip_device):
     """(64, 96): whole tiles; (40, 100): ragged grid with partial edge tiles (the reference trains on 100^2);
-    (128, 256): 4 x 8 tiles, the XCD-aware block -> tile map is active (2 x 2 tiles per XCD)."""
+    (128, 256): 4 x 8 tiles, the XCD-aware block -> tile map is active (2 x 2 tiles per XCD).
+    tile_wide = 1 / 2 force the 32 x 40 / 40 x 40 tiles of the 513^2 ... 640^2 range (float32 poly blocks; ignored elsewhere)."""
     import percnn_amd as pa
     T = 19                                       # not a multiple of K
     rs = np.random.RandomState(9)
@@ -685,10 +687,13 @@ def test_tile_variants_bitwise(opts, dtype, hc, shape, hip_device):
     gt = rs.uniform(-1, 1, (T + 1, 2) + shape).astype(dtype)
     ref = o_rollout_fwd(h0, P, T)
     g0_ref, pg_ref = o_rollout_bwd(ref, gt, P)
-    defaults = {"tile": 1, "tile_k": 4, "tile_nt": 512, "tile_by": 0, "vec": 0, "tile_xcd": 1}
+    defaults = {"tile": 1, "tile_k": 4, "tile_nt": 512, "tile_by": 0, "vec": 0, "tile_xcd": 1, "tile_wide": 3}
     try:
         for k, v in opts.items():
             pa.set_option(k, v)
+        if "tile_wide" in opts and dtype == np.float32 and hc == 0:
+            from percnn_amd import _lib
+            assert _lib.rollout_plan(0, shape, 4)["tile"] == ((32, 40, 640) if opts["tile_wide"] == 1 else (40, 40, 768))
         traj = torch.empty((T + 1, 2) + shape, dtype=torch.from_numpy(h0).dtype, device=hip_device)
         traj[0] = dev_t(h0, hip_device)
         pa.rollout_fwd_(traj, dev_t(P, hip_device))
@@ -704,6 +709,33 @@ def test_tile_variants_bitwise(opts, dtype, hc, shape, hip_device):
     finally:
         for k, v in defaults.items():
             pa.set_option(k, v)
+
+
+@pytest.mark.parametrize("shape,tile", [((544, 544), (32, 40, 640)), ((640, 640), (40, 40, 768)), ((560, 600), (40, 40, 768)),
+                                        ((520, 536), (32, 40, 640))])
+def test_wide_tiles_past_512_bitwise(shape, tile, hip_device):
+    """513^2 ... 640^2: the float32 poly tile kernels grow their tiles to 32 x 40 / 40 x 40 so the grid stays
+    one workgroup per CU; state and dL/dh0 bit-identical to the C oracle, fused in-sweep gradients vs the oracle's,
+    squared-error loss folded into the sweep == the materialised route."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    assert _lib.rollout_plan(0, shape, 4)["tile"] == tile and _lib.rollout_plan(0, shape, 4)["fused_gradients"]
+    T = 9
+    rs = np.random.RandomState(31)
+    P = random_block(0, 2, np.float32, 17, scale=0.3)
+    h0 = rs.uniform(0, 1, (2,) + shape).astype(np.float32)
+    gt = rs.uniform(-1, 1, (T + 1, 2) + shape).astype(np.float32)
+    ref = o_rollout_fwd(h0, P, T)
+    g0_ref, pg_ref = o_rollout_bwd(ref, gt, P)
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=hip_device)
+    traj[0] = dev_t(h0, hip_device)
+    pa.rollout_fwd_(traj, dev_t(P, hip_device))
+    assert np.array_equal(traj.cpu().numpy(), ref)
+    g0, pg = pa.rollout_bwd(traj, dev_t(gt, hip_device), dev_t(P, hip_device))
+    assert np.array_equal(g0.cpu().numpy(), g0_ref)
+    assert rel_l2(pg.cpu().numpy(), pg_ref) < 2e-5
+    g0n, pgn = pa.rollout_bwd(traj, dev_t(gt, hip_device), dev_t(P, hip_device), options={"tile_wide": 0})
+    assert torch.equal(g0, g0n) and rel_l2(pg.cpu().numpy(), pgn.cpu().numpy()) < 2e-6
 
 
 # ---------------------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ done
 for wl in gs2d_512 gs3d_128 lo2d_512 gs2d_100; do
   rm -rf /tmp/kt; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --workload $wl --no-cpu-baseline --no-extras --no-also --steps 3 --warmup 1 > /tmp/kt.log 2>&1
   python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) > $O/${ROUND}_final_rocprofv3_kernel_stats_$wl.txt 2>&1
-  tail -1 /tmp/kt.log > $O/${ROUND}_final_bench_under_rocprof_$wl.json
+  grep "^{" /tmp/kt.log | tail -1 > $O/${ROUND}_final_bench_under_rocprof_$wl.json
 done
 (timeout 900 python $R/bench.py --workload gs2d_512 --reaction factored --no-cpu-baseline --no-also 2>&1 | tail -1) > $O/${ROUND}_final_bench_gs2d_512_factored.json
 : > $O/${ROUND}_final_pmc_fetch_write_summary.txt
