@@ -405,7 +405,8 @@ def lo2d_physics_path_extra(pa, dev, reaction, reps=3):
     e1.record()
     torch.cuda.synchronize()
     return {"what": f"lambda-omega {shape[0]}x{shape[1]} float64, T={T}: RCNN.trajectory() + physics_loss + backward per iteration "
-                    "(the loss of percnn_LO_eqn.py:371-373, in the gradient path)",
+                    "(the loss of percnn_LO_eqn.py:371-373, in the gradient path; physics_loss = one autograd node since round 3, "
+                    "the residual-tensor expression took 16.2 ms)",
             "gpu_ms": e0.elapsed_time(e1) / reps, "wall_ms": (time.perf_counter() - t0) / reps * 1e3,
             "time_steps_per_sec": T / (e0.elapsed_time(e1) / reps * 1e-3), "loss_value": float(loss)}
 
@@ -730,9 +731,35 @@ def physics_extra(pa, cell, family, traj, esz, npts):
     tf, tb = ev[0].elapsed_time(ev[1]) / 3 * 1e-3, ev[1].elapsed_time(ev[2]) / 3 * 1e-3
     # algorithmic bytes per point-frame: fwd read h_f, h_{f+1}, write R = 3*C*s; adjoint read h_f, g_f, write = 3*C*s
     b = 3 * 2 * esz * npts * F
-    return {"frames": F, "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_GBps": b / tf / 1e9, "bwd_GBps": b / tb / 1e9,
-            "fwd_frac_of_8TBps": b / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac_of_8TBps": b / tb / 1e9 / HBM_PEAK_GBS,
-            "loss_value": float(physics.physics_loss(sub, Q))}
+    out = {"frames": F, "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "fwd_GBps": b / tf / 1e9, "bwd_GBps": b / tb / 1e9,
+           "fwd_frac_of_8TBps": b / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac_of_8TBps": b / tb / 1e9 / HBM_PEAK_GBS,
+           "loss_value": float(physics.physics_loss(sub, Q))}
+    # the loss AS the consumer sees it (physics.physics_loss = one autograd node: a reducing pass, then two launches that write
+    # dL/dtraj) next to the residual-tensor expression it replaced; algorithmic bytes: loss pass reads the trajectory once
+    # (C*s per point-frame), gradient = scaled residual (read + write) + adjoint (read h, G, write) = 5*C*s
+    del R, gR, g
+    torch.cuda.empty_cache()
+    res = {}
+    for name, fused in (("one_node", True), ("residual_tensor_expression", False)):
+        t = sub.detach().requires_grad_(True)
+        physics.physics_loss(t, Q, fused=fused).backward()
+        t.grad = None
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        loss = physics.physics_loss(t, Q, fused=fused)
+        ev[1].record()
+        loss.backward()
+        ev[2].record()
+        torch.cuda.synchronize()
+        res[name] = {"loss_us": ev[0].elapsed_time(ev[1]) * 1e3, "gradient_us": ev[1].elapsed_time(ev[2]) * 1e3}
+        t.grad = None
+        del t, loss
+        torch.cuda.empty_cache()
+    cs = 2 * esz * npts * F
+    res["one_node"]["loss_frac_of_8TBps"] = cs / (res["one_node"]["loss_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+    res["one_node"]["gradient_frac_of_8TBps"] = 5 * cs / (res["one_node"]["gradient_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+    out["loss_and_gradient"] = res
+    return out
 
 
 def sqerr_extra(pa, traj, P, T, fwd_ms, reps):

@@ -298,9 +298,10 @@ typedef struct percnn_pi_halo_ring {
  * planes per pass of the adjoint, workgroup size} */
 int percnn_pi_debug_blockmap(int ndim, const int64_t* shape, int elem_size, const char* options, int* out);
 /* Host-only: which kernel family a rollout of this problem takes (the library's own dispatch rules, for 16-byte-aligned
- * buffers).  out[11] = {forward family, adjoint family, 1 if the parameter gradients are reduced inside the sweep launches,
+ * buffers).  out[14] = {forward family, adjoint family, 1 if the parameter gradients are reduced inside the sweep launches,
  * time steps per forward launch, per adjoint launch, planes per pass forward, adjoint, lanes per brick workgroup or 0,
- * 2D tile width, tile height, lanes per tile workgroup (0: no tile kernels)}; families: 0 direct step kernels,
+ * 2D tile width, tile height, lanes per tile workgroup of the adjoint sweep (0: no tile kernels), the same three of the
+ * forward}; families: 0 direct step kernels,
  * 1 2D tile kernels, 2 3D plane streaming, 3 3D brick kernels, 4 advective block. */
 int percnn_pi_debug_plan(int hc, int ndim, const int64_t* shape, int elem_size, const char* options, int* out);
 
@@ -380,6 +381,30 @@ int percnn_pi_residual_bwd_f32(const float *traj, const float *g_resid, float *g
                                int ndim, const int64_t *shape, int nframes, void *stream);
 int percnn_pi_residual_bwd_f64(const double *traj, const double *g_resid, double *g_state, const double *params,
                                int ndim, const int64_t *shape, int nframes, void *stream);
+
+/* The residual LOSS and its gradient without the residual itself (round 3).  Replaces loss_gen (2dgs:340-353, 3dgs:333-346,
+ * lo:343-357):  L = MSE(f_u, 0) + MSE(f_v, 0) over resid[0 .. nframes).  weighted != 0 reproduces the reference's padding
+ * (2 cells low, 3 high -> an (N+1)^d evaluation grid in which index 0 of every axis counts twice):
+ *   L = sum_{f,s,x} w(x) resid^2 / (nframes * prod(N_a + 1)),  w = 2^(number of zero coordinates of x);
+ * weighted == 0: the plain mean over the periodic grid.  traj: [nframes+1][2][*S] at least.
+ *   _sqloss     : loss_out[0] (device, compute type) = L.  One pass over the trajectory (8 / 16 B per point and frame), the
+ *                 per-block sums in double, fixed-order final sum.  workspace >= percnn_pi_residual_sqloss_workspace_bytes().
+ *   _sqloss_bwd : g_traj[0 .. nout_frames) = g_loss * dL/dtraj (nout_frames >= nframes + 1; frames the loss does not see are
+ *                 zeroed), g_loss = DEVICE pointer to the upstream scalar gradient (NULL = 1).  Two launches: the scaled
+ *                 residual into `scratch` (nframes frames), then its adjoint incl. the -G/dt part of the later frame.
+ *                 (Was: residual, 6 element-wise autograd nodes over the whole trajectory, zero-fill, adjoint, a division and
+ *                 a subtraction over the whole trajectory: lambda-omega 512^2 x 400 iteration 16.1 ms.) */
+size_t percnn_pi_residual_sqloss_workspace_bytes(void);
+int percnn_pi_residual_sqloss_f32(const float *traj, const float *params, int ndim, const int64_t *shape, int nframes,
+                                  int weighted, float *loss_out, void *workspace, size_t workspace_bytes, void *stream);
+int percnn_pi_residual_sqloss_f64(const double *traj, const double *params, int ndim, const int64_t *shape, int nframes,
+                                  int weighted, double *loss_out, void *workspace, size_t workspace_bytes, void *stream);
+int percnn_pi_residual_sqloss_bwd_f32(const float *traj, const float *g_loss, const float *params, int ndim,
+                                      const int64_t *shape, int nframes, int nout_frames, int weighted, float *scratch,
+                                      float *g_traj, void *stream);
+int percnn_pi_residual_sqloss_bwd_f64(const double *traj, const double *g_loss, const double *params, int ndim,
+                                      const int64_t *shape, int nframes, int nout_frames, int weighted, double *scratch,
+                                      double *g_traj, void *stream);
 
 /* ---- per-call tuning overrides -----------------------------------------------------------------------------------
  * The four calls above that training / inference loops issue, with an `options` string "key=value,key=value" (keys of

@@ -30,7 +30,9 @@ EXPORTS = [
     "percnn_pi_peer_box_open", "percnn_pi_peer_box_close", "percnn_pi_peer_box_status",
     "percnn_pi_peer_exchange_f32", "percnn_pi_peer_exchange_f64",
     "percnn_pi_pack_fwd_f32", "percnn_pi_pack_fwd_f64", "percnn_pi_pack_bwd_f32", "percnn_pi_pack_bwd_f64",
-    "percnn_pi_debug_blockmap", "percnn_pi_debug_plan",
+    "percnn_pi_debug_blockmap", "percnn_pi_debug_plan", "percnn_pi_residual_sqloss_workspace_bytes",
+    "percnn_pi_residual_sqloss_f32", "percnn_pi_residual_sqloss_f64", "percnn_pi_residual_sqloss_bwd_f32",
+    "percnn_pi_residual_sqloss_bwd_f64",
 ] + [f"percnn_pi_{op}_{suf}" for suf in ("f32", "f64")
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
                 "slab_step_fwd_range", "slab_step_bwd_range", "slab_rollout_fwd", "slab_rollout_bwd", "residual_fwd",
@@ -155,6 +157,10 @@ def lib() -> ctypes.CDLL:
         f.restype, f.argtypes = ci, [vp, vp, vp, ci, i64p, ci, vp]
         f = getattr(L, f"percnn_pi_residual_bwd_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, vp, vp, ci, i64p, ci, vp]
+        f = getattr(L, f"percnn_pi_residual_sqloss_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, ci, i64p, ci, ci, vp, vp, sz, vp]
+        f = getattr(L, f"percnn_pi_residual_sqloss_bwd_{suf}")
+        f.restype, f.argtypes = ci, [vp, vp, vp, ci, i64p, ci, ci, ci, vp, vp, vp]
         f = getattr(L, f"percnn_pi_rollout_fwd_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, ci, ci, i64p, ci, vp]
         f = getattr(L, f"percnn_pi_rollout_bwd_{suf}")
@@ -172,6 +178,7 @@ def lib() -> ctypes.CDLL:
         f.restype, f.argtypes = ci, [vp, vp, cs, cd, vp, vp, vp, vp, sz, vp, ci, ci, i64p, ci, cs, vp]
         f = getattr(L, f"percnn_pi_traj_sqerr_{suf}")
         f.restype, f.argtypes = ci, [vp, vp, cs, ci, ci, i64p, cd, vp, vp, sz, vp]
+    L.percnn_pi_residual_sqloss_workspace_bytes.restype, L.percnn_pi_residual_sqloss_workspace_bytes.argtypes = sz, []
     L.percnn_pi_s1_param_count.restype = sz
     L.percnn_pi_s1_param_count.argtypes = []
     L.percnn_pi_s1_step_fwd_f32.restype, L.percnn_pi_s1_step_fwd_f32.argtypes = ci, [vp, vp, vp, i64p, vp]
@@ -244,12 +251,13 @@ FAMILIES = {0: "direct", 1: "tile2d", 2: "stream3d", 3: "brick3d", 4: "advective
 
 def rollout_plan(hc: int, shape, elem_size: int, options=None) -> dict:
     """Kernel families a rollout of this problem runs on (the library's own dispatch, ``percnn_pi_debug_plan``)."""
-    out = (ctypes.c_int * 11)()
+    out = (ctypes.c_int * 14)()
     check(lib().percnn_pi_debug_plan(int(hc), len(shape), shape_arg(shape), int(elem_size), options_arg(options), out),
           "debug_plan")
     return {"fwd": FAMILIES[out[0]], "bwd": FAMILIES[out[1]], "fused_gradients": bool(out[2]), "fwd_steps_per_launch": out[3],
             "bwd_steps_per_launch": out[4], "fwd_planes_per_pass": out[5], "bwd_planes_per_pass": out[6],
-            "brick_lanes": out[7], "tile": (out[8], out[9], out[10]) if out[10] else None}
+            "brick_lanes": out[7], "tile": (out[8], out[9], out[10]) if out[10] else None,
+            "tile_fwd": (out[11], out[12], out[13]) if out[13] else None}
 
 
 def set_option(key: str, value: int) -> None:

@@ -865,8 +865,13 @@ int tile_by_for(const Problem& p)
 // 164).  0: 32-wide tiles by tile_by_for; 1: 32 x 40 / 640; 2: 40 x 40 / 768.  Option tile_wide = 0 switches the rule off,
 // 1 / 2 force a shape (tests).  Float64 keeps 32 x 32: its fused sweep's [20][lanes] LDS accumulators do not fit next to a
 // larger window.
+// The two directions choose independently (frames have one layout whatever tile wrote them): the sweep is register-bound
+// at one workgroup per CU and gains from both shapes (same box, us per step 32 x 32 -> wide: 544^2 5.43 -> 3.83, 640^2 5.31 ->
+// 3.82); the forward is bound by waves per SIMD and sub-step (50 registers: its second round of 32 x 32 tiles is co-resident),
+// a 32 x 40 tile's nine wave slots per launch against seven still beat two rounds (544^2 2.47 -> 2.24) but a 40 x 40 tile's do
+// not (640^2 2.41 -> 2.91), so the forward stops at 32 x 40 (profiles/r03_tile_cliff.txt).
 template <typename T>
-int tile_wide_for(const Problem& p)
+int tile_wide_for(const Problem& p, bool adjoint)
 {
     if (sizeof(T) != 4 || p.hc != 0 || p.opt.tile_wide == 0 || p.opt.tile_k != 4 || p.opt.tile_nt != 512 || p.opt.tile_by != 0)
         return 0;
@@ -875,24 +880,24 @@ int tile_wide_for(const Problem& p)
     const int cus = 256;
     if (tiles(32, 32) <= cus) return 0;
     if (tiles(32, 40) <= cus) return 1;
-    if (tiles(40, 40) <= cus) return 2;
+    if (adjoint && tiles(40, 40) <= cus) return 2;
     return 0;
 }
 
 struct TileShape { int bx, by, nt; };
 template <typename T>
-TileShape tile_shape_for(const Problem& p)
+TileShape tile_shape_for(const Problem& p, bool adjoint)
 {
-    switch (tile_wide_for<T>(p)) {
+    switch (tile_wide_for<T>(p, adjoint)) {
         case 1: return {32, 40, 640};
         case 2: return {40, 40, 768};
         default: return {TILE_B, tile_by_for(p), 0};
     }
 }
 template <typename T>
-int64_t tile_count(const Problem& p)
+int64_t tile_count(const Problem& p, bool adjoint)
 {
-    const TileShape s = tile_shape_for<T>(p);
+    const TileShape s = tile_shape_for<T>(p, adjoint);
     return ((p.n0 + s.by - 1) / s.by) * ((p.W + s.bx - 1) / s.bx);
 }
 
@@ -902,12 +907,12 @@ bool tile_eligible(const Problem& p, std::initializer_list<const void*> ptrs, bo
     if (!p.opt.tile || p.opt.vec == 1 || p.ndim != 2 || p.slab) return false;
     if (p.hc != 0 && p.hc != 2 && p.hc != 4 && p.hc != 8) return false;
     // ragged grids (e.g. the reference's 100^2) run with partial edge tiles; the window must not wrap onto itself
-    const TileShape shp = tile_shape_for<T>(p);
+    const TileShape shp = tile_shape_for<T>(p, adjoint);
     auto fits = [](int64_t n, int64_t b) { return (n + b - 1) / b * b + 16 <= 2 * n; };        // one wrap per window coordinate
     if (p.W % pi::vec_width<T>::value || !fits(p.n0, shp.by < TILE_B ? TILE_B : shp.by) || !fits(p.W, shp.bx)) return false;
     // the adjoint tile kernel owns one partial row per workgroup: beyond MAX_BWD_BLOCKS tiles the grid-stride
     // direct kernels take over (4096^2 = 16384 tiles)
-    if (tile_count<T>(p) > MAX_BWD_BLOCKS) return false;
+    if (tile_count<T>(p, true) > MAX_BWD_BLOCKS) return false;
     // temporal blocking pays while launches are latency-bound; beyond, the halo ring's redundant traffic costs more than
     // the launches it saves.  Round 2 (write-through frame stores, cheaper tails; profiles/r02_direct_kernel_option_sweeps.txt,
     // us per step tiles / direct): forward 1024^2 4.5 / 6.4, 1536^2 8.6 / 9.9, 2048^2 14.4 / 14.9; backward 1024^2 11.0 / 12.2,
@@ -999,7 +1004,7 @@ template <typename T>
 hipError_t fwd_tile(T* frame_t, const T* P, const Problem& p, hipStream_t st)
 {
     if constexpr (sizeof(T) == 4) {
-        switch (tile_wide_for<T>(p)) {
+        switch (tile_wide_for<T>(p, false)) {
             case 1: return launch_fwd_tile<T, pi::POLY, 4, 640, 40, 32>(frame_t, P, p, st);
             case 2: return launch_fwd_tile<T, pi::POLY, 4, 768, 40, 40>(frame_t, P, p, st);
             default: break;
@@ -1022,7 +1027,7 @@ bool tile_fuse_ok(const Problem& p)
     // profiles/r02_fp64_fused_tile_sweep.txt); with LDS accumulators: 186 VGPRs, no scratch, lambda-omega 512^2 backward
     // 5.45 -> 4.48 us per step, 1024^2 19.1 -> 15.9 (profiles/r02_fp64_fused_lds_accumulators.txt)
     return p.opt.tile_fuse && !p.opt.skip_wgrad && p.hc == 0 &&
-           p.opt.tile_k == 4 && p.opt.tile_nt == 512 && (tile_by_for(p) == TILE_B || tile_wide_for<T>(p) != 0);
+           p.opt.tile_k == 4 && p.opt.tile_nt == 512 && (tile_by_for(p) == TILE_B || tile_wide_for<T>(p, true) != 0);
 }
 
 template <typename T>
@@ -1033,7 +1038,7 @@ hipError_t adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, unsigned 
         const bool fused = tile_fuse_ok<T>(p);
 #define CALL_WIDE(NT, BY, BX, MOM) \
     launch_adj_tile<T, pi::POLY, 4, NT, BY, MOM, BX>(hframe_t, gframe_t, aframe_t, inj_mask, g_h0, steps_to_zero, partials, P, p, st)
-        switch (tile_wide_for<T>(p)) {
+        switch (tile_wide_for<T>(p, true)) {
             case 1: return fused ? CALL_WIDE(640, 40, 32, true) : CALL_WIDE(640, 40, 32, false);
             case 2: return fused ? CALL_WIDE(768, 40, 40, true) : CALL_WIDE(768, 40, 40, false);
             default: break;
@@ -1645,7 +1650,7 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     int t_cur = t_top;
     if (tile_eligible<T>(p, {traj, g_traj, g_h0, adj}, true)) {
         const int K = (p.opt.tile_k == 8 && p.hc != 0) ? 4 : p.opt.tile_k;
-        rows = (unsigned)tile_count<T>(p);
+        rows = (unsigned)tile_count<T>(p, true);
         for (; t_cur - K >= 0; t_cur -= K) {
             unsigned m = 0;
             for (int q = 0; q < K; ++q) if (has(t_cur - 1 - q)) m |= 1u << q;
@@ -1706,6 +1711,75 @@ int residual_impl(const T* traj, const T* G, T* out, const T* Q, int ndim, const
     if (ndim == 2) { if (vec == 1) PI_RES(2, 1); else PI_RES(2, V); }
     else           { if (vec == 1) PI_RES(3, 1); else PI_RES(3, V); }
 #undef PI_RES
+    return (int)hipGetLastError();
+}
+
+// ---- the residual LOSS (MSE of f_u + MSE of f_v, optionally with the reference's padded-grid weighting) and its gradient
+// w.r.t. the trajectory, without materialising the residual or the autograd temporaries of the loss expression ----
+constexpr unsigned RESLOSS_SLOTS = 16384;           // per-block partial sums of the loss pass (doubles)
+
+double resloss_scale(const Problem& p, int ndim, const int64_t* shape, int nframes, int weighted)
+{
+    double pts = 1.0;
+    for (int a = 0; a < ndim; ++a) pts *= (double)(shape[a] + (weighted ? 1 : 0));
+    (void)p;
+    return 1.0 / ((double)nframes * pts);
+}
+
+template <typename T>
+int residual_sqloss_impl(const T* traj, const T* Q, int ndim, const int64_t* shape, int nframes, int weighted, T* loss_out,
+                         void* ws, size_t ws_bytes, void* stream)
+{
+    Problem p;
+    if (int rc = make_problem(0, ndim, shape, false, p)) return rc;
+    if (!traj || !Q || !loss_out || nframes < 1) return PERCNN_PI_EINVAL;
+    if (!ws || ws_bytes < RESLOSS_SLOTS * sizeof(double) || reinterpret_cast<uintptr_t>(ws) % 8) return PERCNN_PI_EWORKSPACE;
+    const Geom g = make_geom(p);
+    const int vec = pick_vec<T>(p, {traj});
+    const long nchunks = (long)g.rows * (g.W / vec);
+    const unsigned gx = (unsigned)((nchunks + 255) / 256);
+    if (gx > RESLOSS_SLOTS) return PERCNN_PI_ETOOLARGE;
+    unsigned gy = RESLOSS_SLOTS / gx;
+    if (gy > (unsigned)nframes) gy = (unsigned)nframes;
+    auto st = static_cast<hipStream_t>(stream);
+    double* partials = static_cast<double*>(ws);
+    const pi::ResLoss rl{resloss_scale(p, ndim, shape, nframes, weighted), nullptr, weighted};
+    constexpr int V = pi::vec_width<T>::value;
+#define PI_RSQ(NDIM, VEC) hipLaunchKernelGGL((pi::pi_residual_sq_kernel<T, NDIM, VEC, false>), dim3(gx, gy), dim3(256), 0, st, \
+                                             traj, (T*)nullptr, partials, Q, g, nframes, rl)
+    if (ndim == 2) { if (vec == 1) PI_RSQ(2, 1); else PI_RSQ(2, V); }
+    else           { if (vec == 1) PI_RSQ(3, 1); else PI_RSQ(3, V); }
+#undef PI_RSQ
+    hipLaunchKernelGGL((pi::pi_sqerr_finish_kernel<T>), dim3(1), dim3(64), 0, st, partials, (int)(gx * gy), rl.scale, loss_out);
+    return (int)hipGetLastError();
+}
+
+// g_traj[0 .. nout) = g_loss * dL/dtraj for L over the residuals of frames 0 .. nframes-1 (nout >= nframes + 1; frames past
+// nframes are zeroed).  scratch: nframes frames (the scaled residual G).  Two launches.
+template <typename T>
+int residual_sqloss_bwd_impl(const T* traj, const T* g_loss, const T* Q, int ndim, const int64_t* shape, int nframes, int nout,
+                             int weighted, T* scratch, T* g_traj, void* stream)
+{
+    Problem p;
+    if (int rc = make_problem(0, ndim, shape, false, p)) return rc;
+    if (!traj || !Q || !scratch || !g_traj || nframes < 1 || nout < nframes + 1 || nout > 65535) return PERCNN_PI_EINVAL;
+    const Geom g = make_geom(p);
+    const int vec = pick_vec<T>(p, {traj, scratch, g_traj});
+    const long nchunks = (long)g.rows * (g.W / vec);
+    const unsigned gx = (unsigned)((nchunks + 255) / 256);
+    auto st = static_cast<hipStream_t>(stream);
+    const pi::ResLoss rl{resloss_scale(p, ndim, shape, nframes, weighted), g_loss, weighted};
+    constexpr int V = pi::vec_width<T>::value;
+#define PI_RSB(NDIM, VEC)                                                                                                   \
+    do {                                                                                                                    \
+        hipLaunchKernelGGL((pi::pi_residual_sq_kernel<T, NDIM, VEC, true>), dim3(gx, (unsigned)nframes), dim3(256), 0, st,  \
+                           traj, scratch, (double*)nullptr, Q, g, nframes, rl);                                             \
+        hipLaunchKernelGGL((pi::pi_residual_adj_kernel<T, NDIM, VEC, true>), dim3(gx, (unsigned)nout), dim3(256), 0, st,    \
+                           traj, (const T*)scratch, g_traj, Q, g, nframes);                                                 \
+    } while (0)
+    if (ndim == 2) { if (vec == 1) PI_RSB(2, 1); else PI_RSB(2, V); }
+    else           { if (vec == 1) PI_RSB(3, 1); else PI_RSB(3, V); }
+#undef PI_RSB
     return (int)hipGetLastError();
 }
 
@@ -1936,7 +2010,7 @@ namespace {
 // rules, evaluated for 16-byte-aligned buffers (bench.py labels its roofline entries with it instead of mirroring the rules).
 // out = {forward family, adjoint family, gradients reduced inside the sweep launches (0 / 1), time steps per forward launch,
 //        per adjoint launch, planes per pass forward, adjoint, lanes per brick workgroup (0: no bricks), 2D tile width,
-//        height, lanes per tile workgroup (0: no tiles)}; families: 0 direct, 1 2D tiles, 2 plane streaming, 3 3D bricks,
+//        height, lanes per tile workgroup of the adjoint (0: no tiles), the same three of the forward}; families: 0 direct, 1 2D tiles, 2 plane streaming, 3 3D bricks,
 //        4 advective block
 template <typename T>
 int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options, int* out)
@@ -1968,12 +2042,14 @@ int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options,
     out[3] = out[0] == 1 ? K : 1;
     out[4] = out[1] == 1 ? K : 1;
     out[7] = (out[0] == 3 || out[1] == 3) ? brick_nt_for(p, vec) : 0;     // lanes per brick workgroup
-    out[8] = out[9] = out[10] = 0;
-    if (out[0] == 1 || out[1] == 1) {                                      // 2D tiles: width, height, lanes per workgroup
-        const TileShape ts = tile_shape_for<T>(p);
-        out[8] = ts.bx; out[9] = ts.by;
-        out[10] = ts.nt ? ts.nt : (p.opt.tile_k == 2 ? 256 : (p.hc == 0 && p.opt.tile_k == 8) ? 1024 : (p.hc == 0 && p.opt.tile_nt == 1024) ? 1024 :
-                                   (p.hc == 0 && ts.by == 16) ? 320 : (p.hc == 0 && ts.by == 8) ? 256 : p.opt.tile_nt == 256 ? 256 : 512);
+    for (int i = 8; i < 14; ++i) out[i] = 0;
+    for (int dir = 0; dir < 2; ++dir) {                                    // 2D tiles: width, height, lanes per workgroup
+        if (out[dir] != 1) continue;
+        const TileShape ts = tile_shape_for<T>(p, dir == 1);
+        int* o = out + (dir == 1 ? 8 : 11);
+        o[0] = ts.bx; o[1] = ts.by;
+        o[2] = ts.nt ? ts.nt : (p.opt.tile_k == 2 ? 256 : (p.hc == 0 && p.opt.tile_k == 8) ? 1024 : (p.hc == 0 && p.opt.tile_nt == 1024) ? 1024 :
+                                (p.hc == 0 && ts.by == 16) ? 320 : (p.hc == 0 && ts.by == 8) ? 256 : p.opt.tile_nt == 256 ? 256 : 512);
     }
     return 0;
 }
@@ -2250,5 +2326,22 @@ PI_EXPORT_LOSS(f64, double)
 
 PI_EXPORT_RES(f32, float)
 PI_EXPORT_RES(f64, double)
+
+size_t percnn_pi_residual_sqloss_workspace_bytes(void) { return RESLOSS_SLOTS * sizeof(double); }
+
+#define PI_EXPORT_RESLOSS(SUF, T)                                                                                   \
+    int percnn_pi_residual_sqloss_##SUF(const T* traj, const T* params, int ndim, const int64_t* shape, int nframes, \
+                                        int weighted, T* loss_out, void* workspace, size_t workspace_bytes,         \
+                                        void* stream)                                                               \
+    { return residual_sqloss_impl<T>(traj, params, ndim, shape, nframes, weighted, loss_out, workspace,             \
+                                     workspace_bytes, stream); }                                                    \
+    int percnn_pi_residual_sqloss_bwd_##SUF(const T* traj, const T* g_loss, const T* params, int ndim,              \
+                                            const int64_t* shape, int nframes, int nout_frames, int weighted,       \
+                                            T* scratch, T* g_traj, void* stream)                                    \
+    { return residual_sqloss_bwd_impl<T>(traj, g_loss, params, ndim, shape, nframes, nout_frames, weighted, scratch, \
+                                         g_traj, stream); }
+
+PI_EXPORT_RESLOSS(f32, float)
+PI_EXPORT_RESLOSS(f64, double)
 
 }  // extern "C"

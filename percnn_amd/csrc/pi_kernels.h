@@ -965,12 +965,111 @@ pi_residual_kernel(const T* __restrict__ traj, T* __restrict__ R, const T* __res
     }
 }
 
+// The residual LOSS without a materialised residual (round 3; reference: loss_gen, train_2drd.py:340-353, percnn_LO_eqn.py:
+// 343-357 -- MSE of f_u plus MSE of f_v).  The reference pads 2 cells low / 3 high, i.e. it evaluates on an (N+1)^d grid in which
+// index 0 of every axis appears twice: weight w(x) = 2^(number of zero coordinates) (ResLoss::weighted), else 1.
+//   GRAD = false: partials[block] = sum over this block's chunks and its frames f = blockIdx.y, += gridDim.y of w * R^2 (double)
+//   GRAD = true : G(f, x) = a * w * R(f, x),  a = 2 * scale * (upstream gradient, read from the device) -- what
+//                 pi_residual_adj_kernel<FULL> turns into dL/dtraj
+struct ResLoss {
+    double scale;          // 1 / (frames * prod(n + 1))  (weighted)  or  1 / (frames * prod(n))
+    const void* g_dev;     // GRAD: device pointer to the upstream scalar gradient in the compute type (nullptr = 1)
+    int weighted;
+};
+
+template <typename T, int NDIM, int VEC, bool GRAD>
+__global__ void __launch_bounds__(256)
+pi_residual_sq_kernel(const T* __restrict__ traj, T* __restrict__ G, double* __restrict__ partials,
+                      const T* __restrict__ Q, Geom g, int nframes, ResLoss rl)
+{
+    __shared__ double red[256 / WAVE];
+    const int cpr = g.W / VEC;
+    const long nchunks = (long)g.rows * cpr;
+    const long cid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = cid < nchunks;
+    int i0 = 0, i1 = 0, x0 = 0;
+    long e = 0;
+    if (live) chunk_coords<NDIM>(g, cid, cpr, VEC, i0, i1, x0, e);
+    const long frame = 2 * g.ss;
+    const T dt = Q[P_DT];
+    const T wrow = rl.weighted ? T((i0 == 0 ? 2 : 1) * ((NDIM == 3 && i1 == 0) ? 2 : 1)) : T(1);
+    T a = T(1);
+    if constexpr (GRAD) a = (T)(2.0 * rl.scale) * (rl.g_dev ? *static_cast<const T*>(rl.g_dev) : T(1));
+    double acc = 0.0;
+    for (int f = blockIdx.y; f < nframes && live; f += gridDim.y) {
+        const T* h = traj + (long)f * frame;
+        const T* hn = h + frame;
+        const Pack<T, VEC> cu = ld<T, VEC>(h + e), cv = ld<T, VEC>(h + g.ss + e);
+        T lap[2][VEC];
+        star<T, NDIM, VEC, +1>(h, Q, g, i0, i1, x0, e, cu, lap[0]);
+        star<T, NDIM, VEC, +1>(h + g.ss, Q, g, i0, i1, x0, e, cv, lap[1]);
+        T part = T(0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const Pack<T, VEC> nx = ld<T, VEC>(hn + s * g.ss + e);
+            const T* c = Q + P_W + 10 * s;
+            Pack<T, VEC> o;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const T hs = s == 0 ? cu.v[i] : cv.v[i];
+                const T rhs = Q[P_COEF + s] * lap[s][i] + poly_r(c, cu.v[i], cv.v[i]);
+                const T r = rhs - (nx.v[i] - hs) / dt;                     // the residual, as pi_residual_kernel forms it
+                const T w = (rl.weighted && x0 + i == 0) ? wrow * T(2) : wrow;
+                if constexpr (GRAD) o.v[i] = (a * w) * r;
+                else part = fma_(w * r, r, part);
+            }
+            if constexpr (GRAD) st<T, VEC>(G + (long)f * frame + s * g.ss + e, o);
+        }
+        acc += (double)part;
+    }
+    if constexpr (!GRAD) {
+        acc = wave_sum_to_last(acc);
+        if (threadIdx.x % WAVE == REDUCE_LANE) red[threadIdx.x / WAVE] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < 256 / WAVE; ++w) t += red[w];
+            partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = t;
+        }
+    }
+}
+
 // (dR_f/dh_f)^T G  =  coef * LapT(G) + J_r(h_f)^T G + G / dt        (the -G/dt part w.r.t. h_{f+1} is pointwise)
-template <typename T, int NDIM, int VEC>
+// FULL: `out` has nout >= nframes + 1 frames and is written completely -- frame f < nframes as above minus G_{f-1} / dt
+// (the pointwise part of step f - 1), frame nframes = -G_{nframes-1} / dt, later frames zero: dL/dtraj of a loss over
+// R_0 .. R_{nframes-1} in ONE launch (was: zero-fill, this kernel, a full-trajectory division and a subtraction).
+template <typename T, int NDIM, int VEC, bool FULL = false>
 __global__ void __launch_bounds__(256)
 pi_residual_adj_kernel(const T* __restrict__ traj, const T* __restrict__ G, T* __restrict__ out,
-                       const T* __restrict__ Q, Geom g)
+                       const T* __restrict__ Q, Geom g, int nframes = 0)
 {
+    if constexpr (FULL) {
+        const int f = blockIdx.y;
+        if (f >= nframes) {
+            const int cprF = g.W / VEC;
+            const long cidF = (long)blockIdx.x * blockDim.x + threadIdx.x;
+            if (cidF >= (long)g.rows * cprF) return;
+            int j0, j1, y0;
+            long eF;
+            chunk_coords<NDIM>(g, cidF, cprF, VEC, j0, j1, y0, eF);
+            const long frameF = 2 * g.ss;
+            const T dtF = Q[P_DT];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                Pack<T, VEC> o;
+                if (f == nframes) {
+                    const Pack<T, VEC> gp = ld<T, VEC>(G + (long)(f - 1) * frameF + s * g.ss + eF);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) o.v[i] = T(0) - gp.v[i] / dtF;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) o.v[i] = T(0);
+                }
+                st<T, VEC>(out + (long)f * frameF + s * g.ss + eF, o);
+            }
+            return;
+        }
+    }
     const int cpr = g.W / VEC;
     const long nchunks = (long)g.rows * cpr;
     const long cid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -995,6 +1094,16 @@ pi_residual_adj_kernel(const T* __restrict__ traj, const T* __restrict__ G, T* _
         poly_dr(Q + P_W + 10, u.v[i], v.v[i], rvu, rvv);
         ou.v[i] = fma_(Q[P_COEF + 0], lg[0][i], fma_(gu.v[i], ruu, gv.v[i] * rvu)) + gu.v[i] / dt;
         ov.v[i] = fma_(Q[P_COEF + 1], lg[1][i], fma_(gu.v[i], ruv, gv.v[i] * rvv)) + gv.v[i] / dt;
+    }
+    if constexpr (FULL) {
+        if (blockIdx.y > 0) {
+            const Pack<T, VEC> pu = ld<T, VEC>(Gf - frame + e), pv = ld<T, VEC>(Gf - frame + g.ss + e);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                ou.v[i] -= pu.v[i] / dt;
+                ov.v[i] -= pv.v[i] / dt;
+            }
+        }
     }
     st<T, VEC>(out + (long)blockIdx.y * frame + e, ou);
     st<T, VEC>(out + (long)blockIdx.y * frame + g.ss + e, ov);

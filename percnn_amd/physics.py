@@ -87,15 +87,60 @@ class PhysicsResidualFunction(torch.autograd.Function):
         return g, None
 
 
+class PhysicsLossFunction(torch.autograd.Function):
+    """output [F+2, 2, *S] (a rollout incl. its last frame, which ``loss_gen`` drops) -> the scalar residual loss over frames
+    0 .. F-1, as ONE node: the forward is one reducing pass over the trajectory (no residual tensor), the backward two launches
+    that write dL/d output completely (``percnn_pi_residual_sqloss_*``).  The expression it replaces -- residual, square, two
+    weight multiplies, two sums, and autograd's mirror image of them, then zero-fill / adjoint / divide / subtract -- moved
+    ~20x the trajectory's bytes: lambda-omega 512^2 x 400 spent 13 of its 16 ms per training iteration there."""
+
+    @staticmethod
+    def forward(ctx, output, Q, nres, weighted):
+        F_pi._require(output, "output"); F_pi._require(Q, "pde block", output.dtype)
+        if Q.numel() != F_pi.NPOLY:
+            raise RuntimeError("percnn_amd: the physics residual takes a 36-entry pre-contracted equation block")
+        if nres < 1 or output.shape[0] < nres + 1:
+            raise RuntimeError("percnn_amd: the residual of frame f needs frame f + 1")
+        L = _lib.lib()
+        ws = torch.empty(L.percnn_pi_residual_sqloss_workspace_bytes() // 8, dtype=torch.float64, device=output.device)
+        loss = torch.empty((), dtype=output.dtype, device=output.device)
+        shape = output.shape[2:]
+        f = getattr(L, "percnn_pi_residual_sqloss_" + F_pi._SUF[output.dtype])
+        with torch.cuda.device(output.device):
+            _lib.check(f(output.data_ptr(), Q.data_ptr(), len(shape), _lib.shape_arg(shape), int(nres), int(bool(weighted)),
+                         loss.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "residual_sqloss")
+        ctx.save_for_backward(output, Q)
+        ctx.nres, ctx.weighted = int(nres), bool(weighted)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        output, Q = ctx.saved_tensors
+        gl = gl.to(output.dtype).contiguous()
+        shape = output.shape[2:]
+        scratch = torch.empty((ctx.nres,) + tuple(output.shape[1:]), dtype=output.dtype, device=output.device)
+        g = torch.empty_like(output)
+        f = getattr(_lib.lib(), "percnn_pi_residual_sqloss_bwd_" + F_pi._SUF[output.dtype])
+        with torch.cuda.device(output.device):
+            _lib.check(f(output.data_ptr(), gl.data_ptr(), Q.data_ptr(), len(shape), _lib.shape_arg(shape), ctx.nres,
+                         output.shape[0], int(ctx.weighted), scratch.data_ptr(), g.data_ptr(),
+                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "residual_sqloss_bwd")
+        return g, None, None, None
+
+
 def physics_residual(traj: torch.Tensor, Q: torch.Tensor) -> torch.Tensor:
     return PhysicsResidualFunction.apply(traj.contiguous(), Q)
 
 
-def physics_loss(output: torch.Tensor, Q: torch.Tensor, reference_weighting: bool = True) -> torch.Tensor:
+def physics_loss(output: torch.Tensor, Q: torch.Tensor, reference_weighting: bool = True, fused: bool = True) -> torch.Tensor:
     """Drop-in for ``loss_gen(output, loss_func)`` (train_2drd.py:340-353): MSE of f_u plus MSE of f_v over
     frames ``output[0:-2]``.  The reference pads 2 cells on the low and 3 on the high side, so it evaluates
     the residual on an (N+1)^d grid in which the first row / column / plane appears twice;
-    ``reference_weighting`` reproduces that weighting exactly (False: plain mean over the periodic grid)."""
+    ``reference_weighting`` reproduces that weighting exactly (False: plain mean over the periodic grid).
+    One autograd node (``PhysicsLossFunction``); ``fused=False`` keeps the residual-tensor expression (tests compare the two)."""
+    if fused and output.is_cuda and output.shape[0] >= 3 and output.shape[0] <= 65535:
+        return PhysicsLossFunction.apply(output.contiguous(), Q, output.shape[0] - 2, reference_weighting)
     R = physics_residual(output[:-1], Q)              # frames 0 .. len-3
     sq = R * R
     if reference_weighting:

@@ -1078,6 +1078,19 @@ def test_physics_loss_vs_reference(fn, hip_device):
     # plain periodic mean (no duplicated first row/column) is a different, slightly smaller weighting
     plain = physics.physics_loss(out.detach(), Q, reference_weighting=False)
     assert torch.isfinite(plain) and plain.item() > 0
+    # the one-node loss (no residual tensor, dL/dtraj written by two launches) == the residual-tensor expression it replaced
+    tol = 2e-6 if g.dtype == np.float32 else 1e-12
+    for weighted in (True, False):
+        a = out.detach().clone().requires_grad_(True)
+        b = out.detach().clone().requires_grad_(True)
+        la = physics.physics_loss(a, Q, reference_weighting=weighted)
+        lb = physics.physics_loss(b, Q, reference_weighting=weighted, fused=False)
+        assert type(la.grad_fn).__name__ == "PhysicsLossFunctionBackward" and la.shape == lb.shape == ()
+        assert abs(la.item() - lb.item()) <= tol * abs(lb.item())
+        (3.0 * la).backward()
+        (3.0 * lb).backward()
+        assert a.grad.shape == b.grad.shape and not a.grad[-1].any()       # loss_gen drops the last frame
+        assert rel_l2(a.grad.cpu().numpy(), b.grad.cpu().numpy()) < 10 * tol
 
 
 def test_physics_residual_gradcheck_fp64(hip_device):
@@ -1091,6 +1104,13 @@ def test_physics_residual_gradcheck_fp64(hip_device):
     Q3 = physics.gray_scott_block(cell3, 0.2, 0.1, 0.025, 0.055)
     traj3 = torch.rand((3, 2, 4, 6, 4), dtype=torch.float64, device=hip_device, requires_grad=True)
     assert torch.autograd.gradcheck(lambda t: physics.physics_residual(t, Q3), (traj3,), eps=1e-6, atol=1e-6, rtol=1e-5)
+    # the fused loss node: both weightings, 2D / 3D, a width the 16-byte lanes do not divide (6)
+    for weighted in (True, False):
+        assert torch.autograd.gradcheck(lambda t: physics.physics_loss(t, Q, weighted), (traj,), eps=1e-6, atol=1e-7, rtol=1e-5)
+        assert torch.autograd.gradcheck(lambda t: physics.physics_loss(t, Q3, weighted), (traj3,), eps=1e-6, atol=1e-7, rtol=1e-5)
+        odd = torch.rand((5, 2, 7, 6), dtype=torch.float64, device=hip_device, requires_grad=True)
+        assert torch.autograd.gradcheck(lambda t: physics.physics_loss(t, Q, weighted), (odd,), eps=1e-6, atol=1e-7, rtol=1e-5)
+        assert torch.allclose(physics.physics_loss(odd, Q, weighted), physics.physics_loss(odd, Q, weighted, fused=False), rtol=1e-12)
 
 
 # ---------------------------------------------------------------------------------------------
