@@ -1690,6 +1690,12 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
 
 
 // ---- physics residual over a trajectory (time-parallel; pre-contracted block of the TRUE equation) ----
+pi::FrameGrid make_frame_grid(long nchunks, unsigned frame_slots)
+{
+    const unsigned gx = (unsigned)((nchunks + 255) / 256);
+    return pi::FrameGrid{gx, frame_slots, (gx + pi::NXCD - 1) / pi::NXCD};
+}
+
 template <typename T, bool ADJ>
 int residual_impl(const T* traj, const T* G, T* out, const T* Q, int ndim, const int64_t* shape, int nframes, void* stream)
 {
@@ -1700,13 +1706,14 @@ int residual_impl(const T* traj, const T* G, T* out, const T* Q, int ndim, const
     const Geom g = make_geom(p);
     const int vec = pick_vec<T>(p, {traj, G, out});
     const long nchunks = (long)g.rows * (g.W / vec);
-    const dim3 grid((unsigned)((nchunks + 255) / 256), (unsigned)nframes), block(256);
+    const pi::FrameGrid fg = make_frame_grid(nchunks, (unsigned)nframes);
+    const dim3 grid(pi::frame_grid_blocks(fg)), block(256);
     auto st = static_cast<hipStream_t>(stream);
     constexpr int V = pi::vec_width<T>::value;
 #define PI_RES(NDIM, VEC)                                                                                      \
     do {                                                                                                       \
-        if constexpr (ADJ) hipLaunchKernelGGL((pi::pi_residual_adj_kernel<T, NDIM, VEC>), grid, block, 0, st, traj, G, out, Q, g); \
-        else hipLaunchKernelGGL((pi::pi_residual_kernel<T, NDIM, VEC>), grid, block, 0, st, traj, out, Q, g);    \
+        if constexpr (ADJ) hipLaunchKernelGGL((pi::pi_residual_adj_kernel<T, NDIM, VEC>), grid, block, 0, st, traj, G, out, Q, g, fg, 0); \
+        else hipLaunchKernelGGL((pi::pi_residual_kernel<T, NDIM, VEC>), grid, block, 0, st, traj, out, Q, g, fg);    \
     } while (0)
     if (ndim == 2) { if (vec == 1) PI_RES(2, 1); else PI_RES(2, V); }
     else           { if (vec == 1) PI_RES(3, 1); else PI_RES(3, V); }
@@ -1741,12 +1748,13 @@ int residual_sqloss_impl(const T* traj, const T* Q, int ndim, const int64_t* sha
     if (gx > RESLOSS_SLOTS) return PERCNN_PI_ETOOLARGE;
     unsigned gy = RESLOSS_SLOTS / gx;
     if (gy > (unsigned)nframes) gy = (unsigned)nframes;
+    const pi::FrameGrid fg = make_frame_grid(nchunks, gy);
     auto st = static_cast<hipStream_t>(stream);
     double* partials = static_cast<double*>(ws);
     const pi::ResLoss rl{resloss_scale(p, ndim, shape, nframes, weighted), nullptr, weighted};
     constexpr int V = pi::vec_width<T>::value;
-#define PI_RSQ(NDIM, VEC) hipLaunchKernelGGL((pi::pi_residual_sq_kernel<T, NDIM, VEC, false>), dim3(gx, gy), dim3(256), 0, st, \
-                                             traj, (T*)nullptr, partials, Q, g, nframes, rl)
+#define PI_RSQ(NDIM, VEC) hipLaunchKernelGGL((pi::pi_residual_sq_kernel<T, NDIM, VEC, false>), dim3(pi::frame_grid_blocks(fg)), \
+                                             dim3(256), 0, st, traj, (T*)nullptr, partials, Q, g, nframes, rl, fg)
     if (ndim == 2) { if (vec == 1) PI_RSQ(2, 1); else PI_RSQ(2, V); }
     else           { if (vec == 1) PI_RSQ(3, 1); else PI_RSQ(3, V); }
 #undef PI_RSQ
@@ -1766,16 +1774,16 @@ int residual_sqloss_bwd_impl(const T* traj, const T* g_loss, const T* Q, int ndi
     const Geom g = make_geom(p);
     const int vec = pick_vec<T>(p, {traj, scratch, g_traj});
     const long nchunks = (long)g.rows * (g.W / vec);
-    const unsigned gx = (unsigned)((nchunks + 255) / 256);
+    const pi::FrameGrid fg1 = make_frame_grid(nchunks, (unsigned)nframes), fg2 = make_frame_grid(nchunks, (unsigned)nout);
     auto st = static_cast<hipStream_t>(stream);
     const pi::ResLoss rl{resloss_scale(p, ndim, shape, nframes, weighted), g_loss, weighted};
     constexpr int V = pi::vec_width<T>::value;
 #define PI_RSB(NDIM, VEC)                                                                                                   \
     do {                                                                                                                    \
-        hipLaunchKernelGGL((pi::pi_residual_sq_kernel<T, NDIM, VEC, true>), dim3(gx, (unsigned)nframes), dim3(256), 0, st,  \
-                           traj, scratch, (double*)nullptr, Q, g, nframes, rl);                                             \
-        hipLaunchKernelGGL((pi::pi_residual_adj_kernel<T, NDIM, VEC, true>), dim3(gx, (unsigned)nout), dim3(256), 0, st,    \
-                           traj, (const T*)scratch, g_traj, Q, g, nframes);                                                 \
+        hipLaunchKernelGGL((pi::pi_residual_sq_kernel<T, NDIM, VEC, true>), dim3(pi::frame_grid_blocks(fg1)), dim3(256), 0, \
+                           st, traj, scratch, (double*)nullptr, Q, g, nframes, rl, fg1);                                    \
+        hipLaunchKernelGGL((pi::pi_residual_adj_kernel<T, NDIM, VEC, true>), dim3(pi::frame_grid_blocks(fg2)), dim3(256),   \
+                           0, st, traj, (const T*)scratch, g_traj, Q, g, fg2, nframes);                                     \
     } while (0)
     if (ndim == 2) { if (vec == 1) PI_RSB(2, 1); else PI_RSB(2, V); }
     else           { if (vec == 1) PI_RSB(3, 1); else PI_RSB(3, V); }

@@ -923,6 +923,21 @@ pi_moments_kernel(const T* __restrict__ traj, const T* __restrict__ adj, double*
     }
 }
 
+// Frame-parallel launches (grid = chunk blocks x frames), XCD-aware: workgroup b runs on XCD b % 8, and with the plain
+// (blockIdx.x, blockIdx.y) = (chunk block, frame) grid the 8 XCDs interleave the ROWS of a frame -- every XCD's L2 then fetches
+// the four neighbour rows of each of its rows from the fabric itself (5x the algorithmic reads: the lambda-omega 512^2 loss
+// pass ran at 1.1 TB/s).  Here the launch is 1-D, XCD x owns the contiguous chunk blocks [x * per, (x + 1) * per) of EVERY frame
+// (per = ceil(gx / 8)) and walks them frame by frame: neighbour rows come from the XCD's own L2 except at its two seams.
+struct FrameGrid { unsigned gx, gy, per; };          // chunk blocks per frame, frame slots, chunk blocks per frame and XCD
+__host__ __device__ inline unsigned frame_grid_blocks(const FrameGrid& fg) { return NXCD * fg.per * fg.gy; }
+struct FrameBlock { unsigned bx, by; bool live; };
+__device__ __forceinline__ FrameBlock frame_block(const FrameGrid& fg)
+{
+    const unsigned b = blockIdx.x, x = b % NXCD, j = b / NXCD;
+    const unsigned by = j / fg.per, bx = x * fg.per + (j - by * fg.per);
+    return FrameBlock{bx, by, bx < fg.gx};
+}
+
 // ---------------------------------------------------------------------------------------------
 // physics residual of a polynomial reaction-diffusion equation over a whole trajectory, time-parallel
 // (reference: loss_generator.get_phy_Loss, train_2drd.py:270-329, train_3drd.py:287-323,
@@ -933,17 +948,18 @@ pi_moments_kernel(const T* __restrict__ traj, const T* __restrict__ adj, double*
 // ---------------------------------------------------------------------------------------------
 template <typename T, int NDIM, int VEC>
 __global__ void __launch_bounds__(256)
-pi_residual_kernel(const T* __restrict__ traj, T* __restrict__ R, const T* __restrict__ Q, Geom g)
+pi_residual_kernel(const T* __restrict__ traj, T* __restrict__ R, const T* __restrict__ Q, Geom g, FrameGrid fg)
 {
+    const FrameBlock fb = frame_block(fg);
     const int cpr = g.W / VEC;
     const long nchunks = (long)g.rows * cpr;
-    const long cid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (cid >= nchunks) return;
+    const long cid = (long)fb.bx * blockDim.x + threadIdx.x;
+    if (!fb.live || cid >= nchunks) return;
     int i0, i1, x0;
     long e;
     chunk_coords<NDIM>(g, cid, cpr, VEC, i0, i1, x0, e);
     const long frame = 2 * g.ss;
-    const T* h = traj + (long)blockIdx.y * frame;
+    const T* h = traj + (long)fb.by * frame;
     const T* hn = h + frame;
     const Pack<T, VEC> cu = ld<T, VEC>(h + e), cv = ld<T, VEC>(h + g.ss + e);
     T lap[2][VEC];
@@ -961,7 +977,7 @@ pi_residual_kernel(const T* __restrict__ traj, T* __restrict__ R, const T* __res
             const T rhs = Q[P_COEF + s] * lap[s][i] + poly_r(c, cu.v[i], cv.v[i]);
             o.v[i] = rhs - (nx.v[i] - hs) / dt;
         }
-        st<T, VEC>(R + (long)blockIdx.y * frame + s * g.ss + e, o);
+        st<T, VEC>(R + (long)fb.by * frame + s * g.ss + e, o);
     }
 }
 
@@ -980,12 +996,14 @@ struct ResLoss {
 template <typename T, int NDIM, int VEC, bool GRAD>
 __global__ void __launch_bounds__(256)
 pi_residual_sq_kernel(const T* __restrict__ traj, T* __restrict__ G, double* __restrict__ partials,
-                      const T* __restrict__ Q, Geom g, int nframes, ResLoss rl)
+                      const T* __restrict__ Q, Geom g, int nframes, ResLoss rl, FrameGrid fg)
 {
     __shared__ double red[256 / WAVE];
+    const FrameBlock fb = frame_block(fg);
+    if (!fb.live) return;
     const int cpr = g.W / VEC;
     const long nchunks = (long)g.rows * cpr;
-    const long cid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long cid = (long)fb.bx * blockDim.x + threadIdx.x;
     const bool live = cid < nchunks;
     int i0 = 0, i1 = 0, x0 = 0;
     long e = 0;
@@ -996,7 +1014,7 @@ pi_residual_sq_kernel(const T* __restrict__ traj, T* __restrict__ G, double* __r
     T a = T(1);
     if constexpr (GRAD) a = (T)(2.0 * rl.scale) * (rl.g_dev ? *static_cast<const T*>(rl.g_dev) : T(1));
     double acc = 0.0;
-    for (int f = blockIdx.y; f < nframes && live; f += gridDim.y) {
+    for (int f = (int)fb.by; f < nframes && live; f += (int)fg.gy) {
         const T* h = traj + (long)f * frame;
         const T* hn = h + frame;
         const Pack<T, VEC> cu = ld<T, VEC>(h + e), cv = ld<T, VEC>(h + g.ss + e);
@@ -1029,7 +1047,7 @@ pi_residual_sq_kernel(const T* __restrict__ traj, T* __restrict__ G, double* __r
         if (threadIdx.x == 0) {
             double t = 0.0;
             for (int w = 0; w < 256 / WAVE; ++w) t += red[w];
-            partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = t;
+            partials[(long)fb.by * fg.gx + fb.bx] = t;
         }
     }
 }
@@ -1041,13 +1059,15 @@ pi_residual_sq_kernel(const T* __restrict__ traj, T* __restrict__ G, double* __r
 template <typename T, int NDIM, int VEC, bool FULL = false>
 __global__ void __launch_bounds__(256)
 pi_residual_adj_kernel(const T* __restrict__ traj, const T* __restrict__ G, T* __restrict__ out,
-                       const T* __restrict__ Q, Geom g, int nframes = 0)
+                       const T* __restrict__ Q, Geom g, FrameGrid fg, int nframes = 0)
 {
+    const FrameBlock fb = frame_block(fg);
+    if (!fb.live) return;
     if constexpr (FULL) {
-        const int f = blockIdx.y;
+        const int f = (int)fb.by;
         if (f >= nframes) {
             const int cprF = g.W / VEC;
-            const long cidF = (long)blockIdx.x * blockDim.x + threadIdx.x;
+            const long cidF = (long)fb.bx * blockDim.x + threadIdx.x;
             if (cidF >= (long)g.rows * cprF) return;
             int j0, j1, y0;
             long eF;
@@ -1072,14 +1092,14 @@ pi_residual_adj_kernel(const T* __restrict__ traj, const T* __restrict__ G, T* _
     }
     const int cpr = g.W / VEC;
     const long nchunks = (long)g.rows * cpr;
-    const long cid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long cid = (long)fb.bx * blockDim.x + threadIdx.x;
     if (cid >= nchunks) return;
     int i0, i1, x0;
     long e;
     chunk_coords<NDIM>(g, cid, cpr, VEC, i0, i1, x0, e);
     const long frame = 2 * g.ss;
-    const T* h = traj + (long)blockIdx.y * frame;
-    const T* Gf = G + (long)blockIdx.y * frame;
+    const T* h = traj + (long)fb.by * frame;
+    const T* Gf = G + (long)fb.by * frame;
     const Pack<T, VEC> u = ld<T, VEC>(h + e), v = ld<T, VEC>(h + g.ss + e);
     const Pack<T, VEC> gu = ld<T, VEC>(Gf + e), gv = ld<T, VEC>(Gf + g.ss + e);
     T lg[2][VEC];
@@ -1096,7 +1116,7 @@ pi_residual_adj_kernel(const T* __restrict__ traj, const T* __restrict__ G, T* _
         ov.v[i] = fma_(Q[P_COEF + 1], lg[1][i], fma_(gu.v[i], ruv, gv.v[i] * rvv)) + gv.v[i] / dt;
     }
     if constexpr (FULL) {
-        if (blockIdx.y > 0) {
+        if (fb.by > 0) {
             const Pack<T, VEC> pu = ld<T, VEC>(Gf - frame + e), pv = ld<T, VEC>(Gf - frame + g.ss + e);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
@@ -1105,8 +1125,8 @@ pi_residual_adj_kernel(const T* __restrict__ traj, const T* __restrict__ G, T* _
             }
         }
     }
-    st<T, VEC>(out + (long)blockIdx.y * frame + e, ou);
-    st<T, VEC>(out + (long)blockIdx.y * frame + g.ss + e, ov);
+    st<T, VEC>(out + (long)fb.by * frame + e, ou);
+    st<T, VEC>(out + (long)fb.by * frame + g.ss + e, ov);
 }
 
 // ---------------------------------------------------------------------------------------------
