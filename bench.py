@@ -321,15 +321,19 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
     for key, fn in (("list_cat_dense_loss_ms", it_list), ("trajectory_dense_loss_ms", it_traj),
                     ("loss_mse_dense_ms", it_loss_mse), ("observe_strided_loss_ms", it_observe)):
         fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        e0.record()
-        for _ in range(reps):
+        marks[0].record()
+        for i in range(reps):
             fn()
-        e1.record()
+            marks[i + 1].record()
         torch.cuda.synchronize()
-        out[key] = {"gpu_ms": e0.elapsed_time(e1) / reps, "wall_ms": (time.perf_counter() - t0) / reps * 1e3}
+        per_it = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(reps))
+        # median of the iterations: the boxes show an occasional one-off stall of tens of ms (seen once on either side of an
+        # otherwise 6 ms iteration), which a mean over three would turn into the number
+        out[key] = {"gpu_ms": per_it[reps // 2], "gpu_ms_mean": marks[0].elapsed_time(marks[reps]) / reps,
+                    "wall_ms": (time.perf_counter() - t0) / reps * 1e3}
     out["what"] = (f"one training iteration through the drop-in modules at {'x'.join(map(str, shape))} x T={T}: RCNN.forward() "
                    "+ torch.cat + mean(traj^2) + backward; RCNN.trajectory() (torch.ops.percnn.pi_rollout, no list / cat) + the same loss; "
                    "RCNN.loss_mse() = the same dense loss as ONE autograd node with the rollout (gradient formed inside the sweep); "
@@ -397,18 +401,22 @@ def lo2d_physics_path_extra(pa, dev, reaction, reps=3):
 
     it()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(reps):
+    for i in range(reps):
         loss = it()
+        marks[i].record()
     e1.record()
     torch.cuda.synchronize()
-    return {"what": f"lambda-omega {shape[0]}x{shape[1]} float64, T={T}: RCNN.trajectory() + physics_loss + backward per iteration "
+    per_it = [([e0] + marks)[i].elapsed_time(marks[i]) for i in range(reps)]
+    med = sorted(per_it)[reps // 2]
+    return {"per_iteration_ms": per_it, "what": f"lambda-omega {shape[0]}x{shape[1]} float64, T={T}: RCNN.trajectory() + physics_loss + backward per iteration "
                     "(the loss of percnn_LO_eqn.py:371-373, in the gradient path; physics_loss = one autograd node since round 3, "
                     "the residual-tensor expression took 16.2 ms)",
-            "gpu_ms": e0.elapsed_time(e1) / reps, "wall_ms": (time.perf_counter() - t0) / reps * 1e3,
-            "time_steps_per_sec": T / (e0.elapsed_time(e1) / reps * 1e-3), "loss_value": float(loss)}
+            "gpu_ms": med, "gpu_ms_mean": e0.elapsed_time(e1) / reps, "wall_ms": (time.perf_counter() - t0) / reps * 1e3,
+            "time_steps_per_sec": T / (med * 1e-3), "loss_value": float(loss.detach())}
 
 
 def main():
