@@ -870,7 +870,7 @@ def _all_max(dist, dev, x):
 
 
 def sharded_rollout(dev, dist, rank, world, full_shape, T, halo, reps, transport, force_p2p, P, blocks_seed=0,
-                    breakdown=True):
+                    breakdown=True, overlap=None):
     """3D Gray-Scott, Hc=2, fp32: the global grid `full_shape` cut into `world` slabs along axis 0 (axis 0 must divide).
     Times T-step forward + backward rollouts of the slab path (barrier on both sides, max over ranks, median of `reps`),
     checks every rank's forward state bit for bit against the single-domain rollout of the whole grid, and -- breakdown --
@@ -895,7 +895,8 @@ def sharded_rollout(dev, dist, rank, world, full_shape, T, halo, reps, transport
             dist.barrier()
         torch.cuda.synchronize()
 
-    overlap = bool(int(os.environ.get("PERCNN_SLAB_OVERLAP", "0")))
+    if overlap is None:
+        overlap = bool(int(os.environ.get("PERCNN_SLAB_OVERLAP", "0")))
 
     def timed(fn, n):
         fn()
@@ -1061,6 +1062,13 @@ def sharded_series(dev, dist, rank, world, one_gpu, checkpoint=lambda res: None)
             out["strong_scaling"]["by_grid_peer"] = {}
             strong_on("peer", out["strong_scaling"]["by_grid_peer"])
             out["strong_scaling"]["transport_picked_by_probe"] = "peer"
+        checkpoint(out)
+    # ---- phase 3 (last: nothing above can be lost to it): the faces-first schedule on the proven transport -- faces of the
+    # frame about to be exchanged computed first, the exchange on a side stream under the interior planes.  On ONE GPU it costs
+    # more than it hides (three launches per step, 104 us to self); whether a real xGMI wire turns that around is for this
+    # line to say.
+    weak[base + "_faces_first_overlap"] = guarded(lambda: sharded_rollout(
+        dev, dist, rank, world, (planes * world, hw, hw), Tw, halo, reps, base, force_p2p, P, breakdown=False, overlap=True))
     return out
 
 
