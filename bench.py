@@ -837,6 +837,10 @@ def slab_extra_isolated(a, dev, dist, rank, world, local_rank):
     for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RESTART_COUNT",
               "TORCHELASTIC_MAX_RESTARTS", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME"):
         env.pop(k, None)                             # plain env:// rendezvous on the new port
+    # a mailbox exchange whose neighbour never delivers gives up after this many seconds (library default: 300) -- in a bench
+    # the ranks are in lock step, and a stuck exchange must end as "timed_out_exchange" in the line, not as a spinning kernel
+    # that the watchdog below has to kill
+    env.setdefault("PERCNN_PEER_TIMEOUT_S", "15")
     child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--slab-child", "--gpus", str(a.gpus)], env=env,
                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     timed_out = False
