@@ -1743,6 +1743,36 @@ int residual_sqloss_impl(const T* traj, const T* Q, int ndim, const int64_t* sha
     if (!ws || ws_bytes < RESLOSS_SLOTS * sizeof(double) || reinterpret_cast<uintptr_t>(ws) % 8) return PERCNN_PI_EWORKSPACE;
     const Geom g = make_geom(p);
     const int vec = pick_vec<T>(p, {traj});
+    auto st0 = static_cast<hipStream_t>(stream);
+    // 3D grids the brick kernels take: plane neighbours from a register window, in-plane neighbours from LDS (pi_brick3d.h)
+    if (ndim == 3 && p.opt.brick3d) {
+        const int brz = brick_rz_for<T>(p, vec, false);
+        if (brz == 1 || brz == 2) {
+            pi::BrickGeom b = make_brick_geom(p, pi::vec_width<T>::value, brz, pi::BRICK_NT, false);
+            if (b.nblk > 0 && b.nblk <= RESLOSS_SLOTS) {
+                unsigned gy = RESLOSS_SLOTS / b.nblk;
+                if (gy > (unsigned)nframes) gy = (unsigned)nframes;
+                if (gy > 65535u) gy = 65535u;
+                const size_t lds = (size_t)2 * brz * pi::brick_wb(pi::BRICK_NT);
+                const double scale = resloss_scale(p, ndim, shape, nframes, weighted);
+                double* partials = static_cast<double*>(ws);
+                const long frame = 2 * p.n;
+                hipError_t e = hipSuccess;
+                if (brz == 2) {
+                    auto* k = pi::pi_res3d_brick_kernel<T, 2>;
+                    e = allow_lds(k, lds);
+                    if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(b.nblk, gy), dim3(pi::BRICK_NT), lds, st0, traj, partials, Q, b, frame, nframes, weighted);
+                } else {
+                    auto* k = pi::pi_res3d_brick_kernel<T, 1>;
+                    e = allow_lds(k, lds);
+                    if (e == hipSuccess) hipLaunchKernelGGL(k, dim3(b.nblk, gy), dim3(pi::BRICK_NT), lds, st0, traj, partials, Q, b, frame, nframes, weighted);
+                }
+                if (e != hipSuccess) return (int)e;
+                hipLaunchKernelGGL((pi::pi_sqerr_finish_kernel<T>), dim3(1), dim3(64), 0, st0, partials, (int)(b.nblk * gy), scale, loss_out);
+                return (int)hipGetLastError();
+            }
+        }
+    }
     const long nchunks = (long)g.rows * (g.W / vec);
     const unsigned gx = (unsigned)((nchunks + 255) / 256);
     if (gx > RESLOSS_SLOTS) return PERCNN_PI_ETOOLARGE;

@@ -277,6 +277,90 @@ pi_fwd3d_brick_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __r
 }
 
 // ---------------------------------------------------------------------------------------------
+// physics-residual LOSS of a 3D trajectory on the brick machinery (pi_residual_sq_kernel<GRAD = false> is the generic flavour;
+// reference: loss_gen / get_phy_Loss, train_3drd.py:287-346): per frame f the residual
+//   R_s = coef_s * Lap(h_f)_s + r_s(h_f) - (h_{f+1,s} - h_{f,s}) / dt          (Q: pre-contracted block of the TRUE equation)
+// is formed exactly as the forward brick kernel forms `res` (same taps, same order: bit-identical to the generic kernel's R) and
+// w * R^2 is summed per workgroup in double; workgroup (x, y) walks frames y, y + gridDim.y, ... of brick x.
+// The generic kernel asks the vector L1 for 24 sixteen-byte pieces per chunk and frame (12x the bytes that reach HBM): 128^3,
+// 200 frames 2.7 ms = 0.15 of HBM; here the plane neighbours come from the register window and the in-plane ones from LDS.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int RZ, int NT = BRICK_NT>
+__global__ void __launch_bounds__(NT)
+pi_res3d_brick_kernel(const T* __restrict__ traj, double* __restrict__ partials, const T* __restrict__ Q, BrickGeom g,
+                      long frame_stride, int nframes, int weighted)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double red[NT / WAVE];
+    Brick<T, RZ, NT> B;
+    B.locate(g, blockIdx.x, gridDim.x, 0u);
+    Lane L;
+    L.i0 = B.i0; L.eb = B.eb;
+    Geom gg = brick_as_geom(g);
+    // weights of the reference's padded evaluation grid: index 0 of every axis counts twice
+    const unsigned idx = (unsigned)(B.cb + min((int)threadIdx.x, B.nown - 1));
+    const unsigned row = g.dcpr.div(idx), xc = idx - row * (unsigned)g.cpr;
+    const T wyx = weighted ? T(row == 0u ? 2 : 1) : T(1);
+    const T dt = Q[P_DT];
+    double acc = 0.0;
+    for (int f = (int)blockIdx.y; f < nframes; f += (int)gridDim.y) {
+        const T* h = traj + (long)f * frame_stride;
+        const T* hs[2] = {h + g.off, h + g.ss + g.off};
+        PlaneWindow<T, VEC, RZ> win[2];
+        win[0].load(hs[0], gg, L);
+        win[1].load(hs[1], gg, L);
+        B.request_halo(h, g, 0u);
+        Pack<T, VEC> nx[RZ][2];                              // the same chunk of frame f + 1: requested with the window
+#pragma unroll
+        for (int j = 0; j < RZ; ++j) {
+            const int iz = min(B.i0 + j, g.n0 - 1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                nx[j][s] = ldb<T, VEC>(sgpr_ptr(reinterpret_cast<const char*>(hs[s] + frame_stride + (long)iz * g.s0)), B.eb);
+        }
+        B.commit(smem_raw, win);
+        lds_barrier();
+        T part = T(0);
+#pragma unroll
+        for (int j = 0; j < RZ; ++j) {
+            const int iz = B.i0 + j;
+            if (iz >= g.n0) break;                           // partial last plane group (block-uniform)
+            const Pack<T, VEC> cu = win[0].w[j + 2], cv = win[1].w[j + 2];
+            T lap[2][VEC];
+            win[0].template planes<+1>(j, Q, lap[0]);
+            win[1].template planes<+1>(j, Q, lap[1]);
+            B.template inplane<+1>(smem_raw, 2 * j, Q, cu, lap[0]);
+            B.template inplane<+1>(smem_raw, 2 * j + 1, Q, cv, lap[1]);
+            const T wz = (weighted && iz == 0) ? wyx * T(2) : wyx;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const T* c = Q + P_W + 10 * s;
+                const T coef = Q[P_COEF + s];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const T hv = s == 0 ? cu.v[i] : cv.v[i];
+                    const T rhs = coef * lap[s][i] + poly_r(c, cu.v[i], cv.v[i]);
+                    const T r = rhs - (nx[j][s].v[i] - hv) / dt;
+                    const T w = (weighted && xc == 0u && i == 0) ? wz * T(2) : wz;
+                    part = fma_(w * r, r, part);
+                }
+            }
+        }
+        if (B.valid) acc += (double)part;
+        lds_barrier();                                       // the next frame's window overwrites this one
+    }
+    acc = wave_sum_to_last(acc);
+    if (threadIdx.x % WAVE == REDUCE_LANE) red[threadIdx.x / WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < NT / WAVE; ++w) t += red[w];
+        partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // adjoint of one step (see pi_bwd_kernel): Gp = G + coef*dt*LapT(G) + dt*J_react(h)^T G (+ inj), diffusion-coefficient
 // sums always, and -- MOM, pre-contracted blocks -- the 20 coefficient moments carried per lane over all bricks of the
 // workgroup and reduced once per launch.  partials: one row of np doubles per workgroup (owner-block read-modify-write).

@@ -1113,6 +1113,31 @@ def test_physics_residual_gradcheck_fp64(hip_device):
         assert torch.allclose(physics.physics_loss(odd, Q, weighted), physics.physics_loss(odd, Q, weighted, fused=False), rtol=1e-12)
 
 
+@pytest.mark.parametrize("shape,dtype", [((40, 24, 48), torch.float32), ((9, 12, 16), torch.float32), ((128, 128, 128), torch.float32),
+                                         ((7, 6, 8), torch.float64), ((33, 20, 128), torch.float64)])
+def test_physics_loss_3d_brick_pass_equals_generic_pass(shape, dtype, hip_device):
+    """3D: the loss pass runs on the brick machinery (register plane window + LDS rows, pi_res3d_brick_kernel) where the step
+    kernels do; the residual it squares is bit-identical to the generic kernel's, only the order of the double sums differs."""
+    import percnn_amd as pa
+    from percnn_amd import physics
+    cell = pa.RCNNCell(3, 2, dx=0.5, dt=0.1, mu_up=0.2, dtype=dtype).to(hip_device)
+    Q = physics.gray_scott_block(cell, 0.2, 0.1, 0.025, 0.055)
+    F = 3 if shape[0] == 128 else 7
+    out = torch.rand((F + 2, 2) + shape, dtype=dtype, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(5))
+    tol = 1e-6 if dtype == torch.float32 else 1e-13
+    try:
+        for weighted in (True, False):
+            a = physics.physics_loss(out, Q, reference_weighting=weighted)
+            pa.set_option("brick3d", 0)
+            b = physics.physics_loss(out, Q, reference_weighting=weighted)
+            pa.set_option("brick3d", 1)
+            c = physics.physics_loss(out, Q, reference_weighting=weighted, fused=False)
+            assert abs(a.item() - b.item()) <= tol * abs(b.item()), (a.item(), b.item())
+            assert abs(a.item() - c.item()) <= 4 * tol * abs(c.item()), (a.item(), c.item())
+    finally:
+        pa.set_option("brick3d", 1)
+
+
 # ---------------------------------------------------------------------------------------------
 # SURVEY 8f rank 2: Stage-3 physics-based lambda-omega cell vs the reference script's cell
 # ---------------------------------------------------------------------------------------------
