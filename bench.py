@@ -1025,7 +1025,7 @@ def sharded_series(dev, dist, rank, world, one_gpu, checkpoint=lambda res: None)
         except Exception as e:
             return {"error": repr(e)[:300]}
 
-    def strong_on(transport, dest):
+    def strong_on(transport, dest, overlap=False):
         for n3, T in grids:
             full, key = (n3, n3, n3), f"{n3}^3"
             if n3 % world or n3 // world < halo:
@@ -1033,15 +1033,33 @@ def sharded_series(dev, dist, rank, world, one_gpu, checkpoint=lambda res: None)
             elif not sharded:
                 dest[key] = guarded(lambda: single_domain_anchor(dev, full, T, 3, P))
             else:
-                dest[key] = guarded(lambda: sharded_rollout(dev, dist, rank, world, full, T, halo, 3, transport, force_p2p, P))
+                dest[key] = guarded(lambda: sharded_rollout(dev, dist, rank, world, full, T, halo, 3, transport, force_p2p, P,
+                                                            overlap=overlap))
+
+    def weak_pair(transport):
+        """The weak-scaled slab on `transport` with the plain schedule (exchange between two steps) and with the faces-first
+        schedule (faces of the frame about to be exchanged computed first, the exchange on a side stream under the interior
+        planes).  On ONE GPU the second costs more than it hides (three launches per step: 104 us to self); whether a real
+        xGMI wire turns that around is decided HERE, by measurement on the hardware the run is on -> the schedule the strong
+        series then uses."""
+        weak[transport] = guarded(lambda: sharded_rollout(dev, dist, rank, world, (planes * world, hw, hw), Tw, halo, reps,
+                                                          transport, force_p2p, P))
+        checkpoint(out)
+        key = transport + "_faces_first_overlap"
+        weak[key] = guarded(lambda: sharded_rollout(dev, dist, rank, world, (planes * world, hw, hw), Tw, halo, reps,
+                                                    transport, force_p2p, P, breakdown=False, overlap=True))
+        a, b = weak[transport].get("us_per_time_step_fwd_bwd"), weak[key].get("us_per_time_step_fwd_bwd")
+        ok_b = weak[key].get("forward_state_equals_single_domain_rollout") is True
+        return bool(a and b and ok_b and b < a)          # every rank computes the same answer: both times are maxima over ranks
 
     # ---- phase 1: the proven transport
+    overlap_base = False
     if not sharded:
         weak["local_wrap"] = guarded(lambda: sharded_rollout(dev, dist, rank, world, (planes, hw, hw), Tw, halo, reps, "dist", False, P))
     else:
-        weak[base] = guarded(lambda: sharded_rollout(dev, dist, rank, world, (planes * world, hw, hw), Tw, halo, reps, base,
-                                                     force_p2p, P))
-    strong_on(base, strong)
+        overlap_base = weak_pair(base)
+        out["strong_scaling"]["schedule"] = "faces first, exchange on a side stream" if overlap_base else "exchange between two steps"
+    strong_on(base, strong, overlap_base)
     checkpoint(out)
     # ---- phase 2: peer mailboxes (xGMI load / store + epoch flags)
     if int(os.environ.get("PERCNN_NO_PEER", "0")):
@@ -1059,20 +1077,15 @@ def sharded_series(dev, dist, rank, world, one_gpu, checkpoint=lambda res: None)
     out["transport_probe"] = probe
     checkpoint(out)
     if probe.get("peer", {}).get("usable_on_every_rank"):
-        weak["peer"] = guarded(lambda: sharded_rollout(dev, dist, rank, world, (planes * world, hw, hw), Tw, halo, reps, "peer",
-                                                       force_p2p, P))
+        overlap_peer = weak_pair("peer")
         checkpoint(out)
         if picked == "peer":
             out["strong_scaling"]["by_grid_peer"] = {}
-            strong_on("peer", out["strong_scaling"]["by_grid_peer"])
+            out["strong_scaling"]["schedule_peer"] = "faces first, exchange on a side stream" if overlap_peer else \
+                "exchange between two steps (forward faces put by the step launch itself)"
+            strong_on("peer", out["strong_scaling"]["by_grid_peer"], overlap_peer)
             out["strong_scaling"]["transport_picked_by_probe"] = "peer"
         checkpoint(out)
-    # ---- phase 3 (last: nothing above can be lost to it): the faces-first schedule on the proven transport -- faces of the
-    # frame about to be exchanged computed first, the exchange on a side stream under the interior planes.  On ONE GPU it costs
-    # more than it hides (three launches per step, 104 us to self); whether a real xGMI wire turns that around is for this
-    # line to say.
-    weak[base + "_faces_first_overlap"] = guarded(lambda: sharded_rollout(
-        dev, dist, rank, world, (planes * world, hw, hw), Tw, halo, reps, base, force_p2p, P, breakdown=False, overlap=True))
     return out
 
 
