@@ -43,6 +43,7 @@ struct Options {
     int skip_wgrad = 0;     // diagnostics: rollout_bwd runs the adjoint sweep only (bench uses it to time the sweep alone)
     int tile_xcd = 1;       // XCD-aware block -> tile map of the 2D tile kernels (0 = identity)
     int tile_by = 0;        // tile height of the 2D tile kernels: 32, 16, or 0 = by grid size (see tile_by_for)
+    int slab_fused_put_adj = 0; // ... and the adjoint sweep's faces by the sweep launch (to self: no gain; across xGMI: bench.py decides)
     int tile_wide = 3;      // float32 poly blocks: 3 = 32x40 / 40x40 tiles where they keep the grid in one round (tile_wide_for),
                             // 0 = never, 1 / 2 = force 32x40 / 40x40
     int fwd_blocks = 0;     // direct forward kernel: grid cap (0 = none; measured: a bounded persistent grid loses, 384^3 376 -> 416 us)
@@ -730,44 +731,67 @@ unsigned brick_bwd_grid(const Problem& p, int vec, int rz)
 
 template <typename T, int HC, int RZ, bool MOM, int NT = pi::BRICK_NT>
 hipError_t launch_brick_bwd(const T* h, const T* G, const T* inj, T* Gp, double* partials, const T* P, const Problem& p,
-                            hipStream_t st)
+                            hipStream_t st, const FusedPut* fp = nullptr)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
-    const pi::BrickGeom b = make_brick_geom(p, VEC, RZ, NT);
+    pi::BrickGeom b = make_brick_geom(p, VEC, RZ, NT);
     if (b.n0 <= 0) return hipSuccess;
     const unsigned grid = brick_bwd_grid(p, VEC, RZ);
     const size_t head = (size_t)(NT / pi::WAVE) * 2 * sizeof(double);
     const size_t windows = (size_t)2 * RZ * pi::brick_wb(NT), scratch = MOM ? (size_t)(32 + 20 * (NT + 8)) * sizeof(T) : 0;
     const size_t lds = head + (windows > scratch ? windows : scratch) + (size_t)p.opt.lds_pad;
+    if constexpr (HC == pi::POLY && RZ == 1 && NT == pi::BRICK_NT) {
+        if (fp && p.loss.mode == 0) {                        // slab sweep over the mailboxes: faces put by this launch
+            const pi::PeerPutFused put = fused_put_args<RZ>(fp, p, b);
+            b.wt = 1;                                        // the put workgroups read what the bricks wrote THROUGH
+            auto* k = pi::pi_adj3d_brick_kernel<T, HC, RZ, MOM, 0, NT, true>;
+            if (hipError_t e = allow_lds(k, lds)) return e;
+            hipLaunchKernelGGL(k, dim3(grid + (unsigned)put.nput), dim3(NT), lds, st, h, G, inj, Gp, partials, P, b, p.hc, put);
+            return hipGetLastError();
+        }
+    }
+    if (fp) return hipErrorInvalidValue;                     // (the caller checks brick_bwd_can_put first)
     if constexpr (NT != pi::BRICK_NT) {
         auto* k = pi::pi_adj3d_brick_kernel<T, HC, RZ, MOM, 0, NT>;
         if (hipError_t e = allow_lds(k, lds)) return e;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, h, G, inj, Gp, partials, P, b, p.hc);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, h, G, inj, Gp, partials, P, b, p.hc, pi::NoPut{});
         return hipGetLastError();
     }
     if (p.loss.mode == 1) {
         auto* k = pi::pi_adj3d_brick_kernel<T, HC, RZ, MOM, 1>;
         if (hipError_t e = allow_lds(k, lds)) return e;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(pi::BRICK_NT), lds, st, h, G, inj, Gp, partials, P, b, p.hc);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(pi::BRICK_NT), lds, st, h, G, inj, Gp, partials, P, b, p.hc, pi::NoPut{});
         return hipGetLastError();
     }
     if (p.loss.mode == 2) {
         auto* k = pi::pi_adj3d_brick_kernel<T, HC, RZ, MOM, 2>;
         if (hipError_t e = allow_lds(k, lds)) return e;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(pi::BRICK_NT), lds, st, h, G, inj, Gp, partials, P, b, p.hc);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(pi::BRICK_NT), lds, st, h, G, inj, Gp, partials, P, b, p.hc, pi::NoPut{});
         return hipGetLastError();
     }
     auto* k = pi::pi_adj3d_brick_kernel<T, HC, RZ, MOM>;
     if (hipError_t e = allow_lds(k, lds)) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(pi::BRICK_NT), lds, st, h, G, inj, Gp, partials, P, b, p.hc);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(pi::BRICK_NT), lds, st, h, G, inj, Gp, partials, P, b, p.hc, pi::NoPut{});
     return hipGetLastError();
 }
 
 // mom: all gradients of a pre-contracted block in the sweep launch; else adjoint state + diffusion-coefficient sums
+// the flavours that exist with the put inside: pre-contracted blocks, one-plane bricks of 256 lanes, plain injection
+template <typename T>
+bool brick_bwd_can_put(int rz, const Problem& p)
+{
+    return p.hc == 0 && rz == 1 && p.loss.mode == 0 && brick_nt_for(p, 16 / (int)sizeof(T)) != 512;
+}
+
 template <typename T>
 hipError_t brick_bwd(int rz, bool mom, const T* h, const T* G, const T* inj, T* Gp, double* partials, const T* P,
-                     const Problem& p, hipStream_t st)
+                     const Problem& p, hipStream_t st, const FusedPut* fp = nullptr)
 {
+    if (fp) {
+        if (!brick_bwd_can_put<T>(rz, p)) return hipErrorInvalidValue;
+        return mom ? launch_brick_bwd<T, pi::POLY, 1, true>(h, G, inj, Gp, partials, P, p, st, fp)
+                   : launch_brick_bwd<T, pi::POLY, 1, false>(h, G, inj, Gp, partials, P, p, st, fp);
+    }
 #define CALL_BB(HC, RZ, MOM) launch_brick_bwd<T, HC, RZ, MOM>(h, G, inj, Gp, partials, P, p, st)
     if (p.hc == 0) {
         if (rz <= 2 && brick_nt_for(p, 16 / (int)sizeof(T)) == 512) {
@@ -1495,6 +1519,9 @@ int slab_rollout_bwd_impl(const T* traj, const T* g_traj, T* adj, double* param_
     const bool wide = ring && !ring->peer && !side && p.opt.slab_wide_adjoint && halo >= 4 && n >= 4 &&
                       (size_t)2 * p.n * sizeof(T) >= w.partials_bytes;
     T* g_mut = const_cast<T*>(g_traj);
+    const bool fuse_put = ring && ring->peer && p.opt.slab_fused_put_adj && !side && !wide;
+    pi::PeerXfer take_pending{};
+    bool have_take = false, take_vec = false;
     for (int t = T_steps; t >= 1; --t) {
         if (wide && t >= 2) {
             if (int rc = ring_exchange<T>(adj + (size_t)t * frame, p, 4, ring, st, g_mut + (size_t)(t - 1) * frame, 2)) return rc;
@@ -1505,10 +1532,36 @@ int slab_rollout_bwd_impl(const T* traj, const T* g_traj, T* adj, double* param_
             if (int rc = sweep(t, halo, halo + (int)n)) return rc;
             continue;
         }
-        if (pending) {
+        if (have_take) {                                   // the put of this exchange rode on the previous sweep launch
+            if (int rc = peer_launch_take(take_pending, take_vec, ring->peer, st)) return rc;
+            have_take = false;
+        } else if (pending) {
             if (hipError_t e = hipStreamWaitEvent(st, pending, 0)) return (int)e;
             pending = nullptr;
         } else if (int rc = ring_exchange<T>(adj + (size_t)t * frame, p, 2, ring, st)) return rc;
+        if (fuse_put && t > 1) {
+            // peer mailboxes + brick kernels: the sweep launch that writes adj[t-1] puts its faces itself
+            Problem q = p;
+            if (int rc = set_slab_range(q, halo, halo, halo + (int)n)) return rc;
+            const T* hf = traj + (size_t)(t - 1) * frame;
+            const T* gf = adj + (size_t)t * frame;
+            const T* jf = g_traj + (size_t)(t - 1) * frame;
+            T* of = adj + (size_t)(t - 1) * frame;
+            const int vq = pick_vec<T>(q, {hf, gf, jf, of});
+            const bool streams = stream3d_vec<T>(q, {hf, gf, jf, of}, true) != 0;
+            const int brz = streams ? 0 : brick_rz_for<T>(q, vq, true);
+            if (brz && brick_bwd_can_put<T>(brz, q) && (size_t)vq * sizeof(T) == 16) {
+                FusedPut fp{};
+                if (int rc = peer_prepare<T>(of, p, 2, ring->peer, fp.x, take_pending, take_vec)) return rc;
+                fp.vec16 = take_vec;
+                fp.timeout_ticks = peer_ticks(ring->peer);
+                fp.face_lo[0] = halo + (int)n - 2; fp.face_hi[0] = halo + (int)n;        // my LAST interior planes -> next
+                fp.face_lo[1] = halo;              fp.face_hi[1] = halo + 2;              // my FIRST interior planes -> prev
+                if (hipError_t e = brick_bwd<T>(brz, fuse, hf, gf, jf, of, w.partials, P, q, st, &fp)) return (int)e;
+                have_take = true;
+                continue;
+            }
+        }
         if (side && t > 1) {
             if (int rc = sweep(t, halo, halo + 2)) return rc;
             if (int rc = sweep(t, halo + (int)n - 2, halo + (int)n)) return rc;
@@ -1844,6 +1897,7 @@ int apply_option(Options& o, const char* key, long value)
         o.tile_by = (int)value;
         return 0;
     }
+    if (!std::strcmp(key, "slab_fused_put_adj")) { o.slab_fused_put_adj = value != 0; return 0; }
     if (!std::strcmp(key, "tile_wide")) {
         if (value < 0 || value > 3) return PERCNN_PI_EINVAL;
         o.tile_wide = (int)value;

@@ -369,15 +369,33 @@ pi_res3d_brick_kernel(const T* __restrict__ traj, double* __restrict__ partials,
 // dL/dout (a template parameter, not a run-time switch: the kernel sits at the edge of its 128-register budget and of the 102
 // SGPRs -- the generic form spilled)
 // (LOSS = pi::LossInj::mode, 0 / 1 / 2)
-template <typename T, int HC, int RZ, bool MOM, int LOSS = 0, int NT = BRICK_NT>
-__global__ void __launch_bounds__(NT, (RZ == 1 && HC == POLY && LOSS != 2 && sizeof(T) == 4) ? 4 : 2)   // one-plane bricks of pre-contracted float32
+// PUT: the slab sweep's flavour that carries the faces of the adjoint frame it writes into the neighbours' mailboxes itself
+// (pi_peer.h "put fused into the step kernel"; the lowest put.nput block ids).  A template parameter, and the argument an empty
+// struct otherwise: as a plain extra argument it pushed three flavours of this kernel, which sits at its 128-VGPR / 102-SGPR
+// edge, into scratch.  Through the rank's OWN mailbox it buys little (a put to self is 2 MiB of uncached stores into the same
+// HBM the sweep streams from); across xGMI the same bytes are ~16 us of wire per step that would otherwise sit between two
+// sweep launches.
+struct NoPut {};
+template <bool PUT> struct AdjPutArg { using type = NoPut; };
+template <> struct AdjPutArg<true> { using type = PeerPutFused; };
+
+template <typename T, int HC, int RZ, bool MOM, int LOSS = 0, int NT = BRICK_NT, bool PUT = false>
+__global__ void __launch_bounds__(NT, (RZ == 1 && HC == POLY && LOSS != 2 && sizeof(T) == 4 && !PUT) ? 4 : 2)   // one-plane bricks of pre-contracted float32
 pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restrict__ inj, T* __restrict__ Gp,
-                      double* __restrict__ partials, const T* __restrict__ P, BrickGeom g, int hc_rt)
+                      double* __restrict__ partials, const T* __restrict__ P, BrickGeom g, int hc_rt,
+                      typename AdjPutArg<PUT>::type put)
 {
-    // (no fused put here, unlike the forward kernel: measured on the 32 x 256^2 slab through the rank's own mailbox it bought
-    // 1.4 us per step where the forward's buys 4, and the extra kernel argument pushed three flavours of this kernel, which sits
-    // at its 128-VGPR / 102-SGPR edge, into scratch)
     static_assert(!MOM || HC == POLY, "fused moments are those of the pre-contracted block");
+    unsigned bid = blockIdx.x, nwg = gridDim.x;              // this workgroup among the brick workgroups
+    if constexpr (PUT) {
+        if ((int)blockIdx.x < put.nput) {
+            if (put.vec16) peer_put_block<true>(put, (int)blockIdx.x);
+            else peer_put_block<false>(put, (int)blockIdx.x);
+            return;
+        }
+        bid -= (unsigned)put.nput;
+        nwg -= (unsigned)put.nput;
+    }
     constexpr int VEC = 16 / (int)sizeof(T), NW = NT / WAVE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int hc = HC == POLY ? 0 : (HC > 0 ? HC : hc_rt);
@@ -388,7 +406,7 @@ pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T*
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
     // this workgroup's partial row: requested now, needed at the very end
     auto slot_of = [&](int k) { return k < 2 ? P_COEF + k : P_W + k - 2; };
-    double* const prow = partials + (long)blockIdx.x * np;
+    double* const prow = partials + (long)bid * np;
     const int nsum = MOM ? 22 : 2;
     const double pold = (int)threadIdx.x < nsum ? prow[slot_of((int)threadIdx.x)] : 0.0;
 
@@ -404,9 +422,9 @@ pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T*
     Geom gg = brick_as_geom(g);
     bool staged = false;
     PI_STAMP3(0);
-    for (unsigned vb = blockIdx.x; vb < g.nblk; vb += gridDim.x) {
+    for (unsigned vb = bid; vb < g.nblk; vb += nwg) {
         Brick<T, RZ, NT> B;
-        B.locate(g, vb, gridDim.x, WIN0);
+        B.locate(g, vb, nwg, WIN0);
         Lane L;
         L.i0 = B.i0; L.eb = B.eb;
         PlaneWindow<T, VEC, RZ> win[2];
@@ -541,6 +559,9 @@ pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T*
                 else { stb<T, VEC>(pu, B.eb, ou); stb<T, VEC>(pv, B.eb, ov); }
             }
             PI_STAMP3(4 + (j > 0));
+        }
+        if constexpr (PUT) {                                 // block-uniform: only bricks that hold face planes count themselves
+            if (peer_holds_face(put, B.i0, min(B.i0 + RZ, g.n0))) peer_face_stored(put, B.i0, min(B.i0 + RZ, g.n0));
         }
     }
     PI_STAMP3(6);

@@ -102,6 +102,12 @@ struct PeerPutFused {
     int vec16;                   // all face / slot pointers 16-byte aligned, sizes multiples of 16
 };
 
+// does a brick of planes [z0, z1) hold a share of one of the two faces?  (block-uniform)
+__device__ __forceinline__ bool peer_holds_face(const PeerPutFused& f, int z0, int z1)
+{
+    return (z0 < f.hi[0] && z1 > f.lo[0]) || (z0 < f.hi[1] && z1 > f.lo[1]);
+}
+
 // a brick that has stored planes [z0, z1): all its (write-through) stores are drained before the counters move
 __device__ __forceinline__ void peer_face_stored(const PeerPutFused& f, int z0, int z1)
 {

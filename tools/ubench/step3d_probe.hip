@@ -173,8 +173,8 @@ int main(int argc, char** argv)
                 for (int t = T; t >= 1; --t) {
                     const float* hf = traj + (size_t)(t - 1) * n;
                     const float* jf = noinj ? nullptr : inj + (size_t)(t - 1) * n;
-                    if (rz == 1) hipLaunchKernelGGL((pi::pi_adj3d_brick_kernel<float, pi::POLY, 1, true>), dim3(grid), dim3(256), lds, st, hf, x, jf, y, partials, P, bg, 0);
-                    else         hipLaunchKernelGGL((pi::pi_adj3d_brick_kernel<float, pi::POLY, 2, true>), dim3(grid), dim3(256), lds, st, hf, x, jf, y, partials, P, bg, 0);
+                    if (rz == 1) hipLaunchKernelGGL((pi::pi_adj3d_brick_kernel<float, pi::POLY, 1, true>), dim3(grid), dim3(256), lds, st, hf, x, jf, y, partials, P, bg, 0, pi::NoPut{});
+                    else         hipLaunchKernelGGL((pi::pi_adj3d_brick_kernel<float, pi::POLY, 2, true>), dim3(grid), dim3(256), lds, st, hf, x, jf, y, partials, P, bg, 0, pi::NoPut{});
                     std::swap(x, y);
                 }
                 CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
