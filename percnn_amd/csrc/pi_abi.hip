@@ -44,6 +44,8 @@ struct Options {
     int tile_xcd = 1;       // XCD-aware block -> tile map of the 2D tile kernels (0 = identity)
     int tile_by = 0;        // tile height of the 2D tile kernels: 32, 16, or 0 = by grid size (see tile_by_for)
     int slab_fused_put_adj = 0; // ... and the adjoint sweep's faces by the sweep launch (to self: no gain; across xGMI: bench.py decides)
+    int peer_upb = 2048;    // mailbox put / take launches: 16-byte units per workgroup and species (peer_prepare)
+    int peer_upb_take = 0;  // ... of the take alone (0 = as the put)
     int tile_wide = 3;      // float32 poly blocks: 3 = 32x40 / 40x40 tiles where they keep the grid in one round (tile_wide_for),
                             // 0 = never, 1 / 2 = force 32x40 / 40x40
     int fwd_blocks = 0;     // direct forward kernel: grid cap (0 = none; measured: a bounded persistent grid loses, 384^3 376 -> 416 us)
@@ -1255,10 +1257,16 @@ int peer_prepare(T* slab, const Problem& p, int width, percnn_pi_peer_ring* pr, 
             vec = vec && reinterpret_cast<uintptr_t>(put.src[d][s]) % 16 == 0 && reinterpret_cast<uintptr_t>(take.dst[d][s]) % 16 == 0;
     }
     const size_t units = bytes / (vec ? 16 : 4);
-    const int bpd = (int)std::min<size_t>(256, std::max<size_t>(1, (units + 1023) / 1024));   // 4 units in flight per lane and species
+    // units per workgroup and species.  Measured through the rank's own mailbox (32 x 256^2 slab, us per fwd+bwd step, put and
+    // take alike): 256 -> 89, 512 -> 67, 1024 -> 57.3, 2048 -> 52.4, 4096 -> 52.7, 8192 -> 61, 16384 -> 76: uncached stores / loads
+    // from MANY workgroups at once contend (profiles/r03_peer_units_per_block.txt)
+    const size_t upb = (size_t)p.opt.peer_upb, upt = (size_t)(p.opt.peer_upb_take ? p.opt.peer_upb_take : p.opt.peer_upb);
+    const int bpd = (int)std::min<size_t>(256, std::max<size_t>(1, (units + upb - 1) / upb));
+    const int bpt = (int)std::min<size_t>(256, std::max<size_t>(1, (units + upt - 1) / upt));
     put.bytes = take.bytes = bytes;
     put.epoch = take.epoch = epoch;
-    put.blocks_per_dir = take.blocks_per_dir = bpd;
+    put.blocks_per_dir = bpd;
+    take.blocks_per_dir = bpt;
     put.mine = take.mine = static_cast<pi::PeerBox*>(pr->my_box);
     put.signal[0] = static_cast<pi::PeerBox*>(pr->next_box);
     put.signal[1] = static_cast<pi::PeerBox*>(pr->prev_box);
@@ -1898,6 +1906,12 @@ int apply_option(Options& o, const char* key, long value)
         return 0;
     }
     if (!std::strcmp(key, "slab_fused_put_adj")) { o.slab_fused_put_adj = value != 0; return 0; }
+    if (!std::strcmp(key, "peer_upb") || !std::strcmp(key, "peer_upb_take")) {
+        const bool take = key[8] == '_';
+        if ((value < 256 && !(take && value == 0)) || value > 65536) return PERCNN_PI_EINVAL;
+        (take ? o.peer_upb_take : o.peer_upb) = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "tile_wide")) {
         if (value < 0 || value > 3) return PERCNN_PI_EINVAL;
         o.tile_wide = (int)value;
