@@ -1834,6 +1834,24 @@ int residual_sqloss_impl(const T* traj, const T* Q, int ndim, const int64_t* sha
             }
         }
     }
+    // 2D grids the tile machinery takes: the tile + its 2-wide ring once through LDS (pi_tile2d.h)
+    if (ndim == 2 && p.opt.tile && vec == pi::vec_width<T>::value && p.n0 >= TILE_B + 2 && p.W >= TILE_B + 2 &&
+        reinterpret_cast<uintptr_t>(traj) % 16 == 0) {
+        const pi::TileGeom tg = make_tile_geom(p, TILE_B, TILE_B);
+        const unsigned tiles = (unsigned)(((p.n0 + TILE_B - 1) / TILE_B) * tg.tiles_x);
+        if (tiles <= RESLOSS_SLOTS) {
+            unsigned gy = RESLOSS_SLOTS / tiles;
+            if (gy > (unsigned)nframes) gy = (unsigned)nframes;
+            if (gy > 65535u) gy = 65535u;
+            const size_t lds = (size_t)2 * (TILE_B + 8) * (TILE_B + 4) * sizeof(T);
+            double* partials = static_cast<double*>(ws);
+            auto* k = pi::pi_res2d_tile_kernel<T, TILE_B, TILE_B, 256>;
+            hipLaunchKernelGGL(k, dim3(tiles, gy), dim3(256), lds, st0, traj, partials, Q, tg, (long)(2 * p.n), nframes, weighted);
+            hipLaunchKernelGGL((pi::pi_sqerr_finish_kernel<T>), dim3(1), dim3(64), 0, st0, partials, (int)(tiles * gy),
+                               resloss_scale(p, ndim, shape, nframes, weighted), loss_out);
+            return (int)hipGetLastError();
+        }
+    }
     const long nchunks = (long)g.rows * (g.W / vec);
     const unsigned gx = (unsigned)((nchunks + 255) / 256);
     if (gx > RESLOSS_SLOTS) return PERCNN_PI_ETOOLARGE;

@@ -290,6 +290,16 @@ __device__ __forceinline__ void lds_star4v(const T* pl, int ly, int lx, const T*
     }
 }
 
+// pi::poly_r on 2-vectors (same operations in the same order)
+template <typename T>
+__device__ __forceinline__ V2<T> poly_r_v(const T* __restrict__ c, V2<T> u, V2<T> v)
+{
+    const V2<T> A0 = vfma(v, vfma(v, vfma(v, vs(c[9]), vs(c[5])), vs(c[2])), vs(c[0]));
+    const V2<T> A1 = vfma(v, vfma(v, vs(c[8]), vs(c[4])), vs(c[1]));
+    const V2<T> A2 = vfma(v, vs(c[7]), vs(c[3]));
+    return vfma(u, vfma(u, vfma(u, vs(c[6]), A2), A1), A0);
+}
+
 template <typename T>
 __device__ __forceinline__ void poly_dr_v(const T* __restrict__ c, V2<T> u, V2<T> v, V2<T>& ru, V2<T>& rv)
 {
@@ -407,6 +417,119 @@ pi_fwd2d_tile_kernel(T* __restrict__ frames /* frame t; t+1..t+K are written */,
     PI_STAMP(1);
     fwd_substeps<T, HC, K, BX, BY, NT, 0>(b0, b1, frames, frame_stride, g, ty0, tx0, P);
     PI_STAMP(15);
+}
+
+// ------------------------------------------------------------------------------------------------
+// physics-residual LOSS of a 2D trajectory on the tile machinery (generic flavour: pi_residual_sq_kernel<GRAD = false>;
+// reference: loss_gen / get_phy_Loss, train_2drd.py:270-353 -- evaluated every training iteration as a monitor, :405):
+//   R_s(f, x) = coef_s * Lap(h_f)_s + r_s(h_f) - (h_{f+1,s} - h_{f,s}) / dt ,   partial = sum w * R^2   (Q: the TRUE equation)
+// A workgroup stages the BX x BY tile of frame f plus its 2-wide periodic ring in LDS once (K = 1 window) and every lane forms
+// the residual of one 4-point strip from it with lds_star4 -- the taps in pi::star's order, i.e. the generic kernel's R bit for
+// bit -- and the strip of frame f + 1 it requested with the window.  Workgroup (x, y) walks frames y, y + gridDim.y, ...
+// The generic kernel spends, per 512^2 frame, 0.6 us issuing 316 unpacked VALU instructions per wave, 0.5 us on 16 vector-L1
+// requests per chunk and 0.26 us on HBM, one after the other (1.38 us); here: 5 requests per lane and the packed strip body.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BX, int BY, int NT>
+__global__ void __launch_bounds__(NT)
+pi_res2d_tile_kernel(const T* __restrict__ traj, double* __restrict__ partials, const T* __restrict__ Q, TileGeom g,
+                     long frame_stride, int nframes, int weighted)
+{
+    // window: BY + 4 rows (2 above, 2 below) x BX + 8 columns -- FOUR halo columns per side although the star needs two, so
+    // that every 16-byte piece of the window starts at a multiple of 4 columns and never straddles the periodic wrap (the
+    // K-step kernels' windows start at tx0 - 2K with K even; a window starting at tx0 - 2 would)
+    constexpr int VEC = vec_width<T>::value;
+    constexpr int LX = BX + 8, LY = BY + 4, PLANE = LX * LY, LXV = LX / VEC;
+    constexpr int NLD = 2 * LY * LXV, TRIPS = (NLD + NT - 1) / NT;
+    constexpr int RW4 = BX / 4, RN4 = BX * BY / 4, PT = RN4 / NT;
+    static_assert(RN4 % NT == 0 && LX % 4 == 0, "whole strips per lane, 16-byte rows");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double red[NT / WAVE];
+    T* b0 = reinterpret_cast<T*>(smem_raw);
+    const int tile = tile_of_block(blockIdx.x, g);
+    const int ty0 = (tile / g.tiles_x) * BY, tx0 = (tile % g.tiles_x) * BX;
+    const T dt = Q[P_DT];
+    // what a lane loads of the window (the same pieces of every frame) ...
+    long woff[TRIPS];
+    int wdst[TRIPS];
+#pragma unroll
+    for (int q = 0; q < TRIPS; ++q) {
+        const int i = (int)threadIdx.x + q * NT;
+        wdst[q] = -1;
+        woff[q] = 0;
+        if (i < NLD) {
+            const int s = i / (LY * LXV), r = i - s * (LY * LXV);
+            const int ly = r / LXV, c = r - ly * LXV;
+            const int gy = wrap1(ty0 - 2 + ly, g.H), gx = wrap1(tx0 - 4 + c * VEC, g.W);
+            woff[q] = s * g.ss + (long)gy * g.W + gx;
+            wdst[q] = s * PLANE + ly * LX + c * VEC;
+        }
+    }
+    // ... and the strips it owns: window position, offset inside a species plane, ownership (edge tiles of a ragged grid)
+    int ry[PT], rc[PT];
+    long e[PT];
+    bool own[PT];
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int idx = (int)threadIdx.x + q * NT;
+        ry[q] = idx / RW4; rc[q] = idx - ry[q] * RW4;
+        own[q] = ty0 + ry[q] < g.H && tx0 + 4 * rc[q] < g.W;
+        e[q] = own[q] ? (long)(ty0 + ry[q]) * g.W + tx0 + 4 * rc[q] : 0;
+    }
+    double acc = 0.0;
+    for (int f = (int)blockIdx.y; f < nframes; f += (int)gridDim.y) {
+        const T* h = traj + (long)f * frame_stride;
+        Pack<T, VEC> wreg[TRIPS];
+#pragma unroll
+        for (int q = 0; q < TRIPS; ++q) wreg[q] = ld<T, VEC>(h + woff[q]);
+        Pack<T, 2> nx[PT][2][2];                           // [strip][species][half]: the strip in frame f + 1
+#pragma unroll
+        for (int q = 0; q < PT; ++q)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                nx[q][s][0] = ld<T, 2>(h + frame_stride + s * g.ss + e[q]);
+                nx[q][s][1] = ld<T, 2>(h + frame_stride + s * g.ss + e[q] + 2);
+            }
+#pragma unroll
+        for (int q = 0; q < TRIPS; ++q)
+            if (wdst[q] >= 0) st<T, VEC>(b0 + wdst[q], wreg[q]);
+        lds_barrier();
+        // the strip body on explicit 2-vectors (v_pk_fma_f32 / v_pk_mul_f32): left to itself the compiler issued 292 scalar
+        // VALU instructions per strip here, none packed -- the pass is issue-bound (one wave per SIMD and workgroup)
+        T part = T(0);
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            V2<T> c2[2][2], lap[2][2];                     // [species][half of the strip]
+            lds_star4v<T, LX, +1>(b0, ry[q] + 2, 4 * rc[q] + 4, Q, c2[0], lap[0]);
+            lds_star4v<T, LX, +1>(b0 + PLANE, ry[q] + 2, 4 * rc[q] + 4, Q, c2[1], lap[1]);
+            const T wrow = (weighted && ty0 + ry[q] == 0) ? T(2) : T(1);
+            const V2<T> w0 = V2<T>{(weighted && tx0 + 4 * rc[q] == 0) ? wrow * T(2) : wrow, wrow}, w1 = vs(wrow);
+            V2<T> sp = vs(T(0));
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const T* c = Q + P_W + 10 * s;
+                const V2<T> coef = vs(Q[P_COEF + s]);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const V2<T> rhs = coef * lap[s][hh] + poly_r_v(c, c2[0][hh], c2[1][hh]);
+                    const V2<T> nxv = V2<T>{nx[q][s][hh].v[0], nx[q][s][hh].v[1]};
+                    const V2<T> d = nxv - c2[s][hh];
+                    const V2<T> r = rhs - V2<T>{d.x / dt, d.y / dt};
+                    sp = vfma((hh == 0 ? w0 : w1) * r, r, sp);
+                }
+            }
+            part += own[q] ? sp.x + sp.y : T(0);
+        }
+        acc += (double)part;
+        lds_barrier();                                     // the next frame's window overwrites this one
+    }
+    acc = wave_sum_to_last(acc);
+    if (threadIdx.x % WAVE == REDUCE_LANE) red[threadIdx.x / WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < NT / WAVE; ++w) t += red[w];
+        partials[(long)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1113,6 +1113,32 @@ def test_physics_residual_gradcheck_fp64(hip_device):
         assert torch.allclose(physics.physics_loss(odd, Q, weighted), physics.physics_loss(odd, Q, weighted, fused=False), rtol=1e-12)
 
 
+@pytest.mark.parametrize("shape,dtype", [((64, 96), torch.float32), ((40, 100), torch.float32), ((512, 512), torch.float32),
+                                         ((34, 36), torch.float64), ((100, 100), torch.float64), ((33, 64), torch.float32)])
+def test_physics_loss_2d_tile_pass_equals_generic_pass(shape, dtype, hip_device):
+    """2D: the loss pass runs on the tile machinery (tile + 2-wide ring once through LDS, pi_res2d_tile_kernel) from 34 x 34 on;
+    its residual is the generic kernel's bit for bit (lds_star4 = pi::star's tap order), only the order of the double sums
+    differs.  (40, 100): ragged edge tiles; (33, 64): below the window's single-wrap limit -> generic kernel either way."""
+    import percnn_amd as pa
+    from percnn_amd import physics
+    cell = (pa.gs2d_cell() if dtype == torch.float32 else pa.lo2d_cell()).to(hip_device)
+    Q = physics.gray_scott_block(cell, 2e-5, 5e-6, 0.04, 0.06) if dtype == torch.float32 else physics.lambda_omega_block(cell, 0.1)
+    F = 5 if shape[0] == 512 else 9
+    out = torch.rand((F + 2, 2) + shape, dtype=dtype, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(3))
+    tol = 1e-6 if dtype == torch.float32 else 1e-13
+    try:
+        for weighted in (True, False):
+            a = physics.physics_loss(out, Q, reference_weighting=weighted)
+            pa.set_option("tile", 0)
+            b = physics.physics_loss(out, Q, reference_weighting=weighted)
+            pa.set_option("tile", 1)
+            c = physics.physics_loss(out, Q, reference_weighting=weighted, fused=False)
+            assert abs(a.item() - b.item()) <= tol * abs(b.item()), (a.item(), b.item())
+            assert abs(a.item() - c.item()) <= 4 * tol * abs(c.item()), (a.item(), c.item())
+    finally:
+        pa.set_option("tile", 1)
+
+
 @pytest.mark.parametrize("shape,dtype", [((40, 24, 48), torch.float32), ((9, 12, 16), torch.float32), ((128, 128, 128), torch.float32),
                                          ((7, 6, 8), torch.float64), ((33, 20, 128), torch.float64)])
 def test_physics_loss_3d_brick_pass_equals_generic_pass(shape, dtype, hip_device):
