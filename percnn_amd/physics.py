@@ -139,7 +139,9 @@ def physics_loss(output: torch.Tensor, Q: torch.Tensor, reference_weighting: boo
     the residual on an (N+1)^d grid in which the first row / column / plane appears twice;
     ``reference_weighting`` reproduces that weighting exactly (False: plain mean over the periodic grid).
     One autograd node (``PhysicsLossFunction``); ``fused=False`` keeps the residual-tensor expression (tests compare the two)."""
-    if fused and output.is_cuda and output.shape[0] >= 3 and output.shape[0] <= 65535:
+    # (the one-node route keeps one partial sum per workgroup in a fixed 16384-slot workspace: grids beyond 2^24 points per
+    # species take the residual-tensor expression)
+    if fused and output.is_cuda and 3 <= output.shape[0] <= 65535 and output[0, 0].numel() <= (1 << 24):
         return PhysicsLossFunction.apply(output.contiguous(), Q, output.shape[0] - 2, reference_weighting)
     R = physics_residual(output[:-1], Q)              # frames 0 .. len-3
     sq = R * R
