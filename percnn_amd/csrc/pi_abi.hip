@@ -1785,6 +1785,9 @@ int residual_impl(const T* traj, const T* G, T* out, const T* Q, int ndim, const
 // ---- the residual LOSS (MSE of f_u + MSE of f_v, optionally with the reference's padded-grid weighting) and its gradient
 // w.r.t. the trajectory, without materialising the residual or the autograd temporaries of the loss expression ----
 constexpr unsigned RESLOSS_SLOTS = 16384;           // per-block partial sums of the loss pass (doubles)
+// 2D tile flavour: workgroups in flight ~ twice what the chip holds; each walks its frames y, y + gy, ... (512^2 x 200 frames:
+// 203 -> 196 us against 16384 short-lived workgroups; PMC: 832 VALU instructions per wave of which a third were prologue)
+constexpr unsigned RESLOSS_WGS = 4096;
 
 double resloss_scale(const Problem& p, int ndim, const int64_t* shape, int nframes, int weighted)
 {
@@ -1811,7 +1814,7 @@ int residual_sqloss_impl(const T* traj, const T* Q, int ndim, const int64_t* sha
         if (brz == 1 || brz == 2) {
             pi::BrickGeom b = make_brick_geom(p, pi::vec_width<T>::value, brz, pi::BRICK_NT, false);
             if (b.nblk > 0 && b.nblk <= RESLOSS_SLOTS) {
-                unsigned gy = RESLOSS_SLOTS / b.nblk;
+                unsigned gy = RESLOSS_SLOTS / b.nblk;                    // (4096 workgroups measured slower here: 1.61 -> 1.69 ms at 128^3)
                 if (gy > (unsigned)nframes) gy = (unsigned)nframes;
                 if (gy > 65535u) gy = 65535u;
                 const size_t lds = (size_t)2 * brz * pi::brick_wb(pi::BRICK_NT);
@@ -1840,7 +1843,7 @@ int residual_sqloss_impl(const T* traj, const T* Q, int ndim, const int64_t* sha
         const pi::TileGeom tg = make_tile_geom(p, TILE_B, TILE_B);
         const unsigned tiles = (unsigned)(((p.n0 + TILE_B - 1) / TILE_B) * tg.tiles_x);
         if (tiles <= RESLOSS_SLOTS) {
-            unsigned gy = RESLOSS_SLOTS / tiles;
+            unsigned gy = std::max(1u, RESLOSS_WGS / tiles);
             if (gy > (unsigned)nframes) gy = (unsigned)nframes;
             if (gy > 65535u) gy = 65535u;
             const size_t lds = (size_t)2 * (TILE_B + 8) * (TILE_B + 4) * sizeof(T);
