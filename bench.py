@@ -458,6 +458,10 @@ def main():
 
     ensure_library(local_rank)
     import percnn_amd as pa
+    if one_gpu:
+        # several PROCESSES on one GPU (test mode): two persistent sweeps would each hold part of the CUs (include/percnn_pi.h,
+        # option tile_persist) -- the launch-per-group sweep here
+        pa.set_option("tile_persist", 0)
     if a.slab_child:
         def checkpoint(res):
             flush_c_stdio()

@@ -46,6 +46,13 @@ struct Options {
     int slab_fused_put_adj = 0; // ... and the adjoint sweep's faces by the sweep launch (to self: no gain; across xGMI: bench.py decides)
     int peer_upb = 2048;    // mailbox put / take launches: 16-byte units per workgroup and species (peer_prepare)
     int peer_upb_take = 0;  // ... of the take alone (0 = as the put)
+    int tile_persist = 2;   // float32 poly blocks on whole 32 x 32 tiles, <= one tile per CU, no frame mask: the whole tile sweep
+                            // of a rollout in ONE launch of resident workgroups (pi_adj2d_persist_kernel).  2 = plain launch (one
+                            // workgroup fills a CU's LDS, so a grid of <= #CUs is resident as long as no OTHER kernel holds whole
+                            // CUs: calls on other streams of this process are detected and take the launch-per-group path;
+                            // processes that share one GPU must set 0); 1 = cooperative launch (residency guaranteed by the
+                            // runtime, but ~0.4 ms per launch on ROCm 7.2: slower than what it saves at T = 1000); 0 = off
+    int persist_dbg = 0;    // timing experiments on the persistent sweep (WRONG results): see pi::PersistArgs::dbg
     int tile_wide = 3;      // float32 poly blocks: 3 = 32x40 / 40x40 tiles where they keep the grid in one round (tile_wide_for),
                             // 0 = never, 1 / 2 = force 32x40 / 40x40
     int fwd_blocks = 0;     // direct forward kernel: grid cap (0 = none; measured: a bounded persistent grid loses, 384^3 376 -> 416 us)
@@ -1080,6 +1087,105 @@ hipError_t adj_tile(const T* hframe_t, const T* gframe_t, T* aframe_t, unsigned 
 #undef CALL_AT
 }
 
+// ---- persistent fused sweep (pi_tile2d.h "PERSISTENT fused sweep") ---------------------------------------------------------
+int device_cu_count()
+{
+    static int cu_count[16] = {};                           // per device, asked once (benign race: same value)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (!cu_count[dev]) {
+        int n = 0;
+        cu_count[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : -1;
+    }
+    return cu_count[dev] > 0 ? cu_count[dev] : 0;
+}
+
+constexpr int PERSIST_BAND = 2 * (TILE_B * TILE_B - (TILE_B - 16) * (TILE_B - 16));     // granules per tile and parity (K = 4)
+size_t persist_outbox_bytes(const Problem& p)
+{
+    return (size_t)2 * (size_t)((p.n0 / TILE_B) * (p.W / TILE_B)) * PERSIST_BAND * sizeof(unsigned long long);
+}
+
+// can the tile sweep of this rollout run as one cooperative launch?  (everything the kernel assumes, checked here)
+template <typename T>
+bool persist_ok(const Problem& p, const unsigned char* mask, int ngroups, hipStream_t st)
+{
+    if (!p.opt.tile_persist || sizeof(T) != 4 || mask || ngroups < 2) return false;
+    if (!tile_fuse_ok<T>(p) || tile_wide_for<T>(p, true) != 0 || tile_by_for(p) != TILE_B) return false;
+    if (p.n0 % TILE_B || p.W % TILE_B) return false;
+    const int64_t tiles = (p.n0 / TILE_B) * (p.W / TILE_B);
+    const int cus = device_cu_count();
+    if (tiles < 16 || cus <= 0 || tiles > cus) return false;          // (tiny grids: the 8-row tile kernels are faster anyway)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
+    return true;
+}
+
+// Two persistent sweeps in flight on ONE device would each hold part of the CUs and wait for workgroups that cannot become
+// resident.  Within a process: the last persistent launch per device leaves an event behind; a call on ANOTHER stream while that
+// event is not ready takes the launch-per-group path (same stream: ordered behind it anyway).
+struct PersistGuard {
+    std::mutex mu;
+    hipEvent_t ev[16] = {};
+    hipStream_t st[16] = {};
+    bool armed[16] = {};
+};
+PersistGuard g_persist;
+
+bool persist_enter(hipStream_t st, int& dev)
+{
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    std::lock_guard<std::mutex> lk(g_persist.mu);
+    if (g_persist.armed[dev] && g_persist.st[dev] != st && hipEventQuery(g_persist.ev[dev]) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
+void persist_leave(hipStream_t st, int dev)
+{
+    std::lock_guard<std::mutex> lk(g_persist.mu);
+    if (!g_persist.ev[dev] && hipEventCreateWithFlags(&g_persist.ev[dev], hipEventDisableTiming) != hipSuccess) return;
+    if (hipEventRecord(g_persist.ev[dev], st) == hipSuccess) { g_persist.st[dev] = st; g_persist.armed[dev] = true; }
+}
+
+// groups of 4 steps from frame t_top down; g_h0 only if the last group ends at frame 0.  Returns hipErrorCooperativeLaunchTooLarge
+// (or whatever the runtime says) WITHOUT having launched anything if the workgroups cannot all be resident: the caller then
+// runs the launch-per-group path.
+template <typename T>
+hipError_t launch_adj_persist(const T* hframe_t, const T* gframe_t, T* aframe_t, T* g_h0, int ngroups, double* partials,
+                              unsigned long long* outbox, int* error, const T* P, const Problem& p, hipStream_t st)
+{
+    constexpr int K = 4, NT = 512;
+    using TL = pi::Tile<K, TILE_B, TILE_B>;
+    pi::TileGeom g = make_tile_geom(p, TILE_B);
+    const unsigned grid = (unsigned)((p.n0 / TILE_B) * g.tiles_x);
+    (void)sizeof(TL);
+    // state buffers | [20][NT] double moment sums per lane | publish / gather tables (3 + 5 + 5 ints per lane)
+    const size_t lds = pi::tile_state_bytes<T, K, TILE_B, TILE_B>() + (size_t)20 * NT * sizeof(double) + (size_t)13 * NT * sizeof(int);
+    auto* k = pi::pi_adj2d_persist_kernel<T, K, TILE_B, TILE_B, NT>;
+    if (hipError_t e = allow_lds(k, lds)) return e;
+    static int resident[16] = {};                           // per device: does one workgroup of this kernel fit a CU? (asked once)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    if (!resident[dev]) {
+        int nb = 0;
+        resident[dev] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, NT, lds) == hipSuccess && nb >= 1) ? 1 : -1;
+    }
+    if (resident[dev] < 0) return hipErrorCooperativeLaunchTooLarge;
+    if (hipError_t e = hipMemsetAsync(outbox, 0, persist_outbox_bytes(p), st)) return e;
+    long frame_stride = (long)(2 * p.n);
+    int np = pi::nparams(p.hc);
+    pi::PersistArgs pa{outbox, error, ngroups, 200000000ull /* 2 s of the 100 MHz clock */, p.opt.persist_dbg};
+    void* args[] = {(void*)&hframe_t, (void*)&gframe_t, (void*)&aframe_t, (void*)&frame_stride, (void*)&g_h0, (void*)&partials,
+                    (void*)&np, (void*)&P, (void*)&g, (void*)&pa};
+    if (p.opt.tile_persist == 2) {                          // plain launch: one workgroup per CU fits, nothing else must hold CUs
+        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, hframe_t, gframe_t, aframe_t, frame_stride, g_h0, partials, np, P, g, pa);
+        return hipGetLastError();
+    }
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k), dim3(grid), dim3(NT), args, (unsigned)lds, st);
+}
+
 // ---- workspace carving -------------------------------------------------------------------------
 struct Workspace {
     void* adj[2];
@@ -1712,6 +1818,25 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     if (tile_eligible<T>(p, {traj, g_traj, g_h0, adj}, true)) {
         const int K = (p.opt.tile_k == 8 && p.hc != 0) ? 4 : p.opt.tile_k;
         rows = (unsigned)tile_count<T>(p, true);
+        // the whole tile sweep as ONE cooperative launch where that applies (pi_adj2d_persist_kernel); its granule outbox
+        // lives in the three adjoint frames between the hand-over frame and the group above it, which nobody touches then
+        if constexpr (sizeof(T) == 4) {
+            const int ngroups = K == 4 ? t_cur / K : 0;
+            if (tile_fused && ngroups >= 2 && persist_ok<T>(p, mask, ngroups, st) &&
+                persist_outbox_bytes(p) <= (size_t)(K - 1) * frame_bytes) {
+                const int t_end = t_cur - K * ngroups;
+                auto* outbox = reinterpret_cast<unsigned long long*>(adj + (size_t)(t_end + 1) * frame);
+                int* err = reinterpret_cast<int*>(w.partials + (size_t)(MAX_BWD_BLOCKS - 1) * pi::nparams(p.hc));
+                int pdev = 0;
+                if (persist_enter(st, pdev)) {
+                    const hipError_t e = launch_adj_persist<T>(traj + (size_t)t_cur * frame, g_traj + (size_t)t_cur * frame,
+                                                               adj + (size_t)t_cur * frame, t_end == 0 ? g_h0 : nullptr, ngroups,
+                                                               w.partials, outbox, err, P, p, st);
+                    if (e == hipSuccess) { t_cur = t_end; persist_leave(st, pdev); }
+                    else (void)hipGetLastError();           // not resident / not supported: the launch-per-group path below
+                }
+            }
+        }
         for (; t_cur - K >= 0; t_cur -= K) {
             unsigned m = 0;
             for (int q = 0; q < K; ++q) if (has(t_cur - 1 - q)) m |= 1u << q;
@@ -1933,6 +2058,12 @@ int apply_option(Options& o, const char* key, long value)
         (take ? o.peer_upb_take : o.peer_upb) = (int)value;
         return 0;
     }
+    if (!std::strcmp(key, "tile_persist")) {
+        if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
+        o.tile_persist = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "persist_dbg")) { o.persist_dbg = (int)value; return 0; }
     if (!std::strcmp(key, "tile_wide")) {
         if (value < 0 || value > 3) return PERCNN_PI_EINVAL;
         o.tile_wide = (int)value;

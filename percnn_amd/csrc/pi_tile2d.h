@@ -784,7 +784,7 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
                                              T* __restrict__ g_h0, int steps_to_zero, const TileGeom& g, int ty0,
                                              int tx0, const T* __restrict__ P, double (&acc_c)[2],
                                              const StripOps<T>& ops, TileMoments<T, MOM>& mom, const StripAddr (&sa)[K],
-                                             double* lacc = nullptr)
+                                             double* lacc = nullptr, bool store_handover = true)
 {
     T* cur = (M & 1) ? b1 : b0;
     T* nxt = (M & 1) ? b0 : b1;
@@ -815,13 +815,16 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
     // the adjoint of frame 0 is the caller's dL/dh0 output.  MOM: nobody reads the intermediate adjoint frames (the
     // moments are reduced right here), only the hand-over frame t-K goes to memory
     if constexpr (!MOM || M + 1 == K) {
-        T* dst = (M + 1 == steps_to_zero && g_h0) ? g_h0 : abase + fo;
-        tile_store<T, K, BX, BY, NT, (M & 1) != 0>(nxt, dst, g, ty0, tx0);
+        if (store_handover) {                              // (persistent sweep: the state stays in LDS between groups)
+            T* dst = (M + 1 == steps_to_zero && g_h0) ? g_h0 : abase + fo;
+            tile_store<T, K, BX, BY, NT, (M & 1) != 0>(nxt, dst, g, ty0, tx0);
+        }
     }
     PI_STAMP(4 + 3 * M);
     if constexpr (M + 1 < K)
         adj_substeps<T, HC, K, BX, BY, NT, M + 1, PRE, MOM>(b0, b1, hbase, gbase, abase, frame_stride, inj_mask, g_h0,
-                                                            steps_to_zero, g, ty0, tx0, P, acc_c, ahead, mom, sa, lacc);
+                                                            steps_to_zero, g, ty0, tx0, P, acc_c, ahead, mom, sa, lacc,
+                                                            store_handover);
 }
 
 template <typename T, int HC, int K, int BX, int BY, int NT, bool MOM = false>
@@ -960,6 +963,218 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
         *pslot = pold + sum;
     }
     PI_STAMP(15);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT fused sweep (round 3): the whole reverse sweep of a rollout in ONE cooperative launch, one resident workgroup
+// per tile.  What a K = 4 sweep launch spends outside its four sub-steps -- kernel boundary 2.3 us, cold window load 2.4 us,
+// moment reduction + partial-row update 1.2 us, of 11.6 us -- is replaced by a halo hand-over between resident workgroups
+// with DATA-TAGGED GRANULES (8-byte {group number, value} words, agent-scope relaxed stores / loads: the data is the flag;
+// tools/handover_granule_microbench.hip measured 3.4 us per hand-over for exactly this geometry).  Per group of K steps a
+// workgroup: gathers its 2K-wide halo ring from the eight neighbours' bands (polling until every tag matches) around the tile
+// it kept in LDS, runs the K sub-steps of pi_adj2d_tile_kernel (same device functions, same arithmetic: dL/dh0 bit-identical),
+// publishes the 2K-wide border band of its tile.  The 20 coefficient moments are folded into double registers once per group
+// and reduced ONCE per rollout.  Whole 32 x 32 tiles, float32 pre-contracted blocks, every frame carries a gradient (no mask).
+// Double-buffered by group parity; why that suffices: my publish of group e + 2 comes after my gather of e + 1, which saw the
+// neighbour's band e + 1, which it published after ITS gather of e -- the last read of the slot I am about to overwrite.
+// ------------------------------------------------------------------------------------------------
+struct PersistArgs {
+    unsigned long long* outbox;    // [2][tiles][BAND] granules, zeroed before the launch
+    int* error;                    // != 0: a gather timed out (neighbour not resident?) -- outputs are poisoned
+    int ngroups;                   // groups of K steps run here: frames t_top .. t_top - K * ngroups
+    unsigned long long timeout_ticks;
+    int dbg;                       // timing experiments only (wrong results): 1 = gather without waiting for the tags, 2 = no hand-over
+};
+
+template <int B, int HW>
+__device__ __forceinline__ int band_index(int y, int x)      // position inside the tile -> index inside its border band
+{
+    if (y < HW) return y * B + x;
+    if (y >= B - HW) return HW * B + (y - (B - HW)) * B + x;
+    const int r = y - HW;                                     // middle rows: 2 * HW values per row
+    return 2 * HW * B + r * 2 * HW + (x < HW ? x : HW + (x - (B - HW)));
+}
+
+template <typename T, int K, int BX, int BY, int NT>
+__global__ void __launch_bounds__(NT)
+pi_adj2d_persist_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gframe_t, T* __restrict__ aframe_t,
+                        long frame_stride, T* __restrict__ g_h0, double* __restrict__ partials, int np,
+                        const T* __restrict__ P, TileGeom g, PersistArgs pa)
+{
+    static_assert(sizeof(T) == 4 && BX == BY, "float32, square tiles");
+    using TL = Tile<K, BX, BY>;
+    constexpr int HW = 2 * K, LXW = TL::LX;
+    constexpr int BANDH = BX * BX - (BX - 2 * HW) * (BX - 2 * HW);      // border values per species
+    constexpr int RINGH = LXW * LXW - BX * BX;                          // halo values per species
+    constexpr int NPUB = (2 * BANDH + NT - 1) / NT, NGAT = (2 * RINGH + NT - 1) / NT;
+    constexpr bool PRE = true;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* b0 = reinterpret_cast<T*>(smem_raw) + lds_pad0<T>::value;
+    T* b1 = reinterpret_cast<T*>(smem_raw) + 2 * TL::PLANE + lds_pad1<T>::value;
+    const int tile = tile_of_block(blockIdx.x, g);
+    const int tyi = tile / g.tiles_x, txi = tile % g.tiles_x, tiles_y = g.H / BY;
+    const int ty0 = tyi * BY, tx0 = txi * BX;
+    const int ntiles = g.tiles_x * tiles_y;
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    gu64* outbox = (gu64*)pa.outbox;
+
+    // ---- what this lane publishes / gathers in every hand-over (fixed geometry): tables in LDS, not registers -- the sub-steps
+    // hold 164 registers, and geometry + double accumulators on top of that spilled
+    // LDS: state buffers | [20][NT] doubles: the lane's moments of all groups so far | int tables
+    double* lacc = reinterpret_cast<double*>(smem_raw + tile_state_bytes<T, K, BX, BY>());
+    int* tab_pub = reinterpret_cast<int*>(lacc + 20 * NT);                  // [NPUB][NT]: LDS position of a border value
+    int* tab_gl = tab_pub + NPUB * NT;                                      // [NGAT][NT]: LDS position of a halo value
+    int* tab_gs = tab_gl + NGAT * NT;                                       // [NGAT][NT]: granule index inside a parity half
+#pragma unroll
+    for (int m = 0; m < 20; ++m) lacc[m * NT + (int)threadIdx.x] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NPUB; ++q) {
+        const int i = (int)threadIdx.x + q * NT;
+        int pl = -1;
+        if (i < 2 * BANDH) {
+            const int sp = i / BANDH, e = i - sp * BANDH;
+            int y, x;                                      // inverse of band_index
+            if (e < HW * BX) { y = e / BX; x = e - y * BX; }
+            else if (e < 2 * HW * BX) { const int m = e - HW * BX; y = BX - HW + m / BX; x = m % BX; }
+            else { const int m = e - 2 * HW * BX; y = HW + m / (2 * HW); const int c = m % (2 * HW); x = c < HW ? c : BX - 2 * HW + c; }
+            pl = sp * TL::PLANE + (HW + y) * LXW + HW + x;
+        }
+        tab_pub[q * NT + (int)threadIdx.x] = pl;
+    }
+#pragma unroll
+    for (int q = 0; q < NGAT; ++q) {
+        const int r = (int)threadIdx.x + q * NT;
+        int gl = -1, gs = 0;
+        if (r < 2 * RINGH) {
+            const int sp = r / RINGH, e = r - sp * RINGH;
+            int wy, wx;                                    // ring positions row-major over the window, skipping the centre
+            if (e < HW * LXW) { wy = e / LXW; wx = e - wy * LXW; }
+            else if (e < HW * LXW + BX * 2 * HW) { const int m = e - HW * LXW; wy = HW + m / (2 * HW); const int c = m % (2 * HW); wx = c < HW ? c : BX + c; }
+            else { const int m = e - HW * LXW - BX * 2 * HW; wy = HW + BX + m / LXW; wx = m % LXW; }
+            const int gy = ty0 + wy - HW, gx = tx0 + wx - HW;                       // global point (may wrap)
+            const int nty = ((gy + g.H) / BY) % tiles_y, ntx = ((gx + g.W) / BX) % g.tiles_x;
+            const int ly = (gy + g.H) % BY, lx = (gx + g.W) % BX;
+            gl = sp * TL::PLANE + wy * LXW + wx;
+            gs = (nty * g.tiles_x + ntx) * (2 * BANDH) + sp * BANDH + band_index<BX, HW>(ly, lx);
+        }
+        tab_gl[q * NT + (int)threadIdx.x] = gl;
+        tab_gs[q * NT + (int)threadIdx.x] = gs;
+    }
+
+    // ---- group 0 starts from the adjoint frame in memory (the top frame), like a launch of pi_adj2d_tile_kernel ----------
+    WindowLoader<T, K, BX, BY, NT> wl;
+    wl.issue(aframe_t, g, ty0, tx0);
+    StripOps<T> ops0;
+    StripAddr sa[K];
+    strip_addr_table<K, BX, BY, NT, 0>(sa, g, ty0, tx0);
+    adj_load_ops<T, K, BX, BY, NT, 0>(ops0, 0, hframe_t - frame_stride, gframe_t - frame_stride, g, ty0, tx0, &sa[0]);
+    wl.commit(b0);
+    lds_barrier();
+    double acc_c[2] = {0.0, 0.0};
+    bool failed = false;
+    TileMoments<T, true> mom;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int m = 0; m < 10; ++m) mom.a[s][m] = V2<T>{T(0), T(0)};
+    for (int grp = 0; grp < pa.ngroups; ++grp) {
+        const long go = -(long)grp * K * frame_stride;     // this group's frame t relative to the top frame
+        const bool last = grp + 1 == pa.ngroups;
+        // the last group hands its result to memory (frame t - K of the adjoint trajectory, or dL/dh0 itself)
+        adj_substeps<T, POLY, K, BX, BY, NT, 0, PRE, true>(b0, b1, hframe_t + go, gframe_t + go, aframe_t + go, frame_stride,
+                                                           (1u << K) - 1u, g_h0, g_h0 && last ? K : 0, g, ty0, tx0, P, acc_c, ops0,
+                                                           mom, sa, nullptr, last);
+        // the float32 2-vector moment sums (what a launch of the tile sweep carries over its K steps) are folded into the lane's
+        // double sums in LDS every fourth group -- plain read-add-write, the slot is the lane's own (ds_add_f64 processes about one
+        // lane per clock: 20 of them per lane and group were 5 us of a 10.7 us group)
+        if ((grp & 3) == 3 || last) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int m = 0; m < 10; ++m) {
+                    double* slot = lacc + (10 * s + m) * NT + (int)threadIdx.x;
+                    *slot += (double)mom_total(mom.a[s][m]);
+                    mom.a[s][m] = V2<T>{T(0), T(0)};
+                }
+        }
+        if (last) break;
+        // operands of the next group's first sub-step: requested now, they travel during the hand-over
+        const long gn = go - (long)K * frame_stride;
+        adj_load_ops<T, K, BX, BY, NT, 0>(ops0, 0, hframe_t + gn - frame_stride, gframe_t + gn - frame_stride, g, ty0, tx0, &sa[0]);
+        lds_barrier();                                     // sub-step K - 1 wrote buffer 0 (K even): everybody's strips are in
+        // ---- hand-over: publish my band, gather my ring ----
+        if (pa.dbg == 2) continue;
+        const unsigned epoch = (unsigned)grp + 1u;
+        gu64* half = outbox + (size_t)(epoch & 1u) * (size_t)ntiles * (2 * BANDH);
+        gu64* mine = half + (size_t)tile * (2 * BANDH);
+#pragma unroll
+        for (int q = 0; q < NPUB; ++q) {
+            const int pl = tab_pub[q * NT + (int)threadIdx.x];
+            if (pl >= 0) {
+                const unsigned v = __builtin_bit_cast(unsigned, b0[pl]);
+                __hip_atomic_store(mine + (int)threadIdx.x + q * NT, ((unsigned long long)epoch << 32) | v, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        int gl[NGAT], gs[NGAT];
+#pragma unroll
+        for (int q = 0; q < NGAT; ++q) { gl[q] = tab_gl[q * NT + (int)threadIdx.x]; gs[q] = tab_gs[q * NT + (int)threadIdx.x]; }
+        unsigned gv[NGAT];
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < NGAT; ++q)
+                if (gl[q] >= 0) {
+                    const unsigned long long x = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gv[q] = (unsigned)x;
+                    ok &= (unsigned)(x >> 32) == epoch;
+                }
+            if (__all(ok) || pa.dbg == 1) break;
+            if (wall_clock64() - t0 > pa.timeout_ticks) { failed = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int q = 0; q < NGAT; ++q)
+            if (gl[q] >= 0) b0[gl[q]] = failed ? __builtin_bit_cast(T, 0x7fc00000u) : __builtin_bit_cast(T, gv[q]);
+        lds_barrier();
+    }
+    if (failed && threadIdx.x % WAVE == 0) atomicAdd(pa.error, 1);
+
+    // ---- once per rollout: diffusion-coefficient sums and the 20 moments of this tile -> its partial row -------------------
+    lds_barrier();
+    double* red = reinterpret_cast<double*>(smem_raw);     // state buffers are dead now: [2][NT / WAVE] doubles
+    constexpr int NW = NT / WAVE;
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const double r = wave_sum_to_last(acc_c[s]);
+        if (lane == REDUCE_LANE) red[s * NW + wave] = r;
+    }
+    lds_barrier();
+    if (threadIdx.x < 2) {
+        double sum = 0.0;
+        for (int w = 0; w < NW; ++w) sum += red[(int)threadIdx.x * NW + w];
+        partials[(long)blockIdx.x * np + P_COEF + (int)threadIdx.x] += sum;
+    }
+    // the moments sit transposed in LDS ([moment][lane], complete: the barrier above waited for the LDS adds): 16 lanes per
+    // moment add NT / 16 of them each and fold with four DPP steps (as the float64 tile sweep does)
+    if (threadIdx.x < 320) {
+        const int mm = (int)threadIdx.x >> 4, part = (int)threadIdx.x & 15;
+        const double* row = lacc + mm * NT + part;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NT; k += 64) {
+            const double v0 = row[k], v1 = row[k + 16], v2 = row[k + 32], v3 = row[k + 48];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        double a = (a0 + a1) + (a2 + a3);
+        a += dpp_mov<0x111, 0xF>(a);
+        a += dpp_mov<0x112, 0xF>(a);
+        a += dpp_mov<0x114, 0xF>(a);
+        a += dpp_mov<0x118, 0xF>(a);
+        if (part == 15) partials[(long)blockIdx.x * np + P_W + mm] += a;
+    }
 }
 
 }  // namespace pi

@@ -671,7 +671,7 @@ def test_peer_mailbox_exchange_to_self(hip_device):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("opts", [{"tile": 0}, {"tile_xcd": 0}, {"tile_k": 2}, {"tile_k": 4, "tile_nt": 256},
                                   {"tile_k": 4, "tile_nt": 512}, {"tile_k": 4, "tile_nt": 1024}, {"tile_k": 8}, {"tile_by": 8}, {"tile_by": 16}, {"tile_by": 32}, {"vec": 1},
-                                  {"tile_wide": 1}, {"tile_wide": 2}])
+                                  {"tile_wide": 1}, {"tile_wide": 2}, {"tile_persist": 0}])
 @pytest.mark.parametrize("dtype,hc", [(np.float32, 8), (np.float32, 2), (np.float64, 4), (np.float32, 0),
                                       (np.float64, 0)])
 @pytest.mark.parametrize("shape", [(64, 96), (40, 100), (128, 256)])
@@ -687,7 +687,7 @@ def test_tile_variants_bitwise(opts, dtype, hc, shape, hip_device):
     gt = rs.uniform(-1, 1, (T + 1, 2) + shape).astype(dtype)
     ref = o_rollout_fwd(h0, P, T)
     g0_ref, pg_ref = o_rollout_bwd(ref, gt, P)
-    defaults = {"tile": 1, "tile_k": 4, "tile_nt": 512, "tile_by": 0, "vec": 0, "tile_xcd": 1, "tile_wide": 3}
+    defaults = {"tile": 1, "tile_k": 4, "tile_nt": 512, "tile_by": 0, "vec": 0, "tile_xcd": 1, "tile_wide": 3, "tile_persist": 1}
     try:
         for k, v in opts.items():
             pa.set_option(k, v)
@@ -1096,6 +1096,7 @@ def test_physics_loss_vs_reference(fn, hip_device):
 def test_physics_residual_gradcheck_fp64(hip_device):
     import percnn_amd as pa
     from percnn_amd import physics
+    torch.manual_seed(11)                                  # (unseeded inputs made the finite-difference check flaky once in ~10 runs)
     cell = pa.lo2d_cell().to(hip_device)
     Q = physics.lambda_omega_block(cell, 0.1)
     traj = torch.rand((4, 2, 6, 8), dtype=torch.float64, device=hip_device, requires_grad=True)
