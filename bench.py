@@ -241,6 +241,7 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
                  "direct": "pi_bwd_kernel", "advective": "pi_adv_bwd_kernel"}
     fwd_kernel = fwd_names[plan["fwd"]]
     bwd_kernel = bwd_names[plan["bwd"]] + (("<sweep+moments>" if fused else "") if tiled else ("<sweep+moments>" if fused else "<sweep>"))
+    persistent = bool(plan.get("bwd_persistent")) and tiled and fused and not opts.get("tile_persist") == "0" and T // K >= 2
     if fused:
         sweep_ms, red_ms = bwd_ms, 1e-6
     clock = "HIP events on the launch stream, this run (fwd / bwd phases of every pass; sweep alone via options=skip_wgrad)"
@@ -254,6 +255,12 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
     ]
     if fused:
         kernels.pop()                                   # no separate reduction launch
+    if persistent:
+        # the whole tile sweep of the rollout is ONE launch of resident workgroups (pi_adj2d_persist_kernel): T // K groups of
+        # K steps inside it; the < K remaining steps (none at T = 1000) run on the direct kernels
+        kernels[1] = {"kernel": "pi_adj2d_persist_kernel<sweep+moments, %d groups of %d steps per launch>" % (T // K, K),
+                      "launches_per_pass": 1, "algorithmic_bytes_per_launch": 4 * Cs * npts * (T // K) * K,
+                      "avg_launch_us": sweep_ms * 1e3}
     for k in kernels:
         k["achieved"] = k["algorithmic_bytes_per_launch"] / (k["avg_launch_us"] * 1e-6) / 1e9
         k["frac"] = k["achieved"] / HBM_PEAK_GBS
@@ -263,7 +270,10 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
     traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, "profiles", f"traffic_{name}.json")
     if os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get(dom["kernel"].split("<")[0])
+        tj = json.load(open(tfile))
+        traffic = tj.get(dom["kernel"].split("<")[0])
+        if dom["kernel"].startswith("pi_adj2d_persist_kernel") and tj.get("pi_adj2d_persist_kernel_per_group"):
+            traffic = tj["pi_adj2d_persist_kernel_per_group"] * (T // K)        # measured at T = 100: per group of K steps
         traffic_source = (f"profiles/traffic_{name}.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, "
                           "collected in separate passes on MI355X and committed (not re-measured in this run)")
     res = {

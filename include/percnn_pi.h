@@ -298,10 +298,11 @@ typedef struct percnn_pi_halo_ring {
  * planes per pass of the adjoint, workgroup size} */
 int percnn_pi_debug_blockmap(int ndim, const int64_t* shape, int elem_size, const char* options, int* out);
 /* Host-only: which kernel family a rollout of this problem takes (the library's own dispatch rules, for 16-byte-aligned
- * buffers).  out[14] = {forward family, adjoint family, 1 if the parameter gradients are reduced inside the sweep launches,
+ * buffers).  out[15] = {forward family, adjoint family, 1 if the parameter gradients are reduced inside the sweep launches,
  * time steps per forward launch, per adjoint launch, planes per pass forward, adjoint, lanes per brick workgroup or 0,
  * 2D tile width, tile height, lanes per tile workgroup of the adjoint sweep (0: no tile kernels), the same three of the
- * forward}; families: 0 direct step kernels,
+ * forward, 1 if the tile sweep of a long rollout without frame mask runs as ONE launch of resident workgroups (option
+ * tile_persist; asks the current device for its CU count -- 0 without a device)}; families: 0 direct step kernels,
  * 1 2D tile kernels, 2 3D plane streaming, 3 3D brick kernels, 4 advective block. */
 int percnn_pi_debug_plan(int hc, int ndim, const int64_t* shape, int elem_size, const char* options, int* out);
 

@@ -251,13 +251,13 @@ FAMILIES = {0: "direct", 1: "tile2d", 2: "stream3d", 3: "brick3d", 4: "advective
 
 def rollout_plan(hc: int, shape, elem_size: int, options=None) -> dict:
     """Kernel families a rollout of this problem runs on (the library's own dispatch, ``percnn_pi_debug_plan``)."""
-    out = (ctypes.c_int * 14)()
+    out = (ctypes.c_int * 15)()
     check(lib().percnn_pi_debug_plan(int(hc), len(shape), shape_arg(shape), int(elem_size), options_arg(options), out),
           "debug_plan")
     return {"fwd": FAMILIES[out[0]], "bwd": FAMILIES[out[1]], "fused_gradients": bool(out[2]), "fwd_steps_per_launch": out[3],
             "bwd_steps_per_launch": out[4], "fwd_planes_per_pass": out[5], "bwd_planes_per_pass": out[6],
             "brick_lanes": out[7], "tile": (out[8], out[9], out[10]) if out[10] else None,
-            "tile_fwd": (out[11], out[12], out[13]) if out[13] else None}
+            "tile_fwd": (out[11], out[12], out[13]) if out[13] else None, "bwd_persistent": bool(out[14])}
 
 
 def set_option(key: str, value: int) -> None:

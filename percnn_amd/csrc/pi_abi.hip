@@ -52,7 +52,6 @@ struct Options {
                             // CUs: calls on other streams of this process are detected and take the launch-per-group path;
                             // processes that share one GPU must set 0); 1 = cooperative launch (residency guaranteed by the
                             // runtime, but ~0.4 ms per launch on ROCm 7.2: slower than what it saves at T = 1000); 0 = off
-    int persist_dbg = 0;    // timing experiments on the persistent sweep (WRONG results): see pi::PersistArgs::dbg
     int tile_wide = 3;      // float32 poly blocks: 3 = 32x40 / 40x40 tiles where they keep the grid in one round (tile_wide_for),
                             // 0 = never, 1 / 2 = force 32x40 / 40x40
     int fwd_blocks = 0;     // direct forward kernel: grid cap (0 = none; measured: a bounded persistent grid loses, 384^3 376 -> 416 us)
@@ -1176,7 +1175,7 @@ hipError_t launch_adj_persist(const T* hframe_t, const T* gframe_t, T* aframe_t,
     if (hipError_t e = hipMemsetAsync(outbox, 0, persist_outbox_bytes(p), st)) return e;
     long frame_stride = (long)(2 * p.n);
     int np = pi::nparams(p.hc);
-    pi::PersistArgs pa{outbox, error, ngroups, 200000000ull /* 2 s of the 100 MHz clock */, p.opt.persist_dbg};
+    pi::PersistArgs pa{outbox, error, ngroups, 200000000ull /* 2 s of the 100 MHz clock */};
     void* args[] = {(void*)&hframe_t, (void*)&gframe_t, (void*)&aframe_t, (void*)&frame_stride, (void*)&g_h0, (void*)&partials,
                     (void*)&np, (void*)&P, (void*)&g, (void*)&pa};
     if (p.opt.tile_persist == 2) {                          // plain launch: one workgroup per CU fits, nothing else must hold CUs
@@ -2063,7 +2062,6 @@ int apply_option(Options& o, const char* key, long value)
         o.tile_persist = (int)value;
         return 0;
     }
-    if (!std::strcmp(key, "persist_dbg")) { o.persist_dbg = (int)value; return 0; }
     if (!std::strcmp(key, "tile_wide")) {
         if (value < 0 || value > 3) return PERCNN_PI_EINVAL;
         o.tile_wide = (int)value;
@@ -2268,7 +2266,8 @@ namespace {
 // rules, evaluated for 16-byte-aligned buffers (bench.py labels its roofline entries with it instead of mirroring the rules).
 // out = {forward family, adjoint family, gradients reduced inside the sweep launches (0 / 1), time steps per forward launch,
 //        per adjoint launch, planes per pass forward, adjoint, lanes per brick workgroup (0: no bricks), 2D tile width,
-//        height, lanes per tile workgroup of the adjoint (0: no tiles), the same three of the forward}; families: 0 direct, 1 2D tiles, 2 plane streaming, 3 3D bricks,
+//        height, lanes per tile workgroup of the adjoint (0: no tiles), the same three of the forward, 1 if the tile sweep of a
+//        long unmasked rollout runs as ONE persistent launch}; families: 0 direct, 1 2D tiles, 2 plane streaming, 3 3D bricks,
 //        4 advective block
 template <typename T>
 int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options, int* out)
@@ -2300,7 +2299,9 @@ int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options,
     out[3] = out[0] == 1 ? K : 1;
     out[4] = out[1] == 1 ? K : 1;
     out[7] = (out[0] == 3 || out[1] == 3) ? brick_nt_for(p, vec) : 0;     // lanes per brick workgroup
-    for (int i = 8; i < 14; ++i) out[i] = 0;
+    for (int i = 8; i < 15; ++i) out[i] = 0;
+    // the whole tile sweep as one launch of resident workgroups (needs a device to ask for its CU count: 0 without one)
+    if constexpr (sizeof(T) == 4) out[14] = (out[1] == 1 && persist_ok<T>(p, nullptr, 1 << 20, nullptr)) ? 1 : 0;
     for (int dir = 0; dir < 2; ++dir) {                                    // 2D tiles: width, height, lanes per workgroup
         if (out[dir] != 1) continue;
         const TileShape ts = tile_shape_for<T>(p, dir == 1);

@@ -983,7 +983,6 @@ struct PersistArgs {
     int* error;                    // != 0: a gather timed out (neighbour not resident?) -- outputs are poisoned
     int ngroups;                   // groups of K steps run here: frames t_top .. t_top - K * ngroups
     unsigned long long timeout_ticks;
-    int dbg;                       // timing experiments only (wrong results): 1 = gather without waiting for the tags, 2 = no hand-over
 };
 
 template <int B, int HW>
@@ -1103,7 +1102,6 @@ pi_adj2d_persist_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gf
         adj_load_ops<T, K, BX, BY, NT, 0>(ops0, 0, hframe_t + gn - frame_stride, gframe_t + gn - frame_stride, g, ty0, tx0, &sa[0]);
         lds_barrier();                                     // sub-step K - 1 wrote buffer 0 (K even): everybody's strips are in
         // ---- hand-over: publish my band, gather my ring ----
-        if (pa.dbg == 2) continue;
         const unsigned epoch = (unsigned)grp + 1u;
         gu64* half = outbox + (size_t)(epoch & 1u) * (size_t)ntiles * (2 * BANDH);
         gu64* mine = half + (size_t)tile * (2 * BANDH);
@@ -1130,7 +1128,7 @@ pi_adj2d_persist_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gf
                     gv[q] = (unsigned)x;
                     ok &= (unsigned)(x >> 32) == epoch;
                 }
-            if (__all(ok) || pa.dbg == 1) break;
+            if (__all(ok)) break;
             if (wall_clock64() - t0 > pa.timeout_ticks) { failed = true; break; }
             __builtin_amdgcn_s_sleep(1);
         }

@@ -16,12 +16,17 @@ for line in open(src):
                 any(l.startswith(wl + " ") and "pi_adj2d_tile_kernel" in l and ", true>" in l for l in open(src)):
             kern = "pi_adj2d_tile_kernel_sweep_only"
         rows.setdefault(wl, {}).setdefault(kern, {})[ctr] = float(avg) * 1024.0
+        rows[wl]["_T"] = int(T)
 for wl, kernels in rows.items():
     out = {"_source": f"{src} (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --workload {wl} --T 100)",
            "_note": "bytes per launch. FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane coalesced reads "
                     "(verified on pi_moments_kernel: raw FETCH = 0.49 x the 16 B/point-step it streams)", "detail": {}}
+    T_run = kernels.pop("_T", 100)
     for k, v in kernels.items():
         f, w = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
+        if k == "pi_adj2d_persist_kernel":
+            # ONE launch per rollout (T // 4 groups of 4 steps inside): bench.py scales the per-group bytes to its own T
+            out["pi_adj2d_persist_kernel_per_group"] = (2 * f + w) / max(1, T_run // 4)
         out["detail"][k] = {"fetch_raw_bytes": f, "fetch_corrected_bytes": 2 * f, "write_bytes": w, "hbm_bytes_per_launch": 2 * f + w}
         if k in ("pi_adj2d_tile_kernel", "pi_fwd2d_tile_kernel", "pi_fwd_kernel", "pi_bwd_kernel", "pi_fwd3d_brick_kernel",
                  "pi_adj3d_brick_kernel", "pi_stream3d_kernel"):
