@@ -140,6 +140,15 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *   "tile_fuse"    1 (default): the pre-contracted tile sweep with 32x32 tiles reduces the 20 coefficient moments itself
  *                  and stores only every K-th adjoint frame (no separate moments pass; float32: register accumulators,
  *                  float64: per-lane accumulators in LDS updated with ds_add_f64); 0: split schedule
+ *   "tile_persist" 2 (default): where it applies (float32 pre-contracted blocks, whole 32x32 tiles, 16 .. #CUs tiles, no frame
+ *                  mask, >= 8 steps) the whole tile sweep of percnn_pi_rollout_bwd_* runs as ONE launch of resident workgroups
+ *                  that keep the adjoint tile in LDS and hand their halos over through device memory (512^2: 218 -> 235 k
+ *                  steps/s).  One workgroup fills a CU's LDS, so the grid is resident unless ANOTHER kernel holds whole CUs:
+ *                  calls on other streams of the process are detected and use one launch per K steps; a hand-over that waits
+ *                  longer than 2 s fills its halo with NaNs instead of hanging.  PROCESSES THAT SHARE ONE GPU MUST SET 0.
+ *                  1 = the same through hipLaunchCooperativeKernel (residency guaranteed, +0.4 ms per launch); 0 = off
+ *   "tile_wide"    3 (default): float32 pre-contracted blocks past 512^2 use 32x40 / 40x40 tiles while that keeps the grid in
+ *                  one resident round; 0 never; 1 / 2 force a shape
  *   "rz"           direct 3D kernels, pre-contracted blocks: consecutive planes per workgroup pass that share their plane
  *                  neighbours in registers (1, 2, 4; default 0 = by grid size: large grids 4 forward / 2 backward)
  *   "block_small"  1 (default): 128-thread workgroups for the direct kernels on grids below ~1 M points
