@@ -1107,9 +1107,10 @@ size_t persist_outbox_bytes(const Problem& p)
 
 // can the tile sweep of this rollout run as one cooperative launch?  (everything the kernel assumes, checked here)
 template <typename T>
-bool persist_ok(const Problem& p, const unsigned char* mask, int ngroups, hipStream_t st)
+bool persist_ok(const Problem& p, const unsigned char* mask, int t_top, int ngroups, hipStream_t st)
 {
-    if (!p.opt.tile_persist || sizeof(T) != 4 || mask || ngroups < 2) return false;
+    if (!p.opt.tile_persist || sizeof(T) != 4 || ngroups < 2) return false;
+    if (mask && t_top >= 4096) return false;                 // the frame mask travels as a kernel argument (4096 bits)
     if (!tile_fuse_ok<T>(p) || tile_wide_for<T>(p, true) != 0 || tile_by_for(p) != TILE_B) return false;
     if (p.n0 % TILE_B || p.W % TILE_B) return false;
     const int64_t tiles = (p.n0 / TILE_B) * (p.W / TILE_B);
@@ -1152,8 +1153,9 @@ void persist_leave(hipStream_t st, int dev)
 // (or whatever the runtime says) WITHOUT having launched anything if the workgroups cannot all be resident: the caller then
 // runs the launch-per-group path.
 template <typename T>
-hipError_t launch_adj_persist(const T* hframe_t, const T* gframe_t, T* aframe_t, T* g_h0, int ngroups, double* partials,
-                              unsigned long long* outbox, int* error, const T* P, const Problem& p, hipStream_t st)
+hipError_t launch_adj_persist(const T* hframe_t, const T* gframe_t, T* aframe_t, T* g_h0, int t_top, const unsigned char* mask,
+                              int ngroups, double* partials, unsigned long long* outbox, int* error, const T* P,
+                              const Problem& p, hipStream_t st)
 {
     constexpr int K = 4, NT = 512;
     using TL = pi::Tile<K, TILE_B, TILE_B>;
@@ -1175,7 +1177,14 @@ hipError_t launch_adj_persist(const T* hframe_t, const T* gframe_t, T* aframe_t,
     if (hipError_t e = hipMemsetAsync(outbox, 0, persist_outbox_bytes(p), st)) return e;
     long frame_stride = (long)(2 * p.n);
     int np = pi::nparams(p.hc);
-    pi::PersistArgs pa{outbox, error, ngroups, 200000000ull /* 2 s of the 100 MHz clock */};
+    pi::PersistArgs pa{};
+    pa.outbox = outbox; pa.error = error; pa.ngroups = ngroups;
+    pa.timeout_ticks = 200000000ull;                        // 2 s of the 100 MHz clock
+    pa.t_top = t_top;
+    pa.masked = mask ? 1 : 0;
+    if (mask)
+        for (int t = 0; t < t_top && t < 4096; ++t)
+            if (mask[t]) pa.frames[t >> 5] |= 1u << (t & 31);
     void* args[] = {(void*)&hframe_t, (void*)&gframe_t, (void*)&aframe_t, (void*)&frame_stride, (void*)&g_h0, (void*)&partials,
                     (void*)&np, (void*)&P, (void*)&g, (void*)&pa};
     if (p.opt.tile_persist == 2) {                          // plain launch: one workgroup per CU fits, nothing else must hold CUs
@@ -1821,7 +1830,7 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
         // lives in the three adjoint frames between the hand-over frame and the group above it, which nobody touches then
         if constexpr (sizeof(T) == 4) {
             const int ngroups = K == 4 ? t_cur / K : 0;
-            if (tile_fused && ngroups >= 2 && persist_ok<T>(p, mask, ngroups, st) &&
+            if (tile_fused && ngroups >= 2 && persist_ok<T>(p, mask, t_cur, ngroups, st) &&
                 persist_outbox_bytes(p) <= (size_t)(K - 1) * frame_bytes) {
                 const int t_end = t_cur - K * ngroups;
                 auto* outbox = reinterpret_cast<unsigned long long*>(adj + (size_t)(t_end + 1) * frame);
@@ -1829,8 +1838,8 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
                 int pdev = 0;
                 if (persist_enter(st, pdev)) {
                     const hipError_t e = launch_adj_persist<T>(traj + (size_t)t_cur * frame, g_traj + (size_t)t_cur * frame,
-                                                               adj + (size_t)t_cur * frame, t_end == 0 ? g_h0 : nullptr, ngroups,
-                                                               w.partials, outbox, err, P, p, st);
+                                                               adj + (size_t)t_cur * frame, t_end == 0 ? g_h0 : nullptr, t_cur,
+                                                               mask, ngroups, w.partials, outbox, err, P, p, st);
                     if (e == hipSuccess) { t_cur = t_end; persist_leave(st, pdev); }
                     else (void)hipGetLastError();           // not resident / not supported: the launch-per-group path below
                 }
@@ -2301,7 +2310,7 @@ int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options,
     out[7] = (out[0] == 3 || out[1] == 3) ? brick_nt_for(p, vec) : 0;     // lanes per brick workgroup
     for (int i = 8; i < 15; ++i) out[i] = 0;
     // the whole tile sweep as one launch of resident workgroups (needs a device to ask for its CU count: 0 without one)
-    if constexpr (sizeof(T) == 4) out[14] = (out[1] == 1 && persist_ok<T>(p, nullptr, 1 << 20, nullptr)) ? 1 : 0;
+    if constexpr (sizeof(T) == 4) out[14] = (out[1] == 1 && persist_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr)) ? 1 : 0;
     for (int dir = 0; dir < 2; ++dir) {                                    // 2D tiles: width, height, lanes per workgroup
         if (out[dir] != 1) continue;
         const TileShape ts = tile_shape_for<T>(p, dir == 1);

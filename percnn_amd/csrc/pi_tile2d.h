@@ -974,7 +974,7 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
 // workgroup: gathers its 2K-wide halo ring from the eight neighbours' bands (polling until every tag matches) around the tile
 // it kept in LDS, runs the K sub-steps of pi_adj2d_tile_kernel (same device functions, same arithmetic: dL/dh0 bit-identical),
 // publishes the 2K-wide border band of its tile.  The 20 coefficient moments are folded into double registers once per group
-// and reduced ONCE per rollout.  Whole 32 x 32 tiles, float32 pre-contracted blocks, every frame carries a gradient (no mask).
+// and reduced ONCE per rollout.  Whole 32 x 32 tiles, float32 pre-contracted blocks; frame masks up to 4096 frames (kernel argument).
 // Double-buffered by group parity; why that suffices: my publish of group e + 2 comes after my gather of e + 1, which saw the
 // neighbour's band e + 1, which it published after ITS gather of e -- the last read of the slot I am about to overwrite.
 // ------------------------------------------------------------------------------------------------
@@ -983,7 +983,24 @@ struct PersistArgs {
     int* error;                    // != 0: a gather timed out (neighbour not resident?) -- outputs are poisoned
     int ngroups;                   // groups of K steps run here: frames t_top .. t_top - K * ngroups
     unsigned long long timeout_ticks;
+    int t_top;                     // frame number of the top frame (group g covers frames t_top - K g - 1 ... t_top - K g - K)
+    int masked;                    // 1: only the frames whose bit is set in `frames` carry a gradient (RCNN.observe's strided loss)
+    unsigned frames[128];          // bit t of word t / 32: frame t carries a gradient (t < 4096)
 };
+
+// injection mask of the K steps below frame t: bit q = frame t - 1 - q carries a gradient
+template <int K>
+__device__ __forceinline__ unsigned persist_mask(const PersistArgs& pa, int t)
+{
+    if (!pa.masked) return (1u << K) - 1u;
+    unsigned m = 0;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        const int f = t - 1 - q;
+        m |= ((pa.frames[f >> 5] >> (f & 31)) & 1u) << q;
+    }
+    return m;
+}
 
 template <int B, int HW>
 __device__ __forceinline__ int band_index(int y, int x)      // position inside the tile -> index inside its border band
@@ -1066,7 +1083,9 @@ pi_adj2d_persist_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gf
     StripOps<T> ops0;
     StripAddr sa[K];
     strip_addr_table<K, BX, BY, NT, 0>(sa, g, ty0, tx0);
-    adj_load_ops<T, K, BX, BY, NT, 0>(ops0, 0, hframe_t - frame_stride, gframe_t - frame_stride, g, ty0, tx0, &sa[0]);
+    unsigned gmask = persist_mask<K>(pa, pa.t_top);
+    adj_load_ops<T, K, BX, BY, NT, 0>(ops0, 0, hframe_t - frame_stride, gmask & 1u ? gframe_t - frame_stride : nullptr, g, ty0, tx0,
+                                      &sa[0]);
     wl.commit(b0);
     lds_barrier();
     double acc_c[2] = {0.0, 0.0};
@@ -1081,7 +1100,7 @@ pi_adj2d_persist_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gf
         const bool last = grp + 1 == pa.ngroups;
         // the last group hands its result to memory (frame t - K of the adjoint trajectory, or dL/dh0 itself)
         adj_substeps<T, POLY, K, BX, BY, NT, 0, PRE, true>(b0, b1, hframe_t + go, gframe_t + go, aframe_t + go, frame_stride,
-                                                           (1u << K) - 1u, g_h0, g_h0 && last ? K : 0, g, ty0, tx0, P, acc_c, ops0,
+                                                           gmask, g_h0, g_h0 && last ? K : 0, g, ty0, tx0, P, acc_c, ops0,
                                                            mom, sa, nullptr, last);
         // the float32 2-vector moment sums (what a launch of the tile sweep carries over its K steps) are folded into the lane's
         // double sums in LDS every fourth group -- plain read-add-write, the slot is the lane's own (ds_add_f64 processes about one
@@ -1099,7 +1118,9 @@ pi_adj2d_persist_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gf
         if (last) break;
         // operands of the next group's first sub-step: requested now, they travel during the hand-over
         const long gn = go - (long)K * frame_stride;
-        adj_load_ops<T, K, BX, BY, NT, 0>(ops0, 0, hframe_t + gn - frame_stride, gframe_t + gn - frame_stride, g, ty0, tx0, &sa[0]);
+        gmask = persist_mask<K>(pa, pa.t_top - K * (grp + 1));
+        adj_load_ops<T, K, BX, BY, NT, 0>(ops0, 0, hframe_t + gn - frame_stride, gmask & 1u ? gframe_t + gn - frame_stride : nullptr, g,
+                                          ty0, tx0, &sa[0]);
         lds_barrier();                                     // sub-step K - 1 wrote buffer 0 (K even): everybody's strips are in
         // ---- hand-over: publish my band, gather my ring ----
         const unsigned epoch = (unsigned)grp + 1u;
