@@ -140,8 +140,8 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *   "tile_fuse"    1 (default): the pre-contracted tile sweep with 32x32 tiles reduces the 20 coefficient moments itself
  *                  and stores only every K-th adjoint frame (no separate moments pass; float32: register accumulators,
  *                  float64: per-lane accumulators in LDS updated with ds_add_f64); 0: split schedule
- *   "tile_persist" 2 (default): where it applies (float32 pre-contracted blocks, whole 32x32 tiles, 16 .. #CUs tiles, no frame
- *                  mask, >= 8 steps) the whole tile sweep of percnn_pi_rollout_bwd_* runs as ONE launch of resident workgroups
+ *   "tile_persist" 2 (default): where it applies (float32 pre-contracted blocks, whole 32x32 tiles, 16 .. #CUs tiles, >= 8
+ *                  steps, frame masks up to 4096 frames) the whole tile sweep of percnn_pi_rollout_bwd_* runs as ONE launch of resident workgroups
  *                  that keep the adjoint tile in LDS and hand their halos over through device memory (512^2: 218 -> 235 k
  *                  steps/s).  One workgroup fills a CU's LDS, so the grid is resident unless ANOTHER kernel holds whole CUs:
  *                  calls on other streams of the process are detected and use one launch per K steps; a hand-over that waits

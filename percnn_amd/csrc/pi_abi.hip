@@ -46,7 +46,7 @@ struct Options {
     int slab_fused_put_adj = 0; // ... and the adjoint sweep's faces by the sweep launch (to self: no gain; across xGMI: bench.py decides)
     int peer_upb = 2048;    // mailbox put / take launches: 16-byte units per workgroup and species (peer_prepare)
     int peer_upb_take = 0;  // ... of the take alone (0 = as the put)
-    int tile_persist = 2;   // float32 poly blocks on whole 32 x 32 tiles, <= one tile per CU, no frame mask: the whole tile sweep
+    int tile_persist = 2;   // float32 poly blocks on whole 32 x 32 tiles, <= one tile per CU: the whole tile sweep
                             // of a rollout in ONE launch of resident workgroups (pi_adj2d_persist_kernel).  2 = plain launch (one
                             // workgroup fills a CU's LDS, so a grid of <= #CUs is resident as long as no OTHER kernel holds whole
                             // CUs: calls on other streams of this process are detected and take the launch-per-group path;
