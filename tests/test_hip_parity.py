@@ -711,6 +711,39 @@ def test_tile_variants_bitwise(opts, dtype, hc, shape, hip_device):
             pa.set_option(k, v)
 
 
+@pytest.mark.parametrize("shape,T", [((384, 384), 23), ((384, 512), 9), ((512, 512), 41)])
+def test_persistent_sweep_equals_launch_per_group(shape, T, hip_device):
+    """The whole tile sweep as ONE launch of resident workgroups (pi_adj2d_persist_kernel, option tile_persist): dL/dh0 is the
+    launch-per-group sweep's bit for bit (same device functions, the halo travels through tagged granules instead of a kernel
+    boundary), the parameter gradients agree to summation round-off; dense dL/dtraj, a frame mask, and T not a multiple of K
+    (the remaining steps run on the direct kernels)."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    assert _lib.rollout_plan(0, shape, 4)["bwd_persistent"] and not _lib.rollout_plan(0, shape, 4, "tile_persist=0")["bwd_persistent"]
+    assert not _lib.rollout_plan(0, (100, 100), 4)["bwd_persistent"] and not _lib.rollout_plan(0, shape, 8)["bwd_persistent"]
+    rs = np.random.RandomState(4)
+    P = dev_t(random_block(0, 2, np.float32, 21, scale=0.1), hip_device)
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=hip_device)
+    traj[0] = dev_t(rs.uniform(0, 1, (2,) + shape).astype(np.float32), hip_device)
+    pa.rollout_fwd_(traj, P)
+    assert torch.isfinite(traj[-1]).all()
+    g = torch.randn(traj.shape, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(1)) / traj[0].numel()
+    for mask in (None, [t % 3 != 1 for t in range(T + 1)], [t == T or t % 5 == 0 for t in range(T + 1)]):
+        a0, ag = pa.rollout_bwd(traj, g, P, frame_mask=mask)
+        b0, bg = pa.rollout_bwd(traj, g, P, frame_mask=mask, options={"tile_persist": 0})
+        assert torch.equal(a0, b0)
+        assert rel_l2(ag.cpu().numpy(), bg.cpu().numpy()) < 2e-6
+    # twice in a row on two streams: the second call finds the first one's event and must not start a second resident grid
+    s2 = torch.cuda.Stream(device=hip_device)
+    a0, ag = pa.rollout_bwd(traj, g, P)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s2):
+        c0, cg = pa.rollout_bwd(traj, g, P)
+    d0, dg = pa.rollout_bwd(traj, g, P)
+    torch.cuda.synchronize()
+    assert torch.equal(a0, c0) and torch.equal(a0, d0)
+
+
 @pytest.mark.parametrize("shape,tile", [((544, 544), (32, 40, 640)), ((640, 640), (40, 40, 768)), ((560, 600), (40, 40, 768)),
                                         ((520, 536), (32, 40, 640))])
 def test_wide_tiles_past_512_bitwise(shape, tile, hip_device):
