@@ -70,6 +70,11 @@ extern "C" {
 #define PERCNN_PI_EWORKSPACE (-2) /* workspace smaller than *_workspace_bytes says */
 #define PERCNN_PI_ETOOLARGE (-3)  /* grid beyond the 32-bit byte offsets of the step kernels: a 2D field (+ 4 rows) or a 3D
                                    * plane of 4 GiB or more per species (e.g. 32768^2 float32); nothing was launched */
+#define PERCNN_PI_EASYNC (-4)     /* an EARLIER call's persistent tile sweep (option "tile_persist", launched with
+                                   * "persist_handshake=0") aborted on the device: the outputs of that call are invalid.  Reported
+                                   * once, by the first entry point called after the abort; nothing was launched by this call.
+                                   * percnn_pi_persist_status tells where.  (With the handshake -- the default -- an aborted sweep is
+                                   * re-run launch by launch inside the same call and no error is ever reported.) */
 
 /* ABI version of the loaded library (== PERCNN_PI_ABI_VERSION it was built with). */
 int percnn_pi_abi_version(void);
@@ -107,6 +112,22 @@ int percnn_pi_pack_fwd_f32(const percnn_pi_param_ptrs* params, int hc, int ndim,
                            int contract, float* block, void* stream);
 int percnn_pi_pack_fwd_f64(const percnn_pi_param_ptrs* params, int hc, int ndim, double dt, double mu_up, int sigmoid,
                            int contract, double* block, void* stream);
+/* ... with the CONDITIONING GUARD of the pre-contracted form: the reference evaluates Wh4(Wh1*Wh2*Wh3) literally
+ * (train_2drd.py:115-116); the expanded cubic the `contract` block holds cancels its monomials only to rounding, so its
+ * per-step noise relative to the state is eps * A,  A = |dt| * max_s sum_m |c[s][m]| phi_m(u_max, v_max) / max(u_max, v_max).
+ * The launch writes {A, seq} (A first, then seq with release semantics) to `host_slot`, two doubles of HOST-MAPPED memory
+ * (percnn_pi_host_words_alloc), whether it packs the contracted or the factored block -- the caller reads them without
+ * synchronising and packs the factored block while A is above its bound (float32: 10, float64: 1e4; RCNNCell.param_block). */
+int percnn_pi_pack_fwd_guard_f32(const percnn_pi_param_ptrs* params, int hc, int ndim, double dt, double mu_up, int sigmoid,
+                                 int contract, float* block, double u_max, double v_max, double* host_slot, double seq,
+                                 void* stream);
+int percnn_pi_pack_fwd_guard_f64(const percnn_pi_param_ptrs* params, int hc, int ndim, double dt, double mu_up, int sigmoid,
+                                 int contract, double* block, double u_max, double v_max, double* host_slot, double seq,
+                                 void* stream);
+/* `bytes` of zeroed host memory mapped into the device's address space (hipHostMalloc, coherent): written by kernels with
+ * system-scope stores, read by the host with plain loads.  Returns 0 or a hipError_t. */
+int percnn_pi_host_words_alloc(void** p, size_t bytes);
+int percnn_pi_host_words_free(void* p);
 int percnn_pi_pack_bwd_f32(const percnn_pi_param_ptrs* params, const percnn_pi_param_ptrs* grads, int hc, int ndim, double dt,
                            double mu_up, int sigmoid, int contract, const float* g_block, void* stream);
 int percnn_pi_pack_bwd_f64(const percnn_pi_param_ptrs* params, const percnn_pi_param_ptrs* grads, int hc, int ndim, double dt,
@@ -167,8 +188,29 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *   "overlap", "overlap_chunk"  run the time-parallel gradient pass of finished chunks on a side stream under the sweep
  *   "skip_wgrad"   diagnostics: adjoint sweep only, parameter gradients of the branches come back as zeros
  *   "lds_pad"      diagnostics: extra dynamic LDS per workgroup (limits workgroups per CU)
+ *   "tile_persist" 2D float32 pre-contracted blocks on whole 32 x 32 tiles, 16 .. #CUs tiles: the whole tile sweep of a rollout
+ *                  backward as ONE launch of resident workgroups that hand their halos to each other (2 = plain launch, default;
+ *                  1 = hipLaunchCooperativeKernel; 0 = one launch per four steps).  RESIDENCY IS CHECKED, NOT ASSUMED: every
+ *                  workgroup answers a roll call when it starts, a hand-over wait is bounded ("persist_first_timeout_ms",
+ *                  default 100, for the first one; "persist_timeout_ms", default 2000, later), and a workgroup whose wait runs out
+ *                  aborts the whole launch -- no output of an aborted launch is ever written.
+ *   "persist_handshake"  1 (default): the entry point waits on a host-mapped word (no stream synchronisation) until the launch
+ *                  reports "all resident" -- normally microseconds after the kernel starts, i.e. the call returns once the stream
+ *                  has reached the sweep -- or "aborted"; after an abort the launch-per-group sweep is enqueued by the same call,
+ *                  a one-line warning goes to stderr and the device keeps the launch-per-group path until "persist_reset".  0: no
+ *                  wait; an abort is reported by the next entry point as PERCNN_PI_EASYNC.
+ *   "persist_reset"  (any value) re-arm the persistent sweep after an abort
  * Returns 0, or PERCNN_PI_EINVAL for an unknown key / bad value. */
 int percnn_pi_set_option(const char *key, long value);
+
+/* State of the persistent tile sweep in this process: info[0] launches so far, info[1] launches that aborted, info[2] 1 if the
+ * current device has been switched to the launch-per-group path by an abort, info[3] / info[4] group / tile of the last abort,
+ * info[5] the state word of the most recent launch as the device left it (0 not started yet, 1 every workgroup resident, 2
+ * aborted; -1: no launch yet).  `info` holds at least 8 longs. */
+int percnn_pi_persist_status(long *info);
+/* Diagnostics for tests of that abort path: `blocks` workgroups that each hold `lds_bytes` of a CU's LDS for `ms` milliseconds
+ * on `stream` (a stand-in for "another kernel holds whole CUs"). */
+int percnn_pi_debug_hog(int blocks, int lds_bytes, int ms, void *stream);
 
 /* ---- one Pi-block step ------------------------------------------------------------------
  * Replaces RCNNCell.forward(h) (2dgs:105-121, 3dgs:123-139, lo:98-112): periodic pad,
@@ -464,7 +506,7 @@ int percnn_pi_rollout_bwd_sqerr_f64(const double *traj, const double *target, co
                                     size_t workspace_bytes, const double *params, int hc, int ndim, const int64_t *shape,
                                     int T_steps, const char *options, void *stream);
 /* The loss value itself: out[0] = scale * sum_{f < nframes : frame_mask[f]} sum_x (traj_f - target_f)^2 in ONE streaming
- * pass (float64 accumulation); workspace >= 8 KiB, 8-byte aligned; at most 64 runs of consecutive selected frames. */
+ * pass (float64 accumulation); workspace >= 8 KiB, 8-byte aligned; one launch per run of consecutive selected frames (any number of runs). */
 int percnn_pi_traj_sqerr_f32(const float *traj, const float *target, const unsigned char *frame_mask, int nframes, int ndim,
                              const int64_t *shape, double scale, float *out, void *workspace, size_t workspace_bytes,
                              void *stream);

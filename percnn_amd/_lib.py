@@ -25,11 +25,13 @@ SOURCES = {
 
 EXPORTS = [
     "percnn_pi_abi_version", "percnn_pi_param_count", "percnn_pi_bwd_workspace_bytes",
-    "percnn_pi_rollout_bwd_workspace_bytes", "percnn_pi_set_option", "percnn_pi_halo_ring_bytes",
+    "percnn_pi_rollout_bwd_workspace_bytes", "percnn_pi_set_option", "percnn_pi_persist_status", "percnn_pi_halo_ring_bytes",
     "percnn_pi_peer_box_bytes", "percnn_pi_peer_box_alloc", "percnn_pi_peer_box_free", "percnn_pi_peer_box_export",
     "percnn_pi_peer_box_open", "percnn_pi_peer_box_close", "percnn_pi_peer_box_status",
     "percnn_pi_peer_exchange_f32", "percnn_pi_peer_exchange_f64",
     "percnn_pi_pack_fwd_f32", "percnn_pi_pack_fwd_f64", "percnn_pi_pack_bwd_f32", "percnn_pi_pack_bwd_f64",
+    "percnn_pi_pack_fwd_guard_f32", "percnn_pi_pack_fwd_guard_f64", "percnn_pi_host_words_alloc", "percnn_pi_host_words_free",
+    "percnn_pi_debug_hog",
     "percnn_pi_debug_blockmap", "percnn_pi_debug_plan", "percnn_pi_residual_sqloss_workspace_bytes",
     "percnn_pi_residual_sqloss_f32", "percnn_pi_residual_sqloss_f64", "percnn_pi_residual_sqloss_bwd_f32",
     "percnn_pi_residual_sqloss_bwd_f64",
@@ -105,6 +107,7 @@ def lib() -> ctypes.CDLL:
     L.percnn_pi_rollout_bwd_workspace_bytes.argtypes = [ci, ci, i64p, ci, ci]
     L.percnn_pi_set_option.restype = ci
     L.percnn_pi_set_option.argtypes = [ctypes.c_char_p, ctypes.c_long]
+    L.percnn_pi_persist_status.restype, L.percnn_pi_persist_status.argtypes = ci, [ctypes.POINTER(ctypes.c_long)]
     L.percnn_pi_halo_ring_bytes.restype, L.percnn_pi_halo_ring_bytes.argtypes = sz, []
     if L.percnn_pi_halo_ring_bytes() != ctypes.sizeof(HaloRing):
         raise RuntimeError("percnn_amd: percnn_pi_halo_ring layout differs between the python binding and libpercnn_pi.so")
@@ -127,6 +130,11 @@ def lib() -> ctypes.CDLL:
         f.restype, f.argtypes = ci, [ctypes.POINTER(ParamPtrs), ci, ci, cd, cd, ci, ci, vp, vp]
         f = getattr(L, f"percnn_pi_pack_bwd_{suf}")
         f.restype, f.argtypes = ci, [ctypes.POINTER(ParamPtrs), ctypes.POINTER(ParamPtrs), ci, ci, cd, cd, ci, ci, vp, vp]
+        f = getattr(L, f"percnn_pi_pack_fwd_guard_{suf}")
+        f.restype, f.argtypes = ci, [ctypes.POINTER(ParamPtrs), ci, ci, cd, cd, ci, ci, vp, cd, cd, vp, cd, vp]
+    L.percnn_pi_host_words_alloc.restype, L.percnn_pi_host_words_alloc.argtypes = ci, [ctypes.POINTER(ctypes.c_void_p), sz]
+    L.percnn_pi_host_words_free.restype, L.percnn_pi_host_words_free.argtypes = ci, [vp]
+    L.percnn_pi_debug_hog.restype, L.percnn_pi_debug_hog.argtypes = ci, [ci, ci, ci, vp]
     for suf in ("f32", "f64"):
         f = getattr(L, f"percnn_pi_peer_exchange_{suf}")
         f.restype, f.argtypes = ci, [vp, ci, i64p, ci, ci, ctypes.POINTER(PeerRing), vp]
@@ -224,10 +232,37 @@ class HaloRing(ctypes.Structure):
                 ("stage", ctypes.c_void_p), ("stage_bytes", ctypes.c_size_t)]
 
 
+def persist_status() -> dict:
+    """percnn_pi_persist_status: what the persistent tile sweep has done in this process (launches, aborts, whether the current
+    device fell back to one launch per group of steps, where the last abort happened)."""
+    info = (ctypes.c_long * 8)()
+    lib().percnn_pi_persist_status(info)
+    return {"launches": info[0], "aborts": info[1], "disabled_on_current_device": bool(info[2]), "last_abort_group": info[3],
+            "last_abort_tile": info[4], "last_launch_state": info[5]}
+
+
+def _persist_note() -> str:
+    try:
+        return f"persist_status() = {persist_status()}"
+    except Exception:                                        # pragma: no cover
+        return ""
+
+
+class GridTooLargeError(RuntimeError):
+    """PERCNN_PI_ETOOLARGE: nothing was launched; callers with another route for such grids catch this."""
+
+
 def check(rc: int, what: str) -> None:
+    if rc == -3:
+        raise GridTooLargeError(f"percnn_amd: {what} failed: grid too large for this kernel family's 32-bit offsets / fixed "
+                                f"workspace (a 2D field or a 3D plane of >= 4 GiB per species, or more workgroups than the "
+                                f"loss pass has partial slots)")
     if rc != 0:
         names = {-1: "invalid argument", -2: "workspace too small",
-                 -3: "grid too large for the step kernels' 32-bit offsets (a 2D field or a 3D plane of >= 4 GiB per species)"}
+                 -3: "grid too large for the step kernels' 32-bit offsets (a 2D field or a 3D plane of >= 4 GiB per species)",
+                 -4: "an EARLIER call's persistent tile sweep aborted on the device (its workgroups could not all be resident: "
+                     "another process / kernel holds CUs, or a CU mask is set) -- the results of that earlier backward are "
+                     "invalid; this call launched nothing.  " + _persist_note()}
         raise RuntimeError(f"percnn_amd: {what} failed: {names.get(rc, 'hipError_t ' + str(rc))}")
 
 

@@ -5,8 +5,11 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <thread>
 
 #include "../../include/percnn_pi.h"
 #include "pi_kernels.h"
@@ -52,6 +55,15 @@ struct Options {
                             // CUs: calls on other streams of this process are detected and take the launch-per-group path;
                             // processes that share one GPU must set 0); 1 = cooperative launch (residency guaranteed by the
                             // runtime, but ~0.4 ms per launch on ROCm 7.2: slower than what it saves at T = 1000); 0 = off
+    int persist_handshake = 1;  // persistent sweep: the entry point waits (host spin on a host-mapped word, no stream sync) until
+                            // the launch reports that every workgroup is resident -- or that it aborted, in which case the
+                            // launch-per-group sweep is enqueued in the same call and the persistent path is switched off for
+                            // this device (percnn_pi_persist_status).  0: no wait; an aborted launch is reported by the NEXT
+                            // entry point (PERCNN_PI_EASYNC) instead
+    int persist_split = 1;      // persistent sweep: 1 = split flavour (pi_adj2d_persist_split_kernel: the halo-independent
+                            // "pyramid" of the next group runs while the granules of the hand-over travel), 0 = round 3's kernel
+    int persist_timeout_ms = 2000;       // bound of one hand-over wait inside the persistent sweep
+    int persist_first_timeout_ms = 100;  // ... of the first one (residency check)
     int tile_wide = 3;      // float32 poly blocks: 3 = 32x40 / 40x40 tiles where they keep the grid in one round (tile_wide_for),
                             // 0 = never, 1 / 2 = force 32x40 / 40x40
     int fwd_blocks = 0;     // direct forward kernel: grid cap (0 = none; measured: a bounded persistent grid loses, 384^3 376 -> 416 us)
@@ -90,6 +102,8 @@ Options g_defaults;
 std::mutex g_defaults_mu;
 int apply_option(Options& o, const char* key, long value);
 int apply_overrides(Options& o, const char* spec);
+void persist_reset();
+int persist_async_error();
 
 template <typename F>
 hipError_t allow_lds(F* f, size_t bytes)
@@ -139,13 +153,16 @@ struct Problem {
     pi::LossInj loss{0.0, nullptr, 0};   // adjoint calls: what the injection pointer means (pi_device.h); mode 0 = dL/dout itself
 };
 
-int make_problem(int hc, int ndim, const int64_t* shape, bool slab, Problem& p, const char* overrides = nullptr)
+int make_problem(int hc, int ndim, const int64_t* shape, bool slab, Problem& p, const char* overrides = nullptr,
+                 bool launches = true)                      // launches = false: a pure size / plan query
 {
     {
         std::lock_guard<std::mutex> lk(g_defaults_mu);
         p.opt = g_defaults;
     }
     if (int rc = apply_overrides(p.opt, overrides)) return rc;
+    if (launches)
+        if (int rc = persist_async_error()) return rc;      // an earlier persistent sweep aborted and nobody has been told yet
     if (!shape || (ndim != 2 && ndim != 3) || hc < -1 || hc > 64) return PERCNN_PI_EINVAL;   // hc == 0: poly, -1: advective
     if (hc == -1 && slab) return PERCNN_PI_EINVAL;
     for (int a = 0; a < ndim; ++a)
@@ -1099,6 +1116,7 @@ int device_cu_count()
     return cu_count[dev] > 0 ? cu_count[dev] : 0;
 }
 
+bool persist_disabled_here();
 constexpr int PERSIST_BAND = 2 * (TILE_B * TILE_B - (TILE_B - 16) * (TILE_B - 16));     // granules per tile and parity (K = 4)
 size_t persist_outbox_bytes(const Problem& p)
 {
@@ -1110,6 +1128,7 @@ template <typename T>
 bool persist_ok(const Problem& p, const unsigned char* mask, int t_top, int ngroups, hipStream_t st)
 {
     if (!p.opt.tile_persist || sizeof(T) != 4 || ngroups < 2) return false;
+    if (persist_disabled_here()) return false;               // a launch aborted on this device (see PersistGuard)
     if (mask && t_top >= 4096) return false;                 // the frame mask travels as a kernel argument (4096 bits)
     if (!tile_fuse_ok<T>(p) || tile_wide_for<T>(p, true) != 0 || tile_by_for(p) != TILE_B) return false;
     if (p.n0 % TILE_B || p.W % TILE_B) return false;
@@ -1124,23 +1143,83 @@ bool persist_ok(const Problem& p, const unsigned char* mask, int t_top, int ngro
 // Two persistent sweeps in flight on ONE device would each hold part of the CUs and wait for workgroups that cannot become
 // resident.  Within a process: the last persistent launch per device leaves an event behind; a call on ANOTHER stream while that
 // event is not ready takes the launch-per-group path (same stream: ordered behind it anyway).
+// Anything ELSE that keeps workgroups from becoming resident -- another process on the GPU, a CU mask (HSA_CU_MASK, a CU-masked
+// stream), a long kernel on another stream -- is caught by the launch itself: its workgroups give up within a bound, write
+// nothing, and say so in a host-mapped status slot (pi_tile2d.h, PersistArgs::host).  With the handshake (default) the entry
+// point waits for that word -- "all resident" normally arrives a few microseconds after the kernel starts -- and enqueues the
+// launch-per-group sweep itself on an abort; the device then keeps the launch-per-group path until persist_reset.
+constexpr int PERSIST_SLOTS = 32;
+struct PersistHost {                                      // host-mapped (hipHostMalloc): written by the device, read here
+    volatile int slot[PERSIST_SLOTS][4];                  // {roll call complete, group, tile, aborted}: see PersistArgs::host
+};
 struct PersistGuard {
     std::mutex mu;
     hipEvent_t ev[16] = {};
     hipStream_t st[16] = {};
     bool armed[16] = {};
+    bool disabled[16] = {};                               // a launch aborted on this device: launch-per-group until persist_reset
+    PersistHost* host = nullptr;
+    bool host_tried = false;
+    bool watch[PERSIST_SLOTS] = {};                       // slots of launches nobody has looked at since (no-handshake mode)
+    int next_slot = 0;
+    long launches = 0, aborts = 0;
+    int last_group = -1, last_tile = -1;
+    bool warned = false;
 };
 PersistGuard g_persist;
+
+bool persist_disabled_here()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return true;
+    std::lock_guard<std::mutex> lk(g_persist.mu);
+    return g_persist.disabled[dev];
+}
+
+void persist_reset()
+{
+    std::lock_guard<std::mutex> lk(g_persist.mu);
+    for (bool& d : g_persist.disabled) d = false;
+    for (bool& w : g_persist.watch) w = false;
+    g_persist.warned = false;
+}
+
+// the launches of no-handshake callers: has one of them aborted since anybody looked?  (reads of cached host memory)
+int persist_async_error()
+{
+    if (!g_persist.host) return 0;
+    std::lock_guard<std::mutex> lk(g_persist.mu);
+    int rc = 0;
+    for (int i = 0; i < PERSIST_SLOTS; ++i)
+        if (g_persist.watch[i] && g_persist.host->slot[i][3] != 0) {
+            g_persist.watch[i] = false;
+            g_persist.last_group = g_persist.host->slot[i][1];
+            g_persist.last_tile = g_persist.host->slot[i][2];
+            ++g_persist.aborts;
+            for (bool& d : g_persist.disabled) d = true;
+            rc = PERCNN_PI_EASYNC;
+        }
+    return rc;
+}
 
 bool persist_enter(hipStream_t st, int& dev)
 {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
     std::lock_guard<std::mutex> lk(g_persist.mu);
+    if (g_persist.disabled[dev]) return false;
     if (g_persist.armed[dev] && g_persist.st[dev] != st && hipEventQuery(g_persist.ev[dev]) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
-    return true;
+    if (!g_persist.host_tried) {
+        g_persist.host_tried = true;
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, sizeof(PersistHost), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hp) {
+            std::memset(hp, 0, sizeof(PersistHost));
+            g_persist.host = static_cast<PersistHost*>(hp);
+        } else (void)hipGetLastError();
+    }
+    return g_persist.host != nullptr;                      // no status word, no persistent launch
 }
 void persist_leave(hipStream_t st, int dev)
 {
@@ -1150,36 +1229,49 @@ void persist_leave(hipStream_t st, int dev)
 }
 
 // groups of 4 steps from frame t_top down; g_h0 only if the last group ends at frame 0.  Returns hipErrorCooperativeLaunchTooLarge
-// (or whatever the runtime says) WITHOUT having launched anything if the workgroups cannot all be resident: the caller then
-// runs the launch-per-group path.
+// (or whatever the runtime says) WITHOUT having launched anything if the workgroups cannot all be resident, and
+// hipErrorLaunchFailure if the launch ran and ABORTED (handshake mode; nothing it was asked for has been written): the caller
+// then runs the launch-per-group path.  `sync`: three zeroed device words (PersistArgs::sync).
 template <typename T>
 hipError_t launch_adj_persist(const T* hframe_t, const T* gframe_t, T* aframe_t, T* g_h0, int t_top, const unsigned char* mask,
-                              int ngroups, double* partials, unsigned long long* outbox, int* error, const T* P,
-                              const Problem& p, hipStream_t st)
+                              int ngroups, double* partials, unsigned long long* outbox, unsigned* sync, const T* P,
+                              const Problem& p, int dev, hipStream_t st)
 {
     constexpr int K = 4, NT = 512;
     using TL = pi::Tile<K, TILE_B, TILE_B>;
     pi::TileGeom g = make_tile_geom(p, TILE_B);
     const unsigned grid = (unsigned)((p.n0 / TILE_B) * g.tiles_x);
     (void)sizeof(TL);
-    // state buffers | [20][NT] double moment sums per lane | publish / gather tables (3 + 5 + 5 ints per lane)
-    const size_t lds = pi::tile_state_bytes<T, K, TILE_B, TILE_B>() + (size_t)20 * NT * sizeof(double) + (size_t)13 * NT * sizeof(int);
-    auto* k = pi::pi_adj2d_persist_kernel<T, K, TILE_B, TILE_B, NT>;
+    // state buffers | [20][NT] double moment sums per lane | publish / gather tables (3 + 5 + 5 ints per lane) | abort word
+    const size_t lds = pi::tile_state_bytes<T, K, TILE_B, TILE_B>() + (size_t)20 * NT * sizeof(double) +
+                       (size_t)13 * NT * sizeof(int) + 16;
+    auto* k = p.opt.persist_split ? pi::pi_adj2d_persist_split_kernel<T, K, TILE_B, TILE_B, NT>
+                                  : pi::pi_adj2d_persist_kernel<T, K, TILE_B, TILE_B, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
-    static int resident[16] = {};                           // per device: does one workgroup of this kernel fit a CU? (asked once)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipErrorInvalidDevice;
-    if (!resident[dev]) {
+    static int resident[16][2] = {};                        // per device and flavour: does one workgroup fit a CU? (asked once)
+    int& res = resident[dev][p.opt.persist_split ? 1 : 0];
+    if (!res) {
         int nb = 0;
-        resident[dev] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, NT, lds) == hipSuccess && nb >= 1) ? 1 : -1;
+        res = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, NT, lds) == hipSuccess && nb >= 1) ? 1 : -1;
     }
-    if (resident[dev] < 0) return hipErrorCooperativeLaunchTooLarge;
+    if (res < 0) return hipErrorCooperativeLaunchTooLarge;
     if (hipError_t e = hipMemsetAsync(outbox, 0, persist_outbox_bytes(p), st)) return e;
     long frame_stride = (long)(2 * p.n);
     int np = pi::nparams(p.hc);
     pi::PersistArgs pa{};
-    pa.outbox = outbox; pa.error = error; pa.ngroups = ngroups;
-    pa.timeout_ticks = 200000000ull;                        // 2 s of the 100 MHz clock
+    int slot;
+    {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        slot = g_persist.next_slot++ % PERSIST_SLOTS;
+        g_persist.watch[slot] = false;
+        ++g_persist.launches;
+    }
+    volatile int* hs = g_persist.host->slot[slot];
+    hs[0] = 0; hs[1] = -1; hs[2] = -1; hs[3] = 0;
+    pa.outbox = outbox; pa.sync = sync; pa.ngroups = ngroups;
+    pa.host = const_cast<int*>(hs);
+    pa.timeout_ticks = (unsigned long long)p.opt.persist_timeout_ms * 100000ull;             // 100 MHz clock
+    pa.first_timeout_ticks = (unsigned long long)p.opt.persist_first_timeout_ms * 100000ull;
     pa.t_top = t_top;
     pa.masked = mask ? 1 : 0;
     if (mask)
@@ -1187,11 +1279,46 @@ hipError_t launch_adj_persist(const T* hframe_t, const T* gframe_t, T* aframe_t,
             if (mask[t]) pa.frames[t >> 5] |= 1u << (t & 31);
     void* args[] = {(void*)&hframe_t, (void*)&gframe_t, (void*)&aframe_t, (void*)&frame_stride, (void*)&g_h0, (void*)&partials,
                     (void*)&np, (void*)&P, (void*)&g, (void*)&pa};
-    if (p.opt.tile_persist == 2) {                          // plain launch: one workgroup per CU fits, nothing else must hold CUs
+    hipError_t e;
+    if (p.opt.tile_persist == 2) {                          // plain launch: one workgroup per CU fits (residency: see above)
         hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, hframe_t, gframe_t, aframe_t, frame_stride, g_h0, partials, np, P, g, pa);
-        return hipGetLastError();
+        e = hipGetLastError();
+    } else {
+        e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k), dim3(grid), dim3(NT), args, (unsigned)lds, st);
     }
-    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k), dim3(grid), dim3(NT), args, (unsigned)lds, st);
+    if (e != hipSuccess) return e;
+    {   // whoever launched it: an abort nobody has dealt with surfaces at the next entry point (PERCNN_PI_EASYNC)
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        g_persist.watch[slot] = true;
+    }
+    if (!p.opt.persist_handshake) return hipSuccess;        // fire and forget
+    // wait for the roll call (not for the sweep): normally a few microseconds after the kernel starts, i.e. this returns when the
+    // stream has reached the sweep.  The bound only guards against a device that never runs the launch at all.
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (hs[0] == 0 && hs[3] == 0) {
+        if ((++spins & 0x3ff) == 0) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(600)) return hipErrorLaunchTimeOut;
+            std::this_thread::yield();
+        }
+    }
+    if (hs[3] != 0) {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        g_persist.watch[slot] = false;                      // dealt with here: the caller re-runs the sweep launch by launch
+        ++g_persist.aborts;
+        g_persist.last_group = hs[1];
+        g_persist.last_tile = hs[2];
+        g_persist.disabled[dev] = true;
+        if (!g_persist.warned) {
+            g_persist.warned = true;
+            std::fprintf(stderr, "percnn_pi: the persistent tile sweep could not keep all %u workgroups resident on device %d "
+                                 "(group %d, tile %d: another process / kernel holds CUs, or a CU mask is set); using one launch "
+                                 "per group of steps from now on (percnn_pi_set_option(\"persist_reset\", 1) re-arms it)\n",
+                         grid, dev, (int)hs[1], (int)hs[2]);
+        }
+        return hipErrorLaunchFailure;
+    }
+    return hipSuccess;
 }
 
 // ---- workspace carving -------------------------------------------------------------------------
@@ -1834,14 +1961,22 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
                 persist_outbox_bytes(p) <= (size_t)(K - 1) * frame_bytes) {
                 const int t_end = t_cur - K * ngroups;
                 auto* outbox = reinterpret_cast<unsigned long long*>(adj + (size_t)(t_end + 1) * frame);
-                int* err = reinterpret_cast<int*>(w.partials + (size_t)(MAX_BWD_BLOCKS - 1) * pi::nparams(p.hc));
+                // roll-call / abort words: the last partial row (zeroed above; tiles <= #CUs << MAX_BWD_BLOCKS rows are in use)
+                unsigned* sync = reinterpret_cast<unsigned*>(w.partials + (size_t)(MAX_BWD_BLOCKS - 1) * pi::nparams(p.hc));
                 int pdev = 0;
                 if (persist_enter(st, pdev)) {
                     const hipError_t e = launch_adj_persist<T>(traj + (size_t)t_cur * frame, g_traj + (size_t)t_cur * frame,
                                                                adj + (size_t)t_cur * frame, t_end == 0 ? g_h0 : nullptr, t_cur,
-                                                               mask, ngroups, w.partials, outbox, err, P, p, st);
+                                                               mask, ngroups, w.partials, outbox, sync, P, p, pdev, st);
                     if (e == hipSuccess) { t_cur = t_end; persist_leave(st, pdev); }
-                    else (void)hipGetLastError();           // not resident / not supported: the launch-per-group path below
+                    else if (e == hipErrorLaunchTimeOut) return (int)e;
+                    else {
+                        (void)hipGetLastError();            // not resident / not supported / aborted: the launch-per-group path
+                        if (e == hipErrorLaunchFailure) {   // it RAN and gave up: workgroups that were already through may have
+                            persist_leave(st, pdev);        // added to their partial rows -- start the rows over
+                            if (hipError_t e2 = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e2;
+                        }
+                    }
                 }
             }
         }
@@ -2071,6 +2206,14 @@ int apply_option(Options& o, const char* key, long value)
         o.tile_persist = (int)value;
         return 0;
     }
+    if (!std::strcmp(key, "persist_handshake")) { o.persist_handshake = value != 0; return 0; }
+    if (!std::strcmp(key, "persist_split")) { o.persist_split = value != 0; return 0; }
+    if (!std::strcmp(key, "persist_timeout_ms") || !std::strcmp(key, "persist_first_timeout_ms")) {
+        if (value < 1 || value > 600000) return PERCNN_PI_EINVAL;
+        (key[8] == 'f' ? o.persist_first_timeout_ms : o.persist_timeout_ms) = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(key, "persist_reset")) { persist_reset(); return 0; }
     if (!std::strcmp(key, "tile_wide")) {
         if (value < 0 || value > 3) return PERCNN_PI_EINVAL;
         o.tile_wide = (int)value;
@@ -2247,15 +2390,17 @@ int sqerr_impl(const T* traj, const T* target, const unsigned char* mask, int nf
     int nruns = 0;
     for (int f = 0; f < nframes; ++f)
         if ((!mask || mask[f]) && (f == 0 || (mask && !mask[f - 1]))) ++nruns;
-    if (nruns > 64) return PERCNN_PI_EINVAL;                  // pathological masks: the caller sums frame by frame
-    const unsigned nb = nruns ? NB / (unsigned)nruns : NB;
+    // (more than 64 runs -- e.g. every 10th frame of 1000: the runs take the 64 stripes in turn and ADD to them; launches of
+    // one stream are ordered, so the sums stay deterministic)
+    const unsigned stripes = (unsigned)(nruns > 64 ? 64 : nruns);
+    const unsigned nb = stripes ? NB / stripes : NB;
     int f = 0, run = 0;
     while (f < nframes) {
         while (f < nframes && mask && !mask[f]) ++f;
         int g = f;
         while (g < nframes && (!mask || mask[g])) ++g;
         if (g > f) {
-            double* dst = partials + (size_t)run++ * nb;
+            double* dst = partials + (size_t)(run++ % (int)stripes) * nb;
             const T* tr = traj + (size_t)f * frame;
             const T* tg = target ? target + (size_t)f * frame : nullptr;
             if (v16) hipLaunchKernelGGL((pi::pi_sqerr_kernel<T, pi::vec_width<T>::value>), dim3(nb), dim3(256), 0, st, tr, tg,
@@ -2282,7 +2427,7 @@ template <typename T>
 int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options, int* out)
 {
     Problem p;
-    if (int rc = make_problem(hc, ndim, shape, false, p, options)) return rc;
+    if (int rc = make_problem(hc, ndim, shape, false, p, options, false)) return rc;
     const int vec = pick_vec<T>(p, {});
     auto family = [&](bool adjoint, bool wgrad, int& planes) {
         planes = 1;
@@ -2454,7 +2599,19 @@ bool pack_ptrs(const percnn_pi_param_ptrs* in, bool need_all, pi::PackPtrs& out)
         if (!pack_ptrs(params, true, pp) || !block || hc < 1 || hc > pi::CONTRACT_LDS_HC || (ndim != 2 && ndim != 3))  \
             return PERCNN_PI_EINVAL;                                                                                    \
         hipLaunchKernelGGL((pi::pi_pack_fwd_kernel<T>), dim3(1), dim3(128), 0, static_cast<hipStream_t>(stream), pp, hc, \
-                           ndim, dt, mu_up, sigmoid, contract, block);                                                  \
+                           ndim, dt, mu_up, sigmoid, contract, block, pi::PackGuard{1.0, 1.0, nullptr, 0.0});           \
+        return (int)hipGetLastError();                                                                                  \
+    }                                                                                                                   \
+    int percnn_pi_pack_fwd_guard_##SUF(const percnn_pi_param_ptrs* params, int hc, int ndim, double dt, double mu_up,   \
+                                       int sigmoid, int contract, T* block, double u_max, double v_max,                 \
+                                       double* host_slot, double seq, void* stream)                                     \
+    {                                                                                                                   \
+        pi::PackPtrs pp;                                                                                                \
+        if (!pack_ptrs(params, true, pp) || !block || hc < 1 || hc > pi::CONTRACT_LDS_HC || (ndim != 2 && ndim != 3) || \
+            !(u_max >= 0.0) || !(v_max >= 0.0))                                                                         \
+            return PERCNN_PI_EINVAL;                                                                                    \
+        hipLaunchKernelGGL((pi::pi_pack_fwd_kernel<T>), dim3(1), dim3(128), 0, static_cast<hipStream_t>(stream), pp, hc, \
+                           ndim, dt, mu_up, sigmoid, contract, block, pi::PackGuard{u_max, v_max, host_slot, seq});     \
         return (int)hipGetLastError();                                                                                  \
     }                                                                                                                   \
     int percnn_pi_pack_bwd_##SUF(const percnn_pi_param_ptrs* params, const percnn_pi_param_ptrs* grads, int hc, int ndim, \
@@ -2475,7 +2632,7 @@ PI_PACK(f64, double)
 size_t percnn_pi_bwd_workspace_bytes(int hc, int ndim, const int64_t* shape, int elem_size)
 {
     Problem p;
-    if (make_problem(hc, ndim, shape, false, p) || (elem_size != 4 && elem_size != 8)) return 0;
+    if (make_problem(hc, ndim, shape, false, p, nullptr, false) || (elem_size != 4 && elem_size != 8)) return 0;
     // sized for the padded slab layout as well: (n0+4) planes
     Problem q = p;
     q.n = (p.n0 + 4) * p.n1 * p.W;
@@ -2485,7 +2642,7 @@ size_t percnn_pi_bwd_workspace_bytes(int hc, int ndim, const int64_t* shape, int
 size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t* shape, int T_steps, int elem_size)
 {
     Problem p;
-    if (make_problem(hc, ndim, shape, false, p) || (elem_size != 4 && elem_size != 8) || T_steps < 0) return 0;
+    if (make_problem(hc, ndim, shape, false, p, nullptr, false) || (elem_size != 4 && elem_size != 8) || T_steps < 0) return 0;
     return rollout_workspace_bytes(p, T_steps, elem_size);
 }
 
@@ -2493,6 +2650,59 @@ int percnn_pi_set_option(const char* key, long value)
 {
     std::lock_guard<std::mutex> lk(g_defaults_mu);
     return apply_option(g_defaults, key, value);
+}
+
+// host-mapped words the device can write and the host can read without synchronising (pack guard slots)
+int percnn_pi_host_words_alloc(void** p, size_t bytes)
+{
+    if (!p || bytes == 0) return PERCNN_PI_EINVAL;
+    void* hp = nullptr;
+    if (hipError_t e = hipHostMalloc(&hp, bytes, hipHostMallocMapped | hipHostMallocCoherent)) return (int)e;
+    std::memset(hp, 0, bytes);
+    *p = hp;
+    return 0;
+}
+int percnn_pi_host_words_free(void* p) { return p ? (int)hipHostFree(p) : 0; }
+
+// diagnostics (tests of the persistent sweep's abort path): `blocks` workgroups that each hold `lds_bytes` of a CU's LDS for
+// `ms` milliseconds on `stream` -- what "another kernel holds whole CUs" looks like
+namespace {
+__global__ void pi_debug_hog_kernel(unsigned long long ticks, int* sink)
+{
+    extern __shared__ unsigned char hog_lds[];
+    hog_lds[threadIdx.x] = (unsigned char)threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (hog_lds[(threadIdx.x + 1) % 64] == 255 && sink) *sink = 1;
+}
+}  // namespace
+int percnn_pi_debug_hog(int blocks, int lds_bytes, int ms, void* stream)
+{
+    if (blocks < 1 || blocks > 4096 || lds_bytes < 64 || lds_bytes > 160 * 1024 || ms < 1 || ms > 10000) return PERCNN_PI_EINVAL;
+    if (hipError_t e = allow_lds(pi_debug_hog_kernel, (size_t)lds_bytes)) return (int)e;
+    hipLaunchKernelGGL(pi_debug_hog_kernel, dim3((unsigned)blocks), dim3(64), (size_t)lds_bytes, static_cast<hipStream_t>(stream),
+                       (unsigned long long)ms * 100000ull, (int*)nullptr);
+    return (int)hipGetLastError();
+}
+
+int percnn_pi_persist_status(long* info)
+{
+    if (!info) return PERCNN_PI_EINVAL;
+    int dev = 0;
+    const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16;
+    if (!have_dev) (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(g_persist.mu);
+    info[0] = g_persist.launches;
+    info[1] = g_persist.aborts;
+    info[2] = have_dev && g_persist.disabled[dev] ? 1 : 0;
+    info[3] = g_persist.last_group;
+    info[4] = g_persist.last_tile;
+    // state word of the most recent launch as the device left it: 0 not started, 1 every workgroup resident, 2 aborted
+    if (g_persist.host && g_persist.next_slot > 0) {
+        volatile int* hs = g_persist.host->slot[(g_persist.next_slot - 1) % PERSIST_SLOTS];
+        info[5] = hs[3] ? 2 : hs[0];
+    } else info[5] = -1;
+    return 0;
 }
 
 #define PI_EXPORT(SUF, T)                                                                                           \

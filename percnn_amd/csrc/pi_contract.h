@@ -184,20 +184,32 @@ __device__ __forceinline__ void pack_stage(const PackPtrs& pp, int hc, int ndim,
     __syncthreads();
 }
 
+// Conditioning guard of the pre-contracted form (RCNNCell docstring "WHEN 'factored' IS REQUIRED"): the expanded cubic cancels
+// its monomials only to rounding, so its per-step noise relative to the state is eps * A,
+//   A = |dt| * max_s sum_m |c[s][m]| * phi_m(u_max, v_max) / max(u_max, v_max).
+// The pack launch computes A from the coefficients it forms anyway and leaves {A, seq} in a HOST-MAPPED slot: the module reads
+// it without synchronising (one training iteration late) and packs the factored block instead while A is above its bound.
+struct PackGuard {
+    double u_max, v_max;   // state bound the amplification is priced at
+    double* slot;          // host-mapped {A, seq}; null: no guard
+    double seq;            // written AFTER A (release): the host knows which pack a value belongs to
+};
+
 template <typename T>
 __global__ void __launch_bounds__(128) pi_pack_fwd_kernel(PackPtrs pp, int hc, int ndim, double dt, double mu_up, int sigmoid,
-                                                          int contract, T* __restrict__ out)
+                                                          int contract, T* __restrict__ out, PackGuard guard)
 {
     __shared__ T stage[P_W + 2 * (10 * CONTRACT_LDS_HC + 1)];
     __shared__ double mono[2 * CONTRACT_LDS_HC][10];
+    __shared__ double amp[20];
     const int t = threadIdx.x;
     pack_stage<T>(pp, hc, ndim, dt, mu_up, sigmoid, stage);
     if (!contract) {
         for (int i = t; i < nparams(hc); i += blockDim.x) out[i] = stage[i];
-        return;
+        if (!guard.slot) return;                          // (the factored block also prices its contraction while guarded)
     }
     // same arithmetic and order as pi_contract_fwd_kernel (bit-identical blocks)
-    if (t < P_W) out[t] = stage[t];
+    if (contract && t < P_W) out[t] = stage[t];
     for (int idx = t; idx < 2 * hc; idx += blockDim.x) {
         const int s = idx / hc, j = idx - s * hc;
         const T* w = stage + P_W + s * species_block(hc) + 10 * j;
@@ -215,13 +227,30 @@ __global__ void __launch_bounds__(128) pi_pack_fwd_kernel(PackPtrs pp, int hc, i
         for (int m = 0; m < 10; ++m) mono[idx][m] = sj[m];
     }
     __syncthreads();
-    if (t >= 20) return;
-    const int s = t / 10, m = t % 10;
-    const T* B = stage + P_W + s * species_block(hc);
-    double acc = 0.0;
-    for (int j = 0; j < hc; ++j) acc += (double)B[10 * j + 9] * mono[s * hc + j][m];
-    if (m == 0) acc += (double)B[10 * hc];
-    out[P_W + t] = (T)acc;
+    if (t < 20) {
+        const int s = t / 10, m = t % 10;
+        const T* B = stage + P_W + s * species_block(hc);
+        double acc = 0.0;
+        for (int j = 0; j < hc; ++j) acc += (double)B[10 * j + 9] * mono[s * hc + j][m];
+        if (m == 0) acc += (double)B[10 * hc];
+        if (contract) out[P_W + t] = (T)acc;
+        if (guard.slot) {
+            const double u = guard.u_max, v = guard.v_max;
+            const double phi[10] = {1.0, u, v, u * u, u * v, v * v, u * u * u, u * u * v, u * v * v, v * v * v};
+            amp[t] = fabs((double)(T)acc) * phi[m];       // the ROUNDED coefficient is what the kernels evaluate
+        }
+    }
+    if (!guard.slot) return;
+    __syncthreads();
+    if (t == 0) {
+        double a[2] = {0.0, 0.0};
+        for (int s = 0; s < 2; ++s)
+            for (int m = 0; m < 10; ++m) a[s] += amp[10 * s + m];
+        const double bound = guard.u_max > guard.v_max ? guard.u_max : guard.v_max;
+        const double A = fabs(dt) * (a[0] > a[1] ? a[0] : a[1]) / (bound > 0.0 ? bound : 1.0);
+        __hip_atomic_store(guard.slot, A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(guard.slot + 1, guard.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // g_block = dL/d(block) (contracted: 36 entries, else nparams(hc)) -> gradients of the 18 trainable tensors (`gp`, same slots

@@ -1197,7 +1197,7 @@ pi_sqerr_kernel(const T* __restrict__ traj, const T* __restrict__ target, long n
     if (threadIdx.x == 0) {
         double s = 0.0;
         for (int w = 0; w < 256 / WAVE; ++w) s += red[w];
-        partials[blockIdx.x] = s;
+        partials[blockIdx.x] += s;                       // slots are zeroed by the host; runs beyond the 64th share slots (stream-ordered)
     }
 }
 

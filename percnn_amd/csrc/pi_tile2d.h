@@ -25,6 +25,12 @@ namespace pi {
 #ifndef PI_PIN_MOMENTS
 #define PI_PIN_MOMENTS 1
 #endif
+#ifndef PI_PERSIST_LAUNDER
+#define PI_PERSIST_LAUNDER 0
+#endif
+#ifndef PI_PERSIST_OPAQUE_TID
+#define PI_PERSIST_OPAQUE_TID 1
+#endif
 
 
 #ifdef PI_TILE_TIMING
@@ -39,6 +45,15 @@ __device__ long long pi_tile_wave_stamps[256 * 16 * 16];      // [block < 256][w
 #else
 #define PI_STAMP(i) do { } while (0)
 #define PI_STAMP_PREV() do { } while (0)
+#endif
+
+#ifdef PI_PERSIST_STAMPS
+// debug build only (tools/persist_dev.hip): per-wave 100 MHz stamps of ONE group of the persistent sweeps
+__device__ long long pi_persist_stamps[256 * 8 * 16];
+#define PI_PSTAMP(i) do { if (grp == PI_PERSIST_STAMPS && threadIdx.x % 64 == 0 && blockIdx.x < 256)                      \
+                              pi_persist_stamps[(blockIdx.x * 8 + threadIdx.x / 64) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define PI_PSTAMP(i) do { } while (0)
 #endif
 
 template <int K, int BX, int BY>
@@ -541,17 +556,58 @@ pi_res2d_tile_kernel(const T* __restrict__ traj, double* __restrict__ partials, 
 // pointwise operands (state h_{t-1-M}, injected dL/dout_{t-1-M}) of one 4-point strip
 template <typename T> struct StripOps { T u[4], v[4], ju[4], jv[4]; };
 
+// Which strips of sub-step M's region R_M (side B + 4 (K - M - 1), origin O = 2 (M + 1) in window coordinates) a pass covers:
+//   PART_FULL  all of R_M, row-major (the launch-per-group kernels);
+//   PART_PYR   the centred square I_M of side B - 4 (M + 1): the points whose value after sub-step M depends on the workgroup's
+//              OWN tile only -- computable before the neighbours' halo has arrived (persistent sweep, split flavour);
+//   PART_ANN   the rest, R_M \ I_M: a ring 2K points thick (top / bottom bands of whole rows, then 2K-wide side pieces).
+// I_M sits on R_M's own grid of 4-point strips (its origin is 2K = 0 mod 4 further in), so every strip keeps the 16-byte
+// LDS alignment of lds_pad0 and the arithmetic of a point does not depend on which pass computes it.
+enum : int { PART_FULL = 0, PART_PYR = 1, PART_ANN = 2 };
+
+template <int K, int BX, int BY, int M, int PART>
+struct StripMap {
+    using TL = Tile<K, BX, BY>;
+    static constexpr int RW4 = TL::region_w(M) / 4, RH = TL::region_h(M);
+    static constexpr int SW4 = (BX - 4 * (M + 1)) / 4, SH = BY - 4 * (M + 1);
+    static constexpr int HWD = 2 * K, HW4 = HWD / 4;
+    static_assert(PART == PART_FULL || (HWD % 4 == 0 && SW4 > 0 && SH > 0), "split passes: K even, tile larger than 4K");
+    static constexpr int BANDS = 2 * HWD * RW4;                            // strips of the top + bottom bands of the ring
+    static constexpr int N = PART == PART_FULL ? RW4 * RH : (PART == PART_PYR ? SW4 * SH : BANDS + 2 * HW4 * SH);
+    static __device__ __forceinline__ void locate(int idx, int& ry, int& rc)
+    {
+        if constexpr (PART == PART_FULL) {
+            ry = idx / RW4; rc = idx - ry * RW4;
+        } else if constexpr (PART == PART_PYR) {
+            const int r = idx / SW4;
+            ry = HWD + r; rc = HW4 + idx - r * SW4;
+        } else {
+            if (idx < BANDS) {
+                const int j = idx / RW4;
+                rc = idx - j * RW4;
+                ry = j < HWD ? j : j + SH;
+            } else {
+                const int k = idx - BANDS, r = k / (2 * HW4), c = k - r * (2 * HW4);
+                ry = HWD + r;
+                rc = c < HW4 ? c : c + SW4;
+            }
+        }
+    }
+};
+
 // element offsets (inside one species plane) of the two halves of the strip a lane owns in sub-step M
 struct StripAddr { long e0, e1; };
 
-template <int K, int BX, int BY, int NT, int M>
+template <int K, int BX, int BY, int NT, int M, int PART = PART_FULL, int TID0 = 0>
 __device__ __forceinline__ StripAddr strip_addr(int q, const TileGeom& g, int ty0, int tx0)
 {
-    using TL = Tile<K, BX, BY>;
-    constexpr int RW4 = TL::region_w(M) / 4, RN4 = TL::region_n(M) / 4, O = 2 * (M + 1);
-    int idx = threadIdx.x + q * NT;
+    using SM = StripMap<K, BX, BY, M, PART>;
+    constexpr int RN4 = SM::N, O = 2 * (M + 1);
+    int idx = (int)threadIdx.x - TID0 + q * NT;            // TID0: first lane of the waves that work on this part (mixed passes)
     if (idx >= RN4) idx = RN4 - 1;
-    const int ry = idx / RW4, rc = idx - ry * RW4;
+    if (idx < 0) idx = 0;
+    int ry, rc;
+    SM::locate(idx, ry, rc);
     const int ly = ry + O, lx = 4 * rc + O;
     // two 8/16-byte pieces per row: the strip may straddle the periodic wrap
     const int gy = wrap1(ty0 - 2 * K + ly, g.H);
@@ -621,30 +677,39 @@ __device__ __forceinline__ void mom_add1(double& a, V2<double> g) { a += g.x + g
 __device__ __forceinline__ float mom_total(V2<float> a) { return a.x + a.y; }
 __device__ __forceinline__ double mom_total(double a) { return a; }
 
-template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE, bool MOM>
+template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE, bool MOM, int PART = PART_FULL, int TID0 = 0>
 __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict__ hfr, const T* __restrict__ gfr,
                                             const TileGeom& g, int ty0, int tx0, const T* __restrict__ P,
                                             double (&acc_c)[2], const StripOps<T>& pre, TileMoments<T, MOM>& mom,
                                             double* lacc = nullptr)
 {
     using TL = Tile<K, BX, BY>;
-    constexpr int RW4 = TL::region_w(M) / 4, RN4 = TL::region_n(M) / 4, O = 2 * (M + 1);
+    using SM = StripMap<K, BX, BY, M, PART>;
+    constexpr int RN4 = SM::N, O = 2 * (M + 1);
     constexpr int PT = (RN4 + NT - 1) / NT;
     static_assert(!PRE || PT == 1, "prefetched operands cover one strip per lane");
     const T dt = P[P_DT];
+    int tid = (int)threadIdx.x;
+#if PI_PERSIST_OPAQUE_TID
+    // split persistent sweep: eight passes inlined into one loop.  Everything derived from the lane's strip position (LDS
+    // offsets, ownership masks, ...) is loop-invariant there and would be hoisted out of the group loop for ALL eight passes
+    // at once -- ~80 VGPRs held for the whole kernel, which then spills.  An opaque lane id keeps each pass's geometry local.
+    if constexpr (PART != PART_FULL) asm volatile("" : "+v"(tid));
+#endif
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
-        int idx = threadIdx.x + q * NT;
+        int idx = tid - TID0 + q * NT;                     // (TID0 != 0: the caller has sent the waves below TID0 elsewhere)
         const bool live = idx < RN4;
         if (!live) idx = RN4 - 1;
-        const int ry = idx / RW4, rc = idx - ry * RW4;
+        int ry, rc;
+        SM::locate(idx, ry, rc);
         const int ly = ry + O, lx = 4 * rc + O;
         const int off = ly * TL::LX + lx;
         StripOps<T> lo;
         if constexpr (!PRE) adj_load_ops<T, K, BX, BY, NT, M>(lo, q, hfr, gfr, g, ty0, tx0);
         // whole waves beyond the region skip the strip (see fwd_substep); their operand loads above stay unconditional --
         // loads inside a branch would cost the compiler its count of outstanding requests
-        if (((int)threadIdx.x & ~(WAVE - 1)) + q * NT >= RN4) continue;
+        if (((int)threadIdx.x & ~(WAVE - 1)) - TID0 + q * NT >= RN4) continue;
         const StripOps<T>& op = PRE ? pre : lo;
         const T (&u)[4] = op.u;
         const T (&v)[4] = op.v;
@@ -980,9 +1045,16 @@ pi_adj2d_tile_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gfram
 // ------------------------------------------------------------------------------------------------
 struct PersistArgs {
     unsigned long long* outbox;    // [2][tiles][BAND] granules, zeroed before the launch
-    int* error;                    // != 0: a gather timed out (neighbour not resident?) -- outputs are poisoned
+    unsigned* sync;                // device words, zeroed before the launch: [0] workgroups that have started, [1] abort flag,
+                                   // [2] number of time-outs
+    int* host;                     // host-mapped status slot of THIS launch (may be null): [0] 1 once every workgroup has started
+                                   // (roll call), [3] 1 once the launch has ABORTED (no output of it is valid), [1] / [2] group /
+                                   // tile of the first time-out.  Separate words: a late workgroup that completes the roll call of
+                                   // an aborted launch must not hide the abort.  Plain system-scope stores (no PCIe atomics).
     int ngroups;                   // groups of K steps run here: frames t_top .. t_top - K * ngroups
-    unsigned long long timeout_ticks;
+    unsigned long long timeout_ticks;        // bound of a hand-over wait (100 MHz ticks)
+    unsigned long long first_timeout_ticks;  // ... of the FIRST hand-over: that is where a workgroup that never became resident
+                                   // (CUs held by another process / kernel, CU mask) shows -- kept short so the host can fall back
     int t_top;                     // frame number of the top frame (group g covers frames t_top - K g - 1 ... t_top - K g - K)
     int masked;                    // 1: only the frames whose bit is set in `frames` carry a gradient (RCNN.observe's strided loss)
     unsigned frames[128];          // bit t of word t / 32: frame t carries a gradient (t < 4096)
@@ -1041,6 +1113,15 @@ pi_adj2d_persist_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gf
     int* tab_pub = reinterpret_cast<int*>(lacc + 20 * NT);                  // [NPUB][NT]: LDS position of a border value
     int* tab_gl = tab_pub + NPUB * NT;                                      // [NGAT][NT]: LDS position of a halo value
     int* tab_gs = tab_gl + NGAT * NT;                                       // [NGAT][NT]: granule index inside a parity half
+    int* wg_abort = tab_gs + NGAT * NT;                                     // [1]: some wave of this workgroup gave up
+    // residency roll call: the workgroup that completes it tells the host (which may be waiting for exactly that before it
+    // returns from the entry point -- see launch_adj_persist); a workgroup that never starts shows as a time-out of the first
+    // hand-over of its neighbours
+    if (threadIdx.x == 0) {
+        *wg_abort = 0;
+        const unsigned n = __hip_atomic_fetch_add(pa.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (n == (unsigned)ntiles && pa.host) __hip_atomic_store(pa.host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 #pragma unroll
     for (int m = 0; m < 20; ++m) lacc[m * NT + (int)threadIdx.x] = 0.0;
 #pragma unroll
@@ -1140,6 +1221,7 @@ pi_adj2d_persist_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gf
         for (int q = 0; q < NGAT; ++q) { gl[q] = tab_gl[q * NT + (int)threadIdx.x]; gs[q] = tab_gs[q * NT + (int)threadIdx.x]; }
         unsigned gv[NGAT];
         const unsigned long long t0 = wall_clock64();
+        const unsigned long long bound = grp == 0 ? pa.first_timeout_ticks : pa.timeout_ticks;
         for (;;) {
             bool ok = true;
 #pragma unroll
@@ -1150,15 +1232,35 @@ pi_adj2d_persist_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gf
                     ok &= (unsigned)(x >> 32) == epoch;
                 }
             if (__all(ok)) break;
-            if (wall_clock64() - t0 > pa.timeout_ticks) { failed = true; break; }
+            // give up when the wait is over its bound (the first to do so raises the abort flag below) or when another workgroup
+            // already has: a launch whose workgroups are not all resident ends within the bound instead of hanging the GPU
+            if (wall_clock64() - t0 > bound ||
+                __hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { failed = true; break; }
             __builtin_amdgcn_s_sleep(1);
         }
+        if (failed) {
+            if (threadIdx.x % WAVE == 0) *wg_abort = 1;
+        } else {
 #pragma unroll
-        for (int q = 0; q < NGAT; ++q)
-            if (gl[q] >= 0) b0[gl[q]] = failed ? __builtin_bit_cast(T, 0x7fc00000u) : __builtin_bit_cast(T, gv[q]);
+            for (int q = 0; q < NGAT; ++q)
+                if (gl[q] >= 0) b0[gl[q]] = __builtin_bit_cast(T, gv[q]);
+        }
         lds_barrier();
+        if (*wg_abort) {
+            // ABORT: nothing this launch was asked for is written (no adjoint frame, no partial row) -- the host learns it from its
+            // status slot and runs the launch-per-group sweep instead (or, without the handshake, reports the error at the next
+            // entry point): never a poisoned result
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(pa.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_exchange(pa.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && pa.host) {
+                    __hip_atomic_store(pa.host + 1, grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pa.host + 2, tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pa.host + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            return;
+        }
     }
-    if (failed && threadIdx.x % WAVE == 0) atomicAdd(pa.error, 1);
 
     // ---- once per rollout: diffusion-coefficient sums and the 20 moments of this tile -> its partial row -------------------
     lds_barrier();
@@ -1178,6 +1280,379 @@ pi_adj2d_persist_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gf
     }
     // the moments sit transposed in LDS ([moment][lane], complete: the barrier above waited for the LDS adds): 16 lanes per
     // moment add NT / 16 of them each and fold with four DPP steps (as the float64 tile sweep does)
+    if (threadIdx.x < 320) {
+        const int mm = (int)threadIdx.x >> 4, part = (int)threadIdx.x & 15;
+        const double* row = lacc + mm * NT + part;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NT; k += 64) {
+            const double v0 = row[k], v1 = row[k + 16], v2 = row[k + 32], v3 = row[k + 48];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        double a = (a0 + a1) + (a2 + a3);
+        a += dpp_mov<0x111, 0xF>(a);
+        a += dpp_mov<0x112, 0xF>(a);
+        a += dpp_mov<0x114, 0xF>(a);
+        a += dpp_mov<0x118, 0xF>(a);
+        if (part == 15) partials[(long)blockIdx.x * np + P_W + mm] += a;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT fused sweep, SPLIT flavour (round 4).  The hand-over of pi_adj2d_persist_kernel -- publish, ~1 us until the
+// granules are visible on the memory side, ~1.8 us for 2560 uncached 8-byte loads per workgroup, the slowest neighbour -- was
+// 3.8-4.8 of every 8.8-10.8 us group and nothing ran under it.  A third of a group's work does not need the halo at all:
+// sub-step m restricted to the centred square I_m of side B - 4 (m + 1) depends on the workgroup's own tile only (the
+// "pyramid": 196 + 144 + 100 + 64 of 1464 strips); the rest of each sub-step's region is a ring A_m 2K points thick.
+// Device timelines (tools/persist_dev.hip) say what a barrier interval costs: ~1.15 us for ONE wave per SIMD whatever the
+// strip count (a wave's ~400 instructions issue in ~1 us), ~1.6-1.8 us for two -- so doing pyramid and ring in eight
+// intervals of their own (built first: 12.5 us per group against 10.8) loses what it hides.  What pays is to run the two
+// chains CONCURRENTLY on different waves of the same interval, and only as much pyramid up front as the hand-over needs:
+//     publish | P0: I_0 | request the ring granules | P1: I_1 | check tags, ring -> LDS |
+//     P2: I_2 (waves 0-1) + A_0 (waves 2-6) | P3: A_1 | P4: A_2 | P5: I_3 (wave 0) + A_3 (waves 1-3) | publish ...
+// (seven wave-slots on the busiest SIMD, as the four sub-steps of the unsplit kernel have)
+// The ping-pong buffers need no extra storage: I_m overwrites only the centre of the buffer A_(m-1) no longer reads (A_(m-1)
+// reads level m - 2 outside the square of side B - 4 m - 4, I_m writes level m inside it), and the two parts of a mixed pass
+// write disjoint regions of the same buffer.  Every point is computed by the same device function with the same operands as
+// in the launch-per-group kernel: adjoint state and dL/dh0 stay bit-identical; only the order in which a lane's moment sums
+// are accumulated changes (gradients to summation round-off, as between any two of the sweep's flavours).
+// ------------------------------------------------------------------------------------------------
+// BYTE offsets (inside one species plane) of the two halves of a lane's strip: six passes per group keep six of these
+// alive, and 32-bit offsets next to wave-uniform frame bases (`global_load v, v_off, s[base]`) cost neither the 64-bit
+// per-lane address registers nor the address arithmetic of the StripAddr form
+struct StripOff { unsigned o0, o1; };
+
+template <typename T, int K, int BX, int BY, int NT, int M, int PART, int TID0>
+__device__ __forceinline__ StripOff persist_strip_off(const TileGeom& g, int ty0, int tx0)
+{
+    const StripAddr a = strip_addr<K, BX, BY, NT, M, PART, TID0>(0, g, ty0, tx0);
+    return StripOff{(unsigned)a.e0 * (unsigned)sizeof(T), (unsigned)a.e1 * (unsigned)sizeof(T)};
+}
+
+// pointwise operands of one strip through scalar frame bases (see adj_load_ops for why the loads are unconditional)
+template <typename T>
+__device__ __forceinline__ void persist_load_ops(StripOps<T>& o, const T* __restrict__ hfr, const T* __restrict__ gfr,
+                                                 const TileGeom& g, const StripOff& so)
+{
+    const T* gsrc = gfr ? gfr : hfr;
+    const char* hu = reinterpret_cast<const char*>(hfr);
+    const char* hv = reinterpret_cast<const char*>(hfr + g.ss);
+    const char* ju = reinterpret_cast<const char*>(gsrc);
+    const char* jv = reinterpret_cast<const char*>(gsrc + g.ss);
+    const Pack<T, 2> a = *reinterpret_cast<const Pack<T, 2>*>(hu + so.o0), b = *reinterpret_cast<const Pack<T, 2>*>(hu + so.o1);
+    const Pack<T, 2> c = *reinterpret_cast<const Pack<T, 2>*>(hv + so.o0), d = *reinterpret_cast<const Pack<T, 2>*>(hv + so.o1);
+    const Pack<T, 2> a2 = *reinterpret_cast<const Pack<T, 2>*>(ju + so.o0), b2 = *reinterpret_cast<const Pack<T, 2>*>(ju + so.o1);
+    const Pack<T, 2> c2 = *reinterpret_cast<const Pack<T, 2>*>(jv + so.o0), d2 = *reinterpret_cast<const Pack<T, 2>*>(jv + so.o1);
+    o.u[0] = a.v[0]; o.u[1] = a.v[1]; o.u[2] = b.v[0]; o.u[3] = b.v[1];
+    o.v[0] = c.v[0]; o.v[1] = c.v[1]; o.v[2] = d.v[0]; o.v[3] = d.v[1];
+    o.ju[0] = a2.v[0]; o.ju[1] = a2.v[1]; o.ju[2] = b2.v[0]; o.ju[3] = b2.v[1];
+    o.jv[0] = c2.v[0]; o.jv[1] = c2.v[1]; o.jv[2] = d2.v[0]; o.jv[3] = d2.v[1];
+}
+
+// The six passes of a group: which sub-step / part the waves below SPLIT work on (M1, PART1; strips indexed from lane 0) and
+// which the waves from SPLIT on (M2, PART2; strips indexed from lane SPLIT); SPLIT == NT: one part only.
+template <int PASS> struct PersistPass;
+template <> struct PersistPass<0> { static constexpr int M1 = 0, P1 = PART_PYR, SPLIT = 1 << 30, M2 = 0, P2 = PART_PYR; };
+template <> struct PersistPass<1> { static constexpr int M1 = 1, P1 = PART_PYR, SPLIT = 1 << 30, M2 = 1, P2 = PART_PYR; };
+template <> struct PersistPass<2> { static constexpr int M1 = 2, P1 = PART_PYR, SPLIT = 128, M2 = 0, P2 = PART_ANN; };
+template <> struct PersistPass<3> { static constexpr int M1 = 1, P1 = PART_ANN, SPLIT = 1 << 30, M2 = 1, P2 = PART_ANN; };
+template <> struct PersistPass<4> { static constexpr int M1 = 2, P1 = PART_ANN, SPLIT = 1 << 30, M2 = 2, P2 = PART_ANN; };
+template <> struct PersistPass<5> { static constexpr int M1 = 3, P1 = PART_PYR, SPLIT = 64, M2 = 3, P2 = PART_ANN; };
+
+// the sub-step whose frame a lane's strip of pass PASS belongs to (wave-uniform)
+template <int PASS>
+__device__ __forceinline__ int persist_level(bool upper)
+{
+    using PP = PersistPass<PASS>;
+    return upper ? PP::M2 : PP::M1;
+}
+
+template <typename T, int K, int BX, int BY, int NT, int PASS>
+__device__ __forceinline__ StripOff persist_pass_off(const TileGeom& g, int ty0, int tx0, bool upper)
+{
+    using PP = PersistPass<PASS>;
+    StripOff so;
+    if constexpr (PP::SPLIT >= NT) {
+        so = persist_strip_off<T, K, BX, BY, NT, PP::M1, PP::P1, 0>(g, ty0, tx0);
+    } else {
+        const StripOff lo = persist_strip_off<T, K, BX, BY, NT, PP::M1, PP::P1, 0>(g, ty0, tx0);
+        const StripOff hi = persist_strip_off<T, K, BX, BY, NT, PP::M2, PP::P2, PP::SPLIT>(g, ty0, tx0);
+        so = upper ? hi : lo;
+    }
+    asm volatile("" : "+v"(so.o0), "+v"(so.o1));           // computed in the prologue, not where it is consumed
+    return so;
+}
+
+// one pass: request the NEXT pass's pointwise operands (frames hn / gn, chosen by the caller for this wave), compute, barrier
+template <typename T, int K, int BX, int BY, int NT, int PASS>
+__device__ __forceinline__ void persist_pass(T* b0, T* b1, const T* const (&hf)[K], const T* const (&gf)[K],
+                                             const T* __restrict__ hn, const T* __restrict__ gn, const StripOff& so_next,
+                                             const TileGeom& g, int ty0, int tx0, const T* __restrict__ P, double (&acc_c)[2],
+                                             StripOps<T>& ops, TileMoments<T, true>& mom, bool upper)
+{
+    using PP = PersistPass<PASS>;
+    StripOps<T> ahead;
+    persist_load_ops<T>(ahead, hn, gn, g, so_next);
+    if constexpr (PP::SPLIT >= NT) {
+        constexpr int M = PP::M1;
+        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P1, 0>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M], g, ty0, tx0, P,
+                                                                      acc_c, ops, mom, nullptr);
+    } else if (!upper) {                                   // wave-uniform
+        constexpr int M = PP::M1;
+        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P1, 0>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M], g, ty0, tx0, P,
+                                                                      acc_c, ops, mom, nullptr);
+    } else {
+        constexpr int M = PP::M2;
+        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P2, PP::SPLIT>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M], g, ty0,
+                                                                              tx0, P, acc_c, ops, mom, nullptr);
+    }
+#if PI_PIN_MOMENTS
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int m = 0; m < 10; ++m) asm volatile("" : "+v"(mom.a[s][m]));
+#endif
+    lds_barrier();
+    ops = ahead;
+}
+
+template <typename T, int K, int BX, int BY, int NT>
+__global__ void __launch_bounds__(NT)
+pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gframe_t, T* __restrict__ aframe_t,
+                              long frame_stride, T* __restrict__ g_h0, double* __restrict__ partials, int np,
+                              const T* __restrict__ P, TileGeom g, PersistArgs pa)
+{
+    static_assert(sizeof(T) == 4 && BX == BY && K == 4 && BX == 32 && NT == 512, "float32, 32 x 32 tiles, four sub-steps, 8 waves");
+    using TL = Tile<K, BX, BY>;
+    constexpr int HW = 2 * K, LXW = TL::LX;
+    constexpr int BANDH = BX * BX - (BX - 2 * HW) * (BX - 2 * HW);      // border values per species
+    constexpr int RINGH = LXW * LXW - BX * BX;                          // halo values per species
+    constexpr int NPUB = (2 * BANDH + NT - 1) / NT, NGAT = (2 * RINGH + NT - 1) / NT;
+    static_assert(NPUB + 2 * NGAT <= 13, "tables fit the LDS the host reserves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* b0 = reinterpret_cast<T*>(smem_raw) + lds_pad0<T>::value;
+    T* b1 = reinterpret_cast<T*>(smem_raw) + 2 * TL::PLANE + lds_pad1<T>::value;
+    const int tile = tile_of_block(blockIdx.x, g);
+    const int tyi = tile / g.tiles_x, txi = tile % g.tiles_x, tiles_y = g.H / BY;
+    const int ty0 = tyi * BY, tx0 = txi * BX;
+    const int ntiles = g.tiles_x * tiles_y;
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    gu64* outbox = (gu64*)pa.outbox;
+    // which half of a mixed pass this wave works on (wave-uniform, kept in a scalar register)
+    const int wave_id = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool up2 = wave_id * WAVE >= PersistPass<2>::SPLIT, up5 = wave_id * WAVE >= PersistPass<5>::SPLIT;
+
+    // LDS: state buffers | [20][NT] doubles: the lane's moments of all groups so far | int tables | abort word
+    double* lacc = reinterpret_cast<double*>(smem_raw + tile_state_bytes<T, K, BX, BY>());
+    int* tab_pub = reinterpret_cast<int*>(lacc + 20 * NT);                  // [NPUB][NT]: LDS position of a border value
+    int* tab_gl = tab_pub + NPUB * NT;                                      // [NGAT][NT]: LDS position of a halo value
+    int* tab_gs = tab_gl + NGAT * NT;                                       // [NGAT][NT]: granule index inside a parity half
+    int* wg_abort = tab_pub + 13 * NT;
+    if (threadIdx.x == 0) {                                                 // residency roll call (see pi_adj2d_persist_kernel)
+        *wg_abort = 0;
+        const unsigned n = __hip_atomic_fetch_add(pa.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (n == (unsigned)ntiles && pa.host) __hip_atomic_store(pa.host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+#pragma unroll
+    for (int m = 0; m < 20; ++m) lacc[m * NT + (int)threadIdx.x] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NPUB; ++q) {
+        const int i = (int)threadIdx.x + q * NT;
+        int pl = -1;
+        if (i < 2 * BANDH) {
+            const int sp = i / BANDH, e = i - sp * BANDH;
+            int y, x;                                      // inverse of band_index
+            if (e < HW * BX) { y = e / BX; x = e - y * BX; }
+            else if (e < 2 * HW * BX) { const int m = e - HW * BX; y = BX - HW + m / BX; x = m % BX; }
+            else { const int m = e - 2 * HW * BX; y = HW + m / (2 * HW); const int c = m % (2 * HW); x = c < HW ? c : BX - 2 * HW + c; }
+            pl = sp * TL::PLANE + (HW + y) * LXW + HW + x;
+        }
+        tab_pub[q * NT + (int)threadIdx.x] = pl;
+    }
+#pragma unroll
+    for (int q = 0; q < NGAT; ++q) {
+        const int r = (int)threadIdx.x + q * NT;
+        int gl = -1, gs = 0;
+        if (r < 2 * RINGH) {
+            const int sp = r / RINGH, e = r - sp * RINGH;
+            int wy, wx;                                    // ring positions row-major over the window, skipping the centre
+            if (e < HW * LXW) { wy = e / LXW; wx = e - wy * LXW; }
+            else if (e < HW * LXW + BX * 2 * HW) { const int m = e - HW * LXW; wy = HW + m / (2 * HW); const int c = m % (2 * HW); wx = c < HW ? c : BX + c; }
+            else { const int m = e - HW * LXW - BX * 2 * HW; wy = HW + BX + m / LXW; wx = m % LXW; }
+            const int gy = ty0 + wy - HW, gx = tx0 + wx - HW;                       // global point (may wrap)
+            const int nty = ((gy + g.H) / BY) % tiles_y, ntx = ((gx + g.W) / BX) % g.tiles_x;
+            const int ly = (gy + g.H) % BY, lx = (gx + g.W) % BX;
+            gl = sp * TL::PLANE + wy * LXW + wx;
+            gs = (nty * g.tiles_x + ntx) * (2 * BANDH) + sp * BANDH + band_index<BX, HW>(ly, lx);
+        }
+        tab_gl[q * NT + (int)threadIdx.x] = gl;
+        tab_gs[q * NT + (int)threadIdx.x] = gs;
+    }
+
+    // group 0 starts from the adjoint frame in memory (window = tile + ring), like a launch of pi_adj2d_tile_kernel
+    WindowLoader<T, K, BX, BY, NT> wl;
+    wl.issue(aframe_t, g, ty0, tx0);
+    // the lane's strip in each of the six passes (byte offsets of its pointwise operands)
+    const StripOff so0 = persist_pass_off<T, K, BX, BY, NT, 0>(g, ty0, tx0, false);
+    const StripOff so1 = persist_pass_off<T, K, BX, BY, NT, 1>(g, ty0, tx0, false);
+    const StripOff so2 = persist_pass_off<T, K, BX, BY, NT, 2>(g, ty0, tx0, up2);
+    const StripOff so3 = persist_pass_off<T, K, BX, BY, NT, 3>(g, ty0, tx0, false);
+    const StripOff so4 = persist_pass_off<T, K, BX, BY, NT, 4>(g, ty0, tx0, false);
+    const StripOff so5 = persist_pass_off<T, K, BX, BY, NT, 5>(g, ty0, tx0, up5);
+    unsigned gmask = persist_mask<K>(pa, pa.t_top);
+    StripOps<T> ops;
+    persist_load_ops<T>(ops, hframe_t - frame_stride, gmask & 1u ? gframe_t - frame_stride : nullptr, g, so0);
+    wl.commit(b0);
+    lds_barrier();
+    double acc_c[2] = {0.0, 0.0};
+    TileMoments<T, true> mom;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int m = 0; m < 10; ++m) mom.a[s][m] = V2<T>{T(0), T(0)};
+    for (int grp = 0; grp < pa.ngroups; ++grp) {
+        const bool last = grp + 1 == pa.ngroups;
+        const T* hb = hframe_t - (long)grp * K * frame_stride;            // this group's frame t
+        const T* gb = gframe_t - (long)grp * K * frame_stride;
+        // frame t - 1 - m: the state sub-step m linearises about / the gradient it injects (null: none)
+        const T* hf[K];
+        const T* gf[K];
+#pragma unroll
+        for (int m = 0; m < K; ++m) {
+            hf[m] = hb - (long)(m + 1) * frame_stride;
+            gf[m] = (gmask >> m) & 1u ? gb - (long)(m + 1) * frame_stride : (const T*)nullptr;
+        }
+        PI_PSTAMP(0);
+        // ---- P0: the top of the pyramid -- needs my own tile only; the neighbours' granules are on their way ----
+        persist_pass<T, K, BX, BY, NT, 0>(b0, b1, hf, gf, hf[1], gf[1], so1, g, ty0, tx0, P, acc_c, ops, mom, false);
+        PI_PSTAMP(1);
+        // ---- request the halo ring my neighbours published at the end of their previous group: the loads travel under P1.
+        // (Requested before P0 they come back stale and a second round trip is exposed; requested by the four waves that idle in
+        // P0 / P1 alone, with the publish moved under P0 as well, the hand-over takes those waves 2 us and P0 waits for them --
+        // both measured, tools/persist_dev.hip, profiles/r04_persistent_split_timelines.txt.) ----
+        const unsigned epoch = (unsigned)grp;
+        gu64* half = outbox + (size_t)(epoch & 1u) * (size_t)ntiles * (2 * BANDH);
+        int gs[NGAT];
+        unsigned long long gx[NGAT];
+        if (grp > 0) {
+#pragma unroll
+            for (int q = 0; q < NGAT; ++q) {
+                gs[q] = tab_gs[q * NT + (int)threadIdx.x];
+                gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (lanes without: granule 0)
+            }
+        }
+        // ---- P1 ----
+        persist_pass<T, K, BX, BY, NT, 1>(b0, b1, hf, gf, up2 ? hf[0] : hf[2], up2 ? gf[0] : gf[2], so2, g, ty0, tx0, P, acc_c, ops, mom,
+                                          false);
+        PI_PSTAMP(2);
+        if (grp > 0) {
+            int gl[NGAT];
+#pragma unroll
+            for (int q = 0; q < NGAT; ++q) gl[q] = tab_gl[q * NT + (int)threadIdx.x];
+            const unsigned long long t0 = wall_clock64();
+            const unsigned long long bound = grp == 1 ? pa.first_timeout_ticks : pa.timeout_ticks;
+            bool failed = false;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < NGAT; ++q)
+                    if (gl[q] >= 0) ok &= (unsigned)(gx[q] >> 32) == epoch;
+                if (__all(ok)) break;
+                // give up when the wait is over its bound (the first to do so raises the abort flag below) or when another
+                // workgroup already has: a launch whose workgroups are not all resident ends within the bound
+                if (wall_clock64() - t0 > bound ||
+                    __hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { failed = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int q = 0; q < NGAT; ++q)
+                    if (gl[q] >= 0 && (unsigned)(gx[q] >> 32) != epoch)
+                        gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (failed) {
+                if (threadIdx.x % WAVE == 0) *wg_abort = 1;
+            } else {
+#pragma unroll
+                for (int q = 0; q < NGAT; ++q)
+                    if (gl[q] >= 0) b0[gl[q]] = __builtin_bit_cast(T, (unsigned)gx[q]);
+            }
+            lds_barrier();
+        }
+        if (grp > 0 && *wg_abort) {                        // ABORT: nothing this launch was asked for is written
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(pa.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_exchange(pa.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && pa.host) {
+                    __hip_atomic_store(pa.host + 1, grp - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pa.host + 2, tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pa.host + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            return;
+        }
+        PI_PSTAMP(3);
+        // ---- P2 .. P5: the rest of the pyramid next to the ring passes ----
+        persist_pass<T, K, BX, BY, NT, 2>(b0, b1, hf, gf, hf[1], gf[1], so3, g, ty0, tx0, P, acc_c, ops, mom, up2);
+        PI_PSTAMP(4);
+        persist_pass<T, K, BX, BY, NT, 3>(b0, b1, hf, gf, hf[2], gf[2], so4, g, ty0, tx0, P, acc_c, ops, mom, false);
+        PI_PSTAMP(5);
+        persist_pass<T, K, BX, BY, NT, 4>(b0, b1, hf, gf, hf[3], gf[3], so5, g, ty0, tx0, P, acc_c, ops, mom, false);
+        PI_PSTAMP(6);
+        // (the operands the last pass requests belong to the next group's P0: frame t - K - 1)
+        const unsigned gmask_next = last ? gmask : persist_mask<K>(pa, pa.t_top - K * (grp + 1));
+        const T* hn = last ? hf[3] : hb - (long)(K + 1) * frame_stride;
+        const T* gn = last ? gf[3] : (gmask_next & 1u ? gb - (long)(K + 1) * frame_stride : (const T*)nullptr);
+        persist_pass<T, K, BX, BY, NT, 5>(b0, b1, hf, gf, hn, gn, last ? so5 : so0, g, ty0, tx0, P, acc_c, ops, mom, up5);
+        PI_PSTAMP(7);
+        // the float32 2-vector moment sums are folded into the lane's double sums in LDS every fourth group (see the unsplit kernel)
+        if ((grp & 3) == 3 || last) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int m = 0; m < 10; ++m) {
+                    double* slot = lacc + (10 * s + m) * NT + (int)threadIdx.x;
+                    *slot += (double)mom_total(mom.a[s][m]);
+                    mom.a[s][m] = V2<T>{T(0), T(0)};
+                }
+        }
+        if (last) {
+            // the result of the last group goes to memory: frame t - K of the adjoint trajectory, or dL/dh0 itself
+            T* dst = g_h0 ? g_h0 : aframe_t - (long)(grp + 1) * K * frame_stride;
+            tile_store<T, K, BX, BY, NT, true>(b0, dst, g, ty0, tx0);
+            break;
+        }
+        gmask = gmask_next;
+        // ---- publish my band (the border 2K points of the tile, complete since the barrier that ended P5) ----
+        const unsigned ep1 = (unsigned)grp + 1u;
+        gu64* mine = outbox + (size_t)(ep1 & 1u) * (size_t)ntiles * (2 * BANDH) + (size_t)tile * (2 * BANDH);
+#pragma unroll
+        for (int q = 0; q < NPUB; ++q) {
+            const int pl = tab_pub[q * NT + (int)threadIdx.x];
+            if (pl >= 0) {
+                const unsigned v = __builtin_bit_cast(unsigned, b0[pl]);
+                __hip_atomic_store(mine + (int)threadIdx.x + q * NT, ((unsigned long long)ep1 << 32) | v, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        PI_PSTAMP(8);
+        // (no barrier: the next pass, P0, reads b0 -- complete -- and writes b1's centre, which nobody reads any more)
+    }
+
+    // ---- once per rollout: diffusion-coefficient sums and the 20 moments of this tile -> its partial row -------------------
+    lds_barrier();
+    double* red = reinterpret_cast<double*>(smem_raw);     // state buffers are dead now: [2][NT / WAVE] doubles
+    constexpr int NW = NT / WAVE;
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const double r = wave_sum_to_last(acc_c[s]);
+        if (lane == REDUCE_LANE) red[s * NW + wave] = r;
+    }
+    lds_barrier();
+    if (threadIdx.x < 2) {
+        double sum = 0.0;
+        for (int w = 0; w < NW; ++w) sum += red[(int)threadIdx.x * NW + w];
+        partials[(long)blockIdx.x * np + P_COEF + (int)threadIdx.x] += sum;
+    }
     if (threadIdx.x < 320) {
         const int mm = (int)threadIdx.x >> 4, part = (int)threadIdx.x & 15;
         const double* row = lacc + mm * NT + part;

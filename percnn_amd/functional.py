@@ -116,15 +116,75 @@ def _check_pack_inputs(tensors):
             raise ValueError("pack_block: tensors must be contiguous and share device and dtype")
 
 
-def pack_fwd_hip(tensors, hc: int, ndim: int, dt: float, mu_up: float, sigmoid: bool, contract: bool) -> torch.Tensor:
+def pack_fwd_hip(tensors, hc: int, ndim: int, dt: float, mu_up: float, sigmoid: bool, contract: bool, guard=None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """guard = (host_slot_address, seq, u_max, v_max): the launch also leaves the conditioning number A of the pre-contracted
+    form and `seq` in the host-mapped slot (include/percnn_pi.h, percnn_pi_pack_fwd_guard_*); out: write into this block."""
     _check_pack_inputs(tensors)
     w = tensors[2]
-    out = torch.empty(NPOLY if contract else param_count(hc), dtype=w.dtype, device=w.device)
-    f = getattr(_lib.lib(), "percnn_pi_pack_fwd_" + _SUF[w.dtype])
+    n = NPOLY if contract else param_count(hc)
+    if out is None:
+        out = torch.empty(n, dtype=w.dtype, device=w.device)
+    elif out.numel() != n or out.dtype != w.dtype or out.device != w.device or not out.is_contiguous():
+        raise ValueError("pack_fwd_hip: `out` does not fit this block")
     with torch.cuda.device(w.device):
-        _lib.check(f(ctypes.byref(_param_ptrs(tensors)), hc, ndim, float(dt), float(mu_up), int(sigmoid), int(contract),
-                     out.data_ptr(), _stream()), "pack_fwd")
+        if guard is None:
+            f = getattr(_lib.lib(), "percnn_pi_pack_fwd_" + _SUF[w.dtype])
+            _lib.check(f(ctypes.byref(_param_ptrs(tensors)), hc, ndim, float(dt), float(mu_up), int(sigmoid), int(contract),
+                         out.data_ptr(), _stream()), "pack_fwd")
+        else:
+            slot, seq, u_max, v_max = guard
+            f = getattr(_lib.lib(), "percnn_pi_pack_fwd_guard_" + _SUF[w.dtype])
+            _lib.check(f(ctypes.byref(_param_ptrs(tensors)), hc, ndim, float(dt), float(mu_up), int(sigmoid), int(contract),
+                         out.data_ptr(), float(u_max), float(v_max), ctypes.c_void_p(slot), float(seq), _stream()),
+                       "pack_fwd_guard")
     return out
+
+
+class PolyGuard:
+    """Host side of the conditioning guard of reaction='poly' (VERDICT r3 #2a; the rule is RCNNCell's docstring): every pack
+    launch leaves A = |dt| max_s sum_m |c_m^s| phi_m(bound) / max(bound) and its sequence number in two host-mapped doubles;
+    ``decide()`` reads them WITHOUT synchronising -- the value of the most recent pack that has completed, normally the previous
+    training iteration's -- and flips the cell between the pre-contracted and the factored block with hysteresis."""
+
+    def __init__(self, device):
+        self._lib = _lib
+        p = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().percnn_pi_host_words_alloc(ctypes.byref(p), 16), "host_words_alloc")
+        self.address = p.value
+        self._view = (ctypes.c_double * 2).from_address(self.address)
+        self.issued = 0                  # sequence number of the last pack launched with this slot
+        self.seen = 0                    # ... of the last one whose A has been read
+        self.A = None
+        self.factored = False
+        import weakref
+        weakref.finalize(self, _lib.lib().percnn_pi_host_words_free, ctypes.c_void_p(self.address))
+
+    def next_seq(self) -> int:
+        self.issued += 1
+        return self.issued
+
+    def read(self):
+        """-> (A, seq) of the latest completed pack, or (None, 0)"""
+        s0 = self._view[1]
+        a = self._view[0]
+        s1 = self._view[1]
+        if s0 != s1:                     # a launch wrote between the two reads: the next call sees it
+            return self.A, self.seen
+        if s1 > 0:
+            self.A, self.seen = float(a), int(s1)
+        return self.A, self.seen
+
+    def decide(self, a_max: float) -> bool:
+        """True: pack the factored block.  Switch up above a_max, back below a_max / 2."""
+        A, _ = self.read()
+        if A is not None:
+            if not self.factored and A > a_max:
+                self.factored = True
+            elif self.factored and A < 0.5 * a_max:
+                self.factored = False
+        return self.factored
 
 
 def pack_bwd_hip(tensors, g_block: torch.Tensor, hc: int, ndim: int, dt: float, mu_up: float, sigmoid: bool,
@@ -153,22 +213,30 @@ def pack_bwd_hip(tensors, g_block: torch.Tensor, hc: int, ndim: int, dt: float, 
 
 
 class PackBlockFunction(torch.autograd.Function):
-    """Eager-mode front of the two pack kernels: ``apply(meta, *tensors)`` with meta = (hc, ndim, dt, mu_up, sigmoid,
-    contract).  A plain autograd.Function on purpose -- measured on the MI355X box's host (tools/pack_time.py), per call
+    """Eager-mode front of the two pack kernels: ``apply(meta, guard, *tensors)`` with meta = (hc, ndim, dt, mu_up, sigmoid,
+    contract), guard = None or pack_fwd_hip's guard tuple.  A plain autograd.Function on purpose -- measured on the MI355X box's host (tools/pack_time.py), per call
     without / with backward: stock tensor ops 86 / 550 us, the registered operator (torch.ops.percnn.pack_block, what
     torch.compile traces) 38 / 480-840 us, this 21 / 320 us: with one small launch each way the dispatcher's Python
     layers are what is left to pay."""
 
     @staticmethod
-    def forward(ctx, meta, *tensors):
+    def forward(ctx, meta, guard, *tensors):
         ctx.meta = meta
-        ctx.save_for_backward(*tensors)
-        return pack_fwd_hip(tensors, *meta)
+        # NOT save_for_backward: the block is cached by RCNNCell.param_block and shared by every step of an iteration, so
+        # several backward() calls may run through this node (`out1 = cell(h1); out2 = cell(h2); out1.sum().backward();
+        # out2.sum().backward()`, ADVICE r3) -- saved tensors would be freed by the first.  The parameters are leaves that
+        # outlive the node; the in-place check save_for_backward would have made is done by hand.
+        ctx.tensors = tensors
+        ctx.versions = tuple(t._version for t in tensors)
+        return pack_fwd_hip(tensors, *meta, guard=guard)
 
     @staticmethod
     def backward(ctx, g):
-        gr = pack_bwd_hip(ctx.saved_tensors, g, *ctx.meta, one_buffer=True)
-        return (None, gr[0], gr[1], None, *gr[2:])
+        if tuple(t._version for t in ctx.tensors) != ctx.versions:
+            raise RuntimeError("percnn_amd: a parameter of the packed block was modified in place between the forward and "
+                               "this backward pass (same rule as autograd's saved tensors)")
+        gr = pack_bwd_hip(ctx.tensors, g, *ctx.meta, one_buffer=True)
+        return (None, None, gr[0], gr[1], None, *gr[2:])
 
 
 # ------------------------------------------------------------------------------------------------

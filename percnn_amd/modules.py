@@ -97,6 +97,14 @@ class RCNNCell(nn.Module):
         self._stencil_checked_version = None
         self._dt_cache = None
         self._block_cache = None            # (key, packed block) of the last param_block() call, see _block_key
+        # conditioning guard of reaction='poly' (class docstring): on a HIP device the pack launch prices the expanded cubic
+        # (amplification A for states inside `state_bound`) and the cell packs the FACTORED block -- the reference's own
+        # operation order -- while A is above `poly_guard_max` (None: 10 in float32, 1e4 in float64)
+        self.poly_guard = True
+        self.state_bound = (1.0, 1.0)       # |u|, |v| the amplification is priced at (Gray-Scott / lambda-omega states)
+        self.poly_guard_max = None
+        self._guard = None
+        self._guard_warned = False
 
     def init_filter(self, filter_list, c, mode="xavier"):
         for f in filter_list:
@@ -108,6 +116,7 @@ class RCNNCell(nn.Module):
                 f.weight.data.uniform_(-b, b)
             if f.bias is not None:
                 f.bias.data.fill_(0.0)
+        self.invalidate_cache()            # `.data` edits do not move the version counters the cache is keyed on
 
     # -- parameter block ----------------------------------------------------------------------
     def coefficients(self):
@@ -145,33 +154,40 @@ class RCNNCell(nn.Module):
         self.__dict__["_pack_list"] = (tensors, src)
         return tensors
 
-    def _block_key(self, tensors):
-        """What a packed block depends on: every parameter's version counter and storage (optimizer.step(), load_state_dict,
-        .to(), parameter surgery), dt (the reference reads self.dt every step, train_2drd.py:117), the reaction mode and
-        whether autograd records."""
-        return (tuple(t._version for t in tensors), tensors[0].data_ptr(), tensors[2].data_ptr(), tensors[3].data_ptr(),
-                float(self.dt), self.reaction, self.diffusion, torch.is_grad_enabled())
+    def invalidate_cache(self) -> None:
+        """Drop the cached parameter block.  REQUIRED after editing a parameter through ``.data`` (``p.data.mul_()``,
+        ``.data.uniform_()``, ``.data.fill_()``, ...): such edits do not move the version counters the cache is keyed on
+        (``init_filter`` calls this itself).  Ordinary updates -- ``optimizer.step()``, ``load_state_dict``, ``p.copy_()`` under
+        ``no_grad``, ``.to()``, replacing a Parameter or its ``.data`` -- are seen without it."""
+        self.__dict__["_block_cache"] = None
 
-    def param_block(self) -> torch.Tensor:
+    def _block_key(self, tensors):
+        """What a packed block depends on: every parameter's version counter AND storage address (optimizer.step(),
+        load_state_dict, .to(), parameter surgery, `p.data = new` on any of the 19 tensors -- ADVICE r3), dt (the reference
+        reads self.dt every step, train_2drd.py:117), the reaction mode, the guard's settings and whether autograd records."""
+        return (tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors), float(self.dt), self.reaction,
+                self.diffusion, torch.is_grad_enabled(), bool(self.poly_guard), tuple(self.state_bound), self.poly_guard_max)
+
+    def param_block(self, fresh: bool = False) -> torch.Tensor:
         """The packed parameter block the kernels read.  A caller that keeps the reference's own step loop
         (``for step in range(T): h, _ = cell(h)``, train_2drd.py:169-188) calls this once per time step; the block is
         therefore cached until something it depends on changes (_block_key) or until a backward pass has run through it
-        (its autograd node is consumed then): one pack launch and ONE pack-backward per training iteration instead of T,
-        the per-step gradients accumulate on the shared block.  (20-55 us per call, 180-280 us with
-        backward, per STEP before.)"""
-        w = self.W_laplace.weight
+        (the gradient of that pass has been delivered: the next iteration gets a fresh block): one pack launch and ONE
+        pack-backward per training iteration instead of T, the per-step gradients accumulate on the shared block.
+        ``fresh=True`` (what ``RCNN``'s rollout entry points pass: one pack launch per ROLLOUT is free) never returns a cached
+        block, so a rollout sees ``.data`` edits even without ``invalidate_cache()``."""
         if not torch.compiler.is_compiling():
             tensors = self._pack_tensors()
             key = self._block_key(tensors)
             hit = self._block_cache
-            if hit is not None and hit[0] == key:
+            if hit is not None and hit[0] == key and not fresh:
                 return hit[1]
             P = self._param_block_uncached()
             if P.requires_grad:
                 import weakref
                 me = weakref.ref(self)
 
-                def consumed(_g, me=me, P_id=id(P)):          # backward reached the block: its graph is gone after this pass
+                def consumed(_g, me=me, P_id=id(P)):          # a backward pass reached the block: next iteration, new block
                     cell = me()
                     if cell is not None and cell._block_cache is not None and id(cell._block_cache[1]) == P_id:
                         cell._block_cache = None
@@ -179,6 +195,52 @@ class RCNNCell(nn.Module):
             self._block_cache = (key, P)
             return P
         return self._param_block_uncached()
+
+    # -- conditioning guard of the pre-contracted form ------------------------------------------------
+    def _guard_bound(self, dtype) -> float:
+        if self.poly_guard_max is not None:
+            return float(self.poly_guard_max)
+        return 10.0 if dtype == torch.float32 else 1.0e4
+
+    def _pack_guarded(self, tensors, meta_head):
+        """Pack with the guard slot attached.  The decision uses the amplification of the latest pack launch that has
+        COMPLETED (no synchronisation: in a training loop that is the previous iteration's, and the weights move by one
+        optimizer step in between; hysteresis a_max -> a_max / 2); only the very first pack of a cell waits for its own
+        value (one event synchronisation), so a freshly loaded ill-conditioned checkpoint never runs a step in 'poly'."""
+        w = tensors[2]
+        if self._guard is None:
+            self._guard = F_pi.PolyGuard(w.device)
+        gd = self._guard
+        a_max = self._guard_bound(w.dtype)
+        first = gd.seen == 0
+        was = gd.factored
+        factored = gd.decide(a_max)
+        ub, vb = (float(x) for x in self.state_bound)
+        P = F_pi.PackBlockFunction.apply(meta_head + (not factored,), (gd.address, gd.next_seq(), ub, vb), *tensors)
+        if first and not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record()
+            ev.synchronize()
+            if gd.decide(a_max) != factored:                  # the first value is in: ill-conditioned from the start
+                factored = gd.factored
+                P = F_pi.PackBlockFunction.apply(meta_head + (not factored,), (gd.address, gd.next_seq(), ub, vb), *tensors)
+        if factored != was:
+            import warnings
+            if factored and not self._guard_warned:
+                self._guard_warned = True
+                warnings.warn(
+                    f"percnn_amd: reaction='poly' is ill-conditioned for these weights (amplification A = {gd.A:.3g} > "
+                    f"{a_max:g} for states within {tuple(self.state_bound)}): this cell evaluates the FACTORED form -- the "
+                    f"reference's own operation order, train_2drd.py:115-116 -- until A drops below {0.5 * a_max:g}.  "
+                    f"Construct the cell with reaction='factored' to silence this, or set cell.state_bound / "
+                    f"cell.poly_guard_max.", RuntimeWarning, stacklevel=4)
+        return P
+
+    @property
+    def effective_reaction(self) -> str:
+        """'factored' while the guard has switched a reaction='poly' cell to the literal evaluation, else ``reaction``."""
+        gd = self._guard
+        return "factored" if (self.reaction == "poly" and gd is not None and gd.factored) else self.reaction
 
     def _param_block_uncached(self) -> torch.Tensor:
         w = self.W_laplace.weight
@@ -191,12 +253,14 @@ class RCNNCell(nn.Module):
             # (anything the kernel's pointer table cannot describe -- views, mixed dtypes / devices -- takes the tensor-op
             # assembly below instead of raising)
             if all(t.is_contiguous() and t.dtype == w.dtype and t.device == w.device for t in tensors):
-                meta = (self.hidden_channels, self.ndim, float(self.dt),
-                        float(self.mu_up) if self.diffusion == "sigmoid" else 0.0, self.diffusion == "sigmoid",
-                        self.reaction == "poly")
-                if torch.compiler.is_compiling():            # the registered operator is what a graph can hold
-                    return torch.ops.percnn.pack_block(tensors, *meta)
-                return F_pi.PackBlockFunction.apply(meta, *tensors)
+                head = (self.hidden_channels, self.ndim, float(self.dt),
+                        float(self.mu_up) if self.diffusion == "sigmoid" else 0.0, self.diffusion == "sigmoid")
+                meta = head + (self.reaction == "poly",)
+                if torch.compiler.is_compiling():            # the registered operator is what a graph can hold (no guard
+                    return torch.ops.percnn.pack_block(tensors, *meta)    # inside a traced graph: see INTEGRATION.md)
+                if self.reaction == "poly" and self.poly_guard:
+                    return self._pack_guarded(tensors, head)
+                return F_pi.PackBlockFunction.apply(meta, None, *tensors)
         if torch.compiler.is_compiling():
             # traced by torch.compile: no host-side checks / caches inside the graph (the stencil was validated by the
             # eager call that preceded compilation or is validated by the first eager use)
@@ -565,13 +629,21 @@ class RCNN(nn.Module):
     def cell(self):
         return getattr(self, self.cell_name)
 
+    def _block(self):
+        """The cell's parameter block for ONE rollout: packed afresh where the cell caches (``RCNNCell.param_block(fresh=True)``
+        -- a pack launch per rollout costs nothing and a rollout then never runs on a block made stale by a ``.data`` edit)."""
+        cell = self.cell
+        if isinstance(cell, RCNNCell):
+            return cell.param_block(fresh=True)
+        return cell.param_block()
+
     def trajectory(self) -> torch.Tensor:
         """[step+1, 2, *S]: every state of the rollout (what callers cat together, train_2drd.py:394)."""
         if hasattr(self, "UpconvBlock"):
             self.init_state = self.UpconvBlock(self.init_state_low)
         if hasattr(self.cell, "rollout"):                   # cells with their own kernels (Stage-1 block)
             return self.cell.rollout(self.init_state, self.step)
-        return F_pi.pi_rollout(self.init_state, self.cell.param_block(), self.step)
+        return F_pi.pi_rollout(self.init_state, self._block(), self.step)
 
     def observe(self, t_slice=slice(None), space_stride: int = 1):
         """``torch.cat(self()[0])[t_slice][:, :, ::s, ::s(, ::s)]`` -- the tensor the reference's data loss is computed
@@ -587,7 +659,7 @@ class RCNN(nn.Module):
         if hasattr(self.cell, "rollout_observe"):           # cells with their own kernels (Stage-1 block)
             pred, traj = self.cell.rollout_observe(self.init_state, self.step, t_idx, (space_stride,) * ndim)
         else:
-            pred, traj = F_pi.pi_rollout_observe(self.init_state, self.cell.param_block(), self.step, t_idx,
+            pred, traj = F_pi.pi_rollout_observe(self.init_state, self._block(), self.step, t_idx,
                                                  (space_stride,) * ndim)
         self.last_trajectory = traj
         return pred
@@ -619,7 +691,7 @@ class RCNN(nn.Module):
         if hasattr(self, "UpconvBlock"):
             self.init_state = self.UpconvBlock(self.init_state_low)
         frames = list(range(self.step + 1))[t_slice]
-        loss, traj = F_pi.pi_rollout_sqerr(self.init_state, self.cell.param_block(), self.step, target, frames, reduction)
+        loss, traj = F_pi.pi_rollout_sqerr(self.init_state, self._block(), self.step, target, frames, reduction)
         self.last_trajectory = traj
         return loss
 
@@ -634,7 +706,7 @@ class RCNN(nn.Module):
         if hasattr(self.cell, "rollout_frames"):            # cells with their own kernels (Stage-1 block)
             outs = self.cell.rollout_frames(self.init_state, self.step, frames)
         else:
-            outs = F_pi.pi_rollout_frames(self.init_state, self.cell.param_block(), self.step, frames)
+            outs = F_pi.pi_rollout_frames(self.init_state, self._block(), self.step, frames)
         outputs = list(outs[:n_out])
         second_last_state = outs[n_out].clone() if self.step >= 2 else []
         return outputs, second_last_state

@@ -141,8 +141,13 @@ def physics_loss(output: torch.Tensor, Q: torch.Tensor, reference_weighting: boo
     One autograd node (``PhysicsLossFunction``); ``fused=False`` keeps the residual-tensor expression (tests compare the two)."""
     # (the one-node route keeps one partial sum per workgroup in a fixed 16384-slot workspace: grids beyond 2^24 points per
     # species take the residual-tensor expression)
+    # and so does any grid the fused pass turns down (PERCNN_PI_ETOOLARGE: e.g. float64 256^3, or a float32 grid above 2^22
+    # points that loses its 16-byte lanes -- more workgroups than partial slots; nothing has been launched then)
     if fused and output.is_cuda and 3 <= output.shape[0] <= 65535 and output[0, 0].numel() <= (1 << 24):
-        return PhysicsLossFunction.apply(output.contiguous(), Q, output.shape[0] - 2, reference_weighting)
+        try:
+            return PhysicsLossFunction.apply(output.contiguous(), Q, output.shape[0] - 2, reference_weighting)
+        except _lib.GridTooLargeError:
+            pass
     R = physics_residual(output[:-1], Q)              # frames 0 .. len-3
     sq = R * R
     if reference_weighting:

@@ -147,6 +147,13 @@ class HaloExchanger:
         self.exchange(slab, halo, width)
         return _Done()
 
+    def check_and_all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        """End of a slab backward: ``check()`` then the gradient all-reduce.  Transports whose exchanges can fail WITHOUT an
+        error code override this so that a rank that found a failure still takes part in the collective (and every rank
+        raises): raising before the all-reduce would leave the healthy ranks blocked in it."""
+        self.check()
+        return self.all_reduce_sum_(t)
+
     def all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
         if self.world > 1:
             if t.is_cuda and dist.get_backend(self.group) == "gloo":
@@ -411,6 +418,24 @@ class PeerHaloExchanger(HaloExchanger):
         if e:
             raise RuntimeError(f"percnn_amd: peer-mailbox halo exchange #{e} of rank {self.rank} timed out (a ring neighbour "
                                f"did not deliver within PERCNN_PEER_TIMEOUT_S); halos from that exchange on are NaN")
+
+    def check_and_all_reduce_sum_(self, t: torch.Tensor) -> torch.Tensor:
+        """The failure flag rides on the gradient all-reduce (one extra element): a rank whose take timed out does not raise
+        BEFORE the collective -- its peers would wait in it for ever -- and afterwards every rank raises."""
+        err = None
+        try:
+            self.check()
+        except RuntimeError as e:
+            err = e
+        buf = torch.cat([t.reshape(-1), t.new_full((1,), 1.0 if err is not None else 0.0)])
+        self.all_reduce_sum_(buf)
+        t.copy_(buf[:-1].reshape(t.shape))
+        if err is not None:
+            raise err
+        if self.world > 1 and float(buf[-1]) > 0:
+            raise RuntimeError(f"percnn_amd: a peer-mailbox halo exchange timed out on {int(float(buf[-1]))} other rank(s) of "
+                               f"this ring; the gradients of this backward are invalid")
+        return t
 
     # -- exchanges -------------------------------------------------------------------------------------------------
     def exchange(self, slab: torch.Tensor, halo: int, width: Optional[int] = None) -> None:
@@ -696,8 +721,7 @@ def slab_rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor, 
         usable, ring = ex.native_ring()
         if usable:
             adj, pg = F_pi.slab_rollout_bwd_native(traj, g_traj, P, halo, ring, overlap and ring is not None)
-            ex.check()
-            ex.all_reduce_sum_(pg)
+            ex.check_and_all_reduce_sum_(pg)
             return adj[0], pg
     T = traj.shape[0] - 1
     n = traj.shape[2] - 2 * halo
@@ -753,8 +777,7 @@ def slab_rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor, 
         g0 = adj[0]
     else:
         g0 = dst(1)
-    ex.check()
-    ex.all_reduce_sum_(pg)
+    ex.check_and_all_reduce_sum_(pg)
     return g0, pg
 
 
