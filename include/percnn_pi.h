@@ -474,6 +474,22 @@ int percnn_pi_step_bwd_opt_f32(const float *h, const float *g_out, const float *
 int percnn_pi_step_bwd_opt_f64(const double *h, const double *g_out, const double *g_inject, double *g_in,
                                double *param_grad, void *workspace, size_t workspace_bytes, const double *params,
                                int hc, int ndim, const int64_t *shape, const char *options, void *stream);
+/* One adjoint step whose parameter-gradient sums STAY in the workspace's partial rows (a reference-style loop,
+ * train_2drd.py:169-188, differentiated by autograd node by node: T calls of this, ONE percnn_pi_bwd_rows_finish_* at the end
+ * instead of a reset + reduction launch per step).  flags: PERCNN_PI_NO_RESET when the rows already hold sums of earlier calls
+ * of the same pass (the first call of a pass zeroes them).  The workspace must be the same buffer, and (hc, shape) the same
+ * problem, for all calls of one pass.  Arguments otherwise as percnn_pi_step_bwd_*. */
+int percnn_pi_step_bwd_rows_f32(const float *h, const float *g_out, const float *g_inject, float *g_in, void *workspace,
+                                size_t workspace_bytes, const float *params, int hc, int ndim, const int64_t *shape,
+                                int flags, void *stream);
+int percnn_pi_step_bwd_rows_f64(const double *h, const double *g_out, const double *g_inject, double *g_in, void *workspace,
+                                size_t workspace_bytes, const double *params, int hc, int ndim, const int64_t *shape,
+                                int flags, void *stream);
+/* param_grad (double[percnn_pi_param_count(hc)]) += the sums those calls left in the rows (one launch). */
+int percnn_pi_bwd_rows_finish_f32(void *workspace, size_t workspace_bytes, int hc, int ndim, const int64_t *shape,
+                                  double *param_grad, void *stream);
+int percnn_pi_bwd_rows_finish_f64(void *workspace, size_t workspace_bytes, int hc, int ndim, const int64_t *shape,
+                                  double *param_grad, void *stream);
 int percnn_pi_rollout_fwd_opt_f32(float *traj, const float *params, int hc, int ndim, const int64_t *shape,
                                   int T, const char *options, void *stream);
 int percnn_pi_rollout_fwd_opt_f64(double *traj, const double *params, int hc, int ndim, const int64_t *shape,

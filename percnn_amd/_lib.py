@@ -23,6 +23,31 @@ SOURCES = {
     "pi_up3d_abi.hip": ["pi_up3d.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h")],
 }
 
+# the PyTorch operator library + eager fast path (csrc/torch_ext.cpp: TORCH_LIBRARY(percnn) operators with C++ autograd,
+# dispatcher -> C-ABI without a Python / ctypes frame); links libpercnn_pi.so, loaded by `torch_ext()` below
+TORCH_EXT_SRC = os.path.join(CSRC, "torch_ext.cpp")
+TORCH_EXT_PATH = os.path.join(CSRC, "percnn_torch.so")
+
+
+def _torch_ext_commands():
+    """(compile command, link command) of the operator library: plain g++ against the torch headers of THIS interpreter's
+    PyTorch-ROCm (hip headers only for the stream type: -D__HIP_PLATFORM_AMD__ is what they ask for, not a dual path)"""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    cxx = os.environ.get("CXX", "g++")
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    obj = os.path.join(CSRC, "torch_ext.o")
+    inc = [f"-I{d}" for d in ce.include_paths()] + ["-I/opt/rocm/include", f"-I{sysconfig.get_paths()['include']}",
+                                                    f"-I{os.path.join(CSRC, _INC)}"]
+    abi = int(getattr(torch._C, "_GLIBCXX_USE_CXX11_ABI", True))
+    compile_cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+                   "-DTORCH_EXTENSION_NAME=percnn_torch", f"-D_GLIBCXX_USE_CXX11_ABI={abi}"] + inc + ["-c", "-o", obj, TORCH_EXT_SRC]
+    link_cmd = [cxx, "-shared", "-o", TORCH_EXT_PATH, obj, f"-L{tlib}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip",
+                "-ltorch_hip", "-ltorch_python", f"-L{CSRC}", "-lpercnn_pi", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    return obj, compile_cmd, link_cmd
+
+
 EXPORTS = [
     "percnn_pi_abi_version", "percnn_pi_param_count", "percnn_pi_bwd_workspace_bytes",
     "percnn_pi_rollout_bwd_workspace_bytes", "percnn_pi_set_option", "percnn_pi_persist_status", "percnn_pi_halo_ring_bytes",
@@ -39,7 +64,7 @@ EXPORTS = [
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
                 "slab_step_fwd_range", "slab_step_bwd_range", "slab_rollout_fwd", "slab_rollout_bwd", "residual_fwd",
                 "residual_bwd", "contract_fwd", "contract_bwd", "step_fwd_opt", "step_bwd_opt", "rollout_fwd_opt",
-                "rollout_bwd_opt", "rollout_bwd_sqerr", "traj_sqerr")] + [
+                "rollout_bwd_opt", "rollout_bwd_sqerr", "traj_sqerr", "step_bwd_rows", "bwd_rows_finish")] + [
     "percnn_pi_s1_param_count", "percnn_pi_s1_step_fwd_f32", "percnn_pi_s1_rollout_fwd_f32",
     "percnn_pi_s1_rollout_bwd_workspace_bytes", "percnn_pi_s1_rollout_bwd_f32", "percnn_pi_s1_set_option",
     "percnn_pi_conv3d_k5c8_f32", "percnn_pi_conv3d_k5c8_wgrad_workspace_bytes", "percnn_pi_conv3d_k5c8_wgrad_f32",
@@ -62,12 +87,21 @@ def build(force: bool = False, extra_flags=(), out: str | None = None) -> str:
             cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-c", "-o", obj, os.path.join(CSRC, src)]
             procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
             relink = True
+    # the operator library's object compiles next to the HIP translation units (g++, ~40 s), it is linked after the library
+    ext_obj, ext_compile, ext_link = _torch_ext_commands()
+    ext_deps = [TORCH_EXT_SRC, os.path.join(CSRC, _INC, "percnn_pi.h")]
+    ext_stale = force or not os.path.exists(ext_obj) or any(os.path.getmtime(ext_obj) < os.path.getmtime(d) for d in ext_deps)
+    if ext_stale and not tag:
+        procs.append((ext_compile, subprocess.Popen(ext_compile, cwd=CSRC)))
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
     relinked = relink or any(os.path.getmtime(out) < os.path.getmtime(o) for o in objs)
     if relinked:
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs, cwd=CSRC)
+    if not tag and out == os.path.join(CSRC, "libpercnn_pi.so") and (
+            ext_stale or not os.path.exists(TORCH_EXT_PATH) or os.path.getmtime(TORCH_EXT_PATH) < os.path.getmtime(ext_obj)):
+        subprocess.check_call(ext_link, cwd=CSRC)
     # what this call actually did (a tree that already carries objects / the library compiles nothing unless forced)
     global last_build
     last_build = {"build_mode": "forced" if force else "incremental",
@@ -80,6 +114,30 @@ last_build: dict = {}
 
 
 _lib = None
+_torch_ext = None
+
+
+def torch_ext():
+    """The operator library (csrc/torch_ext.cpp), imported once: registers torch.ops.percnn.{pi_step, pi_rollout} (+ backward,
+    C++ autograd) with the dispatcher and returns the module with the eager fast-path entry points.  Fails loudly when it has
+    not been built or was built against another libpercnn_pi.so -- there is no Python fallback."""
+    global _torch_ext
+    if _torch_ext is not None:
+        return _torch_ext
+    if not os.path.exists(TORCH_EXT_PATH):
+        raise RuntimeError(f"percnn_amd: operator library not found at {TORCH_EXT_PATH} -- build it with "
+                           f"`python -c 'import percnn_amd; percnn_amd.build()'` (needs hipcc and g++).")
+    lib()                                                     # libpercnn_pi.so first: same file, checked ABI
+    import importlib.machinery
+    import importlib.util
+    loader = importlib.machinery.ExtensionFileLoader("percnn_torch", TORCH_EXT_PATH)
+    spec = importlib.util.spec_from_loader("percnn_torch", loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    if mod.abi_version() != ABI_VERSION:
+        raise RuntimeError("percnn_amd: percnn_torch.so was linked against another ABI version of libpercnn_pi.so")
+    _torch_ext = mod
+    return mod
 
 
 def lib() -> ctypes.CDLL:

@@ -1402,7 +1402,7 @@ int step_bwd_impl(const T* h, const T* g_out, const T* g_inj, T* g_in, double* p
         if (lo >= 0) { if (int rc = set_slab_range(p, halo, lo, hi)) return rc; }
         else if (int rc = set_slab(p, halo, halo - 2)) return rc;     // adjoint: interior planes only
     }
-    if (!h || !g_out || !g_in || !param_grad || !P || g_in == g_out) return PERCNN_PI_EINVAL;
+    if (!h || !g_out || !g_in || (!param_grad && !(flags & PERCNN_PI_NO_FINISH)) || !P || g_in == g_out) return PERCNN_PI_EINVAL;
     Workspace w;
     if (!carve(ws, ws_bytes, p, sizeof(T), w)) return PERCNN_PI_EWORKSPACE;
     auto st = static_cast<hipStream_t>(stream);
@@ -1417,6 +1417,18 @@ int step_bwd_impl(const T* h, const T* g_out, const T* g_inj, T* g_in, double* p
     if (e) return (int)e;
     if (flags & PERCNN_PI_NO_FINISH) return 0;
     return (int)finish_grads(w, (flags & PERCNN_PI_NO_RESET) ? (unsigned)MAX_BWD_BLOCKS : grid, hc, param_grad, st);
+}
+
+// the partial rows of a workspace that earlier step_bwd launches (NO_FINISH) left their sums in -> param_grad (+=)
+template <typename T>
+int bwd_rows_finish_impl(void* ws, size_t ws_bytes, int hc, int ndim, const int64_t* shape, double* param_grad, void* stream)
+{
+    Problem p;
+    if (int rc = make_problem(hc, ndim, shape, false, p)) return rc;
+    if (!param_grad) return PERCNN_PI_EINVAL;
+    Workspace w;
+    if (!carve(ws, ws_bytes, p, sizeof(T), w)) return PERCNN_PI_EWORKSPACE;
+    return (int)finish_grads(w, (unsigned)MAX_BWD_BLOCKS, hc, param_grad, static_cast<hipStream_t>(stream));
 }
 
 // branch-weight / coefficient-moment gradients of T steps over the interior of LOCAL slab trajectories
@@ -2667,22 +2679,45 @@ int percnn_pi_host_words_free(void* p) { return p ? (int)hipHostFree(p) : 0; }
 // diagnostics (tests of the persistent sweep's abort path): `blocks` workgroups that each hold `lds_bytes` of a CU's LDS for
 // `ms` milliseconds on `stream` -- what "another kernel holds whole CUs" looks like
 namespace {
-__global__ void pi_debug_hog_kernel(unsigned long long ticks, int* sink)
+__global__ void pi_debug_hog_kernel(unsigned long long ticks, int* started)
 {
     extern __shared__ unsigned char hog_lds[];
     hog_lds[threadIdx.x] = (unsigned char)threadIdx.x;
+    // roll call into host-mapped words (plain system-scope stores, no PCIe atomics): the host returns from the entry point
+    // only once every hog workgroup holds its CU -- otherwise whether the hog or the kernel under test is dispatched first
+    // is up to the queue scheduler and the test it serves is a coin toss
+    if (threadIdx.x == 0 && started) __hip_atomic_store(started + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
-    if (hog_lds[(threadIdx.x + 1) % 64] == 255 && sink) *sink = 1;
+    if (hog_lds[(threadIdx.x + 1) % 64] == 255 && started) started[blockIdx.x] = 2;
 }
 }  // namespace
 int percnn_pi_debug_hog(int blocks, int lds_bytes, int ms, void* stream)
 {
     if (blocks < 1 || blocks > 4096 || lds_bytes < 64 || lds_bytes > 160 * 1024 || ms < 1 || ms > 10000) return PERCNN_PI_EINVAL;
     if (hipError_t e = allow_lds(pi_debug_hog_kernel, (size_t)lds_bytes)) return (int)e;
+    static int* started = nullptr;                          // (tests only: one hog at a time)
+    if (!started) {
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 4096 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            (void)hipGetLastError();
+            hp = nullptr;
+        }
+        started = static_cast<int*>(hp);
+    }
+    if (started) std::memset(started, 0, (size_t)blocks * sizeof(int));
     hipLaunchKernelGGL(pi_debug_hog_kernel, dim3((unsigned)blocks), dim3(64), (size_t)lds_bytes, static_cast<hipStream_t>(stream),
-                       (unsigned long long)ms * 100000ull, (int*)nullptr);
-    return (int)hipGetLastError();
+                       (unsigned long long)ms * 100000ull, started);
+    if (hipError_t e = hipGetLastError()) return (int)e;
+    if (started) {                                          // wait (bounded: 2 s) until every hog workgroup is resident
+        const auto t0 = std::chrono::steady_clock::now();
+        volatile int* vs = started;
+        for (int b = 0; b < blocks;) {
+            if (vs[b] != 0) { ++b; continue; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+        }
+    }
+    return 0;
 }
 
 int percnn_pi_persist_status(long* info)
@@ -2762,6 +2797,14 @@ int percnn_pi_persist_status(long* info)
                                      const int64_t* shape, const char* options, void* stream)                       \
     { return step_bwd_impl<T>(h, g_out, g_inject, g_in, param_grad, workspace, workspace_bytes, params, hc, ndim,  \
                               shape, stream, false, 2, 0, -1, -1, options); }                                       \
+    int percnn_pi_step_bwd_rows_##SUF(const T* h, const T* g_out, const T* g_inject, T* g_in, void* workspace,      \
+                                      size_t workspace_bytes, const T* params, int hc, int ndim,                    \
+                                      const int64_t* shape, int flags, void* stream)                                \
+    { return step_bwd_impl<T>(h, g_out, g_inject, g_in, nullptr, workspace, workspace_bytes, params, hc, ndim,     \
+                              shape, stream, false, 2, (flags & PERCNN_PI_NO_RESET) | PERCNN_PI_NO_FINISH); }       \
+    int percnn_pi_bwd_rows_finish_##SUF(void* workspace, size_t workspace_bytes, int hc, int ndim,                  \
+                                        const int64_t* shape, double* param_grad, void* stream)                     \
+    { return bwd_rows_finish_impl<T>(workspace, workspace_bytes, hc, ndim, shape, param_grad, stream); }            \
     int percnn_pi_rollout_fwd_opt_##SUF(T* traj, const T* params, int hc, int ndim, const int64_t* shape,          \
                                         int T_steps, const char* options, void* stream)                             \
     { return rollout_fwd_impl<T>(traj, params, hc, ndim, shape, T_steps, stream, options); }                        \

@@ -148,7 +148,7 @@ class PolyGuard:
     training iteration's -- and flips the cell between the pre-contracted and the factored block with hysteresis."""
 
     def __init__(self, device):
-        self._lib = _lib
+        self.device = torch.device(device)
         p = ctypes.c_void_p()
         with torch.cuda.device(device):
             _lib.check(_lib.lib().percnn_pi_host_words_alloc(ctypes.byref(p), 16), "host_words_alloc")
@@ -160,6 +160,16 @@ class PolyGuard:
         self.factored = False
         import weakref
         weakref.finalize(self, _lib.lib().percnn_pi_host_words_free, ctypes.c_void_p(self.address))
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(cell) / pickling a cell: the copy gets a host slot of its own (the slot is process-local pinned
+        memory, not data) and starts from this guard's decision"""
+        g = PolyGuard(self.device)
+        g.factored = self.factored
+        return g
+
+    def __reduce__(self):
+        return (PolyGuard, (self.device,))
 
     def next_seq(self) -> int:
         self.issued += 1
@@ -220,8 +230,12 @@ class PackBlockFunction(torch.autograd.Function):
     layers are what is left to pay."""
 
     @staticmethod
-    def forward(ctx, meta, guard, *tensors):
+    def forward(ctx, meta, guard, acc, *tensors):
+        """acc: None, or the native BlockState whose workspace rows the per-step nodes of a reference-style loop leave their
+        parameter-gradient sums in (csrc/torch_ext.cpp: cell_step) -- this node delivers them, once per backward pass."""
         ctx.meta = meta
+        ctx.acc = acc
+        ctx.set_materialize_grads(False)
         # NOT save_for_backward: the block is cached by RCNNCell.param_block and shared by every step of an iteration, so
         # several backward() calls may run through this node (`out1 = cell(h1); out2 = cell(h2); out1.sum().backward();
         # out2.sum().backward()`, ADVICE r3) -- saved tensors would be freed by the first.  The parameters are leaves that
@@ -235,8 +249,15 @@ class PackBlockFunction(torch.autograd.Function):
         if tuple(t._version for t in ctx.tensors) != ctx.versions:
             raise RuntimeError("percnn_amd: a parameter of the packed block was modified in place between the forward and "
                                "this backward pass (same rule as autograd's saved tensors)")
+        if ctx.acc is not None:
+            extra = _lib.torch_ext().take_block_grad(ctx.acc, ctx.tensors[2])  # the step nodes' sums of THIS pass (or None)
+            if extra is not None:
+                extra = extra[:NPOLY if ctx.meta[5] else param_count(ctx.meta[0])]   # (the accumulator is sized for either block kind)
+                g = extra if g is None else g + extra
+        if g is None:
+            return (None,) * (3 + len(ctx.tensors))
         gr = pack_bwd_hip(ctx.tensors, g, *ctx.meta, one_buffer=True)
-        return (None, None, gr[0], gr[1], None, *gr[2:])
+        return (None, None, None, gr[0], gr[1], None, *gr[2:])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -901,21 +922,28 @@ def pi_rollout_observe(h0: torch.Tensor, P: torch.Tensor, steps: int, t_idx: Seq
     return pred, traj.detach()
 
 
+def _native():
+    """torch.ops.percnn.{pi_step, pi_rollout}: loaded on first use if the package was imported before it was built"""
+    from . import ops
+    ops.load_native()
+    return _lib.torch_ext()
+
+
 def pi_step(h: torch.Tensor, P: torch.Tensor, options=None) -> torch.Tensor:
-    """One fused Pi-block step.  Under ``torch.compile`` the registered operator ``torch.ops.percnn.pi_step`` (percnn_amd/
-    ops.py) is what the graph holds; in eager mode the plain ``autograd.Function`` does the same work without the
-    dispatcher's per-call cost -- this is the call a reference-style step loop makes T times per iteration."""
-    if torch.compiler.is_compiling() or options:
-        return torch.ops.percnn.pi_step(h, P, _options_str(options))
-    return PiStepFunction.apply(h, P)
+    """One fused Pi-block step: the registered operator ``torch.ops.percnn.pi_step`` (csrc/torch_ext.cpp: C++ implementation and
+    C++ autograd node, no Python frame between the dispatcher and the C-ABI) -- what a ``torch.compile`` graph holds and what
+    eager callers of this function get.  ``RCNNCell.forward`` -- the call a reference-style step loop makes T times per
+    iteration -- goes through the library's eager entry points instead (``cell_step`` / ``step_nograd``, same kernels)."""
+    _native()
+    return torch.ops.percnn.pi_step(h, P, _options_str(options))
 
 
 def pi_step_nograd(h: torch.Tensor, P: torch.Tensor) -> torch.Tensor:
     """One fused step without an autograd node (inference loops; the caller has checked that nothing records)."""
-    _check_state(h)
-    return _step_fwd_lean(h.contiguous(), P.contiguous())
+    return _native().step_nograd(h, P)
 
 
 def pi_rollout(h0: torch.Tensor, P: torch.Tensor, steps: int, options=None) -> torch.Tensor:
     """T fused steps -> trajectory [T+1,2,*S] through ``torch.ops.percnn.pi_rollout``."""
+    _native()
     return torch.ops.percnn.pi_rollout(h0, P, int(steps), _options_str(options))

@@ -30,6 +30,24 @@ def laplace_stencil(ndim: int) -> np.ndarray:
     return w
 
 
+_ext_probe = [False, None]
+
+
+def _native_ext(required: bool = False):
+    """The operator library's module (csrc/torch_ext.cpp), or None while the package has not been built (CPU-side tools)."""
+    if _ext_probe[1] is not None:
+        return _ext_probe[1]
+    if required or not _ext_probe[0]:
+        import os
+        from . import _lib
+        _ext_probe[0] = True
+        if required or (os.path.exists(_lib.TORCH_EXT_PATH) and os.path.exists(_lib.LIB_PATH)):
+            from . import ops
+            ops.load_native()
+            _ext_probe[1] = _lib.torch_ext()
+    return _ext_probe[1]
+
+
 class RCNNCell(nn.Module):
     """Pi-block cell: ``forward(h[1,2,*S]) -> (h_next, h_next)`` (train_2drd.py:105-121).
 
@@ -105,6 +123,24 @@ class RCNNCell(nn.Module):
         self.poly_guard_max = None
         self._guard = None
         self._guard_warned = False
+        # A step loop that hands every output back as the next input (`for step in range(T): h, _ = cell(h)`, train_2drd.py:169-188)
+        # gets its next 4 / 8 / 16 states from ONE fused launch (csrc/torch_ext.cpp, BlockState::step): bit-identical, and only
+        # when the input IS the previous output, unmodified.  False: every call is a single-step launch.
+        self.speculate = True
+
+    # caches and device-side handles are not state: copy.deepcopy(cell) / pickling a whole model start without them
+    _TRANSIENT = ("_block_cache", "_block_acc", "_pack_list", "_dt_cache")
+
+    def __getstate__(self):
+        return {k: (None if k in self._TRANSIENT else v) for k, v in self.__dict__.items() if k != "_pack_list"}
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     def init_filter(self, filter_list, c, mode="xavier"):
         for f in filter_list:
@@ -164,9 +200,16 @@ class RCNNCell(nn.Module):
     def _block_key(self, tensors):
         """What a packed block depends on: every parameter's version counter AND storage address (optimizer.step(),
         load_state_dict, .to(), parameter surgery, `p.data = new` on any of the 19 tensors -- ADVICE r3), dt (the reference
-        reads self.dt every step, train_2drd.py:117), the reaction mode, the guard's settings and whether autograd records."""
-        return (tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors), float(self.dt), self.reaction,
-                self.diffusion, torch.is_grad_enabled(), bool(self.poly_guard), tuple(self.state_bound), self.poly_guard_max)
+        reads self.dt every step, train_2drd.py:117), the reaction mode, the guard's settings and whether autograd records.
+        The 38 tensor properties are hashed by the operator library (one call instead of 38: this runs once per time step of a
+        reference-style loop)."""
+        ext = _native_ext()
+        if ext is not None:
+            tk = ext.block_key(tensors)
+        else:                                                 # (CPU-only tools before the package has been built)
+            tk = (tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors))
+        return (tk, float(self.dt), self.reaction, self.diffusion, torch.is_grad_enabled(), bool(self.poly_guard),
+                tuple(self.state_bound), self.poly_guard_max, bool(self.speculate))
 
     def param_block(self, fresh: bool = False) -> torch.Tensor:
         """The packed parameter block the kernels read.  A caller that keeps the reference's own step loop
@@ -182,7 +225,18 @@ class RCNNCell(nn.Module):
             hit = self._block_cache
             if hit is not None and hit[0] == key and not fresh:
                 return hit[1]
-            P = self._param_block_uncached()
+            # the block's native state (csrc/torch_ext.cpp: BlockState): the rows a reference-style step loop's per-step nodes
+            # leave their parameter-gradient sums in (delivered once per backward pass by the pack node) and the speculative
+            # multi-step forward of such a loop
+            acc = None
+            w = tensors[2]
+            if w.is_cuda:
+                ext = _native_ext()
+                if ext is not None:
+                    acc = ext.new_block_state(w, max(F_pi.NPOLY, F_pi.param_count(self.hidden_channels)))
+                    acc.speculate = bool(self.speculate)
+            P = self._param_block_uncached(acc)
+            self.__dict__["_block_acc"] = acc
             if P.requires_grad:
                 import weakref
                 me = weakref.ref(self)
@@ -202,7 +256,7 @@ class RCNNCell(nn.Module):
             return float(self.poly_guard_max)
         return 10.0 if dtype == torch.float32 else 1.0e4
 
-    def _pack_guarded(self, tensors, meta_head):
+    def _pack_guarded(self, tensors, meta_head, acc=None):
         """Pack with the guard slot attached.  The decision uses the amplification of the latest pack launch that has
         COMPLETED (no synchronisation: in a training loop that is the previous iteration's, and the weights move by one
         optimizer step in between; hysteresis a_max -> a_max / 2); only the very first pack of a cell waits for its own
@@ -216,14 +270,14 @@ class RCNNCell(nn.Module):
         was = gd.factored
         factored = gd.decide(a_max)
         ub, vb = (float(x) for x in self.state_bound)
-        P = F_pi.PackBlockFunction.apply(meta_head + (not factored,), (gd.address, gd.next_seq(), ub, vb), *tensors)
+        P = F_pi.PackBlockFunction.apply(meta_head + (not factored,), (gd.address, gd.next_seq(), ub, vb), acc, *tensors)
         if first and not torch.cuda.is_current_stream_capturing():
             ev = torch.cuda.Event()
             ev.record()
             ev.synchronize()
             if gd.decide(a_max) != factored:                  # the first value is in: ill-conditioned from the start
                 factored = gd.factored
-                P = F_pi.PackBlockFunction.apply(meta_head + (not factored,), (gd.address, gd.next_seq(), ub, vb), *tensors)
+                P = F_pi.PackBlockFunction.apply(meta_head + (not factored,), (gd.address, gd.next_seq(), ub, vb), acc, *tensors)
         if factored != was:
             import warnings
             if factored and not self._guard_warned:
@@ -242,7 +296,7 @@ class RCNNCell(nn.Module):
         gd = self._guard
         return "factored" if (self.reaction == "poly" and gd is not None and gd.factored) else self.reaction
 
-    def _param_block_uncached(self) -> torch.Tensor:
+    def _param_block_uncached(self, acc=None) -> torch.Tensor:
         w = self.W_laplace.weight
         if w.is_cuda and not w.requires_grad:
             # one launch each way (torch.ops.percnn.pack_block): the tensor-op assembly below costs 79 us per call on
@@ -259,8 +313,8 @@ class RCNNCell(nn.Module):
                 if torch.compiler.is_compiling():            # the registered operator is what a graph can hold (no guard
                     return torch.ops.percnn.pack_block(tensors, *meta)    # inside a traced graph: see INTEGRATION.md)
                 if self.reaction == "poly" and self.poly_guard:
-                    return self._pack_guarded(tensors, head)
-                return F_pi.PackBlockFunction.apply(meta, None, *tensors)
+                    return self._pack_guarded(tensors, head, acc)
+                return F_pi.PackBlockFunction.apply(meta, None, acc, *tensors)
         if torch.compiler.is_compiling():
             # traced by torch.compile: no host-side checks / caches inside the graph (the stencil was validated by the
             # eager call that preceded compilation or is validated by the first eager use)
@@ -300,10 +354,22 @@ class RCNNCell(nn.Module):
     # -- reference interface -------------------------------------------------------------------
     def forward(self, h):
         P = self.param_block()
-        if not torch.compiler.is_compiling() and not (torch.is_grad_enabled() and (h.requires_grad or P.requires_grad)):
-            ch = F_pi.pi_step_nograd(h, P)                 # nothing to record: straight to the kernel
+        if torch.compiler.is_compiling():
+            ch = F_pi.pi_step(h, P)                        # the registered operator is what a graph holds
+            return ch, ch
+        ext = _native_ext(required=True)
+        acc = self.__dict__.get("_block_acc")
+        if acc is not None and P is not self._block_cache[1]:
+            acc = None
+        if not (torch.is_grad_enabled() and (h.requires_grad or P.requires_grad)):
+            ch = ext.step_nograd(h, P, acc)                # nothing to record: straight to the kernel(s)
         else:
-            ch = F_pi.pi_step(h, P)
+            if acc is not None:
+                # one C++ autograd node per step; its backward adds the step's parameter-gradient sums to the block's shared
+                # accumulator instead of returning a gradient block per node
+                ch = ext.cell_step(h, P, acc)
+            else:
+                ch = F_pi.pi_step(h, P)
         return ch, ch
 
     def init_hidden_tensor(self, prev_state):
@@ -694,6 +760,18 @@ class RCNN(nn.Module):
         loss, traj = F_pi.pi_rollout_sqerr(self.init_state, self._block(), self.step, target, frames, reduction)
         self.last_trajectory = traj
         return loss
+
+    def ic_loss(self, mode: Optional[str] = None) -> torch.Tensor:
+        """``get_ic_loss(model)`` of the reference scripts (train_2drd.py:331-338, train_3drd.py:325-332): MSE between the IC
+        generator's output and the low-resolution measurement interpolated to ITS output size (bicubic in 2D, trilinear in
+        3D -- the reference hard-codes (100, 100) / (48, 48, 48), the grids it trains on)."""
+        if not hasattr(self, "UpconvBlock"):
+            raise ValueError("ic_loss() needs an upscaler (the reference's UpconvBlock)")
+        pred = self.UpconvBlock(self.init_state_low)
+        ndim = pred.dim() - 2
+        target = torch.nn.functional.interpolate(self.init_state_low, tuple(pred.shape[2:]),
+                                                 mode=mode or ("bicubic" if ndim == 2 else "trilinear"))
+        return torch.nn.functional.mse_loss(pred, target)
 
     def forward(self):
         if hasattr(self, "UpconvBlock"):

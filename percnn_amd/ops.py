@@ -3,7 +3,7 @@
 north_star / SURVEY 8(b): the existing PeRCNN modules reach the fused kernels through registered operators with
 autograd support, as a drop-in for the per-step ATen sequence of ``RCNNCell.forward``
 (DataDrivenModeling/2d_gs_rd/train_2drd.py:105-121) at the call sites ``train_2drd.py:393`` (``model()``) and
-``train_2drd.py:407`` (``loss.backward()``).  Registered with ``torch.library.custom_op`` on top of the C-ABI
+``train_2drd.py:407`` (``loss.backward()``).  Registered on top of the C-ABI
 (``include/percnn_pi.h``) -- the dispatcher sees real schemas, FakeTensor / meta implementations and autograd formulas,
 so the operators pass ``torch.library.opcheck`` and trace under ``torch.compile(fullgraph=True)``:
 
@@ -18,6 +18,10 @@ so the operators pass ``torch.library.opcheck`` and trace under ``torch.compile(
             -> (Tensor pred, Tensor traj)
     percnn::pi_rollout_observe_backward(Tensor traj, Tensor params, Tensor g_pred, int[] t_idx, int[] strides,
             str options="") -> (Tensor, Tensor)
+
+``pi_step`` / ``pi_rollout`` and their backward operators are C++ (``csrc/torch_ext.cpp``: ``TORCH_LIBRARY(percnn)`` + C++
+``torch::autograd::Function``, linked against ``libpercnn_pi.so``); the others -- one call per rollout or per training
+iteration -- are ``torch.library.custom_op`` over the same C-ABI.
 
 ``params`` is the packed parameter block of ``include/percnn_pi.h`` (factored, pre-contracted or advective; the kind is
 encoded in its length); ``options`` carries per-call tuning overrides ("key=value,...", the keys of
@@ -122,90 +126,39 @@ pack_block.register_autograd(_pack_bwd, setup_context=_pack_setup)
 
 
 # ------------------------------------------------------------------------------------------------
-# one step
+# one step, T-step rollout: defined in C++ (csrc/torch_ext.cpp -- TORCH_LIBRARY(percnn): HIP implementation, C++
+# torch::autograd::Function registered on the Autograd key; dispatcher -> C-ABI launcher with no Python frame).  Here: loading
+# the library and the FakeTensor implementations (what torch.compile / opcheck trace with).
 # ------------------------------------------------------------------------------------------------
-@torch.library.custom_op(f"{_lib_ns}::pi_step", mutates_args=())
-def pi_step(h: torch.Tensor, params: torch.Tensor, options: str = "") -> torch.Tensor:
-    F_pi._check_state(h)
-    h, params = h.contiguous(), params.contiguous()
-    return F_pi.step_fwd(h[0], params, options=_opts(options))[None]
+_native_loaded = False
 
 
-@pi_step.register_fake
-def _(h, params, options=""):
-    return torch.empty_like(h, memory_format=torch.contiguous_format)
+def load_native() -> None:
+    """Import csrc/percnn_torch.so (once) and attach the fake implementations of its operators.  Called at package import when
+    the library has been built, and by every entry point that needs the operators otherwise -- a missing library raises."""
+    global _native_loaded
+    if _native_loaded:
+        return
+    from . import _lib
+    _lib.torch_ext()
 
+    @torch.library.register_fake(f"{_lib_ns}::pi_step")
+    def _(h, params, options=""):
+        return torch.empty_like(h, memory_format=torch.contiguous_format)
 
-@torch.library.custom_op(f"{_lib_ns}::pi_step_backward", mutates_args=())
-def pi_step_backward(h: torch.Tensor, params: torch.Tensor, g_out: torch.Tensor,
-                     options: str = "") -> Tuple[torch.Tensor, torch.Tensor]:
-    h, params, g_out = h.contiguous(), params.contiguous(), g_out.contiguous()
-    g_in, pg = F_pi.step_bwd(h[0], g_out[0], params, options=_opts(options))
-    return g_in[None], pg.to(params.dtype)
+    @torch.library.register_fake(f"{_lib_ns}::pi_step_backward")
+    def _(h, params, g_out, options=""):
+        return torch.empty_like(h, memory_format=torch.contiguous_format), torch.empty_like(params)
 
+    @torch.library.register_fake(f"{_lib_ns}::pi_rollout")
+    def _(h0, params, steps, options=""):
+        return h0.new_empty((steps + 1,) + tuple(h0.shape[1:]))
 
-@pi_step_backward.register_fake
-def _(h, params, g_out, options=""):
-    return torch.empty_like(h, memory_format=torch.contiguous_format), torch.empty_like(params)
+    @torch.library.register_fake(f"{_lib_ns}::pi_rollout_backward")
+    def _(traj, params, g_traj, options=""):
+        return traj.new_empty((1,) + tuple(traj.shape[1:])), torch.empty_like(params)
 
-
-def _step_setup(ctx, inputs, output):
-    h, params, options = inputs
-    ctx.save_for_backward(h, params)
-    ctx.options = options
-
-
-def _step_bwd(ctx, g):
-    h, params = ctx.saved_tensors
-    g_in, g_p = torch.ops.percnn.pi_step_backward(h, params, g, ctx.options)
-    return g_in, g_p, None
-
-
-pi_step.register_autograd(_step_bwd, setup_context=_step_setup)
-
-
-# ------------------------------------------------------------------------------------------------
-# T-step rollout -> whole trajectory
-# ------------------------------------------------------------------------------------------------
-@torch.library.custom_op(f"{_lib_ns}::pi_rollout", mutates_args=())
-def pi_rollout(h0: torch.Tensor, params: torch.Tensor, steps: int, options: str = "") -> torch.Tensor:
-    F_pi._check_state(h0)
-    params = params.contiguous()
-    traj = torch.empty((steps + 1,) + tuple(h0.shape[1:]), dtype=h0.dtype, device=h0.device)
-    traj[0].copy_(h0[0])
-    return F_pi.rollout_fwd_(traj, params, options=_opts(options))
-
-
-@pi_rollout.register_fake
-def _(h0, params, steps, options=""):
-    return h0.new_empty((steps + 1,) + tuple(h0.shape[1:]))
-
-
-@torch.library.custom_op(f"{_lib_ns}::pi_rollout_backward", mutates_args=())
-def pi_rollout_backward(traj: torch.Tensor, params: torch.Tensor, g_traj: torch.Tensor,
-                        options: str = "") -> Tuple[torch.Tensor, torch.Tensor]:
-    g_h0, pg = F_pi.rollout_bwd(traj, g_traj.contiguous(), params.contiguous(), options=_opts(options))
-    return g_h0[None], pg.to(params.dtype)
-
-
-@pi_rollout_backward.register_fake
-def _(traj, params, g_traj, options=""):
-    return traj.new_empty((1,) + tuple(traj.shape[1:])), torch.empty_like(params)
-
-
-def _rollout_setup(ctx, inputs, output):
-    _h0, params, _steps, options = inputs
-    ctx.save_for_backward(output, params)
-    ctx.options = options
-
-
-def _rollout_bwd(ctx, g_traj):
-    traj, params = ctx.saved_tensors
-    g_h0, g_p = torch.ops.percnn.pi_rollout_backward(traj, params, g_traj, ctx.options)
-    return g_h0, g_p, None, None
-
-
-pi_rollout.register_autograd(_rollout_bwd, setup_context=_rollout_setup)
+    _native_loaded = True
 
 
 # ------------------------------------------------------------------------------------------------
@@ -273,3 +226,16 @@ def _observe_bwd(ctx, g_pred, g_traj):
 
 
 pi_rollout_observe.register_autograd(_observe_bwd, setup_context=_observe_setup)
+
+
+import os as _os
+
+from . import _lib as _lib_mod
+
+if _os.path.exists(_lib_mod.TORCH_EXT_PATH) and _os.path.exists(_lib_mod.LIB_PATH):
+    # a tree that has not been built yet -- or holds a library older than its sources -- still imports (percnn_amd.build()
+    # lives in the package); the first entry point that needs the operators loads them and raises if it cannot
+    try:
+        load_native()
+    except RuntimeError:
+        pass

@@ -23,10 +23,27 @@ def dev_t(a, device):
     return torch.tensor(np.ascontiguousarray(a), device=device)
 
 
-def _hog(blocks, lds_bytes, ms, stream):
+def _hog(blocks, lds_bytes, ms, device):
+    """Hold `blocks` CUs' LDS for `ms` milliseconds NEXT TO the current stream; returns the side stream the hog runs on.
+    HIP multiplexes streams onto a few hardware queues: a freshly created stream may share its queue with the current stream, and
+    then the hog and the kernel under test simply run one after the other (seen in the full suite, never in a short script: the
+    queue a new stream gets depends on how many streams the process has created).  The entry point returns once every hog
+    workgroup is resident; a probe on the current stream then tells whether that stream still makes progress."""
     import ctypes
+    import time
     from percnn_amd import _lib
-    _lib.check(_lib.lib().percnn_pi_debug_hog(blocks, lds_bytes, ms, ctypes.c_void_p(stream.cuda_stream)), "debug_hog")
+    for _ in range(8):
+        side = torch.cuda.Stream(device=device)
+        _lib.check(_lib.lib().percnn_pi_debug_hog(blocks, lds_bytes, ms, ctypes.c_void_p(side.cuda_stream)), "debug_hog")
+        probe, ev = torch.zeros(1, device=device), torch.cuda.Event()
+        probe.add_(1)
+        ev.record()
+        t0 = time.perf_counter()
+        ev.synchronize()
+        if time.perf_counter() - t0 < 0.25 * ms / 1000.0:
+            return side
+        side.synchronize()                                     # serialised behind the hog: it is over by now, try another stream
+    pytest.skip("no side stream that runs concurrently with the current stream")
 
 
 def _sweep_problem(hip_device, shape=(512, 512), T=41):
@@ -56,9 +73,8 @@ def test_persistent_sweep_aborts_cleanly_and_falls_back(hip_device):
     assert s1["launches"] == s0["launches"] + 1 and s1["aborts"] == s0["aborts"] and not s1["disabled_on_current_device"]
     assert torch.equal(a0, ref0)
     torch.cuda.synchronize()
-    side = torch.cuda.Stream(device=hip_device)
     try:
-        _hog(16, 150 * 1024, 1500, side)                         # 16 CUs' LDS for 1.5 s: 16 of the 256 tiles cannot start
+        _hog(16, 150 * 1024, 1500, hip_device)                        # 16 CUs' LDS for 1.5 s: 16 of the 256 tiles cannot start
         b0, bg = pa.rollout_bwd(traj, g, P, options={"persist_first_timeout_ms": 20})
         s2 = _lib.persist_status()
         torch.cuda.synchronize()
@@ -91,9 +107,8 @@ def test_persistent_sweep_abort_without_handshake_is_reported(hip_device):
     traj, g, P = _sweep_problem(hip_device, T=41)
     ref0, _ = pa.rollout_bwd(traj, g, P, options={"tile_persist": 0})
     torch.cuda.synchronize()
-    side = torch.cuda.Stream(device=hip_device)
     try:
-        _hog(16, 150 * 1024, 1000, side)
+        _hog(16, 150 * 1024, 1000, hip_device)
         pa.rollout_bwd(traj, g, P, options={"persist_first_timeout_ms": 20, "persist_handshake": 0})
         torch.cuda.synchronize()
         with pytest.raises(RuntimeError, match="EARLIER call's persistent tile sweep aborted"):
