@@ -314,6 +314,11 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
         loss = (traj ** 2).mean()
         torch.autograd.grad(loss, params + [h0])
 
+    def it_stacked():
+        outs, _ = model()
+        loss = (outs.stacked ** 2).mean()                # the reference's call pattern minus its torch.cat
+        torch.autograd.grad(loss, params + [h0])
+
     def it_traj():
         loss = (model.trajectory() ** 2).mean()
         torch.autograd.grad(loss, params + [h0])
@@ -328,7 +333,8 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
         torch.autograd.grad(loss, params + [h0])
 
     out = {}
-    for key, fn in (("list_cat_dense_loss_ms", it_list), ("trajectory_dense_loss_ms", it_traj),
+    for key, fn in (("list_cat_dense_loss_ms", it_list), ("list_stacked_dense_loss_ms", it_stacked),
+                    ("trajectory_dense_loss_ms", it_traj),
                     ("loss_mse_dense_ms", it_loss_mse), ("observe_strided_loss_ms", it_observe)):
         fn()
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
@@ -345,7 +351,7 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
         out[key] = {"gpu_ms": per_it[reps // 2], "gpu_ms_mean": marks[0].elapsed_time(marks[reps]) / reps,
                     "wall_ms": (time.perf_counter() - t0) / reps * 1e3}
     out["what"] = (f"one training iteration through the drop-in modules at {'x'.join(map(str, shape))} x T={T}: RCNN.forward() "
-                   "+ torch.cat + mean(traj^2) + backward; RCNN.trajectory() (torch.ops.percnn.pi_rollout, no list / cat) + the same loss; "
+                   "+ torch.cat + mean(traj^2) + backward; the same with outputs.stacked in place of the cat; RCNN.trajectory() (torch.ops.percnn.pi_rollout, no list / cat) + the same loss; "
                    "RCNN.loss_mse() = the same dense loss as ONE autograd node with the rollout (gradient formed inside the sweep); "
                    "RCNN.observe(0:-1:20, ::4) + MSE + backward "
                    "(forward, loss, full backward incl. parameter gradients; wall = host clock around the same loop)")
@@ -358,8 +364,10 @@ def cell_loop_extra(pa, dev, reaction):
     and the whole training iteration (torch.cat + dense loss + backward + Adam step).  VERDICT r2 #4."""
     from percnn_amd import synthetic
     sd = load_params(WORKLOADS["gs2d_512"][5])
-    out = {"what": "for step in range(T): h, _ = cell(h) -- wall-clock us per time step (host-bound: the block is packed once "
-                   "per iteration and cached, each step is one autograd node + one launch)"}
+    out = {"what": "for step in range(T): h, _ = cell(h) -- wall-clock us per time step through the operator library's eager path "
+                   "(csrc/torch_ext.cpp): one call validates the cached block; a loop that feeds every output back in gets its next "
+                   "4 / 8 / 16 states from ONE fused launch (bit-identical), as ONE autograd node per group whose backward is one "
+                   "fused sweep; parameter-gradient sums are delivered once per backward pass"}
     for n, T in ((100, 200), (512, 100)):
         cell = make_cell("gs2d", sd, dev, reaction)
         h0 = synthetic.gs_initial_state((n, n), seed=0).to(dev)

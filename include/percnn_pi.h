@@ -474,6 +474,18 @@ int percnn_pi_step_bwd_opt_f32(const float *h, const float *g_out, const float *
 int percnn_pi_step_bwd_opt_f64(const double *h, const double *g_out, const double *g_inject, double *g_in,
                                double *param_grad, void *workspace, size_t workspace_bytes, const double *params,
                                int hc, int ndim, const int64_t *shape, const char *options, void *stream);
+/* percnn_pi_rollout_bwd_opt_* with the gradient of the LAST frame in a buffer of its own: frame T of `g_traj` is never read,
+ * `g_top` ([2][*S]) is used instead (frame_mask, if given, must select frame T).  For callers whose per-frame gradients are
+ * slices of one buffer except the newest one -- what autograd hands a node that produced T consecutive frames of a step loop
+ * (train_2drd.py:169-188) when the last of them also feeds the next node. */
+int percnn_pi_rollout_bwd_top_f32(const float *traj, const float *g_traj, const float *g_top, const unsigned char *frame_mask,
+                                  float *g_h0, double *param_grad, void *workspace, size_t workspace_bytes,
+                                  const float *params, int hc, int ndim, const int64_t *shape, int T, const char *options,
+                                  void *stream);
+int percnn_pi_rollout_bwd_top_f64(const double *traj, const double *g_traj, const double *g_top, const unsigned char *frame_mask,
+                                  double *g_h0, double *param_grad, void *workspace, size_t workspace_bytes,
+                                  const double *params, int hc, int ndim, const int64_t *shape, int T, const char *options,
+                                  void *stream);
 /* One adjoint step whose parameter-gradient sums STAY in the workspace's partial rows (a reference-style loop,
  * train_2drd.py:169-188, differentiated by autograd node by node: T calls of this, ONE percnn_pi_bwd_rows_finish_* at the end
  * instead of a reset + reduction launch per step).  flags: PERCNN_PI_NO_RESET when the rows already hold sums of earlier calls

@@ -64,7 +64,7 @@ EXPORTS = [
      for op in ("step_fwd", "step_bwd", "rollout_fwd", "rollout_bwd", "slab_step_fwd", "slab_step_bwd", "slab_wgrad",
                 "slab_step_fwd_range", "slab_step_bwd_range", "slab_rollout_fwd", "slab_rollout_bwd", "residual_fwd",
                 "residual_bwd", "contract_fwd", "contract_bwd", "step_fwd_opt", "step_bwd_opt", "rollout_fwd_opt",
-                "rollout_bwd_opt", "rollout_bwd_sqerr", "traj_sqerr", "step_bwd_rows", "bwd_rows_finish")] + [
+                "rollout_bwd_opt", "rollout_bwd_sqerr", "traj_sqerr", "step_bwd_rows", "bwd_rows_finish", "rollout_bwd_top")] + [
     "percnn_pi_s1_param_count", "percnn_pi_s1_step_fwd_f32", "percnn_pi_s1_rollout_fwd_f32",
     "percnn_pi_s1_rollout_bwd_workspace_bytes", "percnn_pi_s1_rollout_bwd_f32", "percnn_pi_s1_set_option",
     "percnn_pi_conv3d_k5c8_f32", "percnn_pi_conv3d_k5c8_wgrad_workspace_bytes", "percnn_pi_conv3d_k5c8_wgrad_f32",

@@ -1866,10 +1866,12 @@ size_t rollout_workspace_bytes(const Problem& p, int T_steps, int elem)
 template <typename T>
 int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, T* g_h0, double* param_grad, void* ws,
                      size_t ws_bytes, const T* P, int hc, int ndim, const int64_t* shape, int T_steps, void* stream,
-                     const char* options = nullptr, const pi::LossInj* loss = nullptr)
+                     const char* options = nullptr, const pi::LossInj* loss = nullptr, const T* g_top = nullptr)
 {
     Problem p;
     if (int rc = make_problem(hc, ndim, shape, false, p, options)) return rc;
+    // g_top: dL/d(frame T_steps) lives in a buffer of its own (frame T_steps of g_traj is then never read; needs mask[T_steps])
+    if (g_top && (loss || (mask && !mask[T_steps]))) return PERCNN_PI_EINVAL;
     // loss != nullptr: no dL/dtraj exists; `g_traj` is the TARGET trajectory (mode 2) or ignored (mode 1) and the sweep forms
     // the gradient of frame t from the state it reads anyway (pi::LossInj); `mask` then selects the frames inside the loss
     if (loss) {
@@ -1898,7 +1900,8 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     // dL/dh of one frame that no later step injects (the top frame): a copy, or -- loss form -- a * (h - target)
     auto top_frame = [&](int t, T* dst) -> hipError_t {
         if (!loss)
-            return hipMemcpyAsync(dst, g_traj + (size_t)t * frame, frame_bytes, hipMemcpyDeviceToDevice, st);
+            return hipMemcpyAsync(dst, (g_top && t == T_steps) ? g_top : g_traj + (size_t)t * frame, frame_bytes,
+                                  hipMemcpyDeviceToDevice, st);
         const T* tg = p.loss.mode == 2 ? g_traj + (size_t)t * frame : nullptr;
         const bool v16 = frame % pi::vec_width<T>::value == 0 && reinterpret_cast<uintptr_t>(traj) % 16 == 0 &&
                          reinterpret_cast<uintptr_t>(dst) % 16 == 0 && (!tg || reinterpret_cast<uintptr_t>(g_traj) % 16 == 0) &&
@@ -2808,6 +2811,12 @@ int percnn_pi_persist_status(long* info)
     int percnn_pi_rollout_fwd_opt_##SUF(T* traj, const T* params, int hc, int ndim, const int64_t* shape,          \
                                         int T_steps, const char* options, void* stream)                             \
     { return rollout_fwd_impl<T>(traj, params, hc, ndim, shape, T_steps, stream, options); }                        \
+    int percnn_pi_rollout_bwd_top_##SUF(const T* traj, const T* g_traj, const T* g_top, const unsigned char* frame_mask, \
+                                        T* g_h0, double* param_grad, void* workspace, size_t workspace_bytes,      \
+                                        const T* params, int hc, int ndim, const int64_t* shape, int T_steps,      \
+                                        const char* options, void* stream)                                          \
+    { return rollout_bwd_impl<T>(traj, g_traj, frame_mask, g_h0, param_grad, workspace, workspace_bytes, params,   \
+                                 hc, ndim, shape, T_steps, stream, options, nullptr, g_top); }                      \
     int percnn_pi_rollout_bwd_opt_##SUF(const T* traj, const T* g_traj, const unsigned char* frame_mask, T* g_h0,  \
                                         double* param_grad, void* workspace, size_t workspace_bytes,               \
                                         const T* params, int hc, int ndim, const int64_t* shape, int T_steps,      \

@@ -282,47 +282,25 @@ Tensor pi_rollout_autograd(const Tensor& h0, const Tensor& params, int64_t steps
 }
 
 // ---- eager fast path of a reference-style step loop -----------------------------------------------------------------------
-// Native state of ONE packed parameter block (RCNNCell.param_block caches the block together with this object):
+// Native state of ONE packed parameter block (RCNNCell.param_block caches the block together with these objects).
 //
-// (1) shared gradient accumulator.  The per-step autograd nodes of a pass leave their parameter-gradient sums in the partial
-//     rows of ONE workspace (percnn_pi_step_bwd_rows_*: no reset, no reduction launch per step) and return NO gradient for the
-//     block; the block's own node (functional.PackBlockFunction) calls take(): one reduction launch, one cast.  A backward pass
-//     is identified by autograd's graph-task id: sums left behind by a pass that never reached the block's node
-//     (torch.autograd.grad(loss, [h0]) prunes it) are dropped by the next pass, never delivered to it.
-//
-// (2) speculative steps.  `for step in range(T): h, _ = cell(h)` hands each output back as the next input.  When the input IS
-//     the tensor the previous call returned (same TensorImpl, unmodified, same block, same stream), the following states are
-//     already determined: the call that notices computes the next 4 / 8 / 16 steps with ONE call of the fused K-step rollout
-//     (percnn_pi_rollout_fwd_*: the temporally blocked kernels, 4 steps per launch) into a chunk of frames, and the next calls
-//     return those frames without launching anything.  Bit-identical to step-by-step (the fused kernels are bit-identical to
-//     the direct ones, asserted by the parity tests); anything else -- another input, an input modified in place, another
-//     stream, a new block -- is a plain single step.  Frames are separate tensors that share the chunk's storage (like the
-//     frames RCNN.forward returns); grids above 2^20 points are never speculated on.
-struct BlockState : torch::CustomClassHolder {
+// GradSink -- shared parameter-gradient accumulator.  The autograd nodes a step loop creates do NOT return a gradient for the
+//   block: single-step nodes leave their sums in the partial rows of ONE workspace (percnn_pi_step_bwd_rows_*: no reset, no
+//   reduction launch per step), group nodes add theirs to `acc` directly (percnn_pi_rollout_bwd_* accumulates); the block's own
+//   node (functional.PackBlockFunction) calls take(): one reduction launch, one cast.  A backward pass is identified by
+//   autograd's graph-task id: sums left behind by a pass that never reached the block's node (torch.autograd.grad(loss, [h0])
+//   prunes it) are dropped by the next pass, never delivered to it.
+struct GradSink : torch::CustomClassHolder {
     std::mutex mu;
-    // (1)
-    Tensor acc;                 // double[np_max]: sums already reduced (another problem shape was met within one pass)
-    Tensor ws;                  // workspace whose partial rows hold the sums of the current pass
+    Tensor acc;                 // double[np_max]
+    Tensor ws;                  // workspace whose partial rows hold sums of the current pass
     int64_t task = -1;          // graph task the sums belong to (-1: none; acc is zero, rows are clean)
     bool rows_dirty = false, acc_dirty = false;
     int ws_hc = 0, ws_ndim = 0;
     int64_t ws_shape[3] = {0, 0, 0};
     at::ScalarType ws_dtype = at::kFloat;
-    // (2)
-    Tensor chunk;               // [L, 2, *S] frames
-    std::vector<Tensor> frames; // frames[i]: [1, 2, *S] tensor on chunk's storage (created when frame i is computed)
-    int64_t valid = -1;         // frames[0 .. valid] hold enqueued results
-    int64_t next = -1;          // frame a hit returns
-    int depth = 0;              // steps of the last speculative launch (0: none yet)
-    c10::TensorImpl* last_out = nullptr;
-    uint32_t last_version = 0;
-    c10::TensorImpl* p_impl = nullptr;
-    uint32_t p_version = 0;
-    void* stream = nullptr;
-    bool speculate = true;
-    int64_t spec_launches = 0, spec_hits = 0;
 
-    explicit BlockState(Tensor a) : acc(std::move(a)) {}
+    explicit GradSink(Tensor a) : acc(std::move(a)) {}
 
     bool same_problem(const Tensor& h, int hc, const Shape& sh) const
     {
@@ -330,8 +308,7 @@ struct BlockState : torch::CustomClassHolder {
         for (int i = 0; i < sh.ndim; ++i) if (ws_shape[i] != sh.s[i]) return false;
         return true;
     }
-    // rows -> acc (one launch); the rows are clean afterwards (the next step launch resets them)
-    void flush_rows(void* st)
+    void flush_rows(void* st)                                // rows -> acc (one launch); the next step launch resets the rows
     {
         if (!rows_dirty) return;
         int rc;
@@ -349,6 +326,10 @@ struct BlockState : torch::CustomClassHolder {
         acc_dirty = rows_dirty = false;
         task = -1;
     }
+    void enter(int64_t current)
+    {
+        if (task != current) { if (task != -1) drop(); task = current; }
+    }
     // adjoint of one step of the pass `current`, sums into the rows
     Tensor step_bwd(const Tensor& h, const Tensor& g, const Tensor& P, int64_t current)
     {
@@ -356,7 +337,7 @@ struct BlockState : torch::CustomClassHolder {
         const Shape sh(h, 2);
         const int hc = hc_of(P);
         void* st = stream_of(h);
-        if (task != current) { if (task != -1) drop(); task = current; }
+        enter(current);
         if (!same_problem(h, hc, sh)) {
             flush_rows(st);
             ws = step_workspace(h, hc, sh);
@@ -388,8 +369,47 @@ struct BlockState : torch::CustomClassHolder {
         drop();
         return out;
     }
+};
 
-    // ---- (2) ----
+int64_t current_task() { return (int64_t)torch::autograd::get_current_graph_task_id(); }
+
+struct BlockState;
+Tensor single_step_recorded(const Tensor& h, const Tensor& P, const c10::intrusive_ptr<GradSink>& sink, BlockState* bs);
+variable_list group_recorded(const Tensor& h, const Tensor& P, BlockState* bs, int64_t want);
+
+// BlockState -- speculative steps.  `for step in range(T): h, _ = cell(h)` hands each output back as the next input.  When the
+//   input IS the tensor the previous call returned (same TensorImpl, unmodified, same block, same stream, same grad mode), the
+//   following states are already determined: the call that notices computes the next 4 / 8 / 16 steps with ONE call of the fused
+//   rollout (percnn_pi_rollout_fwd_*: the temporally blocked kernels) into a chunk of frames, and the next calls return those
+//   frames without launching anything.  Bit-identical to step-by-step (the fused kernels are bit-identical to the direct ones,
+//   asserted by the parity tests); anything else -- another input, an input modified in place, another stream, a new block --
+//   is a plain single step.  Frames are separate tensors that share the chunk's storage (like the frames RCNN.forward
+//   returns); grids above 2^21 scalars per state are never speculated on.
+//   While autograd records, such a group of steps is ONE node with one output per frame (GroupStepFn): the chain between its
+//   frames is internal to the node, so neither T nodes nor T gradient additions by the engine, and its backward is ONE call of
+//   the fused sweep over the group (percnn_pi_rollout_bwd_*, frames without a gradient masked).
+struct BlockState : torch::CustomClassHolder {
+    std::mutex mu;
+    c10::intrusive_ptr<GradSink> sink;
+    Tensor chunk;               // [L, 2, *S] frames
+    std::vector<Tensor> frames; // frames[i]: [1, 2, *S] tensor on chunk's storage (created when frame i is computed)
+    int64_t valid = -1;         // frames[0 .. valid] hold enqueued results
+    int64_t next = -1;          // frame a hit returns
+    int depth = 0;              // steps of the last speculative launch (0: none yet)
+    bool recorded = false;      // the frames beyond `next` belong to an autograd node
+    c10::TensorImpl* last_out = nullptr;
+    uint32_t last_version = 0;
+    c10::TensorImpl* p_impl = nullptr;
+    uint32_t p_version = 0;
+    void* stream = nullptr;
+    bool speculate = true;
+    int64_t spec_launches = 0, spec_hits = 0;
+    // the cached block this state belongs to and the key it was packed under (RCNNCell.param_block; fast_forward below)
+    Tensor block;
+    int64_t key = -1;
+
+    explicit BlockState(Tensor a) : sink(c10::make_intrusive<GradSink>(std::move(a))) {}
+
     void forget()
     {
         frames.clear(); chunk = Tensor();
@@ -425,22 +445,58 @@ struct BlockState : torch::CustomClassHolder {
         frames.assign((size_t)L, Tensor());
         valid = -1;
     }
-    // one forward step of a loop; h contiguous [1,2,*S]
-    Tensor step(const Tensor& h, const Tensor& P)
+    // the launch of a group: frames from+1 .. from+want of the chunk (from = the frame that holds h's values); no autograd here
+    variable_list launch_group(const Tensor& h, const Tensor& P, int64_t from, int64_t want)
+    {
+        const Shape sh(h, 2);
+        const int hc = hc_of(P);
+        void* st = stream_of(h);
+        char* base = static_cast<char*>(chunk.mutable_data_ptr()) + from * chunk.stride(0) * (int64_t)chunk.element_size();
+        int rc;
+        if (h.scalar_type() == at::kFloat)
+            rc = percnn_pi_rollout_fwd_opt_f32(reinterpret_cast<float*>(base), P.const_data_ptr<float>(), hc, sh.ndim, sh.s, (int)want, nullptr, st);
+        else
+            rc = percnn_pi_rollout_fwd_opt_f64(reinterpret_cast<double*>(base), P.const_data_ptr<double>(), hc, sh.ndim, sh.s, (int)want, nullptr, st);
+        check(rc, "rollout_fwd");
+        variable_list outs;
+        outs.reserve((size_t)want);
+        for (int64_t i = from + 1; i <= from + want; ++i) outs.push_back(frame_tensor(i));
+        return outs;
+    }
+    Tensor single_step(const Tensor& h, const Tensor& P)   // h -> frame 1 of a fresh chunk; no autograd here
+    {
+        const Shape sh(h, 2);
+        const int hc = hc_of(P);
+        void* st = stream_of(h);
+        new_chunk(h);
+        char* o = static_cast<char*>(chunk.mutable_data_ptr()) + chunk.stride(0) * (int64_t)chunk.element_size();
+        int rc;
+        if (h.scalar_type() == at::kFloat)
+            rc = percnn_pi_step_fwd_opt_f32(h.const_data_ptr<float>(), reinterpret_cast<float*>(o), P.const_data_ptr<float>(), hc, sh.ndim,
+                                            sh.s, nullptr, st);
+        else
+            rc = percnn_pi_step_fwd_opt_f64(h.const_data_ptr<double>(), reinterpret_cast<double*>(o), P.const_data_ptr<double>(), hc, sh.ndim,
+                                            sh.s, nullptr, st);
+        check(rc, "step_fwd");
+        return frame_tensor(1);
+    }
+    // one forward step of a loop; h, P contiguous; record: autograd is recording for this call
+    Tensor step(const Tensor& h, const Tensor& P, bool record)
     {
         std::lock_guard<std::mutex> lk(mu);
         void* st = stream_of(h);
         const bool small = h.numel() <= (int64_t(2) << 20);
-        if (!speculate || !small) return step_fwd_raw(h, P, std::string());
+        if (!speculate || !small) {
+            if (record) return single_step_recorded(h, P, sink, nullptr);
+            return step_fwd_raw(h, P, std::string());
+        }
         const bool hit = last_out != nullptr && h.unsafeGetTensorImpl() == last_out && h._version() == last_version &&
                          P.unsafeGetTensorImpl() == p_impl && P._version() == p_version && st == stream && chunk.defined();
-        if (hit && next <= valid) { ++spec_hits; return returned(next, st, P); }
-        const Shape sh(h, 2);
-        const int hc = hc_of(P);
-        if (hit) {
-            // the input is the newest frame we hold: the loop pattern.  Compute the next `depth` steps in one fused call.
+        if (hit && next <= valid && record == recorded) { ++spec_hits; return returned(next, st, P); }
+        if (hit && next > valid) {
+            // the input is the newest frame we hold: the loop pattern.  Compute the next `want` steps in one fused call.
             const int64_t L = chunk.size(0);
-            int want = depth == 0 ? 4 : (depth < 16 ? 2 * depth : 16);
+            int64_t want = depth == 0 ? 4 : (depth < 16 ? 2 * depth : 16);
             int64_t from = next - 1;                         // frame index of h
             if (from + 1 >= L) {                             // chunk exhausted: its last frame becomes frame 0 of a new one
                 const Tensor keep = h;
@@ -449,48 +505,36 @@ struct BlockState : torch::CustomClassHolder {
                 frames[0] = keep;                            // (never returned again; keeps the indexing simple)
                 from = 0;
             }
-            if (from + want >= L) want = (int)(L - 1 - from);
-            char* base = static_cast<char*>(chunk.mutable_data_ptr()) + from * chunk.stride(0) * (int64_t)chunk.element_size();
-            int rc;
-            if (h.scalar_type() == at::kFloat)
-                rc = percnn_pi_rollout_fwd_opt_f32(reinterpret_cast<float*>(base), P.const_data_ptr<float>(), hc, sh.ndim, sh.s, want, nullptr, st);
-            else
-                rc = percnn_pi_rollout_fwd_opt_f64(reinterpret_cast<double*>(base), P.const_data_ptr<double>(), hc, sh.ndim, sh.s, want, nullptr, st);
-            check(rc, "rollout_fwd");
-            for (int64_t i = from + 1; i <= from + want; ++i) frames[(size_t)i] = frame_tensor(i);
+            if (from + want >= L) want = L - 1 - from;
+            group_from = from;
+            variable_list outs = record ? group_recorded(h, P, this, want) : launch_group(h, P, from, want);
+            for (int64_t i = 0; i < want; ++i) frames[(size_t)(from + 1 + i)] = outs[(size_t)i];
             valid = from + want;
-            depth = want;
+            depth = (int)want;
+            recorded = record;
             ++spec_launches;
             return returned(from + 1, st, P);
         }
         // anything else: a plain single step, written into frame 1 of a fresh chunk so that the next call can recognise its output
-        new_chunk(h);
         depth = 0;
-        {
-            char* o = static_cast<char*>(chunk.mutable_data_ptr()) + chunk.stride(0) * (int64_t)chunk.element_size();
-            int rc;
-            if (h.scalar_type() == at::kFloat)
-                rc = percnn_pi_step_fwd_opt_f32(h.const_data_ptr<float>(), reinterpret_cast<float*>(o), P.const_data_ptr<float>(), hc, sh.ndim,
-                                                sh.s, nullptr, st);
-            else
-                rc = percnn_pi_step_fwd_opt_f64(h.const_data_ptr<double>(), reinterpret_cast<double*>(o), P.const_data_ptr<double>(), hc, sh.ndim,
-                                                sh.s, nullptr, st);
-            check(rc, "step_fwd");
-        }
-        frames[1] = frame_tensor(1);
+        Tensor out = record ? single_step_recorded(h, P, sink, this) : single_step(h, P);
+        frames[1] = out;
         valid = 1;
+        recorded = record;
         return returned(1, st, P);
     }
+    int64_t group_from = 0;     // (argument of the group launch in flight: see GroupStepFn::forward)
 };
 
-int64_t current_task() { return (int64_t)torch::autograd::get_current_graph_task_id(); }
-
+// one step = one node; its backward leaves the parameter-gradient sums in the sink's rows
 struct CellStepFn : public torch::autograd::Function<CellStepFn> {
-    static Tensor forward(AutogradContext* ctx, const Tensor& h, const Tensor& params, const c10::intrusive_ptr<BlockState>& bs)
+    static Tensor forward(AutogradContext* ctx, const Tensor& h, const Tensor& params, const c10::intrusive_ptr<GradSink>& sink,
+                          int64_t bs_ptr)
     {
-        Tensor out = bs->step(h, params);
+        BlockState* bs = reinterpret_cast<BlockState*>(bs_ptr);
+        Tensor out = bs ? bs->single_step(h, params) : step_fwd_raw(h, params, std::string());
         ctx->save_for_backward({h, params});
-        ctx->saved_data["bs"] = c10::IValue(bs);
+        ctx->saved_data["sink"] = c10::IValue(sink);
         return out;
     }
     static variable_list backward(AutogradContext* ctx, variable_list grads)
@@ -498,17 +542,122 @@ struct CellStepFn : public torch::autograd::Function<CellStepFn> {
         const auto saved = ctx->get_saved_variables();
         const Tensor& h = saved[0];
         const Tensor& P = saved[1];
+        if (!grads[0].defined()) return {Tensor(), Tensor(), Tensor(), Tensor()};
         c10::hip::HIPGuard guard(h.device().index());
         const Tensor g = grads[0].contiguous();
         if (ctx->needs_input_grad(1)) {
-            auto bs = ctx->saved_data["bs"].toCustomClass<BlockState>();
-            return {bs->step_bwd(h, g, P, current_task()), Tensor(), Tensor()};
+            auto sink = ctx->saved_data["sink"].toCustomClass<GradSink>();
+            return {sink->step_bwd(h, g, P, current_task()), Tensor(), Tensor(), Tensor()};
         }
         // nobody asked for dL/dparams in this pass: the sums go to a scratch block
         Tensor scratch = at::zeros({P.numel()}, h.options().dtype(at::kDouble));
-        return {step_bwd_raw(h, g, P, scratch, std::string()), Tensor(), Tensor()};
+        return {step_bwd_raw(h, g, P, scratch, std::string()), Tensor(), Tensor(), Tensor()};
     }
 };
+
+// a group of speculated steps = one node with one output per frame
+struct GroupStepFn : public torch::autograd::Function<GroupStepFn> {
+    static variable_list forward(AutogradContext* ctx, const Tensor& h, const Tensor& params, const c10::intrusive_ptr<GradSink>& sink,
+                                 int64_t bs_ptr, int64_t want)
+    {
+        BlockState* bs = reinterpret_cast<BlockState*>(bs_ptr);
+        const int64_t from = bs->group_from;
+        variable_list outs = bs->launch_group(h, params, from, want);
+        variable_list keep = {h, params};
+        keep.insert(keep.end(), outs.begin(), outs.end());
+        ctx->save_for_backward(keep);                       // (outputs included: an in-place edit of a frame is caught at unpack)
+        ctx->saved_data["sink"] = c10::IValue(sink);
+        ctx->saved_data["base"] = bs->frame_tensor(from);   // frame `from` of the chunk: h's values, contiguous with the outputs
+        return outs;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list grads)
+    {
+        const auto saved = ctx->get_saved_variables();
+        const Tensor& h = saved[0];
+        const Tensor& P = saved[1];
+        const Tensor base = ctx->saved_data["base"].toTensor();
+        int64_t T = 0;
+        for (int64_t k = (int64_t)grads.size(); k >= 1; --k)
+            if (grads[(size_t)k - 1].defined()) { T = k; break; }
+        if (T == 0) return {Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        c10::hip::HIPGuard guard(h.device().index());
+        const Shape sh(h, 2);
+        const int hc = hc_of(P);
+        void* st = stream_of(h);
+        const int64_t frame_elems = h.numel(), esz = (int64_t)h.element_size(), frame_bytes = frame_elems * esz;
+        // dL/dtraj of the group: the gradients of frames 1..T.  After torch.cat, frames 1..T-1 are consecutive slices of ONE
+        // buffer (CatBackward narrows its incoming gradient) and the sweep reads them in place; frame T -- which also fed the next
+        // node, so the engine summed two contributions into a tensor of its own -- is passed separately (percnn_pi_rollout_bwd_top_*);
+        // frames without a gradient are masked.
+        std::vector<unsigned char> mask((size_t)T + 1, 0);
+        mask[(size_t)T] = 1;
+        const Tensor g_top = grads[(size_t)T - 1].contiguous();
+        const char* first = nullptr;
+        int64_t kf = 0;
+        bool inplace = true;
+        for (int64_t k = 1; k < T; ++k) {
+            const Tensor& g = grads[(size_t)k - 1];
+            if (!g.defined()) continue;
+            mask[(size_t)k] = 1;
+            if (!g.is_contiguous() || g.scalar_type() != h.scalar_type() || g.device() != h.device()) { inplace = false; continue; }
+            const char* p = static_cast<const char*>(g.const_data_ptr());
+            if (!first) { first = p; kf = k; }
+            else if (p != first + (k - kf) * frame_bytes) inplace = false;
+        }
+        Tensor gbuf;
+        const char* gptr;
+        if (!first) {
+            gptr = static_cast<const char*>(g_top.const_data_ptr());    // nothing below the top frame is read
+        } else if (inplace) {
+            gptr = first - kf * frame_bytes;                // (frames below kf are masked: never dereferenced there)
+        } else {
+            auto sizes = h.sizes().vec();
+            sizes[0] = T;
+            gbuf = at::empty(sizes, h.options());
+            for (int64_t k = 1; k < T; ++k)
+                if (mask[(size_t)k]) gbuf.select(0, k).copy_(grads[(size_t)k - 1].select(0, 0));
+            gptr = static_cast<const char*>(gbuf.const_data_ptr());
+        }
+        Tensor g_h = at::empty_like(h);
+        const size_t nbytes = percnn_pi_rollout_bwd_workspace_bytes(hc, sh.ndim, sh.s, (int)T, (int)esz);
+        TORCH_CHECK(nbytes != 0, "percnn_amd: invalid problem shape");
+        Tensor ws = at::empty({(int64_t)nbytes}, h.options().dtype(at::kByte));
+        auto sink = ctx->saved_data["sink"].toCustomClass<GradSink>();
+        Tensor pg;
+        std::unique_lock<std::mutex> lk(sink->mu, std::defer_lock);
+        if (ctx->needs_input_grad(1)) {
+            lk.lock();
+            sink->enter(current_task());
+            pg = sink->acc;
+            sink->acc_dirty = true;
+        } else {
+            pg = at::zeros({P.numel()}, h.options().dtype(at::kDouble));
+        }
+        // (short sweeps: the launch-per-group tile sweep; the persistent flavour pays a host handshake per call)
+        int rc;
+        if (h.scalar_type() == at::kFloat)
+            rc = percnn_pi_rollout_bwd_top_f32(base.const_data_ptr<float>(), reinterpret_cast<const float*>(gptr),
+                                               g_top.const_data_ptr<float>(), mask.data(), g_h.mutable_data_ptr<float>(),
+                                               pg.mutable_data_ptr<double>(), ws.mutable_data_ptr(), nbytes, P.const_data_ptr<float>(), hc,
+                                               sh.ndim, sh.s, (int)T, "tile_persist=0", st);
+        else
+            rc = percnn_pi_rollout_bwd_top_f64(base.const_data_ptr<double>(), reinterpret_cast<const double*>(gptr),
+                                               g_top.const_data_ptr<double>(), mask.data(), g_h.mutable_data_ptr<double>(),
+                                               pg.mutable_data_ptr<double>(), ws.mutable_data_ptr(), nbytes, P.const_data_ptr<double>(), hc,
+                                               sh.ndim, sh.s, (int)T, "tile_persist=0", st);
+        check(rc, "rollout_bwd");
+        return {g_h, Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+Tensor single_step_recorded(const Tensor& h, const Tensor& P, const c10::intrusive_ptr<GradSink>& sink, BlockState* bs)
+{
+    return CellStepFn::apply(h, P, sink, (int64_t)reinterpret_cast<intptr_t>(bs));
+}
+variable_list group_recorded(const Tensor& h, const Tensor& P, BlockState* bs, int64_t want)
+{
+    return GroupStepFn::apply(h, P, bs->sink, (int64_t)reinterpret_cast<intptr_t>(bs), want);
+}
 
 inline void check_cell_args(const Tensor& h, const Tensor& params)
 {
@@ -522,7 +671,7 @@ Tensor cell_step(const Tensor& h, const Tensor& params, const c10::intrusive_ptr
     check_cell_args(h, params);
     c10::hip::OptionalHIPGuard guard;
     if (c10::hip::current_device() != h.device().index()) guard.set_index(h.device().index());
-    return CellStepFn::apply(h.contiguous(), params.contiguous(), bs);
+    return bs->step(h.contiguous(), params.contiguous(), true);
 }
 
 Tensor step_nograd(const Tensor& h, const Tensor& params, const c10::optional<c10::intrusive_ptr<BlockState>>& bs)
@@ -531,7 +680,7 @@ Tensor step_nograd(const Tensor& h, const Tensor& params, const c10::optional<c1
     at::NoGradGuard ng;
     c10::hip::OptionalHIPGuard guard;
     if (c10::hip::current_device() != h.device().index()) guard.set_index(h.device().index());
-    if (bs.has_value() && h.is_contiguous() && params.is_contiguous()) return (*bs)->step(h, params);
+    if (bs.has_value() && h.is_contiguous() && params.is_contiguous()) return (*bs)->step(h, params, false);
     return step_fwd_raw(h.contiguous(), params.contiguous(), std::string());
 }
 
@@ -555,6 +704,86 @@ int64_t block_key(const py::list& tensors)
     return (int64_t)(hsh & 0x7FFFFFFFFFFFFFFFull);
 }
 
+// The same key straight from the module tree: `src` lists, per tensor, (dict, module name or None, parameter name) -- the
+// cell's own `_parameters` (name None) or its `_modules` + the name of the sub-module whose `_parameters` holds the tensor.  Hashes
+// the identity of every sub-module and tensor OBJECT as well, so parameter surgery and replaced sub-modules change the key
+// (one call per time step of a reference-style loop instead of ~60 Python-level lookups).
+int64_t block_key_src(const py::list& src)
+{
+    static PyObject* params_attr = PyUnicode_InternFromString("_parameters");
+    uint64_t hsh = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) {
+        for (int i = 0; i < 8; ++i) { hsh ^= (v >> (8 * i)) & 0xFFu; hsh *= 1099511628211ull; }
+    };
+    const Py_ssize_t n = PyList_GET_SIZE(src.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* e = PyList_GET_ITEM(src.ptr(), i);
+        TORCH_CHECK(PyTuple_Check(e) && PyTuple_GET_SIZE(e) == 3, "block_key_src: (dict, module name | None, parameter name) tuples");
+        PyObject* d = PyTuple_GET_ITEM(e, 0);
+        PyObject* mname = PyTuple_GET_ITEM(e, 1);
+        PyObject* pname = PyTuple_GET_ITEM(e, 2);
+        py::object holder;                                  // keeps the sub-module's _parameters alive while we look
+        if (mname != Py_None) {
+            PyObject* mod = PyDict_GetItemWithError(d, mname);
+            if (!mod) return -1;
+            mix((uint64_t)reinterpret_cast<uintptr_t>(mod));
+            holder = py::reinterpret_steal<py::object>(PyObject_GetAttr(mod, params_attr));
+            if (!holder) { PyErr_Clear(); return -1; }
+            d = holder.ptr();
+        }
+        PyObject* o = PyDict_Check(d) ? PyDict_GetItemWithError(d, pname) : nullptr;
+        if (!o || !THPVariable_Check(o)) return -1;
+        const Tensor& t = THPVariable_Unpack(o);
+        mix((uint64_t)reinterpret_cast<uintptr_t>(o));
+        mix((uint64_t)t._version());
+        mix((uint64_t)reinterpret_cast<uintptr_t>(t.unsafeGetTensorImpl()->unsafe_storage().unsafeGetStorageImpl()->data()) +
+            (uint64_t)t.storage_offset());
+    }
+    return (int64_t)(hsh & 0x7FFFFFFFFFFFFFFFull);
+}
+
+// RCNNCell._block_key: the tensors (block_key_src over cell._pack_src_list) + everything else a packed block depends on --
+// dt, reaction mode, diffusion kind, guard settings, speculation switch (hash of the attribute VALUES) and whether autograd
+// records.  -1: something is missing or unhashable (the Python side then takes its slow path).
+int64_t cell_key(PyObject* cell_dict)
+{
+    static PyObject* names[8] = {nullptr};
+    if (!names[0]) {
+        const char* n[8] = {"_pack_src_list", "dt", "reaction", "diffusion", "poly_guard", "state_bound", "poly_guard_max", "speculate"};
+        for (int i = 0; i < 8; ++i) names[i] = PyUnicode_InternFromString(n[i]);
+    }
+    PyObject* src = PyDict_GetItemWithError(cell_dict, names[0]);
+    if (!src || !PyList_Check(src)) return -1;
+    const int64_t tk = block_key_src(py::reinterpret_borrow<py::list>(src));
+    if (tk < 0) return -1;
+    uint64_t hsh = (uint64_t)tk ^ (at::GradMode::is_enabled() ? 0x9E3779B97F4A7C15ull : 0ull);
+    for (int i = 1; i < 8; ++i) {
+        PyObject* v = PyDict_GetItemWithError(cell_dict, names[i]);
+        if (!v) return -1;
+        const Py_hash_t hv = PyObject_Hash(v);
+        if (hv == -1 && PyErr_Occurred()) { PyErr_Clear(); return -1; }
+        hsh = (hsh ^ (uint64_t)hv) * 1099511628211ull + (uint64_t)i;
+    }
+    return (int64_t)(hsh & 0x7FFFFFFFFFFFFFFFull);
+}
+
+// RCNNCell.forward's hit path in one call: validate the cached block against the module tree, then the step (speculated frame,
+// single launch, or one autograd node).  Returns None when the cache does not apply -- the Python side repacks and comes back.
+py::object fast_forward(const py::object& cell, const Tensor& h)
+{
+    PyObject** dp = _PyObject_GetDictPtr(cell.ptr());
+    if (!dp || !*dp) return py::none();
+    static PyObject* st_name = PyUnicode_InternFromString("_block_acc");
+    PyObject* so = PyDict_GetItemWithError(*dp, st_name);
+    if (!so || so == Py_None) return py::none();
+    c10::intrusive_ptr<BlockState> bs;
+    try { bs = py::cast<c10::intrusive_ptr<BlockState>>(py::handle(so)); } catch (const py::cast_error&) { return py::none(); }
+    if (bs->key < 0 || !bs->block.defined() || cell_key(*dp) != bs->key) return py::none();
+    const Tensor& P = bs->block;
+    if (at::GradMode::is_enabled() && (h.requires_grad() || P.requires_grad())) return py::cast(cell_step(h, P, bs));
+    return py::cast(step_nograd(h, P, bs));
+}
+
 }  // namespace
 
 TORCH_LIBRARY_FRAGMENT(percnn, m)
@@ -563,6 +792,7 @@ TORCH_LIBRARY_FRAGMENT(percnn, m)
     m.def("pi_step_backward(Tensor h, Tensor params, Tensor g_out, str options=\"\") -> (Tensor, Tensor)");
     m.def("pi_rollout(Tensor h0, Tensor params, SymInt steps, str options=\"\") -> Tensor");
     m.def("pi_rollout_backward(Tensor traj, Tensor params, Tensor g_traj, str options=\"\") -> (Tensor, Tensor)");
+    m.class_<GradSink>("GradSink").def(torch::init<Tensor>());
     m.class_<BlockState>("BlockState").def(torch::init<Tensor>());
 }
 
@@ -593,20 +823,31 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.doc() = "percnn_amd: eager fast path of the Pi-block step (see torch_ext.cpp)";
     py::class_<BlockState, c10::intrusive_ptr<BlockState>>(m, "BlockState")
-        .def_property_readonly("task", [](const BlockState& b) { return b.task; })
+        .def_property_readonly("task", [](const BlockState& b) { return b.sink->task; })
         .def_property_readonly("spec_launches", [](const BlockState& b) { return b.spec_launches; })
         .def_property_readonly("spec_hits", [](const BlockState& b) { return b.spec_hits; })
         .def_property("speculate", [](const BlockState& b) { return b.speculate; },
                       [](BlockState& b, bool v) { std::lock_guard<std::mutex> lk(b.mu); b.speculate = v; if (!v) b.forget(); });
     m.def("abi_version", []() { return percnn_pi_abi_version(); });
     m.def("block_key", &block_key);
+    m.def("block_key_src", &block_key_src);
+    m.def("cell_key", [](const py::object& cell) {
+        PyObject** dp = _PyObject_GetDictPtr(cell.ptr());
+        return (dp && *dp) ? cell_key(*dp) : (int64_t)-1;
+    });
+    m.def("fast_forward", &fast_forward);
+    m.def("bind_block", [](const c10::intrusive_ptr<BlockState>& bs, const Tensor& block, int64_t key) {
+        std::lock_guard<std::mutex> lk(bs->mu);
+        bs->block = block;
+        bs->key = key;
+    });
     m.def("step_nograd", &step_nograd, py::arg("h"), py::arg("params"), py::arg("state") = py::none());
     m.def("cell_step", &cell_step);
     m.def("new_block_state", [](const Tensor& like, int64_t np) {
         return c10::make_intrusive<BlockState>(at::zeros({np}, like.options().dtype(at::kDouble)));
     });
     m.def("take_block_grad", [](const c10::intrusive_ptr<BlockState>& bs, const Tensor& like) -> c10::optional<Tensor> {
-        Tensor t = bs->take(current_task(), like);
+        Tensor t = bs->sink->take(current_task(), like);
         if (!t.defined()) return c10::nullopt;
         return t;
     });

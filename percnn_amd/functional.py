@@ -808,7 +808,9 @@ class PiRolloutFramesFunction(torch.autograd.Function):
     appends every effective step to a Python list).  The frames are views of ONE trajectory buffer; the backward
     receives one gradient per frame and runs ONE fused rollout backward.  (Slicing an autograd tensor T+1 times
     instead would make autograd allocate and zero a full-trajectory gradient per slice: 1.4 s instead of 6 ms per
-    iteration at 512^2 x 1000 -- measured.)"""
+    iteration at 512^2 x 1000 -- measured.)  The LAST output is that buffer itself, [T+1,2,*S]: what the reference's callers
+    build with ``torch.cat(tuple(outputs), dim=0)`` (train_2drd.py:394) without the 2 GiB copy and its CatBackward
+    (``RCNN.forward()`` hands it out as ``outputs.stacked``)."""
 
     @staticmethod
     def forward(ctx, h0, P, steps, frames):
@@ -819,21 +821,32 @@ class PiRolloutFramesFunction(torch.autograd.Function):
         rollout_fwd_(traj, P)
         ctx.save_for_backward(traj, P)
         ctx.frames = tuple(int(k) for k in frames)
+        ctx.set_materialize_grads(False)
         views = traj.unsqueeze(1).unbind(0)                 # all [1,2,*S] frame views in one call
-        return tuple(views[k] for k in ctx.frames)
+        return tuple(views[k] for k in ctx.frames) + (traj.view(traj.shape),)
 
     @staticmethod
     def backward(ctx, *grads):
         traj, P = ctx.saved_tensors
-        if all(g is None for g in grads):
+        g_stacked, grads = grads[-1], grads[:-1]
+        if g_stacked is None and all(g is None for g in grads):
             return None, None, None, None
-        g_traj, mask = _assemble_frame_grads(grads, ctx.frames, traj)
+        if g_stacked is not None and all(g is None for g in grads):
+            g_traj, mask = g_stacked.contiguous(), None     # the loss was written on `outputs.stacked` alone: zero-copy
+        elif g_stacked is None:
+            g_traj, mask = _assemble_frame_grads(grads, ctx.frames, traj)
+        else:                                               # both: per-frame gradients on top of a copy of the stacked one
+            g_traj, mask = g_stacked.clone(), None
+            for k, g in zip(ctx.frames, grads):
+                if g is not None:
+                    g_traj[k].add_(g[0])
         g_h0, pg = rollout_bwd(traj, g_traj, P, frame_mask=mask)
         return g_h0[None], pg.to(P.dtype), None, None
 
 
-def pi_rollout_frames(h0: torch.Tensor, P: torch.Tensor, steps: int, frames: Sequence[int]):
-    return PiRolloutFramesFunction.apply(h0, P, int(steps), tuple(frames))
+def pi_rollout_frames(h0: torch.Tensor, P: torch.Tensor, steps: int, frames: Sequence[int], with_stacked: bool = False):
+    out = PiRolloutFramesFunction.apply(h0, P, int(steps), tuple(frames))
+    return out if with_stacked else out[:-1]
 
 
 def _progression(t_idx: Sequence[int]):

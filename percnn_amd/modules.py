@@ -129,10 +129,10 @@ class RCNNCell(nn.Module):
         self.speculate = True
 
     # caches and device-side handles are not state: copy.deepcopy(cell) / pickling a whole model start without them
-    _TRANSIENT = ("_block_cache", "_block_acc", "_pack_list", "_dt_cache")
+    _TRANSIENT = ("_block_cache", "_block_acc", "_dt_cache")
 
     def __getstate__(self):
-        return {k: (None if k in self._TRANSIENT else v) for k, v in self.__dict__.items() if k != "_pack_list"}
+        return {k: (None if k in self._TRANSIENT else v) for k, v in self.__dict__.items() if k != "_pack_src_list"}
 
     def __deepcopy__(self, memo):
         import copy
@@ -167,28 +167,21 @@ class RCNNCell(nn.Module):
             F_pi.check_star_stencil(w)
             self._stencil_checked_version = key
 
+    def _pack_src(self):
+        """Where the 19 tensors of the block live, in packing order: (dict, sub-module name or None, parameter name)."""
+        src = self.__dict__.get("_pack_src_list")
+        if src is None:
+            names = ("CA", "CB") if self.diffusion == "sigmoid" else ("DA", "DB")
+            src = [(self._parameters, None, names[0]), (self._parameters, None, names[1]), (self._modules, "W_laplace", "weight")]
+            for s in ("u", "v"):
+                for k in (1, 2, 3, 4):
+                    src += [(self._modules, f"Wh{k}_{s}", "weight"), (self._modules, f"Wh{k}_{s}", "bias")]
+            self.__dict__["_pack_src_list"] = src
+        return src
+
     def _pack_tensors(self):
-        """The 19 tensors of the block in packing order.  nn.Module attribute access costs ~1 us apiece (18 us for this list),
-        more than a 100^2 step kernel, and a reference-style loop asks once per time step: the list is kept together with
-        the `_parameters` dictionaries it was read from and only re-validated by identity (parameter surgery replaces the
-        dictionary entries; in-place updates keep them and show up in the version counters instead)."""
-        hit = self.__dict__.get("_pack_list")
-        if hit is not None:
-            tensors, src = hit
-            for (d, k), t in zip(src, tensors):
-                if d[k] is not t:
-                    break
-            else:
-                return tensors
-        names = ("CA", "CB") if self.diffusion == "sigmoid" else ("DA", "DB")
-        src = [(self._parameters, names[0]), (self._parameters, names[1]), (self.W_laplace._parameters, "weight")]
-        for s in ("u", "v"):
-            for k in (1, 2, 3, 4):
-                m = getattr(self, f"Wh{k}_{s}")
-                src += [(m._parameters, "weight"), (m._parameters, "bias")]
-        tensors = [d[k] for d, k in src]
-        self.__dict__["_pack_list"] = (tensors, src)
-        return tensors
+        """The 19 tensors of the block in packing order (read afresh from the module tree: only a cache MISS asks)."""
+        return [(d if m is None else d[m]._parameters)[k] for d, m, k in self._pack_src()]
 
     def invalidate_cache(self) -> None:
         """Drop the cached parameter block.  REQUIRED after editing a parameter through ``.data`` (``p.data.mul_()``,
@@ -196,20 +189,24 @@ class RCNNCell(nn.Module):
         (``init_filter`` calls this itself).  Ordinary updates -- ``optimizer.step()``, ``load_state_dict``, ``p.copy_()`` under
         ``no_grad``, ``.to()``, replacing a Parameter or its ``.data`` -- are seen without it."""
         self.__dict__["_block_cache"] = None
+        self.__dict__["_block_acc"] = None
 
-    def _block_key(self, tensors):
-        """What a packed block depends on: every parameter's version counter AND storage address (optimizer.step(),
-        load_state_dict, .to(), parameter surgery, `p.data = new` on any of the 19 tensors -- ADVICE r3), dt (the reference
-        reads self.dt every step, train_2drd.py:117), the reaction mode, the guard's settings and whether autograd records.
-        The 38 tensor properties are hashed by the operator library (one call instead of 38: this runs once per time step of a
-        reference-style loop)."""
+    def _block_key(self):
+        """What a packed block depends on: identity, version counter AND storage address of every parameter (optimizer.step(),
+        load_state_dict, .to(), parameter surgery, replaced sub-modules, `p.data = new` on any of the 19 tensors -- ADVICE r3),
+        dt (the reference reads self.dt every step, train_2drd.py:117), the reaction mode, the guard's settings and whether
+        autograd records.  The tensor part is ONE call into the operator library (this runs once per time step of a
+        reference-style loop; ~60 Python-level lookups otherwise)."""
         ext = _native_ext()
         if ext is not None:
-            tk = ext.block_key(tensors)
-        else:                                                 # (CPU-only tools before the package has been built)
-            tk = (tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors))
-        return (tk, float(self.dt), self.reaction, self.diffusion, torch.is_grad_enabled(), bool(self.poly_guard),
-                tuple(self.state_bound), self.poly_guard_max, bool(self.speculate))
+            self._pack_src()
+            k = ext.cell_key(self)                             # the same function fast_forward validates the cache with
+            if k >= 0:
+                return k
+        ts = self._pack_tensors()
+        return ((tuple(id(t) for t in ts), tuple(t._version for t in ts), tuple(t.data_ptr() for t in ts)), float(self.dt),
+                self.reaction, self.diffusion, torch.is_grad_enabled(), self.poly_guard, tuple(self.state_bound),
+                self.poly_guard_max, self.speculate)
 
     def param_block(self, fresh: bool = False) -> torch.Tensor:
         """The packed parameter block the kernels read.  A caller that keeps the reference's own step loop
@@ -220,11 +217,11 @@ class RCNNCell(nn.Module):
         ``fresh=True`` (what ``RCNN``'s rollout entry points pass: one pack launch per ROLLOUT is free) never returns a cached
         block, so a rollout sees ``.data`` edits even without ``invalidate_cache()``."""
         if not torch.compiler.is_compiling():
-            tensors = self._pack_tensors()
-            key = self._block_key(tensors)
+            key = self._block_key()
             hit = self._block_cache
             if hit is not None and hit[0] == key and not fresh:
                 return hit[1]
+            tensors = self._pack_tensors()
             # the block's native state (csrc/torch_ext.cpp: BlockState): the rows a reference-style step loop's per-step nodes
             # leave their parameter-gradient sums in (delivered once per backward pass by the pack node) and the speculative
             # multi-step forward of such a loop
@@ -237,6 +234,8 @@ class RCNNCell(nn.Module):
                     acc.speculate = bool(self.speculate)
             P = self._param_block_uncached(acc)
             self.__dict__["_block_acc"] = acc
+            if acc is not None and isinstance(key, int):
+                ext.bind_block(acc, P, key)                  # forward()'s one-call hit path (csrc/torch_ext.cpp: fast_forward)
             if P.requires_grad:
                 import weakref
                 me = weakref.ref(self)
@@ -245,6 +244,7 @@ class RCNNCell(nn.Module):
                     cell = me()
                     if cell is not None and cell._block_cache is not None and id(cell._block_cache[1]) == P_id:
                         cell._block_cache = None
+                        cell.__dict__["_block_acc"] = None
                 P.register_hook(consumed)
             self._block_cache = (key, P)
             return P
@@ -353,20 +353,22 @@ class RCNNCell(nn.Module):
 
     # -- reference interface -------------------------------------------------------------------
     def forward(self, h):
-        P = self.param_block()
         if torch.compiler.is_compiling():
-            ch = F_pi.pi_step(h, P)                        # the registered operator is what a graph holds
+            ch = F_pi.pi_step(h, self.param_block())       # the registered operator is what a graph holds
             return ch, ch
         ext = _native_ext(required=True)
-        acc = self.__dict__.get("_block_acc")
-        if acc is not None and P is not self._block_cache[1]:
-            acc = None
-        if not (torch.is_grad_enabled() and (h.requires_grad or P.requires_grad)):
-            ch = ext.step_nograd(h, P, acc)                # nothing to record: straight to the kernel(s)
-        else:
-            if acc is not None:
-                # one C++ autograd node per step; its backward adds the step's parameter-gradient sums to the block's shared
-                # accumulator instead of returning a gradient block per node
+        # hit path of a step loop (train_2drd.py:169-188 calls this T times per iteration): ONE call validates the cached block
+        # against the module tree and steps -- a speculated frame, a single launch, or one C++ autograd node whose backward
+        # leaves the step's parameter-gradient sums in the block's shared workspace rows
+        ch = ext.fast_forward(self, h)
+        if ch is None:
+            P = self.param_block()                         # (re)pack, then the same entry points
+            acc = self.__dict__.get("_block_acc")
+            if acc is not None and P is not self._block_cache[1]:
+                acc = None
+            if not (torch.is_grad_enabled() and (h.requires_grad or P.requires_grad)):
+                ch = ext.step_nograd(h, P, acc)
+            elif acc is not None:
                 ch = ext.cell_step(h, P, acc)
             else:
                 ch = F_pi.pi_step(h, P)
@@ -665,6 +667,15 @@ class Upscaler(nn.Module):
         return self.convnet(h)
 
 
+class FrameList(list):
+    """The list of frames ``RCNN.forward()`` returns (train_2drd.py:187-188) -- an ordinary list -- plus, when every step is an
+    effective step, ``.stacked``: the [step+1, 2, *S] tensor the reference's callers build from it with
+    ``torch.cat(tuple(output), dim=0)`` (train_2drd.py:394), as an output of the SAME autograd node.  The frames are views of
+    that tensor, so ``output.stacked`` costs nothing where the cat copies the whole trajectory (2 GiB at 512^2 x 1000) forward
+    and its CatBackward slices it again backward."""
+    stacked: Optional[torch.Tensor] = None
+
+
 class RCNN(nn.Module):
     """Rollout: ``forward() -> (outputs, second_last_state)`` (train_2drd.py:162-190).
 
@@ -781,10 +792,14 @@ class RCNN(nn.Module):
         n_out = len(frames)
         if self.step >= 2:
             frames.append(self.step - 1)                    # second_last_state rides along as one more output
+        stacked = None
         if hasattr(self.cell, "rollout_frames"):            # cells with their own kernels (Stage-1 block)
             outs = self.cell.rollout_frames(self.init_state, self.step, frames)
         else:
-            outs = F_pi.pi_rollout_frames(self.init_state, self._block(), self.step, frames)
-        outputs = list(outs[:n_out])
+            outs = F_pi.pi_rollout_frames(self.init_state, self._block(), self.step, frames, with_stacked=True)
+            outs, stacked = outs[:-1], outs[-1]
+        outputs = FrameList(outs[:n_out])
+        if stacked is not None and n_out == self.step + 1:
+            outputs.stacked = stacked                       # dense effective_step: == torch.cat(tuple(outputs), dim=0), no copy
         second_last_state = outs[n_out].clone() if self.step >= 2 else []
         return outputs, second_last_state

@@ -168,3 +168,31 @@ def test_shared_block_gradient_rows_survive_odd_backward_patterns():
     loss_of(_loop(cell, hb, 3)).backward()
     small = param_grads()
     assert rel_l2((both - small).cpu().numpy(), ref.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("kind,shape,T", [("gs2d", (64, 64), 24), ("gs3d", (16, 16, 16), 9)])
+def test_stacked_attribute_of_the_frame_list_equals_cat(kind, shape, T):
+    """``outputs.stacked`` == ``torch.cat(tuple(outputs), dim=0)`` (train_2drd.py:394) as an output of the same node: same values,
+    same gradients, alone or next to losses written on single frames."""
+    import percnn_amd as pa
+    cell = _cell(kind)
+    h0 = _h0(kind, shape).requires_grad_(True)
+    model = pa.RCNN(cell, step=T, effective_step=list(range(T)), init_state=h0)
+    params = [p for p in cell.parameters() if p.requires_grad]
+
+    def flat(gs):
+        return torch.cat([g.reshape(-1) for g in gs])
+
+    outs, _ = model()
+    ref = flat(torch.autograd.grad((torch.cat(tuple(outs), 0) ** 2).mean() + outs[3].sum() * 1e-3, params + [h0]))
+    outs, _ = model()
+    assert isinstance(outs, list) and len(outs) == T + 1 and torch.equal(outs.stacked, torch.cat(tuple(outs), 0))
+    got = flat(torch.autograd.grad((outs.stacked ** 2).mean() + outs[3].sum() * 1e-3, params + [h0]))
+    assert rel_l2(got.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+    outs, _ = model()
+    only = flat(torch.autograd.grad((outs.stacked ** 2).mean(), params + [h0]))
+    outs, _ = model()
+    cat = flat(torch.autograd.grad((torch.cat(tuple(outs), 0) ** 2).mean(), params + [h0]))
+    assert rel_l2(only.cpu().numpy(), cat.cpu().numpy()) < 1e-6
+    sparse, _ = pa.RCNN(cell, step=T, effective_step=[0, 2, 5], init_state=h0)()
+    assert sparse.stacked is None and len(sparse) == 4
