@@ -317,7 +317,7 @@ class PeerHaloExchanger(HaloExchanger):
     rank; it has not run across two physical GPUs yet, so ``make_exchanger`` only picks it on request
     (``transport="peer"`` / ``PERCNN_SLAB_TRANSPORT=peer``)."""
 
-    def __init__(self, group=None, force_p2p: bool = False, slot_bytes: int = 1 << 20):
+    def __init__(self, group=None, force_p2p: bool = False, slot_bytes: int = 4 << 20):
         super().__init__(group, force_p2p)
         import ctypes
         from . import _lib
@@ -337,9 +337,18 @@ class PeerHaloExchanger(HaloExchanger):
         self._release()
         slot_bytes = (int(slot_bytes) + (1 << 20) - 1) & ~((1 << 20) - 1)
         box = ct.c_void_p()
-        self._L.check(L.percnn_pi_peer_box_alloc(ct.byref(box), slot_bytes), "peer_box_alloc")
         handle = (ct.c_char * 64)()
-        self._L.check(L.percnn_pi_peer_box_export(box, handle), "peer_box_export")
+        err = None
+        try:
+            self._L.check(L.percnn_pi_peer_box_alloc(ct.byref(box), slot_bytes), "peer_box_alloc")
+            self._L.check(L.percnn_pi_peer_box_export(box, handle), "peer_box_export")
+        except Exception as e:                      # a rank that cannot allocate / export must not leave the others in the
+            err = e                                 # all_gather below: agree first, then every rank raises
+        if not _all_ranks_agree(err is None, self.group):
+            if box.value:
+                L.percnn_pi_peer_box_free(box)
+            raise err if err is not None else RuntimeError(
+                "percnn_amd: another rank of the ring could not allocate / export its peer mailbox")
         mine = (socket.gethostname(), bytes(handle.raw), slot_bytes)
         infos = [mine]
         if self.world > 1:
@@ -394,6 +403,14 @@ class PeerHaloExchanger(HaloExchanger):
         for m in self._mapped:
             L.percnn_pi_peer_box_close(m)
         self._mapped = []
+        # nobody frees a mailbox a neighbour still has mapped: freeing an allocation another process holds open through hipIpc
+        # leaves the runtime unable to export the NEXT allocation (hipIpcGetMemHandle: invalid value -- seen as soon as a ring of
+        # >= 2 processes re-sized its mailboxes for faces above the initial 1 MiB, i.e. at BASELINE configs[4]'s 256^2 planes)
+        if self.world > 1 and barrier and dist.is_available() and dist.is_initialized():
+            try:
+                dist.barrier(group=self.group)
+            except Exception:
+                pass
         L.percnn_pi_peer_box_free(self._box)
         self._peer = self._ring = self._box = None
 
@@ -600,6 +617,10 @@ def probe_transport(sample: torch.Tensor, halo: int, group=None, candidates=("rc
             ok = type(ex) is want
             if ok:
                 ex.prepare(sample, halo)
+                if name == "peer" and getattr(ex, "_peer", None) is not None:
+                    # a candidate that does not deliver must cost the probe seconds, not the production bound of a take
+                    # (PERCNN_PEER_TIMEOUT_S, 300 s): 100 MHz ticks, restored below
+                    keep_ticks, ex._peer.timeout_ticks = ex._peer.timeout_ticks, int(5e8)
                 work = sample.clone()
                 ex.exchange(work, halo, halo)                       # also the warm-up (lazily created channels)
                 if cuda:
@@ -618,6 +639,8 @@ def probe_transport(sample: torch.Tensor, halo: int, group=None, candidates=("rc
                     ts.append(time.perf_counter() - t0)
                 entry["us_per_exchange_pair"] = min(ts) * 1e6
                 ex.check()
+                if name == "peer" and getattr(ex, "_peer", None) is not None:
+                    ex._peer.timeout_ticks = keep_ticks
         except Exception as e:                                      # a transport that cannot come up here is not a candidate
             ok = False
             entry["error"] = repr(e)[:200]
