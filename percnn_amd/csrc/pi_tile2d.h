@@ -25,6 +25,12 @@ namespace pi {
 #ifndef PI_PIN_MOMENTS
 #define PI_PIN_MOMENTS 1
 #endif
+#ifndef PI_FWD_IDLE_STORE
+#define PI_FWD_IDLE_STORE 1
+#endif
+#ifndef PI_FWD_IDLE_MAX
+#define PI_FWD_IDLE_MAX 4
+#endif
 #ifndef PI_PERSIST_LAUNDER
 #define PI_PERSIST_LAUNDER 0
 #endif
@@ -400,16 +406,71 @@ __device__ __forceinline__ void fwd_substep(T* cur, T* nxt, const T* __restrict_
     }
 }
 
+// first lane of the waves that own no strip in sub-step M (NT: every wave works)
+template <int K, int BX, int BY, int NT, int M, int CHUNKS>
+constexpr int fwd_first_idle_lane()
+{
+    constexpr int rn4 = Tile<K, BX, BY>::region_n(M) / 4;
+    constexpr int busy = (rn4 + WAVE - 1) / WAVE * WAVE;
+    // only where the idle waves get away with <= PI_FWD_IDLE_MAX chunks per lane: ONE idle wave storing a whole frame (8 chunks
+    // per lane, 16 in float64) takes longer than the sub-step it hides behind and becomes the critical path (measured: 512^2
+    // forward 1.70 -> 1.86 us per step, lambda-omega 2.78 -> 4.04)
+    return (busy < NT && CHUNKS <= PI_FWD_IDLE_MAX * (NT - busy)) ? busy : NT;
+}
+
+// tile_store by the lanes from FIRST on only (whole waves): frame M of the launch, written while the other waves compute
+template <typename T, int K, int BX, int BY, int NT, int FIRST, bool PADDED>
+__device__ __forceinline__ void tile_store_by_idle(const T* buf, T* __restrict__ dst, const TileGeom& g, int ty0, int tx0)
+{
+    using TL = Tile<K, BX, BY>;
+    constexpr int VEC = vec_width<T>::value;
+    constexpr int BXV = BX / VEC;
+    constexpr int N = 2 * BY * BXV;
+    constexpr int LANES = NT - FIRST;
+    for (int i = (int)threadIdx.x - FIRST; i < N; i += LANES) {
+        const int s = i / (BY * BXV);
+        const int r = i - s * (BY * BXV);
+        const int y = r / BXV, c = r - y * BXV;
+        if (ty0 + y >= g.H || tx0 + c * VEC >= g.W) continue;          // partial edge tile of a ragged grid
+        const T* src = buf + s * TL::PLANE + (2 * K + y) * TL::LX + 2 * K + c * VEC;
+        Pack<T, VEC> p;
+        if constexpr (PADDED && lds_pad0<T>::value != 0) {
+            const Pack<T, 2> a = ld<T, 2>(src), b = ld<T, 2>(src + 2);
+            p.v[0] = a.v[0]; p.v[1] = a.v[1]; p.v[2] = b.v[0]; p.v[3] = b.v[1];
+        } else {
+            p = ld<T, VEC>(src);
+        }
+        st_frame_wt<T, VEC>(dst + s * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC, p);
+    }
+}
+
+// Who stores frame M (= the level sub-step M reads, M >= 1)?  The regions shrink -- (B + 4 (K - M - 1))^2 points at sub-step M --,
+// so from sub-step 1 on whole waves have no strip (32 x 32 tile, 512 lanes: one wave in sub-step 1, two in 2, four in 3), and
+// the sub-steps are VALU-issue-bound on the waves that do.  Round 4: those idle waves store frame M from the buffer the busy
+// waves are READING (LDS reads and global stores issue next to the other waves' VALU work) instead of all waves storing it
+// between the barrier and the next sub-step, where the LDS round trip and the store issue sat on every wave's critical path
+// (device timeline, round 1: 0.3-0.4 us of each 1.1 us sub-step).  Frame K is stored by everybody at the end, as before.
+// `STORE_AHEAD`: sub-step M has idle waves (compile time; otherwise the all-waves store after the barrier stays).
 template <typename T, int HC, int K, int BX, int BY, int NT, int M>
 __device__ __forceinline__ void fwd_substeps(T* b0, T* b1, T* __restrict__ frames, long frame_stride, const TileGeom& g,
                                              int ty0, int tx0, const T* __restrict__ P)
 {
     T* cur = (M & 1) ? b1 : b0;
     T* nxt = (M & 1) ? b0 : b1;
+    constexpr int CHUNKS = 2 * BY * BX / vec_width<T>::value;
+    constexpr int IDLE = fwd_first_idle_lane<K, BX, BY, NT, M, CHUNKS>();
+    constexpr bool STORE_HERE = PI_FWD_IDLE_STORE && M >= 1 && IDLE < NT;       // frame M: by this sub-step's idle waves
+    if constexpr (STORE_HERE) {
+        if ((int)threadIdx.x >= IDLE)
+            tile_store_by_idle<T, K, BX, BY, NT, IDLE, ((M - 1) & 1) != 0>(cur, frames + (long)M * frame_stride, g, ty0, tx0);
+    }
     fwd_substep<T, HC, K, BX, BY, NT, M>(cur, nxt, P);
     PI_STAMP(2 + 2 * M);
     lds_barrier();                                         // do not drain the previous frame's global stores
-    tile_store<T, K, BX, BY, NT, (M & 1) != 0>(nxt, frames + (long)(M + 1) * frame_stride, g, ty0, tx0);
+    // frame M + 1: left to the idle waves of the next sub-step if it has any, else stored now by everybody
+    constexpr bool NEXT_STORES = PI_FWD_IDLE_STORE && M + 1 < K && fwd_first_idle_lane<K, BX, BY, NT, (M + 1 < K ? M + 1 : M), CHUNKS>() < NT;
+    if constexpr (!NEXT_STORES)
+        tile_store<T, K, BX, BY, NT, (M & 1) != 0>(nxt, frames + (long)(M + 1) * frame_stride, g, ty0, tx0);
     PI_STAMP(3 + 2 * M);
     if constexpr (M + 1 < K) fwd_substeps<T, HC, K, BX, BY, NT, M + 1>(b0, b1, frames, frame_stride, g, ty0, tx0, P);
 }

@@ -660,6 +660,28 @@ def probe_transport(sample: torch.Tensor, halo: int, group=None, candidates=("rc
     return best, report
 
 
+_picked: dict = {}
+
+
+def pick_exchanger(sample: torch.Tensor, halo: int, group=None) -> HaloExchanger:
+    """The exchanger a slab rollout uses when the caller names none: with more than one rank on HIP devices the transport is
+    chosen ONCE per (group, device) by ``probe_transport`` on the caller's own slab -- RCCL send / recv against the peer mailboxes,
+    each accepted only if it comes up on every rank and reproduces the portable exchange bit for bit -- unless
+    ``PERCNN_SLAB_TRANSPORT`` names one.  Collective on first use."""
+    import os
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if world == 1 or not sample.is_cuda or os.environ.get("PERCNN_SLAB_TRANSPORT"):
+        return make_exchanger(group)
+    pg = _group_object(group)
+    key = (id(pg) if pg is not None else None, sample.device.index)
+    hit = _picked.get(key)
+    if hit is not None and hit[1] is pg:
+        return make_exchanger(group, prefer_rccl=(hit[0] != "dist"), transport=hit[0])
+    name, report = probe_transport(sample, halo, group, candidates=("rccl", "peer"))
+    _picked[key] = (name, pg, report)
+    return make_exchanger(group, prefer_rccl=(name != "dist"), transport=name)
+
+
 def close_exchangers(barrier: bool = True) -> None:
     """Close every cached exchanger.  Call it (on all ranks) BEFORE ``dist.destroy_process_group()``: the mailbox transport
     synchronises its ranks once more so that nobody unmaps a mailbox a neighbour still writes to.  ``barrier=False`` (what
@@ -671,6 +693,7 @@ def close_exchangers(barrier: bool = True) -> None:
             except Exception:
                 pass
     _exchangers.clear()
+    _picked.clear()
 
 
 import atexit
@@ -828,4 +851,4 @@ class SlabRolloutFunction(torch.autograd.Function):
 
 def slab_rollout(h0_local: torch.Tensor, P: torch.Tensor, steps: int, halo: int = 2,
                  ex: Optional[HaloExchanger] = None) -> torch.Tensor:
-    return SlabRolloutFunction.apply(h0_local, P, int(steps), int(halo), ex or make_exchanger())
+    return SlabRolloutFunction.apply(h0_local, P, int(steps), int(halo), ex or pick_exchanger(h0_local, int(halo)))

@@ -84,6 +84,11 @@ def _worker(rank, world, port, shape, halo, T, hc, dtype_name, overlap, transpor
         out = slab.slab_rollout(loc, P, T, halo=halo, ex=ex)
         (out[:, :, halo:halo + n] * g_ref[:, :, lo:hi]).sum().backward()
         ok_auto = bool(torch.equal(loc.grad[:, halo:halo + n], g0_ref[:, lo:hi]))
+        # no exchanger named: the transport is picked by the start-up probe (RCCL cannot come up with two ranks on one device:
+        # rejected on every rank; the mailboxes are accepted only if they reproduce the portable exchange bit for bit)
+        with torch.no_grad():
+            out_p = slab.slab_rollout(local0.clone(), P, T, halo=halo)
+        ok_auto = ok_auto and bool(torch.equal(out_p[:, :, halo:halo + n], traj_ref[:, :, lo:hi]))
         if transport == "peer":
             ok_auto = ok_auto and ex.status() == 0            # no take ever timed out
             # the Python orchestration (one exchange call per step) over the same mailboxes
