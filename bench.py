@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Benchmark of the Pi-block rollout hot path (see DESIGN.md "Measurement").
+"""Benchmark of the Pi-block rollout hot path.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gs2d_512|gs3d_128|lo2d_512] [--T T]
 
