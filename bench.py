@@ -258,7 +258,9 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
     if persistent:
         # the whole tile sweep of the rollout is ONE launch of resident workgroups (pi_adj2d_persist_kernel): T // K groups of
         # K steps inside it; the < K remaining steps (none at T = 1000) run on the direct kernels
-        kernels[1] = {"kernel": "pi_adj2d_persist_kernel<sweep+moments, %d groups of %d steps per launch>" % (T // K, K),
+        # (round 4: the split flavour -- halo-independent pyramid under the hand-over -- unless the option says otherwise)
+        pname = "pi_adj2d_persist_kernel" if str(opts.get("persist_split", "1")) == "0" else "pi_adj2d_persist_split_kernel"
+        kernels[1] = {"kernel": pname + "<sweep+moments, %d groups of %d steps per launch>" % (T // K, K),
                       "launches_per_pass": 1, "algorithmic_bytes_per_launch": 4 * Cs * npts * (T // K) * K,
                       "avg_launch_us": sweep_ms * 1e3}
     for k in kernels:
@@ -272,7 +274,7 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
     if os.path.exists(tfile):
         tj = json.load(open(tfile))
         traffic = tj.get(dom["kernel"].split("<")[0])
-        if dom["kernel"].startswith("pi_adj2d_persist_kernel") and tj.get("pi_adj2d_persist_kernel_per_group"):
+        if dom["kernel"].startswith("pi_adj2d_persist") and tj.get("pi_adj2d_persist_kernel_per_group"):
             traffic = tj["pi_adj2d_persist_kernel_per_group"] * (T // K)        # measured at T = 100: per group of K steps
         traffic_source = (f"profiles/traffic_{name}.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, "
                           "collected in separate passes on MI355X and committed (not re-measured in this run)")

@@ -89,6 +89,7 @@ struct Options {
     int brick_rz = 0;       // planes per brick (1, 2, 4; 0 = by size)
     int brick_xcd = 1;      // brick kernels: XCD regions split in y as well as in z where the counts divide (BrickGeom::xny):
                             // 0 never, 1 where it measured no worse (make_brick_geom), 2 always
+    int brick_wide = 1;     // 3D rows of 65 .. 128 chunks on 512-lane bricks (0: the direct kernels, as before round 4)
     int brick_nt = 0;       // lanes per brick workgroup: 512 = the wide flavour (pre-contracted blocks; see brick_nt_for), else 256
     int brick_wgs = 0;      // adjoint brick kernel: resident workgroups per CU that walk the bricks (0 = 4 / 2 by planes per brick)
     int brick_wt = 1;       // brick kernels store their output frame write-through (BrickGeom::wt)
@@ -593,18 +594,29 @@ hipError_t stream3d(int vec, const T* f, T* out, const T* h, const T* inj, doubl
 
 // ---- 3D brick kernels (pi_brick3d.h) --------------------------------------------------------------
 // rows of up to 64 sixteen-byte chunks, planes below 4 GiB; returns planes per brick, 0 = not this path
+// (wide = false: callers whose kernels exist with 256 lanes only -- the residual loss pass)
 template <typename T>
-int brick_rz_for(const Problem& p, int vec, bool adjoint)
+int brick_rz_for(const Problem& p, int vec, bool adjoint, bool wide = true)
 {
     if (!p.opt.brick3d || p.ndim != 3 || p.hc < 0 || (size_t)vec * sizeof(T) != 16) return 0;
     const int64_t cpr = p.W / vec;
-    if (cpr > pi::BRICK_CPR_MAX || p.n1 < 2 || p.n1 * p.W * (int64_t)sizeof(T) >= (int64_t(1) << 32)) return 0;
+    // rows of 65 .. 128 chunks (W = 260 .. 512 float32): the 512-lane flavours, which exist for pre-contracted blocks with the
+    // plain injection form
+    const int64_t cpr_max = (wide && p.opt.brick_wide && p.hc == 0 && p.loss.mode == 0) ? pi::brick_cpr_max(512) : pi::BRICK_CPR_MAX;
+    if (cpr > cpr_max || p.n1 < 2 || p.n1 * p.W * (int64_t)sizeof(T) >= (int64_t(1) << 32)) return 0;
+    // wide rows, same-box A/B (us per step, direct -> 512-lane bricks; profiles/r04_wide_bricks.txt): forward 384^3 281 -> 253,
+    // 320^3 172 -> 146, 192 x 192 x 512 97 -> 86, 64 x 384^2 a tie; adjoint 64 x 384^2 125 -> 81, 192 x 192 x 512 198 -> 173, but
+    // 320^3 288 -> 295, 384^3 475 -> 493 (one 512-lane workgroup per CU next to its 42 KB moment scratch)
+    // -> the forward takes them from 16 M points on, the adjoint below 25 M
+    const bool wide_row = cpr > pi::BRICK_CPR_MAX;
+    if (wide_row && !p.opt.brick_rz && (adjoint ? p.n >= (int64_t(3) << 23) : p.n < (int64_t(1) << 24))) return 0;
     // planes per brick (profiles/r03_brick_sweeps.txt): sharing plane neighbours pays in the forward kernel from ~2 M points on
     // (128^3: 8.8 -> 8.4 us, 200^3: 33 -> 30); the adjoint keeps one plane (more workgroups in flight beats the reuse: 144^3 25.4 vs
     // 26.1 us, 200^3 59.3 vs 60.9; 128^3 ties); small grids need the workgroups (48^3: 99 k vs 89 k steps/s)
     // (beyond ~12 M points the adjoint is DRAM-bound and takes two planes as well: 256^3 172 -> 140 us)
     int rz = p.opt.brick_rz ? p.opt.brick_rz : (p.n >= (adjoint ? (int64_t(3) << 22) : (int64_t(1) << 21)) ? 2 : 1);
     if (rz > 1 && p.hc != 0) rz = 1;                        // the multi-plane flavours exist for pre-contracted blocks
+    if (wide_row && rz > 2) rz = 2;                         // the 512-lane flavours: one or two planes per brick
     return rz;
 }
 
@@ -617,7 +629,7 @@ int brick_rz_for(const Problem& p, int vec, bool adjoint)
 // 7.84 us, adjoint 17.78 -> 18.29).  Not a default: option brick_nt = 512 selects them.
 int brick_nt_for(const Problem& p, int vec)
 {
-    (void)vec;
+    if (p.hc == 0 && p.loss.mode == 0 && p.W / std::max(1, vec) > pi::BRICK_CPR_MAX) return 512;     // wide rows (brick_rz_for)
     return (p.opt.brick_nt == 512 && p.hc == 0 && p.loss.mode == 0) ? 512 : 256;
 }
 
@@ -2093,7 +2105,7 @@ int residual_sqloss_impl(const T* traj, const T* Q, int ndim, const int64_t* sha
     auto st0 = static_cast<hipStream_t>(stream);
     // 3D grids the brick kernels take: plane neighbours from a register window, in-plane neighbours from LDS (pi_brick3d.h)
     if (ndim == 3 && p.opt.brick3d) {
-        const int brz = brick_rz_for<T>(p, vec, false);
+        const int brz = brick_rz_for<T>(p, vec, false, false);
         if (brz == 1 || brz == 2) {
             pi::BrickGeom b = make_brick_geom(p, pi::vec_width<T>::value, brz, pi::BRICK_NT, false);
             if (b.nblk > 0 && b.nblk <= RESLOSS_SLOTS) {
@@ -2315,6 +2327,7 @@ int apply_option(Options& o, const char* key, long value)
         o.brick_xcd = (int)value;
         return 0;
     }
+    if (!std::strcmp(key, "brick_wide")) { o.brick_wide = value != 0; return 0; }
     if (!std::strcmp(key, "brick_nt")) {
         if (value != 0 && value != 256 && value != 512) return PERCNN_PI_EINVAL;
         o.brick_nt = (int)value;

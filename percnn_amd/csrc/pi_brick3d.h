@@ -24,9 +24,11 @@
 namespace pi {
 
 constexpr int BRICK_NT = 256;                        // lanes per workgroup = own chunks per plane of a brick (NT = 512: wide rows)
-constexpr int BRICK_CPR_MAX = 64;                    // rows of up to 64 chunks (W <= 256 float32 / 128 float64)
-// chunks / bytes per LDS window (fixed stride -> immediate offsets): 8 KiB per (plane, species) with 256 lanes, 12 KiB with 512
-__host__ __device__ constexpr int brick_wb(int nt) { return (nt + 4 * BRICK_CPR_MAX) * 16; }
+constexpr int BRICK_CPR_MAX = 64;                    // 256-lane bricks: rows of up to 64 chunks (W <= 256 float32 / 128 float64)
+// 512-lane bricks take rows of up to 128 chunks (W <= 512 float32: 384^3 ran on the direct kernels at 0.41 of HBM, round 4)
+__host__ __device__ constexpr int brick_cpr_max(int nt) { return nt >= 512 ? 2 * BRICK_CPR_MAX : BRICK_CPR_MAX; }
+// chunks / bytes per LDS window (fixed stride -> immediate offsets): 8 KiB per (plane, species) with 256 lanes, 16 KiB with 512
+__host__ __device__ constexpr int brick_wb(int nt) { return (nt + 4 * brick_cpr_max(nt)) * 16; }
 constexpr int BRICK_WB = brick_wb(BRICK_NT);
 
 struct BrickGeom {
@@ -62,7 +64,7 @@ struct Brick {
     static constexpr int VEC = 16 / (int)sizeof(T);
     static constexpr int NW = NT / 64;
     static constexpr int WB = brick_wb(NT);
-    static constexpr int MH = (2 * RZ * 4 + NW - 1) / NW;   // halo tasks per wave: 2 RZ nseg / NW waves, nseg <= 4
+    static constexpr int MH = (2 * RZ * (4 * brick_cpr_max(NT) / 64) + NW - 1) / NW;   // halo tasks per wave: 2 RZ nseg / NW waves, nseg <= 4 (8: wide rows)
     int i0, cb, nown;                                // first plane of the group; first own chunk of the plane; how many
     bool valid;
     unsigned eb;                                     // byte offset of the lane's chunk inside a plane

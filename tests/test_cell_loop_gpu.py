@@ -196,3 +196,41 @@ def test_stacked_attribute_of_the_frame_list_equals_cat(kind, shape, T):
     assert rel_l2(only.cpu().numpy(), cat.cpu().numpy()) < 1e-6
     sparse, _ = pa.RCNN(cell, step=T, effective_step=[0, 2, 5], init_state=h0)()
     assert sparse.stacked is None and len(sparse) == 4
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_speculation_fuzz_against_single_steps(seed):
+    """Random interleavings of everything a caller can do between two `cell(h)` calls -- continue the loop, branch off an older
+    state, edit the state in place, toggle grad mode, two loops taking turns, the speculation switch -- every returned state
+    compared bit for bit with an independent single step of the same input (`torch.ops.percnn.pi_rollout(h, P, 1)`)."""
+    import percnn_amd as pa
+    rs = np.random.RandomState(seed)
+    cell = _cell("gs2d")
+    hs = [_h0("gs2d", (64, 64)), _h0("gs2d", (64, 64)) * 0.9]
+    history = [[hs[0]], [hs[1]]]
+    P = cell.param_block().detach()
+    checked = 0
+    for it in range(160):
+        lane = int(rs.randint(2)) if rs.rand() < 0.15 else 0        # mostly one loop, sometimes a second one taking turns
+        op = rs.rand()
+        h = history[lane][-1]
+        if op < 0.08 and len(history[lane]) > 3:                     # branch off an older state
+            h = history[lane][int(rs.randint(1, len(history[lane]) - 1))]
+        elif op < 0.14:                                              # in-place edit of the newest state
+            with torch.no_grad():
+                h.mul_(0.999)
+        elif op < 0.18:
+            cell.speculate = not cell.speculate
+        record = rs.rand() < 0.3
+        ref = pa.pi_rollout(h.detach(), P, 1)[1:2]
+        if record:
+            hin = h.detach().requires_grad_(True) if rs.rand() < 0.3 else h
+            out, _ = cell(hin)
+        else:
+            with torch.no_grad():
+                out, _ = cell(h)
+        assert out.requires_grad == (record and torch.is_grad_enabled()), (it, record)
+        assert torch.equal(out.detach(), ref), f"step {it}: lane {lane}, op {op:.2f}, record {record}"
+        history[lane].append(out)
+        checked += 1
+    assert checked == 160

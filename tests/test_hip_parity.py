@@ -862,7 +862,10 @@ def test_direct_kernel_variants_bitwise(opts, shape, dtype, hip_device):
                                             ((8, 32, 64), np.float32, 0), ((16, 64, 32), np.float32, 0),   # XCD regions split in z and y
                                             ((10, 24, 48), np.float64, 0), ((2, 6, 8), np.float64, 0), ((7, 5, 128), np.float64, 0),
                                             ((9, 12, 64), np.float32, 2), ((6, 33, 40), np.float32, 8), ((5, 9, 24), np.float64, 4),
-                                            ((4, 7, 20), np.float32, 3)])
+                                            ((4, 7, 20), np.float32, 3),
+                                            # rows of 65 .. 128 chunks: the 512-lane bricks take them since round 4 (384^3)
+                                            ((5, 6, 384), np.float32, 0), ((4, 3, 512), np.float32, 0), ((3, 5, 260), np.float32, 0),
+                                            ((4, 4, 192), np.float64, 0), ((4, 6, 384), np.float32, 4)])
 def test_brick3d_bitwise(opts, shape, dtype, hc, hip_device):
     """Round-3 brick kernels (pi_brick3d.h: z neighbours in a register window, y / x neighbours from LDS windows staged once per
     workgroup, halo rows fetched by whole waves): forward, adjoint sweep with fused moments, sweep + separate reduction, masked

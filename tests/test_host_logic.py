@@ -521,7 +521,12 @@ def test_rollout_plan_follows_the_dispatch_rules():
     p = plan(0, (256, 256, 256), 4)                       # forward keeps the z-march from 8 M points on, the adjoint takes bricks
     assert p["fwd"] == "stream3d" and p["bwd"] == "brick3d" and p["bwd_planes_per_pass"] == 2
     assert plan(0, (64, 256, 256), 4)["fwd"] == "brick3d"
-    assert plan(0, (384, 384, 384), 4)["fwd"] == "direct"                 # rows of 96 chunks: beyond the brick windows
+    p = plan(0, (384, 384, 384), 4)                       # rows of 96 chunks: 512-lane bricks since round 4 (were: direct kernels)
+    assert p["fwd"] == "brick3d" and p["bwd"] == "direct" and p["brick_lanes"] == 512      # (adjoint: below 25 M points only)
+    q = plan(0, (64, 384, 384), 4)
+    assert q["fwd"] == "direct" and q["bwd"] == "brick3d" and q["brick_lanes"] == 512      # (forward: from 16 M points on)
+    assert plan(0, (384, 384, 384), 4, "brick_wide=0")["fwd"] == "direct" and plan(0, (64, 64, 640), 4)["fwd"] == "direct"
+    assert plan(2, (384, 384, 384), 4)["fwd"] == "direct"                 # (the wide flavours exist for pre-contracted blocks)
     assert plan(0, (128, 128, 128), 4, "brick3d=0")["fwd"] == "direct"
     assert plan(2, (48, 48, 48), 4)["bwd"] == "brick3d" and not plan(2, (48, 48, 48), 4)["fused_gradients"]
     assert plan(0, (30, 30, 30), 4)["fwd"] == "direct"                    # W % 4 != 0: 4-byte lanes
