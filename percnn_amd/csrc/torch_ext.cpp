@@ -434,11 +434,14 @@ struct BlockState : torch::CustomClassHolder {
         next = i + 1;
         return out;
     }
-    void new_chunk(const Tensor& h)
+    // frames of one allocation.  Every frame a caller keeps pins its whole chunk, so chunks stay small: 32 MiB at most, and TWO
+    // frames for the single step of a call that matched nothing (a loop that never hands an output back -- `h = f(cell(h)[0])` --
+    // would otherwise pin a full chunk per step); the first call that does match moves on to a full chunk (one frame copy).
+    void new_chunk(const Tensor& h, bool single = false)
     {
         const int64_t frame_bytes = h.numel() * (int64_t)h.element_size();
-        int64_t L = (int64_t(64) << 20) / (frame_bytes > 0 ? frame_bytes : 1);
-        L = L < 6 ? 6 : (L > 64 ? 64 : L);
+        int64_t L = (int64_t(32) << 20) / (frame_bytes > 0 ? frame_bytes : 1);
+        L = single ? 2 : (L < 6 ? 6 : (L > 64 ? 64 : L));
         auto sizes = h.sizes().vec();
         sizes[0] = L;
         chunk = at::empty(sizes, h.options());
@@ -468,7 +471,7 @@ struct BlockState : torch::CustomClassHolder {
         const Shape sh(h, 2);
         const int hc = hc_of(P);
         void* st = stream_of(h);
-        new_chunk(h);
+        new_chunk(h, true);
         char* o = static_cast<char*>(chunk.mutable_data_ptr()) + chunk.stride(0) * (int64_t)chunk.element_size();
         int rc;
         if (h.scalar_type() == at::kFloat)

@@ -69,6 +69,11 @@ def test_speculation_never_outlives_its_premises():
         P = cell.param_block()
         outs = _loop(cell, h0, 10)                         # speculated frames beyond outs[10] exist now
         ref = pa.pi_rollout(h0, P, 12)
+        # every kept frame pins its chunk: <= 32 MiB, and a step that matched nothing pins two frames, not a chunk
+        fb = h0.numel() * h0.element_size()
+        assert outs[10].untyped_storage().nbytes() <= 32 << 20
+        lone, _ = cell(h0 * 1.0)
+        assert lone.untyped_storage().nbytes() <= 2 * fb
         # (a) the newest output, modified in place
         h = outs[10]
         h.mul_(0.5)
