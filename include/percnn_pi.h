@@ -199,6 +199,12 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *                  has reached the sweep -- or "aborted"; after an abort the launch-per-group sweep is enqueued by the same call,
  *                  a one-line warning goes to stderr and the device keeps the launch-per-group path until "persist_reset".  0: no
  *                  wait; an abort is reported by the next entry point as PERCNN_PI_EASYNC.
+ *   "persist_split"  1 (default): the persistent sweep computes the halo-independent part of every step while the granules
+ *                  travel (pi_adj2d_persist_split_kernel); 0: round 3's kernel
+ *   "persist_small"  1 (default): grids in the 32 x 8-tile regime (below ~300^2, ragged ones included: the reference's own
+ *                  100^2, train_2drd.py:597-636) run their sweep as one resident launch as well (pi_adj2d_persist_small_kernel;
+ *                  its granule outbox is part of percnn_pi_rollout_bwd_workspace_bytes); 0: one launch per four steps
+ *   "brick_wide"   1 (default): 3D rows of 65 .. 128 sixteen-byte chunks on 512-lane bricks where they win; 0: direct kernels
  *   "persist_reset"  (any value) re-arm the persistent sweep after an abort
  * Returns 0, or PERCNN_PI_EINVAL for an unknown key / bad value. */
 int percnn_pi_set_option(const char *key, long value);

@@ -60,6 +60,7 @@ struct Options {
                             // launch-per-group sweep is enqueued in the same call and the persistent path is switched off for
                             // this device (percnn_pi_persist_status).  0: no wait; an aborted launch is reported by the NEXT
                             // entry point (PERCNN_PI_EASYNC) instead
+    int persist_small = 1;      // the 32 x 8-tile regime (grids below ~300^2, split schedule) as one persistent launch too
     int persist_split = 1;      // persistent sweep: 1 = split flavour (pi_adj2d_persist_split_kernel: the halo-independent
                             // "pyramid" of the next group runs while the granules of the hand-over travel), 0 = round 3's kernel
     int persist_timeout_ms = 2000;       // bound of one hand-over wait inside the persistent sweep
@@ -1333,6 +1334,103 @@ hipError_t launch_adj_persist(const T* hframe_t, const T* gframe_t, T* aframe_t,
     return hipSuccess;
 }
 
+// ---- small-tile persistent sweep (pi_adj2d_persist_small_kernel): the 32 x 8 / 256-lane regime with the split schedule --------
+// granule outbox of the small-tile persistent sweep (pi_adj2d_persist_small_kernel): two parities x tiles x the 2 x 32 x 8 values
+// a tile publishes; behind the partial rows (every adjoint frame is in use in the split schedule it serves)
+constexpr int SMALL_BY = 8, SMALL_NT = 256, SMALL_OWN = 2 * TILE_B * SMALL_BY;
+size_t persist_small_outbox_bytes(const Problem& p, int elem)
+{
+    if (p.ndim != 2 || p.hc != 0 || elem != 4 || p.slab) return 0;
+    const int64_t tiles = ((p.n0 + SMALL_BY - 1) / SMALL_BY) * ((p.W + TILE_B - 1) / TILE_B);
+    if (tiles > 256) return 0;
+    return align_up((size_t)2 * (size_t)tiles * SMALL_OWN * sizeof(unsigned long long), 256);
+}
+
+template <typename T>
+bool persist_small_ok(const Problem& p, const unsigned char* mask, int t_top, int ngroups, hipStream_t st)
+{
+    if (!p.opt.tile_persist || !p.opt.persist_small || sizeof(T) != 4 || ngroups < 2 || p.hc != 0) return false;
+    if (persist_disabled_here()) return false;
+    if (mask && t_top >= 4096) return false;
+    if (p.opt.tile_k != 4 || tile_wide_for<T>(p, true) != 0 || tile_by_for(p) != SMALL_BY || tile_fuse_ok<T>(p)) return false;
+    const int64_t tiles = ((p.n0 + SMALL_BY - 1) / SMALL_BY) * ((p.W + TILE_B - 1) / TILE_B);
+    const int cus = device_cu_count();
+    if (tiles < 2 || cus <= 0 || tiles > cus || tiles > 256) return false;    // one workgroup per CU at most: resident for sure
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
+    return true;
+}
+
+// as launch_adj_persist; every adjoint frame of the groups it runs is written
+template <typename T>
+hipError_t launch_adj_persist_small(const T* hframe_t, const T* gframe_t, T* aframe_t, T* g_h0, int t_top, const unsigned char* mask,
+                                    int ngroups, double* partials, unsigned long long* outbox, unsigned* sync, const T* P,
+                                    const Problem& p, int dev, hipStream_t st)
+{
+    constexpr int K = 4, NT = SMALL_NT, BY = SMALL_BY;
+    using TL = pi::Tile<K, TILE_B, BY>;
+    pi::TileGeom g = make_tile_geom(p, BY);
+    const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
+    constexpr int RINGH = TL::LX * TL::LY - TILE_B * BY, NGAT = (2 * RINGH + NT - 1) / NT;
+    const size_t lds = pi::tile_state_bytes<T, K, TILE_B, BY>() + (size_t)2 * NGAT * NT * sizeof(int) + 16;
+    auto* k = pi::pi_adj2d_persist_small_kernel<T, K, TILE_B, BY, NT>;
+    if (hipError_t e = allow_lds(k, lds)) return e;
+    if (hipError_t e = hipMemsetAsync(outbox, 0, persist_small_outbox_bytes(p, (int)sizeof(T)), st)) return e;
+    long frame_stride = (long)(2 * p.n);
+    int np = pi::nparams(p.hc);
+    pi::PersistArgs pa{};
+    int slot;
+    {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        slot = g_persist.next_slot++ % PERSIST_SLOTS;
+        g_persist.watch[slot] = false;
+        ++g_persist.launches;
+    }
+    volatile int* hs = g_persist.host->slot[slot];
+    hs[0] = 0; hs[1] = -1; hs[2] = -1; hs[3] = 0;
+    pa.outbox = outbox; pa.sync = sync; pa.ngroups = ngroups;
+    pa.host = const_cast<int*>(hs);
+    pa.timeout_ticks = (unsigned long long)p.opt.persist_timeout_ms * 100000ull;
+    pa.first_timeout_ticks = (unsigned long long)p.opt.persist_first_timeout_ms * 100000ull;
+    pa.t_top = t_top;
+    pa.masked = mask ? 1 : 0;
+    if (mask)
+        for (int t = 0; t < t_top && t < 4096; ++t)
+            if (mask[t]) pa.frames[t >> 5] |= 1u << (t & 31);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, hframe_t, gframe_t, aframe_t, frame_stride, g_h0, partials, np, P, g, pa);
+    if (hipError_t e = hipGetLastError()) return e;
+    {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        g_persist.watch[slot] = true;
+    }
+    if (!p.opt.persist_handshake) return hipSuccess;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (hs[0] == 0 && hs[3] == 0) {
+        if ((++spins & 0x3ff) == 0) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(600)) return hipErrorLaunchTimeOut;
+            std::this_thread::yield();
+        }
+    }
+    if (hs[3] != 0) {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        g_persist.watch[slot] = false;
+        ++g_persist.aborts;
+        g_persist.last_group = hs[1];
+        g_persist.last_tile = hs[2];
+        g_persist.disabled[dev] = true;
+        if (!g_persist.warned) {
+            g_persist.warned = true;
+            std::fprintf(stderr, "percnn_pi: the persistent tile sweep could not keep all %u workgroups resident on device %d "
+                                 "(group %d, tile %d: another process / kernel holds CUs, or a CU mask is set); using one launch "
+                                 "per group of steps from now on (percnn_pi_set_option(\"persist_reset\", 1) re-arms it)\n",
+                         grid, dev, (int)hs[1], (int)hs[2]);
+        }
+        return hipErrorLaunchFailure;
+    }
+    return hipSuccess;
+}
+
 // ---- workspace carving -------------------------------------------------------------------------
 struct Workspace {
     void* adj[2];
@@ -1872,7 +1970,7 @@ int rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* shape
 
 size_t rollout_workspace_bytes(const Problem& p, int T_steps, int elem)
 {
-    return align_up((size_t)(T_steps + 1) * 2 * p.n * elem, 256) + partials_bytes_for(p.hc);
+    return align_up((size_t)(T_steps + 1) * 2 * p.n * elem, 256) + partials_bytes_for(p.hc) + persist_small_outbox_bytes(p, elem);
 }
 
 template <typename T>
@@ -2001,6 +2099,32 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
                         (void)hipGetLastError();            // not resident / not supported / aborted: the launch-per-group path
                         if (e == hipErrorLaunchFailure) {   // it RAN and gave up: workgroups that were already through may have
                             persist_leave(st, pdev);        // added to their partial rows -- start the rows over
+                            if (hipError_t e2 = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e2;
+                        }
+                    }
+                }
+            }
+        }
+        // the small-tile regime (32 x 8 tiles, split schedule): the same, with every adjoint frame written and the granule
+        // outbox behind the partial rows
+        if constexpr (sizeof(T) == 4) {
+            const int ngroups = K == 4 ? t_cur / K : 0;
+            if (t_cur == t_top && !tile_fused && !loss && ngroups >= 2 && persist_small_ok<T>(p, mask, t_cur, ngroups, st) &&
+                ws_bytes >= rollout_workspace_bytes(p, T_steps, sizeof(T))) {
+                const int t_end = t_cur - K * ngroups;
+                auto* outbox = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(w.partials) + w.partials_bytes);
+                unsigned* sync = reinterpret_cast<unsigned*>(w.partials + (size_t)(MAX_BWD_BLOCKS - 1) * pi::nparams(p.hc));
+                int pdev = 0;
+                if (persist_enter(st, pdev)) {
+                    const hipError_t e = launch_adj_persist_small<T>(traj + (size_t)t_cur * frame, g_traj + (size_t)t_cur * frame,
+                                                                     adj + (size_t)t_cur * frame, t_end == 0 ? g_h0 : nullptr, t_cur,
+                                                                     mask, ngroups, w.partials, outbox, sync, P, p, pdev, st);
+                    if (e == hipSuccess) { t_cur = t_end; persist_leave(st, pdev); }
+                    else if (e == hipErrorLaunchTimeOut) return (int)e;
+                    else {
+                        (void)hipGetLastError();
+                        if (e == hipErrorLaunchFailure) {
+                            persist_leave(st, pdev);
                             if (hipError_t e2 = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e2;
                         }
                     }
@@ -2235,6 +2359,7 @@ int apply_option(Options& o, const char* key, long value)
     }
     if (!std::strcmp(key, "persist_handshake")) { o.persist_handshake = value != 0; return 0; }
     if (!std::strcmp(key, "persist_split")) { o.persist_split = value != 0; return 0; }
+    if (!std::strcmp(key, "persist_small")) { o.persist_small = value != 0; return 0; }
     if (!std::strcmp(key, "persist_timeout_ms") || !std::strcmp(key, "persist_first_timeout_ms")) {
         if (value < 1 || value > 600000) return PERCNN_PI_EINVAL;
         (key[8] == 'f' ? o.persist_first_timeout_ms : o.persist_timeout_ms) = (int)value;
@@ -2483,7 +2608,9 @@ int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options,
     out[7] = (out[0] == 3 || out[1] == 3) ? brick_nt_for(p, vec) : 0;     // lanes per brick workgroup
     for (int i = 8; i < 15; ++i) out[i] = 0;
     // the whole tile sweep as one launch of resident workgroups (needs a device to ask for its CU count: 0 without one)
-    if constexpr (sizeof(T) == 4) out[14] = (out[1] == 1 && persist_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr)) ? 1 : 0;
+    if constexpr (sizeof(T) == 4)
+        out[14] = (out[1] == 1 && (persist_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr) ||
+                                   persist_small_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr))) ? 1 : 0;
     for (int dir = 0; dir < 2; ++dir) {                                    // 2D tiles: width, height, lanes per workgroup
         if (out[dir] != 1) continue;
         const TileShape ts = tile_shape_for<T>(p, dir == 1);

@@ -941,7 +941,9 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
     // the adjoint of frame 0 is the caller's dL/dh0 output.  MOM: nobody reads the intermediate adjoint frames (the
     // moments are reduced right here), only the hand-over frame t-K goes to memory
     if constexpr (!MOM || M + 1 == K) {
-        if (store_handover) {                              // (persistent sweep: the state stays in LDS between groups)
+        // (persistent sweeps keep the state in LDS between groups: store_handover = false skips the store of frame t - K; the
+        // split schedule's intermediate frames -- !MOM, M + 1 < K -- are always written)
+        if (store_handover || (!MOM && M + 1 < K)) {
             T* dst = (M + 1 == steps_to_zero && g_h0) ? g_h0 : abase + fo;
             tile_store<T, K, BX, BY, NT, (M & 1) != 0>(nxt, dst, g, ty0, tx0);
         }
@@ -1356,6 +1358,181 @@ pi_adj2d_persist_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gf
         a += dpp_mov<0x114, 0xF>(a);
         a += dpp_mov<0x118, 0xF>(a);
         if (part == 15) partials[(long)blockIdx.x * np + P_W + mm] += a;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT sweep for the SMALL-TILE regime (round 4): grids below ~300^2 -- the reference's own 100^2 x 200
+// (train_2drd.py:597-636) among them -- run on 32 x 8 tiles of 256 lanes with the SPLIT schedule (every adjoint frame is stored,
+// the 20 moments come from one time-parallel pass afterwards), ragged edge tiles included.  A K = 4 sweep launch there is 7.3 us
+// of which the four sub-steps are under two: the rest is the kernel boundary and the cold window load.  Same idea as
+// pi_adj2d_persist_kernel -- resident workgroups, adjoint tile kept in LDS, data-tagged granules -- with two simplifications the
+// small tiles allow: a tile publishes ALL its BX x BY values (its 2K-wide border band would be the whole tile anyway), and the
+// gather tables are built from global coordinates (owner tile = (gy / BY, gx / BX) after the periodic wrap), which makes ragged
+// grids, halos that reach across two neighbours and grids of a single tile column the same code.  The out-of-grid part of a ragged
+// edge tile holds the periodic duplicates of the first columns / rows exactly as the launch-per-group kernel's window does; they
+// are recomputed there like a halo and never published.  Sub-steps = the device functions of pi_adj2d_tile_kernel<MOM = false>:
+// adjoint frames and dL/dh0 bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int K, int BX, int BY, int NT>
+__global__ void __launch_bounds__(NT)
+pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gframe_t, T* __restrict__ aframe_t,
+                              long frame_stride, T* __restrict__ g_h0, double* __restrict__ partials, int np,
+                              const T* __restrict__ P, TileGeom g, PersistArgs pa)
+{
+    static_assert(sizeof(T) == 4 && K % 2 == 0, "float32; an even number of sub-steps leaves the state in buffer 0");
+    using TL = Tile<K, BX, BY>;
+    constexpr int HW = 2 * K, LXW = TL::LX, LYW = TL::LY;
+    constexpr int OWN = BX * BY;                                         // values per species a tile publishes
+    constexpr int RINGH = LXW * LYW - OWN;                               // halo values per species
+    constexpr int NPUB = (2 * OWN + NT - 1) / NT, NGAT = (2 * RINGH + NT - 1) / NT;
+    constexpr bool PRE = PI_TILE_ADJ_PIPE && TL::region_n(0) / 4 <= NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* b0 = reinterpret_cast<T*>(smem_raw) + lds_pad0<T>::value;
+    T* b1 = reinterpret_cast<T*>(smem_raw) + 2 * TL::PLANE + lds_pad1<T>::value;
+    const int tile = tile_of_block(blockIdx.x, g);
+    const int tiles_y = (g.H + BY - 1) / BY;
+    const int tyi = tile / g.tiles_x, txi = tile % g.tiles_x;
+    const int ty0 = tyi * BY, tx0 = txi * BX;
+    const int ntiles = g.tiles_x * tiles_y;
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    gu64* outbox = (gu64*)pa.outbox;
+    // LDS: state buffers | int tables | abort word
+    int* tab_gl = reinterpret_cast<int*>(smem_raw + tile_state_bytes<T, K, BX, BY>());      // [NGAT][NT]: LDS position of a halo value
+    int* tab_gs = tab_gl + NGAT * NT;                                                       // [NGAT][NT]: granule index inside a parity half
+    int* wg_abort = tab_gs + NGAT * NT;
+    if (threadIdx.x == 0) {                                                                 // residency roll call (pi_adj2d_persist_kernel)
+        *wg_abort = 0;
+        const unsigned n = __hip_atomic_fetch_add(pa.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (n == (unsigned)ntiles && pa.host) __hip_atomic_store(pa.host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+#pragma unroll
+    for (int q = 0; q < NGAT; ++q) {
+        const int r = (int)threadIdx.x + q * NT;
+        int gl = -1, gs = 0;
+        if (r < 2 * RINGH) {
+            const int sp = r / RINGH, e = r - sp * RINGH;
+            int wy, wx;                                    // ring positions row-major over the window, skipping the centre
+            if (e < HW * LXW) { wy = e / LXW; wx = e - wy * LXW; }
+            else if (e < HW * LXW + BY * 2 * HW) { const int m = e - HW * LXW; wy = HW + m / (2 * HW); const int c = m % (2 * HW); wx = c < HW ? c : BX + c; }
+            else { const int m = e - HW * LXW - BY * 2 * HW; wy = HW + BY + m / LXW; wx = m % LXW; }
+            int gy = (ty0 + wy - HW) % g.H, gx = (tx0 + wx - HW) % g.W;                     // the global point, periodic
+            gy += gy < 0 ? g.H : 0;
+            gx += gx < 0 ? g.W : 0;
+            const int nty = gy / BY, ntx = gx / BX;
+            gl = sp * TL::PLANE + wy * LXW + wx;
+            gs = (nty * g.tiles_x + ntx) * (2 * OWN) + sp * OWN + (gy - nty * BY) * BX + (gx - ntx * BX);
+        }
+        tab_gl[q * NT + (int)threadIdx.x] = gl;
+        tab_gs[q * NT + (int)threadIdx.x] = gs;
+    }
+    // group 0 starts from the adjoint frame in memory, like a launch of pi_adj2d_tile_kernel
+    WindowLoader<T, K, BX, BY, NT> wl;
+    wl.issue(aframe_t, g, ty0, tx0);
+    StripOps<T> ops0;
+    StripAddr sa[K];
+    unsigned gmask = persist_mask<K>(pa, pa.t_top);
+    if constexpr (PRE) {
+        strip_addr_table<K, BX, BY, NT, 0>(sa, g, ty0, tx0);
+        adj_load_ops<T, K, BX, BY, NT, 0>(ops0, 0, hframe_t - frame_stride, gmask & 1u ? gframe_t - frame_stride : nullptr, g, ty0, tx0,
+                                          &sa[0]);
+    }
+    wl.commit(b0);
+    lds_barrier();
+    double acc_c[2] = {0.0, 0.0};
+    bool failed = false;
+    TileMoments<T, false> mom;
+    for (int grp = 0; grp < pa.ngroups; ++grp) {
+        const long go = -(long)grp * K * frame_stride;     // this group's frame t relative to the top frame
+        const bool last = grp + 1 == pa.ngroups;
+        // every adjoint frame goes to memory (the moments pass reads them); the last one of the sweep may be dL/dh0 itself.  The
+        // frame a group ends on is stored AFTER the tile has been published: the neighbours wait for the granules, nobody for it
+        adj_substeps<T, POLY, K, BX, BY, NT, 0, PRE, false>(b0, b1, hframe_t + go, gframe_t + go, aframe_t + go, frame_stride,
+                                                            gmask, g_h0, g_h0 && last ? K : 0, g, ty0, tx0, P, acc_c, ops0,
+                                                            mom, sa, nullptr, last);
+        if (last) break;
+        const long gn = go - (long)K * frame_stride;
+        gmask = persist_mask<K>(pa, pa.t_top - K * (grp + 1));
+        if constexpr (PRE)
+            adj_load_ops<T, K, BX, BY, NT, 0>(ops0, 0, hframe_t + gn - frame_stride, gmask & 1u ? gframe_t + gn - frame_stride : nullptr, g,
+                                              ty0, tx0, &sa[0]);
+        // (sub-step K - 1 ended with a barrier: buffer 0 is complete)
+        // ---- hand-over: publish my tile, gather my ring ----
+        const unsigned epoch = (unsigned)grp + 1u;
+        gu64* half = outbox + (size_t)(epoch & 1u) * (size_t)ntiles * (2 * OWN);
+        gu64* mine = half + (size_t)tile * (2 * OWN);
+#pragma unroll
+        for (int q = 0; q < NPUB; ++q) {
+            const int i = (int)threadIdx.x + q * NT;
+            if (i < 2 * OWN) {
+                const int sp = i / OWN, e = i - sp * OWN, y = e / BX, x = e - y * BX;
+                const unsigned v = __builtin_bit_cast(unsigned, b0[sp * TL::PLANE + (HW + y) * LXW + HW + x]);
+                __hip_atomic_store(mine + i, ((unsigned long long)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        tile_store<T, K, BX, BY, NT, true>(b0, aframe_t + gn, g, ty0, tx0);       // frame t - K of this group (buffer 0: K even)
+        int gl[NGAT], gs[NGAT];
+        unsigned long long gx[NGAT];
+#pragma unroll
+        for (int q = 0; q < NGAT; ++q) {
+            gl[q] = tab_gl[q * NT + (int)threadIdx.x];
+            gs[q] = tab_gs[q * NT + (int)threadIdx.x];
+            gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (lanes without: granule 0)
+        }
+        const unsigned long long t0 = wall_clock64();
+        const unsigned long long bound = grp == 0 ? pa.first_timeout_ticks : pa.timeout_ticks;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < NGAT; ++q)
+                if (gl[q] >= 0) ok &= (unsigned)(gx[q] >> 32) == epoch;
+            if (__all(ok)) break;
+            if (wall_clock64() - t0 > bound ||
+                __hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { failed = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int q = 0; q < NGAT; ++q)                      // only what has not arrived yet is asked for again
+                if (gl[q] >= 0 && (unsigned)(gx[q] >> 32) != epoch)
+                    gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (failed) {
+            if (threadIdx.x % WAVE == 0) *wg_abort = 1;
+        } else {
+#pragma unroll
+            for (int q = 0; q < NGAT; ++q)
+                if (gl[q] >= 0) b0[gl[q]] = __builtin_bit_cast(T, (unsigned)gx[q]);
+        }
+        lds_barrier();
+        if (*wg_abort) {
+            // ABORT (see pi_adj2d_persist_kernel): the frames of the groups done so far ARE in memory -- they are the same values the
+            // launch-per-group sweep writes -- but this launch reports failure and the host re-runs the whole sweep
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(pa.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_exchange(pa.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && pa.host) {
+                    __hip_atomic_store(pa.host + 1, grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pa.host + 2, tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pa.host + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            return;
+        }
+    }
+    // once per rollout: the two diffusion-coefficient sums of this tile -> its partial row
+    lds_barrier();
+    double* red = reinterpret_cast<double*>(smem_raw);     // state buffers are dead now
+    constexpr int NW = NT / WAVE;
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const double r = wave_sum_to_last(acc_c[s]);
+        if (lane == REDUCE_LANE) red[s * NW + wave] = r;
+    }
+    lds_barrier();
+    if (threadIdx.x < 2) {
+        double sum = 0.0;
+        for (int w = 0; w < NW; ++w) sum += red[(int)threadIdx.x * NW + w];
+        partials[(long)blockIdx.x * np + P_COEF + (int)threadIdx.x] += sum;
     }
 }
 

@@ -720,7 +720,7 @@ def test_persistent_sweep_equals_launch_per_group(shape, T, hip_device):
     import percnn_amd as pa
     from percnn_amd import _lib
     assert _lib.rollout_plan(0, shape, 4)["bwd_persistent"] and not _lib.rollout_plan(0, shape, 4, "tile_persist=0")["bwd_persistent"]
-    assert not _lib.rollout_plan(0, (100, 100), 4)["bwd_persistent"] and not _lib.rollout_plan(0, shape, 8)["bwd_persistent"]
+    assert not _lib.rollout_plan(0, shape, 8)["bwd_persistent"]
     rs = np.random.RandomState(4)
     P = dev_t(random_block(0, 2, np.float32, 21, scale=0.1), hip_device)
     traj = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=hip_device)
@@ -742,6 +742,54 @@ def test_persistent_sweep_equals_launch_per_group(shape, T, hip_device):
     d0, dg = pa.rollout_bwd(traj, g, P)
     torch.cuda.synchronize()
     assert torch.equal(a0, c0) and torch.equal(a0, d0)
+
+
+@pytest.mark.parametrize("shape,T", [((100, 100), 41), ((128, 128), 23), ((64, 96), 17), ((256, 256), 12), ((40, 200), 9), ((72, 64), 13)])
+def test_small_tile_persistent_sweep_equals_launch_per_group(shape, T, hip_device):
+    """Round 4: the 32 x 8-tile regime (split schedule: every adjoint frame stored, moments from one pass afterwards; ragged edge
+    tiles; the reference's own 100^2 among the shapes) as ONE launch of resident workgroups (pi_adj2d_persist_small_kernel):
+    dL/dh0 bit for bit the launch-per-group sweep's and the C oracle's, parameter gradients to the round-off of two double sums;
+    dense dL/dtraj, frame masks, T not a multiple of K; `persist_small=0` is the old path."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    assert _lib.rollout_plan(0, shape, 4)["tile"] == (32, 8, 256)
+    assert _lib.rollout_plan(0, shape, 4)["bwd_persistent"] and not _lib.rollout_plan(0, shape, 4, "persist_small=0")["bwd_persistent"]
+    rs = np.random.RandomState(5)
+    Pn = random_block(0, 2, np.float32, 23, scale=0.1)
+    P = dev_t(Pn, hip_device)
+    h0 = rs.uniform(0, 1, (2,) + shape).astype(np.float32)
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=hip_device)
+    traj[0] = dev_t(h0, hip_device)
+    pa.rollout_fwd_(traj, P)
+    g = torch.randn(traj.shape, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(2)) / traj[0].numel()
+    n0 = _lib.persist_status()["launches"]
+    for mask in (None, [t % 3 != 1 for t in range(T + 1)], [t == T or t % 5 == 0 for t in range(T + 1)]):
+        a0, ag = pa.rollout_bwd(traj, g, P, frame_mask=mask)
+        b0, bg = pa.rollout_bwd(traj, g, P, frame_mask=mask, options={"persist_small": 0})
+        assert torch.equal(a0, b0)
+        assert rel_l2(ag.cpu().numpy(), bg.cpu().numpy()) < 1e-9
+    assert _lib.persist_status()["launches"] == n0 + 3 and _lib.persist_status()["aborts"] == 0
+    if shape[0] * shape[1] <= 128 * 128:
+        g0_ref, pg_ref = o_rollout_bwd(traj.cpu().numpy(), g.cpu().numpy(), Pn)
+        a0, ag = pa.rollout_bwd(traj, g, P)
+        assert np.array_equal(a0.cpu().numpy(), g0_ref) and rel_l2(ag.cpu().numpy(), pg_ref) < 2e-5
+    # the module path on the reference's own grid: gradients through RCNN.forward() + torch.cat
+    if shape == (100, 100):
+        cell = pa.gs2d_cell(8).to(hip_device)
+        for f in cell.filter_list:
+            f.weight.data.mul_(12.0)
+        cell.invalidate_cache()
+        h = dev_t(h0[None], hip_device).requires_grad_(True)
+        outs = {}
+        for name, opt in (("persist", 1), ("per_group", 0)):
+            pa.set_option("persist_small", opt)
+            try:
+                o, _ = pa.RCNN(cell, step=T, effective_step=list(range(T)), init_state=h)()
+                gr = torch.autograd.grad((torch.cat(tuple(o), 0) ** 2).mean(), [h] + [q for q in cell.parameters() if q.requires_grad])
+                outs[name] = torch.cat([x.reshape(-1) for x in gr])
+            finally:
+                pa.set_option("persist_small", 1)
+        assert rel_l2(outs["persist"].cpu().numpy(), outs["per_group"].cpu().numpy()) < 1e-6
 
 
 @pytest.mark.parametrize("shape,tile", [((544, 544), (32, 40, 640)), ((640, 640), (40, 40, 768)), ((560, 600), (40, 40, 768)),
