@@ -242,6 +242,9 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
     fwd_kernel = fwd_names[plan["fwd"]]
     bwd_kernel = bwd_names[plan["bwd"]] + (("<sweep+moments>" if fused else "") if tiled else ("<sweep+moments>" if fused else "<sweep>"))
     persistent = bool(plan.get("bwd_persistent")) and tiled and fused and not opts.get("tile_persist") == "0" and T // K >= 2
+    # the small-tile regime (32 x 8 tiles, split schedule): its sweep is one resident launch too (pi_adj2d_persist_small_kernel)
+    persistent_small = bool(plan.get("bwd_persistent")) and tiled and not fused and not opts.get("tile_persist") == "0" and \
+        str(opts.get("persist_small", "1")) != "0" and T // K >= 2
     if fused:
         sweep_ms, red_ms = bwd_ms, 1e-6
     clock = "HIP events on the launch stream, this run (fwd / bwd phases of every pass; sweep alone via options=skip_wgrad)"
@@ -261,6 +264,10 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
         # (round 4: the split flavour -- halo-independent pyramid under the hand-over -- unless the option says otherwise)
         pname = "pi_adj2d_persist_kernel" if str(opts.get("persist_split", "1")) == "0" else "pi_adj2d_persist_split_kernel"
         kernels[1] = {"kernel": pname + "<sweep+moments, %d groups of %d steps per launch>" % (T // K, K),
+                      "launches_per_pass": 1, "algorithmic_bytes_per_launch": 4 * Cs * npts * (T // K) * K,
+                      "avg_launch_us": sweep_ms * 1e3}
+    if persistent_small:
+        kernels[1] = {"kernel": "pi_adj2d_persist_small_kernel<sweep, %d groups of %d steps per launch>" % (T // K, K),
                       "launches_per_pass": 1, "algorithmic_bytes_per_launch": 4 * Cs * npts * (T // K) * K,
                       "avg_launch_us": sweep_ms * 1e3}
     for k in kernels:
