@@ -1337,13 +1337,14 @@ hipError_t launch_adj_persist(const T* hframe_t, const T* gframe_t, T* aframe_t,
 // ---- small-tile persistent sweep (pi_adj2d_persist_small_kernel): the 32 x 8 / 256-lane regime with the split schedule --------
 // granule outbox of the small-tile persistent sweep (pi_adj2d_persist_small_kernel): two parities x tiles x the 2 x 32 x 8 values
 // a tile publishes; behind the partial rows (every adjoint frame is in use in the split schedule it serves)
-constexpr int SMALL_BY = 8, SMALL_NT = 256, SMALL_OWN = 2 * TILE_B * SMALL_BY;
+// (the 32 x 8 / 256-lane and the 32 x 16 / 320-lane regimes: whatever tile_by_for picks below 32 rows)
+int64_t persist_small_tiles(const Problem& p, int by) { return ((p.n0 + by - 1) / by) * ((p.W + TILE_B - 1) / TILE_B); }
 size_t persist_small_outbox_bytes(const Problem& p, int elem)
 {
     if (p.ndim != 2 || p.hc != 0 || elem != 4 || p.slab) return 0;
-    const int64_t tiles = ((p.n0 + SMALL_BY - 1) / SMALL_BY) * ((p.W + TILE_B - 1) / TILE_B);
-    if (tiles > 256) return 0;
-    return align_up((size_t)2 * (size_t)tiles * SMALL_OWN * sizeof(unsigned long long), 256);
+    const int by = tile_by_for(p);
+    if (by >= TILE_B || persist_small_tiles(p, by) > 256) return 0;
+    return align_up((size_t)2 * (size_t)persist_small_tiles(p, by) * (2 * TILE_B * by) * sizeof(unsigned long long), 256);
 }
 
 template <typename T>
@@ -1352,8 +1353,9 @@ bool persist_small_ok(const Problem& p, const unsigned char* mask, int t_top, in
     if (!p.opt.tile_persist || !p.opt.persist_small || sizeof(T) != 4 || ngroups < 2 || p.hc != 0) return false;
     if (persist_disabled_here()) return false;
     if (mask && t_top >= 4096) return false;
-    if (p.opt.tile_k != 4 || tile_wide_for<T>(p, true) != 0 || tile_by_for(p) != SMALL_BY || tile_fuse_ok<T>(p)) return false;
-    const int64_t tiles = ((p.n0 + SMALL_BY - 1) / SMALL_BY) * ((p.W + TILE_B - 1) / TILE_B);
+    const int by = tile_by_for(p);
+    if (p.opt.tile_k != 4 || p.opt.tile_nt != 512 || tile_wide_for<T>(p, true) != 0 || by >= TILE_B || tile_fuse_ok<T>(p)) return false;
+    const int64_t tiles = persist_small_tiles(p, by);
     const int cus = device_cu_count();
     if (tiles < 2 || cus <= 0 || tiles > cus || tiles > 256) return false;    // one workgroup per CU at most: resident for sure
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1362,12 +1364,12 @@ bool persist_small_ok(const Problem& p, const unsigned char* mask, int t_top, in
 }
 
 // as launch_adj_persist; every adjoint frame of the groups it runs is written
-template <typename T>
-hipError_t launch_adj_persist_small(const T* hframe_t, const T* gframe_t, T* aframe_t, T* g_h0, int t_top, const unsigned char* mask,
+template <typename T, int BY, int NT>
+hipError_t launch_adj_persist_small_t(const T* hframe_t, const T* gframe_t, T* aframe_t, T* g_h0, int t_top, const unsigned char* mask,
                                     int ngroups, double* partials, unsigned long long* outbox, unsigned* sync, const T* P,
                                     const Problem& p, int dev, hipStream_t st)
 {
-    constexpr int K = 4, NT = SMALL_NT, BY = SMALL_BY;
+    constexpr int K = 4;
     using TL = pi::Tile<K, TILE_B, BY>;
     pi::TileGeom g = make_tile_geom(p, BY);
     const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
@@ -1429,6 +1431,16 @@ hipError_t launch_adj_persist_small(const T* hframe_t, const T* gframe_t, T* afr
         return hipErrorLaunchFailure;
     }
     return hipSuccess;
+}
+
+template <typename T>
+hipError_t launch_adj_persist_small(const T* hframe_t, const T* gframe_t, T* aframe_t, T* g_h0, int t_top, const unsigned char* mask,
+                                    int ngroups, double* partials, unsigned long long* outbox, unsigned* sync, const T* P,
+                                    const Problem& p, int dev, hipStream_t st)
+{
+    if (tile_by_for(p) == 16)
+        return launch_adj_persist_small_t<T, 16, 320>(hframe_t, gframe_t, aframe_t, g_h0, t_top, mask, ngroups, partials, outbox, sync, P, p, dev, st);
+    return launch_adj_persist_small_t<T, 8, 256>(hframe_t, gframe_t, aframe_t, g_h0, t_top, mask, ngroups, partials, outbox, sync, P, p, dev, st);
 }
 
 // ---- workspace carving -------------------------------------------------------------------------
