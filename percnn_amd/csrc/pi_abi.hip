@@ -1255,9 +1255,10 @@ hipError_t launch_adj_persist(const T* hframe_t, const T* gframe_t, T* aframe_t,
     pi::TileGeom g = make_tile_geom(p, TILE_B);
     const unsigned grid = (unsigned)((p.n0 / TILE_B) * g.tiles_x);
     (void)sizeof(TL);
-    // state buffers | [20][NT] double moment sums per lane | publish / gather tables (3 + 5 + 5 ints per lane) | abort word
+    // state buffers | [20][NT] double moment sums per lane | publish / gather tables (3 + 5 + 5 ints per lane) and, split sweep,
+    // 6 of strip geometry | abort word
     const size_t lds = pi::tile_state_bytes<T, K, TILE_B, TILE_B>() + (size_t)20 * NT * sizeof(double) +
-                       (size_t)13 * NT * sizeof(int) + 16;
+                       (size_t)(p.opt.persist_split ? pi::PERSIST_SPLIT_TABLE_ROWS : 13) * NT * sizeof(int) + 16;
     auto* k = p.opt.persist_split ? pi::pi_adj2d_persist_split_kernel<T, K, TILE_B, TILE_B, NT>
                                   : pi::pi_adj2d_persist_kernel<T, K, TILE_B, TILE_B, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;

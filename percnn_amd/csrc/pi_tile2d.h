@@ -31,6 +31,9 @@ namespace pi {
 #ifndef PI_FWD_IDLE_MAX
 #define PI_FWD_IDLE_MAX 4
 #endif
+#ifndef PI_PERSIST_GEO
+#define PI_PERSIST_GEO 1
+#endif
 #ifndef PI_PERSIST_LAUNDER
 #define PI_PERSIST_LAUNDER 0
 #endif
@@ -272,9 +275,16 @@ template <typename T> __device__ __forceinline__ V2<T> win_pair(const V2<T> (&W)
 
 // lds_star4 on 2-vectors: ctr/lap[0] = points 0,1 of the strip, [1] = points 2,3; identical operation order
 template <typename T, int LX, int FLIP>
+__device__ __forceinline__ void lds_star4v_at(const T* c, const T* __restrict__ P, V2<T> (&ctr)[2], V2<T> (&lap)[2]);
+template <typename T, int LX, int FLIP>
 __device__ __forceinline__ void lds_star4v(const T* pl, int ly, int lx, const T* __restrict__ P, V2<T> (&ctr)[2], V2<T> (&lap)[2])
 {
-    const T* c = pl + ly * LX + lx;                       // fp32: 16-byte aligned (lds_pad0)
+    lds_star4v_at<T, LX, FLIP>(pl + ly * LX + lx, P, ctr, lap);
+}
+// c = address of the strip's first point (fp32: 16-byte aligned, lds_pad0); cf(i) = the pair {P[i], P[i]}
+template <typename T, int LX, int FLIP, typename CF>
+__device__ __forceinline__ void lds_star4v_cf(const T* c, CF cf, V2<T> (&ctr)[2], V2<T> (&lap)[2])
+{
     V2<T> W[4];
     if constexpr (sizeof(T) == 4) {
         W[0] = ldv2(c - 2);
@@ -286,7 +296,7 @@ __device__ __forceinline__ void lds_star4v(const T* pl, int ly, int lx, const T*
         for (int j = 0; j < 4; ++j) W[j] = ldv2(c - 2 + 2 * j);
     }
     ctr[0] = W[1]; ctr[1] = W[2];
-    const V2<T> c0 = vs(P[P_C0]);
+    const V2<T> c0 = cf(P_C0);
     lap[0] = c0 * ctr[0]; lap[1] = c0 * ctr[1];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -298,17 +308,22 @@ __device__ __forceinline__ void lds_star4v(const T* pl, int ly, int lx, const T*
         } else {
             a = ldv2(c + k * LX); b = ldv2(c + k * LX + 2);
         }
-        const V2<T> w = vs(P[P_TAPS + t]);
+        const V2<T> w = cf(P_TAPS + t);
         lap[0] = vfma(w, a, lap[0]);
         lap[1] = vfma(w, b, lap[1]);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int k = FLIP * (t < 2 ? t - 2 : t - 1);
-        const V2<T> w = vs(P[P_TAPS + 4 + t]);
+        const V2<T> w = cf(P_TAPS + 4 + t);
         lap[0] = vfma(w, win_pair(W, 2 + k), lap[0]);
         lap[1] = vfma(w, win_pair(W, 4 + k), lap[1]);
     }
+}
+template <typename T, int LX, int FLIP>
+__device__ __forceinline__ void lds_star4v_at(const T* c, const T* __restrict__ P, V2<T> (&ctr)[2], V2<T> (&lap)[2])
+{
+    lds_star4v_cf<T, LX, FLIP>(c, [P](int i) { return vs(P[i]); }, ctr, lap);
 }
 
 // pi::poly_r on 2-vectors (same operations in the same order)
@@ -329,6 +344,44 @@ __device__ __forceinline__ void poly_dr_v(const T* __restrict__ c, V2<T> u, V2<T
     ru = vfma(u, vfma(u, vs(T(3) * c[6]), A2x2), A1);
     const V2<T> B0 = vfma(v, vfma(v, vs(T(3) * c[9]), vs(T(2) * c[5])), vs(c[2]));
     const V2<T> B1 = vfma(v, vs(T(2) * c[8]), vs(c[4]));
+    rv = vfma(u, vfma(u, vs(c[7]), B1), B0);
+}
+
+// The Jacobian's coefficient multiples as ready pairs held in vector registers (persistent split sweep).  gfx950 has no scalar
+// float multiply: 2 c / 3 c are VALU products of a uniform value, and every use of one in a packed FMA needs the pair {x, x}
+// built by a v_mov -- per pass, in a loop bound by instruction issue.  Entry j of species s: 0 2c7, 1 2c3, 2 3c6, 3 3c9, 4 2c5,
+// 5 2c8, 6 c4; PI_JAC_MASK says which are held (the others are formed as before; 0x3F measured best of six masks,
+// profiles/r04_persist_issue_trim.txt).  Same single multiplication: bit-identical.
+#ifndef PI_JAC_MASK
+#define PI_JAC_MASK 0x3F
+#endif
+template <typename T> struct JacPairs { V2<T> m[2][7]; };
+template <typename T>
+__device__ __forceinline__ void jac_pairs_load(JacPairs<T>& jp, const T* __restrict__ P)
+{
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const T* c = P + P_W + 10 * s;
+        const T x[7] = {T(2) * c[7], T(2) * c[3], T(3) * c[6], T(3) * c[9], T(2) * c[5], T(2) * c[8], c[4]};
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            jp.m[s][j] = vs(x[j]);
+            if ((PI_JAC_MASK >> j) & 1) asm volatile("" : "+v"(jp.m[s][j]));        // a register pair from here on, not a recipe
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void poly_dr_v_j(const T* __restrict__ c, const V2<T> (&j)[7], V2<T> u, V2<T> v, V2<T>& ru, V2<T>& rv)
+{
+    constexpr int MSK = PI_JAC_MASK;
+    const V2<T> k0 = (MSK & 1) ? j[0] : vs(T(2) * c[7]), k1 = (MSK & 2) ? j[1] : vs(T(2) * c[3]), k2 = (MSK & 4) ? j[2] : vs(T(3) * c[6]);
+    const V2<T> k3 = (MSK & 8) ? j[3] : vs(T(3) * c[9]), k4 = (MSK & 16) ? j[4] : vs(T(2) * c[5]), k5 = (MSK & 32) ? j[5] : vs(T(2) * c[8]);
+    const V2<T> k6 = (MSK & 64) ? j[6] : vs(c[4]);
+    const V2<T> A1 = vfma(v, vfma(v, vs(c[8]), k6), vs(c[1]));
+    const V2<T> A2x2 = vfma(v, k0, k1);
+    ru = vfma(u, vfma(u, k2, A2x2), A1);
+    const V2<T> B0 = vfma(v, vfma(v, k3, k4), vs(c[2]));
+    const V2<T> B1 = vfma(v, k5, k6);
     rv = vfma(u, vfma(u, vs(c[7]), B1), B0);
 }
 
@@ -738,18 +791,24 @@ __device__ __forceinline__ void mom_add1(double& a, V2<double> g) { a += g.x + g
 __device__ __forceinline__ float mom_total(V2<float> a) { return a.x + a.y; }
 __device__ __forceinline__ double mom_total(double a) { return a; }
 
-template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE, bool MOM, int PART = PART_FULL, int TID0 = 0>
+// GEO: the lane's strip geometry of this pass -- LDS offset, liveness, ownership of its four points -- comes packed in one word
+// of an LDS table built once per launch (persistent split sweep: persist_geo_word) instead of being derived from the lane id in
+// every pass of every group: the derivation (strip map with its divisions, clamps, four ownership compares and selects) was
+// ~60 of the ~300 VALU instructions of an issue-bound pass, and hoisting it into registers for all passes at once spills.
+template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE, bool MOM, int PART = PART_FULL, int TID0 = 0,
+          bool GEO = false>
 __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict__ hfr, const T* __restrict__ gfr,
                                             const TileGeom& g, int ty0, int tx0, const T* __restrict__ P,
                                             double (&acc_c)[2], const StripOps<T>& pre, TileMoments<T, MOM>& mom,
-                                            double* lacc = nullptr)
+                                            double* lacc = nullptr, const unsigned* geo = nullptr,
+                                            const JacPairs<T>* jp = nullptr)
 {
+    auto cf = [P](int i) -> V2<T> { return vs(P[i]); };
     using TL = Tile<K, BX, BY>;
     using SM = StripMap<K, BX, BY, M, PART>;
     constexpr int RN4 = SM::N, O = 2 * (M + 1);
     constexpr int PT = (RN4 + NT - 1) / NT;
     static_assert(!PRE || PT == 1, "prefetched operands cover one strip per lane");
-    const T dt = P[P_DT];
     int tid = (int)threadIdx.x;
 #if PI_PERSIST_OPAQUE_TID
     // split persistent sweep: eight passes inlined into one loop.  Everything derived from the lane's strip position (LDS
@@ -759,13 +818,30 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
 #endif
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
-        int idx = tid - TID0 + q * NT;                     // (TID0 != 0: the caller has sent the waves below TID0 elsewhere)
-        const bool live = idx < RN4;
-        if (!live) idx = RN4 - 1;
-        int ry, rc;
-        SM::locate(idx, ry, rc);
-        const int ly = ry + O, lx = 4 * rc + O;
-        const int off = ly * TL::LX + lx;
+        int off;
+        bool live;
+        unsigned ownbits = 0;                              // bit i: point i of the strip is an owned, in-grid point
+        if constexpr (GEO) {
+            static_assert(PT == 1, "geometry words: one strip per lane");
+            const unsigned w = geo[(int)threadIdx.x];
+            off = (int)(w & 0xFFFFu);
+            live = (w >> 16) & 1u;
+            ownbits = (w >> 17) & 0xFu;
+        } else {
+            int idx = tid - TID0 + q * NT;                 // (TID0 != 0: the caller has sent the waves below TID0 elsewhere)
+            live = idx < RN4;
+            if (!live) idx = RN4 - 1;
+            int ry, rc;
+            SM::locate(idx, ry, rc);
+            const int ly = ry + O, lx = 4 * rc + O;
+            off = ly * TL::LX + lx;
+            // owned, in-grid points: one unsigned compare per coordinate against the tile's owned extent (edge tiles of a
+            // ragged grid own less) -- the sub-step is issue-bound, the three-compare form cost 16 VALU per strip
+            const unsigned own_ny = (unsigned)min(BY, g.H - ty0), own_nx = (unsigned)min(BX, g.W - tx0);
+            const bool rowin = live && (unsigned)(ly - 2 * K) < own_ny;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ownbits |= (rowin && (unsigned)(lx + i - 2 * K) < own_nx) ? (1u << i) : 0u;
+        }
         StripOps<T> lo;
         if constexpr (!PRE) adj_load_ops<T, K, BX, BY, NT, M>(lo, q, hfr, gfr, g, ty0, tx0);
         // whole waves beyond the region skip the strip (see fwd_substep); their operand loads above stay unconditional --
@@ -778,13 +854,9 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
         const T (&jv)[4] = op.jv;
         const V2<T> U[2] = {V2<T>{u[0], u[1]}, V2<T>{u[2], u[3]}}, V[2] = {V2<T>{v[0], v[1]}, V2<T>{v[2], v[3]}};
         V2<T> gc[2][2], dl[2][2];                          // [species][half of the strip]
-        lds_star4v<T, TL::LX, -1>(cur, ly, lx, P, gc[0], dl[0]);
-        lds_star4v<T, TL::LX, -1>(cur + TL::PLANE, ly, lx, P, gc[1], dl[1]);
-        // owned, in-grid points: one unsigned compare per coordinate against the tile's owned extent (edge tiles of a
-        // ragged grid own less) -- the sub-step is issue-bound, the three-compare form cost 16 VALU per strip
-        const unsigned own_ny = (unsigned)min(BY, g.H - ty0), own_nx = (unsigned)min(BX, g.W - tx0);
-        const bool rowin = live && (unsigned)(ly - 2 * K) < own_ny;
-        const V2<T> dtv = vs(dt);
+        lds_star4v_cf<T, TL::LX, -1>(cur + off, cf, gc[0], dl[0]);
+        lds_star4v_cf<T, TL::LX, -1>(cur + TL::PLANE + off, cf, gc[1], dl[1]);
+        const V2<T> dtv = cf(P_DT);
         V2<T> own[2];                                      // 1 for owned, in-grid points, else 0 (MOM only)
         V2<T> cs[2] = {vs(T(0)), vs(T(0))};                 // this strip's owned part of sum_x dt*LapT(a)*h, per species
 #pragma unroll
@@ -793,9 +865,7 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
             dl[1][h] *= dtv;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int i = 2 * h + e;
-                const bool mine = rowin && (unsigned)(lx + i - 2 * K) < own_nx;
-                own[h][e] = mine ? T(1) : T(0);            // owned, in-grid points only
+                own[h][e] = ((ownbits >> (2 * h + e)) & 1u) ? T(1) : T(0);        // owned, in-grid points only
             }
             // the four products of a strip are added in the compute type, the strip sum goes to the fp64 accumulator (was:
             // every product converted and added in fp64 -- 16 half-rate instructions per strip in an issue-bound loop; the
@@ -815,7 +885,8 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
                 for (int h = 0; h < 2; ++h) {
                     const V2<T> gr = gc[s][h] * dtv;
                     V2<T> ru, rv;
-                    poly_dr_v(c, U[h], V[h], ru, rv);
+                    if constexpr (GEO && PI_JAC_MASK != 0) poly_dr_v_j(c, jp->m[s], U[h], V[h], ru, rv);
+                    else poly_dr_v(c, U[h], V[h], ru, rv);
                     du[h] = vfma(gr, ru, du[h]);
                     dv[h] = vfma(gr, rv, dv[h]);
                     if constexpr (MOM && sizeof(T) == 4) {
@@ -855,7 +926,7 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
                 }
             }
         }
-        const V2<T> cu = vs(P[P_COEF + 0]), cv = vs(P[P_COEF + 1]);
+        const V2<T> cu = cf(P_COEF + 0), cv = cf(P_COEF + 1);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const V2<T> tu = cu * dl[0][h] + du[h];
@@ -1588,6 +1659,9 @@ __device__ __forceinline__ void persist_load_ops(StripOps<T>& o, const T* __rest
     o.jv[0] = c2.v[0]; o.jv[1] = c2.v[1]; o.jv[2] = d2.v[0]; o.jv[3] = d2.v[1];
 }
 
+// int rows of NT the split sweep keeps in LDS behind the moments: 13 of hand-over tables + 6 of strip geometry (+ the abort word)
+constexpr int PERSIST_SPLIT_TABLE_ROWS = 19;
+
 // The six passes of a group: which sub-step / part the waves below SPLIT work on (M1, PART1; strips indexed from lane 0) and
 // which the waves from SPLIT on (M2, PART2; strips indexed from lane SPLIT); SPLIT == NT: one part only.
 template <int PASS> struct PersistPass;
@@ -1622,28 +1696,66 @@ __device__ __forceinline__ StripOff persist_pass_off(const TileGeom& g, int ty0,
     return so;
 }
 
+// the geometry word of this lane for one part of a pass (adj_substep<GEO>): bits 0-15 LDS offset of its strip inside a species
+// plane, 16 live, 17-20 ownership of its four points.  Same strip map, clamps and compares as adj_substep's own derivation.
+template <int K, int BX, int BY, int NT, int M, int PART, int TID0>
+__device__ __forceinline__ unsigned persist_geo_word(const TileGeom& g, int ty0, int tx0)
+{
+    using TL = Tile<K, BX, BY>;
+    using SM = StripMap<K, BX, BY, M, PART>;
+    constexpr int RN4 = SM::N, O = 2 * (M + 1);
+    int idx = (int)threadIdx.x - TID0;
+    const bool live = idx >= 0 && idx < RN4;
+    if (idx >= RN4) idx = RN4 - 1;
+    if (idx < 0) idx = 0;
+    int ry, rc;
+    SM::locate(idx, ry, rc);
+    const int ly = ry + O, lx = 4 * rc + O;
+    const unsigned own_ny = (unsigned)min(BY, g.H - ty0), own_nx = (unsigned)min(BX, g.W - tx0);
+    const bool rowin = live && (unsigned)(ly - 2 * K) < own_ny;
+    unsigned w = (unsigned)(ly * TL::LX + lx) | (live ? 1u << 16 : 0u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w |= (rowin && (unsigned)(lx + i - 2 * K) < own_nx) ? (1u << (17 + i)) : 0u;
+    return w;
+}
+// ... of pass PASS for this lane (lanes from SPLIT on: the second part)
+template <int K, int BX, int BY, int NT, int PASS>
+__device__ __forceinline__ unsigned persist_pass_geo(const TileGeom& g, int ty0, int tx0)
+{
+    using PP = PersistPass<PASS>;
+    if constexpr (PP::SPLIT >= NT) {
+        return persist_geo_word<K, BX, BY, NT, PP::M1, PP::P1, 0>(g, ty0, tx0);
+    } else {
+        const unsigned lo = persist_geo_word<K, BX, BY, NT, PP::M1, PP::P1, 0>(g, ty0, tx0);
+        const unsigned hi = persist_geo_word<K, BX, BY, NT, PP::M2, PP::P2, PP::SPLIT>(g, ty0, tx0);
+        return (int)threadIdx.x >= PP::SPLIT ? hi : lo;
+    }
+}
+
 // one pass: request the NEXT pass's pointwise operands (frames hn / gn, chosen by the caller for this wave), compute, barrier
 template <typename T, int K, int BX, int BY, int NT, int PASS>
 __device__ __forceinline__ void persist_pass(T* b0, T* b1, const T* const (&hf)[K], const T* const (&gf)[K],
                                              const T* __restrict__ hn, const T* __restrict__ gn, const StripOff& so_next,
                                              const TileGeom& g, int ty0, int tx0, const T* __restrict__ P, double (&acc_c)[2],
-                                             StripOps<T>& ops, TileMoments<T, true>& mom, bool upper)
+                                             StripOps<T>& ops, TileMoments<T, true>& mom, bool upper, const unsigned* geo,
+                                             const JacPairs<T>& jp)
 {
     using PP = PersistPass<PASS>;
     StripOps<T> ahead;
     persist_load_ops<T>(ahead, hn, gn, g, so_next);
+    constexpr bool GEO = PI_PERSIST_GEO != 0;
     if constexpr (PP::SPLIT >= NT) {
         constexpr int M = PP::M1;
-        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P1, 0>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M], g, ty0, tx0, P,
-                                                                      acc_c, ops, mom, nullptr);
+        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P1, 0, GEO>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M], g, ty0, tx0,
+                                                                           P, acc_c, ops, mom, nullptr, geo, &jp);
     } else if (!upper) {                                   // wave-uniform
         constexpr int M = PP::M1;
-        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P1, 0>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M], g, ty0, tx0, P,
-                                                                      acc_c, ops, mom, nullptr);
+        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P1, 0, GEO>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M], g, ty0, tx0,
+                                                                           P, acc_c, ops, mom, nullptr, geo, &jp);
     } else {
         constexpr int M = PP::M2;
-        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P2, PP::SPLIT>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M], g, ty0,
-                                                                              tx0, P, acc_c, ops, mom, nullptr);
+        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P2, PP::SPLIT, GEO>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M], g,
+                                                                                   ty0, tx0, P, acc_c, ops, mom, nullptr, geo, &jp);
     }
 #if PI_PIN_MOMENTS
 #pragma unroll
@@ -1686,12 +1798,19 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
     int* tab_pub = reinterpret_cast<int*>(lacc + 20 * NT);                  // [NPUB][NT]: LDS position of a border value
     int* tab_gl = tab_pub + NPUB * NT;                                      // [NGAT][NT]: LDS position of a halo value
     int* tab_gs = tab_gl + NGAT * NT;                                       // [NGAT][NT]: granule index inside a parity half
-    int* wg_abort = tab_pub + 13 * NT;
+    unsigned* tab_geo = reinterpret_cast<unsigned*>(tab_pub + 13 * NT);     // [6][NT]: the lane's strip in each pass (persist_geo_word)
+    int* wg_abort = tab_pub + PERSIST_SPLIT_TABLE_ROWS * NT;
     if (threadIdx.x == 0) {                                                 // residency roll call (see pi_adj2d_persist_kernel)
         *wg_abort = 0;
         const unsigned n = __hip_atomic_fetch_add(pa.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         if (n == (unsigned)ntiles && pa.host) __hip_atomic_store(pa.host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    tab_geo[0 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 0>(g, ty0, tx0);
+    tab_geo[1 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 1>(g, ty0, tx0);
+    tab_geo[2 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 2>(g, ty0, tx0);
+    tab_geo[3 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 3>(g, ty0, tx0);
+    tab_geo[4 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 4>(g, ty0, tx0);
+    tab_geo[5 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 5>(g, ty0, tx0);
 #pragma unroll
     for (int m = 0; m < 20; ++m) lacc[m * NT + (int)threadIdx.x] = 0.0;
 #pragma unroll
@@ -1749,6 +1868,8 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int m = 0; m < 10; ++m) mom.a[s][m] = V2<T>{T(0), T(0)};
+    JacPairs<T> jp;
+    jac_pairs_load<T>(jp, P);
     for (int grp = 0; grp < pa.ngroups; ++grp) {
         const bool last = grp + 1 == pa.ngroups;
         const T* hb = hframe_t - (long)grp * K * frame_stride;            // this group's frame t
@@ -1763,7 +1884,7 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
         }
         PI_PSTAMP(0);
         // ---- P0: the top of the pyramid -- needs my own tile only; the neighbours' granules are on their way ----
-        persist_pass<T, K, BX, BY, NT, 0>(b0, b1, hf, gf, hf[1], gf[1], so1, g, ty0, tx0, P, acc_c, ops, mom, false);
+        persist_pass<T, K, BX, BY, NT, 0>(b0, b1, hf, gf, hf[1], gf[1], so1, g, ty0, tx0, P, acc_c, ops, mom, false, tab_geo + 0 * NT, jp);
         PI_PSTAMP(1);
         // ---- request the halo ring my neighbours published at the end of their previous group: the loads travel under P1.
         // (Requested before P0 they come back stale and a second round trip is exposed; requested by the four waves that idle in
@@ -1782,7 +1903,7 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
         }
         // ---- P1 ----
         persist_pass<T, K, BX, BY, NT, 1>(b0, b1, hf, gf, up2 ? hf[0] : hf[2], up2 ? gf[0] : gf[2], so2, g, ty0, tx0, P, acc_c, ops, mom,
-                                          false);
+                                          false, tab_geo + 1 * NT, jp);
         PI_PSTAMP(2);
         if (grp > 0) {
             int gl[NGAT];
@@ -1829,17 +1950,17 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
         }
         PI_PSTAMP(3);
         // ---- P2 .. P5: the rest of the pyramid next to the ring passes ----
-        persist_pass<T, K, BX, BY, NT, 2>(b0, b1, hf, gf, hf[1], gf[1], so3, g, ty0, tx0, P, acc_c, ops, mom, up2);
+        persist_pass<T, K, BX, BY, NT, 2>(b0, b1, hf, gf, hf[1], gf[1], so3, g, ty0, tx0, P, acc_c, ops, mom, up2, tab_geo + 2 * NT, jp);
         PI_PSTAMP(4);
-        persist_pass<T, K, BX, BY, NT, 3>(b0, b1, hf, gf, hf[2], gf[2], so4, g, ty0, tx0, P, acc_c, ops, mom, false);
+        persist_pass<T, K, BX, BY, NT, 3>(b0, b1, hf, gf, hf[2], gf[2], so4, g, ty0, tx0, P, acc_c, ops, mom, false, tab_geo + 3 * NT, jp);
         PI_PSTAMP(5);
-        persist_pass<T, K, BX, BY, NT, 4>(b0, b1, hf, gf, hf[3], gf[3], so5, g, ty0, tx0, P, acc_c, ops, mom, false);
+        persist_pass<T, K, BX, BY, NT, 4>(b0, b1, hf, gf, hf[3], gf[3], so5, g, ty0, tx0, P, acc_c, ops, mom, false, tab_geo + 4 * NT, jp);
         PI_PSTAMP(6);
         // (the operands the last pass requests belong to the next group's P0: frame t - K - 1)
         const unsigned gmask_next = last ? gmask : persist_mask<K>(pa, pa.t_top - K * (grp + 1));
         const T* hn = last ? hf[3] : hb - (long)(K + 1) * frame_stride;
         const T* gn = last ? gf[3] : (gmask_next & 1u ? gb - (long)(K + 1) * frame_stride : (const T*)nullptr);
-        persist_pass<T, K, BX, BY, NT, 5>(b0, b1, hf, gf, hn, gn, last ? so5 : so0, g, ty0, tx0, P, acc_c, ops, mom, up5);
+        persist_pass<T, K, BX, BY, NT, 5>(b0, b1, hf, gf, hn, gn, last ? so5 : so0, g, ty0, tx0, P, acc_c, ops, mom, up5, tab_geo + 5 * NT, jp);
         PI_PSTAMP(7);
         // the float32 2-vector moment sums are folded into the lane's double sums in LDS every fourth group (see the unsplit kernel)
         if ((grp & 3) == 3 || last) {

@@ -100,7 +100,7 @@ int main(int argc, char** argv)
         }
     };
     // ---- persistent flavours ----
-    const size_t lds_p = pi::tile_state_bytes<float, K, B, B>() + (size_t)20 * NT * sizeof(double) + (size_t)13 * NT * sizeof(int) + 16;
+    const size_t lds_p = pi::tile_state_bytes<float, K, B, B>() + (size_t)20 * NT * sizeof(double) + (size_t)pi::PERSIST_SPLIT_TABLE_ROWS * NT * sizeof(int) + 16;
     auto* kp0 = pi::pi_adj2d_persist_kernel<float, K, B, B, NT>;
     auto* kp1 = pi::pi_adj2d_persist_split_kernel<float, K, B, B, NT>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kp0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
