@@ -353,9 +353,14 @@ __device__ __forceinline__ void poly_dr_v(const T* __restrict__ c, V2<T> u, V2<T
 // 5 2c8, 6 c4; PI_JAC_MASK says which are held (the others are formed as before; 0x3F measured best of six masks,
 // profiles/r04_persist_issue_trim.txt).  Same single multiplication: bit-identical.
 #ifndef PI_JAC_MASK
-#define PI_JAC_MASK 0x3F
+#define PI_JAC_MASK 0x7F
 #endif
-template <typename T> struct JacPairs { V2<T> m[2][7]; };
+#ifndef PI_STEN_MASK
+#define PI_STEN_MASK 0xFFF
+#endif
+// ... and `st`: the pairs of dt (0), the diffusion coefficients (1, 2), c0 (3) and the eight taps (4..11) -- P[0..11] in P's own
+// order; PI_STEN_MASK says which are held
+template <typename T> struct JacPairs { V2<T> m[2][7]; V2<T> st[12]; };
 template <typename T>
 __device__ __forceinline__ void jac_pairs_load(JacPairs<T>& jp, const T* __restrict__ P)
 {
@@ -368,6 +373,11 @@ __device__ __forceinline__ void jac_pairs_load(JacPairs<T>& jp, const T* __restr
             jp.m[s][j] = vs(x[j]);
             if ((PI_JAC_MASK >> j) & 1) asm volatile("" : "+v"(jp.m[s][j]));        // a register pair from here on, not a recipe
         }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        jp.st[i] = vs(P[i]);
+        if ((PI_STEN_MASK >> i) & 1) asm volatile("" : "+v"(jp.st[i]));
     }
 }
 template <typename T>
@@ -803,7 +813,11 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
                                             double* lacc = nullptr, const unsigned* geo = nullptr,
                                             const JacPairs<T>* jp = nullptr)
 {
-    auto cf = [P](int i) -> V2<T> { return vs(P[i]); };
+    static_assert(P_DT == 0 && P_COEF == 1 && P_C0 == 3 && P_TAPS == 4, "JacPairs::st follows P's order");
+    auto cf = [P, jp](int i) -> V2<T> {
+        if constexpr (GEO && PI_STEN_MASK != 0) { if ((PI_STEN_MASK >> i) & 1) return jp->st[i]; }
+        return vs(P[i]);
+    };
     using TL = Tile<K, BX, BY>;
     using SM = StripMap<K, BX, BY, M, PART>;
     constexpr int RN4 = SM::N, O = 2 * (M + 1);
@@ -846,7 +860,12 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
         if constexpr (!PRE) adj_load_ops<T, K, BX, BY, NT, M>(lo, q, hfr, gfr, g, ty0, tx0);
         // whole waves beyond the region skip the strip (see fwd_substep); their operand loads above stay unconditional --
         // loads inside a branch would cost the compiler its count of outstanding requests
-        if (((int)threadIdx.x & ~(WAVE - 1)) - TID0 + q * NT >= RN4) continue;
+        if constexpr (GEO) {
+            // (from the geometry word too: the two parts of a mixed pass share this one body, see persist_pass)
+            if (__builtin_amdgcn_ballot_w64(live) == 0ull) continue;
+        } else {
+            if (((int)threadIdx.x & ~(WAVE - 1)) - TID0 + q * NT >= RN4) continue;
+        }
         const StripOps<T>& op = PRE ? pre : lo;
         const T (&u)[4] = op.u;
         const T (&v)[4] = op.v;
@@ -1649,10 +1668,11 @@ __device__ __forceinline__ void persist_load_ops(StripOps<T>& o, const T* __rest
     const char* hv = reinterpret_cast<const char*>(hfr + g.ss);
     const char* ju = reinterpret_cast<const char*>(gsrc);
     const char* jv = reinterpret_cast<const char*>(gsrc + g.ss);
-    const Pack<T, 2> a = *reinterpret_cast<const Pack<T, 2>*>(hu + so.o0), b = *reinterpret_cast<const Pack<T, 2>*>(hu + so.o1);
-    const Pack<T, 2> c = *reinterpret_cast<const Pack<T, 2>*>(hv + so.o0), d = *reinterpret_cast<const Pack<T, 2>*>(hv + so.o1);
-    const Pack<T, 2> a2 = *reinterpret_cast<const Pack<T, 2>*>(ju + so.o0), b2 = *reinterpret_cast<const Pack<T, 2>*>(ju + so.o1);
-    const Pack<T, 2> c2 = *reinterpret_cast<const Pack<T, 2>*>(jv + so.o0), d2 = *reinterpret_cast<const Pack<T, 2>*>(jv + so.o1);
+    const unsigned o0 = so.o0, o1 = so.o1;
+    const Pack<T, 2> a = *reinterpret_cast<const Pack<T, 2>*>(hu + o0), b = *reinterpret_cast<const Pack<T, 2>*>(hu + o1);
+    const Pack<T, 2> c = *reinterpret_cast<const Pack<T, 2>*>(hv + o0), d = *reinterpret_cast<const Pack<T, 2>*>(hv + o1);
+    const Pack<T, 2> a2 = *reinterpret_cast<const Pack<T, 2>*>(ju + o0), b2 = *reinterpret_cast<const Pack<T, 2>*>(ju + o1);
+    const Pack<T, 2> c2 = *reinterpret_cast<const Pack<T, 2>*>(jv + o0), d2 = *reinterpret_cast<const Pack<T, 2>*>(jv + o1);
     o.u[0] = a.v[0]; o.u[1] = a.v[1]; o.u[2] = b.v[0]; o.u[3] = b.v[1];
     o.v[0] = c.v[0]; o.v[1] = c.v[1]; o.v[2] = d.v[0]; o.v[3] = d.v[1];
     o.ju[0] = a2.v[0]; o.ju[1] = a2.v[1]; o.ju[2] = b2.v[0]; o.ju[3] = b2.v[1];
@@ -1732,21 +1752,26 @@ __device__ __forceinline__ unsigned persist_pass_geo(const TileGeom& g, int ty0,
     }
 }
 
-// one pass: request the NEXT pass's pointwise operands (frames hn / gn, chosen by the caller for this wave), compute, barrier
+// one pass: request the NEXT pass's pointwise operands (frames hn / gn, chosen by the caller for this wave) into `ahead`, compute
+// with `ops`, barrier.  The caller alternates two operand sets (six passes per group: the roles repeat), nothing is copied.
 template <typename T, int K, int BX, int BY, int NT, int PASS>
 __device__ __forceinline__ void persist_pass(T* b0, T* b1, const T* const (&hf)[K], const T* const (&gf)[K],
                                              const T* __restrict__ hn, const T* __restrict__ gn, const StripOff& so_next,
                                              const TileGeom& g, int ty0, int tx0, const T* __restrict__ P, double (&acc_c)[2],
-                                             StripOps<T>& ops, TileMoments<T, true>& mom, bool upper, const unsigned* geo,
-                                             const JacPairs<T>& jp)
+                                             const StripOps<T>& ops, StripOps<T>& ahead, TileMoments<T, true>& mom, bool upper,
+                                             const unsigned* geo, const JacPairs<T>& jp)
 {
     using PP = PersistPass<PASS>;
-    StripOps<T> ahead;
     persist_load_ops<T>(ahead, hn, gn, g, so_next);
     constexpr bool GEO = PI_PERSIST_GEO != 0;
-    if constexpr (PP::SPLIT >= NT) {
+    if constexpr (PP::SPLIT >= NT || GEO) {
+        // With the geometry in a table the sub-step's body no longer depends on WHICH strips a wave works on: the two parts of a
+        // mixed pass (same parity of M: same buffers) run the same instructions with their own table words and their own
+        // injection frame -- one body instead of two behind a branch (the moments' 20 register pairs were copied at every merge).
+        static_assert(PP::SPLIT >= NT || ((PP::M1 ^ PP::M2) & 1) == 0, "both parts read the same buffer");
         constexpr int M = PP::M1;
-        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P1, 0, GEO>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M], g, ty0, tx0,
+        const T* gfr = (PP::SPLIT < NT && upper) ? gf[PP::M2] : gf[M];
+        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P1, 0, GEO>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gfr, g, ty0, tx0,
                                                                            P, acc_c, ops, mom, nullptr, geo, &jp);
     } else if (!upper) {                                   // wave-uniform
         constexpr int M = PP::M1;
@@ -1764,7 +1789,6 @@ __device__ __forceinline__ void persist_pass(T* b0, T* b1, const T* const (&hf)[
         for (int m = 0; m < 10; ++m) asm volatile("" : "+v"(mom.a[s][m]));
 #endif
     lds_barrier();
-    ops = ahead;
 }
 
 template <typename T, int K, int BX, int BY, int NT>
@@ -1858,7 +1882,7 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
     const StripOff so4 = persist_pass_off<T, K, BX, BY, NT, 4>(g, ty0, tx0, false);
     const StripOff so5 = persist_pass_off<T, K, BX, BY, NT, 5>(g, ty0, tx0, up5);
     unsigned gmask = persist_mask<K>(pa, pa.t_top);
-    StripOps<T> ops;
+    StripOps<T> ops, ops2;                                  // operands of the pass at hand / of the next one, alternating
     persist_load_ops<T>(ops, hframe_t - frame_stride, gmask & 1u ? gframe_t - frame_stride : nullptr, g, so0);
     wl.commit(b0);
     lds_barrier();
@@ -1884,7 +1908,7 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
         }
         PI_PSTAMP(0);
         // ---- P0: the top of the pyramid -- needs my own tile only; the neighbours' granules are on their way ----
-        persist_pass<T, K, BX, BY, NT, 0>(b0, b1, hf, gf, hf[1], gf[1], so1, g, ty0, tx0, P, acc_c, ops, mom, false, tab_geo + 0 * NT, jp);
+        persist_pass<T, K, BX, BY, NT, 0>(b0, b1, hf, gf, hf[1], gf[1], so1, g, ty0, tx0, P, acc_c, ops, ops2, mom, false, tab_geo + 0 * NT, jp);
         PI_PSTAMP(1);
         // ---- request the halo ring my neighbours published at the end of their previous group: the loads travel under P1.
         // (Requested before P0 they come back stale and a second round trip is exposed; requested by the four waves that idle in
@@ -1902,7 +1926,7 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
             }
         }
         // ---- P1 ----
-        persist_pass<T, K, BX, BY, NT, 1>(b0, b1, hf, gf, up2 ? hf[0] : hf[2], up2 ? gf[0] : gf[2], so2, g, ty0, tx0, P, acc_c, ops, mom,
+        persist_pass<T, K, BX, BY, NT, 1>(b0, b1, hf, gf, up2 ? hf[0] : hf[2], up2 ? gf[0] : gf[2], so2, g, ty0, tx0, P, acc_c, ops2, ops, mom,
                                           false, tab_geo + 1 * NT, jp);
         PI_PSTAMP(2);
         if (grp > 0) {
@@ -1950,17 +1974,17 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
         }
         PI_PSTAMP(3);
         // ---- P2 .. P5: the rest of the pyramid next to the ring passes ----
-        persist_pass<T, K, BX, BY, NT, 2>(b0, b1, hf, gf, hf[1], gf[1], so3, g, ty0, tx0, P, acc_c, ops, mom, up2, tab_geo + 2 * NT, jp);
+        persist_pass<T, K, BX, BY, NT, 2>(b0, b1, hf, gf, hf[1], gf[1], so3, g, ty0, tx0, P, acc_c, ops, ops2, mom, up2, tab_geo + 2 * NT, jp);
         PI_PSTAMP(4);
-        persist_pass<T, K, BX, BY, NT, 3>(b0, b1, hf, gf, hf[2], gf[2], so4, g, ty0, tx0, P, acc_c, ops, mom, false, tab_geo + 3 * NT, jp);
+        persist_pass<T, K, BX, BY, NT, 3>(b0, b1, hf, gf, hf[2], gf[2], so4, g, ty0, tx0, P, acc_c, ops2, ops, mom, false, tab_geo + 3 * NT, jp);
         PI_PSTAMP(5);
-        persist_pass<T, K, BX, BY, NT, 4>(b0, b1, hf, gf, hf[3], gf[3], so5, g, ty0, tx0, P, acc_c, ops, mom, false, tab_geo + 4 * NT, jp);
+        persist_pass<T, K, BX, BY, NT, 4>(b0, b1, hf, gf, hf[3], gf[3], so5, g, ty0, tx0, P, acc_c, ops, ops2, mom, false, tab_geo + 4 * NT, jp);
         PI_PSTAMP(6);
         // (the operands the last pass requests belong to the next group's P0: frame t - K - 1)
         const unsigned gmask_next = last ? gmask : persist_mask<K>(pa, pa.t_top - K * (grp + 1));
         const T* hn = last ? hf[3] : hb - (long)(K + 1) * frame_stride;
         const T* gn = last ? gf[3] : (gmask_next & 1u ? gb - (long)(K + 1) * frame_stride : (const T*)nullptr);
-        persist_pass<T, K, BX, BY, NT, 5>(b0, b1, hf, gf, hn, gn, last ? so5 : so0, g, ty0, tx0, P, acc_c, ops, mom, up5, tab_geo + 5 * NT, jp);
+        persist_pass<T, K, BX, BY, NT, 5>(b0, b1, hf, gf, hn, gn, last ? so5 : so0, g, ty0, tx0, P, acc_c, ops2, ops, mom, up5, tab_geo + 5 * NT, jp);
         PI_PSTAMP(7);
         // the float32 2-vector moment sums are folded into the lane's double sums in LDS every fourth group (see the unsplit kernel)
         if ((grp & 3) == 3 || last) {
