@@ -1375,7 +1375,8 @@ hipError_t launch_adj_persist_small_t(const T* hframe_t, const T* gframe_t, T* a
     pi::TileGeom g = make_tile_geom(p, BY);
     const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
     constexpr int RINGH = TL::LX * TL::LY - TILE_B * BY, NGAT = (2 * RINGH + NT - 1) / NT;
-    const size_t lds = pi::tile_state_bytes<T, K, TILE_B, BY>() + (size_t)2 * NGAT * NT * sizeof(int) + 16;
+    // state buffers | gather tables | K rows of strip geometry | abort word
+    const size_t lds = pi::tile_state_bytes<T, K, TILE_B, BY>() + (size_t)(2 * NGAT + K) * NT * sizeof(int) + 16;
     auto* k = pi::pi_adj2d_persist_small_kernel<T, K, TILE_B, BY, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     if (hipError_t e = hipMemsetAsync(outbox, 0, persist_small_outbox_bytes(p, (int)sizeof(T)), st)) return e;

@@ -801,6 +801,28 @@ __device__ __forceinline__ void mom_add1(double& a, V2<double> g) { a += g.x + g
 __device__ __forceinline__ float mom_total(V2<float> a) { return a.x + a.y; }
 __device__ __forceinline__ double mom_total(double a) { return a; }
 
+// the geometry word of this lane for one part of a pass (adj_substep<GEO>): bits 0-15 LDS offset of its strip inside a species
+// plane, 16 live, 17-20 ownership of its four points.  Same strip map, clamps and compares as adj_substep's own derivation.
+template <int K, int BX, int BY, int NT, int M, int PART, int TID0>
+__device__ __forceinline__ unsigned persist_geo_word(const TileGeom& g, int ty0, int tx0)
+{
+    using TL = Tile<K, BX, BY>;
+    using SM = StripMap<K, BX, BY, M, PART>;
+    constexpr int RN4 = SM::N, O = 2 * (M + 1);
+    int idx = (int)threadIdx.x - TID0;
+    const bool live = idx >= 0 && idx < RN4;
+    if (idx >= RN4) idx = RN4 - 1;
+    if (idx < 0) idx = 0;
+    int ry, rc;
+    SM::locate(idx, ry, rc);
+    const int ly = ry + O, lx = 4 * rc + O;
+    const unsigned own_ny = (unsigned)min(BY, g.H - ty0), own_nx = (unsigned)min(BX, g.W - tx0);
+    const bool rowin = live && (unsigned)(ly - 2 * K) < own_ny;
+    unsigned w = (unsigned)(ly * TL::LX + lx) | (live ? 1u << 16 : 0u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w |= (rowin && (unsigned)(lx + i - 2 * K) < own_nx) ? (1u << (17 + i)) : 0u;
+    return w;
+}
 // GEO: the lane's strip geometry of this pass -- LDS offset, liveness, ownership of its four points -- comes packed in one word
 // of an LDS table built once per launch (persistent split sweep: persist_geo_word) instead of being derived from the lane id in
 // every pass of every group: the derivation (strip map with its divisions, clamps, four ownership compares and selects) was
@@ -994,13 +1016,14 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
 
 // PRE: the pointwise operands of sub-step M+1 are requested before sub-step M is computed and stay in flight across
 // its LDS barrier (one strip per lane only); `ops` holds the operands of sub-step M, requested one sub-step earlier.
-template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE, bool MOM>
+template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE, bool MOM, bool GEO = false>
 __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__ hbase, const T* __restrict__ gbase,
                                              T* __restrict__ abase, long frame_stride, unsigned inj_mask,
                                              T* __restrict__ g_h0, int steps_to_zero, const TileGeom& g, int ty0,
                                              int tx0, const T* __restrict__ P, double (&acc_c)[2],
                                              const StripOps<T>& ops, TileMoments<T, MOM>& mom, const StripAddr (&sa)[K],
-                                             double* lacc = nullptr, bool store_handover = true)
+                                             double* lacc = nullptr, bool store_handover = true, const unsigned* geo = nullptr,
+                                             const JacPairs<T>* jp = nullptr)
 {
     T* cur = (M & 1) ? b1 : b0;
     T* nxt = (M & 1) ? b0 : b1;
@@ -1011,8 +1034,9 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
         adj_load_ops<T, K, BX, BY, NT, M + 1>(ahead, 0, hbase + fn, (inj_mask >> (M + 1)) & 1u ? gbase + fn : nullptr, g,
                                               ty0, tx0, &sa[M + 1]);
     }
-    adj_substep<T, HC, K, BX, BY, NT, M, PRE, MOM>(cur, nxt, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g,
-                                                   ty0, tx0, P, acc_c, ops, mom, lacc);
+    // (GEO: row M of the caller's [K][NT] table of geometry words + its held coefficient pairs -- resident sweeps only)
+    adj_substep<T, HC, K, BX, BY, NT, M, PRE, MOM, PART_FULL, 0, GEO>(cur, nxt, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g,
+                                                                      ty0, tx0, P, acc_c, ops, mom, lacc, GEO ? geo + M * NT : nullptr, jp);
 #if PI_PIN_MOMENTS
     // Pin this sub-step's moment accumulation HERE.  Left alone, the scheduler sinks the moment FMAs of all four sub-steps
     // (they depend on no LDS traffic) behind the last barrier -- 350 VALU instructions in the tail of the launch, where all
@@ -1040,9 +1064,9 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
     }
     PI_STAMP(4 + 3 * M);
     if constexpr (M + 1 < K)
-        adj_substeps<T, HC, K, BX, BY, NT, M + 1, PRE, MOM>(b0, b1, hbase, gbase, abase, frame_stride, inj_mask, g_h0,
-                                                            steps_to_zero, g, ty0, tx0, P, acc_c, ahead, mom, sa, lacc,
-                                                            store_handover);
+        adj_substeps<T, HC, K, BX, BY, NT, M + 1, PRE, MOM, GEO>(b0, b1, hbase, gbase, abase, frame_stride, inj_mask, g_h0,
+                                                                 steps_to_zero, g, ty0, tx0, P, acc_c, ahead, mom, sa, lacc,
+                                                                 store_handover, geo, jp);
 }
 
 template <typename T, int HC, int K, int BX, int BY, int NT, bool MOM = false>
@@ -1491,7 +1515,13 @@ pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restric
     // LDS: state buffers | int tables | abort word
     int* tab_gl = reinterpret_cast<int*>(smem_raw + tile_state_bytes<T, K, BX, BY>());      // [NGAT][NT]: LDS position of a halo value
     int* tab_gs = tab_gl + NGAT * NT;                                                       // [NGAT][NT]: granule index inside a parity half
-    int* wg_abort = tab_gs + NGAT * NT;
+    unsigned* tab_geo = reinterpret_cast<unsigned*>(tab_gs + NGAT * NT);                    // [K][NT]: the lane's strip in each sub-step
+    int* wg_abort = reinterpret_cast<int*>(tab_geo + K * NT);
+    static_assert(K == 4, "geometry rows below");
+    tab_geo[0 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 0, PART_FULL, 0>(g, ty0, tx0);
+    tab_geo[1 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 1, PART_FULL, 0>(g, ty0, tx0);
+    tab_geo[2 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 2, PART_FULL, 0>(g, ty0, tx0);
+    tab_geo[3 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 3, PART_FULL, 0>(g, ty0, tx0);
     if (threadIdx.x == 0) {                                                                 // residency roll call (pi_adj2d_persist_kernel)
         *wg_abort = 0;
         const unsigned n = __hip_atomic_fetch_add(pa.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -1533,14 +1563,16 @@ pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restric
     double acc_c[2] = {0.0, 0.0};
     bool failed = false;
     TileMoments<T, false> mom;
+    JacPairs<T> jp;
+    jac_pairs_load<T>(jp, P);
     for (int grp = 0; grp < pa.ngroups; ++grp) {
         const long go = -(long)grp * K * frame_stride;     // this group's frame t relative to the top frame
         const bool last = grp + 1 == pa.ngroups;
         // every adjoint frame goes to memory (the moments pass reads them); the last one of the sweep may be dL/dh0 itself.  The
         // frame a group ends on is stored AFTER the tile has been published: the neighbours wait for the granules, nobody for it
-        adj_substeps<T, POLY, K, BX, BY, NT, 0, PRE, false>(b0, b1, hframe_t + go, gframe_t + go, aframe_t + go, frame_stride,
-                                                            gmask, g_h0, g_h0 && last ? K : 0, g, ty0, tx0, P, acc_c, ops0,
-                                                            mom, sa, nullptr, last);
+        adj_substeps<T, POLY, K, BX, BY, NT, 0, PRE, false, PI_PERSIST_GEO != 0>(b0, b1, hframe_t + go, gframe_t + go, aframe_t + go,
+                                                                                 frame_stride, gmask, g_h0, g_h0 && last ? K : 0, g, ty0,
+                                                                                 tx0, P, acc_c, ops0, mom, sa, nullptr, last, tab_geo, &jp);
         if (last) break;
         const long gn = go - (long)K * frame_stride;
         gmask = persist_mask<K>(pa, pa.t_top - K * (grp + 1));
@@ -1716,28 +1748,6 @@ __device__ __forceinline__ StripOff persist_pass_off(const TileGeom& g, int ty0,
     return so;
 }
 
-// the geometry word of this lane for one part of a pass (adj_substep<GEO>): bits 0-15 LDS offset of its strip inside a species
-// plane, 16 live, 17-20 ownership of its four points.  Same strip map, clamps and compares as adj_substep's own derivation.
-template <int K, int BX, int BY, int NT, int M, int PART, int TID0>
-__device__ __forceinline__ unsigned persist_geo_word(const TileGeom& g, int ty0, int tx0)
-{
-    using TL = Tile<K, BX, BY>;
-    using SM = StripMap<K, BX, BY, M, PART>;
-    constexpr int RN4 = SM::N, O = 2 * (M + 1);
-    int idx = (int)threadIdx.x - TID0;
-    const bool live = idx >= 0 && idx < RN4;
-    if (idx >= RN4) idx = RN4 - 1;
-    if (idx < 0) idx = 0;
-    int ry, rc;
-    SM::locate(idx, ry, rc);
-    const int ly = ry + O, lx = 4 * rc + O;
-    const unsigned own_ny = (unsigned)min(BY, g.H - ty0), own_nx = (unsigned)min(BX, g.W - tx0);
-    const bool rowin = live && (unsigned)(ly - 2 * K) < own_ny;
-    unsigned w = (unsigned)(ly * TL::LX + lx) | (live ? 1u << 16 : 0u);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w |= (rowin && (unsigned)(lx + i - 2 * K) < own_nx) ? (1u << (17 + i)) : 0u;
-    return w;
-}
 // ... of pass PASS for this lane (lanes from SPLIT on: the second part)
 template <int K, int BX, int BY, int NT, int PASS>
 __device__ __forceinline__ unsigned persist_pass_geo(const TileGeom& g, int ty0, int tx0)
