@@ -89,6 +89,24 @@ int main(int argc, char** argv)
         std::printf("round %d: us per launch of %d steps: 512 lanes %.2f | 1024 lanes %.2f   (us per step %.3f | %.3f)\n", rep, K, 1e3 * ms[0] / nl,
                     1e3 * ms[1] / nl, 1e3 * ms[0] / T, 1e3 * ms[1] / T);
     }
+    // the same 250 launches as ONE graph launch (does a captured chain shorten the dependent-kernel boundary?)
+    {
+        hipGraph_t graph; hipGraphExec_t exec;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        launch<512>(dB, fs, dP, g, T, st);
+        CK(hipStreamEndCapture(st, &graph));
+        CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        for (int rep = 0; rep < reps; ++rep) {
+            float ms;
+            CK(hipEventRecord(e0, st));
+            CK(hipGraphLaunch(exec, st));
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            std::printf("graph round %d: %.2f us per launch of %d steps (%.3f us per step)\n", rep, 1e3 * ms / (T / K), K, 1e3 * ms / T);
+        }
+        check("512 lanes, graph");
+    }
 #ifdef PI_TILE_TIMING
     // device timeline of the shipped variant (-DPI_TILE_TIMING): per-workgroup 100 MHz stamps of the LAST launch, medians over the
     // workgroups, microseconds since the workgroup's start; "boundary" = start - latest end of the previous launch
