@@ -744,6 +744,35 @@ def test_persistent_sweep_equals_launch_per_group(shape, T, hip_device):
     assert torch.equal(a0, c0) and torch.equal(a0, d0)
 
 
+def test_persistent_sweeps_fuzz(hip_device):
+    """Random shapes (both resident flavours), horizons and gradient-frame patterns: the one-launch sweeps give dL/dh0 bit for
+    bit as the launch-per-group sweep does -- blown-up trajectories included (same NaN bit patterns) -- and no launch aborts."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    rs = np.random.RandomState(77)
+    shapes = [(512, 512), (384, 384), (384, 512), (512, 256), (448, 448), (320, 512), (100, 100), (128, 96), (200, 40), (288, 288),
+              (300, 320), (64, 64)]
+    n0 = _lib.persist_status()["aborts"]
+    for it in range(16):
+        shape = shapes[rs.randint(len(shapes))]
+        T = int(rs.randint(8, 60))
+        P = dev_t(random_block(0, 2, np.float32, int(rs.randint(1000)), scale=0.1), hip_device)
+        traj = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=hip_device)
+        traj[0] = dev_t(rs.uniform(0, 1, (2,) + shape).astype(np.float32), hip_device)
+        pa.rollout_fwd_(traj, P)
+        g = torch.randn(traj.shape, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(it)) / traj[0].numel()
+        kind = rs.randint(4)
+        mask = None if kind == 0 else [bool(rs.rand() < 0.5) for _ in range(T + 1)] if kind == 1 else \
+            [t % int(rs.randint(2, 9)) == 0 for t in range(T + 1)] if kind == 2 else [t == T for t in range(T + 1)]
+        assert _lib.rollout_plan(0, shape, 4)["bwd_persistent"]
+        a0, ag = pa.rollout_bwd(traj, g, P, frame_mask=mask)
+        b0, bg = pa.rollout_bwd(traj, g, P, frame_mask=mask, options={"tile_persist": 0, "persist_small": 0})
+        assert torch.equal(a0.view(torch.int32), b0.view(torch.int32)), (it, shape, T, kind)
+        if bool(torch.isfinite(traj[-1]).all()):
+            assert rel_l2(ag.cpu().numpy(), bg.cpu().numpy()) < 2e-6, (it, shape, T, kind)
+    assert _lib.persist_status()["aborts"] == n0
+
+
 @pytest.mark.parametrize("shape,T", [((100, 100), 41), ((128, 128), 23), ((64, 96), 17), ((256, 256), 12), ((40, 200), 9), ((72, 64), 13),
                                      ((288, 288), 9), ((300, 320), 13)])      # the 32 x 16 / 320-lane regime
 def test_small_tile_persistent_sweep_equals_launch_per_group(shape, T, hip_device):
