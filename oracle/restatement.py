@@ -314,6 +314,21 @@ class OracleStage3LOCell(nn.Module):
         ch = torch.cat((u_next, v_next), dim=1)
         return ch, ch
 
+    def forward_rk4(self, h):
+        """lo3:154-201: classical RK4 with the same f_rhs (defined in the reference, never called there)."""
+        u0, v0 = h[:, 0:1, ...], h[:, 1:2, ...]
+        k1_u, k1_v = self.f_rhs(u0, v0)
+        u1, v1 = u0 + k1_u * self.dt / 2.0, v0 + k1_v * self.dt / 2.0
+        k2_u, k2_v = self.f_rhs(u1, v1)
+        u2, v2 = u0 + k2_u * self.dt / 2.0, v0 + k2_v * self.dt / 2.0
+        k3_u, k3_v = self.f_rhs(u2, v2)
+        u3, v3 = u0 + k3_u * self.dt, v0 + k3_v * self.dt
+        k4_u, k4_v = self.f_rhs(u3, v3)
+        u_next = u0 + self.dt * (k1_u + 2 * k2_u + 2 * k3_u + k4_u) / 6.0
+        v_next = v0 + self.dt * (k1_v + 2 * k2_v + 2 * k3_v + k4_v) / 6.0
+        ch = torch.cat((u_next, v_next), dim=1)
+        return ch, ch
+
 
 # --------------------------------------------------------------------------------------
 # Stage-3 physics-based cell, 2D Burgers (SURVEY 8f rank 2).  Restates
@@ -362,6 +377,21 @@ class OracleStage3BurgersCell(nn.Module):
         u0, v0 = h[:, 0:1, ...], h[:, 1:2, ...]
         f_u, f_v = self.f_rhs(u0, v0)
         ch = torch.cat((u0 + self.dt * f_u, v0 + self.dt * f_v), dim=1)
+        return ch, ch
+
+    def forward_rk4(self, h):
+        """bur3:159-206: classical RK4 with the same f_rhs (defined in the reference, never called there)."""
+        u0, v0 = h[:, 0:1, ...], h[:, 1:2, ...]
+        k1_u, k1_v = self.f_rhs(u0, v0)
+        u1, v1 = u0 + k1_u * self.dt / 2.0, v0 + k1_v * self.dt / 2.0
+        k2_u, k2_v = self.f_rhs(u1, v1)
+        u2, v2 = u0 + k2_u * self.dt / 2.0, v0 + k2_v * self.dt / 2.0
+        k3_u, k3_v = self.f_rhs(u2, v2)
+        u3, v3 = u0 + k3_u * self.dt, v0 + k3_v * self.dt
+        k4_u, k4_v = self.f_rhs(u3, v3)
+        u_next = u0 + self.dt * (k1_u + 2 * k2_u + 2 * k3_u + k4_u) / 6.0
+        v_next = v0 + self.dt * (k1_v + 2 * k2_v + 2 * k3_v + k4_v) / 6.0
+        ch = torch.cat((u_next, v_next), dim=1)
         return ch, ch
 
 

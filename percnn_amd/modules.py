@@ -419,6 +419,9 @@ class Stage3LambdaOmegaCell(nn.Module):
             self.filter.weight.data = torch.tensor(laplace_stencil(2), dtype=torch.float64)
             self.filter.weight.requires_grad = False
 
+        def forward(self, x):                                       # stock evaluation (f_rhs / forward_rk4 only)
+            return self.filter(x) / self.resol
+
     def __init__(self, dx: float = 0.2, dt: float = 0.0125):
         super().__init__()
         for k, v in self.INIT.items():
@@ -449,6 +452,33 @@ class Stage3LambdaOmegaCell(nn.Module):
         ch = F_pi.pi_step(h, self.param_block())
         return ch, ch
 
+    def f_rhs(self, u, v):
+        """The discovered right-hand side on stock tensor operations (reference f_rhs, lo3:149-152)."""
+        u2, v2 = u ** 2, v ** 2
+        f_u = self.nu_u * self.laplace_op(u) + self.C1_u * u + self.C2_u * u ** 3 + self.C3_u * u2 * v + self.C4_u * u * v2 \
+            + self.C5_u * v ** 3
+        f_v = self.nu_v * self.laplace_op(v) + self.C1_v * v + self.C2_v * u ** 3 + self.C3_v * u2 * v + self.C4_v * u * v2 \
+            + self.C5_v * v ** 3 + self.C6_v * u
+        return f_u, f_v
+
+    def forward_rk4(self, h):
+        """One classical Runge-Kutta step with ``f_rhs`` (reference: ``forward_rk4``, lo3:154-201 -- defined there, never called).
+        Offered for completeness on stock tensor operations (differentiable through stock autograd, any device); the fused
+        kernels implement the explicit Euler ``forward`` the reference trains with."""
+        dt = self.dt
+        u0, v0 = h[:, 0:1], h[:, 1:2]
+        ku, kv = self.f_rhs(u0, v0)
+        su, sv = ku, kv                                             # k1 + 2 k2 + 2 k3 + k4, summed in the reference's order
+        for weight, frac in ((2, 2.0), (2, 2.0), (1, 1.0)):          # stage states u0 + k dt / 2, u0 + k dt / 2, u0 + k dt
+            if frac == 1.0:
+                ku, kv = self.f_rhs(u0 + ku * dt, v0 + kv * dt)
+            else:
+                ku, kv = self.f_rhs(u0 + ku * dt / frac, v0 + kv * dt / frac)
+            su = su + (weight * ku if weight != 1 else ku)
+            sv = sv + (weight * kv if weight != 1 else kv)
+        ch = torch.cat((u0 + dt * su / 6.0, v0 + dt * sv / 6.0), dim=1)
+        return ch, ch
+
     def init_hidden_tensor(self, prev_state):
         return prev_state.to(self.nu_u.device)
 
@@ -473,6 +503,9 @@ class Stage3BurgersCell(nn.Module):
             self.filter = nn.Conv2d(1, 1, 5, 1, padding=2, padding_mode="circular", bias=False, dtype=torch.float64)
             self.filter.weight.data = torch.tensor(stencil, dtype=torch.float64)
             self.filter.weight.requires_grad = False
+
+        def forward(self, x):                                       # stock evaluation (f_rhs / forward_rk4 only)
+            return self.filter(x) / self.resol
 
     def __init__(self, dx: float = 1 / 100, dt: float = 0.00025):
         super().__init__()
@@ -518,6 +551,30 @@ class Stage3BurgersCell(nn.Module):
 
     def forward(self, h):
         ch = F_pi.pi_step(h, self.param_block())
+        return ch, ch
+
+    def f_rhs(self, u, v):
+        """The discovered right-hand side on stock tensor operations (reference f_rhs, bur3:154-157)."""
+        f_u = self.nu_u * self.laplace_op(u) + self.C1_u * u * self.dx_op(u) + self.C2_u * v * self.dy_op(u)
+        f_v = self.nu_v * self.laplace_op(v) + self.C1_v * u * self.dx_op(v) + self.C2_v * v * self.dy_op(v)
+        return f_u, f_v
+
+    def forward_rk4(self, h):
+        """One classical Runge-Kutta step with ``f_rhs`` (reference: ``forward_rk4``, bur3:159-206 -- defined there, never called).
+        Offered for completeness on stock tensor operations (differentiable through stock autograd, any device); the fused
+        kernels implement the explicit Euler ``forward`` the reference trains with."""
+        dt = self.dt
+        u0, v0 = h[:, 0:1], h[:, 1:2]
+        ku, kv = self.f_rhs(u0, v0)
+        su, sv = ku, kv                                             # k1 + 2 k2 + 2 k3 + k4, summed in the reference's order
+        for weight, frac in ((2, 2.0), (2, 2.0), (1, 1.0)):          # stage states u0 + k dt / 2, u0 + k dt / 2, u0 + k dt
+            if frac == 1.0:
+                ku, kv = self.f_rhs(u0 + ku * dt, v0 + kv * dt)
+            else:
+                ku, kv = self.f_rhs(u0 + ku * dt / frac, v0 + kv * dt / frac)
+            su = su + (weight * ku if weight != 1 else ku)
+            sv = sv + (weight * kv if weight != 1 else kv)
+        ch = torch.cat((u0 + dt * su / 6.0, v0 + dt * sv / 6.0), dim=1)
         return ch, ch
 
     def init_hidden_tensor(self, prev_state):

@@ -1339,6 +1339,30 @@ def test_stage3_burgers_cell_vs_reference(name, hip_device):
     assert rel_l2(grads[-1].cpu().numpy()[0], g0_o) < 1e-13
 
 
+@pytest.mark.parametrize("name", ["lo3_stage3_32x32.npz", "bur3_stage3_24x40.npz"])
+def test_stage3_forward_rk4_on_the_device(name, hip_device):
+    """`forward_rk4` of the Stage-3 cells on the GPU (stock tensor operations there: it is not on the hot path) against the
+    vectors of the imported reference's own method -- frames and the gradients of mean(h_5^2)."""
+    import percnn_amd as pa
+    z = np.load(os.path.join(GOLDEN, name))
+    cell = (pa.Stage3LambdaOmegaCell if name.startswith("lo3") else pa.Stage3BurgersCell)()
+    cell.load_state_dict({k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")})
+    cell.to(hip_device)
+    h0 = dev_t(z["h0"], hip_device).requires_grad_(True)
+    h, n = h0, int(z["rk4_steps"])
+    for t in range(1, n + 1):
+        h, _ = cell.forward_rk4(h)
+        if f"rk4/{t}" in z.files:
+            assert rel_l2(h.detach().cpu().numpy(), z[f"rk4/{t}"]) < 1e-13, t
+    loss = (h ** 2).mean()
+    names = [k[len("rk4_grad_meansq/"):] for k in z.files if k.startswith("rk4_grad_meansq/")]
+    g = torch.autograd.grad(loss, [getattr(cell, k) for k in names] + [h0])
+    for k, gi in zip(names, g[:-1]):
+        r = float(z["rk4_grad_meansq/" + k])
+        assert abs(gi.item() - r) <= 1e-9 * max(abs(r), 1e-6), (k, gi.item(), r)
+    assert rel_l2(g[-1].cpu().numpy(), z["rk4_grad_meansq_h0"]) < 1e-11
+
+
 def test_advective_block_3d_and_fp32_vs_oracle(hip_device):
     """The advective kernels are generic over 2D/3D and fp32/fp64 (random blocks, incl. polynomial part)."""
     import percnn_amd as pa

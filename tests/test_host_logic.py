@@ -232,6 +232,33 @@ def test_stage3_burgers_cell_schema_and_block():
     assert pa.lib().percnn_pi_param_count(-1) == 60
 
 
+@pytest.mark.parametrize("name", ["lo3_stage3_32x32.npz", "lo3_stage3_24x40.npz", "bur3_stage3_32x32.npz", "bur3_stage3_24x40.npz"])
+def test_stage3_forward_rk4_vs_reference(name):
+    """`forward_rk4` of the Stage-3 cells (lo3:154-201, bur3:159-206: defined in the reference, never called by its scripts):
+    five RK4 steps and the gradients of mean(h_5^2) against vectors produced by the imported reference's own method
+    (tools/make_golden.py: stage3_rk4_vectors); the oracle restatement and the drop-in cell, both on stock tensor operations."""
+    import percnn_amd as pa
+    from oracle import restatement as R
+    z = np.load(os.path.join(GOLDEN, name))
+    sd = {k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}
+    lo = name.startswith("lo3")
+    for cell in ((R.OracleStage3LOCell if lo else R.OracleStage3BurgersCell)(), (pa.Stage3LambdaOmegaCell if lo else pa.Stage3BurgersCell)()):
+        cell.load_state_dict(sd)
+        h0 = torch.tensor(z["h0"], requires_grad=True)
+        h, n = h0, int(z["rk4_steps"])
+        for t in range(1, n + 1):
+            h, _ = cell.forward_rk4(h)
+            if f"rk4/{t}" in z.files:
+                assert np.abs(h.detach().numpy() - z[f"rk4/{t}"]).max() <= 1e-14 * max(1.0, np.abs(z[f"rk4/{t}"]).max()), (type(cell).__name__, t)
+        loss = (h ** 2).mean()
+        assert abs(loss.item() - float(z["rk4_loss_meansq"])) <= 1e-14
+        names = [k[len("rk4_grad_meansq/"):] for k in z.files if k.startswith("rk4_grad_meansq/")]
+        g = torch.autograd.grad(loss, [getattr(cell, k) for k in names] + [h0])
+        for k, gi in zip(names, g[:-1]):
+            assert abs(gi.item() - float(z["rk4_grad_meansq/" + k])) <= 1e-12 * max(1.0, abs(float(z["rk4_grad_meansq/" + k]))), k
+        assert np.abs(g[-1].numpy() - z["rk4_grad_meansq_h0"]).max() <= 1e-12 * max(1e-30, np.abs(z["rk4_grad_meansq_h0"]).max())
+
+
 def test_frame_gradient_assembly_zero_copy_and_masked():
     """RCNN.forward hands back T+1 frames; their gradients come back as slices of one buffer when the caller cats
     them (zero-copy), or individually / partly missing (copied, rest masked)."""

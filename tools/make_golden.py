@@ -293,6 +293,32 @@ def biggrad_case(case, mod, shape, steps, stride_t):
     print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
 
 
+def stage3_rk4_vectors(rc, oc, h0, rec, steps=5):
+    """forward_rk4 of the reference cell (defined there, never called by its scripts): `steps` RK4 steps from h0, the
+    restatement asserted bit-equal, frames 1 and `steps` + the gradients of mean(h_steps^2) saved."""
+    def roll(cell, h):
+        outs = []
+        for _ in range(steps):
+            h, _ = cell.forward_rk4(h)
+            outs.append(h)
+        return outs
+    h0r, h0o = h0.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+    tr, to = roll(rc, h0r), roll(oc, h0o)
+    for a, b in zip(tr, to):
+        assert torch.equal(a, b), "stage-3 forward_rk4 restatement differs from the reference"
+    rec["rk4_steps"] = steps
+    rec["rk4/1"], rec[f"rk4/{steps}"] = tr[0].detach().numpy(), tr[-1].detach().numpy()
+    lr, lo = (tr[-1] ** 2).mean(), (to[-1] ** 2).mean()
+    gr, ghr = grads_of(lr, rc, h0r)
+    go, gho = grads_of(lo, oc, h0o)
+    for n in gr:
+        assert torch.equal(gr[n], go[n]), n
+        rec["rk4_grad_meansq/" + n] = gr[n].numpy()
+    assert torch.equal(ghr, gho)
+    rec["rk4_loss_meansq"] = lr.item()
+    rec["rk4_grad_meansq_h0"] = ghr.numpy()
+
+
 def stage3_lo_case(mod):
     """the Stage-3 physics-based lambda-omega cell (13 trainable scalars, Euler)."""
     from oracle import restatement as R
@@ -323,6 +349,7 @@ def stage3_lo_case(mod):
         assert torch.equal(ghr, gho)
         rec["loss_meansq"] = lr.item()
         rec["grad_meansq_h0"] = ghr.numpy()
+        stage3_rk4_vectors(rc, oc, h0, rec)
         fn = os.path.join(OUT, f"lo3_stage3_{'x'.join(map(str, shape))}.npz")
         np.savez_compressed(fn, **rec)
         print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
@@ -361,6 +388,7 @@ def stage3_burgers_case(mod):
         assert torch.equal(ghr, gho)
         rec["loss_meansq"] = lr.item()
         rec["grad_meansq_h0"] = ghr.numpy()
+        stage3_rk4_vectors(rc, oc, h0, rec)
         fn = os.path.join(OUT, f"bur3_stage3_{'x'.join(map(str, shape))}.npz")
         np.savez_compressed(fn, **rec)
         print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
