@@ -350,8 +350,9 @@ __device__ __forceinline__ void poly_dr_v(const T* __restrict__ c, V2<T> u, V2<T
 // The Jacobian's coefficient multiples as ready pairs held in vector registers (persistent split sweep).  gfx950 has no scalar
 // float multiply: 2 c / 3 c are VALU products of a uniform value, and every use of one in a packed FMA needs the pair {x, x}
 // built by a v_mov -- per pass, in a loop bound by instruction issue.  Entry j of species s: 0 2c7, 1 2c3, 2 3c6, 3 3c9, 4 2c5,
-// 5 2c8, 6 c4; PI_JAC_MASK says which are held (the others are formed as before; 0x3F measured best of six masks,
-// profiles/r04_persist_issue_trim.txt).  Same single multiplication: bit-identical.
+// 5 2c8, 6 c4; PI_JAC_MASK says which are held (the others are formed as before; all seven since the two parts of a mixed
+// pass share one body and the registers are there -- masks measured: profiles/r04_persist_issue_trim.txt).  Same single
+// multiplication: bit-identical.
 #ifndef PI_JAC_MASK
 #define PI_JAC_MASK 0x7F
 #endif
