@@ -266,6 +266,13 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
         kernels[1] = {"kernel": pname + "<sweep+moments, %d groups of %d steps per launch>" % (T // K, K),
                       "launches_per_pass": 1, "algorithmic_bytes_per_launch": 4 * Cs * npts * (T // K) * K,
                       "avg_launch_us": sweep_ms * 1e3}
+    # the forward of such a grid is one resident launch as well (pi_fwd2d_persist_kernel, round 4), unless switched off
+    fwd_persistent = bool(plan.get("fwd_persistent")) and Kf == 4 and T // Kf >= 2 and not opts.get("tile_persist") == "0" and \
+        str(opts.get("fwd_persist", "1")) != "0"
+    if fwd_persistent:
+        kernels[0] = {"kernel": "pi_fwd2d_persist_kernel<%d groups of %d steps per launch>" % (T // Kf, Kf),
+                      "launches_per_pass": 1, "algorithmic_bytes_per_launch": 2 * Cs * npts * (T // Kf) * Kf,
+                      "avg_launch_us": fwd_ms * 1e3}
     if persistent_small:
         kernels[1] = {"kernel": "pi_adj2d_persist_small_kernel<sweep, %d groups of %d steps per launch>" % (T // K, K),
                       "launches_per_pass": 1, "algorithmic_bytes_per_launch": 4 * Cs * npts * (T // K) * K,

@@ -204,6 +204,11 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *   "persist_small"  1 (default): grids in the 32 x 8-tile regime (below ~300^2, ragged ones included: the reference's own
  *                  100^2, train_2drd.py:597-636) run their sweep as one resident launch as well (pi_adj2d_persist_small_kernel;
  *                  its granule outbox is part of percnn_pi_rollout_bwd_workspace_bytes); 0: one launch per four steps
+ *   "fwd_persist"  1 (default): the FORWARD rollout of a grid the persistent sweep takes (float32 pre-contracted block, whole
+ *                  32 x 32 tiles, 16 .. #CUs of them, T >= 32) runs as one launch of resident workgroups too
+ *                  (pi_fwd2d_persist_kernel: the launch-per-group kernel's trajectory bit for bit; residency check, abort and
+ *                  fallback as "tile_persist"; the library keeps 256 B + 24 KiB per tile of device scratch per device for its
+ *                  granule outbox, allocated at the first such call); 0: one launch per four steps
  *   "brick_wide"   1 (default): 3D rows of 65 .. 128 sixteen-byte chunks on 512-lane bricks where they win; 0: direct kernels
  *   "persist_reset"  (any value) re-arm the persistent sweep after an abort
  * Returns 0, or PERCNN_PI_EINVAL for an unknown key / bad value. */
@@ -358,8 +363,9 @@ int percnn_pi_debug_blockmap(int ndim, const int64_t* shape, int elem_size, cons
  * buffers).  out[15] = {forward family, adjoint family, 1 if the parameter gradients are reduced inside the sweep launches,
  * time steps per forward launch, per adjoint launch, planes per pass forward, adjoint, lanes per brick workgroup or 0,
  * 2D tile width, tile height, lanes per tile workgroup of the adjoint sweep (0: no tile kernels), the same three of the
- * forward, 1 if the tile sweep of a long rollout without frame mask runs as ONE launch of resident workgroups (option
- * tile_persist; asks the current device for its CU count -- 0 without a device)}; families: 0 direct step kernels,
+ * forward, bit 0: the tile sweep of a long rollout without frame mask runs as ONE launch of resident workgroups (option
+ * tile_persist; asks the current device for its CU count -- 0 without a device), bit 1: so does its forward (fwd_persist)};
+ * families: 0 direct step kernels,
  * 1 2D tile kernels, 2 3D plane streaming, 3 3D brick kernels, 4 advective block. */
 int percnn_pi_debug_plan(int hc, int ndim, const int64_t* shape, int elem_size, const char* options, int* out);
 

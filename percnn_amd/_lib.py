@@ -350,7 +350,8 @@ def rollout_plan(hc: int, shape, elem_size: int, options=None) -> dict:
     return {"fwd": FAMILIES[out[0]], "bwd": FAMILIES[out[1]], "fused_gradients": bool(out[2]), "fwd_steps_per_launch": out[3],
             "bwd_steps_per_launch": out[4], "fwd_planes_per_pass": out[5], "bwd_planes_per_pass": out[6],
             "brick_lanes": out[7], "tile": (out[8], out[9], out[10]) if out[10] else None,
-            "tile_fwd": (out[11], out[12], out[13]) if out[13] else None, "bwd_persistent": bool(out[14])}
+            "tile_fwd": (out[11], out[12], out[13]) if out[13] else None, "bwd_persistent": bool(out[14] & 1),
+            "fwd_persistent": bool(out[14] & 2)}
 
 
 def set_option(key: str, value: int) -> None:

@@ -61,6 +61,8 @@ struct Options {
                             // this device (percnn_pi_persist_status).  0: no wait; an aborted launch is reported by the NEXT
                             // entry point (PERCNN_PI_EASYNC) instead
     int persist_small = 1;      // the 32 x 8-tile regime (grids below ~300^2, split schedule) as one persistent launch too
+    int fwd_persist = 1;        // the FORWARD rollout of such a grid as one launch of resident workgroups too (pi_fwd2d_persist_kernel;
+                            // same residency check / abort / fallback; its granule outbox is a per-device scratch of the library)
     int persist_split = 1;      // persistent sweep: 1 = split flavour (pi_adj2d_persist_split_kernel: the halo-independent
                             // "pyramid" of the next group runs while the granules of the hand-over travel), 0 = round 3's kernel
     int persist_timeout_ms = 2000;       // bound of one hand-over wait inside the persistent sweep
@@ -1178,6 +1180,8 @@ struct PersistGuard {
     long launches = 0, aborts = 0;
     int last_group = -1, last_tile = -1;
     bool warned = false;
+    void* fwd_scratch[16] = {};                           // per device: sync words + granule outbox of the resident forward
+    size_t fwd_scratch_bytes[16] = {};
 };
 PersistGuard g_persist;
 
@@ -1326,6 +1330,120 @@ hipError_t launch_adj_persist(const T* hframe_t, const T* gframe_t, T* aframe_t,
         if (!g_persist.warned) {
             g_persist.warned = true;
             std::fprintf(stderr, "percnn_pi: the persistent tile sweep could not keep all %u workgroups resident on device %d "
+                                 "(group %d, tile %d: another process / kernel holds CUs, or a CU mask is set); using one launch "
+                                 "per group of steps from now on (percnn_pi_set_option(\"persist_reset\", 1) re-arms it)\n",
+                         grid, dev, (int)hs[1], (int)hs[2]);
+        }
+        return hipErrorLaunchFailure;
+    }
+    return hipSuccess;
+}
+
+// ---- resident FORWARD (pi_fwd2d_persist_kernel): the same grids, the same residency protocol ----------------------------------
+template <typename T>
+bool fwd_persist_ok(const Problem& p, int ngroups, hipStream_t st)
+{
+    // (eight groups at least: short rollouts -- the step loop's speculative groups of 8 / 16 steps among them -- keep the
+    // launch-per-group kernel and with it a host that never waits for the stream)
+    if (!p.opt.tile_persist || !p.opt.fwd_persist || sizeof(T) != 4 || ngroups < 8) return false;
+    if (persist_disabled_here()) return false;
+    // what the launch-per-group path would run as pi_fwd2d_tile_kernel<float, poly, 4, 32, 32, 512> (the trajectory is that kernel's)
+    if (p.hc != 0 || p.opt.tile_k != 4 || p.opt.tile_nt != 512 || tile_by_for(p) != TILE_B || tile_wide_for<T>(p, false) != 0) return false;
+    if (p.n0 % TILE_B || p.W % TILE_B) return false;
+    const int64_t tiles = (p.n0 / TILE_B) * (p.W / TILE_B);
+    const int cus = device_cu_count();
+    if (tiles < 16 || cus <= 0 || tiles > cus) return false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st && (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) return false;
+    return true;
+}
+
+// frames t0 + 1 .. t0 + 4 * ngroups from frame t0.  Return values as launch_adj_persist: hipErrorLaunchFailure = it ran and
+// ABORTED (frames may be partly written: the caller recomputes them launch by launch, which is deterministic).
+template <typename T>
+hipError_t launch_fwd_persist(T* frame_t0, int ngroups, const T* P, const Problem& p, int dev, hipStream_t st)
+{
+    constexpr int K = 4, NT = 512;
+    pi::TileGeom g = make_tile_geom(p, TILE_B);
+    const unsigned grid = (unsigned)((p.n0 / TILE_B) * g.tiles_x);
+    // state buffers | publish / gather tables and 6 rows of strip geometry | abort word
+    const size_t lds = pi::tile_state_bytes<T, K, TILE_B, TILE_B>() + (size_t)pi::PERSIST_SPLIT_TABLE_ROWS * NT * sizeof(int) + 16;
+    auto* k = pi::pi_fwd2d_persist_kernel<T, K, TILE_B, TILE_B, NT>;
+    if (hipError_t e = allow_lds(k, lds)) return e;
+    static int resident[16] = {};                           // per device: does one workgroup fit a CU? (asked once)
+    if (!resident[dev]) {
+        int nb = 0;
+        resident[dev] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, NT, lds) == hipSuccess && nb >= 1) ? 1 : -1;
+    }
+    if (resident[dev] < 0) return hipErrorCooperativeLaunchTooLarge;
+    // per-device scratch: 256 B of sync words | granule outbox (allocated once, sized for this grid or larger)
+    const size_t need = 256 + persist_outbox_bytes(p);
+    unsigned char* scratch;
+    {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        if (g_persist.fwd_scratch_bytes[dev] < need) {
+            if (g_persist.fwd_scratch[dev]) {               // (a launch that still uses the old one is ordered before this call's
+                (void)hipFree(g_persist.fwd_scratch[dev]);  // work only on its own stream: hipFree synchronises the device)
+                g_persist.fwd_scratch[dev] = nullptr;
+                g_persist.fwd_scratch_bytes[dev] = 0;
+            }
+            void* q = nullptr;
+            if (hipMalloc(&q, need) != hipSuccess || !q) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
+            g_persist.fwd_scratch[dev] = q;
+            g_persist.fwd_scratch_bytes[dev] = need;
+        }
+        scratch = static_cast<unsigned char*>(g_persist.fwd_scratch[dev]);
+    }
+    if (hipError_t e = hipMemsetAsync(scratch, 0, need, st)) return e;
+    long frame_stride = (long)(2 * p.n);
+    pi::PersistArgs pa{};
+    int slot;
+    {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        slot = g_persist.next_slot++ % PERSIST_SLOTS;
+        g_persist.watch[slot] = false;
+        ++g_persist.launches;
+    }
+    volatile int* hs = g_persist.host->slot[slot];
+    hs[0] = 0; hs[1] = -1; hs[2] = -1; hs[3] = 0;
+    pa.outbox = reinterpret_cast<unsigned long long*>(scratch + 256);
+    pa.sync = reinterpret_cast<unsigned*>(scratch);
+    pa.ngroups = ngroups;
+    pa.host = const_cast<int*>(hs);
+    pa.timeout_ticks = (unsigned long long)p.opt.persist_timeout_ms * 100000ull;             // 100 MHz clock
+    pa.first_timeout_ticks = (unsigned long long)p.opt.persist_first_timeout_ms * 100000ull;
+    void* args[] = {(void*)&frame_t0, (void*)&frame_stride, (void*)&P, (void*)&g, (void*)&pa};
+    hipError_t e;
+    if (p.opt.tile_persist == 2) {
+        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, frame_t0, frame_stride, P, g, pa);
+        e = hipGetLastError();
+    } else {
+        e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k), dim3(grid), dim3(NT), args, (unsigned)lds, st);
+    }
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        g_persist.watch[slot] = true;
+    }
+    if (!p.opt.persist_handshake) return hipSuccess;        // fire and forget (an abort: PERCNN_PI_EASYNC at the next entry point)
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (hs[0] == 0 && hs[3] == 0) {
+        if ((++spins & 0x3ff) == 0) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(600)) return hipErrorLaunchTimeOut;
+            std::this_thread::yield();
+        }
+    }
+    if (hs[3] != 0) {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        g_persist.watch[slot] = false;
+        ++g_persist.aborts;
+        g_persist.last_group = hs[1];
+        g_persist.last_tile = hs[2];
+        g_persist.disabled[dev] = true;
+        if (!g_persist.warned) {
+            g_persist.warned = true;
+            std::fprintf(stderr, "percnn_pi: the resident forward rollout could not keep all %u workgroups resident on device %d "
                                  "(group %d, tile %d: another process / kernel holds CUs, or a CU mask is set); using one launch "
                                  "per group of steps from now on (percnn_pi_set_option(\"persist_reset\", 1) re-arms it)\n",
                          grid, dev, (int)hs[1], (int)hs[2]);
@@ -1974,6 +2092,21 @@ int rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* shape
     int t = 0;
     if (tile_eligible<T>(p, {traj}, false)) {
         const int K = (p.opt.tile_k == 8 && p.hc != 0) ? 4 : p.opt.tile_k;
+        // whole groups of four steps as ONE launch of resident workgroups where the grid allows (pi_fwd2d_persist_kernel: the
+        // launch-per-group kernel's trajectory bit for bit); an aborted launch is recomputed below, launch by launch
+        if constexpr (sizeof(T) == 4) {
+            const int ngroups = K == 4 ? T_steps / K : 0;
+            int pdev = 0;
+            if (fwd_persist_ok<T>(p, ngroups, st) && persist_enter(st, pdev)) {
+                const hipError_t e = launch_fwd_persist<T>(traj, ngroups, P, p, pdev, st);
+                if (e == hipSuccess) { t = K * ngroups; persist_leave(st, pdev); }
+                else if (e == hipErrorLaunchTimeOut) return (int)e;
+                else {
+                    (void)hipGetLastError();                // not resident / not supported / aborted
+                    if (e == hipErrorLaunchFailure) persist_leave(st, pdev);
+                }
+            }
+        }
         for (; t + K <= T_steps; t += K)
             if (hipError_t e = fwd_tile<T>(traj + (size_t)t * frame, P, p, st)) return (int)e;
     }
@@ -2374,6 +2507,7 @@ int apply_option(Options& o, const char* key, long value)
     if (!std::strcmp(key, "persist_handshake")) { o.persist_handshake = value != 0; return 0; }
     if (!std::strcmp(key, "persist_split")) { o.persist_split = value != 0; return 0; }
     if (!std::strcmp(key, "persist_small")) { o.persist_small = value != 0; return 0; }
+    if (!std::strcmp(key, "fwd_persist")) { o.fwd_persist = value != 0; return 0; }
     if (!std::strcmp(key, "persist_timeout_ms") || !std::strcmp(key, "persist_first_timeout_ms")) {
         if (value < 1 || value > 600000) return PERCNN_PI_EINVAL;
         (key[8] == 'f' ? o.persist_first_timeout_ms : o.persist_timeout_ms) = (int)value;
@@ -2623,8 +2757,9 @@ int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options,
     for (int i = 8; i < 15; ++i) out[i] = 0;
     // the whole tile sweep as one launch of resident workgroups (needs a device to ask for its CU count: 0 without one)
     if constexpr (sizeof(T) == 4)
-        out[14] = (out[1] == 1 && (persist_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr) ||
-                                   persist_small_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr))) ? 1 : 0;
+        out[14] = ((out[1] == 1 && (persist_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr) ||
+                                    persist_small_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr))) ? 1 : 0) |
+                  ((out[0] == 1 && fwd_persist_ok<T>(p, 1 << 18, nullptr)) ? 2 : 0);
     for (int dir = 0; dir < 2; ++dir) {                                    // 2D tiles: width, height, lanes per workgroup
         if (out[dir] != 1) continue;
         const TileShape ts = tile_shape_for<T>(p, dir == 1);

@@ -2065,4 +2065,277 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT FORWARD (round 4): the T-step forward rollout of a grid of <= #CUs 32 x 32 tiles as ONE launch of resident
+// workgroups, on the machinery of pi_adj2d_persist_split_kernel -- state tile in LDS across groups of K steps, the 2K-wide border
+// band published / the halo ring gathered as data-tagged granules once per group, the halo-independent pyramid I_m of each
+// sub-step computed while the granules travel, strip geometry from the LDS table, residency roll call / bounded waits / abort.
+// What it removes from every K = 4 steps of the launch-per-group kernel: the dependent-kernel boundary (1.9 us) and the cold
+// window load (0.8 us) of a 6.65 us launch.  Every frame still goes to memory (the backward reads the trajectory): the waves
+// that have no strip in a pass store a finished level from LDS while the others compute --
+//     P0 I_0 (+ store level 4 of the previous group) | P1 I_1 (+ the centre of level 1, which I_2 overwrites in P2) |
+//     ring -> LDS | P2 I_2 + A_0 | P3 A_1 (+ the rest of level 1) | P4 A_2 (+ level 2) | P5 I_3 + A_3 (+ level 3) | publish
+// Levels alternate between the two LDS buffers exactly as in pi_fwd2d_tile_kernel; a strip is computed by the same lds_star4 /
+// poly_r / update sequence: the trajectory is that kernel's bit for bit.
+// ------------------------------------------------------------------------------------------------
+// one strip of the forward sub-step, placed by a geometry word (persist_geo_word); pre-contracted block
+template <typename T, int K, int BX, int BY>
+__device__ __forceinline__ void fwd_strip_geo(const T* cur, T* nxt, const T* __restrict__ P, unsigned w)
+{
+    using TL = Tile<K, BX, BY>;
+    if (__builtin_amdgcn_ballot_w64(((w >> 16) & 1u) != 0u) == 0ull) return;       // whole waves without a strip in this pass
+    const int off = (int)(w & 0xFFFFu);
+    const T dt = P[P_DT];
+    T u[4], v[4], lap[2][4];
+    lds_star4<T, TL::LX, +1>(cur + off, 0, 0, P, u, lap[0]);
+    lds_star4<T, TL::LX, +1>(cur + TL::PLANE + off, 0, 0, P, v, lap[1]);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        T rr[4];
+        const T* c = P + P_W + 10 * s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rr[i] = poly_r(c, u[i], v[i]);
+        const T coef = P[P_COEF + s];
+        T o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const T lp = s == 0 ? lap[0][i] : lap[1][i];
+            const T res = coef * lp + rr[i];
+            const T inc = res * dt;
+            o[i] = (s == 0 ? u[i] : v[i]) + inc;
+        }
+        lds_store4(nxt + s * TL::PLANE + off, o);
+    }
+}
+
+// the owned BX x BY region of a level buffer -> its frame, by the lanes [FIRST, NT).  WHICH 0: all of it; 1: the block of rows /
+// 16-byte chunks that covers what I_2 overwrites (level 1 only); 2: everything but that block
+template <typename T, int K, int BX, int BY, int NT, int FIRST, bool PADDED, int WHICH>
+__device__ __forceinline__ void persist_fwd_store(const T* buf, T* __restrict__ dst, const TileGeom& g, int ty0, int tx0)
+{
+    using TL = Tile<K, BX, BY>;
+    constexpr int VEC = vec_width<T>::value;
+    static_assert(VEC == 4, "float32 chunks");
+    constexpr int BXV = BX / VEC, N = 2 * BY * BXV, LANES = NT - FIRST;
+    constexpr int SIDE = BX - 4 * (K - 1), O2 = (BX - SIDE) / 2;           // I_2's output square: side 20 at offset 6
+    constexpr int R0 = O2, R1 = O2 + SIDE, C0 = O2 / VEC, C1 = (O2 + SIDE + VEC - 1) / VEC;
+    static_assert(C0 * VEC >= 2 && C1 * VEC <= BX - 2 && R0 >= 2 && R1 <= BY - 2, "the early block lies inside I_0's output");
+    if ((int)threadIdx.x < FIRST) return;
+    for (int i = (int)threadIdx.x - FIRST; i < N; i += LANES) {
+        const int s = i / (BY * BXV);
+        const int r = i - s * (BY * BXV);
+        const int y = r / BXV, c = r - y * BXV;
+        const bool early = y >= R0 && y < R1 && c >= C0 && c < C1;
+        if (WHICH == 1 && !early) continue;
+        if (WHICH == 2 && early) continue;
+        const T* src = buf + s * TL::PLANE + (2 * K + y) * TL::LX + 2 * K + c * VEC;
+        Pack<T, VEC> p;
+        if constexpr (PADDED && lds_pad0<T>::value != 0) {
+            const Pack<T, 2> a = ld<T, 2>(src), b = ld<T, 2>(src + 2);
+            p.v[0] = a.v[0]; p.v[1] = a.v[1]; p.v[2] = b.v[0]; p.v[3] = b.v[1];
+        } else {
+            p = ld<T, VEC>(src);
+        }
+        st_frame_wt<T, VEC>(dst + s * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC, p);
+    }
+}
+
+#ifndef PI_FWD_PERSIST_REQ_AFTER
+#define PI_FWD_PERSIST_REQ_AFTER 0      // the ring is requested after pass P<this> (0 or 1).  Measured (tools/fwd_dev.hip): after P0 --
+#endif                                  // 0.76 us into the group -- 5.74 us per group; after P1 (1.6 us) 6.55; one launch per group 6.64
+#ifndef PI_FWD_PERSIST_PAUSE
+#define PI_FWD_PERSIST_PAUSE 0          // s_sleep units before the request
+#endif
+
+template <typename T, int K, int BX, int BY, int NT>
+__global__ void __launch_bounds__(NT)
+pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngroups are written */, long frame_stride,
+                        const T* __restrict__ P, TileGeom g, PersistArgs pa)
+{
+    static_assert(sizeof(T) == 4 && BX == BY && K == 4 && BX == 32 && NT == 512, "float32, 32 x 32 tiles, four sub-steps, 8 waves");
+    using TL = Tile<K, BX, BY>;
+    constexpr int HW = 2 * K, LXW = TL::LX;
+    constexpr int BANDH = BX * BX - (BX - 2 * HW) * (BX - 2 * HW);      // border values per species
+    constexpr int RINGH = LXW * LXW - BX * BX;                          // halo values per species
+    constexpr int NPUB = (2 * BANDH + NT - 1) / NT, NGAT = (2 * RINGH + NT - 1) / NT;
+    static_assert(NPUB + 2 * NGAT <= 13, "tables fit the LDS the host reserves");
+    constexpr int IDLE = 4 * WAVE;                                      // waves 4..7 own no strip in P0, P1, P3, P4, P5
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* b0 = reinterpret_cast<T*>(smem_raw) + lds_pad0<T>::value;
+    T* b1 = reinterpret_cast<T*>(smem_raw) + 2 * TL::PLANE + lds_pad1<T>::value;
+    const int tile = tile_of_block(blockIdx.x, g);
+    const int tyi = tile / g.tiles_x, txi = tile % g.tiles_x, tiles_y = g.H / BY;
+    const int ty0 = tyi * BY, tx0 = txi * BX;
+    const int ntiles = g.tiles_x * tiles_y;
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    gu64* outbox = (gu64*)pa.outbox;
+
+    // LDS: state buffers | int tables (publish, gather, geometry) | abort word
+    int* tab_pub = reinterpret_cast<int*>(smem_raw + tile_state_bytes<T, K, BX, BY>());     // [NPUB][NT]: LDS position of a border value
+    int* tab_gl = tab_pub + NPUB * NT;                                      // [NGAT][NT]: LDS position of a halo value
+    int* tab_gs = tab_gl + NGAT * NT;                                       // [NGAT][NT]: granule index inside a parity half
+    unsigned* tab_geo = reinterpret_cast<unsigned*>(tab_pub + 13 * NT);     // [6][NT]: the lane's strip in each pass
+    int* wg_abort = tab_pub + PERSIST_SPLIT_TABLE_ROWS * NT;
+    if (threadIdx.x == 0) {                                                 // residency roll call (see pi_adj2d_persist_kernel)
+        *wg_abort = 0;
+        const unsigned n = __hip_atomic_fetch_add(pa.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (n == (unsigned)ntiles && pa.host) __hip_atomic_store(pa.host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    tab_geo[0 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 0>(g, ty0, tx0);
+    tab_geo[1 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 1>(g, ty0, tx0);
+    tab_geo[2 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 2>(g, ty0, tx0);
+    tab_geo[3 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 3>(g, ty0, tx0);
+    tab_geo[4 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 4>(g, ty0, tx0);
+    tab_geo[5 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 5>(g, ty0, tx0);
+#pragma unroll
+    for (int q = 0; q < NPUB; ++q) {                       // (the tables of pi_adj2d_persist_split_kernel)
+        const int i = (int)threadIdx.x + q * NT;
+        int pl = -1;
+        if (i < 2 * BANDH) {
+            const int sp = i / BANDH, e = i - sp * BANDH;
+            int y, x;                                      // inverse of band_index
+            if (e < HW * BX) { y = e / BX; x = e - y * BX; }
+            else if (e < 2 * HW * BX) { const int m = e - HW * BX; y = BX - HW + m / BX; x = m % BX; }
+            else { const int m = e - 2 * HW * BX; y = HW + m / (2 * HW); const int c = m % (2 * HW); x = c < HW ? c : BX - 2 * HW + c; }
+            pl = sp * TL::PLANE + (HW + y) * LXW + HW + x;
+        }
+        tab_pub[q * NT + (int)threadIdx.x] = pl;
+    }
+#pragma unroll
+    for (int q = 0; q < NGAT; ++q) {
+        const int r = (int)threadIdx.x + q * NT;
+        int gl = -1, gs = 0;
+        if (r < 2 * RINGH) {
+            const int sp = r / RINGH, e = r - sp * RINGH;
+            int wy, wx;                                    // ring positions row-major over the window, skipping the centre
+            if (e < HW * LXW) { wy = e / LXW; wx = e - wy * LXW; }
+            else if (e < HW * LXW + BX * 2 * HW) { const int m = e - HW * LXW; wy = HW + m / (2 * HW); const int c = m % (2 * HW); wx = c < HW ? c : BX + c; }
+            else { const int m = e - HW * LXW - BX * 2 * HW; wy = HW + BX + m / LXW; wx = m % LXW; }
+            const int gy = ty0 + wy - HW, gx = tx0 + wx - HW;                       // global point (may wrap)
+            const int nty = ((gy + g.H) / BY) % tiles_y, ntx = ((gx + g.W) / BX) % g.tiles_x;
+            const int ly = (gy + g.H) % BY, lx = (gx + g.W) % BX;
+            gl = sp * TL::PLANE + wy * LXW + wx;
+            gs = (nty * g.tiles_x + ntx) * (2 * BANDH) + sp * BANDH + band_index<BX, HW>(ly, lx);
+        }
+        tab_gl[q * NT + (int)threadIdx.x] = gl;
+        tab_gs[q * NT + (int)threadIdx.x] = gs;
+    }
+    // group 0 starts from frame t0 in memory (window = tile + ring), like a launch of pi_fwd2d_tile_kernel
+    tile_load<T, K, BX, BY, NT>(frames, g, ty0, tx0, b0);
+    __syncthreads();
+    const int tid = (int)threadIdx.x;
+    for (int grp = 0; grp < pa.ngroups; ++grp) {
+        T* fr = frames + (long)grp * K * frame_stride;                    // this group's frame t: fr + m * frame_stride = level m
+        PI_PSTAMP(0);
+        // ---- P0: I_0 (b0 -> b1); the idle waves store level 4 of the previous group (= this group's level 0, complete in b0) ----
+        if (grp > 0) persist_fwd_store<T, K, BX, BY, NT, IDLE, true, 0>(b0, fr, g, ty0, tx0);
+        fwd_strip_geo<T, K, BX, BY>(b0, b1, P, tab_geo[0 * NT + tid]);
+        lds_barrier();
+        PI_PSTAMP(1);
+        const unsigned epoch = (unsigned)grp;
+        gu64* half = outbox + (size_t)(epoch & 1u) * (size_t)ntiles * (2 * BANDH);
+        int gs[NGAT];
+        unsigned long long gx[NGAT];
+        auto request = [&]() {
+            if (grp > 0) {
+#if PI_FWD_PERSIST_PAUSE
+                __builtin_amdgcn_s_sleep(PI_FWD_PERSIST_PAUSE);
+#endif
+#pragma unroll
+                for (int q = 0; q < NGAT; ++q) {
+                    gs[q] = tab_gs[q * NT + tid];
+                    gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (lanes without: granule 0)
+                }
+            }
+        };
+        if constexpr (PI_FWD_PERSIST_REQ_AFTER == 0) request();
+        // ---- P1: I_1 (b1 -> b0 centre); the idle waves store the block of level 1 that I_2 will overwrite ----
+        persist_fwd_store<T, K, BX, BY, NT, IDLE, false, 1>(b1, fr + frame_stride, g, ty0, tx0);
+        fwd_strip_geo<T, K, BX, BY>(b1, b0, P, tab_geo[1 * NT + tid]);
+        PI_PSTAMP(2);
+        if constexpr (PI_FWD_PERSIST_REQ_AFTER == 1) request();
+        if (grp > 0) {
+            int gl[NGAT];
+#pragma unroll
+            for (int q = 0; q < NGAT; ++q) gl[q] = tab_gl[q * NT + tid];
+            const unsigned long long t0 = wall_clock64();
+            const unsigned long long bound = grp == 1 ? pa.first_timeout_ticks : pa.timeout_ticks;
+            bool failed = false;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < NGAT; ++q)
+                    if (gl[q] >= 0) ok &= (unsigned)(gx[q] >> 32) == epoch;
+                if (__all(ok)) break;
+                if (wall_clock64() - t0 > bound ||
+                    __hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { failed = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int q = 0; q < NGAT; ++q)
+                    if (gl[q] >= 0 && (unsigned)(gx[q] >> 32) != epoch)
+                        gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (failed) {
+                if (threadIdx.x % WAVE == 0) *wg_abort = 1;
+            } else {
+                // (the ring of b0 -- level 0 -- is read by A_0 only; I_1 above wrote b0's centre)
+#pragma unroll
+                for (int q = 0; q < NGAT; ++q)
+                    if (gl[q] >= 0) b0[gl[q]] = __builtin_bit_cast(T, (unsigned)gx[q]);
+            }
+        }
+        lds_barrier();
+        if (grp > 0 && *wg_abort) {                        // ABORT: the host re-runs the rollout with one launch per group
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(pa.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_exchange(pa.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && pa.host) {
+                    __hip_atomic_store(pa.host + 1, grp - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pa.host + 2, tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pa.host + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            return;
+        }
+        PI_PSTAMP(3);
+        // ---- P2: I_2 (b0 centre -> b1 centre) next to A_0 (b0 with its ring -> b1 outside I_0's square) ----
+        fwd_strip_geo<T, K, BX, BY>(b0, b1, P, tab_geo[2 * NT + tid]);
+        lds_barrier();
+        PI_PSTAMP(4);
+        // ---- P3: A_1 (b1 -> b0); level 1 is complete in b1 outside the block stored in P1 ----
+        persist_fwd_store<T, K, BX, BY, NT, IDLE, false, 2>(b1, fr + frame_stride, g, ty0, tx0);
+        fwd_strip_geo<T, K, BX, BY>(b1, b0, P, tab_geo[3 * NT + tid]);
+        lds_barrier();
+        PI_PSTAMP(5);
+        // ---- P4: A_2 (b0 -> b1); level 2 is complete in b0 ----
+        persist_fwd_store<T, K, BX, BY, NT, IDLE, true, 0>(b0, fr + 2 * frame_stride, g, ty0, tx0);
+        fwd_strip_geo<T, K, BX, BY>(b0, b1, P, tab_geo[4 * NT + tid]);
+        lds_barrier();
+        PI_PSTAMP(6);
+        // ---- P5: I_3 + A_3 (b1 -> b0); level 3 is complete in b1 ----
+        persist_fwd_store<T, K, BX, BY, NT, IDLE, false, 0>(b1, fr + 3 * frame_stride, g, ty0, tx0);
+        fwd_strip_geo<T, K, BX, BY>(b1, b0, P, tab_geo[5 * NT + tid]);
+        lds_barrier();
+        PI_PSTAMP(7);
+        if (grp + 1 == pa.ngroups) {                       // the last level 4: stored by everybody
+            tile_store<T, K, BX, BY, NT, true>(b0, fr + (long)K * frame_stride, g, ty0, tx0);
+            break;
+        }
+        // ---- publish my band of level 4 (complete since the barrier) ----
+        const unsigned ep1 = (unsigned)grp + 1u;
+        gu64* mine = outbox + (size_t)(ep1 & 1u) * (size_t)ntiles * (2 * BANDH) + (size_t)tile * (2 * BANDH);
+#pragma unroll
+        for (int q = 0; q < NPUB; ++q) {
+            const int pl = tab_pub[q * NT + tid];
+            if (pl >= 0) {
+                const unsigned v = __builtin_bit_cast(unsigned, b0[pl]);
+                __hip_atomic_store(mine + tid + q * NT, ((unsigned long long)ep1 << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        PI_PSTAMP(8);
+        // (no barrier: P0 reads b0 -- complete -- and writes b1 inside I_0's square; the store of level 3 from b1 was issued before
+        // the barrier that ended P5 -- its LDS reads are done)
+    }
+}
+
 }  // namespace pi

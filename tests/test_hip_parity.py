@@ -744,6 +744,51 @@ def test_persistent_sweep_equals_launch_per_group(shape, T, hip_device):
     assert torch.equal(a0, c0) and torch.equal(a0, d0)
 
 
+@pytest.mark.parametrize("shape,T", [((384, 384), 35), ((384, 512), 33), ((512, 512), 41), ((448, 448), 64)])
+def test_persistent_forward_equals_launch_per_group(shape, T, hip_device):
+    """Round 4: the forward rollout of a grid of whole 32 x 32 tiles (16 .. #CUs of them) as ONE launch of resident workgroups
+    (pi_fwd2d_persist_kernel, option fwd_persist): every frame of the trajectory is the launch-per-group kernel's bit for bit
+    (same strip arithmetic; the halo travels through tagged granules, frames are stored by the waves that idle in a pass), T not
+    a multiple of four (the remaining steps run on the tile / direct kernels), the C oracle on the small case, twice on two
+    streams, and no aborts."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    assert _lib.rollout_plan(0, shape, 4)["fwd_persistent"] and not _lib.rollout_plan(0, shape, 4, "fwd_persist=0")["fwd_persistent"]
+    assert not _lib.rollout_plan(0, shape, 8)["fwd_persistent"] and not _lib.rollout_plan(8, shape, 4)["fwd_persistent"]
+    assert not _lib.rollout_plan(0, (100, 100), 4)["fwd_persistent"] and not _lib.rollout_plan(0, (1024, 1024), 4)["fwd_persistent"]
+    short = torch.empty((24 + 1, 2) + shape, dtype=torch.float32, device=hip_device)      # fewer than eight groups: launch per group
+    short[0] = 0.5
+    n_short = _lib.persist_status()["launches"]
+    pa.rollout_fwd_(short, dev_t(random_block(0, 2, np.float32, 31, scale=0.1), hip_device))
+    assert _lib.persist_status()["launches"] == n_short
+    rs = np.random.RandomState(6)
+    P = dev_t(random_block(0, 2, np.float32, 31, scale=0.1), hip_device)
+    h0 = rs.uniform(0, 1, (2,) + shape).astype(np.float32)
+    n0 = _lib.persist_status()
+    a = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=hip_device)
+    b = torch.full_like(a, float("nan"))
+    a[0] = dev_t(h0, hip_device)
+    b[0] = a[0]
+    pa.rollout_fwd_(a, P)
+    pa.rollout_fwd_(b, P, options={"fwd_persist": 0})
+    n1 = _lib.persist_status()
+    assert n1["launches"] == n0["launches"] + 1 and n1["aborts"] == n0["aborts"]
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    if shape == (384, 384):
+        assert np.array_equal(a[:9].cpu().numpy(), o_rollout_fwd(h0, P.cpu().numpy(), 8))
+    s2 = torch.cuda.Stream(device=hip_device)
+    c = torch.empty_like(a)
+    c[0] = a[0]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s2):
+        pa.rollout_fwd_(c, P)
+    d = torch.empty_like(a)
+    d[0] = a[0]
+    pa.rollout_fwd_(d, P)
+    torch.cuda.synchronize()
+    assert torch.equal(a, c) and torch.equal(a, d)
+
+
 def test_persistent_sweeps_fuzz(hip_device):
     """Random shapes (both resident flavours), horizons and gradient-frame patterns: the one-launch sweeps give dL/dh0 bit for
     bit as the launch-per-group sweep does -- blown-up trajectories included (same NaN bit patterns) -- and no launch aborts."""

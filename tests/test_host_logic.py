@@ -542,7 +542,7 @@ def test_rollout_plan_follows_the_dispatch_rules():
     assert plan(0, (544, 544), 4, "tile_wide=0")["tile"] == (32, 32, 512) and plan(8, (544, 544), 4)["tile"] == (32, 32, 512)
     p = plan(0, (128, 128, 128), 4)                       # 3D Gray-Scott 128^3: bricks, two planes forward, one adjoint
     assert p == {"fwd": "brick3d", "bwd": "brick3d", "fused_gradients": True, "fwd_steps_per_launch": 1,
-                 "bwd_steps_per_launch": 1, "fwd_planes_per_pass": 2, "bwd_planes_per_pass": 1, "brick_lanes": 256, "tile": None, "tile_fwd": None, "bwd_persistent": False}
+                 "bwd_steps_per_launch": 1, "fwd_planes_per_pass": 2, "bwd_planes_per_pass": 1, "brick_lanes": 256, "tile": None, "tile_fwd": None, "bwd_persistent": False, "fwd_persistent": False}
     assert plan(0, (48, 48, 48), 4)["fwd_planes_per_pass"] == 1 and plan(0, (48, 48, 48), 4)["brick_lanes"] == 256
     assert plan(0, (32, 256, 256), 4, "brick_nt=512")["brick_lanes"] == 512 and plan(0, (144, 144, 144), 4)["brick_lanes"] == 256
     p = plan(0, (256, 256, 256), 4)                       # forward keeps the z-march from 8 M points on, the adjoint takes bricks

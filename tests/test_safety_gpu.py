@@ -95,6 +95,40 @@ def test_persistent_sweep_aborts_cleanly_and_falls_back(hip_device):
     assert _lib.persist_status()["launches"] == s2["launches"] + 1 and torch.equal(d0, ref0)
 
 
+def test_persistent_forward_aborts_cleanly_and_falls_back(hip_device):
+    """The resident forward under the same stress (CUs held by another kernel): the launch gives up at its first hand-over, the
+    same rollout_fwd_ call recomputes the trajectory launch by launch -- bit-identical to fwd_persist=0, no NaNs -- and the
+    device stays on the launch-per-group path until persist_reset."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    pa.set_option("persist_reset", 1)
+    traj, _, P = _sweep_problem(hip_device)
+    ref = torch.empty_like(traj)
+    ref[0] = traj[0]
+    pa.rollout_fwd_(ref, P, options={"fwd_persist": 0})
+    s0 = _lib.persist_status()
+    a = torch.full_like(traj, float("nan"))
+    a[0] = traj[0]
+    pa.rollout_fwd_(a, P)                                         # healthy: one resident launch
+    s1 = _lib.persist_status()
+    assert s1["launches"] == s0["launches"] + 1 and s1["aborts"] == s0["aborts"] and torch.equal(a, ref)
+    torch.cuda.synchronize()
+    try:
+        _hog(144, 150 * 1024, 1500, hip_device)                  # (two of its 77 KB workgroups fit a CU: 112 free CUs hold 224 < 256)
+        b = torch.full_like(traj, float("nan"))
+        b[0] = traj[0]
+        pa.rollout_fwd_(b, P, options={"persist_first_timeout_ms": 20})
+        s2 = _lib.persist_status()
+        torch.cuda.synchronize()
+        assert s2["launches"] == s1["launches"] + 1 and s2["aborts"] == s1["aborts"] + 1 and s2["disabled_on_current_device"]
+        assert torch.isfinite(b).all() and torch.equal(b, ref)
+        assert not _lib.rollout_plan(0, (512, 512), 4)["fwd_persistent"]
+    finally:
+        torch.cuda.synchronize()
+        pa.set_option("persist_reset", 1)
+    assert _lib.rollout_plan(0, (512, 512), 4)["fwd_persistent"]
+
+
 def test_persistent_sweep_abort_without_handshake_is_reported(hip_device):
     """persist_handshake=0 (fire and forget): an aborted launch leaves its outputs unwritten and the NEXT entry point raises
     (PERCNN_PI_EASYNC), once; after persist_reset everything is back."""

@@ -89,6 +89,57 @@ int main(int argc, char** argv)
         std::printf("round %d: us per launch of %d steps: 512 lanes %.2f | 1024 lanes %.2f   (us per step %.3f | %.3f)\n", rep, K, 1e3 * ms[0] / nl,
                     1e3 * ms[1] / nl, 1e3 * ms[0] / T, 1e3 * ms[1] / T);
     }
+    // ---- the whole rollout as ONE launch of resident workgroups (pi_fwd2d_persist_kernel) ----
+    {
+        constexpr int NT = 512, BAND = 2 * (B * B - (B - 16) * (B - 16));
+        const int tiles = (N / B) * (N / B), ngroups = T / K;
+        const size_t outbox_bytes = (size_t)2 * tiles * BAND * sizeof(unsigned long long);
+        unsigned long long* outbox; unsigned* sync; int* host;
+        CK(hipMalloc(&outbox, outbox_bytes));
+        CK(hipMalloc(&sync, 64));
+        CK(hipHostMalloc(&host, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        auto* kp = pi::pi_fwd2d_persist_kernel<float, K, B, B, NT>;
+        const size_t lds_p = pi::tile_state_bytes<float, K, B, B>() + (size_t)pi::PERSIST_SPLIT_TABLE_ROWS * NT * sizeof(int) + 16;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+        auto run_p = [&]() {
+            CK(hipMemsetAsync(outbox, 0, outbox_bytes, st));
+            CK(hipMemsetAsync(sync, 0, 64, st));
+            host[0] = 0; host[3] = 0;
+            pi::PersistArgs pa{};
+            pa.outbox = outbox; pa.sync = sync; pa.host = host; pa.ngroups = ngroups;
+            pa.timeout_ticks = 200000000ull; pa.first_timeout_ticks = 200000000ull;
+            hipLaunchKernelGGL(kp, dim3(tiles), dim3(NT), lds_p, st, dB, fs, dP, g, pa);
+        };
+        run_p();
+        check("persistent forward");
+        std::printf("  host state: roll call %d, aborted %d\n", host[0], host[3]);
+        for (int rep = 0; rep < reps; ++rep) {
+            float ms0, ms1;
+            CK(hipEventRecord(e0, st)); launch<512>(dB, fs, dP, g, T, st); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms0, e0, e1));
+            CK(hipEventRecord(e0, st)); run_p(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms1, e0, e1));
+            std::printf("persistent round %d: us per group of %d steps: launch per group %.2f | one resident launch %.2f   (us per step %.3f | %.3f)\n",
+                        rep, K, 1e3 * ms0 / ngroups, 1e3 * ms1 / ngroups, 1e3 * ms0 / T, 1e3 * ms1 / T);
+        }
+    }
+#ifdef PI_PERSIST_STAMPS
+    {   // device timeline of one group of the resident launch: medians over the workgroups of wave 0's / wave 7's stamps
+        static long long hs[256 * 8 * 16];
+        CK(hipMemcpyFromSymbol(hs, HIP_SYMBOL(pi::pi_persist_stamps), sizeof(hs)));
+        const char* names[9] = {"group start", "P0", "P1 computed", "ring in LDS", "P2", "P3", "P4", "P5", "published"};
+        for (int w = 0; w < 8; w += 7) {
+            std::printf("wave %d:", w);
+            for (int i = 0; i < 9; ++i) {
+                std::vector<double> v;
+                for (int b = 0; b < 256; ++b) v.push_back((hs[(b * 8 + w) * 16 + i] - hs[(b * 8 + 0) * 16 + 0]) * 0.01);
+                std::sort(v.begin(), v.end());
+                std::printf(" %s %.2f", names[i], v[128]);
+            }
+            std::printf("\n");
+        }
+    }
+#endif
     // the same 250 launches as ONE graph launch (does a captured chain shorten the dependent-kernel boundary?)
     {
         hipGraph_t graph; hipGraphExec_t exec;
