@@ -209,6 +209,10 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *                  (pi_fwd2d_persist_kernel: the launch-per-group kernel's trajectory bit for bit; residency check, abort and
  *                  fallback as "tile_persist"; the library keeps 256 B + 24 KiB per tile of device scratch per device for its
  *                  granule outbox, allocated at the first such call); 0: one launch per four steps
+ *   "fwd_persist_per_cu"  1 (default) or 2: two of its 77 KB workgroups fit a CU, so grids of up to 2 x #CUs tiles can run the
+ *                  resident forward (576^2 .. 704^2: -9 .. -16 % per forward step, profiles/r04_forward_persistent.txt).  Not the
+ *                  default: with every CU doubly booked any other kernel that holds LDS makes the launch abort, and an abort
+ *                  switches the resident launches off for the device until "persist_reset"
  *   "brick_wide"   1 (default): 3D rows of 65 .. 128 sixteen-byte chunks on 512-lane bricks where they win; 0: direct kernels
  *   "persist_reset"  (any value) re-arm the persistent sweep after an abort
  * Returns 0, or PERCNN_PI_EINVAL for an unknown key / bad value. */

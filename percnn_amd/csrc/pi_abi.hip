@@ -61,6 +61,7 @@ struct Options {
                             // this device (percnn_pi_persist_status).  0: no wait; an aborted launch is reported by the NEXT
                             // entry point (PERCNN_PI_EASYNC) instead
     int persist_small = 1;      // the 32 x 8-tile regime (grids below ~300^2, split schedule) as one persistent launch too
+    int fwd_persist_per_cu = 1; // ... on grids of up to this many tiles per CU (1 or 2)
     int fwd_persist = 1;        // the FORWARD rollout of such a grid as one launch of resident workgroups too (pi_fwd2d_persist_kernel;
                             // same residency check / abort / fallback; its granule outbox is a per-device scratch of the library)
     int persist_split = 1;      // persistent sweep: 1 = split flavour (pi_adj2d_persist_split_kernel: the halo-independent
@@ -1352,7 +1353,8 @@ bool fwd_persist_ok(const Problem& p, int ngroups, hipStream_t st)
     if (p.n0 % TILE_B || p.W % TILE_B) return false;
     const int64_t tiles = (p.n0 / TILE_B) * (p.W / TILE_B);
     const int cus = device_cu_count();
-    if (tiles < 16 || cus <= 0 || tiles > cus) return false;
+    // (its 77 KB workgroups fit two per CU: up to 2 x #CUs tiles, option fwd_persist_per_cu; the launch asks the runtime)
+    if (tiles < 16 || cus <= 0 || tiles > (int64_t)cus * p.opt.fwd_persist_per_cu) return false;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (st && (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) return false;
     return true;
@@ -1370,12 +1372,12 @@ hipError_t launch_fwd_persist(T* frame_t0, int ngroups, const T* P, const Proble
     const size_t lds = pi::tile_state_bytes<T, K, TILE_B, TILE_B>() + (size_t)pi::PERSIST_SPLIT_TABLE_ROWS * NT * sizeof(int) + 16;
     auto* k = pi::pi_fwd2d_persist_kernel<T, K, TILE_B, TILE_B, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
-    static int resident[16] = {};                           // per device: does one workgroup fit a CU? (asked once)
+    static int resident[16] = {};                           // per device: workgroups that fit a CU (asked once; -1: none)
     if (!resident[dev]) {
         int nb = 0;
-        resident[dev] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, NT, lds) == hipSuccess && nb >= 1) ? 1 : -1;
+        resident[dev] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, NT, lds) == hipSuccess && nb >= 1) ? nb : -1;
     }
-    if (resident[dev] < 0) return hipErrorCooperativeLaunchTooLarge;
+    if (resident[dev] < 0 || (int64_t)grid > (int64_t)device_cu_count() * resident[dev]) return hipErrorCooperativeLaunchTooLarge;
     // per-device scratch: 256 B of sync words | granule outbox (allocated once, sized for this grid or larger)
     const size_t need = 256 + persist_outbox_bytes(p);
     unsigned char* scratch;
@@ -2508,6 +2510,11 @@ int apply_option(Options& o, const char* key, long value)
     if (!std::strcmp(key, "persist_split")) { o.persist_split = value != 0; return 0; }
     if (!std::strcmp(key, "persist_small")) { o.persist_small = value != 0; return 0; }
     if (!std::strcmp(key, "fwd_persist")) { o.fwd_persist = value != 0; return 0; }
+    if (!std::strcmp(key, "fwd_persist_per_cu")) {
+        if (value < 1 || value > 2) return PERCNN_PI_EINVAL;
+        o.fwd_persist_per_cu = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "persist_timeout_ms") || !std::strcmp(key, "persist_first_timeout_ms")) {
         if (value < 1 || value > 600000) return PERCNN_PI_EINVAL;
         (key[8] == 'f' ? o.persist_first_timeout_ms : o.persist_timeout_ms) = (int)value;

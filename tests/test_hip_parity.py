@@ -776,6 +776,17 @@ def test_persistent_forward_equals_launch_per_group(shape, T, hip_device):
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     if shape == (384, 384):
         assert np.array_equal(a[:9].cpu().numpy(), o_rollout_fwd(h0, P.cpu().numpy(), 8))
+    if shape == (384, 384):                                # two workgroups per CU (opt-in): a grid of 400 tiles
+        big = (640, 640)
+        assert not _lib.rollout_plan(0, big, 4)["fwd_persistent"] and _lib.rollout_plan(0, big, 4, "fwd_persist_per_cu=2")["fwd_persistent"]
+        e = torch.empty((33 + 1, 2) + big, dtype=torch.float32, device=hip_device)
+        e[0] = dev_t(rs.uniform(0, 1, (2,) + big).astype(np.float32), hip_device)
+        f = e.clone()
+        n2 = _lib.persist_status()
+        pa.rollout_fwd_(e, P, options={"fwd_persist_per_cu": 2})
+        pa.rollout_fwd_(f, P)
+        n3 = _lib.persist_status()
+        assert n3["launches"] == n2["launches"] + 1 and n3["aborts"] == n2["aborts"] and torch.equal(e, f)
     s2 = torch.cuda.Stream(device=hip_device)
     c = torch.empty_like(a)
     c[0] = a[0]
