@@ -2137,13 +2137,21 @@ __device__ __forceinline__ void persist_fwd_store(const T* buf, T* __restrict__ 
         } else {
             p = ld<T, VEC>(src);
         }
+        #if PI_FWD_PERSIST_WT
         st_frame_wt<T, VEC>(dst + s * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC, p);
+#else
+        *reinterpret_cast<Pack<T, VEC>*>(dst + s * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC) = p;
+#endif
     }
 }
 
 #ifndef PI_FWD_PERSIST_REQ_AFTER
 #define PI_FWD_PERSIST_REQ_AFTER 0      // the ring is requested after pass P<this> (0 or 1).  Measured (tools/fwd_dev.hip): after P0 --
 #endif                                  // 0.76 us into the group -- 5.74 us per group; after P1 (1.6 us) 6.55; one launch per group 6.64
+#ifndef PI_FWD_PERSIST_WT
+#define PI_FWD_PERSIST_WT 0             // frame stores of the resident forward: 0 = plain (write-back) stores.  Nobody reads a frame from
+#endif                                  // memory before the launch ends (the state lives in LDS, halos travel as granules), and write-through
+                                        // stores compete with the latency-critical granule loads: 5.8 -> 5.45 us per group (tools/fwd_dev.hip)
 #ifndef PI_FWD_PERSIST_PAUSE
 #define PI_FWD_PERSIST_PAUSE 0          // s_sleep units before the request
 #endif
