@@ -105,6 +105,9 @@ int main(int argc, char** argv)
     auto* kp1 = pi::pi_adj2d_persist_split_kernel<float, K, B, B, NT>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kp0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kp1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+    // what-if (timing only, results wrong): argv[3] = "l2" makes every group of the split sweep read the SAME operand frames, i.e. from
+    // the L2 instead of HBM -- what the streaming of 16 MB of operands per group costs the sweep
+    const long fs_split = (argc > 3 && !std::strcmp(argv[3], "l2")) ? 0 : fs;
     auto run_persist = [&](int split) {
         CK(hipMemsetAsync(outbox, 0, outbox_bytes, st));
         CK(hipMemsetAsync(sync, 0, 64, st));
@@ -113,7 +116,7 @@ int main(int argc, char** argv)
         pa.outbox = outbox; pa.sync = sync; pa.host = host; pa.ngroups = ngroups;
         pa.timeout_ticks = 200000000ull; pa.first_timeout_ticks = 200000000ull;
         pa.t_top = T; pa.masked = 0;
-        if (split) hipLaunchKernelGGL(kp1, dim3(tiles), dim3(NT), lds_p, st, hfr, gfr, afr, fs, (float*)nullptr, dpart, np, dP, g, pa);
+        if (split) hipLaunchKernelGGL(kp1, dim3(tiles), dim3(NT), lds_p, st, hfr, gfr, afr, fs_split, (float*)nullptr, dpart, np, dP, g, pa);
         else       hipLaunchKernelGGL(kp0, dim3(tiles), dim3(NT), lds_p, st, hfr, gfr, afr, fs, (float*)nullptr, dpart, np, dP, g, pa);
     };
 
