@@ -41,6 +41,10 @@ def test_library_exports_every_declared_symbol():
     assert percnn_amd.lib().percnn_pi_set_option(b"nonsense", 1) == -1
     assert percnn_amd.lib().percnn_pi_set_option(b"bwd_cpl", 0) == -1
     assert percnn_amd.lib().percnn_pi_set_option(b"bwd_cpl", 2) == 0
+    L = percnn_amd.lib()                                   # round 4: the resident forward's switches
+    assert L.percnn_pi_set_option(b"fwd_persist", 0) == 0 and L.percnn_pi_set_option(b"fwd_persist", 1) == 0
+    assert L.percnn_pi_set_option(b"fwd_persist_per_cu", 3) == -1 and L.percnn_pi_set_option(b"fwd_persist_per_cu", 0) == -1
+    assert L.percnn_pi_set_option(b"fwd_persist_per_cu", 2) == 0 and L.percnn_pi_set_option(b"fwd_persist_per_cu", 1) == 0
 
 
 def test_argument_errors_do_not_need_a_gpu():
