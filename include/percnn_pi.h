@@ -58,7 +58,9 @@
 extern "C" {
 #endif
 
-#define PERCNN_PI_ABI_VERSION 2   /* 2: percnn_pi_halo_ring gained `peer`; percnn_pi_peer_*, *_opt entry points */
+#define PERCNN_PI_ABI_VERSION 3   /* 2: percnn_pi_halo_ring gained `peer`; percnn_pi_peer_*, *_opt entry points.
+                                    3: step_bwd_rows, bwd_rows_finish, rollout_bwd_top, pack_fwd_guard, host_words_*, persist_status,
+                                       PERCNN_PI_EASYNC; debug_plan out[14] is a bit field; round 5: persist_fence */
 
 #define PERCNN_PI_SWEEP_ONLY 1    /* flags of percnn_pi_slab_step_bwd_*: adjoint state + diffusion-coefficient
                                    * gradients only; branch gradients come from percnn_pi_slab_wgrad_* later */

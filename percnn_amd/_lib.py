@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("PERCNN_PI_LIB", os.path.join(CSRC, "libpercnn_pi.so"))
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 _INC = os.path.join("..", "..", "include")
@@ -318,8 +318,9 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         names = {-1: "invalid argument", -2: "workspace too small",
                  -3: "grid too large for the step kernels' 32-bit offsets (a 2D field or a 3D plane of >= 4 GiB per species)",
-                 -4: "an EARLIER call's persistent tile sweep aborted on the device (its workgroups could not all be resident: "
-                     "another process / kernel holds CUs, or a CU mask is set) -- the results of that earlier backward are "
+                 -4: "an EARLIER call's persistent launch (resident forward or tile sweep) aborted on the device (its workgroups "
+                     "could not all be resident: another process / kernel holds CUs, or a CU mask is set) -- the results of "
+                     "that earlier persistent launch (forward or backward) are "
                      "invalid; this call launched nothing.  " + _persist_note()}
         raise RuntimeError(f"percnn_amd: {what} failed: {names.get(rc, 'hipError_t ' + str(rc))}")
 

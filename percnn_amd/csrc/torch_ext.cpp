@@ -49,8 +49,9 @@ constexpr int64_t NPOLY = 36, NADV = 60;
     case PERCNN_PI_EWORKSPACE: msg = "workspace too small"; break;
     case PERCNN_PI_ETOOLARGE: msg = "grid too large for the step kernels' 32-bit offsets (a 2D field or a 3D plane of >= 4 GiB per species)"; break;
     case PERCNN_PI_EASYNC:
-        msg = "an EARLIER call's persistent tile sweep aborted on the device (its workgroups could not all be resident: another "
-              "process / kernel holds CUs, or a CU mask is set) -- the results of that earlier backward are invalid; this call "
+        msg = "an EARLIER call's persistent launch (resident forward or tile sweep) aborted on the device (its workgroups could not "
+              "all be resident: another process / kernel holds CUs, or a CU mask is set) -- the results of that earlier "
+              "persistent launch (forward or backward) are invalid; this call "
               "launched nothing (percnn_amd._lib.persist_status() tells where)";
         break;
     default: msg = nullptr;
@@ -825,8 +826,15 @@ TORCH_LIBRARY_IMPL(percnn, Autograd, m)
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.doc() = "percnn_amd: eager fast path of the Pi-block step (see torch_ext.cpp)";
+    // (the pack node's ctx holds the SINK, never the BlockState: BlockState -> block -> grad_fn -> ctx -> BlockState would be a
+    // reference cycle through C++ that Python's collector cannot see -- ADVICE r4)
+    py::class_<GradSink, c10::intrusive_ptr<GradSink>>(m, "GradSink")
+        .def_property_readonly("task", [](const GradSink& s) { return s.task; });
     py::class_<BlockState, c10::intrusive_ptr<BlockState>>(m, "BlockState")
         .def_property_readonly("task", [](const BlockState& b) { return b.sink->task; })
+        .def_property_readonly("sink", [](const BlockState& b) { return b.sink; })
+        .def_property_readonly("holds_block", [](const BlockState& b) { return b.block.defined(); })
+        .def_property_readonly("held_frames", [](const BlockState& b) { return (int64_t)b.frames.size(); })
         .def_property_readonly("spec_launches", [](const BlockState& b) { return b.spec_launches; })
         .def_property_readonly("spec_hits", [](const BlockState& b) { return b.spec_hits; })
         .def_property("speculate", [](const BlockState& b) { return b.speculate; },
@@ -849,8 +857,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("new_block_state", [](const Tensor& like, int64_t np) {
         return c10::make_intrusive<BlockState>(at::zeros({np}, like.options().dtype(at::kDouble)));
     });
-    m.def("take_block_grad", [](const c10::intrusive_ptr<BlockState>& bs, const Tensor& like) -> c10::optional<Tensor> {
-        Tensor t = bs->sink->take(current_task(), like);
+    // the cell is done with this state (a backward pass consumed the block, the block was replaced or invalidated): drop the
+    // block, the speculated frames and the key, so that nothing reachable from the state refers to an autograd graph any more
+    m.def("release_block", [](const c10::intrusive_ptr<BlockState>& bs) {
+        std::lock_guard<std::mutex> lk(bs->mu);
+        bs->forget();
+        bs->block = Tensor();
+        bs->key = -1;
+    });
+    m.def("take_block_grad", [](const c10::intrusive_ptr<GradSink>& sink, const Tensor& like) -> c10::optional<Tensor> {
+        Tensor t = sink->take(current_task(), like);
         if (!t.defined()) return c10::nullopt;
         return t;
     });

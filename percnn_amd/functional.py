@@ -231,8 +231,9 @@ class PackBlockFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, meta, guard, acc, *tensors):
-        """acc: None, or the native BlockState whose workspace rows the per-step nodes of a reference-style loop leave their
-        parameter-gradient sums in (csrc/torch_ext.cpp: cell_step) -- this node delivers them, once per backward pass."""
+        """acc: None, or the native GradSink (``BlockState.sink``) whose workspace rows the per-step nodes of a reference-style
+        loop leave their parameter-gradient sums in (csrc/torch_ext.cpp: cell_step) -- this node delivers them, once per
+        backward pass.  The sink, not the BlockState: the state holds this node's output."""
         ctx.meta = meta
         ctx.acc = acc
         ctx.set_materialize_grads(False)

@@ -188,8 +188,18 @@ class RCNNCell(nn.Module):
         ``.data.uniform_()``, ``.data.fill_()``, ...): such edits do not move the version counters the cache is keyed on
         (``init_filter`` calls this itself).  Ordinary updates -- ``optimizer.step()``, ``load_state_dict``, ``p.copy_()`` under
         ``no_grad``, ``.to()``, replacing a Parameter or its ``.data`` -- are seen without it."""
+        self._drop_block()
+
+    def _drop_block(self) -> None:
+        """Forget the cached block AND empty its native state (block, speculated frames): the state is reachable from autograd
+        nodes' frames, so whatever it still held would keep an iteration's graph alive."""
+        acc = self.__dict__.get("_block_acc")
         self.__dict__["_block_cache"] = None
         self.__dict__["_block_acc"] = None
+        if acc is not None:
+            ext = _native_ext()
+            if ext is not None:
+                ext.release_block(acc)
 
     def _block_key(self):
         """What a packed block depends on: identity, version counter AND storage address of every parameter (optimizer.step(),
@@ -232,7 +242,16 @@ class RCNNCell(nn.Module):
                 if ext is not None:
                     acc = ext.new_block_state(w, max(F_pi.NPOLY, F_pi.param_count(self.hidden_channels)))
                     acc.speculate = bool(self.speculate)
+            old = self.__dict__.get("_block_acc")
+            if old is not None:
+                self._drop_block()                           # the replaced block's state lets go of its frames / block
+            self.__dict__["_acc_delivered"] = False
             P = self._param_block_uncached(acc)
+            if acc is not None and P.requires_grad and not self.__dict__.get("_acc_delivered"):
+                # the block came from the tensor-op assembly (a trainable stencil, a non-contiguous / mixed-dtype parameter):
+                # no node would ever deliver the sums per-step nodes leave in the state -> those steps return the block's
+                # gradient themselves (F_pi.pi_step), the state is not used (gradients were silently lost)
+                acc = None
             self.__dict__["_block_acc"] = acc
             if acc is not None and isinstance(key, int):
                 ext.bind_block(acc, P, key)                  # forward()'s one-call hit path (csrc/torch_ext.cpp: fast_forward)
@@ -243,8 +262,7 @@ class RCNNCell(nn.Module):
                 def consumed(_g, me=me, P_id=id(P)):          # a backward pass reached the block: next iteration, new block
                     cell = me()
                     if cell is not None and cell._block_cache is not None and id(cell._block_cache[1]) == P_id:
-                        cell._block_cache = None
-                        cell.__dict__["_block_acc"] = None
+                        cell._drop_block()
                 P.register_hook(consumed)
             self._block_cache = (key, P)
             return P
@@ -270,14 +288,16 @@ class RCNNCell(nn.Module):
         was = gd.factored
         factored = gd.decide(a_max)
         ub, vb = (float(x) for x in self.state_bound)
-        P = F_pi.PackBlockFunction.apply(meta_head + (not factored,), (gd.address, gd.next_seq(), ub, vb), acc, *tensors)
+        sink = None if acc is None else acc.sink          # (the node holds the SINK: holding the state would be a cycle)
+        self.__dict__["_acc_delivered"] = sink is not None
+        P = F_pi.PackBlockFunction.apply(meta_head + (not factored,), (gd.address, gd.next_seq(), ub, vb), sink, *tensors)
         if first and not torch.cuda.is_current_stream_capturing():
             ev = torch.cuda.Event()
             ev.record()
             ev.synchronize()
             if gd.decide(a_max) != factored:                  # the first value is in: ill-conditioned from the start
                 factored = gd.factored
-                P = F_pi.PackBlockFunction.apply(meta_head + (not factored,), (gd.address, gd.next_seq(), ub, vb), acc, *tensors)
+                P = F_pi.PackBlockFunction.apply(meta_head + (not factored,), (gd.address, gd.next_seq(), ub, vb), sink, *tensors)
         if factored != was:
             import warnings
             if factored and not self._guard_warned:
@@ -314,7 +334,8 @@ class RCNNCell(nn.Module):
                     return torch.ops.percnn.pack_block(tensors, *meta)    # inside a traced graph: see INTEGRATION.md)
                 if self.reaction == "poly" and self.poly_guard:
                     return self._pack_guarded(tensors, head, acc)
-                return F_pi.PackBlockFunction.apply(meta, None, acc, *tensors)
+                self.__dict__["_acc_delivered"] = acc is not None
+                return F_pi.PackBlockFunction.apply(meta, None, None if acc is None else acc.sink, *tensors)
         if torch.compiler.is_compiling():
             # traced by torch.compile: no host-side checks / caches inside the graph (the stencil was validated by the
             # eager call that preceded compilation or is validated by the first eager use)

@@ -235,7 +235,9 @@ from . import _lib as _lib_mod
 if _os.path.exists(_lib_mod.TORCH_EXT_PATH) and _os.path.exists(_lib_mod.LIB_PATH):
     # a tree that has not been built yet -- or holds a library older than its sources -- still imports (percnn_amd.build()
     # lives in the package); the first entry point that needs the operators loads them and raises if it cannot
+    # (ImportError / OSError: a percnn_torch.so built against another torch / ROCm -- undefined symbols at dlopen; CPU-side
+    # tools that never need the operators must still be able to import the package)
     try:
         load_native()
-    except RuntimeError:
+    except (RuntimeError, ImportError, OSError):
         pass

@@ -71,6 +71,11 @@ class HaloExchanger:
         self.next = (self.rank + 1) % self.world
         self._bufs = {}
 
+    @property
+    def ranks_seen(self) -> int:
+        """ranks of the group this exchanger talks to (transport-specific subclasses ask their own communicator)"""
+        return int(self.world)
+
     def _global(self, r):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
 
@@ -253,6 +258,13 @@ class RcclHaloExchanger(HaloExchanger):
             self._check(N.ncclRecv(ptr(s, halo - width), cnt, dt, self.prev, self._comm, stream), "ncclRecv")
             self._check(N.ncclRecv(ptr(s, halo + n), cnt, dt, self.next, self._comm, stream), "ncclRecv")
         self._check(N.ncclGroupEnd(), "ncclGroupEnd")
+
+    @property
+    def ranks_seen(self) -> int:
+        """how many ranks the communicator itself reports (ncclCommCount), not what torch.distributed was told"""
+        n = self._ct.c_int(0)
+        self._check(self._nccl.ncclCommCount(self._comm, self._ct.byref(n)), "ncclCommCount")
+        return int(n.value)
 
     def native_ring(self):
         if self.world == 1 and not self.force_p2p:
