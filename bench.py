@@ -1052,13 +1052,13 @@ def sharded_rollout(dev, dist, rank, world, full_shape, T, halo, reps, transport
     ok = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev if (dist is None or dist.get_backend() == "nccl") else "cpu")
     if dist is not None:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    name = "none (one rank: periodic wrap by device copies)" if local_wrap else type(ex).__name__
+    name = "none (one rank: periodic wrap by index inside the step launches)" if local_wrap else type(ex).__name__
     out = {"workload": f"gs3d {'x'.join(map(str, full_shape))} cut into {world} slab(s) of {planes} planes, Hc=2, "
                        f"T={T} fwd+bwd, forward halo {halo} (={halo // 2} steps per exchange), adjoint sweep "
                        f"exchanges 2 planes per step; native C loop (one call per rollout), overlap={int(overlap)}",
            "transport": name,
            "steps_per_sec_fwd_bwd": T / el, "us_per_time_step_fwd_bwd": el / T * 1e6,
-           "exchange": ("periodic wrap by device copies (one rank, no transport involved)" if local_wrap
+           "exchange": ("periodic wrap by index inside the step launches (one rank, no transport, no face copies)" if local_wrap
                         else {"PeerHaloExchanger": "peer mailboxes: put / take kernels + epoch flags (csrc/pi_peer.h)",
                               "RcclHaloExchanger": "ncclSend / ncclRecv groups issued by the native loop",
                               "HaloExchanger": "torch.distributed point-to-point"}[type(ex).__name__]
@@ -1067,6 +1067,13 @@ def sharded_rollout(dev, dist, rank, world, full_shape, T, halo, reps, transport
            "ranks_seen_by_transport": int(ex.ranks_seen),
            "points_per_rank": planes * int(np.prod(full_shape[1:])), "global_points": int(np.prod(full_shape)),
            "halo_bytes_per_exchange_per_direction": 2 * halo * int(np.prod(full_shape[1:])) * 4}
+    if breakdown and local_wrap:
+        # the launches each rank of a multi-rank run issues, minus the transport: face copies into the halo planes, the outer
+        # planes of every second forward step recomputed (until round 5 this WAS the one-rank schedule)
+        lw = slab.LocalWrapExchanger(copies=True)
+        comp = timed(lambda: run(lw), max(2, reps // 2))
+        out["multi_rank_launches_with_face_copies_us_per_time_step"] = comp / T * 1e6
+        run()                                    # the frames' interiors as the index-wrap schedule leaves them
     if breakdown and not local_wrap:
         lw = slab.LocalWrapExchanger()
         comp = timed(lambda: run(lw), max(2, reps // 2))
@@ -1158,7 +1165,7 @@ def sharded_series(dev, dist, rank, world, one_gpu, checkpoint=lambda res: None,
     force_p2p = bool(int(os.environ.get("PERCNN_FORCE_P2P", "0")))
     small = bool(int(os.environ.get("PERCNN_BENCH_SMALL", "0")))          # test mode: tiny grids, same control flow
     hw, planes, halo = (64, 8, 4) if small else (256, 32, 4)
-    Tw, reps = (6, 2) if small else (40, 5)
+    Tw, reps = (6, 2) if small else (100, 5)      # (T = 100: the rollout length of configs[4]; 40 until round 4)
     grids = (((32, 2), (16, 2)) if small else ((256, 10), (128, 40)))
     head_n, head_T = (32, 6) if small else (256, int(os.environ.get("PERCNN_BENCH_HEADLINE_T", "100")))
     sharded = world > 1 or force_p2p

@@ -175,6 +175,10 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *   "rz"           direct 3D kernels, pre-contracted blocks: consecutive planes per workgroup pass that share their plane
  *                  neighbours in registers (1, 2, 4; default 0 = by grid size: large grids 4 forward / 2 backward)
  *   "block_small"  1 (default): 128-thread workgroups for the direct kernels on grids below ~1 M points
+ *   "slab_local_index"   1 (default): native slab rollouts of ONE rank (ring == NULL) resolve the periodic wrap by index inside the
+ *                        step launches -- no face copies, no recomputed halo planes, the halo planes of the frames are neither read
+ *                        nor written; 0: by face copies into the halo planes (the launches of a multi-rank run minus its
+ *                        transport).  Per call: bit 1 of the `overlap` argument of percnn_pi_slab_rollout_* selects the copies.
  *   "slab_wide_adjoint"  1: the native slab backward over an RCCL ring exchanges once per two adjoint steps (default 0:
  *                  measured slower, an ncclGroup costs per operation)
  *   "lane_x"       direct kernels: log2 of the 16-byte chunks a wave takes from one row (2..6), or 7 = flat (a workgroup
@@ -389,6 +393,8 @@ int percnn_pi_peer_exchange_f64(double* slab, int ndim, const int64_t* shape, in
                                 percnn_pi_peer_ring* ring, void* stream);
 
 size_t percnn_pi_halo_ring_bytes(void);   /* sizeof(percnn_pi_halo_ring) of the library build: bindings check their layout */
+/* overlap: bit 0 = faces first, exchange on a side stream; bit 1 (ring == NULL only) = periodic wrap by face copies into the
+ * halo planes instead of by index (option "slab_local_index") */
 int percnn_pi_slab_rollout_fwd_f32(float* traj, const float* params, int hc, int ndim, const int64_t* shape, int halo,
                                    int T_steps, const percnn_pi_halo_ring* ring, int overlap, void* stream);
 int percnn_pi_slab_rollout_fwd_f64(double* traj, const double* params, int hc, int ndim, const int64_t* shape, int halo,

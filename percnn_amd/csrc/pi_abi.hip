@@ -81,6 +81,11 @@ struct Options {
     int slab_put_blocks = 16; // ... workgroups per direction of that fused put (a multiple of 4)
     int slab_fused_put = 1; // native slab rollouts over the peer mailboxes: the step kernel that writes a frame about to be exchanged
                             // also carries its faces into the neighbours' mailboxes (pi_peer.h "put fused into the step kernel")
+    int slab_local_index = 1;   // native slab rollouts of ONE rank (ring == NULL): 1 = the periodic wrap is resolved by index inside the
+                            // step launches (no face copies, no recomputed halo planes: 32 x 256^2, us per fwd+bwd step: 34.6 with one
+                            // copy launch per exchange -> see profiles/r05_slab_local_wrap.txt); 0 = by face copies into the halo
+                            // planes -- the launches of a multi-rank run minus its transport (what bench.py's compute / exchange
+                            // split times; also selected per call by bit 1 of the `overlap` argument)
     int slab_wide_adjoint = 0;  // native slab backward over RCCL: one exchange per TWO adjoint steps (4 adjoint planes + 2 dL/dtraj
                             // planes per side in one group call), the 2-plane strips next to the faces recomputed locally.
                             // Built for VERDICT r1 #3, measured SLOWER on MI355X (RCCL to self, 32 x 256^2 slab: 74.0 -> 79.6 us
@@ -93,6 +98,8 @@ struct Options {
     int brick_rz = 0;       // planes per brick (1, 2, 4; 0 = by size)
     int brick_xcd = 1;      // brick kernels: XCD regions split in y as well as in z where the counts divide (BrickGeom::xny):
                             // 0 never, 1 where it measured no worse (make_brick_geom), 2 always
+    int brick_xny = 0;      // ... 0 = regions sized by the L2 (make_brick_geom), 1 = contiguous plane ranges, 2 / 4 / 8 = force that many
+                            // row strips (tuning aid); -1 = the round-4 rule for forward steps of >= 8 M points (contiguous)
     int brick_wide = 1;     // 3D rows of 65 .. 128 chunks on 512-lane bricks (0: the direct kernels, as before round 4)
     int brick_nt = 0;       // lanes per brick workgroup: 512 = the wide flavour (pre-contracted blocks; see brick_nt_for), else 256
     int brick_wgs = 0;      // adjoint brick kernel: resident workgroups per CU that walk the bricks (0 = 4 / 2 by planes per brick)
@@ -154,6 +161,9 @@ struct Problem {
     int halo = 2;       // slab layout: planes present on each side of axis 0 (even, >= 2)
     int skip = 0;       // slab layout: outermost planes per side that this call neither reads nor writes
     int lo = -1, hi = -1;   // slab layout, plane-range calls: padded plane indices [lo, hi) this call computes
+    bool slab_periodic = false; // slab layout of ONE rank: the n0 interior planes are a periodic domain of their own -- the wrap is
+                                // resolved by index inside the step launches (plane -1 = interior plane n0 - 1), the halo planes
+                                // are neither read nor written
     Options opt;            // this call's tuning options: process defaults at entry + per-call overrides
     pi::LossInj loss{0.0, nullptr, 0};   // adjoint calls: what the injection pointer means (pi_device.h); mode 0 = dL/dout itself
 };
@@ -309,7 +319,11 @@ Geom make_geom(const Problem& p)
     g.n0 = (int)p.n0; g.n1 = (int)p.n1; g.W = (int)p.W;
     g.rows = (int)(p.n0 * p.n1);
     g.s0 = (long)(p.n1 * p.W);
-    if (p.slab) {
+    if (p.slab && p.slab_periodic) {
+        g.ss = (long)(p.n0 + 2 * p.halo) * g.s0;
+        g.off = (long)p.halo * g.s0;
+        g.wrap0 = 1;
+    } else if (p.slab) {
         // local array: n0 + 2*halo planes; this call computes planes [skip+2, n0+2*halo-skip-2)
         g.ss = (long)(p.n0 + 2 * p.halo) * g.s0;
         if (p.lo >= 0) {                                   // explicit plane range (communication overlap: faces first)
@@ -658,16 +672,32 @@ pi::BrickGeom make_brick_geom(const Problem& p, int vec, int rz, int nt = pi::BR
     // problem -- four planes per XCD before, as many halo planes as own ones -- 29.1 -> 34.5 k; neutral at 64^3 .. 160^3; the
     // 256^3 FORWARD loses (66 -> 76 us) while its adjoint gains a little, hence: option 1 = everywhere but forward steps of
     // 8 M points and more, 2 = everywhere
-    const bool split = p.opt.brick_xcd == 2 || (p.opt.brick_xcd == 1 && (adjoint || p.n < (int64_t(1) << 23)));
-    if (split && b.nblk % pi::NXCD == 0) {
-        double best = 4.0 * rz / (double)std::max<long>(1, (npg / pi::NXCD) * rz);     // halo share of the contiguous map: 4 planes / its planes
+    // Round 5 (profiles/r05_counters_summary.txt, TCC_EA0_RDREQ_128B): at 256^3 the memory-side reads were 1.44-1.48x the
+    // algorithmic ones -- the adjoint brick sweep asked the fabric for 579 MB where 403 MB are needed, ALL of the excess on the
+    // stencil-read field (2.3x): a region as tall as half the grid streams 2 MB of new lines through a 4 MB L2 per plane group,
+    // so the plane neighbours the next group would have found there are gone.  The regions are now sized by what an L2 holds:
+    // the three plane groups that share plane neighbours (footprint = rows x row bytes x planes per brick x arrays touched) must
+    // fit L2_KEEP; among the maps that do, the smallest halo share wins; strips of 1/8 of the rows (ny = 8) are a candidate too.
+    const bool split = p.opt.brick_xcd == 2 || (p.opt.brick_xcd == 1 && (adjoint || p.n < (int64_t(1) << 23) || p.opt.brick_xny >= 0));
+    if (split && b.nblk % pi::NXCD == 0 && p.opt.brick_xny != 1) {
         const long rows_per_brick = std::max<long>(1, nt / std::max(1, b.cpr));
-        for (int ny : {2, 4}) {
+        const double row_bytes = 16.0 * b.cpr;
+        const double arrays = adjoint ? 8.0 : 4.0;                           // species-planes streamed per output plane
+        constexpr double L2_KEEP = 2.5 * 1024 * 1024;                        // of the 4 MiB per XCD
+        auto footprint = [&](double rows) { return 3.0 * rows * row_bytes * rz * arrays; };
+        // the contiguous map: an XCD takes npg / 8 plane groups of ALL rows
+        const double all_rows = (double)b.nrg * rows_per_brick;
+        double best = 4.0 * rz / (double)std::max<long>(1, (npg / pi::NXCD) * rz);
+        bool best_fits = footprint(all_rows) <= L2_KEEP;
+        for (int ny : {2, 4, 8}) {
+            if (p.opt.brick_xny > 1 && ny != p.opt.brick_xny) continue;
             const int nz = pi::NXCD / ny;
             if (npg % nz || b.nrg % ny) continue;
             const double planes = (double)(npg / nz) * rz, rows = (double)(b.nrg / ny) * rows_per_brick;
             const double share = 4.0 / planes + 4.0 / rows;
-            if (share < best - 1e-9) { best = share; b.xny = ny; b.xpg = (int)(npg / nz); b.xrg = b.nrg / ny; }
+            const bool fits = footprint(rows) <= L2_KEEP;
+            const bool take = p.opt.brick_xny > 1 || (fits && !best_fits) || (fits == best_fits && (fits ? share < best + 1e-9 : true));   // (ties: the narrower strips)
+            if (take) { best = share; best_fits = fits; b.xny = ny; b.xpg = (int)(npg / nz); b.xrg = b.nrg / ny; }
         }
         if (b.xny) b.dxrg = make_fastdiv((unsigned)b.xrg);
     }
@@ -1910,6 +1940,15 @@ int slab_rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* 
     const int k = halo / 2;
     const int64_t n = p.n0;
     const size_t frame = (size_t)2 * (p.n0 + 2 * halo) * p.n1 * p.W;
+    if (!ring && !(overlap & 2) && p.opt.slab_local_index) {
+        // one rank: the interior IS the periodic domain -- no exchange, no halo planes, one launch per step
+        Problem q = p;
+        q.slab_periodic = true;
+        for (int t = 0; t < T_steps; ++t)
+            if (hipError_t e = step_fwd<T>(traj + (size_t)t * frame, traj + (size_t)(t + 1) * frame, P, q, st)) return (int)e;
+        return 0;
+    }
+    overlap &= 1;
     SideStream* side = overlap && n >= 2 * halo ? side_stream() : nullptr;
     hipEvent_t pending = nullptr;
     auto range = [&](T* in, T* out, int lo, int hi) -> int {
@@ -1998,13 +2037,16 @@ int slab_rollout_bwd_impl(const T* traj, const T* g_traj, T* adj, double* param_
     }
     if (T_steps == 0) return 0;
     if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
-    SideStream* side = overlap && n >= 4 ? side_stream() : nullptr;
+    const bool by_index = !ring && !(overlap & 2) && p.opt.slab_local_index;     // one rank: wrap by index, no exchange
+    overlap &= 1;
+    SideStream* side = overlap && n >= 4 && !by_index ? side_stream() : nullptr;
     hipEvent_t pending = nullptr;
     // float32 poly mode: the 20 coefficient moments are reduced inside the sweep launches (no slab_wgrad pass)
     const bool fuse = hc == 0 && sizeof(T) == 4 && p.opt.fuse_wgrad != 0;
     auto sweep = [&](int t, int lo, int hi, bool strip = false) -> int {   // adjoint planes [lo, hi) of frame t-1 from frame t
         Problem q = p;
-        if (int rc = set_slab_range(q, halo, lo, hi)) return rc;
+        if (by_index) q.slab_periodic = true;
+        else if (int rc = set_slab_range(q, halo, lo, hi)) return rc;
         unsigned grid = 0;
         const T* hf = traj + (size_t)(t - 1) * frame;
         const T* gf = adj + (size_t)t * frame;
@@ -2034,6 +2076,10 @@ int slab_rollout_bwd_impl(const T* traj, const T* g_traj, T* adj, double* param_
             if (int rc = sweep(t, halo + (int)n, halo + (int)n + 2, true)) return rc;
             if (int rc = sweep(t, halo, halo + (int)n)) return rc;
             --t;                                           // adj[t-1] now has 2 valid halo planes per side
+            if (int rc = sweep(t, halo, halo + (int)n)) return rc;
+            continue;
+        }
+        if (by_index) {
             if (int rc = sweep(t, halo, halo + (int)n)) return rc;
             continue;
         }
@@ -2570,6 +2616,8 @@ int apply_option(Options& o, const char* key, long value)
     }
     if (!std::strcmp(key, "block_small")) { o.block_small = value != 0; return 0; }
     if (!std::strcmp(key, "slab_wide_adjoint")) { o.slab_wide_adjoint = value != 0; return 0; }
+    if (!std::strcmp(key, "slab_local_index")) { o.slab_local_index = value != 0; return 0; }
+    if (!std::strcmp(key, "brick_xny")) { if (value < -1 || value > 8 || value == 3 || (value > 4 && value < 8)) return PERCNN_PI_EINVAL; o.brick_xny = (int)value; return 0; }
     if (!std::strcmp(key, "slab_fused_put")) { o.slab_fused_put = value != 0; return 0; }
     if (!std::strcmp(key, "slab_put_blocks")) {
         if (value < 4 || value > 256 || value % 4) return PERCNN_PI_EINVAL;

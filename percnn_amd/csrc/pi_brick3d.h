@@ -234,6 +234,12 @@ pi_fwd3d_brick_kernel(const T* __restrict__ h, T* __restrict__ out, const T* __r
 #pragma clang loop unroll(disable)
         for (int s = 0; s < 2; ++s) {
             T rr[VEC];
+#if defined(PI_BRICK_SKELETON)      // access-pattern ceiling (tools/gpu_brick_skeleton.sh; WRONG results): loads, LDS traffic, stencil
+            if constexpr (true) {   // taps and stores of the step, without the reaction term
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) rr[i] = T(0);
+            } else
+#endif
             if constexpr (HC == POLY) {
                 const T* c = P + P_W + 10 * s;
 #pragma unroll
@@ -382,7 +388,10 @@ template <bool PUT> struct AdjPutArg { using type = NoPut; };
 template <> struct AdjPutArg<true> { using type = PeerPutFused; };
 
 template <typename T, int HC, int RZ, bool MOM, int LOSS = 0, int NT = BRICK_NT, bool PUT = false>
-__global__ void __launch_bounds__(NT, (RZ == 1 && HC == POLY && LOSS != 2 && sizeof(T) == 4 && !PUT) ? 4 : 2)   // one-plane bricks of pre-contracted float32
+#ifndef PI_ADJ_RZ2_WAVES
+#define PI_ADJ_RZ2_WAVES 2
+#endif
+__global__ void __launch_bounds__(NT, (RZ == 1 && HC == POLY && LOSS != 2 && sizeof(T) == 4 && !PUT) ? 4 : (RZ == 2 && HC == POLY && LOSS == 0 && sizeof(T) == 4 && NT == 256 && !PUT ? PI_ADJ_RZ2_WAVES : 2))   // one-plane bricks of pre-contracted float32
 pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T* __restrict__ inj, T* __restrict__ Gp,
                       double* __restrict__ partials, const T* __restrict__ P, BrickGeom g, int hc_rt,
                       typename AdjPutArg<PUT>::type put)
@@ -474,6 +483,12 @@ pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T*
             T du[VEC], dv[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) du[i] = dv[i] = T(0);
+#if defined(PI_BRICK_SKELETON)      // access-pattern ceiling: no Jacobian, no moments, no coefficient sums (the operands are
+            if constexpr (true) {   // still loaded and consumed by one add each)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { du[i] = u.v[i]; dv[i] = v.v[i]; }
+            } else
+#endif
             if constexpr (HC == POLY) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {

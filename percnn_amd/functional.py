@@ -647,14 +647,15 @@ def step_bwd(h: torch.Tensor, g_out: torch.Tensor, P: torch.Tensor, g_inject: Op
 
 def slab_rollout_fwd_native_(traj: torch.Tensor, P: torch.Tensor, halo: int, ring, overlap: bool) -> torch.Tensor:
     """The whole T-step slab loop incl. halo exchanges in one C call (include/percnn_pi.h, native slab rollouts).
-    ring: ctypes pointer to a ``_lib.HaloRing`` or None (single rank: periodic wrap by device copies)."""
+    ring: ctypes pointer to a ``_lib.HaloRing`` or None (single rank: periodic wrap by index inside the step launches).
+    overlap: bool, or the C entry point's flag word (bit 0 faces first, bit 1 single-rank wrap by face copies)."""
     _require(traj, "traj"); _require(P, "params", traj.dtype)
     shape = list(traj.shape[2:])
     shape[0] -= 2 * halo
     f = getattr(_lib.lib(), "percnn_pi_slab_rollout_fwd_" + _SUF[traj.dtype])
     with torch.cuda.device(traj.device):
         _lib.check(f(traj.data_ptr(), P.data_ptr(), _hc_of(P), len(shape), _lib.shape_arg(shape), halo,
-                     traj.shape[0] - 1, ring, 1 if overlap else 0, _stream()), "slab_rollout_fwd")
+                     traj.shape[0] - 1, ring, int(overlap), _stream()), "slab_rollout_fwd")
     return traj
 
 
@@ -671,7 +672,7 @@ def slab_rollout_bwd_native(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.T
     with torch.cuda.device(traj.device):
         _lib.check(f(traj.data_ptr(), g_traj.data_ptr(), adj.data_ptr(), pg.data_ptr(), ws.data_ptr(), ws.numel(),
                      P.data_ptr(), hc, len(shape), _lib.shape_arg(shape), halo, traj.shape[0] - 1, ring,
-                     1 if overlap else 0, _stream()), "slab_rollout_bwd")
+                     int(overlap), _stream()), "slab_rollout_bwd")
     return adj, pg
 
 

@@ -598,9 +598,15 @@ def make_exchanger(group=None, prefer_rccl: bool = True, force_p2p: bool = False
 class LocalWrapExchanger(HaloExchanger):
     """No neighbours: every exchange wraps the slab onto itself with device copies, whatever process group is up.  What
     ``bench.py`` uses to time the COMPUTE share of a sharded rollout (same local arrays, same kernels, no transport);
-    physically meaningful only for world size 1."""
+    physically meaningful only for world size 1.
 
-    def __init__(self):
+    copies=True (default here): the native loops keep the launches of a multi-rank run -- face copies into the halo planes,
+    the outer planes of every second forward step recomputed -- so that the time is that run's compute share.  copies=False: the
+    single-rank schedule of the library (what a world-size-1 ``HaloExchanger`` gets): the wrap resolved by index inside the
+    step launches, no copies, the frames' halo planes left untouched."""
+
+    def __init__(self, copies: bool = True):
+        self.copies = bool(copies)
         self.group, self.force_p2p = None, False
         self.rank, self.world, self.prev, self.next = 0, 1, 0, 0
         self._bufs = {}
@@ -733,7 +739,7 @@ def slab_rollout_fwd_(traj: torch.Tensor, P: torch.Tensor, ex: HaloExchanger, ha
     if step_fwd is F_pi.step_fwd and traj.is_cuda:
         usable, ring = ex.native_ring()
         if usable:                                    # the whole loop in one C call (no per-step host work)
-            F_pi.slab_rollout_fwd_native_(traj, P, halo, ring, overlap and ring is not None)
+            F_pi.slab_rollout_fwd_native_(traj, P, halo, ring, int(bool(overlap and ring is not None)) | (2 if getattr(ex, "copies", False) else 0))
             ex.check()
             return traj
     T = traj.shape[0] - 1
@@ -778,7 +784,8 @@ def slab_rollout_bwd(traj: torch.Tensor, g_traj: torch.Tensor, P: torch.Tensor, 
     if step_bwd is F_pi.step_bwd and wgrad is F_pi.slab_wgrad and traj.is_cuda:
         usable, ring = ex.native_ring()
         if usable:
-            adj, pg = F_pi.slab_rollout_bwd_native(traj, g_traj, P, halo, ring, overlap and ring is not None)
+            adj, pg = F_pi.slab_rollout_bwd_native(traj, g_traj, P, halo, ring,
+                                                   int(bool(overlap and ring is not None)) | (2 if getattr(ex, "copies", False) else 0))
             ex.check_and_all_reduce_sum_(pg)
             return adj[0], pg
     T = traj.shape[0] - 1

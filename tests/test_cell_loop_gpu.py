@@ -276,7 +276,7 @@ def test_training_step_loop_does_not_leak(speculate):
     # a consumed block's state holds neither the block nor frames any more
     outs = _loop(cell, h0, 6)
     st = cell._block_acc
-    assert st.holds_block and st.held_frames > 0
+    assert st.holds_block and (st.held_frames > 0 or not speculate)
     (torch.cat(outs, 0) ** 2).mean().backward()
     assert cell._block_acc is None and not st.holds_block and st.held_frames == 0
 

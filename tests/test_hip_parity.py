@@ -287,6 +287,44 @@ def test_slab_rollout_single_rank_equals_rollout(fam, halo, hip_device):
     assert torch.equal(lo.grad[:, halo:halo + n0], h1.grad[0])
 
 
+@pytest.mark.parametrize("shape,halo", [((16, 32, 64), 4), ((8, 24, 40), 2), ((32, 256, 256), 4)])
+def test_single_rank_slab_wrap_by_index_equals_wrap_by_copies(shape, halo, hip_device):
+    """Round 5: one rank's native slab loops resolve the periodic wrap by index inside the step launches (no face copies, no
+    recomputed halo planes).  Same interior, bit for bit, as the face-copy schedule (the launches of a multi-rank run minus
+    its transport: LocalWrapExchanger(copies=True)) and as the single-domain rollout; same adjoint field; the frames' halo
+    planes are left untouched."""
+    import percnn_amd as pa
+    from percnn_amd import slab
+    g = Golden(os.path.join(GOLDEN, "gs3d_ckpt_16x16x16.npz"))
+    cell = g.product_cell(hip_device)
+    with torch.no_grad():
+        P = cell.param_block().contiguous()
+    from percnn_amd import synthetic
+    h0 = synthetic.gs_initial_state(shape, seed=1).to(hip_device)
+    T, n0 = 6, shape[0]
+    ref = pa.pi_rollout(h0, P, T)
+    gen = torch.Generator(device=hip_device).manual_seed(9)
+    gref = torch.randn(ref.shape, device=hip_device, generator=gen) / ref.numel()
+    g0_ref, pg_ref = pa.rollout_bwd(ref, gref, P)
+    res = {}
+    for name, ex in (("index", slab.LocalWrapExchanger(copies=False)), ("copies", slab.LocalWrapExchanger(copies=True)),
+                     ("default", slab.HaloExchanger())):
+        traj = torch.full((T + 1, 2, n0 + 2 * halo) + tuple(shape[1:]), 7.0, device=hip_device)
+        traj[0, :, halo:halo + n0] = h0[0]
+        gt = torch.zeros_like(traj)
+        gt[:, :, halo:halo + n0] = gref
+        slab.slab_rollout_fwd_(traj, P, ex, halo)
+        assert torch.equal(traj[:, :, halo:halo + n0], ref), name
+        if name != "copies":                               # nobody wrote a halo plane
+            assert float((traj[1:, :, :halo] - 7.0).abs().max()) == 0.0 and float((traj[1:, :, halo + n0:] - 7.0).abs().max()) == 0.0
+        g0, pg = slab.slab_rollout_bwd(traj, gt, P, ex, halo)
+        assert torch.equal(g0[:, halo:halo + n0], g0_ref), name
+        assert float(g0[:, :halo].abs().max()) == 0.0 and float(g0[:, halo + n0:].abs().max()) == 0.0
+        res[name] = pg
+        assert rel_l2(pg.cpu().numpy(), pg_ref.cpu().numpy()) < 2e-5, name
+    assert torch.equal(res["index"], res["default"])
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json full sizes
 # ---------------------------------------------------------------------------------------------

@@ -25,7 +25,10 @@ for r in recs:
 
 def short(kn):
     m = re.search(r"pi::(\w+)(<[^(]*>)?", kn)
-    return (m.group(1) + (m.group(2) or "")) if m else kn[:60]
+    if m:
+        return m.group(1) + (m.group(2) or "")
+    m = re.search(r"(elementwise_kernel|vectorized_elementwise_kernel)", kn)
+    return (m.group(1) + " (torch copy)") if m else kn[:60]
 
 
 def g(d, k):
@@ -40,7 +43,7 @@ def fmt(x, p="{:.3f}"):
     return "   n/a" if x is None else p.format(x)
 
 
-want = ("pi_fwd2d_persist", "pi_adj2d_persist", "pi_fwd3d_brick", "pi_adj3d_brick", "pi_stream3d", "pi_fwd2d_tile", "pi_adj2d_tile",
+want = ("elementwise", "vectorized", "pi_fwd2d_persist", "pi_adj2d_persist", "pi_fwd3d_brick", "pi_adj3d_brick", "pi_stream3d", "pi_fwd2d_tile", "pi_adj2d_tile",
         "pi_moments", "pi_bwd_kernel", "pi_fwd_kernel")
 print("# per-launch averages; SQ cycle counters in quad-cycles summed over waves; shares are of SQ_WAVE_CYCLES")
 print(f"{'workload':<16} {'kernel':<66} {'us':>8} | {'issue':>6} {'stall':>6} {'parked':>6} | {'VALU/wv-cyc':>11} {'LDSact':>6} {'VMEMact':>7} | "

@@ -7,8 +7,8 @@ O=$R/gpurun_out/r05_counters
 mkdir -p $O
 cd /tmp
 rocprofv3 -L > $O/avail.txt 2>&1
-: > $O/records.jsonl
-: > $O/log.txt
+[ -n "$PMC_APPEND" ] || : > $O/records.jsonl
+[ -n "$PMC_APPEND" ] || : > $O/log.txt
 PASSES=(
  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM"
@@ -21,7 +21,10 @@ PASSES=(
  "FETCH_SIZE"
  "WRITE_SIZE"
 )
+if [ -n "$PMC_PASSES" ]; then IFS=';' read -r -a PASSES <<< "$PMC_PASSES"; fi
 declare -A CMD
+# calibration: a device-to-device copy of 128 MiB (known bytes: 134.2 MB read + 134.2 MB written per launch)
+CMD[copy_128MiB]="python -c \"import torch; a=torch.rand(1<<25,device='cuda'); b=torch.empty_like(a); [b.copy_(a) for _ in range(6)]; torch.cuda.synchronize()\""
 CMD[gs2d_512]="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-also --workload gs2d_512 --T 100"
 CMD[gs3d_128]="python $R/tools/opt_sweep.py --family gs3d --shape 128 128 128 --T 20 --reps 1"
 CMD[gs3d_256]="python $R/tools/opt_sweep.py --family gs3d --shape 256 256 256 --T 6 --reps 1"
@@ -35,7 +38,7 @@ for wl in ${WORKLOADS:-gs2d_512 gs3d_128 gs3d_256 gs3d_32x256x256 lo2d_512}; do
     done
     [ -z "$keep" ] && continue
     rm -rf /tmp/pmcout
-    timeout 600 rocprofv3 --kernel-trace --pmc $keep -d /tmp/pmcout -o pmc -- ${CMD[$wl]} > /tmp/pmc.log 2>&1
+    eval "timeout 600 rocprofv3 --kernel-trace --pmc $keep -d /tmp/pmcout -o pmc -- ${CMD[$wl]}" > /tmp/pmc.log 2>&1
     rc=$?
     db=$(find /tmp/pmcout -name "*.db" | head -1)
     if [ -n "$db" ]; then python $R/tools/pmc_dump.py $db "$wl" $O/records.jsonl 2>> $O/log.txt
