@@ -135,7 +135,8 @@ struct SideStream {
 };
 SideStream* side_stream()
 {
-    static SideStream per_dev[16];
+    // per host THREAD and device: two threads that drive two streams of one device must not share the event ring
+    static thread_local SideStream per_dev[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     SideStream& s = per_dev[dev];
@@ -571,6 +572,9 @@ inline int stream3d_zc(const Problem& p, const Geom& g, bool adj)
 {
     int zc = adj ? 2 * p.opt.zc : p.opt.zc;               // the heavier adjoint body amortises its prologue over more planes
     const long ytiles = p.n1 / STREAM_TY;
+    // forward, round 5 (profiles/r05_counters_summary.txt): a chain of 8 planes fetches 12 -- memory-side reads at 256^3 were
+    // 199 MB for a 134 MB state; 16 planes per chain while >= 1024 workgroups remain: 172 MB, 64.8 -> 61.9 us per step
+    if (!adj && p.opt.zc == 8 && ((g.n0 + 15) / 16) * ytiles >= 1024) zc = 16;
     while ((long)((g.n0 + zc - 1) / zc) * ytiles > MAX_BWD_BLOCKS) zc *= 2;
     return zc;
 }

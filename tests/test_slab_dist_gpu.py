@@ -241,3 +241,104 @@ def test_bench_eight_ranks_on_one_gpu_at_256cubed(hip_device):
     for key, g in strong.items():
         assert g.get("forward_state_equals_single_domain_rollout") is True and g["steps_per_sec_fwd_bwd"] > 0, (key, g)
     assert sl["weak_scaling"]["by_transport"]["dist"].get("forward_state_equals_single_domain_rollout") is True
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the native loops' ring callbacks with world > 1: an in-process fake of RCCL's group semantics (tests/fake_ring.py)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _fake_ring_run(world, shape, halo, T, overlap, packed, fail_at=None, dtype=torch.float32):
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import percnn_amd as pa
+    from percnn_amd import slab
+    from fake_ring import FakeFabric, FakeRingExchanger
+    from util import random_block
+    dev = torch.device("cuda:0")
+    ndim = len(shape)
+    npdt = np.float32 if dtype == torch.float32 else np.float64
+    rs = np.random.RandomState(11)
+    P = torch.tensor(random_block(0, ndim, np.dtype(npdt), 5, scale=0.3), device=dev)
+    h0 = torch.tensor(rs.uniform(0, 1, (2,) + shape).astype(npdt), device=dev)
+    ref = torch.empty((T + 1, 2) + shape, dtype=dtype, device=dev)
+    ref[0] = h0
+    pa.rollout_fwd_(ref, P)
+    g_ref = torch.tensor(rs.uniform(-1, 1, tuple(ref.shape)).astype(npdt), device=dev)
+    g0_ref, pg_ref = pa.rollout_bwd(ref, g_ref, P)
+    torch.cuda.synchronize()
+    fabric = FakeFabric(world, take_timeout_s=10.0)
+    exs = [FakeRingExchanger(fabric, r, fail_at=fail_at if r == 0 else None, packed=packed) for r in range(world)]
+    cuts = slab.split_extent(shape[0], world)
+    out, errs = [None] * world, [None] * world
+
+    def rank_main(r):
+        try:
+            torch.cuda.set_device(dev)
+            st = torch.cuda.Stream(device=dev)
+            lo, hi = cuts[r]
+            n = hi - lo
+            with torch.cuda.stream(st):
+                traj = torch.zeros((T + 1, 2, n + 2 * halo) + shape[1:], dtype=dtype, device=dev)
+                traj[0, :, halo:halo + n] = h0[:, lo:lo + n]
+                gt = torch.zeros_like(traj)
+                gt[:, :, halo:halo + n] = g_ref[:, :, lo:lo + n]
+                slab.slab_rollout_fwd_(traj, P, exs[r], halo, overlap=overlap)
+                g0, pg = slab.slab_rollout_bwd(traj, gt, P, exs[r], halo, overlap=overlap)
+                st.synchronize()
+                out[r] = (traj[:, :, halo:halo + n].clone(), g0[:, halo:halo + n].clone(), pg.clone(), lo, n)
+        except Exception as e:
+            errs[r] = e
+            try:
+                fabric.barrier.abort()
+            except Exception:
+                pass
+
+    ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=180)
+    assert not any(t.is_alive() for t in ths), "a rank hangs"
+    return out, errs, exs, fabric, (ref, g0_ref, pg_ref)
+
+
+@pytest.mark.parametrize("world,shape,halo,T,overlap,packed", [
+    (2, (16, 24, 32), 4, 7, False, True),            # prev == next: per peer, sends and receives pair up in issue order
+    (3, (24, 16, 64), 4, 6, False, True),            # prev != next
+    (3, (24, 16, 64), 2, 5, False, False),           # per-species messages straight from the slab (4 + 4 per exchange)
+    (2, (16, 24, 32), 4, 6, True, True),             # faces first, exchange on the side stream
+    (4, (32, 256, 256), 4, 4, False, True),          # the per-rank shape class of configs[4] (64-chunk rows), 2 MiB faces
+])
+def test_native_slab_loops_through_a_fake_rccl_ring(world, shape, halo, T, overlap, packed, hip_device):
+    """the native loops' ncclGroupStart / Send / Recv / End call pattern with MORE THAN ONE rank -- group
+    discipline, neighbour addressing (prev != next), pairing order for prev == next, packed and per-species messages, the
+    overlap schedule's side stream -- before real hardware sees it.  Interior states and dL/dh0 bit-identical to the
+    single-domain rollout, gradient block to reduction round-off."""
+    out, errs, exs, fabric, (ref, g0_ref, pg_ref) = _fake_ring_run(world, shape, halo, T, overlap, packed)
+    assert all(e is None for e in errs), errs
+    assert not fabric.errors, fabric.errors
+    k = halo // 2
+    n_exch = (T + k - 1) // k + T                    # forward: one per k steps; adjoint: one per step
+    for r, ex in enumerate(exs):
+        assert not ex.in_group and ex.groups == n_exch, (r, ex.groups, n_exch)
+        assert ex.ops == n_exch * (4 if packed else 8), (r, ex.ops)
+        # every operation of a rank names one of its two ring neighbours, and both of them when they differ
+        peers = {p for (rk, _, p, _) in fabric.log if rk == r}
+        assert peers == {ex.prev, ex.next}, (r, peers)
+    for q in fabric.fifo.values():
+        assert q.empty()                             # every send met its receive
+    for r in range(world):
+        traj, g0, pg, lo, n = out[r]
+        assert torch.equal(traj, ref[:, :, lo:lo + n]), r
+        assert torch.equal(g0, g0_ref[:, lo:lo + n]), r
+        err = float((pg - pg_ref).norm() / pg_ref.norm())
+        assert err < 2e-5, (r, err)
+        assert torch.equal(pg, out[0][2])            # the all-reduced block is the same on every rank
+
+
+@pytest.mark.parametrize("fail_at", [("send", 3), ("recv", 2), ("group_end", 2), ("group_start", 1)])
+def test_native_slab_loops_hand_back_a_failing_ring_call(fail_at, hip_device):
+    """an RCCL call that returns an error inside the native loop must surface as that loop's return code (-> RuntimeError on
+    the rank it happened on), not be swallowed; the other rank ends with a bounded 'no matching send', not a hang"""
+    out, errs, exs, fabric, _ = _fake_ring_run(2, (16, 16, 32), 4, 5, False, True, fail_at=fail_at)
+    assert isinstance(errs[0], RuntimeError) and "slab_rollout" in str(errs[0]), errs
+    assert errs[1] is None or isinstance(errs[1], (RuntimeError, Exception))

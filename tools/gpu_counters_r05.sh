@@ -27,7 +27,7 @@ declare -A CMD
 CMD[copy_128MiB]="python -c \"import torch; a=torch.rand(1<<25,device='cuda'); b=torch.empty_like(a); [b.copy_(a) for _ in range(6)]; torch.cuda.synchronize()\""
 CMD[gs2d_512]="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-also --workload gs2d_512 --T 100"
 CMD[gs3d_128]="python $R/tools/opt_sweep.py --family gs3d --shape 128 128 128 --T 20 --reps 1"
-CMD[gs3d_256]="python $R/tools/opt_sweep.py --family gs3d --shape 256 256 256 --T 6 --reps 1"
+CMD[gs3d_256]="python $R/tools/opt_sweep.py --family gs3d --shape 256 256 256 --T 6 --reps 1 --opts \"$OPT256\""
 CMD[gs3d_32x256x256]="python $R/tools/opt_sweep.py --family gs3d --shape 32 256 256 --T 20 --reps 1"
 CMD[lo2d_512]="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-also --workload lo2d_512 --T 100"
 for wl in ${WORKLOADS:-gs2d_512 gs3d_128 gs3d_256 gs3d_32x256x256 lo2d_512}; do
