@@ -60,6 +60,7 @@ struct Options {
                             // launch-per-group sweep is enqueued in the same call and the persistent path is switched off for
                             // this device (percnn_pi_persist_status).  0: no wait; an aborted launch is reported by the NEXT
                             // entry point (PERCNN_PI_EASYNC) instead
+    int fwd_small_pause = 12;   // small-tile resident forward: 64-clock units between publish and the first ring request (PersistArgs::pause)
     int persist_small = 1;      // the 32 x 8-tile regime (grids below ~300^2, split schedule) as one persistent launch too
     int fwd_persist_per_cu = 1; // ... on grids of up to this many tiles per CU (1 or 2)
     int fwd_persist = 1;        // the FORWARD rollout of such a grid as one launch of resident workgroups too (pi_fwd2d_persist_kernel;
@@ -1589,6 +1590,129 @@ hipError_t launch_adj_persist_small_t(const T* hframe_t, const T* gframe_t, T* a
     return hipSuccess;
 }
 
+// ---- small-tile / ragged resident FORWARD (pi_fwd2d_persist_small_kernel) ------------------------------------------------------
+// tile height the resident small forward runs on: what the launch-per-group forward would use (8 / 16 rows), or 32 rows for the
+// grids the 32 x 32 resident forward does not take (ragged, fewer than 16 tiles); 0 = not this path
+template <typename T>
+int fwd_persist_small_by(const Problem& p, int ngroups, hipStream_t st)
+{
+    // (eight groups at least, as the 32 x 32 resident forward: short rollouts -- the step loop's speculative groups among them --
+    // keep the launch-per-group kernel and a host that never waits for the stream)
+    if (!p.opt.tile_persist || !p.opt.persist_small || !p.opt.fwd_persist || sizeof(T) != 4 || ngroups < 8 || p.hc != 0) return 0;
+    if (persist_disabled_here()) return 0;
+    if (p.opt.tile_k != 4 || p.opt.tile_nt != 512 || tile_wide_for<T>(p, false) != 0) return 0;
+    const int by = tile_by_for(p);
+    // Measured (profiles/r05_small_tile_resident_forward.txt, us per forward step, launch per group -> resident): 32 x 8 tiles
+    // 100^2 1.23 -> 1.08, 256^2 1.22 -> 1.14; 32 x 16 tiles (300 x 320) 1.46 -> 1.63 and ragged 32 x 32 tiles (500^2) 1.92 -> 2.28:
+    // whole-tile granules and an un-overlapped hand-over only pay where the sub-steps are short -> the 8-row regime by default,
+    // persist_small = 2 takes the others too (tests)
+    if (by != 8 && p.opt.persist_small < 2) return 0;
+    const int64_t tiles = ((p.n0 + by - 1) / by) * ((p.W + TILE_B - 1) / TILE_B);
+    const int cus = device_cu_count();
+    if (tiles < 2 || cus <= 0 || tiles > cus || tiles > 256) return 0;       // one workgroup per CU at most: resident for sure
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st && (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) return 0;
+    return by;
+}
+
+// wait for the roll call of a resident launch (or its abort); what launch_fwd_persist / launch_adj_persist do inline
+hipError_t persist_wait_roll_call(volatile int* hs, int slot, int dev, unsigned grid, const char* what)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (hs[0] == 0 && hs[3] == 0) {
+        if ((++spins & 0x3ff) == 0) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(600)) return hipErrorLaunchTimeOut;
+            std::this_thread::yield();
+        }
+    }
+    if (hs[3] != 0) {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        g_persist.watch[slot] = false;
+        ++g_persist.aborts;
+        g_persist.last_group = hs[1];
+        g_persist.last_tile = hs[2];
+        g_persist.disabled[dev] = true;
+        if (!g_persist.warned) {
+            g_persist.warned = true;
+            std::fprintf(stderr, "percnn_pi: %s could not keep all %u workgroups resident on device %d (group %d, tile %d: another "
+                                 "process / kernel holds CUs, or a CU mask is set); using one launch per group of steps from now on "
+                                 "(percnn_pi_set_option(\"persist_reset\", 1) re-arms it)\n", what, grid, dev, (int)hs[1], (int)hs[2]);
+        }
+        return hipErrorLaunchFailure;
+    }
+    return hipSuccess;
+}
+
+// frames t0 + 1 .. t0 + 4 * ngroups from frame t0; return values as launch_fwd_persist
+template <typename T, int BY, int NT>
+hipError_t launch_fwd_persist_small_t(T* frame_t0, int ngroups, const T* P, const Problem& p, int dev, hipStream_t st)
+{
+    constexpr int K = 4;
+    using TL = pi::Tile<K, TILE_B, BY>;
+    pi::TileGeom g = make_tile_geom(p, BY);
+    const unsigned grid = (unsigned)(((p.n0 + BY - 1) / BY) * g.tiles_x);
+    constexpr int RINGH = TL::LX * TL::LY - TILE_B * BY, NGAT = (2 * RINGH + NT - 1) / NT;
+    // state buffers | gather tables | K rows of strip geometry | abort word
+    const size_t lds = pi::tile_state_bytes<T, K, TILE_B, BY>() + (size_t)(2 * NGAT + K) * NT * sizeof(int) + 16;
+    auto* k = pi::pi_fwd2d_persist_small_kernel<T, K, TILE_B, BY, NT>;
+    if (hipError_t e = allow_lds(k, lds)) return e;
+    // per-device scratch (shared with the 32 x 32 resident forward): 256 B of sync words | granule outbox: 2 parities x tiles x 2 x 32 x BY
+    const size_t outbox_bytes = (size_t)2 * grid * (2 * TILE_B * BY) * sizeof(unsigned long long);
+    const size_t need = 256 + outbox_bytes;
+    unsigned char* scratch;
+    {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        if (g_persist.fwd_scratch_bytes[dev] < need) {
+            if (g_persist.fwd_scratch[dev]) {
+                (void)hipFree(g_persist.fwd_scratch[dev]);
+                g_persist.fwd_scratch[dev] = nullptr;
+                g_persist.fwd_scratch_bytes[dev] = 0;
+            }
+            void* q = nullptr;
+            if (hipMalloc(&q, need) != hipSuccess || !q) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
+            g_persist.fwd_scratch[dev] = q;
+            g_persist.fwd_scratch_bytes[dev] = need;
+        }
+        scratch = static_cast<unsigned char*>(g_persist.fwd_scratch[dev]);
+    }
+    if (hipError_t e = hipMemsetAsync(scratch, 0, need, st)) return e;
+    long frame_stride = (long)(2 * p.n);
+    pi::PersistArgs pa{};
+    int slot;
+    {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        slot = g_persist.next_slot++ % PERSIST_SLOTS;
+        g_persist.watch[slot] = false;
+        ++g_persist.launches;
+    }
+    volatile int* hs = g_persist.host->slot[slot];
+    hs[0] = 0; hs[1] = -1; hs[2] = -1; hs[3] = 0;
+    pa.outbox = reinterpret_cast<unsigned long long*>(scratch + 256);
+    pa.sync = reinterpret_cast<unsigned*>(scratch);
+    pa.ngroups = ngroups;
+    pa.host = const_cast<int*>(hs);
+    pa.timeout_ticks = (unsigned long long)p.opt.persist_timeout_ms * 100000ull;             // 100 MHz clock
+    pa.first_timeout_ticks = (unsigned long long)p.opt.persist_first_timeout_ms * 100000ull;
+    pa.pause = p.opt.fwd_small_pause;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, frame_t0, frame_stride, P, g, pa);
+    if (hipError_t e = hipGetLastError()) return e;
+    {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        g_persist.watch[slot] = true;
+    }
+    if (!p.opt.persist_handshake) return hipSuccess;        // fire and forget (an abort: PERCNN_PI_EASYNC at the next entry point)
+    return persist_wait_roll_call(hs, slot, dev, grid, "the resident forward rollout (small tiles)");
+}
+
+template <typename T>
+hipError_t launch_fwd_persist_small(int by, T* frame_t0, int ngroups, const T* P, const Problem& p, int dev, hipStream_t st)
+{
+    if (by == 8) return launch_fwd_persist_small_t<T, 8, 256>(frame_t0, ngroups, P, p, dev, st);
+    if (by == 16) return launch_fwd_persist_small_t<T, 16, 320>(frame_t0, ngroups, P, p, dev, st);
+    return launch_fwd_persist_small_t<T, TILE_B, 512>(frame_t0, ngroups, P, p, dev, st);
+}
+
 template <typename T>
 hipError_t launch_adj_persist_small(const T* hframe_t, const T* gframe_t, T* aframe_t, T* g_h0, int t_top, const unsigned char* mask,
                                     int ngroups, double* partials, unsigned long long* outbox, unsigned* sync, const T* P,
@@ -2149,8 +2273,13 @@ int rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* shape
         if constexpr (sizeof(T) == 4) {
             const int ngroups = K == 4 ? T_steps / K : 0;
             int pdev = 0;
-            if (fwd_persist_ok<T>(p, ngroups, st) && persist_enter(st, pdev)) {
-                const hipError_t e = launch_fwd_persist<T>(traj, ngroups, P, p, pdev, st);
+            const bool big = fwd_persist_ok<T>(p, ngroups, st);
+            // ... and the grids the 32 x 32 flavour does not take -- small-tile regime, ragged grids, fewer than 16 tiles -- on
+            // pi_fwd2d_persist_small_kernel (round 5)
+            const int small_by = big ? 0 : fwd_persist_small_by<T>(p, ngroups, st);
+            if ((big || small_by) && persist_enter(st, pdev)) {
+                const hipError_t e = big ? launch_fwd_persist<T>(traj, ngroups, P, p, pdev, st)
+                                         : launch_fwd_persist_small<T>(small_by, traj, ngroups, P, p, pdev, st);
                 if (e == hipSuccess) { t = K * ngroups; persist_leave(st, pdev); }
                 else if (e == hipErrorLaunchTimeOut) return (int)e;
                 else {
@@ -2558,7 +2687,7 @@ int apply_option(Options& o, const char* key, long value)
     }
     if (!std::strcmp(key, "persist_handshake")) { o.persist_handshake = value != 0; return 0; }
     if (!std::strcmp(key, "persist_split")) { o.persist_split = value != 0; return 0; }
-    if (!std::strcmp(key, "persist_small")) { o.persist_small = value != 0; return 0; }
+    if (!std::strcmp(key, "persist_small")) { if (value < 0 || value > 2) return PERCNN_PI_EINVAL; o.persist_small = (int)value; return 0; }
     if (!std::strcmp(key, "fwd_persist")) { o.fwd_persist = value != 0; return 0; }
     if (!std::strcmp(key, "fwd_persist_per_cu")) {
         if (value < 1 || value > 2) return PERCNN_PI_EINVAL;
@@ -2621,6 +2750,7 @@ int apply_option(Options& o, const char* key, long value)
     if (!std::strcmp(key, "block_small")) { o.block_small = value != 0; return 0; }
     if (!std::strcmp(key, "slab_wide_adjoint")) { o.slab_wide_adjoint = value != 0; return 0; }
     if (!std::strcmp(key, "slab_local_index")) { o.slab_local_index = value != 0; return 0; }
+    if (!std::strcmp(key, "fwd_small_pause")) { if (value < 0 || value > 200) return PERCNN_PI_EINVAL; o.fwd_small_pause = (int)value; return 0; }
     if (!std::strcmp(key, "brick_xny")) { if (value < -1 || value > 8 || value == 3 || (value > 4 && value < 8)) return PERCNN_PI_EINVAL; o.brick_xny = (int)value; return 0; }
     if (!std::strcmp(key, "slab_fused_put")) { o.slab_fused_put = value != 0; return 0; }
     if (!std::strcmp(key, "slab_put_blocks")) {
@@ -2818,7 +2948,7 @@ int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options,
     if constexpr (sizeof(T) == 4)
         out[14] = ((out[1] == 1 && (persist_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr) ||
                                     persist_small_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr))) ? 1 : 0) |
-                  ((out[0] == 1 && fwd_persist_ok<T>(p, 1 << 18, nullptr)) ? 2 : 0);
+                  ((out[0] == 1 && (fwd_persist_ok<T>(p, 1 << 18, nullptr) || fwd_persist_small_by<T>(p, 1 << 18, nullptr) != 0)) ? 2 : 0);
     for (int dir = 0; dir < 2; ++dir) {                                    // 2D tiles: width, height, lanes per workgroup
         if (out[dir] != 1) continue;
         const TileShape ts = tile_shape_for<T>(p, dir == 1);

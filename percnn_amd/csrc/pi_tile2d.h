@@ -174,7 +174,8 @@ __device__ __forceinline__ void tile_load(const T* __restrict__ src, const TileG
 }
 
 // write the BX x BY centre of buf to frame `dst`
-template <typename T, int K, int BX, int BY, int NT, bool PADDED = false>
+// WT = false: plain (write-back) stores -- the resident forwards: nobody reads a frame from memory before the launch ends
+template <typename T, int K, int BX, int BY, int NT, bool PADDED = false, bool WT = true>
 __device__ __forceinline__ void tile_store(const T* buf, T* __restrict__ dst, const TileGeom& g, int ty0, int tx0)
 {
     using TL = Tile<K, BX, BY>;
@@ -194,7 +195,8 @@ __device__ __forceinline__ void tile_store(const T* buf, T* __restrict__ dst, co
         } else {
             p = ld<T, VEC>(src);
         }
-        st_frame_wt<T, VEC>(dst + s * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC, p);
+        if constexpr (WT) st_frame_wt<T, VEC>(dst + s * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC, p);
+        else *reinterpret_cast<Pack<T, VEC>*>(dst + s * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC) = p;
     }
 }
 
@@ -483,7 +485,7 @@ constexpr int fwd_first_idle_lane()
 }
 
 // tile_store by the lanes from FIRST on only (whole waves): frame M of the launch, written while the other waves compute
-template <typename T, int K, int BX, int BY, int NT, int FIRST, bool PADDED>
+template <typename T, int K, int BX, int BY, int NT, int FIRST, bool PADDED, bool WT = true>
 __device__ __forceinline__ void tile_store_by_idle(const T* buf, T* __restrict__ dst, const TileGeom& g, int ty0, int tx0)
 {
     using TL = Tile<K, BX, BY>;
@@ -504,7 +506,8 @@ __device__ __forceinline__ void tile_store_by_idle(const T* buf, T* __restrict__
         } else {
             p = ld<T, VEC>(src);
         }
-        st_frame_wt<T, VEC>(dst + s * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC, p);
+        if constexpr (WT) st_frame_wt<T, VEC>(dst + s * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC, p);
+        else *reinterpret_cast<Pack<T, VEC>*>(dst + s * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC) = p;
     }
 }
 
@@ -515,9 +518,14 @@ __device__ __forceinline__ void tile_store_by_idle(const T* buf, T* __restrict__
 // between the barrier and the next sub-step, where the LDS round trip and the store issue sat on every wave's critical path
 // (device timeline, round 1: 0.3-0.4 us of each 1.1 us sub-step).  Frame K is stored by everybody at the end, as before.
 // `STORE_AHEAD`: sub-step M has idle waves (compile time; otherwise the all-waves store after the barrier stays).
-template <typename T, int HC, int K, int BX, int BY, int NT, int M>
+template <typename T, int K, int BX, int BY>
+__device__ __forceinline__ void fwd_strip_geo(const T* cur, T* nxt, const T* __restrict__ P, unsigned w);
+// LAST_STORE = false: frame K stays in LDS (the resident small-tile forward stores it after its hand-over has been started);
+// GEO: the lane's strip of each sub-step comes as a geometry word from an LDS table ([K][NT], persist_geo_word; one strip per
+// lane) instead of being derived from the lane id in every sub-step of every group; WT = false: plain frame stores
+template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool LAST_STORE = true, bool GEO = false, bool WT = true>
 __device__ __forceinline__ void fwd_substeps(T* b0, T* b1, T* __restrict__ frames, long frame_stride, const TileGeom& g,
-                                             int ty0, int tx0, const T* __restrict__ P)
+                                             int ty0, int tx0, const T* __restrict__ P, const unsigned* geo = nullptr)
 {
     T* cur = (M & 1) ? b1 : b0;
     T* nxt = (M & 1) ? b0 : b1;
@@ -526,17 +534,23 @@ __device__ __forceinline__ void fwd_substeps(T* b0, T* b1, T* __restrict__ frame
     constexpr bool STORE_HERE = PI_FWD_IDLE_STORE && M >= 1 && IDLE < NT;       // frame M: by this sub-step's idle waves
     if constexpr (STORE_HERE) {
         if ((int)threadIdx.x >= IDLE)
-            tile_store_by_idle<T, K, BX, BY, NT, IDLE, ((M - 1) & 1) != 0>(cur, frames + (long)M * frame_stride, g, ty0, tx0);
+            tile_store_by_idle<T, K, BX, BY, NT, IDLE, ((M - 1) & 1) != 0, WT>(cur, frames + (long)M * frame_stride, g, ty0, tx0);
     }
-    fwd_substep<T, HC, K, BX, BY, NT, M>(cur, nxt, P);
+    if constexpr (GEO) {
+        static_assert(HC == POLY && Tile<K, BX, BY>::region_n(0) / 4 <= NT, "one strip per lane, pre-contracted block");
+        fwd_strip_geo<T, K, BX, BY>(cur, nxt, P, geo[M * NT + (int)threadIdx.x]);
+    } else {
+        fwd_substep<T, HC, K, BX, BY, NT, M>(cur, nxt, P);
+    }
     PI_STAMP(2 + 2 * M);
     lds_barrier();                                         // do not drain the previous frame's global stores
     // frame M + 1: left to the idle waves of the next sub-step if it has any, else stored now by everybody
     constexpr bool NEXT_STORES = PI_FWD_IDLE_STORE && M + 1 < K && fwd_first_idle_lane<K, BX, BY, NT, (M + 1 < K ? M + 1 : M), CHUNKS>() < NT;
-    if constexpr (!NEXT_STORES)
-        tile_store<T, K, BX, BY, NT, (M & 1) != 0>(nxt, frames + (long)(M + 1) * frame_stride, g, ty0, tx0);
+    if constexpr (!NEXT_STORES && (M + 1 < K || LAST_STORE))
+        tile_store<T, K, BX, BY, NT, (M & 1) != 0, WT>(nxt, frames + (long)(M + 1) * frame_stride, g, ty0, tx0);
     PI_STAMP(3 + 2 * M);
-    if constexpr (M + 1 < K) fwd_substeps<T, HC, K, BX, BY, NT, M + 1>(b0, b1, frames, frame_stride, g, ty0, tx0, P);
+    if constexpr (M + 1 < K)
+        fwd_substeps<T, HC, K, BX, BY, NT, M + 1, LAST_STORE, GEO, WT>(b0, b1, frames, frame_stride, g, ty0, tx0, P, geo);
 }
 
 template <typename T, int HC, int K, int BX, int BY, int NT>
@@ -1234,6 +1248,9 @@ struct PersistArgs {
     unsigned long long first_timeout_ticks;  // ... of the FIRST hand-over: that is where a workgroup that never became resident
                                    // (CUs held by another process / kernel, CU mask) shows -- kept short so the host can fall back
     int t_top;                     // frame number of the top frame (group g covers frames t_top - K g - 1 ... t_top - K g - K)
+    int pause;                     // small-tile resident forward: units of 64 clocks between the publish and the FIRST request of the
+                                   // ring (granules asked for before the neighbours' stores are visible come back stale and cost a
+                                   // second round trip)
     int masked;                    // 1: only the frames whose bit is set in `frames` carry a gradient (RCNN.observe's strided loss)
     unsigned frames[128];          // bit t of word t / 32: frame t carries a gradient (t < 4096)
 };
@@ -2343,6 +2360,158 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
         PI_PSTAMP(8);
         // (no barrier: P0 reads b0 -- complete -- and writes b1 inside I_0's square; the store of level 3 from b1 was issued before
         // the barrier that ended P5 -- its LDS reads are done)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT FORWARD for the SMALL-TILE regime and ragged grids (round 5): grids that are not whole 32 x 32
+// tiles or have fewer than 16 of them -- the reference's own 100^2 x 200 rollout (train_2drd.py:162-190, :597-636) among them --
+// paid one launch per four steps: 5.0 us for sub-steps that take under two.  Here the T-step rollout is ONE launch of resident
+// workgroups on the machinery of pi_adj2d_persist_small_kernel: the state tile stays in LDS across groups of K steps, a tile
+// publishes ALL its BX x BY values of the frame a group ends on as data-tagged granules, the 2K-wide ring is gathered through
+// tables built from GLOBAL coordinates (owner tile after the periodic wrap -- ragged edge tiles, halos that span two neighbours and
+// single-column grids are the same code), residency roll call / bounded waits / clean abort as everywhere.  The sub-steps are
+// pi_fwd2d_tile_kernel's own device functions (fwd_substeps): the trajectory is that kernel's bit for bit.  The frame a group ends
+// on is stored AFTER the tile has been published and the ring requested: the neighbours wait for the granules, nobody for it.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int K, int BX, int BY, int NT>
+__global__ void __launch_bounds__(NT)
+pi_fwd2d_persist_small_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngroups are written */, long frame_stride,
+                              const T* __restrict__ P, TileGeom g, PersistArgs pa)
+{
+    static_assert(sizeof(T) == 4 && K % 2 == 0, "float32; an even number of sub-steps leaves the state in buffer 0");
+    using TL = Tile<K, BX, BY>;
+    constexpr int HW = 2 * K, LXW = TL::LX, LYW = TL::LY;
+    constexpr int OWN = BX * BY;                                         // values per species a tile publishes
+    constexpr int RINGH = LXW * LYW - OWN;                               // halo values per species
+    constexpr int NPUB = (2 * OWN + NT - 1) / NT, NGAT = (2 * RINGH + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* b0 = reinterpret_cast<T*>(smem_raw) + lds_pad0<T>::value;
+    T* b1 = reinterpret_cast<T*>(smem_raw) + 2 * TL::PLANE + lds_pad1<T>::value;
+    const int tile = tile_of_block(blockIdx.x, g);
+    const int tiles_y = (g.H + BY - 1) / BY;
+    const int tyi = tile / g.tiles_x, txi = tile % g.tiles_x;
+    const int ty0 = tyi * BY, tx0 = txi * BX;
+    const int ntiles = g.tiles_x * tiles_y;
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    gu64* outbox = (gu64*)pa.outbox;
+    // LDS: state buffers | gather tables | abort word
+    int* tab_gl = reinterpret_cast<int*>(smem_raw + tile_state_bytes<T, K, BX, BY>());      // [NGAT][NT]: LDS position of a halo value
+    int* tab_gs = tab_gl + NGAT * NT;                                                       // [NGAT][NT]: granule index inside a parity half
+    unsigned* tab_geo = reinterpret_cast<unsigned*>(tab_gs + NGAT * NT);                    // [K][NT]: the lane's strip in each sub-step
+    int* wg_abort = reinterpret_cast<int*>(tab_geo + K * NT);
+    // Measured and not adopted (profiles/r05_small_tile_resident_forward.txt): strip geometry from the table (GEO) together with
+    // plain instead of write-through frame stores -- what pays in the 32 x 32 resident forward -- 100^2 1.075 -> 1.096 us per
+    // step, 256^2 1.137 -> 1.165: these sub-steps are a single wave per SIMD with one strip, the division by a constant they save
+    // is cheaper than the table read, and write-back lines of the frames compete with the granules later
+    constexpr bool GEO = false, WT = true;
+    static_assert(K == 4, "geometry rows below");
+    if constexpr (GEO) {
+        tab_geo[0 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 0, PART_FULL, 0>(g, ty0, tx0);
+        tab_geo[1 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 1, PART_FULL, 0>(g, ty0, tx0);
+        tab_geo[2 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 2, PART_FULL, 0>(g, ty0, tx0);
+        tab_geo[3 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 3, PART_FULL, 0>(g, ty0, tx0);
+    }
+    if (threadIdx.x == 0) {                                                                 // residency roll call (pi_adj2d_persist_kernel)
+        *wg_abort = 0;
+        const unsigned n = __hip_atomic_fetch_add(pa.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (n == (unsigned)ntiles && pa.host) __hip_atomic_store(pa.host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+#pragma unroll
+    for (int q = 0; q < NGAT; ++q) {                       // (the tables of pi_adj2d_persist_small_kernel)
+        const int r = (int)threadIdx.x + q * NT;
+        int gl = -1, gs = 0;
+        if (r < 2 * RINGH) {
+            const int sp = r / RINGH, e = r - sp * RINGH;
+            int wy, wx;                                    // ring positions row-major over the window, skipping the centre
+            if (e < HW * LXW) { wy = e / LXW; wx = e - wy * LXW; }
+            else if (e < HW * LXW + BY * 2 * HW) { const int m = e - HW * LXW; wy = HW + m / (2 * HW); const int c = m % (2 * HW); wx = c < HW ? c : BX + c; }
+            else { const int m = e - HW * LXW - BY * 2 * HW; wy = HW + BY + m / LXW; wx = m % LXW; }
+            int gy = (ty0 + wy - HW) % g.H, gx = (tx0 + wx - HW) % g.W;                     // the global point, periodic
+            gy += gy < 0 ? g.H : 0;
+            gx += gx < 0 ? g.W : 0;
+            const int nty = gy / BY, ntx = gx / BX;
+            gl = sp * TL::PLANE + wy * LXW + wx;
+            gs = (nty * g.tiles_x + ntx) * (2 * OWN) + sp * OWN + (gy - nty * BY) * BX + (gx - ntx * BX);
+        }
+        tab_gl[q * NT + (int)threadIdx.x] = gl;
+        tab_gs[q * NT + (int)threadIdx.x] = gs;
+    }
+    // group 0 starts from frame t0 in memory (window = tile + ring), like a launch of pi_fwd2d_tile_kernel
+    tile_load<T, K, BX, BY, NT>(frames, g, ty0, tx0, b0);
+    __syncthreads();
+    const int tid = (int)threadIdx.x;
+    for (int grp = 0; grp < pa.ngroups; ++grp) {
+        T* fr = frames + (long)grp * K * frame_stride;                    // this group's frame t
+        const bool last = grp + 1 == pa.ngroups;
+        // frames t + 1 .. t + K - 1 go to memory as in the launch-per-group kernel (idle-wave stores included); frame t + K is
+        // complete in buffer 0 after the barrier that ends sub-step K - 1
+        fwd_substeps<T, POLY, K, BX, BY, NT, 0, false, GEO, WT>(b0, b1, fr, frame_stride, g, ty0, tx0, P, tab_geo);
+        if (last) {
+            tile_store<T, K, BX, BY, NT, true, WT>(b0, fr + (long)K * frame_stride, g, ty0, tx0);
+            break;
+        }
+        // ---- hand-over: publish my tile, request my ring, THEN store the frame ----
+        const unsigned epoch = (unsigned)grp + 1u;
+        gu64* half = outbox + (size_t)(epoch & 1u) * (size_t)ntiles * (2 * OWN);
+        gu64* mine = half + (size_t)tile * (2 * OWN);
+#pragma unroll
+        for (int q = 0; q < NPUB; ++q) {
+            const int i = tid + q * NT;
+            if (i < 2 * OWN) {
+                const int sp = i / OWN, e = i - sp * OWN, y = e / BX, x = e - y * BX;
+                const unsigned v = __builtin_bit_cast(unsigned, b0[sp * TL::PLANE + (HW + y) * LXW + HW + x]);
+                __hip_atomic_store(mine + i, ((unsigned long long)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        tile_store<T, K, BX, BY, NT, true, WT>(b0, fr + (long)K * frame_stride, g, ty0, tx0);
+        for (int w = 0; w < pa.pause; ++w) __builtin_amdgcn_s_sleep(1);
+        int gl[NGAT], gs[NGAT];
+        unsigned long long gx[NGAT];
+#pragma unroll
+        for (int q = 0; q < NGAT; ++q) {
+            gl[q] = tab_gl[q * NT + tid];
+            gs[q] = tab_gs[q * NT + tid];
+            gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (lanes without: granule 0)
+        }
+        const unsigned long long t0 = wall_clock64();
+        const unsigned long long bound = grp == 0 ? pa.first_timeout_ticks : pa.timeout_ticks;
+        bool failed = false;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < NGAT; ++q)
+                if (gl[q] >= 0) ok &= (unsigned)(gx[q] >> 32) == epoch;
+            if (__all(ok)) break;
+            if (wall_clock64() - t0 > bound ||
+                __hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { failed = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int q = 0; q < NGAT; ++q)                      // only what has not arrived yet is asked for again
+                if (gl[q] >= 0 && (unsigned)(gx[q] >> 32) != epoch)
+                    gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (failed) {
+            if (threadIdx.x % WAVE == 0) *wg_abort = 1;
+        } else {
+#pragma unroll
+            for (int q = 0; q < NGAT; ++q)
+                if (gl[q] >= 0) b0[gl[q]] = __builtin_bit_cast(T, (unsigned)gx[q]);
+        }
+        lds_barrier();
+        if (*wg_abort) {
+            // ABORT: frames written so far are the launch-per-group kernel's values, but the launch reports failure and the host
+            // recomputes the rollout launch by launch (deterministic)
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(pa.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_exchange(pa.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && pa.host) {
+                    __hip_atomic_store(pa.host + 1, grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pa.host + 2, tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pa.host + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            return;
+        }
     }
 }
 

@@ -793,7 +793,7 @@ def test_persistent_forward_equals_launch_per_group(shape, T, hip_device):
     from percnn_amd import _lib
     assert _lib.rollout_plan(0, shape, 4)["fwd_persistent"] and not _lib.rollout_plan(0, shape, 4, "fwd_persist=0")["fwd_persistent"]
     assert not _lib.rollout_plan(0, shape, 8)["fwd_persistent"] and not _lib.rollout_plan(8, shape, 4)["fwd_persistent"]
-    assert not _lib.rollout_plan(0, (100, 100), 4)["fwd_persistent"] and not _lib.rollout_plan(0, (1024, 1024), 4)["fwd_persistent"]
+    assert not _lib.rollout_plan(0, (1024, 1024), 4)["fwd_persistent"]
     short = torch.empty((24 + 1, 2) + shape, dtype=torch.float32, device=hip_device)      # fewer than eight groups: launch per group
     short[0] = 0.5
     n_short = _lib.persist_status()["launches"]
@@ -865,6 +865,76 @@ def test_persistent_sweeps_fuzz(hip_device):
         if bool(torch.isfinite(traj[-1]).all()):
             assert rel_l2(ag.cpu().numpy(), bg.cpu().numpy()) < 2e-6, (it, shape, T, kind)
     assert _lib.persist_status()["aborts"] == n0
+
+
+@pytest.mark.parametrize("shape,T", [((100, 100), 41), ((128, 128), 37), ((64, 96), 33), ((256, 256), 36), ((40, 200), 35), ((72, 64), 34),
+                                     ((288, 288), 33), ((300, 320), 35),       # the 32 x 16 / 320-lane regime
+                                     ((500, 500), 33), ((420, 500), 34),       # ragged grids of 32 x 32 tiles
+                                     ((32, 64), 40), ((64, 32), 32)])          # eight tiles of two / one tile column(s)
+def test_small_tile_persistent_forward_equals_launch_per_group(shape, T, hip_device):
+    """Round 5: the forward rollout of the small-tile regime (32 x 8 / 32 x 16 tiles; the reference's own 100^2
+    among the shapes) and of ragged grids of 32 x 32 tiles as ONE launch of resident workgroups (pi_fwd2d_persist_small_kernel):
+    every frame bit for bit the launch-per-group kernel's (same sub-step functions; whole tiles travel as tagged granules, gather
+    tables from global coordinates), T not a multiple of four, the C oracle on the small cases, rollouts shorter than eight groups
+    stay on launches, `fwd_persist=0` is the old path, no aborts."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    # by default the 8-row regime only (the others measured slower than one launch per group); persist_small = 2 takes them all
+    small8 = _lib.rollout_plan(0, shape, 4)["tile_fwd"] == (32, 8, 256)
+    opt = {} if small8 else {"persist_small": 2}
+    ostr = "" if small8 else "persist_small=2"
+    assert _lib.rollout_plan(0, shape, 4, ostr or None)["fwd_persistent"] and _lib.rollout_plan(0, shape, 4)["fwd_persistent"] == small8
+    assert not _lib.rollout_plan(0, shape, 4, "fwd_persist=0")["fwd_persistent"]
+    assert not _lib.rollout_plan(0, shape, 4, "persist_small=0")["fwd_persistent"]
+    rs = np.random.RandomState(7)
+    Pn = random_block(0, 2, np.float32, 29, scale=0.1)
+    P = dev_t(Pn, hip_device)
+    h0 = rs.uniform(0, 1, (2,) + shape).astype(np.float32)
+    short = torch.empty((28 + 1, 2) + shape, dtype=torch.float32, device=hip_device)      # seven groups: launch per group
+    short[0] = dev_t(h0, hip_device)
+    n_short = _lib.persist_status()["launches"]
+    pa.rollout_fwd_(short, P, options=opt)
+    assert _lib.persist_status()["launches"] == n_short
+    n0 = _lib.persist_status()
+    a = torch.full((T + 1, 2) + shape, float("nan"), dtype=torch.float32, device=hip_device)
+    b = torch.full_like(a, float("nan"))
+    a[0] = dev_t(h0, hip_device)
+    b[0] = a[0]
+    pa.rollout_fwd_(a, P, options=opt)
+    pa.rollout_fwd_(b, P, options={"fwd_persist": 0})
+    n1 = _lib.persist_status()
+    assert n1["launches"] == n0["launches"] + 1 and n1["aborts"] == n0["aborts"]
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert torch.equal(a[:29], short)
+    if shape[0] * shape[1] <= 128 * 128:
+        assert np.array_equal(a[:13].cpu().numpy(), o_rollout_fwd(h0, Pn, 12))
+    # twice, back to back on the same stream (the per-device granule scratch is reused: epochs start over), then on another stream
+    c = torch.full_like(a, float("nan"))
+    c[0] = a[0]
+    pa.rollout_fwd_(c, P, options=opt)
+    assert torch.equal(c, a)
+    s2 = torch.cuda.Stream(device=hip_device)
+    s2.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s2):
+        d = torch.full_like(a, float("nan"))
+        d[0] = a[0]
+        pa.rollout_fwd_(d, P, options=opt)
+    s2.synchronize()
+    assert torch.equal(d, a) and _lib.persist_status()["aborts"] == n0["aborts"]
+    if shape == (100, 100):                                 # the module path on the reference's own grid and rollout length
+        cell = pa.gs2d_cell(8).to(hip_device)
+        for f in cell.filter_list:
+            f.weight.data.mul_(12.0)
+        cell.invalidate_cache()
+        h = dev_t(h0[None], hip_device)
+        with torch.no_grad():
+            o1, _ = pa.RCNN(cell, step=200, effective_step=list(range(200)), init_state=h)()
+            pa.set_option("fwd_persist", 0)
+            try:
+                o2, _ = pa.RCNN(cell, step=200, effective_step=list(range(200)), init_state=h)()
+            finally:
+                pa.set_option("fwd_persist", 1)
+        assert torch.equal(o1.stacked, o2.stacked)
 
 
 @pytest.mark.parametrize("shape,T", [((100, 100), 41), ((128, 128), 23), ((64, 96), 17), ((256, 256), 12), ((40, 200), 9), ((72, 64), 13),
