@@ -63,6 +63,7 @@ struct Options {
     int fwd_small_pause = 12;   // small-tile resident forward: 64-clock units between publish and the first ring request (PersistArgs::pause)
     int persist_small = 1;      // the 32 x 8-tile regime (grids below ~300^2, split schedule) as one persistent launch too
     int fwd_persist_per_cu = 1; // ... on grids of up to this many tiles per CU (1 or 2)
+    int fwd_persist_f64 = 1;    // ... float64 too (lambda-omega; 16-byte granules)
     int fwd_persist = 1;        // the FORWARD rollout of such a grid as one launch of resident workgroups too (pi_fwd2d_persist_kernel;
                             // same residency check / abort / fallback; its granule outbox is a per-device scratch of the library)
     int persist_split = 1;      // persistent sweep: 1 = split flavour (pi_adj2d_persist_split_kernel: the halo-independent
@@ -1169,9 +1170,9 @@ int device_cu_count()
 
 bool persist_disabled_here();
 constexpr int PERSIST_BAND = 2 * (TILE_B * TILE_B - (TILE_B - 16) * (TILE_B - 16));     // granules per tile and parity (K = 4)
-size_t persist_outbox_bytes(const Problem& p)
+size_t persist_outbox_bytes(const Problem& p, int elem = 4)     // 8-byte granules (float32), 16-byte ones (float64 forward)
 {
-    return (size_t)2 * (size_t)((p.n0 / TILE_B) * (p.W / TILE_B)) * PERSIST_BAND * sizeof(unsigned long long);
+    return (size_t)2 * (size_t)((p.n0 / TILE_B) * (p.W / TILE_B)) * PERSIST_BAND * (elem == 8 ? 16 : 8);
 }
 
 // can the tile sweep of this rollout run as one cooperative launch?  (everything the kernel assumes, checked here)
@@ -1381,7 +1382,8 @@ bool fwd_persist_ok(const Problem& p, int ngroups, hipStream_t st)
 {
     // (eight groups at least: short rollouts -- the step loop's speculative groups of 8 / 16 steps among them -- keep the
     // launch-per-group kernel and with it a host that never waits for the stream)
-    if (!p.opt.tile_persist || !p.opt.fwd_persist || sizeof(T) != 4 || ngroups < 8) return false;
+    // (float64 since round 5 -- lambda-omega, BASELINE configs[2] -- on 16-byte granules; option fwd_persist_f64)
+    if (!p.opt.tile_persist || !p.opt.fwd_persist || (sizeof(T) != 4 && !p.opt.fwd_persist_f64) || ngroups < 8) return false;
     if (persist_disabled_here()) return false;
     // what the launch-per-group path would run as pi_fwd2d_tile_kernel<float, poly, 4, 32, 32, 512> (the trajectory is that kernel's)
     if (p.hc != 0 || p.opt.tile_k != 4 || p.opt.tile_nt != 512 || tile_by_for(p) != TILE_B || tile_wide_for<T>(p, false) != 0) return false;
@@ -1414,7 +1416,7 @@ hipError_t launch_fwd_persist(T* frame_t0, int ngroups, const T* P, const Proble
     }
     if (resident[dev] < 0 || (int64_t)grid > (int64_t)device_cu_count() * resident[dev]) return hipErrorCooperativeLaunchTooLarge;
     // per-device scratch: 256 B of sync words | granule outbox (allocated once, sized for this grid or larger)
-    const size_t need = 256 + persist_outbox_bytes(p);
+    const size_t need = 256 + persist_outbox_bytes(p, (int)sizeof(T));
     unsigned char* scratch;
     {
         std::lock_guard<std::mutex> lk(g_persist.mu);
@@ -2270,16 +2272,21 @@ int rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* shape
         const int K = (p.opt.tile_k == 8 && p.hc != 0) ? 4 : p.opt.tile_k;
         // whole groups of four steps as ONE launch of resident workgroups where the grid allows (pi_fwd2d_persist_kernel: the
         // launch-per-group kernel's trajectory bit for bit); an aborted launch is recomputed below, launch by launch
-        if constexpr (sizeof(T) == 4) {
+        {
             const int ngroups = K == 4 ? T_steps / K : 0;
             int pdev = 0;
             const bool big = fwd_persist_ok<T>(p, ngroups, st);
             // ... and the grids the 32 x 32 flavour does not take -- small-tile regime, ragged grids, fewer than 16 tiles -- on
-            // pi_fwd2d_persist_small_kernel (round 5)
-            const int small_by = big ? 0 : fwd_persist_small_by<T>(p, ngroups, st);
+            // pi_fwd2d_persist_small_kernel (round 5; float32)
+            int small_by = 0;
+            if constexpr (sizeof(T) == 4) small_by = big ? 0 : fwd_persist_small_by<T>(p, ngroups, st);
             if ((big || small_by) && persist_enter(st, pdev)) {
-                const hipError_t e = big ? launch_fwd_persist<T>(traj, ngroups, P, p, pdev, st)
-                                         : launch_fwd_persist_small<T>(small_by, traj, ngroups, P, p, pdev, st);
+                hipError_t e;
+                if constexpr (sizeof(T) == 4)
+                    e = big ? launch_fwd_persist<T>(traj, ngroups, P, p, pdev, st)
+                            : launch_fwd_persist_small<T>(small_by, traj, ngroups, P, p, pdev, st);
+                else
+                    e = launch_fwd_persist<T>(traj, ngroups, P, p, pdev, st);
                 if (e == hipSuccess) { t = K * ngroups; persist_leave(st, pdev); }
                 else if (e == hipErrorLaunchTimeOut) return (int)e;
                 else {
@@ -2689,6 +2696,7 @@ int apply_option(Options& o, const char* key, long value)
     if (!std::strcmp(key, "persist_split")) { o.persist_split = value != 0; return 0; }
     if (!std::strcmp(key, "persist_small")) { if (value < 0 || value > 2) return PERCNN_PI_EINVAL; o.persist_small = (int)value; return 0; }
     if (!std::strcmp(key, "fwd_persist")) { o.fwd_persist = value != 0; return 0; }
+    if (!std::strcmp(key, "fwd_persist_f64")) { o.fwd_persist_f64 = value != 0; return 0; }
     if (!std::strcmp(key, "fwd_persist_per_cu")) {
         if (value < 1 || value > 2) return PERCNN_PI_EINVAL;
         o.fwd_persist_per_cu = (int)value;
@@ -2949,6 +2957,8 @@ int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options,
         out[14] = ((out[1] == 1 && (persist_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr) ||
                                     persist_small_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr))) ? 1 : 0) |
                   ((out[0] == 1 && (fwd_persist_ok<T>(p, 1 << 18, nullptr) || fwd_persist_small_by<T>(p, 1 << 18, nullptr) != 0)) ? 2 : 0);
+    else
+        out[14] = (out[0] == 1 && fwd_persist_ok<T>(p, 1 << 18, nullptr)) ? 2 : 0;
     for (int dir = 0; dir < 2; ++dir) {                                    // 2D tiles: width, height, lanes per workgroup
         if (out[dir] != 1) continue;
         const TileShape ts = tile_shape_for<T>(p, dir == 1);

@@ -1825,7 +1825,7 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
                               long frame_stride, T* __restrict__ g_h0, double* __restrict__ partials, int np,
                               const T* __restrict__ P, TileGeom g, PersistArgs pa)
 {
-    static_assert(sizeof(T) == 4 && BX == BY && K == 4 && BX == 32 && NT == 512, "float32, 32 x 32 tiles, four sub-steps, 8 waves");
+    static_assert(BX == BY && K == 4 && BX == 32 && NT == 512, "32 x 32 tiles, four sub-steps, 8 waves");
     using TL = Tile<K, BX, BY>;
     constexpr int HW = 2 * K, LXW = TL::LX;
     constexpr int BANDH = BX * BX - (BX - 2 * HW) * (BX - 2 * HW);      // border values per species
@@ -2096,6 +2096,44 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
 // Levels alternate between the two LDS buffers exactly as in pi_fwd2d_tile_kernel; a strip is computed by the same lds_star4 /
 // poly_r / update sequence: the trajectory is that kernel's bit for bit.
 // ------------------------------------------------------------------------------------------------
+// Data-tagged granules by value type.  float32: the 8-byte word {tag, value} of the sweeps (one agent-scope store / load).
+// float64 (round 5, configs[2]): a 16-byte granule {lo32, tag, hi32, tag} = two self-validating 8-byte words written by ONE
+// 16-byte write-through (sc1) store and read by ONE 16-byte sc1 load -- the request count of a hand-over stays that of the
+// float32 ring (requests are what it costs, not bytes); the reader accepts when BOTH tags match, so a torn pair is just "not yet".
+typedef unsigned pi_v4u __attribute__((ext_vector_type(4)));
+template <typename T> struct GranuleIO;
+template <> struct GranuleIO<float> {
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    using Raw = unsigned long long;
+    static constexpr int BYTES = 8;
+    gu64* base;
+    __device__ __forceinline__ GranuleIO(void* outbox, size_t) : base((gu64*)outbox) {}
+    __device__ __forceinline__ void put(size_t idx, unsigned epoch, float v) const
+    {
+        __hip_atomic_store(base + idx, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ Raw get(size_t idx) const { return __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return (unsigned)(x >> 32) == epoch; }
+    static __device__ __forceinline__ float value(Raw x) { return __builtin_bit_cast(float, (unsigned)x); }
+};
+template <> struct GranuleIO<double> {
+    using Raw = pi_v4u;
+    static constexpr int BYTES = 16;
+    __amdgpu_buffer_rsrc_t rs;
+    // (the descriptor is built from kernel arguments only: wave-uniform by construction)
+    __device__ __forceinline__ GranuleIO(void* outbox, size_t bytes) : rs(__builtin_amdgcn_make_buffer_rsrc(outbox, 0, (int)bytes, 0x00020000)) {}
+    __device__ __forceinline__ void put(size_t idx, unsigned epoch, double v) const
+    {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+        const pi_v4u w = {(unsigned)b, epoch, (unsigned)(b >> 32), epoch};
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)(idx * 16), 0, /*aux: sc1*/ 16);
+    }
+    __device__ __forceinline__ Raw get(size_t idx) const { return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(idx * 16), 0, 16); }
+    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return x.y == epoch && x.w == epoch; }
+    static __device__ __forceinline__ double value(Raw x) { return __builtin_bit_cast(double, ((unsigned long long)x.z << 32) | x.x); }
+};
+
 // one strip of the forward sub-step, placed by a geometry word (persist_geo_word); pre-contracted block
 template <typename T, int K, int BX, int BY>
 __device__ __forceinline__ void fwd_strip_geo(const T* cur, T* nxt, const T* __restrict__ P, unsigned w)
@@ -2132,8 +2170,7 @@ template <typename T, int K, int BX, int BY, int NT, int FIRST, bool PADDED, int
 __device__ __forceinline__ void persist_fwd_store(const T* buf, T* __restrict__ dst, const TileGeom& g, int ty0, int tx0)
 {
     using TL = Tile<K, BX, BY>;
-    constexpr int VEC = vec_width<T>::value;
-    static_assert(VEC == 4, "float32 chunks");
+    constexpr int VEC = vec_width<T>::value;                               // 16-byte chunks: 4 float32 / 2 float64
     constexpr int BXV = BX / VEC, N = 2 * BY * BXV, LANES = NT - FIRST;
     constexpr int SIDE = BX - 4 * (K - 1), O2 = (BX - SIDE) / 2;           // I_2's output square: side 20 at offset 6
     constexpr int R0 = O2, R1 = O2 + SIDE, C0 = O2 / VEC, C1 = (O2 + SIDE + VEC - 1) / VEC;
@@ -2178,7 +2215,7 @@ __global__ void __launch_bounds__(NT)
 pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngroups are written */, long frame_stride,
                         const T* __restrict__ P, TileGeom g, PersistArgs pa)
 {
-    static_assert(sizeof(T) == 4 && BX == BY && K == 4 && BX == 32 && NT == 512, "float32, 32 x 32 tiles, four sub-steps, 8 waves");
+    static_assert(BX == BY && K == 4 && BX == 32 && NT == 512, "32 x 32 tiles, four sub-steps, 8 waves");
     using TL = Tile<K, BX, BY>;
     constexpr int HW = 2 * K, LXW = TL::LX;
     constexpr int BANDH = BX * BX - (BX - 2 * HW) * (BX - 2 * HW);      // border values per species
@@ -2193,8 +2230,7 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
     const int tyi = tile / g.tiles_x, txi = tile % g.tiles_x, tiles_y = g.H / BY;
     const int ty0 = tyi * BY, tx0 = txi * BX;
     const int ntiles = g.tiles_x * tiles_y;
-    typedef __attribute__((address_space(1))) unsigned long long gu64;
-    gu64* outbox = (gu64*)pa.outbox;
+    const GranuleIO<T> gio(pa.outbox, (size_t)2 * (size_t)ntiles * (2 * BANDH) * GranuleIO<T>::BYTES);
 
     // LDS: state buffers | int tables (publish, gather, geometry) | abort word
     int* tab_pub = reinterpret_cast<int*>(smem_raw + tile_state_bytes<T, K, BX, BY>());     // [NPUB][NT]: LDS position of a border value
@@ -2259,9 +2295,9 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
         lds_barrier();
         PI_PSTAMP(1);
         const unsigned epoch = (unsigned)grp;
-        gu64* half = outbox + (size_t)(epoch & 1u) * (size_t)ntiles * (2 * BANDH);
+        const size_t half = (size_t)(epoch & 1u) * (size_t)ntiles * (2 * BANDH);          // granule index of this parity's half
         int gs[NGAT];
-        unsigned long long gx[NGAT];
+        typename GranuleIO<T>::Raw gx[NGAT];
         auto request = [&]() {
             if (grp > 0) {
 #if PI_FWD_PERSIST_PAUSE
@@ -2270,7 +2306,7 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
 #pragma unroll
                 for (int q = 0; q < NGAT; ++q) {
                     gs[q] = tab_gs[q * NT + tid];
-                    gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (lanes without: granule 0)
+                    gx[q] = gio.get(half + (size_t)gs[q]);                                 // (lanes without: granule 0)
                 }
             }
         };
@@ -2291,15 +2327,14 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
                 bool ok = true;
 #pragma unroll
                 for (int q = 0; q < NGAT; ++q)
-                    if (gl[q] >= 0) ok &= (unsigned)(gx[q] >> 32) == epoch;
+                    if (gl[q] >= 0) ok &= GranuleIO<T>::ok(gx[q], epoch);
                 if (__all(ok)) break;
                 if (wall_clock64() - t0 > bound ||
                     __hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { failed = true; break; }
                 __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                 for (int q = 0; q < NGAT; ++q)
-                    if (gl[q] >= 0 && (unsigned)(gx[q] >> 32) != epoch)
-                        gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (gl[q] >= 0 && !GranuleIO<T>::ok(gx[q], epoch)) gx[q] = gio.get(half + (size_t)gs[q]);
             }
             if (failed) {
                 if (threadIdx.x % WAVE == 0) *wg_abort = 1;
@@ -2307,7 +2342,7 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
                 // (the ring of b0 -- level 0 -- is read by A_0 only; I_1 above wrote b0's centre)
 #pragma unroll
                 for (int q = 0; q < NGAT; ++q)
-                    if (gl[q] >= 0) b0[gl[q]] = __builtin_bit_cast(T, (unsigned)gx[q]);
+                    if (gl[q] >= 0) b0[gl[q]] = GranuleIO<T>::value(gx[q]);
             }
         }
         lds_barrier();
@@ -2348,14 +2383,11 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
         }
         // ---- publish my band of level 4 (complete since the barrier) ----
         const unsigned ep1 = (unsigned)grp + 1u;
-        gu64* mine = outbox + (size_t)(ep1 & 1u) * (size_t)ntiles * (2 * BANDH) + (size_t)tile * (2 * BANDH);
+        const size_t mine = (size_t)(ep1 & 1u) * (size_t)ntiles * (2 * BANDH) + (size_t)tile * (2 * BANDH);
 #pragma unroll
         for (int q = 0; q < NPUB; ++q) {
             const int pl = tab_pub[q * NT + tid];
-            if (pl >= 0) {
-                const unsigned v = __builtin_bit_cast(unsigned, b0[pl]);
-                __hip_atomic_store(mine + tid + q * NT, ((unsigned long long)ep1 << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (pl >= 0) gio.put(mine + (size_t)(tid + q * NT), ep1, b0[pl]);
         }
         PI_PSTAMP(8);
         // (no barrier: P0 reads b0 -- complete -- and writes b1 inside I_0's square; the store of level 3 from b1 was issued before

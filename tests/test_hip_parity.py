@@ -792,7 +792,7 @@ def test_persistent_forward_equals_launch_per_group(shape, T, hip_device):
     import percnn_amd as pa
     from percnn_amd import _lib
     assert _lib.rollout_plan(0, shape, 4)["fwd_persistent"] and not _lib.rollout_plan(0, shape, 4, "fwd_persist=0")["fwd_persistent"]
-    assert not _lib.rollout_plan(0, shape, 8)["fwd_persistent"] and not _lib.rollout_plan(8, shape, 4)["fwd_persistent"]
+    assert _lib.rollout_plan(0, shape, 8)["fwd_persistent"] and not _lib.rollout_plan(8, shape, 4)["fwd_persistent"]   # (float64: round 5)
     assert not _lib.rollout_plan(0, (1024, 1024), 4)["fwd_persistent"]
     short = torch.empty((24 + 1, 2) + shape, dtype=torch.float32, device=hip_device)      # fewer than eight groups: launch per group
     short[0] = 0.5
@@ -865,6 +865,52 @@ def test_persistent_sweeps_fuzz(hip_device):
         if bool(torch.isfinite(traj[-1]).all()):
             assert rel_l2(ag.cpu().numpy(), bg.cpu().numpy()) < 2e-6, (it, shape, T, kind)
     assert _lib.persist_status()["aborts"] == n0
+
+
+@pytest.mark.parametrize("shape,T", [((384, 384), 35), ((512, 512), 41), ((288, 512), 33)])
+def test_persistent_forward_float64_equals_launch_per_group(shape, T, hip_device):
+    """Round 5 (BASELINE configs[2], percnn_LO_eqn.py:12,169-218): the float64 forward rollout of a grid of
+    whole 32 x 32 tiles as ONE launch of resident workgroups -- pi_fwd2d_persist_kernel<double> on 16-byte granules
+    {lo32, tag, hi32, tag} (one sc1 store / one sc1 load per value, both tags must match).  Every frame bit for bit the
+    launch-per-group kernel's, the C oracle on the first frames, `fwd_persist_f64=0` is the old path, short rollouts stay on
+    launches, twice back to back and on a second stream, no aborts."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    assert _lib.rollout_plan(0, shape, 8)["fwd_persistent"] and not _lib.rollout_plan(0, shape, 8, "fwd_persist_f64=0")["fwd_persistent"]
+    assert not _lib.rollout_plan(0, shape, 8, "fwd_persist=0")["fwd_persistent"] and not _lib.rollout_plan(4, shape, 8)["fwd_persistent"]
+    rs = np.random.RandomState(8)
+    Pn = random_block(0, 2, np.float64, 37, scale=0.1)
+    P = dev_t(Pn, hip_device)
+    h0 = rs.uniform(0, 1, (2,) + shape)
+    short = torch.empty((28 + 1, 2) + shape, dtype=torch.float64, device=hip_device)
+    short[0] = dev_t(h0, hip_device)
+    n_short = _lib.persist_status()["launches"]
+    pa.rollout_fwd_(short, P)
+    assert _lib.persist_status()["launches"] == n_short
+    n0 = _lib.persist_status()
+    a = torch.full((T + 1, 2) + shape, float("nan"), dtype=torch.float64, device=hip_device)
+    b = torch.full_like(a, float("nan"))
+    a[0] = dev_t(h0, hip_device)
+    b[0] = a[0]
+    pa.rollout_fwd_(a, P)
+    pa.rollout_fwd_(b, P, options={"fwd_persist_f64": 0})
+    n1 = _lib.persist_status()
+    assert n1["launches"] == n0["launches"] + 1 and n1["aborts"] == n0["aborts"]
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+    assert torch.equal(a[:29], short)
+    if shape == (288, 512):
+        assert np.array_equal(a[:5].cpu().numpy(), o_rollout_fwd(h0, Pn, 4))
+    c = torch.full_like(a, float("nan"))
+    c[0] = a[0]
+    pa.rollout_fwd_(c, P)
+    s2 = torch.cuda.Stream(device=hip_device)
+    s2.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s2):
+        d = torch.full_like(a, float("nan"))
+        d[0] = a[0]
+        pa.rollout_fwd_(d, P)
+    s2.synchronize()
+    assert torch.equal(c, a) and torch.equal(d, a) and _lib.persist_status()["aborts"] == n0["aborts"]
 
 
 @pytest.mark.parametrize("shape,T", [((100, 100), 41), ((128, 128), 37), ((64, 96), 33), ((256, 256), 36), ((40, 200), 35), ((72, 64), 34),

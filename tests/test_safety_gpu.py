@@ -129,6 +129,40 @@ def test_persistent_forward_aborts_cleanly_and_falls_back(hip_device):
     assert _lib.rollout_plan(0, (512, 512), 4)["fwd_persistent"]
 
 
+def test_persistent_forward_float64_aborts_cleanly_and_falls_back(hip_device):
+    """the float64 resident forward (round 5) with CUs held by another kernel: gives up at its first hand-over, the same call
+    recomputes the trajectory launch by launch -- bit-identical, no NaNs"""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    pa.set_option("persist_reset", 1)
+    shape, T = (512, 512), 36
+    P = torch.tensor(random_block(0, 2, np.float64, 37, scale=0.1), device=hip_device)
+    h0 = torch.rand((2,) + shape, dtype=torch.float64, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(5))
+    ref = torch.empty((T + 1, 2) + shape, dtype=torch.float64, device=hip_device)
+    ref[0] = h0
+    pa.rollout_fwd_(ref, P, options={"fwd_persist": 0})
+    s0 = _lib.persist_status()
+    a = torch.full_like(ref, float("nan"))
+    a[0] = h0
+    pa.rollout_fwd_(a, P)
+    s1 = _lib.persist_status()
+    assert s1["launches"] == s0["launches"] + 1 and s1["aborts"] == s0["aborts"] and torch.equal(a, ref)
+    torch.cuda.synchronize()
+    try:
+        _hog(16, 150 * 1024, 1500, hip_device)                   # one 113 KB workgroup per CU: 240 free CUs cannot hold 256
+        b = torch.full_like(ref, float("nan"))
+        b[0] = h0
+        pa.rollout_fwd_(b, P, options={"persist_first_timeout_ms": 20})
+        s2 = _lib.persist_status()
+        torch.cuda.synchronize()
+        assert s2["launches"] == s1["launches"] + 1 and s2["aborts"] == s1["aborts"] + 1 and s2["disabled_on_current_device"]
+        assert torch.isfinite(b).all() and torch.equal(b, ref)
+    finally:
+        torch.cuda.synchronize()
+        pa.set_option("persist_reset", 1)
+    assert _lib.rollout_plan(0, shape, 8)["fwd_persistent"]
+
+
 def test_small_tile_persistent_forward_aborts_cleanly_and_falls_back(hip_device):
     """The small-tile resident forward (round 5) under the same stress: CUs held by another kernel -> the launch gives up at its
     first hand-over, the same call recomputes the trajectory launch by launch (bit-identical, no NaNs), the device stays on the
