@@ -1166,7 +1166,7 @@ def sharded_series(dev, dist, rank, world, one_gpu, checkpoint=lambda res: None,
     small = bool(int(os.environ.get("PERCNN_BENCH_SMALL", "0")))          # test mode: tiny grids, same control flow
     hw, planes, halo = (64, 8, 4) if small else (256, 32, 4)
     Tw, reps = (6, 2) if small else (100, 5)      # (T = 100: the rollout length of configs[4]; 40 until round 4)
-    grids = (((32, 2), (16, 2)) if small else ((256, 10), (128, 40)))
+    grids = (((32, 2), (16, 2)) if small else ((256, 20), (128, 40)))       # (256^3: T = 10 until round 4)
     head_n, head_T = (32, 6) if small else (256, int(os.environ.get("PERCNN_BENCH_HEADLINE_T", "100")))
     sharded = world > 1 or force_p2p
     base = "dist" if one_gpu else "rccl"

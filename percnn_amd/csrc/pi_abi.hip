@@ -651,9 +651,14 @@ int brick_rz_for(const Problem& p, int vec, bool adjoint, bool wide = true)
 // (128^3, 32 x 256^2, 16 x 256^2) and lose 8-20 % wherever the coarser granule leaves a round partly empty (112^3, 144^3,
 // 64 x 256^2, the 256^3 adjoint); in the driver's 500-step 128^3 run the gain was inside the box-to-box spread (forward 8.40 ->
 // 7.84 us, adjoint 17.78 -> 18.29).  Not a default: option brick_nt = 512 selects them.
-int brick_nt_for(const Problem& p, int vec)
+// Round 5: FORWARD steps on rows of exactly 64 chunks (W = 256 float32) take the 512-lane bricks by default -- with the L2-sized XCD
+// regions, same box (us per forward step, 256 -> 512 lanes): 16 x 256^2 5.97 -> 5.62, 24 x 256^2 7.95 -> 7.49, 32 x 256^2 9.45 ->
+// 8.50, 64 x 256^2 16.06 -> 15.12; the adjoint loses or ties on all four and stays on 256 lanes (profiles/r05_brick_option_sweeps.txt)
+int brick_nt_for(const Problem& p, int vec, bool adjoint = true)
 {
     if (p.hc == 0 && p.loss.mode == 0 && p.W / std::max(1, vec) > pi::BRICK_CPR_MAX) return 512;     // wide rows (brick_rz_for)
+    if (!adjoint && p.opt.brick_nt == 0 && p.hc == 0 && p.loss.mode == 0 && p.W / std::max(1, vec) == pi::BRICK_CPR_MAX &&
+        p.n1 % 8 == 0) return 512;
     return (p.opt.brick_nt == 512 && p.hc == 0 && p.loss.mode == 0) ? 512 : 256;
 }
 
@@ -760,7 +765,7 @@ template <typename T>
 hipError_t brick_fwd(int rz, const T* h, T* out, const T* P, const Problem& p, hipStream_t st, const FusedPut* fp = nullptr)
 {
     if (p.hc == 0) {
-        if (rz <= 2 && brick_nt_for(p, 16 / (int)sizeof(T)) == 512)
+        if (rz <= 2 && brick_nt_for(p, 16 / (int)sizeof(T), false) == 512)
             return rz == 2 ? launch_brick_fwd<T, pi::POLY, 2, 512>(h, out, P, p, st, fp) : launch_brick_fwd<T, pi::POLY, 1, 512>(h, out, P, p, st, fp);
         if (rz == 4) return launch_brick_fwd<T, pi::POLY, 4>(h, out, P, p, st, fp);
         if (rz == 2) return launch_brick_fwd<T, pi::POLY, 2>(h, out, P, p, st, fp);
@@ -1611,7 +1616,10 @@ int fwd_persist_small_by(const Problem& p, int ngroups, hipStream_t st)
     if (by != 8 && p.opt.persist_small < 2) return 0;
     const int64_t tiles = ((p.n0 + by - 1) / by) * ((p.W + TILE_B - 1) / TILE_B);
     const int cus = device_cu_count();
-    if (tiles < 2 || cus <= 0 || tiles > cus || tiles > 256) return 0;       // one workgroup per CU at most: resident for sure
+    // one workgroup per CU at most: resident for sure (persist_small = 2, experiments: up to fwd_persist_per_cu x 2 per CU --
+    // the launch asks the runtime how many fit, the roll call decides)
+    const int64_t max_tiles = p.opt.persist_small >= 2 ? (int64_t)cus * 2 * p.opt.fwd_persist_per_cu : std::min<int64_t>(cus, 256);
+    if (tiles < 2 || cus <= 0 || tiles > max_tiles) return 0;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (st && (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) return 0;
     return by;
@@ -1659,6 +1667,11 @@ hipError_t launch_fwd_persist_small_t(T* frame_t0, int ngroups, const T* P, cons
     const size_t lds = pi::tile_state_bytes<T, K, TILE_B, BY>() + (size_t)(2 * NGAT + K) * NT * sizeof(int) + 16;
     auto* k = pi::pi_fwd2d_persist_small_kernel<T, K, TILE_B, BY, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
+    {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, NT, lds) != hipSuccess || nb < 1 ||
+            (int64_t)grid > (int64_t)device_cu_count() * nb) { (void)hipGetLastError(); return hipErrorCooperativeLaunchTooLarge; }
+    }
     // per-device scratch (shared with the 32 x 32 resident forward): 256 B of sync words | granule outbox: 2 parities x tiles x 2 x 32 x BY
     const size_t outbox_bytes = (size_t)2 * grid * (2 * TILE_B * BY) * sizeof(unsigned long long);
     const size_t need = 256 + outbox_bytes;
@@ -2159,27 +2172,30 @@ int slab_rollout_bwd_impl(const T* traj, const T* g_traj, T* adj, double* param_
         if (hipError_t e = hipMemsetAsync(adj + (size_t)s * ss + (size_t)(halo + n) * plane, 0,
                                           (size_t)halo * plane * sizeof(T), st)) return (int)e;
     }
-    // adj[T] interior = dL/dtraj[T] interior
-    for (int s = 0; s < 2; ++s) {
-        const size_t o = (size_t)T_steps * frame + (size_t)s * ss + (size_t)halo * plane;
-        if (hipError_t e = hipMemcpyAsync(adj + o, g_traj + o, (size_t)n * plane * sizeof(T), hipMemcpyDeviceToDevice, st))
-            return (int)e;
-    }
+    const bool by_index = !ring && !(overlap & 2) && p.opt.slab_local_index;     // one rank: wrap by index, no exchange
+    // float32 poly mode: the 20 coefficient moments are reduced inside the sweep launches (no slab_wgrad pass)
+    const bool fuse = hc == 0 && sizeof(T) == 4 && p.opt.fuse_wgrad != 0;
+    // adj[T] interior = dL/dtraj[T] interior (one rank, fused sums: the first sweep launch reads dL/dtraj[T] where it lies --
+    // nobody exchanges or re-reads adj[T])
+    const bool top_in_place = by_index && fuse && T_steps > 0;
+    if (!top_in_place)
+        for (int s = 0; s < 2; ++s) {
+            const size_t o = (size_t)T_steps * frame + (size_t)s * ss + (size_t)halo * plane;
+            if (hipError_t e = hipMemcpyAsync(adj + o, g_traj + o, (size_t)n * plane * sizeof(T), hipMemcpyDeviceToDevice, st))
+                return (int)e;
+        }
     if (T_steps == 0) return 0;
     if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
-    const bool by_index = !ring && !(overlap & 2) && p.opt.slab_local_index;     // one rank: wrap by index, no exchange
     overlap &= 1;
     SideStream* side = overlap && n >= 4 && !by_index ? side_stream() : nullptr;
     hipEvent_t pending = nullptr;
-    // float32 poly mode: the 20 coefficient moments are reduced inside the sweep launches (no slab_wgrad pass)
-    const bool fuse = hc == 0 && sizeof(T) == 4 && p.opt.fuse_wgrad != 0;
     auto sweep = [&](int t, int lo, int hi, bool strip = false) -> int {   // adjoint planes [lo, hi) of frame t-1 from frame t
         Problem q = p;
         if (by_index) q.slab_periodic = true;
         else if (int rc = set_slab_range(q, halo, lo, hi)) return rc;
         unsigned grid = 0;
         const T* hf = traj + (size_t)(t - 1) * frame;
-        const T* gf = adj + (size_t)t * frame;
+        const T* gf = (top_in_place && t == T_steps) ? g_traj + (size_t)t * frame : adj + (size_t)t * frame;
         const T* jf = g_traj + (size_t)(t - 1) * frame;
         T* of = adj + (size_t)(t - 1) * frame;
         // strips outside the interior (wide-halo blocks below) belong to the neighbour's sums: their partial rows go to a
@@ -2363,7 +2379,6 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
         return (int)hipMemsetAsync(g_h0, 0, frame_bytes, st);
     }
     if (hipError_t e = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e;
-    if (hipError_t e = top_frame(t_top, adj + (size_t)t_top * frame)) return (int)e;
 
     // 1) sequential reverse sweep: adjoint states (+ diffusion-coefficient gradients), with
     // 2) the time-parallel branch-gradient reduction of every finished chunk of steps running UNDER it on a side
@@ -2381,6 +2396,12 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
     // backward per step 1200^2 29.0 -> 25.1 us, 2048^2 71.5 -> 60.4, 3072^2 187 -> 143 -- no pi_moments_kernel pass)
     const bool fuse = tile_fused || (direct_sweep && !p.opt.skip_wgrad && hc != -1 &&
                                      (p.opt.fuse_wgrad == 1 || (p.opt.fuse_wgrad == 2 && hc == 0)));
+    // The top frame's dL/dh is dL/dtraj[t_top] itself.  Where every step is its own launch and nobody else reads the adjoint
+    // trajectory (fused gradient sums), the first step reads it where it lies instead of from a copy in adj[t_top] -- at 256^3
+    // that copy is 128 MiB, ~45 us of a 10-step rollout (round 5)
+    const T* top_in_place = (direct_sweep && fuse && !loss) ? ((g_top && t_top == T_steps) ? g_top : g_traj + (size_t)t_top * frame) : nullptr;
+    if (!top_in_place)
+        if (hipError_t e = top_frame(t_top, adj + (size_t)t_top * frame)) return (int)e;
     unsigned rows = 0, wrows = 0;
     auto reduce_range = [&](int lo, int hi, hipStream_t s2) -> hipError_t {      // steps (lo, hi]
         if (hi <= lo || p.opt.skip_wgrad || fuse) return hipSuccess;
@@ -2480,9 +2501,10 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
         T* dst = (t == 1) ? g_h0 : adj + (size_t)(t - 1) * frame;
         const T* inj = has(t - 1) ? g_traj + (size_t)(t - 1) * frame : nullptr;
         unsigned r2 = 0;
+        const T* gin = (top_in_place && t == t_top) ? top_in_place : adj + (size_t)t * frame;
         hipError_t e = fuse
-            ? step_bwd<T, true>(traj + (size_t)(t - 1) * frame, adj + (size_t)t * frame, inj, dst, w.partials, P, p, st, &r2)
-            : step_bwd<T, false>(traj + (size_t)(t - 1) * frame, adj + (size_t)t * frame, inj, dst, w.partials, P, p, st, &r2);
+            ? step_bwd<T, true>(traj + (size_t)(t - 1) * frame, gin, inj, dst, w.partials, P, p, st, &r2)
+            : step_bwd<T, false>(traj + (size_t)(t - 1) * frame, gin, inj, dst, w.partials, P, p, st, &r2);
         if (e) return (int)e;
         if (r2 > rows) rows = r2;
         if (hipError_t e2 = hand_over(t - 1)) return (int)e2;
@@ -2950,7 +2972,7 @@ int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options,
     out[2] = fuse ? 1 : 0;
     out[3] = out[0] == 1 ? K : 1;
     out[4] = out[1] == 1 ? K : 1;
-    out[7] = (out[0] == 3 || out[1] == 3) ? brick_nt_for(p, vec) : 0;     // lanes per brick workgroup
+    out[7] = (out[0] == 3 || out[1] == 3) ? brick_nt_for(p, vec, out[1] == 3) : 0;     // lanes per brick workgroup (the adjoint's if it runs on bricks)
     for (int i = 8; i < 15; ++i) out[i] = 0;
     // the whole tile sweep as one launch of resident workgroups (needs a device to ask for its CU count: 0 without one)
     if constexpr (sizeof(T) == 4)
