@@ -267,10 +267,13 @@ def measure_workload(pa, dev, dist, rank, world, name, steps, warmup, reaction, 
                       "launches_per_pass": 1, "algorithmic_bytes_per_launch": 4 * Cs * npts * (T // K) * K,
                       "avg_launch_us": sweep_ms * 1e3}
     # the forward of such a grid is one resident launch as well (pi_fwd2d_persist_kernel, round 4), unless switched off
-    fwd_persistent = bool(plan.get("fwd_persistent")) and Kf == 4 and T // Kf >= 2 and not opts.get("tile_persist") == "0" and \
+    # (rollouts of at least eight groups; round 5: the small-tile regime -- pi_fwd2d_persist_small_kernel -- and float64 too)
+    fwd_persistent = bool(plan.get("fwd_persistent")) and Kf == 4 and T // Kf >= 8 and not opts.get("tile_persist") == "0" and \
         str(opts.get("fwd_persist", "1")) != "0"
     if fwd_persistent:
-        kernels[0] = {"kernel": "pi_fwd2d_persist_kernel<%d groups of %d steps per launch>" % (T // Kf, Kf),
+        small_fwd = plan.get("tile_fwd") is not None and plan["tile_fwd"][1] < 32
+        kernels[0] = {"kernel": ("pi_fwd2d_persist_small_kernel" if small_fwd else "pi_fwd2d_persist_kernel") +
+                                "<%d groups of %d steps per launch>" % (T // Kf, Kf),
                       "launches_per_pass": 1, "algorithmic_bytes_per_launch": 2 * Cs * npts * (T // Kf) * Kf,
                       "avg_launch_us": fwd_ms * 1e3}
     if persistent_small:

@@ -210,15 +210,26 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *   "persist_small"  1 (default): grids in the 32 x 8-tile regime (below ~300^2, ragged ones included: the reference's own
  *                  100^2, train_2drd.py:597-636) run their sweep as one resident launch as well (pi_adj2d_persist_small_kernel;
  *                  its granule outbox is part of percnn_pi_rollout_bwd_workspace_bytes); 0: one launch per four steps
+ *                  Round 5: the FORWARD of that regime too (pi_fwd2d_persist_small_kernel, 32 x 8 tiles, T >= 32; gated by
+ *                  "fwd_persist" as well; scratch from the per-device granule outbox of the resident forward).  2: also the
+ *                  32 x 16 and ragged 32 x 32 grids and up to 2 x "fwd_persist_per_cu" workgroups per CU (measured slower than
+ *                  one launch per four steps: tests and experiments only)
+ *   "fwd_small_pause"  0 .. 200, default 12: units of 64 clocks the small-tile resident forward waits between publishing its tile
+ *                  and the first request of its ring (granules asked for too early come back stale)
  *   "fwd_persist"  1 (default): the FORWARD rollout of a grid the persistent sweep takes (float32 pre-contracted block, whole
  *                  32 x 32 tiles, 16 .. #CUs of them, T >= 32) runs as one launch of resident workgroups too
  *                  (pi_fwd2d_persist_kernel: the launch-per-group kernel's trajectory bit for bit; residency check, abort and
  *                  fallback as "tile_persist"; the library keeps 256 B + 24 KiB per tile of device scratch per device for its
  *                  granule outbox, allocated at the first such call); 0: one launch per four steps
+ *   "fwd_persist_f64"  1 (default): ... and of float64 pre-contracted blocks (lambda-omega, percnn_LO_eqn.py:12) on 16-byte
+ *                  granules {lo32, tag, hi32, tag}; its scratch is 256 B + 48 KiB per tile; 0: one launch per four steps
  *   "fwd_persist_per_cu"  1 (default) or 2: two of its 77 KB workgroups fit a CU, so grids of up to 2 x #CUs tiles can run the
  *                  resident forward (576^2 .. 704^2: -9 .. -16 % per forward step, profiles/r04_forward_persistent.txt).  Not the
  *                  default: with every CU doubly booked any other kernel that holds LDS makes the launch abort, and an abort
  *                  switches the resident launches off for the device until "persist_reset"
+ *   "brick_xny"    3D brick kernels, XCD regions: 0 (default) = sized by what an L2 holds (three plane groups x rows x arrays
+ *                  touched <= 2.5 MiB; among the maps that fit, the smallest halo share), 1 = contiguous plane ranges, 2 / 4 / 8 =
+ *                  force that many row strips, -1 = round 4's rule for forward steps of >= 8 M points.  Pure placement.
  *   "brick_wide"   1 (default): 3D rows of 65 .. 128 sixteen-byte chunks on 512-lane bricks where they win; 0: direct kernels
  *   "persist_reset"  (any value) re-arm the persistent sweep after an abort
  * Returns 0, or PERCNN_PI_EINVAL for an unknown key / bad value. */

@@ -27,7 +27,7 @@ for wl, kernels in rows.items():
         if k in ("pi_adj2d_persist_kernel", "pi_adj2d_persist_split_kernel", "pi_adj2d_persist_small_kernel"):
             # ONE launch per rollout (T // 4 groups of 4 steps inside): bench.py scales the per-group bytes to its own T
             out["pi_adj2d_persist_kernel_per_group"] = (2 * f + w) / max(1, T_run // 4)
-        if k == "pi_fwd2d_persist_kernel":
+        if k in ("pi_fwd2d_persist_kernel", "pi_fwd2d_persist_small_kernel"):
             out["pi_fwd2d_persist_kernel_per_group"] = (2 * f + w) / max(1, T_run // 4)
         out["detail"][k] = {"fetch_raw_bytes": f, "fetch_corrected_bytes": 2 * f, "write_bytes": w, "hbm_bytes_per_launch": 2 * f + w}
         if k in ("pi_adj2d_tile_kernel", "pi_fwd2d_tile_kernel", "pi_fwd_kernel", "pi_bwd_kernel", "pi_fwd3d_brick_kernel",
