@@ -64,6 +64,7 @@ struct Options {
     int persist_small = 1;      // the 32 x 8-tile regime (grids below ~300^2, split schedule) as one persistent launch too
     int fwd_persist_per_cu = 1; // ... on grids of up to this many tiles per CU (1 or 2)
     int fwd_persist_f64 = 1;    // ... float64 too (lambda-omega; 16-byte granules)
+    int adj_persist_f64 = 1;    // the float64 tile SWEEP as one resident launch as well (split flavour, moments in shared LDS rows)
     int fwd_persist = 1;        // the FORWARD rollout of such a grid as one launch of resident workgroups too (pi_fwd2d_persist_kernel;
                             // same residency check / abort / fallback; its granule outbox is a per-device scratch of the library)
     int persist_split = 1;      // persistent sweep: 1 = split flavour (pi_adj2d_persist_split_kernel: the halo-independent
@@ -1184,7 +1185,9 @@ size_t persist_outbox_bytes(const Problem& p, int elem = 4)     // 8-byte granul
 template <typename T>
 bool persist_ok(const Problem& p, const unsigned char* mask, int t_top, int ngroups, hipStream_t st)
 {
-    if (!p.opt.tile_persist || sizeof(T) != 4 || ngroups < 2) return false;
+    // (float64 since round 5: the split flavour on 16-byte granules, moments in shared LDS rows; option adj_persist_f64)
+    if (!p.opt.tile_persist || ngroups < 2) return false;
+    if (sizeof(T) != 4 && (!p.opt.adj_persist_f64 || !p.opt.persist_split)) return false;
     if (persist_disabled_here()) return false;               // a launch aborted on this device (see PersistGuard)
     if (mask && t_top >= 4096) return false;                 // the frame mask travels as a kernel argument (4096 bits)
     if (!tile_fuse_ok<T>(p) || tile_wide_for<T>(p, true) != 0 || tile_by_for(p) != TILE_B) return false;
@@ -1303,19 +1306,22 @@ hipError_t launch_adj_persist(const T* hframe_t, const T* gframe_t, T* aframe_t,
     (void)sizeof(TL);
     // state buffers | [20][NT] double moment sums per lane | publish / gather tables (3 + 5 + 5 ints per lane) and, split sweep,
     // 6 of strip geometry | abort word
-    const size_t lds = pi::tile_state_bytes<T, K, TILE_B, TILE_B>() + (size_t)20 * NT * sizeof(double) +
+    constexpr int LACC = sizeof(T) == 8 ? NT / 2 : NT;      // rows of the moment accumulators (pi_tile2d.h)
+    const size_t lds = pi::tile_state_bytes<T, K, TILE_B, TILE_B>() + (size_t)20 * LACC * sizeof(double) +
                        (size_t)(p.opt.persist_split ? pi::PERSIST_SPLIT_TABLE_ROWS : 13) * NT * sizeof(int) + 16;
-    auto* k = p.opt.persist_split ? pi::pi_adj2d_persist_split_kernel<T, K, TILE_B, TILE_B, NT>
-                                  : pi::pi_adj2d_persist_kernel<T, K, TILE_B, TILE_B, NT>;
+    auto* k = pi::pi_adj2d_persist_split_kernel<T, K, TILE_B, TILE_B, NT>;
+    if constexpr (sizeof(T) == 4) {
+        if (!p.opt.persist_split) k = pi::pi_adj2d_persist_kernel<T, K, TILE_B, TILE_B, NT>;
+    }
     if (hipError_t e = allow_lds(k, lds)) return e;
-    static int resident[16][2] = {};                        // per device and flavour: does one workgroup fit a CU? (asked once)
+    static int resident[16][2] = {};                        // per device and flavour (per value type: a template): one workgroup per CU?
     int& res = resident[dev][p.opt.persist_split ? 1 : 0];
     if (!res) {
         int nb = 0;
         res = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, NT, lds) == hipSuccess && nb >= 1) ? 1 : -1;
     }
     if (res < 0) return hipErrorCooperativeLaunchTooLarge;
-    if (hipError_t e = hipMemsetAsync(outbox, 0, persist_outbox_bytes(p), st)) return e;
+    if (hipError_t e = hipMemsetAsync(outbox, 0, persist_outbox_bytes(p, (int)sizeof(T)), st)) return e;
     long frame_stride = (long)(2 * p.n);
     int np = pi::nparams(p.hc);
     pi::PersistArgs pa{};
@@ -2436,10 +2442,10 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
         rows = (unsigned)tile_count<T>(p, true);
         // the whole tile sweep as ONE cooperative launch where that applies (pi_adj2d_persist_kernel); its granule outbox
         // lives in the three adjoint frames between the hand-over frame and the group above it, which nobody touches then
-        if constexpr (sizeof(T) == 4) {
+        {
             const int ngroups = K == 4 ? t_cur / K : 0;
             if (tile_fused && ngroups >= 2 && persist_ok<T>(p, mask, t_cur, ngroups, st) &&
-                persist_outbox_bytes(p) <= (size_t)(K - 1) * frame_bytes) {
+                persist_outbox_bytes(p, (int)sizeof(T)) <= (size_t)(K - 1) * frame_bytes) {
                 const int t_end = t_cur - K * ngroups;
                 auto* outbox = reinterpret_cast<unsigned long long*>(adj + (size_t)(t_end + 1) * frame);
                 // roll-call / abort words: the last partial row (zeroed above; tiles <= #CUs << MAX_BWD_BLOCKS rows are in use)
@@ -2719,6 +2725,7 @@ int apply_option(Options& o, const char* key, long value)
     if (!std::strcmp(key, "persist_small")) { if (value < 0 || value > 2) return PERCNN_PI_EINVAL; o.persist_small = (int)value; return 0; }
     if (!std::strcmp(key, "fwd_persist")) { o.fwd_persist = value != 0; return 0; }
     if (!std::strcmp(key, "fwd_persist_f64")) { o.fwd_persist_f64 = value != 0; return 0; }
+    if (!std::strcmp(key, "adj_persist_f64")) { o.adj_persist_f64 = value != 0; return 0; }
     if (!std::strcmp(key, "fwd_persist_per_cu")) {
         if (value < 1 || value > 2) return PERCNN_PI_EINVAL;
         o.fwd_persist_per_cu = (int)value;
@@ -2980,7 +2987,8 @@ int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options,
                                     persist_small_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr))) ? 1 : 0) |
                   ((out[0] == 1 && (fwd_persist_ok<T>(p, 1 << 18, nullptr) || fwd_persist_small_by<T>(p, 1 << 18, nullptr) != 0)) ? 2 : 0);
     else
-        out[14] = (out[0] == 1 && fwd_persist_ok<T>(p, 1 << 18, nullptr)) ? 2 : 0;
+        out[14] = ((out[1] == 1 && persist_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr)) ? 1 : 0) |
+                  ((out[0] == 1 && fwd_persist_ok<T>(p, 1 << 18, nullptr)) ? 2 : 0);
     for (int dir = 0; dir < 2; ++dir) {                                    // 2D tiles: width, height, lanes per workgroup
         if (out[dir] != 1) continue;
         const TileShape ts = tile_shape_for<T>(p, dir == 1);

@@ -364,6 +364,8 @@ __device__ __forceinline__ void poly_dr_v(const T* __restrict__ c, V2<T> u, V2<T
 // ... and `st`: the pairs of dt (0), the diffusion coefficients (1, 2), c0 (3) and the eight taps (4..11) -- P[0..11] in P's own
 // order; PI_STEN_MASK says which are held
 template <typename T> struct JacPairs { V2<T> m[2][7]; V2<T> st[12]; };
+// (float32 only: a float64 pair is four registers -- 26 held pairs would be 104 of the 256; float64 forms them where they are used)
+template <typename T> struct held_masks { static constexpr int jac = sizeof(T) == 4 ? (PI_JAC_MASK) : 0, sten = sizeof(T) == 4 ? (PI_STEN_MASK) : 0; };
 template <typename T>
 __device__ __forceinline__ void jac_pairs_load(JacPairs<T>& jp, const T* __restrict__ P)
 {
@@ -374,19 +376,23 @@ __device__ __forceinline__ void jac_pairs_load(JacPairs<T>& jp, const T* __restr
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             jp.m[s][j] = vs(x[j]);
-            if ((PI_JAC_MASK >> j) & 1) asm volatile("" : "+v"(jp.m[s][j]));        // a register pair from here on, not a recipe
+            if constexpr (sizeof(T) == 4) {
+                if ((held_masks<T>::jac >> j) & 1) asm volatile("" : "+v"(jp.m[s][j]));        // a register pair from here on, not a recipe
+            }
         }
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         jp.st[i] = vs(P[i]);
-        if ((PI_STEN_MASK >> i) & 1) asm volatile("" : "+v"(jp.st[i]));
+        if constexpr (sizeof(T) == 4) {
+            if ((held_masks<T>::sten >> i) & 1) asm volatile("" : "+v"(jp.st[i]));
+        }
     }
 }
 template <typename T>
 __device__ __forceinline__ void poly_dr_v_j(const T* __restrict__ c, const V2<T> (&j)[7], V2<T> u, V2<T> v, V2<T>& ru, V2<T>& rv)
 {
-    constexpr int MSK = PI_JAC_MASK;
+    constexpr int MSK = held_masks<T>::jac;
     const V2<T> k0 = (MSK & 1) ? j[0] : vs(T(2) * c[7]), k1 = (MSK & 2) ? j[1] : vs(T(2) * c[3]), k2 = (MSK & 4) ? j[2] : vs(T(3) * c[6]);
     const V2<T> k3 = (MSK & 8) ? j[3] : vs(T(3) * c[9]), k4 = (MSK & 16) ? j[4] : vs(T(2) * c[5]), k5 = (MSK & 32) ? j[5] : vs(T(2) * c[8]);
     const V2<T> k6 = (MSK & 64) ? j[6] : vs(c[4]);
@@ -842,8 +848,10 @@ __device__ __forceinline__ unsigned persist_geo_word(const TileGeom& g, int ty0,
 // of an LDS table built once per launch (persistent split sweep: persist_geo_word) instead of being derived from the lane id in
 // every pass of every group: the derivation (strip map with its divisions, clamps, four ownership compares and selects) was
 // ~60 of the ~300 VALU instructions of an issue-bound pass, and hoisting it into registers for all passes at once spills.
+// LACC: lanes per row of the float64 moment accumulators in LDS (`lacc`[20][LACC]; lanes tid and tid + LACC share a slot -- the
+// adds are LDS atomics)
 template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE, bool MOM, int PART = PART_FULL, int TID0 = 0,
-          bool GEO = false>
+          bool GEO = false, int LACC = NT>
 __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict__ hfr, const T* __restrict__ gfr,
                                             const TileGeom& g, int ty0, int tx0, const T* __restrict__ P,
                                             double (&acc_c)[2], const StripOps<T>& pre, TileMoments<T, MOM>& mom,
@@ -852,7 +860,7 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
 {
     static_assert(P_DT == 0 && P_COEF == 1 && P_C0 == 3 && P_TAPS == 4, "JacPairs::st follows P's order");
     auto cf = [P, jp](int i) -> V2<T> {
-        if constexpr (GEO && PI_STEN_MASK != 0) { if ((PI_STEN_MASK >> i) & 1) return jp->st[i]; }
+        if constexpr (GEO && held_masks<T>::sten != 0) { if ((held_masks<T>::sten >> i) & 1) return jp->st[i]; }
         return vs(P[i]);
     };
     using TL = Tile<K, BX, BY>;
@@ -941,7 +949,7 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
                 for (int h = 0; h < 2; ++h) {
                     const V2<T> gr = gc[s][h] * dtv;
                     V2<T> ru, rv;
-                    if constexpr (GEO && PI_JAC_MASK != 0) poly_dr_v_j(c, jp->m[s], U[h], V[h], ru, rv);
+                    if constexpr (GEO && held_masks<T>::jac != 0) poly_dr_v_j(c, jp->m[s], U[h], V[h], ru, rv);
                     else poly_dr_v(c, U[h], V[h], ru, rv);
                     du[h] = vfma(gr, ru, du[h]);
                     dv[h] = vfma(gr, rv, dv[h]);
@@ -1008,7 +1016,7 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
             // `ds_add_f64` (no return value, nothing to wait for): the LDS pipe does the accumulation, the VALU only the
             // products, and the layout is already the transposed one the tail reduction reads.  Moments LAST, half a strip
             // at a time: the stencil / Jacobian temporaries are dead by now.
-            double* slot = lacc + (int)threadIdx.x;
+            double* slot = lacc + (LACC == NT ? (int)threadIdx.x : (int)threadIdx.x % LACC);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const V2<T> uu = U[h], vv = V[h];
@@ -1016,8 +1024,8 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const V2<T> gm = (gc[s][h] * dtv) * own[h];
-                    double* a = slot + 10 * s * NT;
-                    auto add = [&](int m, V2<T> phi) { lds_add_f64(a + m * NT, fma_(gm.x, phi.x, gm.y * phi.y)); };
+                    double* a = slot + 10 * s * LACC;
+                    auto add = [&](int m, V2<T> phi) { lds_add_f64(a + m * LACC, fma_(gm.x, phi.x, gm.y * phi.y)); };
                     lds_add_f64(a, gm.x + gm.y);
                     add(1, uu); add(2, vv);
                     add(3, u2); add(4, uv); add(5, v2);
@@ -1729,6 +1737,44 @@ __device__ __forceinline__ void persist_load_ops(StripOps<T>& o, const T* __rest
     o.jv[0] = c2.v[0]; o.jv[1] = c2.v[1]; o.jv[2] = d2.v[0]; o.jv[3] = d2.v[1];
 }
 
+// Data-tagged granules by value type.  float32: the 8-byte word {tag, value} of the sweeps (one agent-scope store / load).
+// float64 (round 5, configs[2]): a 16-byte granule {lo32, tag, hi32, tag} = two self-validating 8-byte words written by ONE
+// 16-byte write-through (sc1) store and read by ONE 16-byte sc1 load -- the request count of a hand-over stays that of the
+// float32 ring (requests are what it costs, not bytes); the reader accepts when BOTH tags match, so a torn pair is just "not yet".
+typedef unsigned pi_v4u __attribute__((ext_vector_type(4)));
+template <typename T> struct GranuleIO;
+template <> struct GranuleIO<float> {
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    using Raw = unsigned long long;
+    static constexpr int BYTES = 8;
+    gu64* base;
+    __device__ __forceinline__ GranuleIO(void* outbox, size_t) : base((gu64*)outbox) {}
+    __device__ __forceinline__ void put(size_t idx, unsigned epoch, float v) const
+    {
+        __hip_atomic_store(base + idx, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ Raw get(size_t idx) const { return __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return (unsigned)(x >> 32) == epoch; }
+    static __device__ __forceinline__ float value(Raw x) { return __builtin_bit_cast(float, (unsigned)x); }
+};
+template <> struct GranuleIO<double> {
+    using Raw = pi_v4u;
+    static constexpr int BYTES = 16;
+    __amdgpu_buffer_rsrc_t rs;
+    // (the descriptor is built from kernel arguments only: wave-uniform by construction)
+    __device__ __forceinline__ GranuleIO(void* outbox, size_t bytes) : rs(__builtin_amdgcn_make_buffer_rsrc(outbox, 0, (int)bytes, 0x00020000)) {}
+    __device__ __forceinline__ void put(size_t idx, unsigned epoch, double v) const
+    {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+        const pi_v4u w = {(unsigned)b, epoch, (unsigned)(b >> 32), epoch};
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)(idx * 16), 0, /*aux: sc1*/ 16);
+    }
+    __device__ __forceinline__ Raw get(size_t idx) const { return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(idx * 16), 0, 16); }
+    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return x.y == epoch && x.w == epoch; }
+    static __device__ __forceinline__ double value(Raw x) { return __builtin_bit_cast(double, ((unsigned long long)x.z << 32) | x.x); }
+};
+
 // int rows of NT the split sweep keeps in LDS behind the moments: 13 of hand-over tables + 6 of strip geometry (+ the abort word)
 constexpr int PERSIST_SPLIT_TABLE_ROWS = 19;
 
@@ -1787,11 +1833,12 @@ __device__ __forceinline__ void persist_pass(T* b0, T* b1, const T* const (&hf)[
                                              const T* __restrict__ hn, const T* __restrict__ gn, const StripOff& so_next,
                                              const TileGeom& g, int ty0, int tx0, const T* __restrict__ P, double (&acc_c)[2],
                                              const StripOps<T>& ops, StripOps<T>& ahead, TileMoments<T, true>& mom, bool upper,
-                                             const unsigned* geo, const JacPairs<T>& jp)
+                                             const unsigned* geo, const JacPairs<T>& jp, double* lacc = nullptr)
 {
     using PP = PersistPass<PASS>;
     persist_load_ops<T>(ahead, hn, gn, g, so_next);
     constexpr bool GEO = PI_PERSIST_GEO != 0;
+    constexpr int LACC = sizeof(T) == 8 ? NT / 2 : NT;     // float64: moments straight into the shared LDS rows (adj_substep)
     if constexpr (PP::SPLIT >= NT || GEO) {
         // With the geometry in a table the sub-step's body no longer depends on WHICH strips a wave works on: the two parts of a
         // mixed pass (same parity of M: same buffers) run the same instructions with their own table words and their own
@@ -1799,22 +1846,24 @@ __device__ __forceinline__ void persist_pass(T* b0, T* b1, const T* const (&hf)[
         static_assert(PP::SPLIT >= NT || ((PP::M1 ^ PP::M2) & 1) == 0, "both parts read the same buffer");
         constexpr int M = PP::M1;
         const T* gfr = (PP::SPLIT < NT && upper) ? gf[PP::M2] : gf[M];
-        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P1, 0, GEO>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gfr, g, ty0, tx0,
-                                                                           P, acc_c, ops, mom, nullptr, geo, &jp);
+        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P1, 0, GEO, LACC>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gfr, g, ty0,
+                                                                                 tx0, P, acc_c, ops, mom, lacc, geo, &jp);
     } else if (!upper) {                                   // wave-uniform
         constexpr int M = PP::M1;
-        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P1, 0, GEO>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M], g, ty0, tx0,
-                                                                           P, acc_c, ops, mom, nullptr, geo, &jp);
+        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P1, 0, GEO, LACC>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M], g, ty0,
+                                                                                 tx0, P, acc_c, ops, mom, lacc, geo, &jp);
     } else {
         constexpr int M = PP::M2;
-        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P2, PP::SPLIT, GEO>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M], g,
-                                                                                   ty0, tx0, P, acc_c, ops, mom, nullptr, geo, &jp);
+        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P2, PP::SPLIT, GEO, LACC>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M],
+                                                                                         g, ty0, tx0, P, acc_c, ops, mom, lacc, geo, &jp);
     }
 #if PI_PIN_MOMENTS
+    if constexpr (sizeof(T) == 4) {                        // (float64 keeps no moment registers: LDS rows)
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int m = 0; m < 10; ++m) asm volatile("" : "+v"(mom.a[s][m]));
+            for (int m = 0; m < 10; ++m) asm volatile("" : "+v"(mom.a[s][m]));
+    }
 #endif
     lds_barrier();
 }
@@ -1839,15 +1888,15 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
     const int tyi = tile / g.tiles_x, txi = tile % g.tiles_x, tiles_y = g.H / BY;
     const int ty0 = tyi * BY, tx0 = txi * BX;
     const int ntiles = g.tiles_x * tiles_y;
-    typedef __attribute__((address_space(1))) unsigned long long gu64;
-    gu64* outbox = (gu64*)pa.outbox;
+    const GranuleIO<T> gio(pa.outbox, (size_t)2 * (size_t)ntiles * (2 * BANDH) * GranuleIO<T>::BYTES);
+    constexpr int LACC = sizeof(T) == 8 ? NT / 2 : NT;     // float64: two lanes share a moment slot (LDS atomics), see persist_pass
     // which half of a mixed pass this wave works on (wave-uniform, kept in a scalar register)
     const int wave_id = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const bool up2 = wave_id * WAVE >= PersistPass<2>::SPLIT, up5 = wave_id * WAVE >= PersistPass<5>::SPLIT;
 
-    // LDS: state buffers | [20][NT] doubles: the lane's moments of all groups so far | int tables | abort word
+    // LDS: state buffers | [20][LACC] doubles: the lanes' moments of all groups so far | int tables | abort word
     double* lacc = reinterpret_cast<double*>(smem_raw + tile_state_bytes<T, K, BX, BY>());
-    int* tab_pub = reinterpret_cast<int*>(lacc + 20 * NT);                  // [NPUB][NT]: LDS position of a border value
+    int* tab_pub = reinterpret_cast<int*>(lacc + 20 * LACC);                // [NPUB][NT]: LDS position of a border value
     int* tab_gl = tab_pub + NPUB * NT;                                      // [NGAT][NT]: LDS position of a halo value
     int* tab_gs = tab_gl + NGAT * NT;                                       // [NGAT][NT]: granule index inside a parity half
     unsigned* tab_geo = reinterpret_cast<unsigned*>(tab_pub + 13 * NT);     // [6][NT]: the lane's strip in each pass (persist_geo_word)
@@ -1863,8 +1912,10 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
     tab_geo[3 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 3>(g, ty0, tx0);
     tab_geo[4 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 4>(g, ty0, tx0);
     tab_geo[5 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 5>(g, ty0, tx0);
+    if ((int)threadIdx.x < LACC) {
 #pragma unroll
-    for (int m = 0; m < 20; ++m) lacc[m * NT + (int)threadIdx.x] = 0.0;
+        for (int m = 0; m < 20; ++m) lacc[m * LACC + (int)threadIdx.x] = 0.0;
+    }
 #pragma unroll
     for (int q = 0; q < NPUB; ++q) {
         const int i = (int)threadIdx.x + q * NT;
@@ -1919,7 +1970,7 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int m = 0; m < 10; ++m) mom.a[s][m] = V2<T>{T(0), T(0)};
+        for (int m = 0; m < 10; ++m) mom.a[s][m] = typename MomAcc<T>::type{};
     JacPairs<T> jp;
     jac_pairs_load<T>(jp, P);
     for (int grp = 0; grp < pa.ngroups; ++grp) {
@@ -1936,26 +1987,26 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
         }
         PI_PSTAMP(0);
         // ---- P0: the top of the pyramid -- needs my own tile only; the neighbours' granules are on their way ----
-        persist_pass<T, K, BX, BY, NT, 0>(b0, b1, hf, gf, hf[1], gf[1], so1, g, ty0, tx0, P, acc_c, ops, ops2, mom, false, tab_geo + 0 * NT, jp);
+        persist_pass<T, K, BX, BY, NT, 0>(b0, b1, hf, gf, hf[1], gf[1], so1, g, ty0, tx0, P, acc_c, ops, ops2, mom, false, tab_geo + 0 * NT, jp, lacc);
         PI_PSTAMP(1);
         // ---- request the halo ring my neighbours published at the end of their previous group: the loads travel under P1.
         // (Requested before P0 they come back stale and a second round trip is exposed; requested by the four waves that idle in
         // P0 / P1 alone, with the publish moved under P0 as well, the hand-over takes those waves 2 us and P0 waits for them --
         // both measured, tools/persist_dev.hip, profiles/r04_persistent_split_timelines.txt.) ----
         const unsigned epoch = (unsigned)grp;
-        gu64* half = outbox + (size_t)(epoch & 1u) * (size_t)ntiles * (2 * BANDH);
+        const size_t half = (size_t)(epoch & 1u) * (size_t)ntiles * (2 * BANDH);          // granule index of this parity's half
         int gs[NGAT];
-        unsigned long long gx[NGAT];
+        typename GranuleIO<T>::Raw gx[NGAT];
         if (grp > 0) {
 #pragma unroll
             for (int q = 0; q < NGAT; ++q) {
                 gs[q] = tab_gs[q * NT + (int)threadIdx.x];
-                gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (lanes without: granule 0)
+                gx[q] = gio.get(half + (size_t)gs[q]);                                     // (lanes without: granule 0)
             }
         }
         // ---- P1 ----
         persist_pass<T, K, BX, BY, NT, 1>(b0, b1, hf, gf, up2 ? hf[0] : hf[2], up2 ? gf[0] : gf[2], so2, g, ty0, tx0, P, acc_c, ops2, ops, mom,
-                                          false, tab_geo + 1 * NT, jp);
+                                          false, tab_geo + 1 * NT, jp, lacc);
         PI_PSTAMP(2);
         if (grp > 0) {
             int gl[NGAT];
@@ -1968,7 +2019,7 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
                 bool ok = true;
 #pragma unroll
                 for (int q = 0; q < NGAT; ++q)
-                    if (gl[q] >= 0) ok &= (unsigned)(gx[q] >> 32) == epoch;
+                    if (gl[q] >= 0) ok &= GranuleIO<T>::ok(gx[q], epoch);
                 if (__all(ok)) break;
                 // give up when the wait is over its bound (the first to do so raises the abort flag below) or when another
                 // workgroup already has: a launch whose workgroups are not all resident ends within the bound
@@ -1977,15 +2028,14 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
                 __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                 for (int q = 0; q < NGAT; ++q)
-                    if (gl[q] >= 0 && (unsigned)(gx[q] >> 32) != epoch)
-                        gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (gl[q] >= 0 && !GranuleIO<T>::ok(gx[q], epoch)) gx[q] = gio.get(half + (size_t)gs[q]);
             }
             if (failed) {
                 if (threadIdx.x % WAVE == 0) *wg_abort = 1;
             } else {
 #pragma unroll
                 for (int q = 0; q < NGAT; ++q)
-                    if (gl[q] >= 0) b0[gl[q]] = __builtin_bit_cast(T, (unsigned)gx[q]);
+                    if (gl[q] >= 0) b0[gl[q]] = GranuleIO<T>::value(gx[q]);
             }
             lds_barrier();
         }
@@ -2002,28 +2052,31 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
         }
         PI_PSTAMP(3);
         // ---- P2 .. P5: the rest of the pyramid next to the ring passes ----
-        persist_pass<T, K, BX, BY, NT, 2>(b0, b1, hf, gf, hf[1], gf[1], so3, g, ty0, tx0, P, acc_c, ops, ops2, mom, up2, tab_geo + 2 * NT, jp);
+        persist_pass<T, K, BX, BY, NT, 2>(b0, b1, hf, gf, hf[1], gf[1], so3, g, ty0, tx0, P, acc_c, ops, ops2, mom, up2, tab_geo + 2 * NT, jp, lacc);
         PI_PSTAMP(4);
-        persist_pass<T, K, BX, BY, NT, 3>(b0, b1, hf, gf, hf[2], gf[2], so4, g, ty0, tx0, P, acc_c, ops2, ops, mom, false, tab_geo + 3 * NT, jp);
+        persist_pass<T, K, BX, BY, NT, 3>(b0, b1, hf, gf, hf[2], gf[2], so4, g, ty0, tx0, P, acc_c, ops2, ops, mom, false, tab_geo + 3 * NT, jp, lacc);
         PI_PSTAMP(5);
-        persist_pass<T, K, BX, BY, NT, 4>(b0, b1, hf, gf, hf[3], gf[3], so5, g, ty0, tx0, P, acc_c, ops, ops2, mom, false, tab_geo + 4 * NT, jp);
+        persist_pass<T, K, BX, BY, NT, 4>(b0, b1, hf, gf, hf[3], gf[3], so5, g, ty0, tx0, P, acc_c, ops, ops2, mom, false, tab_geo + 4 * NT, jp, lacc);
         PI_PSTAMP(6);
         // (the operands the last pass requests belong to the next group's P0: frame t - K - 1)
         const unsigned gmask_next = last ? gmask : persist_mask<K>(pa, pa.t_top - K * (grp + 1));
         const T* hn = last ? hf[3] : hb - (long)(K + 1) * frame_stride;
         const T* gn = last ? gf[3] : (gmask_next & 1u ? gb - (long)(K + 1) * frame_stride : (const T*)nullptr);
-        persist_pass<T, K, BX, BY, NT, 5>(b0, b1, hf, gf, hn, gn, last ? so5 : so0, g, ty0, tx0, P, acc_c, ops2, ops, mom, up5, tab_geo + 5 * NT, jp);
+        persist_pass<T, K, BX, BY, NT, 5>(b0, b1, hf, gf, hn, gn, last ? so5 : so0, g, ty0, tx0, P, acc_c, ops2, ops, mom, up5, tab_geo + 5 * NT, jp, lacc);
         PI_PSTAMP(7);
         // the float32 2-vector moment sums are folded into the lane's double sums in LDS every fourth group (see the unsplit kernel)
-        if ((grp & 3) == 3 || last) {
+        // (float64: the sub-steps add straight into the LDS rows)
+        if constexpr (sizeof(T) == 4) {
+            if ((grp & 3) == 3 || last) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int m = 0; m < 10; ++m) {
-                    double* slot = lacc + (10 * s + m) * NT + (int)threadIdx.x;
-                    *slot += (double)mom_total(mom.a[s][m]);
-                    mom.a[s][m] = V2<T>{T(0), T(0)};
-                }
+                    for (int m = 0; m < 10; ++m) {
+                        double* slot = lacc + (10 * s + m) * NT + (int)threadIdx.x;
+                        *slot += (double)mom_total(mom.a[s][m]);
+                        mom.a[s][m] = V2<T>{T(0), T(0)};
+                    }
+            }
         }
         if (last) {
             // the result of the last group goes to memory: frame t - K of the adjoint trajectory, or dL/dh0 itself
@@ -2034,15 +2087,11 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
         gmask = gmask_next;
         // ---- publish my band (the border 2K points of the tile, complete since the barrier that ended P5) ----
         const unsigned ep1 = (unsigned)grp + 1u;
-        gu64* mine = outbox + (size_t)(ep1 & 1u) * (size_t)ntiles * (2 * BANDH) + (size_t)tile * (2 * BANDH);
+        const size_t mine = (size_t)(ep1 & 1u) * (size_t)ntiles * (2 * BANDH) + (size_t)tile * (2 * BANDH);
 #pragma unroll
         for (int q = 0; q < NPUB; ++q) {
             const int pl = tab_pub[q * NT + (int)threadIdx.x];
-            if (pl >= 0) {
-                const unsigned v = __builtin_bit_cast(unsigned, b0[pl]);
-                __hip_atomic_store(mine + (int)threadIdx.x + q * NT, ((unsigned long long)ep1 << 32) | v, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (pl >= 0) gio.put(mine + (size_t)((int)threadIdx.x + q * NT), ep1, b0[pl]);
         }
         PI_PSTAMP(8);
         // (no barrier: the next pass, P0, reads b0 -- complete -- and writes b1's centre, which nobody reads any more)
@@ -2066,10 +2115,10 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
     }
     if (threadIdx.x < 320) {
         const int mm = (int)threadIdx.x >> 4, part = (int)threadIdx.x & 15;
-        const double* row = lacc + mm * NT + part;
+        const double* row = lacc + mm * LACC + part;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-        for (int k = 0; k < NT; k += 64) {
+        for (int k = 0; k < LACC; k += 64) {
             const double v0 = row[k], v1 = row[k + 16], v2 = row[k + 32], v3 = row[k + 48];
             a0 += v0; a1 += v1; a2 += v2; a3 += v3;
         }
@@ -2096,44 +2145,6 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
 // Levels alternate between the two LDS buffers exactly as in pi_fwd2d_tile_kernel; a strip is computed by the same lds_star4 /
 // poly_r / update sequence: the trajectory is that kernel's bit for bit.
 // ------------------------------------------------------------------------------------------------
-// Data-tagged granules by value type.  float32: the 8-byte word {tag, value} of the sweeps (one agent-scope store / load).
-// float64 (round 5, configs[2]): a 16-byte granule {lo32, tag, hi32, tag} = two self-validating 8-byte words written by ONE
-// 16-byte write-through (sc1) store and read by ONE 16-byte sc1 load -- the request count of a hand-over stays that of the
-// float32 ring (requests are what it costs, not bytes); the reader accepts when BOTH tags match, so a torn pair is just "not yet".
-typedef unsigned pi_v4u __attribute__((ext_vector_type(4)));
-template <typename T> struct GranuleIO;
-template <> struct GranuleIO<float> {
-    typedef __attribute__((address_space(1))) unsigned long long gu64;
-    using Raw = unsigned long long;
-    static constexpr int BYTES = 8;
-    gu64* base;
-    __device__ __forceinline__ GranuleIO(void* outbox, size_t) : base((gu64*)outbox) {}
-    __device__ __forceinline__ void put(size_t idx, unsigned epoch, float v) const
-    {
-        __hip_atomic_store(base + idx, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __device__ __forceinline__ Raw get(size_t idx) const { return __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return (unsigned)(x >> 32) == epoch; }
-    static __device__ __forceinline__ float value(Raw x) { return __builtin_bit_cast(float, (unsigned)x); }
-};
-template <> struct GranuleIO<double> {
-    using Raw = pi_v4u;
-    static constexpr int BYTES = 16;
-    __amdgpu_buffer_rsrc_t rs;
-    // (the descriptor is built from kernel arguments only: wave-uniform by construction)
-    __device__ __forceinline__ GranuleIO(void* outbox, size_t bytes) : rs(__builtin_amdgcn_make_buffer_rsrc(outbox, 0, (int)bytes, 0x00020000)) {}
-    __device__ __forceinline__ void put(size_t idx, unsigned epoch, double v) const
-    {
-        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-        const pi_v4u w = {(unsigned)b, epoch, (unsigned)(b >> 32), epoch};
-        __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)(idx * 16), 0, /*aux: sc1*/ 16);
-    }
-    __device__ __forceinline__ Raw get(size_t idx) const { return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(idx * 16), 0, 16); }
-    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return x.y == epoch && x.w == epoch; }
-    static __device__ __forceinline__ double value(Raw x) { return __builtin_bit_cast(double, ((unsigned long long)x.z << 32) | x.x); }
-};
-
 // one strip of the forward sub-step, placed by a geometry word (persist_geo_word); pre-contracted block
 template <typename T, int K, int BX, int BY>
 __device__ __forceinline__ void fwd_strip_geo(const T* cur, T* nxt, const T* __restrict__ P, unsigned w)

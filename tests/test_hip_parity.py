@@ -758,7 +758,6 @@ def test_persistent_sweep_equals_launch_per_group(shape, T, hip_device):
     import percnn_amd as pa
     from percnn_amd import _lib
     assert _lib.rollout_plan(0, shape, 4)["bwd_persistent"] and not _lib.rollout_plan(0, shape, 4, "tile_persist=0")["bwd_persistent"]
-    assert not _lib.rollout_plan(0, shape, 8)["bwd_persistent"]
     rs = np.random.RandomState(4)
     P = dev_t(random_block(0, 2, np.float32, 21, scale=0.1), hip_device)
     traj = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=hip_device)
@@ -772,6 +771,47 @@ def test_persistent_sweep_equals_launch_per_group(shape, T, hip_device):
         assert torch.equal(a0, b0)
         assert rel_l2(ag.cpu().numpy(), bg.cpu().numpy()) < 2e-6
     # twice in a row on two streams: the second call finds the first one's event and must not start a second resident grid
+    s2 = torch.cuda.Stream(device=hip_device)
+    a0, ag = pa.rollout_bwd(traj, g, P)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s2):
+        c0, cg = pa.rollout_bwd(traj, g, P)
+    d0, dg = pa.rollout_bwd(traj, g, P)
+    torch.cuda.synchronize()
+    assert torch.equal(a0, c0) and torch.equal(a0, d0)
+
+
+@pytest.mark.parametrize("shape,T", [((384, 384), 23), ((512, 512), 41), ((288, 512), 14)])
+def test_persistent_sweep_float64_equals_launch_per_group(shape, T, hip_device):
+    """Round 5: the float64 tile sweep (lambda-omega, BASELINE configs[2]) as ONE launch of resident workgroups --
+    pi_adj2d_persist_split_kernel<double>: 16-byte granules, the 20 moment sums added straight into [20][256] LDS rows that two
+    lanes share (LDS atomics; the per-lane [20][512] rows of the launch-per-group kernel do not fit next to the tables).  dL/dh0
+    bit for bit the launch-per-group sweep's, parameter gradients to the round-off of double sums in another order; dense
+    dL/dtraj, frame masks, T not a multiple of four; `adj_persist_f64=0` is the old path; C oracle on the small case."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    assert _lib.rollout_plan(0, shape, 8)["bwd_persistent"] and not _lib.rollout_plan(0, shape, 8, "adj_persist_f64=0")["bwd_persistent"]
+    assert not _lib.rollout_plan(0, shape, 8, "tile_persist=0")["bwd_persistent"] and not _lib.rollout_plan(0, shape, 8, "persist_split=0")["bwd_persistent"]
+    rs = np.random.RandomState(14)
+    Pn = random_block(0, 2, np.float64, 21, scale=0.1)
+    P = dev_t(Pn, hip_device)
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.float64, device=hip_device)
+    traj[0] = dev_t(rs.uniform(0, 1, (2,) + shape), hip_device)
+    pa.rollout_fwd_(traj, P)
+    assert torch.isfinite(traj[-1]).all()
+    g = torch.randn(traj.shape, dtype=torch.float64, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(1)) / traj[0].numel()
+    n0 = _lib.persist_status()
+    for mask in (None, [t % 3 != 1 for t in range(T + 1)], [t == T or t % 5 == 0 for t in range(T + 1)]):
+        a0, ag = pa.rollout_bwd(traj, g, P, frame_mask=mask)
+        b0, bg = pa.rollout_bwd(traj, g, P, frame_mask=mask, options={"adj_persist_f64": 0})
+        assert torch.equal(a0, b0)
+        assert rel_l2(ag.cpu().numpy(), bg.cpu().numpy()) < 1e-12
+    n1 = _lib.persist_status()
+    assert n1["launches"] == n0["launches"] + 3 and n1["aborts"] == n0["aborts"]
+    if shape == (288, 512):
+        g0_ref, pg_ref = o_rollout_bwd(traj.cpu().numpy(), g.cpu().numpy(), Pn)
+        a0, ag = pa.rollout_bwd(traj, g, P)
+        assert np.array_equal(a0.cpu().numpy(), g0_ref) and rel_l2(ag.cpu().numpy(), pg_ref) < 1e-12
     s2 = torch.cuda.Stream(device=hip_device)
     a0, ag = pa.rollout_bwd(traj, g, P)
     torch.cuda.synchronize()

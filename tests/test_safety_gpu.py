@@ -163,6 +163,38 @@ def test_persistent_forward_float64_aborts_cleanly_and_falls_back(hip_device):
     assert _lib.rollout_plan(0, shape, 8)["fwd_persistent"]
 
 
+def test_persistent_sweep_float64_aborts_cleanly_and_falls_back(hip_device):
+    """the float64 resident sweep (round 5) with CUs held by another kernel: gives up at its first hand-over WITHOUT writing
+    outputs, the same rollout_bwd call runs the launch-per-group sweep -- bit-identical dL/dh0, no NaNs"""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    pa.set_option("persist_reset", 1)
+    shape, T = (512, 512), 41
+    P = torch.tensor(random_block(0, 2, np.float64, 21, scale=0.1), device=hip_device)
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.float64, device=hip_device)
+    traj[0] = torch.rand((2,) + shape, dtype=torch.float64, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(6))
+    pa.rollout_fwd_(traj, P)
+    g = torch.randn(traj.shape, dtype=torch.float64, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(1)) / traj[0].numel()
+    ref0, refg = pa.rollout_bwd(traj, g, P, options={"tile_persist": 0})
+    s0 = _lib.persist_status()
+    a0, ag = pa.rollout_bwd(traj, g, P)
+    s1 = _lib.persist_status()
+    assert s1["launches"] == s0["launches"] + 1 and s1["aborts"] == s0["aborts"] and torch.equal(a0, ref0)
+    torch.cuda.synchronize()
+    try:
+        _hog(16, 150 * 1024, 1500, hip_device)
+        b0, bg = pa.rollout_bwd(traj, g, P, options={"persist_first_timeout_ms": 20})
+        s2 = _lib.persist_status()
+        torch.cuda.synchronize()
+        assert s2["launches"] == s1["launches"] + 1 and s2["aborts"] == s1["aborts"] + 1 and s2["disabled_on_current_device"]
+        assert torch.isfinite(b0).all() and torch.equal(b0, ref0) and torch.isfinite(bg).all()
+        assert float((bg - refg).norm() / refg.norm()) < 1e-12
+    finally:
+        torch.cuda.synchronize()
+        pa.set_option("persist_reset", 1)
+    assert _lib.rollout_plan(0, shape, 8)["bwd_persistent"]
+
+
 def test_small_tile_persistent_forward_aborts_cleanly_and_falls_back(hip_device):
     """The small-tile resident forward (round 5) under the same stress: CUs held by another kernel -> the launch gives up at its
     first hand-over, the same call recomputes the trajectory launch by launch (bit-identical, no NaNs), the device stays on the
