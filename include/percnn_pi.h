@@ -223,6 +223,9 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *                  granule outbox, allocated at the first such call); 0: one launch per four steps
  *   "fwd_persist_f64"  1 (default): ... and of float64 pre-contracted blocks (lambda-omega, percnn_LO_eqn.py:12) on 16-byte
  *                  granules {lo32, tag, hi32, tag}; its scratch is 256 B + 48 KiB per tile; 0: one launch per four steps
+ *   "adj_persist_f64"  1 (default): the float64 tile SWEEP as one resident launch too (pi_adj2d_persist_split_kernel<double>:
+ *                  16-byte granules, the 20 moment sums in [20][256] LDS rows shared by two lanes; needs "persist_split" = 1);
+ *                  0: one fused launch per four steps
  *   "fwd_persist_per_cu"  1 (default) or 2: two of its 77 KB workgroups fit a CU, so grids of up to 2 x #CUs tiles can run the
  *                  resident forward (576^2 .. 704^2: -9 .. -16 % per forward step, profiles/r04_forward_persistent.txt).  Not the
  *                  default: with every CU doubly booked any other kernel that holds LDS makes the launch abort, and an abort
