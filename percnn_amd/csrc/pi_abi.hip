@@ -60,6 +60,7 @@ struct Options {
                             // launch-per-group sweep is enqueued in the same call and the persistent path is switched off for
                             // this device (percnn_pi_persist_status).  0: no wait; an aborted launch is reported by the NEXT
                             // entry point (PERCNN_PI_EASYNC) instead
+    int adj_small_pause = 24;   // ... of the small-tile resident SWEEP (100^2 1.53 -> 1.45 us per step, 256^2 1.93 -> 1.70: profiles/r05_small_tile_resident_forward.txt)
     int fwd_small_pause = 12;   // small-tile resident forward: 64-clock units between publish and the first ring request (PersistArgs::pause)
     int persist_small = 1;      // the 32 x 8-tile regime (grids below ~300^2, split schedule) as one persistent launch too
     int fwd_persist_per_cu = 1; // ... on grids of up to this many tiles per CU (1 or 2)
@@ -1565,6 +1566,7 @@ hipError_t launch_adj_persist_small_t(const T* hframe_t, const T* gframe_t, T* a
     pa.timeout_ticks = (unsigned long long)p.opt.persist_timeout_ms * 100000ull;
     pa.first_timeout_ticks = (unsigned long long)p.opt.persist_first_timeout_ms * 100000ull;
     pa.t_top = t_top;
+    pa.pause = p.opt.adj_small_pause;
     pa.masked = mask ? 1 : 0;
     if (mask)
         for (int t = 0; t < t_top && t < 4096; ++t)
@@ -2787,6 +2789,7 @@ int apply_option(Options& o, const char* key, long value)
     if (!std::strcmp(key, "block_small")) { o.block_small = value != 0; return 0; }
     if (!std::strcmp(key, "slab_wide_adjoint")) { o.slab_wide_adjoint = value != 0; return 0; }
     if (!std::strcmp(key, "slab_local_index")) { o.slab_local_index = value != 0; return 0; }
+    if (!std::strcmp(key, "adj_small_pause")) { if (value < 0 || value > 200) return PERCNN_PI_EINVAL; o.adj_small_pause = (int)value; return 0; }
     if (!std::strcmp(key, "fwd_small_pause")) { if (value < 0 || value > 200) return PERCNN_PI_EINVAL; o.fwd_small_pause = (int)value; return 0; }
     if (!std::strcmp(key, "brick_xny")) { if (value < -1 || value > 8 || value == 3 || (value > 4 && value < 8)) return PERCNN_PI_EINVAL; o.brick_xny = (int)value; return 0; }
     if (!std::strcmp(key, "slab_fused_put")) { o.slab_fused_put = value != 0; return 0; }

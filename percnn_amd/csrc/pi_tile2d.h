@@ -1620,6 +1620,7 @@ pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restric
             }
         }
         tile_store<T, K, BX, BY, NT, true>(b0, aframe_t + gn, g, ty0, tx0);       // frame t - K of this group (buffer 0: K even)
+        for (int w = 0; w < pa.pause; ++w) __builtin_amdgcn_s_sleep(1);            // (granules asked for too early come back stale)
         int gl[NGAT], gs[NGAT];
         unsigned long long gx[NGAT];
 #pragma unroll
