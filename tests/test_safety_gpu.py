@@ -149,7 +149,7 @@ def test_persistent_forward_float64_aborts_cleanly_and_falls_back(hip_device):
     assert s1["launches"] == s0["launches"] + 1 and s1["aborts"] == s0["aborts"] and torch.equal(a, ref)
     torch.cuda.synchronize()
     try:
-        _hog(16, 150 * 1024, 1500, hip_device)                   # one 113 KB workgroup per CU: 240 free CUs cannot hold 256
+        _hog(144, 150 * 1024, 1500, hip_device)                  # one 113 KB workgroup per CU: 112 free CUs cannot hold 256
         b = torch.full_like(ref, float("nan"))
         b[0] = h0
         pa.rollout_fwd_(b, P, options={"persist_first_timeout_ms": 20})
@@ -182,7 +182,7 @@ def test_persistent_sweep_float64_aborts_cleanly_and_falls_back(hip_device):
     assert s1["launches"] == s0["launches"] + 1 and s1["aborts"] == s0["aborts"] and torch.equal(a0, ref0)
     torch.cuda.synchronize()
     try:
-        _hog(16, 150 * 1024, 1500, hip_device)
+        _hog(144, 150 * 1024, 1500, hip_device)                  # one 154 KB workgroup per CU: 112 free CUs cannot hold 256
         b0, bg = pa.rollout_bwd(traj, g, P, options={"persist_first_timeout_ms": 20})
         s2 = _lib.persist_status()
         torch.cuda.synchronize()
