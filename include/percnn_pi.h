@@ -244,6 +244,11 @@ int percnn_pi_set_option(const char *key, long value);
  * info[5] the state word of the most recent launch as the device left it (0 not started yet, 1 every workgroup resident, 2
  * aborted; -1: no launch yet).  `info` holds at least 8 longs. */
 int percnn_pi_persist_status(long *info);
+/* For hosts that set "persist_handshake" = 0 (no wait at enqueue time) and pass the outputs of a rollout to code outside this
+ * library: synchronises `stream`, then returns 0, or PERCNN_PI_EASYNC -- once -- if a resident launch aborted since the last
+ * entry point looked (its outputs are invalid: re-run the call; the device is on the launch-per-group path from then on until
+ * "persist_reset").  The library's own entry points make the same check when they are entered. */
+int percnn_pi_persist_fence(void *stream);
 /* Diagnostics for tests of that abort path: `blocks` workgroups that each hold `lds_bytes` of a CU's LDS for `ms` milliseconds
  * on `stream` (a stand-in for "another kernel holds whole CUs"). */
 int percnn_pi_debug_hog(int blocks, int lds_bytes, int ms, void *stream);

@@ -50,7 +50,7 @@ def _torch_ext_commands():
 
 EXPORTS = [
     "percnn_pi_abi_version", "percnn_pi_param_count", "percnn_pi_bwd_workspace_bytes",
-    "percnn_pi_rollout_bwd_workspace_bytes", "percnn_pi_set_option", "percnn_pi_persist_status", "percnn_pi_halo_ring_bytes",
+    "percnn_pi_rollout_bwd_workspace_bytes", "percnn_pi_set_option", "percnn_pi_persist_status", "percnn_pi_persist_fence", "percnn_pi_halo_ring_bytes",
     "percnn_pi_peer_box_bytes", "percnn_pi_peer_box_alloc", "percnn_pi_peer_box_free", "percnn_pi_peer_box_export",
     "percnn_pi_peer_box_open", "percnn_pi_peer_box_close", "percnn_pi_peer_box_status",
     "percnn_pi_peer_exchange_f32", "percnn_pi_peer_exchange_f64",
@@ -288,6 +288,14 @@ class HaloRing(ctypes.Structure):
                 ("group_start", ctypes.c_void_p), ("group_end", ctypes.c_void_p),
                 ("send", ctypes.c_void_p), ("recv", ctypes.c_void_p), ("peer", ctypes.POINTER(PeerRing)),
                 ("stage", ctypes.c_void_p), ("stage_bytes", ctypes.c_size_t)]
+
+
+def persist_fence(stream=None) -> None:
+    """percnn_pi_persist_fence: wait for `stream` (default: torch's current stream) and raise if a fire-and-forget resident launch
+    (persist_handshake = 0) aborted since anybody looked -- for callers that hand rollout outputs to code outside this package."""
+    import torch
+    st = torch.cuda.current_stream() if stream is None else stream
+    check(lib().percnn_pi_persist_fence(ctypes.c_void_p(st.cuda_stream)), "persist_fence")
 
 
 def persist_status() -> dict:

@@ -3264,6 +3264,14 @@ int percnn_pi_persist_status(long* info)
     return 0;
 }
 
+// Fence for callers that run the resident launches fire-and-forget (persist_handshake = 0) and hand their outputs to code
+// that is not this library: waits for `stream`, then reports -- once -- whether a resident launch aborted since anybody looked
+int percnn_pi_persist_fence(void* stream)
+{
+    if (hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream))) return (int)e;
+    return persist_async_error();
+}
+
 #define PI_EXPORT(SUF, T)                                                                                           \
     int percnn_pi_step_fwd_##SUF(const T* h, T* out, const T* params, int hc, int ndim, const int64_t* shape,      \
                                  void* stream)                                                                      \

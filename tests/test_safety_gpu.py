@@ -247,10 +247,11 @@ def test_persistent_sweep_abort_without_handshake_is_reported(hip_device):
     torch.cuda.synchronize()
     try:
         _hog(16, 150 * 1024, 1000, hip_device)
+        _lib.persist_fence()                                     # nothing pending: a plain stream wait
         pa.rollout_bwd(traj, g, P, options={"persist_first_timeout_ms": 20, "persist_handshake": 0})
-        torch.cuda.synchronize()
         with pytest.raises(RuntimeError, match="EARLIER call's persistent launch"):
-            pa.rollout_bwd(traj, g, P)
+            _lib.persist_fence()                                 # (round 5) waits for the stream, reports the abort -- once
+        _lib.persist_fence()
         e0, _ = pa.rollout_bwd(traj, g, P)                       # reported once; the device is on the launch-per-group path
         assert torch.equal(e0, ref0) and _lib.persist_status()["disabled_on_current_device"]
     finally:
