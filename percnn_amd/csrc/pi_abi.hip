@@ -659,8 +659,9 @@ int brick_rz_for(const Problem& p, int vec, bool adjoint, bool wide = true)
 int brick_nt_for(const Problem& p, int vec, bool adjoint = true)
 {
     if (p.hc == 0 && p.loss.mode == 0 && p.W / std::max(1, vec) > pi::BRICK_CPR_MAX) return 512;     // wide rows (brick_rz_for)
+    // (while at least one 512-lane workgroup per CU remains: thinner slabs need the workgroups more than the shorter halo)
     if (!adjoint && p.opt.brick_nt == 0 && p.hc == 0 && p.loss.mode == 0 && p.W / std::max(1, vec) == pi::BRICK_CPR_MAX &&
-        p.n1 % 8 == 0) return 512;
+        p.n1 % 8 == 0 && p.n / (4 * 512) >= 256) return 512;
     return (p.opt.brick_nt == 512 && p.hc == 0 && p.loss.mode == 0) ? 512 : 256;
 }
 
