@@ -725,6 +725,9 @@ def slab_rollout_fwd_(traj: torch.Tensor, P: torch.Tensor, ex: HaloExchanger, ha
 
     On HIP tensors with an exchanger that exposes its ring (``native_ring``) the whole loop, exchanges included, is ONE
     C call (``percnn_pi_slab_rollout_fwd_*``); the Python loop below is the portable path (gloo / CPU stand-ins).
+    ONE rank (world size 1, no ``force_p2p``): the native loop wraps by index inside the step launches -- no face copies,
+    the halo planes of frames 1 .. T are neither read nor written (round 5; ``LocalWrapExchanger(copies=True)`` keeps the
+    launches of a multi-rank run).
 
     overlap (default off -- measured on MI355X with RCCL-to-self, 32 x 256^2 slab: un-split 84 us per fwd+bwd step,
     split + side stream 119 us: the two cross-stream hops and two extra launches per step cost more than the ~26 us of
