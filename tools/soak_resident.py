@@ -37,7 +37,8 @@ for it in range(n_it):
     a, ag = pa.rollout_bwd(traj, g, P, frame_mask=mask)
     b, bg = pa.rollout_bwd(traj, g, P, frame_mask=mask, options={"tile_persist": 0, "persist_small": 0})
     assert torch.equal(a.view(torch.int64 if tdt == torch.float64 else torch.int32), b.view(torch.int64 if tdt == torch.float64 else torch.int32)), (it, kind, shape, T, mk)
-    if bool(torch.isfinite(traj[-1]).all()) and float(bg.norm()) > 0:
+    # (blown-up trajectories -- random blocks do that -- overflow the cubic moments in EVERY path: compare what is finite)
+    if bool(torch.isfinite(traj[-1]).all()) and float(traj.abs().max()) < 1e6 and bool(torch.isfinite(bg).all()) and float(bg.norm()) > 0:
         err = float((ag - bg).norm() / bg.norm())
         assert err < (1e-11 if tdt == torch.float64 else 5e-6), (it, kind, shape, T, mk, err)
     counts[kind] = counts.get(kind, 0) + 1
