@@ -963,6 +963,9 @@ int tile_by_for(const Problem& p)
     if (p.opt.tile_k != 4 || p.opt.tile_nt != 512) return TILE_B;
     const int64_t tiles32 = ((p.n0 + TILE_B - 1) / TILE_B) * ((p.W + TILE_B - 1) / TILE_B);
     const int64_t tiles8 = ((p.n0 + 7) / 8) * ((p.W + TILE_B - 1) / TILE_B);
+    // Round 5: whole-tile grids of 113 .. 128 tiles take 32 x 32 tiles -- the resident pyramid kernels beat the 16-row ones there
+    // (352^2: 262.8 -> 276.3 k steps/s, 256 x 512: 270.1 -> 280.6 k; 288^2 / 320^2 tie: profiles/r05_tile_height_mid_sizes.txt)
+    if (tiles8 > 256 && tiles32 > 112 && tiles32 <= 128 && p.n0 % TILE_B == 0 && p.W % TILE_B == 0) return TILE_B;
     return tiles8 <= 256 ? 8 : (tiles32 <= 128 ? 16 : TILE_B);
 }
 
@@ -3180,7 +3183,15 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t* sh
 {
     Problem p;
     if (make_problem(hc, ndim, shape, false, p, nullptr, false) || (elem_size != 4 && elem_size != 8) || T_steps < 0) return 0;
-    return rollout_workspace_bytes(p, T_steps, elem_size);
+    // a per-call `tile_by` override (percnn_pi_rollout_bwd_opt_*) may pick a tile height whose resident sweep needs the
+    // outbox although the default height does not: size for every height a call may ask for
+    size_t need = rollout_workspace_bytes(p, T_steps, elem_size);
+    for (int by : {8, 16}) {
+        Problem q = p;
+        q.opt.tile_by = by;
+        need = std::max(need, rollout_workspace_bytes(q, T_steps, elem_size));
+    }
+    return need;
 }
 
 int percnn_pi_set_option(const char* key, long value)

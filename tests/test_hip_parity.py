@@ -749,7 +749,7 @@ def test_tile_variants_bitwise(opts, dtype, hc, shape, hip_device):
             pa.set_option(k, v)
 
 
-@pytest.mark.parametrize("shape,T", [((384, 384), 23), ((384, 512), 9), ((512, 512), 41)])
+@pytest.mark.parametrize("shape,T", [((384, 384), 23), ((384, 512), 9), ((512, 512), 41), ((352, 352), 17), ((256, 512), 13)])
 def test_persistent_sweep_equals_launch_per_group(shape, T, hip_device):
     """The whole tile sweep as ONE launch of resident workgroups (pi_adj2d_persist_kernel, option tile_persist): dL/dh0 is the
     launch-per-group sweep's bit for bit (same device functions, the halo travels through tagged granules instead of a kernel
@@ -779,6 +779,25 @@ def test_persistent_sweep_equals_launch_per_group(shape, T, hip_device):
     d0, dg = pa.rollout_bwd(traj, g, P)
     torch.cuda.synchronize()
     assert torch.equal(a0, c0) and torch.equal(a0, d0)
+
+
+@pytest.mark.parametrize("shape", [(352, 352), (256, 512), (512, 512), (100, 100)])
+def test_per_call_tile_height_fits_the_queried_workspace(shape, hip_device):
+    """percnn_pi_rollout_bwd_workspace_bytes knows no per-call options: it sizes for every tile height a `tile_by` override may
+    pick (the 8- / 16-row resident sweeps need an outbox the 32-row one does not -- round 5, when 352^2 / 256 x 512 moved to
+    32 x 32 tiles by default), and every height gives the same dL/dh0 bit for bit."""
+    import percnn_amd as pa
+    T = 33
+    P = dev_t(random_block(0, 2, np.float32, 21, scale=0.1), hip_device)
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=hip_device)
+    traj[0] = torch.rand((2,) + shape, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(3))
+    pa.rollout_fwd_(traj, P)
+    g = torch.randn(traj.shape, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(1)) / traj[0].numel()
+    a0, ag = pa.rollout_bwd(traj, g, P)
+    for by in (8, 16, 32):
+        b0, bg = pa.rollout_bwd(traj, g, P, options={"tile_by": by})
+        assert torch.equal(a0, b0), by
+        assert rel_l2(ag.cpu().numpy(), bg.cpu().numpy()) < 2e-6
 
 
 @pytest.mark.parametrize("shape,T", [((384, 384), 23), ((512, 512), 41), ((288, 512), 14)])
@@ -822,7 +841,7 @@ def test_persistent_sweep_float64_equals_launch_per_group(shape, T, hip_device):
     assert torch.equal(a0, c0) and torch.equal(a0, d0)
 
 
-@pytest.mark.parametrize("shape,T", [((384, 384), 35), ((384, 512), 33), ((512, 512), 41), ((448, 448), 64)])
+@pytest.mark.parametrize("shape,T", [((384, 384), 35), ((384, 512), 33), ((512, 512), 41), ((448, 448), 64), ((352, 352), 37), ((256, 512), 35)])
 def test_persistent_forward_equals_launch_per_group(shape, T, hip_device):
     """Round 4: the forward rollout of a grid of whole 32 x 32 tiles (16 .. #CUs of them) as ONE launch of resident workgroups
     (pi_fwd2d_persist_kernel, option fwd_persist): every frame of the trajectory is the launch-per-group kernel's bit for bit

@@ -537,6 +537,9 @@ def test_rollout_plan_follows_the_dispatch_rules():
     p = plan(0, (512, 512), 4)
     assert p["fwd"] == "tile2d" and p["bwd"] == "tile2d" and p["fused_gradients"] and p["fwd_steps_per_launch"] == 4
     assert p["tile"] == (32, 32, 512) and plan(0, (100, 100), 4)["tile"] == (32, 8, 256)
+    # 16-row tiles up to 112 tiles of 32 x 32; whole-tile grids of 113 .. 128 take 32 x 32 (resident pyramid kernels, round 5)
+    assert plan(0, (320, 320), 4)["tile"] == (32, 16, 320) and plan(0, (352, 352), 4)["tile"] == (32, 32, 512)
+    assert plan(0, (256, 512), 4)["tile"] == (32, 32, 512) and plan(0, (340, 340), 4)["tile"] == (32, 16, 320)
     # past 512^2 the tiles grow while that keeps the grid in one round of 256 workgroups (float32 poly blocks only)
     assert plan(0, (544, 544), 4)["tile"] == (32, 40, 640) and plan(0, (544, 544), 4)["fused_gradients"]
     assert plan(0, (640, 640), 4)["tile"] == (40, 40, 768) and plan(0, (576, 576), 4)["tile"] == (40, 40, 768)
