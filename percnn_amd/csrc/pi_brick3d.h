@@ -383,6 +383,18 @@ pi_res3d_brick_kernel(const T* __restrict__ traj, double* __restrict__ partials,
 // edge, into scratch.  Through the rank's OWN mailbox it buys little (a put to self is 2 MiB of uncached stores into the same
 // HBM the sweep streams from); across xGMI the same bytes are ~16 us of wire per step that would otherwise sit between two
 // sweep launches.
+template <typename T> using BV2 = T __attribute__((ext_vector_type(2)));
+template <typename T, bool PAIR> struct BrickMomAcc {
+    using type = T;
+    static __device__ __forceinline__ T total(T a) { return a; }
+};
+template <typename T> struct BrickMomAcc<T, true> {
+    using type = BV2<T>;
+    static __device__ __forceinline__ T total(BV2<T> a) { return a.x + a.y; }
+};
+#ifndef PI_BRICK_MOM_PAIR_MIN_RZ
+#define PI_BRICK_MOM_PAIR_MIN_RZ 2     // one-plane bricks hold 128 registers for four waves per SIMD: 20 more spill (24.5 vs 17.7 us at 128^3)
+#endif
 struct NoPut {};
 template <bool PUT> struct AdjPutArg { using type = NoPut; };
 template <> struct AdjPutArg<true> { using type = PeerPutFused; };
@@ -423,12 +435,18 @@ pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T*
 
     const T dt = P[P_DT];
     double lane_c[2] = {0.0, 0.0};
-    T macc[MOM ? 2 : 1][MOM ? 10 : 1];
+    // moment accumulators.  PAIR (float32, bricks of two or more planes): 2-vectors over the point pairs (0,1) / (2,3) of the
+    // lane's chunk -- operands that sit in adjacent registers as loaded, so the sums issue as v_pk_fma_f32 without the
+    // v_mov_b32 shuffles hipcc's own packing of the scalar form paid (round 5: 314 of 1037 VALU instructions of the
+    // two-plane kernel were moves; profiles/r05_brick_adjoint_packed_moments.txt)
+    constexpr bool PAIR = MOM && sizeof(T) == 4 && VEC == 4 && RZ >= PI_BRICK_MOM_PAIR_MIN_RZ;
+    using MAcc = typename BrickMomAcc<T, PAIR>::type;
+    MAcc macc[MOM ? 2 : 1][MOM ? 10 : 1];
     if constexpr (MOM) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int m = 0; m < 10; ++m) macc[s][m] = T(0);
+            for (int m = 0; m < 10; ++m) macc[s][m] = MAcc{};
     }
     Geom gg = brick_as_geom(g);
     bool staged = false;
@@ -503,8 +521,8 @@ pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T*
                         poly_dr(c, u.v[i], v.v[i], ru, rv);
                         du[i] = fma_(gr, ru, du[i]);
                         dv[i] = fma_(gr, rv, dv[i]);
-                        if constexpr (MOM) {
-                            T (&acc)[10] = macc[s];
+                        if constexpr (MOM && !PAIR) {
+                            MAcc (&acc)[10] = macc[s];
                             const T uu = u.v[i], vv = v.v[i];
                             const T u2 = uu * uu, uv = uu * vv, v2 = vv * vv;
                             acc[0] += gr;
@@ -515,6 +533,25 @@ pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T*
                         }
                     }
                     lane_c[s] += acc_c;
+                }
+                if constexpr (PAIR) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const BV2<T> uu{u.v[2 * hh], u.v[2 * hh + 1]}, vv{v.v[2 * hh], v.v[2 * hh + 1]};
+                        const BV2<T> u2 = uu * uu, uv = uu * vv, v2 = vv * vv;
+                        const BV2<T> u3 = u2 * uu, u2v = u2 * vv, uv2 = uu * v2, v3 = v2 * vv;
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const BV2<T> gr = BV2<T>{gc[s].v[2 * hh], gc[s].v[2 * hh + 1]} * BV2<T>{dt, dt};
+                            MAcc (&acc)[10] = macc[s];
+                            acc[0] += gr;
+                            acc[1] = __builtin_elementwise_fma(gr, uu, acc[1]); acc[2] = __builtin_elementwise_fma(gr, vv, acc[2]);
+                            acc[3] = __builtin_elementwise_fma(gr, u2, acc[3]); acc[4] = __builtin_elementwise_fma(gr, uv, acc[4]);
+                            acc[5] = __builtin_elementwise_fma(gr, v2, acc[5]);
+                            acc[6] = __builtin_elementwise_fma(gr, u3, acc[6]); acc[7] = __builtin_elementwise_fma(gr, u2v, acc[7]);
+                            acc[8] = __builtin_elementwise_fma(gr, uv2, acc[8]); acc[9] = __builtin_elementwise_fma(gr, v3, acc[9]);
+                        }
+                    }
                 }
             } else {
 #pragma unroll
@@ -598,7 +635,7 @@ pi_adj3d_brick_kernel(const T* __restrict__ h, const T* __restrict__ G, const T*
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int m = 0; m < 10; ++m) scr[(10 * s + m) * RS + (int)threadIdx.x] = macc[s][m];
+            for (int m = 0; m < 10; ++m) scr[(10 * s + m) * RS + (int)threadIdx.x] = BrickMomAcc<T, PAIR>::total(macc[s][m]);
         __syncthreads();
         {
             const int task = (int)threadIdx.x;                           // NT = 256 >= 160 tasks: one trip
