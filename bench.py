@@ -333,6 +333,12 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
         loss = (traj ** 2).mean()
         torch.autograd.grad(loss, params + [h0])
 
+    def it_list_copy():                                  # what that line cost before round 5: the stock, copying torch.cat
+        outs, _ = model()
+        traj = torch.cat(tuple(f.as_subclass(torch.Tensor) for f in outs), dim=0)
+        loss = (traj ** 2).mean()
+        torch.autograd.grad(loss, params + [h0])
+
     def it_stacked():
         outs, _ = model()
         loss = (outs.stacked ** 2).mean()                # the reference's call pattern minus its torch.cat
@@ -352,7 +358,8 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
         torch.autograd.grad(loss, params + [h0])
 
     out = {}
-    for key, fn in (("list_cat_dense_loss_ms", it_list), ("list_stacked_dense_loss_ms", it_stacked),
+    for key, fn in (("list_cat_dense_loss_ms", it_list), ("list_copying_cat_dense_loss_ms", it_list_copy),
+                    ("list_stacked_dense_loss_ms", it_stacked),
                     ("trajectory_dense_loss_ms", it_traj),
                     ("loss_mse_dense_ms", it_loss_mse), ("observe_strided_loss_ms", it_observe)):
         fn()
@@ -370,7 +377,7 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
         out[key] = {"gpu_ms": per_it[reps // 2], "gpu_ms_mean": marks[0].elapsed_time(marks[reps]) / reps,
                     "wall_ms": (time.perf_counter() - t0) / reps * 1e3}
     out["what"] = (f"one training iteration through the drop-in modules at {'x'.join(map(str, shape))} x T={T}: RCNN.forward() "
-                   "+ torch.cat + mean(traj^2) + backward; the same with outputs.stacked in place of the cat; RCNN.trajectory() (torch.ops.percnn.pi_rollout, no list / cat) + the same loss; "
+                   "+ torch.cat(tuple(outputs), dim=0) (the reference's own line: since round 5 it returns the trajectory buffer, functional.Frame) + mean(traj^2) + backward; the same with the stock copying cat (frames as plain tensors); the same with outputs.stacked in place of the cat; RCNN.trajectory() (torch.ops.percnn.pi_rollout, no list / cat) + the same loss; "
                    "RCNN.loss_mse() = the same dense loss as ONE autograd node with the rollout (gradient formed inside the sweep); "
                    "RCNN.observe(0:-1:20, ::4) + MSE + backward "
                    "(forward, loss, full backward incl. parameter gradients; wall = host clock around the same loop)")

@@ -805,6 +805,55 @@ def _assemble_frame_grads(grads, frames, traj):
     return g_traj, mask
 
 
+class Frame(torch.Tensor):
+    """One [1,2,*S] frame of a rollout as ``RCNN.forward()`` hands it out: an ordinary tensor (every operation on it returns
+    plain ``torch.Tensor``s) that remembers which trajectory buffer it is a view of, so that the reference's own next line --
+    ``output = torch.cat(tuple(output), dim=0)`` (train_2drd.py:394, train_3drd.py:400, percnn_LO_eqn.py:367) -- returns
+    that buffer (a slice of it for a run of consecutive steps) instead of copying the whole trajectory forward
+    (2 GiB at 512^2 x 1000) and slicing its gradient apart again backward.  Anything else -- another order, another dim,
+    frames of two rollouts, foreign tensors in the sequence, ``out=`` -- takes the stock ``torch.cat``."""
+
+    _pi_index: int = -1
+    _pi_stacked: Optional[torch.Tensor] = None
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.cat and args and "out" not in kwargs:
+            view = _cat_of_frames(args[0], kwargs.get("dim", args[1] if len(args) > 1 else 0))
+            if view is not None:
+                return view
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
+def _cat_of_frames(seq, dim) -> Optional[torch.Tensor]:
+    """the view of the trajectory buffer that equals torch.cat(seq, dim), or None"""
+    if not isinstance(seq, (tuple, list)) or len(seq) == 0 or type(seq[0]) is not Frame:
+        return None
+    st = seq[0]._pi_stacked
+    if st is None or not isinstance(dim, int) or dim not in (0, -st.dim()):
+        return None
+    i0, n = seq[0]._pi_index, len(seq)
+    if i0 < 0:
+        return None
+    # consecutive steps only: for every n-th step a strided view would be free forward, but its SliceBackward hands the sweep a
+    # dense, mostly zero dL/dtraj where the stock cat's per-frame gradients let it mask the unobserved frames out
+    for j, f in enumerate(seq):
+        if type(f) is not Frame or f._pi_stacked is not st or f._pi_index != i0 + j:
+            return None
+    if i0 == 0 and n == st.shape[0]:
+        return st                                           # every frame: the buffer itself, no node in between
+    return st[i0:i0 + n]
+
+
+def link_frames(frames: Sequence[torch.Tensor], stacked: torch.Tensor) -> None:
+    """tell the frames of one rollout (PiRolloutFramesFunction's outputs) which tensor torch.cat may return for them"""
+    for f in frames:
+        if type(f) is Frame:
+            f._pi_stacked = stacked
+
+
 class PiRolloutFramesFunction(torch.autograd.Function):
     """T fused steps, returned as the reference returns them: a tuple of [1,2,*S] frames (train_2drd.py:162-190
     appends every effective step to a Python list).  The frames are views of ONE trajectory buffer; the backward
@@ -825,7 +874,12 @@ class PiRolloutFramesFunction(torch.autograd.Function):
         ctx.frames = tuple(int(k) for k in frames)
         ctx.set_materialize_grads(False)
         views = traj.unsqueeze(1).unbind(0)                 # all [1,2,*S] frame views in one call
-        return tuple(views[k] for k in ctx.frames) + (traj.view(traj.shape),)
+        outs = []
+        for k in ctx.frames:
+            f = views[k].as_subclass(Frame)                 # (see Frame: what makes the caller's torch.cat free)
+            f._pi_index = k
+            outs.append(f)
+        return tuple(outs) + (traj.view(traj.shape),)
 
     @staticmethod
     def backward(ctx, *grads):

@@ -751,8 +751,10 @@ class FrameList(list):
     """The list of frames ``RCNN.forward()`` returns (train_2drd.py:187-188) -- an ordinary list -- plus, when every step is an
     effective step, ``.stacked``: the [step+1, 2, *S] tensor the reference's callers build from it with
     ``torch.cat(tuple(output), dim=0)`` (train_2drd.py:394), as an output of the SAME autograd node.  The frames are views of
-    that tensor, so ``output.stacked`` costs nothing where the cat copies the whole trajectory (2 GiB at 512^2 x 1000) forward
-    and its CatBackward slices it again backward."""
+    that tensor, so ``output.stacked`` costs nothing where a cat would copy the whole trajectory (2 GiB at 512^2 x 1000) forward
+    and its CatBackward slice it again backward.  Since round 5 the frames are ``functional.Frame``s: the
+    reference's unchanged ``torch.cat(tuple(output), dim=0)`` returns that same tensor -- no caller edit needed for the zero-copy
+    path (runs of consecutive steps; every n-th step keeps the stock cat, whose per-frame gradients the sweep can mask)."""
     stacked: Optional[torch.Tensor] = None
 
 
@@ -878,6 +880,7 @@ class RCNN(nn.Module):
         else:
             outs = F_pi.pi_rollout_frames(self.init_state, self._block(), self.step, frames, with_stacked=True)
             outs, stacked = outs[:-1], outs[-1]
+            F_pi.link_frames(outs[:n_out], stacked)         # torch.cat(tuple(outputs), dim=0) -> a view of `stacked`, no copy
         outputs = FrameList(outs[:n_out])
         if stacked is not None and n_out == self.step + 1:
             outputs.stacked = stacked                       # dense effective_step: == torch.cat(tuple(outputs), dim=0), no copy

@@ -188,19 +188,40 @@ def test_stacked_attribute_of_the_frame_list_equals_cat(kind, shape, T):
     def flat(gs):
         return torch.cat([g.reshape(-1) for g in gs])
 
+    def copying_cat(frames):                              # the stock torch.cat (the frames as plain tensors: no shortcut)
+        return torch.cat(tuple(f.as_subclass(torch.Tensor) for f in frames), 0)
+
     outs, _ = model()
-    ref = flat(torch.autograd.grad((torch.cat(tuple(outs), 0) ** 2).mean() + outs[3].sum() * 1e-3, params + [h0]))
+    ref = flat(torch.autograd.grad((copying_cat(outs) ** 2).mean() + outs[3].sum() * 1e-3, params + [h0]))
     outs, _ = model()
-    assert isinstance(outs, list) and len(outs) == T + 1 and torch.equal(outs.stacked, torch.cat(tuple(outs), 0))
+    assert isinstance(outs, list) and len(outs) == T + 1 and torch.equal(outs.stacked, copying_cat(outs))
+    # round 5: the reference's own line returns the buffer itself -- no copy, no caller edit
+    assert torch.cat(tuple(outs), dim=0) is outs.stacked and copying_cat(outs).data_ptr() != outs.stacked.data_ptr()
+    run = torch.cat(tuple(outs[2:7]), dim=0)
+    assert run.data_ptr() == outs[2].data_ptr() and torch.equal(run, outs.stacked[2:7])
+    mixed = flat(torch.autograd.grad((torch.cat(tuple(outs), 0) ** 2).mean() + outs[3].sum() * 1e-3, params + [h0]))
+    assert rel_l2(mixed.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+    outs, _ = model()
+    part = flat(torch.autograd.grad((torch.cat(tuple(outs[1:]), 0) ** 2).mean(), params + [h0]))
+    outs, _ = model()
+    part_ref = flat(torch.autograd.grad((copying_cat(outs[1:]) ** 2).mean(), params + [h0]))
+    assert rel_l2(part.cpu().numpy(), part_ref.cpu().numpy()) < 1e-6
+    outs, _ = model()
     got = flat(torch.autograd.grad((outs.stacked ** 2).mean() + outs[3].sum() * 1e-3, params + [h0]))
     assert rel_l2(got.cpu().numpy(), ref.cpu().numpy()) < 1e-6
     outs, _ = model()
     only = flat(torch.autograd.grad((outs.stacked ** 2).mean(), params + [h0]))
     outs, _ = model()
-    cat = flat(torch.autograd.grad((torch.cat(tuple(outs), 0) ** 2).mean(), params + [h0]))
+    cat = flat(torch.autograd.grad((copying_cat(outs) ** 2).mean(), params + [h0]))
     assert rel_l2(only.cpu().numpy(), cat.cpu().numpy()) < 1e-6
     sparse, _ = pa.RCNN(cell, step=T, effective_step=[0, 2, 5], init_state=h0)()
     assert sparse.stacked is None and len(sparse) == 4
+    sc = torch.cat(tuple(sparse), dim=0)                  # every n-th step: the stock cat (its per-frame gradients get masked)
+    assert torch.equal(sc, copying_cat(sparse)) and sc.data_ptr() != sparse[0].data_ptr()
+    gs = flat(torch.autograd.grad((sc ** 2).mean(), params + [h0]))
+    sparse, _ = pa.RCNN(cell, step=T, effective_step=[0, 2, 5], init_state=h0)()
+    gs_ref = flat(torch.autograd.grad((copying_cat(sparse) ** 2).mean(), params + [h0]))
+    assert rel_l2(gs.cpu().numpy(), gs_ref.cpu().numpy()) < 1e-6
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])

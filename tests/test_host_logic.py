@@ -618,3 +618,45 @@ def test_bench_promotes_the_sharded_result_for_n_gt_1():
         keep = dict(base, slab_3d=bad)
         bench.promote_sharded_headline(keep, 8)
         assert keep["value"] == 2.0e6 and keep["scaling"] == "weak" and keep["sharded_headline_missing"]
+
+
+def test_frames_make_the_callers_cat_a_view():
+    """functional.Frame (round 5): ``torch.cat(tuple(outputs), dim=0)`` -- the reference's own next line after ``model()``
+    (train_2drd.py:394) -- returns the trajectory buffer for the frames of one rollout in order, a slice for a run of consecutive
+    steps, and is the stock copying cat for everything else (other order, other dim, foreign tensors, two rollouts, ``out=``,
+    every n-th step); operations on a frame return plain tensors."""
+    from percnn_amd import functional as F_pi
+
+    def frames_of(st):
+        fr = []
+        for k, v in enumerate(st.unsqueeze(1).unbind(0)):
+            f = v.as_subclass(F_pi.Frame)
+            f._pi_index = k
+            fr.append(f)
+        F_pi.link_frames(fr, st)
+        return fr
+
+    st = torch.arange(6 * 2 * 3 * 4, dtype=torch.float32).reshape(6, 2, 3, 4)
+    fr = frames_of(st)
+    assert all(isinstance(f, torch.Tensor) and f.shape == (1, 2, 3, 4) for f in fr)
+    for seq in (tuple(fr), list(fr)):
+        c = torch.cat(seq, dim=0)
+        assert c is st and type(c) is torch.Tensor
+    assert torch.cat(tuple(fr), 0) is st and torch.cat(tuple(fr), dim=-4) is st
+    run = torch.cat(tuple(fr[2:5]), dim=0)
+    assert run.data_ptr() == st[2].data_ptr() and run.shape == (3, 2, 3, 4) and torch.equal(run, st[2:5])
+    # everything else: a copy with the stock semantics
+    for seq, kw in (((fr[2], fr[0]), {"dim": 0}), (tuple(fr[::2]), {"dim": 0}), (tuple(fr), {"dim": 1}),
+                    ((fr[0], st[1:2]), {"dim": 0}), ((st[0:1], fr[1]), {"dim": 0})):
+        c = torch.cat(seq, **kw)
+        ref = torch.cat(tuple(t.as_subclass(torch.Tensor) for t in seq), **kw)
+        assert type(c) is torch.Tensor and torch.equal(c, ref) and c.data_ptr() != st.data_ptr()
+    other = frames_of(st.clone())
+    c = torch.cat((fr[0], other[1]), dim=0)
+    assert c.data_ptr() not in (st.data_ptr(), other[0].data_ptr()) and torch.equal(c, st[0:2])
+    buf = torch.empty(6, 2, 3, 4)
+    assert torch.cat(tuple(fr), dim=0, out=buf) is buf and torch.equal(buf, st)
+    # a frame behaves as a tensor and does not spread its type
+    assert type(fr[1] * 2) is torch.Tensor and type(fr[1].clone()) is torch.Tensor and type(fr[1][0]) is torch.Tensor
+    assert fr[3].detach().numpy().shape == (1, 2, 3, 4) and float(fr[1].sum()) == float(st[1].sum())
+    assert type(torch.stack(tuple(fr))) is torch.Tensor and torch.stack(tuple(fr)).shape == (6, 1, 2, 3, 4)
