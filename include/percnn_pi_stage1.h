@@ -38,7 +38,12 @@ size_t percnn_pi_s1_param_count(void);
 /* tuning / diagnostics (results stay within the documented tolerance): "etile" = 1 (default) hands the input-gradient
  * contributions between consecutive launches of the backward sweep as 8x8 footprint tiles when H and W are multiples
  * of 4, 0 = always per-tap planes;  "skip_wgrad" = 1 runs the adjoint sweep only (parameter gradients come back as
- * zeros; used to time the sweep kernel alone).  Returns PERCNN_PI_EINVAL for an unknown key. */
+ * zeros; used to time the sweep kernel alone);  "persist" = 1 (default): rollouts of >= "persist_min_steps" (8) steps on
+ * grids of whole 4x4 patches whose (patch, species) tasks all fit on the device at once run as ONE launch of resident waves
+ * each way (round 5; results bit for bit those of one launch per step; the residency guard, the handshake on the roll
+ * call, PERCNN_PI_EASYNC and the abort -> launch-per-step fallback are those of percnn_pi.h's resident launches, option
+ * keys persist_* there), 0 = one launch per step;  "pause_fwd" / "pause_adj" = s_sleep units between publishing a step's
+ * granules and requesting the neighbours'.  Returns PERCNN_PI_EINVAL for an unknown key. */
 int percnn_pi_s1_set_option(const char* key, long value);
 
 /* one time step; shape = {H, W}, H and W >= 8;  h and h_next: [2][H][W], must not alias */

@@ -19,6 +19,7 @@
 #include "pi_contract.h"
 #include "pi_peer.h"
 #include "pi_adv.h"
+#include "pi_host.h"
 
 namespace {
 
@@ -3010,6 +3011,66 @@ int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options,
 }  // namespace
 
 // ---- exported symbols ---------------------------------------------------------------------------
+// ---- resident launches of the Stage-1 block (pi_s1_abi.hip, the library's second translation unit) ---------------------------
+// They share the residency guard of the 2D resident kernels: one resident grid per device at a time (calls on other streams
+// are detected and refused), host-mapped status slots, a per-device scratch (sync words + granule outbox), the handshake on the
+// roll call and the "disabled after an abort" state (percnn_pi_persist_status / persist_reset report and re-arm both).
+namespace pi_host {
+int resident_async_error() { return persist_async_error(); }
+int resident_cu_count() { return device_cu_count(); }
+// hipSuccess: launch; anything else: take the launch-per-step path (nothing has been enqueued but the memset)
+hipError_t resident_begin(void* stream, size_t outbox_bytes, Resident& r)
+{
+    auto st = static_cast<hipStream_t>(stream);
+    Options o;
+    { std::lock_guard<std::mutex> lk(g_defaults_mu); o = g_defaults; }
+    if (!o.tile_persist || !o.fwd_persist) return hipErrorNotSupported;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return hipErrorNotSupported; }
+    if (!persist_enter(st, r.dev)) return hipErrorNotSupported;
+    const size_t need = 256 + outbox_bytes;
+    {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        if (g_persist.fwd_scratch_bytes[r.dev] < need) {
+            if (g_persist.fwd_scratch[r.dev]) {
+                (void)hipFree(g_persist.fwd_scratch[r.dev]);
+                g_persist.fwd_scratch[r.dev] = nullptr;
+                g_persist.fwd_scratch_bytes[r.dev] = 0;
+            }
+            void* q = nullptr;
+            if (hipMalloc(&q, need) != hipSuccess || !q) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
+            g_persist.fwd_scratch[r.dev] = q;
+            g_persist.fwd_scratch_bytes[r.dev] = need;
+        }
+        r.scratch = static_cast<unsigned char*>(g_persist.fwd_scratch[r.dev]);
+        r.slot = g_persist.next_slot++ % PERSIST_SLOTS;
+        g_persist.watch[r.slot] = false;
+        ++g_persist.launches;
+    }
+    if (hipError_t e = hipMemsetAsync(r.scratch, 0, need, st)) return e;
+    r.hs = g_persist.host->slot[r.slot];
+    r.hs[0] = 0; r.hs[1] = -1; r.hs[2] = -1; r.hs[3] = 0;
+    r.timeout_ticks = (unsigned long long)o.persist_timeout_ms * 100000ull;                 // 100 MHz clock
+    r.first_timeout_ticks = (unsigned long long)o.persist_first_timeout_ms * 100000ull;
+    return hipSuccess;
+}
+// after the launch: hipSuccess = resident and running; hipErrorLaunchFailure = it aborted (the caller recomputes launch by launch)
+hipError_t resident_launched(void* stream, Resident& r, unsigned grid, const char* what)
+{
+    auto st = static_cast<hipStream_t>(stream);
+    int handshake;
+    { std::lock_guard<std::mutex> lk(g_defaults_mu); handshake = g_defaults.persist_handshake; }
+    {
+        std::lock_guard<std::mutex> lk(g_persist.mu);
+        g_persist.watch[r.slot] = true;
+    }
+    hipError_t e = hipSuccess;
+    if (handshake) e = persist_wait_roll_call(r.hs, r.slot, r.dev, grid, what);
+    if (e == hipSuccess || e == hipErrorLaunchFailure) persist_leave(st, r.dev);
+    return e;
+}
+}  // namespace pi_host
+
 extern "C" {
 
 #ifdef PI_TILE_TIMING

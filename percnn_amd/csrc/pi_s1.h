@@ -592,5 +592,300 @@ __global__ void s1_reduce_kernel(const float* __restrict__ partials, const doubl
     if (live && rl == 0) pg[i] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// ================================================================================================================
+// Resident rollouts (round 5).  At the reference's 100^2 a launch per step is its boundary (2.8 us) plus one cold round trip for
+// the operands the previous launch wrote (1.8 us) around 0.6 us (forward) / 1.3 us (sweep) of matrix-pipe work.  Here ONE
+// launch walks all time steps: every wave owns one (patch, species) task for the whole rollout, and what a task needs from the
+// tasks around it travels as data-tagged 8-byte granules {tag = step count, value} through an outbox in global memory
+// (agent-scope write-through stores / loads, the idiom of the 2D resident kernels, pi_tile2d.h): a consumer polls until the tag
+// is the step it waits for.  Two outbox halves by step parity suffice: a producer can only be one step ahead of its consumers
+// (its next step needs THEIR output of this one).  No workgroup barrier after the weights are staged -- waves stay independent.
+// Residency (every task must be on the machine at once) is checked by a roll call into a host-mapped word and bounded waits;
+// an aborted launch is recomputed launch by launch (pi_s1_abi.hip).  Arithmetic = the per-step kernels' own functions, same
+// order: trajectory and adjoint frames bit for bit theirs.  Shapes: H, W multiples of 4 (whole patches).
+// ================================================================================================================
+struct ResArgs {
+    unsigned long long* outbox;     // two parity halves of granules
+    unsigned* sync;                 // [0] roll call, [1] abort flag
+    int* host;                      // host-mapped {roll call complete, step, task, aborted}
+    unsigned long long timeout_ticks, first_timeout_ticks;     // 100 MHz ticks
+    int nwg;                        // workgroups of the launch
+    int pause;                      // s_sleep(1) units between publish and first request
+    int masked;                     // sweep: only the frames whose bit is set in `frames` carry a dL/dtraj
+    unsigned frames[128];           // (T < 4096)
+};
+typedef __attribute__((address_space(1))) unsigned long long res_gu64;
+
+__device__ __forceinline__ void res_put(res_gu64* p, unsigned tag, float v)
+{
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float res_value(unsigned long long x) { return __builtin_bit_cast(float, (unsigned)x); }
+
+// the wave's N granules per lane of one hand-over; false: timed out or somebody aborted
+template <int N>
+__device__ __forceinline__ bool res_poll(res_gu64* half, const unsigned (&gi)[N], unsigned tag, unsigned long long (&gx)[N],
+                                         const ResArgs& ra, bool first)
+{
+#pragma unroll
+    for (int q = 0; q < N; ++q) gx[q] = __hip_atomic_load(half + gi[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long bound = first ? ra.first_timeout_ticks : ra.timeout_ticks;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < N; ++q) ok &= (unsigned)(gx[q] >> 32) == tag;
+        if (__all(ok)) return true;
+        if (wall_clock64() - t0 > bound || __hip_atomic_load(ra.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+            return false;
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int q = 0; q < N; ++q)                         // only what has not arrived yet is asked for again
+            if ((unsigned)(gx[q] >> 32) != tag) gx[q] = __hip_atomic_load(half + gi[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__device__ __forceinline__ void res_roll_call(const ResArgs& ra)
+{
+    if (threadIdx.x == 0) {
+        const unsigned n = __hip_atomic_fetch_add(ra.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (n == (unsigned)ra.nwg && ra.host) __hip_atomic_store(ra.host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// the first wave to give up tells the others (abort flag) and the host (status slot)
+__device__ __forceinline__ void res_abort(const ResArgs& ra, int step, int task, int lane)
+{
+    if (lane == 0 && __hip_atomic_exchange(ra.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ra.host) {
+        __hip_atomic_store(ra.host + 1, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(ra.host + 2, task, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(ra.host + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// granules per parity half of the forward: [2 species][npatch][16 points]
+__host__ __device__ inline size_t res_fwd_half(const Geom& g) { return (size_t)2 * g.npatch * 16; }
+// ... of the sweep: adjoint values [2][npatch][16] | footprint tiles [2 producer species][npatch][2 channels][64]
+__host__ __device__ inline size_t res_adj_half(const Geom& g) { return (size_t)2 * g.npatch * 16 + (size_t)2 * g.npatch * 2 * (WIN * WIN); }
+
+// frames 1 .. T of `traj` from frame 0; grid = (ceil(npatch / WAVES), 2): one task per wave
+__global__ __launch_bounds__(64 * WAVES) void s1_fwd_persist_kernel(float* __restrict__ traj, int T, const float* __restrict__ P,
+                                                                    Geom g, ResArgs ra)
+{
+    __shared__ float lds[WAVES][2 * WIN * WIN];
+    __shared__ __attribute__((aligned(16))) float wl[WMAT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int s = blockIdx.y;
+    const int grp = lane >> 4, pt = lane & 15, py = pt >> 2, px = pt & 3;
+    float* win = lds[wv];
+    res_roll_call(ra);
+    const int patch = blockIdx.x * WAVES + wv;
+    const bool active = patch < g.npatch;
+    const int y0 = (patch / g.px) * 4, x0 = (patch % g.px) * 4;
+    Window wnd;
+    if (active) wnd.load(traj, g, y0, x0, lane);
+    Consts k;
+    k.load(P, s, grp);
+    stage_weights(P, s, wl);
+    if (!active) return;
+
+    float a[3][NKS];
+    load_branch_weights(wl, lane, a);
+    int toff[NKS];
+#pragma unroll
+    for (int q = 0; q < NKS; ++q) toff[q] = tap_offset(q, grp, py, px);
+
+    // where this lane's two window values (both species) come from, and where its own point goes
+    unsigned gi[2];
+    {
+        const int row = wrap1(y0 + (lane >> 3) - 2, g.H), col = wrap1(x0 + (lane & 7) - 2, g.W);
+        const unsigned src = (unsigned)(((row >> 2) * g.px + (col >> 2)) * 16 + (row & 3) * 4 + (col & 3));
+        gi[0] = src;
+        gi[1] = (unsigned)g.npatch * 16u + src;
+    }
+    const size_t half = res_fwd_half(g);
+    res_gu64* outbox = (res_gu64*)ra.outbox;
+    const unsigned mine = (unsigned)((s * g.npatch + patch) * 16 + pt);
+    const long frame = 2 * g.n;
+    const long own = s * g.n + (long)(y0 + py) * g.W + (x0 + px);
+
+    for (int t = 0; t < T; ++t) {
+        wave_sync();
+        wnd.store(win, lane);
+        wave_sync();
+        f4 acc[3];
+        branches(a, win, toff, grp, acc);
+        float r = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r = fma_(k.w4[i], (acc[0][i] * acc[1][i]) * acc[2][i], r);
+        r = xor_add(r, 16);
+        r = xor_add(r, 32);
+        const float rr = r + k.b4;
+        const float* ws = win + s * (WIN * WIN);
+        const float lap = win_star<1>(ws, k, py, px);
+        const float res = k.coef * lap + rr;
+        const float upd = res * k.dt;
+        const float nv = ws[(py + 2) * WIN + (px + 2)] + upd;
+        const unsigned tag = (unsigned)t + 1u;
+        res_gu64* hf = outbox + (size_t)(tag & 1u) * half;
+        if (grp == 0) {
+            if (t + 1 < T) res_put(hf + mine, tag, nv);      // the neighbours wait for this; the frame can follow
+            traj[(long)(t + 1) * frame + own] = nv;
+        }
+        if (t + 1 == T) break;
+        for (int w = 0; w < ra.pause; ++w) __builtin_amdgcn_s_sleep(1);
+        unsigned long long gx[2];
+        if (!res_poll<2>(hf, gi, tag, gx, ra, t == 0)) { res_abort(ra, t, 2 * patch + s, lane); return; }
+        wnd.v[0] = res_value(gx[0]);
+        wnd.v[1] = res_value(gx[1]);
+    }
+}
+
+// the adjoint sweep t = T .. 0 (s1_adj_kernel<ETILE = true>'s two phases per step) in one launch: adjoint frames 1 .. T into
+// `adj` (the time-parallel weight-gradient kernel reads them afterwards), dL/dh0 into g_h0.  What a step hands to the next --
+// the adjoint values of the 8x8 window and the folded footprint tiles -- travels as granules; h_{t-1} and dL/dtraj[t] are
+// plain loads, requested one step ahead.
+__global__ __launch_bounds__(64 * WAVES) void s1_adj_persist_kernel(const float* __restrict__ traj, const float* __restrict__ g_traj,
+                                                                    float* __restrict__ adj, float* __restrict__ g_h0, int T,
+                                                                    const float* __restrict__ P, Geom g, ResArgs ra)
+{
+    __shared__ float lds[WAVES][3 * WIN * WIN + NTAP * 16];   // h window, adjoint window, tap tile
+    __shared__ __attribute__((aligned(16))) float wl[WMAT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int s = blockIdx.y;
+    const int grp = lane >> 4, pt = lane & 15, py = pt >> 2, px = pt & 3;
+    float* win = lds[wv];
+    float* awin = win + 2 * WIN * WIN;
+    float* dl = awin + WIN * WIN;
+    res_roll_call(ra);
+    const int patch = blockIdx.x * WAVES + wv;
+    const bool active = patch < g.npatch;
+    const int y0 = (patch / g.px) * 4, x0 = (patch % g.px) * 4;
+    const long frame = 2 * g.n;
+    const long pidx = (long)(y0 + py) * g.W + (x0 + px);
+    auto has_inj = [&](int t) { return !ra.masked || ((ra.frames[t >> 5] >> (t & 31)) & 1u); };
+    Window wnd;
+    float inj = 0.f;
+    if (active) {
+        if (T > 0) wnd.load(traj + (long)(T - 1) * frame, g, y0, x0, lane);
+        if (has_inj(T)) inj = g_traj[(long)T * frame + s * g.n + pidx];
+    }
+    Consts k;
+    k.load(P, s, grp);
+    stage_weights(P, s, wl);
+    if (!active) return;
+
+    float a[3][NKS];
+    int toff[NKS];
+    load_branch_weights(wl, lane, a);
+#pragma unroll
+    for (int q = 0; q < NKS; ++q) toff[q] = tap_offset(q, grp, py, px);
+
+    const unsigned nA = (unsigned)(2 * g.npatch * 16);
+    unsigned gi[3];
+    {
+        const int row = wrap1(y0 + (lane >> 3) - 2, g.H), col = wrap1(x0 + (lane & 7) - 2, g.W);
+        gi[0] = (unsigned)((s * g.npatch + (row >> 2) * g.px + (col >> 2)) * 16 + (row & 3) * 4 + (col & 3));
+        // lane group = (producer species, own / neighbouring patch row); both patch columns per lane (AdjIn<true>::load)
+        const int sp = grp >> 1;
+        const int dyy = (grp & 1) ? (py >= 2 ? 1 : -1) : 0;
+        const int qy = wrap1(patch / g.px + dyy, g.npy), wyq = py - 4 * dyy + 2;
+#pragma unroll
+        for (int xs = 0; xs < 2; ++xs) {
+            const int dxx = xs ? (px >= 2 ? 1 : -1) : 0;
+            const int qx = wrap1(patch % g.px + dxx, g.px), wxq = px - 4 * dxx + 2;
+            gi[1 + xs] = nA + (unsigned)(((sp * g.npatch + qy * g.px + qx) * 2 + s) * (WIN * WIN) + wyq * WIN + wxq);
+        }
+    }
+    const size_t half = res_adj_half(g);
+    res_gu64* outbox = (res_gu64*)ra.outbox;
+    const unsigned mineA = (unsigned)((s * g.npatch + patch) * 16 + pt);
+    const unsigned mineD = nA + (unsigned)(((s * g.npatch + patch) * 2) * (WIN * WIN) + lane);
+
+    for (int t = T; t >= 0; --t) {
+        const unsigned kdone = (unsigned)(T - t);           // what step t + 1 produced carries tag kdone, what this one produces kdone + 1
+        float aw = 0.f, gsum = 0.f;
+        if (t < T) {
+            unsigned long long gx[3];
+            if (!res_poll<3>(outbox + (size_t)(kdone & 1u) * half, gi, kdone, gx, ra, t == T - 1)) {
+                res_abort(ra, t, 2 * patch + s, lane);
+                return;
+            }
+            aw = res_value(gx[0]);
+            gsum = res_value(gx[1]) + res_value(gx[2]);
+        }
+        wave_sync();
+        if (t > 0) wnd.store(win, lane);
+        awin[lane] = aw;
+        float at = inj;
+        if (t > 0) {                                        // next step's plain operands travel under this step's arithmetic
+            inj = has_inj(t - 1) ? g_traj[(long)(t - 1) * frame + s * g.n + pidx] : 0.f;
+            if (t > 1) wnd.load(traj + (long)(t - 2) * frame, g, y0, x0, lane);
+        }
+        wave_sync();
+        if (t < T) {
+            gsum = xor_add(gsum, 16);
+            gsum = xor_add(gsum, 32);
+            const float lapT = win_star<-1>(awin, k, py, px);
+            at += awin[(py + 2) * WIN + (px + 2)] + fma_(k.dt * k.coef, lapT, gsum);
+        }
+        if (t == 0) {
+            if (grp == 0) g_h0[s * g.n + pidx] = at;
+            break;
+        }
+        res_gu64* hf = outbox + (size_t)((kdone + 1u) & 1u) * half;
+        if (grp == 0) {
+            res_put(hf + mineA, kdone + 1u, at);
+            adj[(long)t * frame + s * g.n + pidx] = at;
+        }
+
+        f4 acc[3];
+        branches(a, win, toff, grp, acc);
+        const float ga = at * k.dt;
+        float G[3][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float gw = ga * k.w4[r];
+            G[0][r] = gw * (acc[1][r] * acc[2][r]);
+            G[1][r] = gw * (acc[0][r] * acc[2][r]);
+            G[2][r] = gw * (acc[0][r] * acc[1][r]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f4 d = f4{0.f, 0.f, 0.f, 0.f};
+            const int kk_a = 16 * mt + pt;
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float w = kk_a < NTAP ? wl[(kb * HC + 4 * grp + r) * KK + kk_a] : 0.f;
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(w, G[kb][r], d, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = 16 * mt + 4 * grp + r;
+                if (kk < NTAP) dl[kk * 16 + pt] = d[r];
+            }
+        }
+        wave_sync();
+        const int wy = lane >> 3, wx = lane & 7;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float e = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 5; ++dx) {
+                    const int qy = wy - dy, qx = wx - dx;
+                    const bool ok = (unsigned)qy < 4u && (unsigned)qx < 4u;
+                    const float v = dl[(c * 25 + dy * 5 + dx) * 16 + (ok ? qy * 4 + qx : 0)];
+                    e += ok ? v : 0.f;
+                }
+            res_put(hf + mineD + (unsigned)c * (WIN * WIN), kdone + 1u, e);
+        }
+        for (int w = 0; w < ra.pause; ++w) __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 }  // namespace s1
 }  // namespace pi

@@ -6,6 +6,7 @@
 #include "../../include/percnn_pi.h"
 #include "../../include/percnn_pi_stage1.h"
 #include "pi_s1.h"
+#include "pi_host.h"
 
 namespace {
 
@@ -14,6 +15,13 @@ using pi::s1::Geom;
 struct S1Options {
     int etile = 1;      // hand the input-gradient contributions over as 8x8 footprint tiles when H, W are multiples of 4
     int skip_wgrad = 0; // diagnostics: run the adjoint sweep only (parameter gradients are returned as zeros)
+    int persist = 1;    // whole rollouts (forward: frames 1..T; sweep: t = T..0) as ONE launch of resident waves where every
+                        // (patch, species) task fits on the device at once (s1_fwd_persist_kernel / s1_adj_persist_kernel);
+                        // 0 = one launch per step.  Residency guard, handshake and abort -> fallback: pi_host.h
+    int persist_min_steps = 8;
+    int pause_fwd = 24; // s_sleep units between publishing a step's granules and asking for the neighbours' (asked for too early
+                        // they come back stale and cost a second round trip: 100^2 forward 4.45 us per step at 0, 3.4 at 24, 3.9 at 48)
+    int pause_adj = 0;  // ... of the sweep: no effect measured (0 .. 32) -- it waits for the tasks that share a SIMD anyway
 } g_s1;
 
 constexpr int MAX_GRID_X = 384;       // workgroups per species (x 2 species = 3 per CU); waves grid-stride over patches beyond that
@@ -40,6 +48,66 @@ hipError_t step_fwd(const float* h, float* out, const float* P, const Geom& g, h
 {
     hipLaunchKernelGGL(pi::s1::s1_fwd_kernel, dim3(grid_x(g), 2), dim3(64 * pi::s1::WAVES), 0, st, h, out, P, g);
     return hipGetLastError();
+}
+
+// ---- resident rollouts ---------------------------------------------------------------------------------------
+// one task per wave: every workgroup of the grid must be on the device at once
+template <typename K>
+bool resident_fits(const Geom& g, int T, K* kernel, unsigned& gx)
+{
+    if (!g_s1.persist || T < g_s1.persist_min_steps || T >= 4096 || g.H % 4 || g.W % 4) return false;
+    gx = (unsigned)((g.npatch + pi::s1::WAVES - 1) / pi::s1::WAVES);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 64 * pi::s1::WAVES, 0) != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const int cus = pi_host::resident_cu_count();
+    return cus > 0 && 2u * gx <= (unsigned)cus * (unsigned)(nb < 4 ? nb : 4);
+}
+
+pi::s1::ResArgs resident_args(const pi_host::Resident& r, unsigned nwg, int pause)
+{
+    pi::s1::ResArgs ra{};
+    ra.outbox = reinterpret_cast<unsigned long long*>(r.scratch + 256);
+    ra.sync = reinterpret_cast<unsigned*>(r.scratch);
+    ra.host = const_cast<int*>(r.hs);
+    ra.timeout_ticks = r.timeout_ticks;
+    ra.first_timeout_ticks = r.first_timeout_ticks;
+    ra.nwg = (int)nwg;
+    ra.pause = pause;
+    return ra;
+}
+
+// hipSuccess: frames 1..T are being written by one resident launch; hipErrorLaunchTimeOut: fatal; else: run the per-step path
+hipError_t rollout_fwd_resident(float* traj, const float* P, const Geom& g, int T, hipStream_t st)
+{
+    unsigned gx = 0;
+    if (!resident_fits(g, T, pi::s1::s1_fwd_persist_kernel, gx)) return hipErrorNotSupported;
+    pi_host::Resident r;
+    if (hipError_t e = pi_host::resident_begin(st, 2 * pi::s1::res_fwd_half(g) * sizeof(unsigned long long), r)) return e;
+    const pi::s1::ResArgs ra = resident_args(r, 2 * gx, g_s1.pause_fwd);
+    hipLaunchKernelGGL(pi::s1::s1_fwd_persist_kernel, dim3(gx, 2), dim3(64 * pi::s1::WAVES), 0, st, traj, T, P, g, ra);
+    if (hipError_t e = hipGetLastError()) return e;
+    return pi_host::resident_launched(st, r, 2 * gx, "the resident Stage-1 forward rollout");
+}
+
+hipError_t sweep_resident(const float* traj, const float* g_traj, const unsigned char* frame_mask, float* adj, float* g_h0,
+                          const float* P, const Geom& g, int T, hipStream_t st)
+{
+    unsigned gx = 0;
+    if (!resident_fits(g, T, pi::s1::s1_adj_persist_kernel, gx)) return hipErrorNotSupported;
+    pi_host::Resident r;
+    if (hipError_t e = pi_host::resident_begin(st, 2 * pi::s1::res_adj_half(g) * sizeof(unsigned long long), r)) return e;
+    pi::s1::ResArgs ra = resident_args(r, 2 * gx, g_s1.pause_adj);
+    if (frame_mask) {
+        ra.masked = 1;
+        for (int t = 0; t <= T; ++t)
+            if (frame_mask[t]) ra.frames[t >> 5] |= 1u << (t & 31);
+    }
+    hipLaunchKernelGGL(pi::s1::s1_adj_persist_kernel, dim3(gx, 2), dim3(64 * pi::s1::WAVES), 0, st, traj, g_traj, adj, g_h0, T, P, g, ra);
+    if (hipError_t e = hipGetLastError()) return e;
+    return pi_host::resident_launched(st, r, 2 * gx, "the resident Stage-1 adjoint sweep");
 }
 
 constexpr int WGRAD_GRID_X = 256;     // x 2 species = 2 workgroups per CU; one float row of partials each
@@ -92,6 +160,10 @@ int percnn_pi_s1_set_option(const char* key, long value)
     if (!key) return PERCNN_PI_EINVAL;
     if (!std::strcmp(key, "etile")) { g_s1.etile = value != 0; return 0; }
     if (!std::strcmp(key, "skip_wgrad")) { g_s1.skip_wgrad = value != 0; return 0; }
+    if (!std::strcmp(key, "persist")) { g_s1.persist = value != 0; return 0; }
+    if (!std::strcmp(key, "persist_min_steps") && value >= 1) { g_s1.persist_min_steps = (int)value; return 0; }
+    if (!std::strcmp(key, "pause_fwd") && value >= 0 && value <= 4096) { g_s1.pause_fwd = (int)value; return 0; }
+    if (!std::strcmp(key, "pause_adj") && value >= 0 && value <= 4096) { g_s1.pause_adj = (int)value; return 0; }
     return PERCNN_PI_EINVAL;
 }
 
@@ -106,7 +178,14 @@ int percnn_pi_s1_rollout_fwd_f32(float* traj, const float* params, const int64_t
 {
     Geom g;
     if (!traj || !params || T_steps < 0 || !make_geom(shape, g)) return PERCNN_PI_EINVAL;
+    if (int rc = pi_host::resident_async_error()) return rc;
     const size_t frame = (size_t)2 * g.n;
+    {
+        const hipError_t e = rollout_fwd_resident(traj, params, g, T_steps, static_cast<hipStream_t>(stream));
+        if (e == hipSuccess) return 0;
+        if (e == hipErrorLaunchTimeOut) return (int)e;
+        (void)hipGetLastError();                            // not eligible / not resident / aborted: launch by launch (deterministic)
+    }
     for (int t = 0; t < T_steps; ++t)
         if (hipError_t e = step_fwd(traj + t * frame, traj + (t + 1) * frame, params, g, static_cast<hipStream_t>(stream)))
             return (int)e;
@@ -133,7 +212,15 @@ int percnn_pi_s1_rollout_bwd_f32(const float* traj, const float* g_traj, const u
     const size_t frame = (size_t)2 * g.n, dsz = (size_t)2 * pi::s1::NTAP * g.n;
     auto inj = [&](int t) { return (!frame_mask || frame_mask[t]) ? g_traj + t * frame : nullptr; };
     auto D = [&](int t) { return w.D + (size_t)(t & 1) * dsz; };
-    for (int t = T_steps; t >= 0; --t) {
+    if (int rc = pi_host::resident_async_error()) return rc;
+    bool swept = false;
+    if (T_steps >= 1) {
+        const hipError_t e = sweep_resident(traj, g_traj, frame_mask, w.adj, g_h0, params, g, T_steps, st);
+        if (e == hipSuccess) swept = true;
+        else if (e == hipErrorLaunchTimeOut) return (int)e;
+        else (void)hipGetLastError();
+    }
+    for (int t = swept ? -1 : T_steps; t >= 0; --t) {
         const bool top = t == T_steps;
         hipError_t e = adj_step(t > 0 ? traj + (size_t)(t - 1) * frame : nullptr, inj(t),
                                 top ? nullptr : w.adj + (size_t)(t + 1) * frame, top ? nullptr : D(t + 1),

@@ -266,3 +266,130 @@ def test_rcnn_wrapper_drives_the_stage1_cell(dev):
         if a is not None:
             assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
 
+
+
+# ---- resident rollouts (round 5) ------------------------------------------------------------------------------------
+def _s1_problem(dev, shape, T, seed=0, family="burgers"):
+    import percnn_amd as pa
+    torch.manual_seed(seed)
+    cell = pa.Stage1Cell(family).to(dev)
+    with torch.no_grad():
+        for p in cell.parameters():
+            if p.requires_grad and p.dim() > 0:
+                p.mul_(0.5)
+        P = cell.param_block().contiguous()
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=dev)
+    traj[0] = torch.rand((2,) + shape, device=dev, generator=torch.Generator(device=dev).manual_seed(seed + 1)) * 0.5
+    return traj, P
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,T", [((100, 100), 40), ((32, 32), 9), ((64, 48), 23), ((8, 8), 12), ((128, 100), 17)])
+def test_resident_rollouts_equal_launch_per_step(shape, T, dev):
+    """s1_fwd_persist_kernel / s1_adj_persist_kernel (whole rollouts as ONE launch of resident waves, hand-over through data-tagged
+    granules): trajectory, dL/dh0 and every adjoint-dependent parameter gradient BIT for bit those of one launch per step (same
+    device functions in the same order); dense dL/dtraj and frame masks; the C oracle on the trajectory; twice in a row."""
+    from oracle import pi_oracle as O
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    pa.set_option("persist_reset", 1)
+    traj, P = _s1_problem(dev, shape, T)
+    ref = traj.clone()
+    s0 = _lib.persist_status()
+    n0 = s0["launches"]
+    try:
+        pa.stage1.set_option("persist", 0)
+        pa.stage1.rollout_fwd_(ref, P)
+        assert _lib.persist_status()["launches"] == n0
+    finally:
+        pa.stage1.set_option("persist", 1)
+    pa.stage1.rollout_fwd_(traj, P)
+    s1 = _lib.persist_status()
+    assert s1["launches"] == n0 + 1 and s1["aborts"] == s0["aborts"]
+    assert torch.isfinite(ref).all() and torch.equal(traj, ref)
+    if shape[0] * shape[1] <= 64 * 48:
+        assert np.array_equal(traj.cpu().numpy(), O.s1_rollout_fwd(traj[0].cpu().numpy(), P.cpu().numpy(), T))
+    again = traj.clone()
+    again[1:] = float("nan")
+    pa.stage1.rollout_fwd_(again, P)
+    assert torch.equal(again, ref)
+    g = torch.randn(traj.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) / traj[0].numel()
+    for mask in (None, [t % 3 != 1 for t in range(T + 1)], [t == T for t in range(T + 1)]):
+        try:
+            pa.stage1.set_option("persist", 0)
+            r0, rg = pa.stage1.rollout_bwd(traj, g, P, frame_mask=mask)
+        finally:
+            pa.stage1.set_option("persist", 1)
+        n1 = _lib.persist_status()["launches"]
+        a0, ag = pa.stage1.rollout_bwd(traj, g, P, frame_mask=mask)
+        assert _lib.persist_status()["launches"] == n1 + 1 and _lib.persist_status()["aborts"] == s1["aborts"]
+        assert torch.isfinite(a0).all() and torch.equal(a0, r0)
+        assert torch.equal(ag, rg)                          # the weight-gradient kernel reads the same adjoint frames
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_resident_rollouts_keep_to_their_shapes(dev):
+    """ragged grids (H or W not a multiple of 4), short rollouts and grids with more tasks than the device holds at once keep
+    one launch per step -- and give the same results as ever."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    pa.set_option("persist_reset", 1)
+    for shape, T in (((30, 32), 12), ((32, 32), 5), ((512, 512), 9)):
+        traj, P = _s1_problem(dev, shape, T)
+        n0 = _lib.persist_status()["launches"]
+        pa.stage1.rollout_fwd_(traj, P)
+        g = torch.randn(traj.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) / traj[0].numel()
+        g0, pg = pa.stage1.rollout_bwd(traj, g, P)
+        assert _lib.persist_status()["launches"] == n0, (shape, T)
+        assert torch.isfinite(traj).all() and torch.isfinite(g0).all() and torch.isfinite(pg).all()
+
+
+@pytest.mark.gpu
+def test_resident_rollouts_abort_and_fall_back(dev):
+    """CUs held by another kernel: not every task of the resident launch is on the device, the waves that are give up at their
+    first hand-over (persist_first_timeout_ms), and the SAME call recomputes launch by launch -- bit-identical results; the
+    device keeps the launch-per-step path until persist_reset (state shared with the 2D resident kernels)."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    from test_safety_gpu import _hog
+    pa.set_option("persist_reset", 1)
+    shape, T = (100, 100), 24
+    traj, P = _s1_problem(dev, shape, T)
+    ref = traj.clone()
+    pa.stage1.rollout_fwd_(ref, P)
+    g = torch.randn(traj.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) / traj[0].numel()
+    r0, rg = pa.stage1.rollout_bwd(ref, g, P)
+    torch.cuda.synchronize()
+    assert not _lib.persist_status()["disabled_on_current_device"]
+    pa.set_option("persist_first_timeout_ms", 20)
+    try:
+        for which in ("forward", "sweep"):
+            _hog(216, 150 * 1024, 1500, dev)                # 40 free CUs: < 314 workgroups of 12 / 26 KB
+            s1 = _lib.persist_status()
+            if which == "forward":
+                out = traj.clone()
+                out[1:] = float("nan")
+                pa.stage1.rollout_fwd_(out, P)
+                torch.cuda.synchronize()
+                assert torch.equal(out, ref)
+            else:
+                a0, ag = pa.stage1.rollout_bwd(ref, g, P)
+                torch.cuda.synchronize()
+                assert torch.equal(a0, r0) and torch.equal(ag, rg)
+            s2 = _lib.persist_status()
+            assert s2["launches"] == s1["launches"] + 1 and s2["aborts"] == s1["aborts"] + 1 and s2["disabled_on_current_device"]
+            n = s2["launches"]
+            again = traj.clone()
+            pa.stage1.rollout_fwd_(again, P)                # disabled: launch per step, no new resident launch
+            assert _lib.persist_status()["launches"] == n and torch.equal(again, ref)
+            torch.cuda.synchronize()
+            pa.set_option("persist_reset", 1)
+    finally:
+        torch.cuda.synchronize()
+        pa.set_option("persist_first_timeout_ms", 100)
+        pa.set_option("persist_reset", 1)
+    out = traj.clone()
+    n = _lib.persist_status()["launches"]
+    pa.stage1.rollout_fwd_(out, P)
+    assert _lib.persist_status()["launches"] == n + 1 and torch.equal(out, ref)
