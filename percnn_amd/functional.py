@@ -816,6 +816,13 @@ class Frame(torch.Tensor):
     _pi_index: int = -1
     _pi_stacked: Optional[torch.Tensor] = None
 
+    # copies and pickles are plain tensors: a copy is no view of the trajectory buffer, and the link must not drag 2 GiB along
+    def __deepcopy__(self, memo):
+        return self.as_subclass(torch.Tensor).__deepcopy__(memo)
+
+    def __reduce_ex__(self, proto):
+        return self.as_subclass(torch.Tensor).__reduce_ex__(proto)
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}

@@ -660,3 +660,14 @@ def test_frames_make_the_callers_cat_a_view():
     assert type(fr[1] * 2) is torch.Tensor and type(fr[1].clone()) is torch.Tensor and type(fr[1][0]) is torch.Tensor
     assert fr[3].detach().numpy().shape == (1, 2, 3, 4) and float(fr[1].sum()) == float(st[1].sum())
     assert type(torch.stack(tuple(fr))) is torch.Tensor and torch.stack(tuple(fr)).shape == (6, 1, 2, 3, 4)
+    # copies and pickles are plain tensors (a copy is no view of the buffer; the link must not drag the trajectory along)
+    import copy, io, pickle
+    c = copy.deepcopy(fr[1])
+    assert type(c) is torch.Tensor and c.data_ptr() != fr[1].data_ptr() and torch.equal(c, st[1:2])
+    assert all(type(t) is torch.Tensor for t in copy.deepcopy(fr)) and type(copy.copy(fr[1])) is torch.Tensor
+    buf_io = io.BytesIO()
+    torch.save(fr[2], buf_io)
+    buf_io.seek(0)
+    back = torch.load(buf_io)
+    assert type(back) is torch.Tensor and torch.equal(back, st[2:3]) and buf_io.getbuffer().nbytes < 4096
+    assert type(pickle.loads(pickle.dumps(fr[3]))) is torch.Tensor
