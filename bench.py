@@ -353,6 +353,13 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
         loss = ((pred - 0.5) ** 2).mean()
         torch.autograd.grad(loss, params + [h0])
 
+    def it_list_strided():                               # the reference's own lines, unchanged (train_2drd.py:393-401)
+        outs, _ = model()
+        output = torch.cat(tuple(outs), dim=0)
+        pred = output[0:-1:20, :, ::4, ::4]
+        loss = ((pred - 0.5) ** 2).mean()
+        torch.autograd.grad(loss, params + [h0])
+
     def it_loss_mse():
         loss = model.loss_mse()                          # mean(traj^2) inside the rollout's autograd node
         torch.autograd.grad(loss, params + [h0])
@@ -361,7 +368,8 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
     for key, fn in (("list_cat_dense_loss_ms", it_list), ("list_copying_cat_dense_loss_ms", it_list_copy),
                     ("list_stacked_dense_loss_ms", it_stacked),
                     ("trajectory_dense_loss_ms", it_traj),
-                    ("loss_mse_dense_ms", it_loss_mse), ("observe_strided_loss_ms", it_observe)):
+                    ("loss_mse_dense_ms", it_loss_mse), ("list_cat_strided_loss_ms", it_list_strided),
+                    ("observe_strided_loss_ms", it_observe)):
         fn()
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
         torch.cuda.synchronize()
@@ -379,7 +387,8 @@ def module_path_extra(pa, family, sd, shape, T, dev, reaction, reps=3):
     out["what"] = (f"one training iteration through the drop-in modules at {'x'.join(map(str, shape))} x T={T}: RCNN.forward() "
                    "+ torch.cat(tuple(outputs), dim=0) (the reference's own line: since round 5 it returns the trajectory buffer, functional.Frame) + mean(traj^2) + backward; the same with the stock copying cat (frames as plain tensors); the same with outputs.stacked in place of the cat; RCNN.trajectory() (torch.ops.percnn.pi_rollout, no list / cat) + the same loss; "
                    "RCNN.loss_mse() = the same dense loss as ONE autograd node with the rollout (gradient formed inside the sweep); "
-                   "RCNN.observe(0:-1:20, ::4) + MSE + backward "
+                   "the reference's unchanged strided data loss torch.cat(tuple(output))[0:-1:20, :, ::4, ::4] + MSE + backward (autograd hands the sweep a dense, mostly zero dL/dtraj); "
+                   "RCNN.observe(0:-1:20, ::4) + MSE + backward (the same loss with the caller edit of INTEGRATION.md 1: masked sweep, no dL/dtraj buffer) "
                    "(forward, loss, full backward incl. parameter gradients; wall = host clock around the same loop)")
     return out
 
