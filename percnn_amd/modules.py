@@ -876,11 +876,11 @@ class RCNN(nn.Module):
             frames.append(self.step - 1)                    # second_last_state rides along as one more output
         stacked = None
         if hasattr(self.cell, "rollout_frames"):            # cells with their own kernels (Stage-1 block)
-            outs = self.cell.rollout_frames(self.init_state, self.step, frames)
+            outs = self.cell.rollout_frames(self.init_state, self.step, frames, with_stacked=True)
         else:
             outs = F_pi.pi_rollout_frames(self.init_state, self._block(), self.step, frames, with_stacked=True)
-            outs, stacked = outs[:-1], outs[-1]
-            F_pi.link_frames(outs[:n_out], stacked)         # torch.cat(tuple(outputs), dim=0) -> a view of `stacked`, no copy
+        outs, stacked = outs[:-1], outs[-1]
+        F_pi.link_frames(outs[:n_out], stacked)             # torch.cat(tuple(outputs), dim=0) -> a view of `stacked`, no copy
         outputs = FrameList(outs[:n_out])
         if stacked is not None and n_out == self.step + 1:
             outputs.stacked = stacked                       # dense effective_step: == torch.cat(tuple(outputs), dim=0), no copy

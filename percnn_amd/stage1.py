@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .functional import _require, _stream, check_star_stencil, _assemble_frame_grads, _observe, _scatter_observed
+from .functional import _require, _stream, check_star_stencil, _assemble_frame_grads, _observe, _scatter_observed, Frame
 
 NP = 16 + 6 * 16 * 52 + 32 + 2          # PERCNN_PI_S1_PARAMS
 _OFF_W, _OFF_W4, _OFF_B4 = 16, 16 + 4992, 16 + 4992 + 32
@@ -162,15 +162,30 @@ class Stage1RolloutFramesFunction(torch.autograd.Function):
         rollout_fwd_(traj, P)
         ctx.save_for_backward(traj, P)
         ctx.frames = tuple(int(k) for k in frames)
+        ctx.set_materialize_grads(False)
         views = traj.unsqueeze(1).unbind(0)                 # all [1,2,*S] frame views in one call
-        return tuple(views[k] for k in ctx.frames)
+        outs = []
+        for k in ctx.frames:                                # functional.Frame: the caller's torch.cat(tuple(output)) is a view
+            f = views[k].as_subclass(Frame)
+            f._pi_index = k
+            outs.append(f)
+        return tuple(outs) + (traj.view(traj.shape),)       # last output: the trajectory itself (bur1:607's torch.cat, no copy)
 
     @staticmethod
     def backward(ctx, *grads):
         traj, P = ctx.saved_tensors
-        if all(g is None for g in grads):
+        g_stacked, grads = grads[-1], grads[:-1]
+        if g_stacked is None and all(g is None for g in grads):
             return None, None, None, None
-        g_traj, mask = _assemble_frame_grads(grads, ctx.frames, traj)
+        if g_stacked is not None and all(g is None for g in grads):
+            g_traj, mask = g_stacked.contiguous(), None
+        elif g_stacked is None:
+            g_traj, mask = _assemble_frame_grads(grads, ctx.frames, traj)
+        else:
+            g_traj, mask = g_stacked.clone(), None
+            for k, g in zip(ctx.frames, grads):
+                if g is not None:
+                    g_traj[k].add_(g[0])
         g_h0, pg = rollout_bwd(traj, g_traj, P, frame_mask=mask)
         return g_h0[None], pg.to(torch.float32), None, None
 
@@ -273,9 +288,11 @@ class Stage1Cell(nn.Module):
         """hook used by ``percnn_amd.RCNN.observe``: -> (observed sub-tensor, detached full trajectory)"""
         return Stage1RolloutObserveFunction.apply(h0, self.param_block(), int(steps), tuple(t_idx), tuple(strides))
 
-    def rollout_frames(self, h0: torch.Tensor, steps: int, frames: Sequence[int]):
-        """hook used by ``percnn_amd.RCNN``: the requested frames as outputs of one autograd node"""
-        return Stage1RolloutFramesFunction.apply(h0, self.param_block(), int(steps), tuple(frames))
+    def rollout_frames(self, h0: torch.Tensor, steps: int, frames: Sequence[int], with_stacked: bool = False):
+        """hook used by ``percnn_amd.RCNN``: the requested frames as outputs of one autograd node (with_stacked: plus, last, the
+        [steps+1,2,H,W] trajectory they are views of)"""
+        out = Stage1RolloutFramesFunction.apply(h0, self.param_block(), int(steps), tuple(frames))
+        return out if with_stacked else out[:-1]
 
     def forward(self, h: torch.Tensor):
         ch = self.rollout(h, 1)[1:2]

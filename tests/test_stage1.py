@@ -247,6 +247,9 @@ def test_rcnn_wrapper_drives_the_stage1_cell(dev):
     assert len(outs) == steps + 1 and outs[0].shape == (1, 2, 24, 24)
     traj = m.trajectory()
     assert torch.equal(torch.cat(tuple(outs), 0), traj) and torch.equal(sl, traj[steps - 1:steps])
+    # round 5: the reference's own torch.cat(tuple(output), dim=0) (bur1:607) returns the trajectory buffer, no copy
+    assert torch.cat(tuple(outs), dim=0) is outs.stacked and outs.stacked.data_ptr() == outs[0].data_ptr()
+    assert torch.cat(tuple(f.as_subclass(torch.Tensor) for f in outs), 0).data_ptr() != outs.stacked.data_ptr()
     w = torch.randn_like(traj)
     params = [p for p in m.parameters() if p.requires_grad]          # W_laplace is frozen
     g1 = torch.autograd.grad((torch.cat(tuple(outs), 0) * w).sum() + (sl ** 2).sum(), params, allow_unused=True)
