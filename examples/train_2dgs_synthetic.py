@@ -27,6 +27,9 @@ def main(argv=None):
     ap.add_argument("--size", type=int, default=100)          # the reference trains on 100 x 100 (train_2drd.py:331)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--lr", type=float, default=2e-4)
+    ap.add_argument("--reference-lines", action="store_true",
+                    help="build the data-loss operand with the reference's own lines (train_2drd.py:393-397: model(), torch.cat, strided "
+                         "slice) instead of RCNN.observe(): since round 5 that torch.cat returns the trajectory buffer (functional.Frame)")
     a = ap.parse_args(argv)
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -58,13 +61,18 @@ def main(argv=None):
             torch.cuda.synchronize()
             t0, n0 = time.perf_counter(), it
         opt.zero_grad()
-        pred = model.observe(slice(0, -1, 20), 4)                            # == torch.cat(outputs)[0:-1:20, :, ::4, ::4]
+        if a.reference_lines:
+            output, second_last_state = model()                              # train_2drd.py:393-397, verbatim
+            output = torch.cat(tuple(output), dim=0)
+            pred = output[0:-1:20, :, ::4, ::4]
+        else:
+            pred = model.observe(slice(0, -1, 20), 4)                        # the same operand from ONE autograd node (masked sweep)
         idx = int(pred.shape[0] * 0.9)
         loss_data = F.mse_loss(pred[:idx], gt[:idx])
         loss_val = F.mse_loss(pred[idx:], gt[idx:])
         loss_ic = F.mse_loss(model.UpconvBlock(low), ic_target)
         with torch.no_grad():                                                # monitoring only, as in the reference
-            loss_phy = physics.physics_loss(model.last_trajectory, Q)
+            loss_phy = physics.physics_loss(output.detach() if a.reference_lines else model.last_trajectory, Q)
         loss = 40 * loss_data + 0.25 * loss_ic
         loss.backward()
         opt.step()

@@ -2131,6 +2131,9 @@ def test_reference_style_training_loop_example(hip_device):
     spec.loader.exec_module(mod)
     losses = mod.main(["--iters", "12", "--size", "48", "--steps", "60"])
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    # the same iteration with the reference's own lines for the data-loss operand (model(); torch.cat; strided slice): same losses
+    ref_lines = mod.main(["--iters", "12", "--size", "48", "--steps", "60", "--reference-lines"])
+    assert np.allclose(ref_lines, losses, rtol=1e-4, atol=0)
 
 
 def test_c_abi_from_a_plain_cpp_host(hip_device, tmp_path):
