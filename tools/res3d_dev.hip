@@ -1,0 +1,219 @@
+// res3d_dev.hip -- development harness for the RESIDENT 3D rollouts (round 6, percnn_amd/csrc/pi_res3d.h): the one-launch forward
+// (and reverse sweep) against a naive launch-per-step kernel of the same operation order -- whole trajectory compared bit for bit,
+// interleaved timing, device timeline of a step (-DPI_R3D_STAMPS=<workgroup>).  Not part of the product; build here, run on the box:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tools/scratch/res3d_dev tools/res3d_dev.hip
+//   ./tools/scratch/res3d_dev [N=128] [T=500] [reps=5] [pause=0]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+
+#include "../percnn_amd/csrc/pi_res3d.h"
+#ifndef R3D_NT
+#define R3D_NT 512
+#endif
+#define R3D_NT_ R3D_NT
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); std::exit(1); } } while (0)
+
+namespace {
+struct Rng {
+    unsigned long long s = 0x9E3779B97F4A7C15ull;
+    float uni() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (float)((s >> 40) & 0xFFFFFF) / 16777216.0f; }
+};
+
+// naive reference: one point per lane, operands from global memory, pi::star's operation order
+__global__ void __launch_bounds__(256) ref_fwd(const float* __restrict__ h, float* __restrict__ out, const float* __restrict__ P, int n0, int n1, int n2)
+{
+    using namespace pi;
+    const long n = (long)n0 * n1 * n2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % n2), y = (int)((i / n2) % n1), z = (int)(i / ((long)n1 * n2));
+    float c[2], lap[2];
+    for (int s = 0; s < 2; ++s) {
+        const float* f = h + s * n;
+        auto at = [&](int zz, int yy, int xx) { return f[((long)((zz + n0) % n0) * n1 + (yy + n1) % n1) * n2 + (xx + n2) % n2]; };
+        c[s] = at(z, y, x);
+        float l = P[P_C0] * c[s];
+        for (int t = 0; t < 4; ++t) { const int k = t < 2 ? t - 2 : t - 1; l = fma_(P[P_TAPS + t], at(z + k, y, x), l); }
+        for (int t = 0; t < 4; ++t) { const int k = t < 2 ? t - 2 : t - 1; l = fma_(P[P_TAPS + 4 + t], at(z, y + k, x), l); }
+        for (int t = 0; t < 4; ++t) { const int k = t < 2 ? t - 2 : t - 1; l = fma_(P[P_TAPS + 8 + t], at(z, y, x + k), l); }
+        lap[s] = l;
+    }
+    const float dt = P[P_DT];
+    for (int s = 0; s < 2; ++s) {
+        const float rr = poly_r(P + P_W + 10 * s, c[0], c[1]);
+        const float res = P[P_COEF + s] * lap[s] + rr;
+        const float inc = res * dt;
+        out[s * n + i] = c[s] + inc;
+    }
+}
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    using namespace pi::r3d;
+    const int N = argc > 1 ? std::atoi(argv[1]) : 128;
+    const int T = argc > 2 ? std::atoi(argv[2]) : 500;
+    const int reps = argc > 3 ? std::atoi(argv[3]) : 5;
+    const int pause = argc > 4 ? std::atoi(argv[4]) : 0;
+    const int n0 = N, n1 = N, n2 = N;
+    const size_t npts = (size_t)n0 * n1 * n2, frame = 2 * npts;
+    std::vector<float> hP(36, 0.0f);
+    Rng r;
+    hP[0] = 0.05f; hP[1] = 0.02f; hP[2] = 0.01f; hP[3] = -7.5f;
+    const float taps[4] = {-1.0f / 12, 4.0f / 3, 4.0f / 3, -1.0f / 12};
+    for (int a = 0; a < 3; ++a) for (int i = 0; i < 4; ++i) hP[4 + 4 * a + i] = taps[i] + 0.01f * (r.uni() - 0.5f);
+    for (int i = 16; i < 36; ++i) hP[i] = 0.05f * (r.uni() - 0.5f);
+    std::vector<float> h0(frame);
+    for (auto& x : h0) x = r.uni();
+    float *dP, *dA, *dB;
+    CK(hipMalloc(&dP, 36 * sizeof(float)));
+    CK(hipMalloc(&dA, (size_t)(T + 1) * frame * sizeof(float)));
+    CK(hipMalloc(&dB, (size_t)(T + 1) * frame * sizeof(float)));
+    CK(hipMemcpy(dP, hP.data(), 36 * sizeof(float), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dA, h0.data(), frame * sizeof(float), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, h0.data(), frame * sizeof(float), hipMemcpyHostToDevice));
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+
+    Args a{};
+    a.n0 = n0; a.n1 = n1; a.n2 = n2;
+    a.gz = n0 / BZ; a.gy = n1 / BY; a.gx = n2 / BX;
+    a.ss = (long)npts; a.frame_stride = (long)frame;
+    a.rz = a.ry = a.rx = 1;
+    if (const char* e = std::getenv("R3D_REGIONS")) std::sscanf(e, "%d,%d,%d", &a.rz, &a.ry, &a.rx);
+    if (const char* e = std::getenv("R3D_SKIP")) a.skip = std::atoi(e);
+    const int nwg = a.gz * a.gy * a.gx;
+    const size_t obytes = (size_t)2 * nwg * Shape<R3D_NT_>::BOX_BYTES;
+    void* outbox;
+    unsigned* sync;
+    unsigned long long* stamps;
+    CK(hipMalloc(&outbox, obytes));
+    CK(hipMalloc(&sync, 64));
+    CK(hipMalloc(&stamps, 64 * sizeof(unsigned long long)));
+    CK(hipMemset(stamps, 0, 64 * sizeof(unsigned long long)));
+    a.outbox = outbox; a.sync = sync; a.host = nullptr;
+    a.nsteps = T; a.pause = pause;
+    a.timeout_ticks = 2000000ull; a.first_timeout_ticks = 2000000ull;      // 20 ms
+#ifndef R3D_NT
+#define R3D_NT 512
+#endif
+    constexpr int NT = R3D_NT;
+    constexpr int BOX_BYTES = Shape<NT>::BOX_BYTES;
+    const size_t lds = LDS_BYTES;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(pi_fwd3d_resident_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, pi_fwd3d_resident_kernel<NT>, NT, lds));
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    std::printf("regions %d x %d x %d; skip %d; ", a.rz, a.ry, a.rx, a.skip);
+    std::printf("grid %d^3, %d workgroups of %d lanes, LDS %zu B, occupancy %d per CU x %d CUs, outbox %.1f MB\n", N, nwg, NT, lds, occ, prop.multiProcessorCount, obytes / 1e6);
+    if (occ * prop.multiProcessorCount < nwg) { std::printf("does not fit\n"); return 1; }
+
+    // reference trajectory
+    for (int t = 0; t < T; ++t)
+        hipLaunchKernelGGL(ref_fwd, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, dA + (size_t)t * frame, dA + (size_t)(t + 1) * frame, dP, n0, n1, n2);
+    CK(hipStreamSynchronize(st));
+
+    auto run = [&]() {
+        CK(hipMemsetAsync(outbox, 0, obytes, st));
+        CK(hipMemsetAsync(sync, 0, 64, st));
+        hipLaunchKernelGGL(pi_fwd3d_resident_kernel<NT>, dim3(nwg), dim3(NT), lds, st, dB, dP, a, stamps);
+    };
+    run();
+    CK(hipStreamSynchronize(st));
+    unsigned hs[4];
+    CK(hipMemcpy(hs, sync, sizeof hs, hipMemcpyDeviceToHost));
+    std::printf("sync: started %u abort %u timeouts %u\n", hs[0], hs[1], hs[2]);
+    // compare
+    {
+        std::vector<float> A(frame), B(frame);
+        size_t bad_total = 0;
+        int first_bad = -1;
+        for (int t = 1; t <= T; t += (t < 8 ? 1 : std::max(1, T / 16))) {
+            CK(hipMemcpy(A.data(), dA + (size_t)t * frame, frame * sizeof(float), hipMemcpyDeviceToHost));
+            CK(hipMemcpy(B.data(), dB + (size_t)t * frame, frame * sizeof(float), hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (size_t i = 0; i < frame; ++i) bad += std::memcmp(&A[i], &B[i], 4) != 0;
+            if (bad && first_bad < 0) {
+                first_bad = t;
+                {   // where inside a block do the differences sit?
+                    std::vector<size_t> hz(BZ, 0), hy(BY, 0), hx(BX, 0);
+                    for (size_t i = 0; i < frame; ++i)
+                        if (std::memcmp(&A[i], &B[i], 4) != 0) {
+                            const size_t p = i % npts;
+                            ++hz[(p / ((size_t)n1 * n2)) % BZ]; ++hy[((p / n2) % n1) % BY]; ++hx[(p % n2) % BX];
+                        }
+                    std::printf("  %zu differences in frame %d; by local z:", bad, t);
+                    for (auto c : hz) std::printf(" %zu", c);
+                    std::printf("\n  by local y:");
+                    for (auto c : hy) std::printf(" %zu", c);
+                    std::printf("\n  by local x:");
+                    for (auto c : hx) std::printf(" %zu", c);
+                    std::printf("\n");
+                }
+                int shown = 0;
+                for (size_t i = 0; i < frame && shown < 8; ++i)
+                    if (std::memcmp(&A[i], &B[i], 4) != 0) {
+                        const size_t p = i % npts;
+                        std::printf("  frame %d s %zu z %zu y %zu x %zu: ref %.9g got %.9g\n", t, i / npts, p / ((size_t)n1 * n2), (p / n2) % n1, p % n2, A[i], B[i]);
+                        ++shown;
+                    }
+            }
+            bad_total += bad;
+        }
+        {   // last frame always
+            CK(hipMemcpy(A.data(), dA + (size_t)T * frame, frame * sizeof(float), hipMemcpyDeviceToHost));
+            CK(hipMemcpy(B.data(), dB + (size_t)T * frame, frame * sizeof(float), hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            double nrm = 0;
+            for (size_t i = 0; i < frame; ++i) { bad += std::memcmp(&A[i], &B[i], 4) != 0; nrm += (double)A[i] * A[i]; }
+            std::printf("last frame: %zu differing values, |ref|^2 = %.6g\n", bad, nrm);
+            bad_total += bad;
+        }
+        std::printf("bitwise: %s (first bad frame %d)\n", bad_total ? "DIFFERENT" : "identical", first_bad);
+    }
+    // timing
+    std::vector<float> ms;
+    for (int i = 0; i < reps; ++i) {
+        CK(hipMemsetAsync(outbox, 0, obytes, st));
+        CK(hipMemsetAsync(sync, 0, 64, st));
+        CK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(pi_fwd3d_resident_kernel<NT>, dim3(nwg), dim3(NT), lds, st, dB, dP, a, stamps);
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float m;
+        CK(hipEventElapsedTime(&m, e0, e1));
+        ms.push_back(m);
+    }
+    std::sort(ms.begin(), ms.end());
+    std::printf("resident forward: median %.3f ms = %.3f us per step (min %.3f); frame bytes per step %.1f MB -> %.2f TB/s of stores\n", ms[ms.size() / 2],
+                1e3 * ms[ms.size() / 2] / T, 1e3 * ms[0] / T, frame * 4 / 1e6, frame * 4 / (1e9 * ms[ms.size() / 2] / T));
+    ms.clear();
+    for (int i = 0; i < std::min(reps, 3); ++i) {
+        CK(hipEventRecord(e0, st));
+        for (int t = 0; t < T; ++t)
+            hipLaunchKernelGGL(ref_fwd, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, dA + (size_t)t * frame, dA + (size_t)(t + 1) * frame, dP, n0, n1, n2);
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float m;
+        CK(hipEventElapsedTime(&m, e0, e1));
+        ms.push_back(m);
+    }
+    std::sort(ms.begin(), ms.end());
+    std::printf("naive launch per step: %.3f us per step\n", 1e3 * ms[ms.size() / 2] / T);
+#ifdef PI_R3D_STAMPS
+    unsigned long long hst[16];
+    CK(hipMemcpy(hst, stamps, sizeof hst, hipMemcpyDeviceToHost));
+    std::printf("timeline of step 20, workgroup %d (us from its start): S strips %.2f | barrier %.2f | published %.2f | I strips %.2f | barrier %.2f | written back %.2f | ring landed + unpacked %.2f\n",
+                PI_R3D_STAMPS, (hst[1] - hst[0]) / 100.0, (hst[2] - hst[0]) / 100.0, (hst[3] - hst[0]) / 100.0, (hst[4] - hst[0]) / 100.0, (hst[5] - hst[0]) / 100.0, (hst[6] - hst[0]) / 100.0, (hst[7] - hst[0]) / 100.0);
+#endif
+    return 0;
+}
