@@ -62,7 +62,7 @@ template <int NT> struct Shape {
     static constexpr int NQ = (2560 + NT - 1) / NT;                     // granule stores / loads per lane and hand-over
     static constexpr int NMASK = NW * NQ * 2;                           // mask granule (wave, q, point) = F_MASK + (wave * NQ + q) * 2 + point
     static constexpr int BOX_GRAN = 2560 + NMASK, BOX_BYTES = BOX_GRAN * 16;
-    static_assert(NT == 512 || NT == 1024, "two or four waves per SIMD");
+    static_assert(NT == 256 || NT == 512 || NT == 1024, "one, two or four waves per SIMD");
 };
 // a block's outbox per parity: six face buffers of 16-byte granules (two x-adjacent points each), then the mask granules.
 // z faces [2 planes][BY][BX / 2], y faces [BZ][2 rows][BX / 2], x faces [BZ][BY] (the two columns of a face are one granule)
@@ -70,7 +70,7 @@ constexpr int GZ = 2 * BY * BX / 2, GY = 2 * BZ * BX / 2, GX = BZ * BY;
 constexpr int F_ZLO = 0, F_ZHI = GZ, F_YLO = 2 * GZ, F_YHI = 2 * GZ + GY, F_XLO = 2 * GZ + 2 * GY, F_XHI = F_XLO + GX;
 constexpr int NGRAN = 2 * GZ + 2 * GY + 2 * GX;                         // 2560 data granules
 constexpr int F_MASK = NGRAN;
-constexpr int LDS_BYTES = STG0 + NGRAN * 16 + 64;                       // 156240 of the CU's 163840
+constexpr int LDS_BYTES = STG0 + NGRAN * 16 + 64 + 16 * 22 * 8;           // 159056 of the CU's 163840 (abort word, the adjoint's sums)
 static_assert(NGRAN == 2560 && GZ % WAVE == 0 && GX % WAVE == 0, "the lane map of the hand-over assumes these face sizes");
 // granule g of a box (0 <= g < NGRAN) -> face, granule inside the face
 __device__ __forceinline__ int face_of(int g) { return g < F_YLO ? g / GZ : (g < F_XLO ? 2 + (g - F_YLO) / GY : 4 + (g - F_XLO) / GX); }
@@ -522,6 +522,317 @@ pi_fwd3d_resident_kernel(float* __restrict__ frames, const float* __restrict__ P
             }
             return;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// REVERSE SWEEP, resident: the adjoint state G lives in the LDS window for the whole sweep; a step reads only its pointwise
+// operands from memory (the state h_{t-1} and, where that frame carries a gradient, dL/dtraj[t-1]: 16 + 16 instead of the brick
+// sweep's 48 + 16 bytes per point and step), always one step ahead of their use, and nothing is written until dL/dh0.
+// Arithmetic = pi_adj3d_brick_kernel's (pre-contracted float32 block, fused moments): the adjoint state is bit-identical, the 22
+// sums differ in summation order only.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct AdjArgs {
+    const float* traj;             // state trajectory; frame f at traj + f * frame_stride
+    const float* gtraj;            // dL/dtraj, same layout (only frames whose bit is set in `frames` are read)
+    const float* gtop;             // the adjoint state the sweep starts from: dL/dh_{t_top} (a whole frame)
+    float* gout;                   // dL/dh_{t_top - nsteps}
+    double* partials;              // [blocks][np] partial rows, added to
+    int np, t_top;
+    unsigned frames[128];          // bit f: frame f carries a gradient (f < 4096)
+};
+
+typedef float av2 __attribute__((ext_vector_type(2)));
+struct AdjOps { v4f u, v; };
+
+__device__ __forceinline__ void adj_load(AdjOps& o, const float* hfr, long ss, unsigned go)
+{
+    o.u = *(const gv4f*)((const gchar*)hfr + go);
+    o.v = *(const gv4f*)((const gchar*)(hfr + ss) + go);
+}
+
+// one strip of one adjoint step: Gp = G + coef * (dt * LapT(G)) + dt * J_react(h)^T G (+ inj); pi_adj3d_brick_kernel's order
+// `jfr` (nullable, wave-uniform): the frame of dL/dtraj this step injects; its strip is requested at the top and used at the bottom
+__device__ __forceinline__ void adj_strip(const unsigned char* smem, unsigned lo, const float* __restrict__ P, const AdjOps& o,
+                                          const float* jfr, long ss, unsigned go, v4f& ou, v4f& ov, float (&mom)[2][10], double (&lane_c)[2])
+{
+    v4f ju, jv;
+    if (jfr) {
+        ju = *(const gv4f*)((const gchar*)jfr + go);
+        jv = *(const gv4f*)((const gchar*)(jfr + ss) + go);
+    }
+    v4f gc[2], dl[2];
+    const float dt = P[P_DT];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const unsigned char* b = smem + s * SP + lo;
+        gc[s] = lds4(b);
+        v4f l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l[i] = P[P_C0] * gc[s][i];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = -(t < 2 ? t - 2 : t - 1);                      // the transposed stencil: taps at mirrored offsets
+            const v4f nb = lds4(b + k * ZS);
+            const float w = P[P_TAPS + t];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) l[i] = fma_(w, nb[i], l[i]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = -(t < 2 ? t - 2 : t - 1);
+            const v4f nb = lds4(b + k * YS);
+            const float w = P[P_TAPS + 4 + t];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) l[i] = fma_(w, nb[i], l[i]);
+        }
+        const v2f xl = lds2(b - 8), xr = lds2(b + 16);
+        const float win[8] = {xl[0], xl[1], gc[s][0], gc[s][1], gc[s][2], gc[s][3], xr[0], xr[1]};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = -(t < 2 ? t - 2 : t - 1);
+            const float w = P[P_TAPS + 8 + t];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) l[i] = fma_(w, win[2 + i + k], l[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dl[s][i] = l[i] * dt;
+    }
+    v4f du = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float* c = P + P_W + 10 * s;
+        const v4f& hs = s == 0 ? o.u : o.v;
+        double acc_c = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float gr = gc[s][i] * dt;
+            acc_c += (double)(dl[s][i] * hs[i]);
+            float ru, rv;
+            poly_dr(c, o.u[i], o.v[i], ru, rv);
+            du[i] = fma_(gr, ru, du[i]);
+            dv[i] = fma_(gr, rv, dv[i]);
+        }
+        lane_c[s] += acc_c;
+    }
+    // the 20 coefficient moments: one float32 sum per lane and moment (pairs would issue half the instructions and hold twice the
+    // registers: with them the sweep spilled 64 registers per lane to scratch -- 22.5 us per step)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float uu = o.u[i], vv = o.v[i];
+        const float u2 = uu * uu, uv = uu * vv, v2 = vv * vv;
+        const float u3 = u2 * uu, u2v = u2 * vv, uv2 = uu * v2, v3 = v2 * vv;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float gr = gc[s][i] * dt;
+            float (&acc)[10] = mom[s];
+            acc[0] += gr;
+            acc[1] = fma_(gr, uu, acc[1]); acc[2] = fma_(gr, vv, acc[2]);
+            acc[3] = fma_(gr, u2, acc[3]); acc[4] = fma_(gr, uv, acc[4]); acc[5] = fma_(gr, v2, acc[5]);
+            acc[6] = fma_(gr, u3, acc[6]); acc[7] = fma_(gr, u2v, acc[7]); acc[8] = fma_(gr, uv2, acc[8]); acc[9] = fma_(gr, v3, acc[9]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float tu = P[P_COEF + 0] * dl[0][i] + du[i];
+        const float tv = P[P_COEF + 1] * dl[1][i] + dv[i];
+        ou[i] = gc[0][i] + tu;
+        ov[i] = gc[1][i] + tv;
+    }
+    if (jfr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ou[i] += ju[i]; ov[i] += jv[i]; }
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT, 1)
+pi_adj3d_resident_kernel(const float* __restrict__ P, Args a, AdjArgs aa, unsigned long long* stamps)
+{
+    using S = Shape<NT>;
+    constexpr int SLOTS = S::SLOTS, NW = S::NW, BOX_BYTES = S::BOX_BYTES;
+    constexpr int WS = NS / WAVE;
+    constexpr int FOLD = 8;                                             // steps between folds of the float32 moment sums into doubles
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* smem = smem_raw + 8;
+    int* wg_abort = reinterpret_cast<int*>(smem + STG0 + NGRAN * 16);
+    double* msum = reinterpret_cast<double*>(smem + STG0 + NGRAN * 16 + 56);    // [NW][20] doubles (8-byte aligned: smem is 8 mod 16)
+    const int tid = (int)threadIdx.x, lane = tid % WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    const int nblk = a.gz * a.gy * a.gx;
+    const int b = (int)blockIdx.x;
+    int bx, by, bz;
+    const unsigned local = locate_block(a, b, bz, by, bx);
+    const unsigned skipf = ((a.skip & 1) ? local : 0u) | ((a.skip & 2) ? (~local & 63u) : 0u);
+    const int me = (bz * a.gy + by) * a.gx + bx;
+    if (tid == 0) {
+        *wg_abort = 0;
+        const unsigned n = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (n == (unsigned)nblk && a.host) __hip_atomic_store(a.host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (lane < 20) msum[wave * 20 + lane] = 0.0;
+    const int half_bytes = nblk * BOX_BYTES;
+    const __amdgpu_buffer_rsrc_t box = __builtin_amdgcn_make_buffer_rsrc(a.outbox, 0, 2 * half_bytes, 0x00020000);
+
+    // per strip only its packed coordinates are kept; LDS address and frame offset are a few integer operations each time (the
+    // sweep holds 32 outputs, 40 moment sums, 32 operands in flight and 24 words of landing ring per lane: registers are what it lacks)
+    unsigned tk[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const Task t = task_of<NT>(s, tid);
+        tk[s] = (unsigned)t.z | (unsigned)t.y << 8 | (unsigned)t.xs << 16;
+    }
+    const unsigned gbase = (unsigned)((((bz * BZ) * a.n1 + by * BY) * a.n2 + bx * BX) * 4);
+    auto task = [&](int s) { return Task{(int)(tk[s] & 255u), (int)(tk[s] >> 8 & 255u), (int)(tk[s] >> 16)}; };
+    auto lo_of = [&](int s) { return lds_of(task(s)); };
+    auto go_of = [&](int s) { const Task t = task(s); return gbase + (unsigned)(((t.z * a.n1 + t.y) * a.n2 + 4 * t.xs) * 4); };
+    Ring<NT> R;
+    ring_setup<NT>(R, a, bz, by, bx, local);
+
+    auto has = [&](int f) { return ((aa.frames[f >> 5] >> (f & 31)) & 1u) != 0u; };
+    // operands of the first step: requested before the window is filled
+    // (a ring of two: strip s reads ops[s & 1] and, done, asks for the operands of the strip two further on -- all four strips'
+    // operands a whole step ahead cost 64 registers and the kernel 396 bytes of scratch)
+    static_assert(SLOTS % 2 == 0, "the operand ring alternates two buffers");
+    AdjOps ops[2];
+    {
+        const int f = aa.t_top - 1;
+        const float* hfr = aa.traj + (long)f * a.frame_stride;
+        adj_load(ops[0], hfr, a.ss, go_of(0));
+        adj_load(ops[1], hfr, a.ss, go_of(1));
+    }
+    // the window of the top frame's adjoint state: own block and halo straight from memory
+    for (int i = tid; i < 2 * (BZ + 4) * (BY + 4) * (BX + 4); i += NT) {
+        const int x = i % (BX + 4), y = (i / (BX + 4)) % (BY + 4), z = (i / ((BX + 4) * (BY + 4))) % (BZ + 4), s = i / ((BX + 4) * (BY + 4) * (BZ + 4));
+        const int g0 = (bz * BZ + z - 2 + a.n0) % a.n0, g1 = (by * BY + y - 2 + a.n1) % a.n1, g2 = (bx * BX + x - 2 + a.n2) % a.n2;
+        const float v = aa.gtop[s * a.ss + ((long)g0 * a.n1 + g1) * a.n2 + g2];
+        *reinterpret_cast<float*>(smem + s * SP + z * ZS + y * YS + OWN0 - 8 + 4 * x) = v;
+    }
+    __syncthreads();
+
+    float mom[2][10];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int m = 0; m < 10; ++m) mom[s][m] = 0.f;
+    double lane_c[2] = {0.0, 0.0};
+    auto fold = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int m = 0; m < 10; ++m) {
+                const float tot = wave_sum_to_last(mom[s][m]);
+                if (lane == REDUCE_LANE) msum[wave * 20 + 10 * s + m] += (double)tot;
+                mom[s][m] = 0.f;
+            }
+    };
+
+    Landing<NT> L;
+    bool failed = false;
+    for (int k = 0; k < a.nsteps; ++k) {
+        const int t = k;                                                 // (the stamps' name for the step)
+        const unsigned ep = (unsigned)k + 1u;
+        const bool more = k + 1 < a.nsteps, ring = more && !(a.skip & 4);
+        const int f = aa.t_top - 1 - k;                                 // this step: G_{f + 1} -> G_f with the operands of frame f
+        const bool inj = has(f);
+        const float* hcu = aa.traj + (long)f * a.frame_stride;
+        const float* jcu = inj ? aa.gtraj + (long)f * a.frame_stride : nullptr;
+        const float* hnx = more ? aa.traj + (long)(f - 1) * a.frame_stride : nullptr;
+        auto next_ops = [&](int s) {                                    // strip s is done: its buffer takes the state of strip s + 2
+            if (s + 2 < SLOTS) adj_load(ops[s & 1], hcu, a.ss, go_of(s + 2));
+            else if (more) adj_load(ops[s & 1], hnx, a.ss, go_of(s + 2 - SLOTS));
+        };
+        v4f ou[SLOTS], ov[SLOTS];
+        R3D_STAMP(0);
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (s * NW + wave < WS) {
+                adj_strip(smem, lo_of(s), P, ops[s & 1], jcu, a.ss, go_of(s), ou[s], ov[s], mom, lane_c);
+                next_ops(s);
+                __builtin_amdgcn_sched_barrier(0);                      // one strip at a time: interleaved strips spill
+                stage_strip(smem, task(s), ou[s], ov[s]);
+            }
+        R3D_STAMP(1);
+        lds_barrier();
+        R3D_STAMP(2);
+        if (ring) {
+            const __amdgpu_buffer_rsrc_t mine = __builtin_amdgcn_make_buffer_rsrc(
+                static_cast<char*>(a.outbox) + ((size_t)(ep & 1u) * (size_t)half_bytes + (size_t)me * BOX_BYTES), 0, BOX_BYTES, 0x00020000);
+            publish<NT>(smem, R, mine, ep, skipf);
+        }
+        R3D_STAMP(3);
+        bool asked = !ring;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (s * NW + wave >= WS) {
+                adj_strip(smem, lo_of(s), P, ops[s & 1], jcu, a.ss, go_of(s), ou[s], ov[s], mom, lane_c);
+                next_ops(s);
+                __builtin_amdgcn_sched_barrier(0);                      // one strip at a time: interleaved strips spill
+            }
+        R3D_STAMP(4);
+        if (!asked) {                                                   // (after the strips: the landing ring is 24 registers the strips need)
+            for (int i = 0; i < a.pause; ++i) __builtin_amdgcn_s_sleep(1);
+            request<NT>(L, R, box, (int)(ep & 1u) * half_bytes, skipf);
+        }
+        if ((k % FOLD) == FOLD - 1 || !more) fold();
+        lds_barrier();
+        R3D_STAMP(5);
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            *reinterpret_cast<v4f*>(smem + lo_of(s)) = ou[s];
+            *reinterpret_cast<v4f*>(smem + SP + lo_of(s)) = ov[s];
+        }
+        if (!more) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                *(gv4f*)((gchar*)aa.gout + go_of(s)) = ou[s];
+                *(gv4f*)((gchar*)(aa.gout + a.ss) + go_of(s)) = ov[s];
+            }
+            break;
+        }
+        R3D_STAMP(6);
+        if (ring) {
+            const int rd = (int)(ep & 1u) * half_bytes;
+            const unsigned long long t0 = ticks();
+            const unsigned long long bound = k == 0 ? a.first_timeout_ticks : a.timeout_ticks;
+            while (!landed<NT>(L, R, box, rd, ep, skipf)) {
+                if (ticks() - t0 > bound || __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { failed = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (failed) {
+                if (tid % WAVE == 0) *wg_abort = 1;
+            } else {
+                unpack<NT>(smem, L, R, skipf);
+            }
+        }
+        R3D_STAMP(7);
+        lds_barrier();
+        if (*wg_abort) {
+            // ABORT: neither dL/dh0 nor a partial row is written; the host runs the launch-per-step sweep instead
+            if (tid == 0) {
+                __hip_atomic_fetch_add(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_exchange(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && a.host) {
+                    __hip_atomic_store(a.host + 1, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(a.host + 2, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(a.host + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            return;
+        }
+    }
+    // ---- once per sweep: the 22 sums of this block into its partial row ----
+    double* csum = msum + NW * 20;                                      // [NW][2]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const double r = wave_sum_to_last(lane_c[s]);
+        if (lane == REDUCE_LANE) csum[wave * 2 + s] = r;
+    }
+    __syncthreads();
+    if (tid < 22) {
+        double tot = 0.0;
+        for (int w = 0; w < NW; ++w) tot += tid < 2 ? csum[w * 2 + tid] : msum[w * 20 + tid - 2];
+        const int slot = tid < 2 ? P_COEF + tid : P_W + tid - 2;
+        aa.partials[(long)b * aa.np + slot] += tot;
     }
 }
 

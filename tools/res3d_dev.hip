@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <algorithm>
 #include <vector>
 
@@ -51,6 +52,46 @@ __global__ void __launch_bounds__(256) ref_fwd(const float* __restrict__ h, floa
         const float inc = res * dt;
         out[s * n + i] = c[s] + inc;
     }
+}
+
+// naive reference of one adjoint step (pi_adj3d_brick_kernel's operation order), sums by double atomics
+__global__ void __launch_bounds__(256) ref_adj(const float* __restrict__ h, const float* __restrict__ G, const float* __restrict__ inj,
+                                               float* __restrict__ Gp, double* __restrict__ sums, const float* __restrict__ P, int n0, int n1, int n2)
+{
+    using namespace pi;
+    const long n = (long)n0 * n1 * n2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % n2), y = (int)((i / n2) % n1), z = (int)(i / ((long)n1 * n2));
+    const float dt = P[P_DT];
+    float gc[2], dl[2];
+    for (int s = 0; s < 2; ++s) {
+        const float* f = G + s * n;
+        auto at = [&](int zz, int yy, int xx) { return f[((long)((zz + n0) % n0) * n1 + (yy + n1) % n1) * n2 + (xx + n2) % n2]; };
+        gc[s] = at(z, y, x);
+        float l = P[P_C0] * gc[s];
+        for (int t = 0; t < 4; ++t) { const int k = -(t < 2 ? t - 2 : t - 1); l = fma_(P[P_TAPS + t], at(z + k, y, x), l); }
+        for (int t = 0; t < 4; ++t) { const int k = -(t < 2 ? t - 2 : t - 1); l = fma_(P[P_TAPS + 4 + t], at(z, y + k, x), l); }
+        for (int t = 0; t < 4; ++t) { const int k = -(t < 2 ? t - 2 : t - 1); l = fma_(P[P_TAPS + 8 + t], at(z, y, x + k), l); }
+        dl[s] = l * dt;
+    }
+    const float u = h[i], v = h[n + i];
+    float du = 0.f, dv = 0.f;
+    for (int s = 0; s < 2; ++s) {
+        const float gr = gc[s] * dt;
+        float ru, rv;
+        poly_dr(P + P_W + 10 * s, u, v, ru, rv);
+        du = fma_(gr, ru, du);
+        dv = fma_(gr, rv, dv);
+        atomicAdd(&sums[s], (double)(dl[s] * (s ? v : u)));
+        const double g = gr, U = u, V = v;
+        const double ph[10] = {1, U, V, U * U, U * V, V * V, U * U * U, U * U * V, U * V * V, V * V * V};
+        for (int m = 0; m < 10; ++m) atomicAdd(&sums[2 + 10 * s + m], g * ph[m]);
+    }
+    const float tu = P[P_COEF + 0] * dl[0] + du, tv = P[P_COEF + 1] * dl[1] + dv;
+    float ou = gc[0] + tu, ov = gc[1] + tv;
+    if (inj) { ou += inj[i]; ov += inj[n + i]; }
+    Gp[i] = ou; Gp[n + i] = ov;
 }
 }  // namespace
 
@@ -215,5 +256,85 @@ int main(int argc, char** argv)
     std::printf("timeline of step 20, workgroup %d (us from its start): S strips %.2f | barrier %.2f | published %.2f | I strips %.2f | barrier %.2f | written back %.2f | ring landed + unpacked %.2f\n",
                 PI_R3D_STAMPS, (hst[1] - hst[0]) / 100.0, (hst[2] - hst[0]) / 100.0, (hst[3] - hst[0]) / 100.0, (hst[4] - hst[0]) / 100.0, (hst[5] - hst[0]) / 100.0, (hst[6] - hst[0]) / 100.0, (hst[7] - hst[0]) / 100.0);
 #endif
+    if (std::getenv("R3D_ADJ")) {
+        // ---- reverse sweep: dA = the reference trajectory, dL/dtraj = a fixed multiple of it with every third frame left out ----
+        const int TA = std::min(T, std::getenv("R3D_TADJ") ? std::atoi(std::getenv("R3D_TADJ")) : T);
+        float *dG, *dG0, *dG1, *dR0;
+        double *dSums, *dPart;
+        CK(hipMalloc(&dG, (size_t)(TA + 1) * frame * sizeof(float)));
+        CK(hipMalloc(&dG0, frame * sizeof(float))); CK(hipMalloc(&dG1, frame * sizeof(float))); CK(hipMalloc(&dR0, frame * sizeof(float)));
+        CK(hipMalloc(&dSums, 22 * sizeof(double))); CK(hipMalloc(&dPart, (size_t)nwg * 36 * sizeof(double)));
+        {
+            std::vector<float> g(frame);
+            Rng r2; r2.s = 12345;
+            for (int t = 0; t <= TA; ++t) {
+                for (auto& x : g) x = 1e-3f * (r2.uni() - 0.5f);
+                CK(hipMemcpy(dG + (size_t)t * frame, g.data(), frame * sizeof(float), hipMemcpyHostToDevice));
+            }
+        }
+        AdjArgs aa{};
+        aa.traj = dA; aa.gtraj = dG; aa.gtop = dG + (size_t)TA * frame; aa.gout = dR0; aa.partials = dPart; aa.np = 36; aa.t_top = TA;
+        for (int f = 0; f < TA; ++f) if (f % 3 != 1) aa.frames[f >> 5] |= 1u << (f & 31);
+        // reference: launch per step, ping-pong
+        CK(hipMemset(dSums, 0, 22 * sizeof(double)));
+        {
+            const float* gin = dG + (size_t)TA * frame;
+            float* pp[2] = {dG0, dG1};
+            for (int t = TA; t >= 1; --t) {
+                const int f = t - 1;
+                const bool h = (aa.frames[f >> 5] >> (f & 31)) & 1u;
+                float* dst = pp[t & 1];
+                hipLaunchKernelGGL(ref_adj, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, dA + (size_t)f * frame, gin, h ? dG + (size_t)f * frame : nullptr, dst, dSums, dP, n0, n1, n2);
+                gin = dst;
+            }
+            CK(hipStreamSynchronize(st));
+            Args b2 = a;
+            b2.nsteps = TA;
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(pi_adj3d_resident_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            std::vector<float> msv;
+            for (int i = 0; i < reps + 1; ++i) {
+                CK(hipMemsetAsync(outbox, 0, obytes, st));
+                CK(hipMemsetAsync(sync, 0, 64, st));
+                CK(hipMemsetAsync(dPart, 0, (size_t)nwg * 36 * sizeof(double), st));
+                CK(hipEventRecord(e0, st));
+                hipLaunchKernelGGL(pi_adj3d_resident_kernel<NT>, dim3(nwg), dim3(NT), lds, st, dP, b2, aa, stamps);
+                CK(hipEventRecord(e1, st));
+                CK(hipStreamSynchronize(st));
+                float m;
+                CK(hipEventElapsedTime(&m, e0, e1));
+                if (i) msv.push_back(m);
+            }
+            CK(hipMemcpy(hs, sync, sizeof hs, hipMemcpyDeviceToHost));
+            std::printf("adjoint sync: started %u abort %u timeouts %u\n", hs[0], hs[1], hs[2]);
+            std::vector<float> A(frame), B(frame);
+            CK(hipMemcpy(A.data(), gin, frame * sizeof(float), hipMemcpyDeviceToHost));
+            CK(hipMemcpy(B.data(), dR0, frame * sizeof(float), hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            double nrm = 0;
+            for (size_t i = 0; i < frame; ++i) { bad += std::memcmp(&A[i], &B[i], 4) != 0; nrm += (double)A[i] * A[i]; }
+            std::printf("adjoint dL/dh0 (T = %d): %zu differing values, |ref|^2 = %.6g -> %s\n", TA, bad, nrm, bad ? "DIFFERENT" : "identical");
+            std::vector<double> hsum(22), part((size_t)nwg * 36);
+            CK(hipMemcpy(hsum.data(), dSums, 22 * sizeof(double), hipMemcpyDeviceToHost));
+            CK(hipMemcpy(part.data(), dPart, part.size() * sizeof(double), hipMemcpyDeviceToHost));
+            double worst = 0;
+            for (int k = 0; k < 22; ++k) {
+                const int slot = k < 2 ? 1 + k : 16 + k - 2;
+                double tot = 0;
+                for (int w = 0; w < nwg; ++w) tot += part[(size_t)w * 36 + slot];
+                const double rel = std::fabs(tot - hsum[k]) / (std::fabs(hsum[k]) + 1e-30);
+                worst = std::max(worst, rel);
+                if (k < 4 || rel > 1e-4) std::printf("  sum %2d: ref %.9e got %.9e rel %.2e\n", k, hsum[k], tot, rel);
+            }
+            std::printf("adjoint sums: worst relative difference %.2e\n", worst);
+            std::sort(msv.begin(), msv.end());
+            std::printf("resident adjoint: median %.3f ms = %.3f us per step (min %.3f)\n", msv[msv.size() / 2], 1e3 * msv[msv.size() / 2] / TA, 1e3 * msv[0] / TA);
+#ifdef PI_R3D_STAMPS
+            unsigned long long hst2[16];
+            CK(hipMemcpy(hst2, stamps, sizeof hst2, hipMemcpyDeviceToHost));
+            std::printf("adjoint timeline of step 20: S strips %.2f | barrier %.2f | published %.2f | I strips %.2f | barrier %.2f | written back %.2f | ring landed + unpacked %.2f\n",
+                        (hst2[1] - hst2[0]) / 100.0, (hst2[2] - hst2[0]) / 100.0, (hst2[3] - hst2[0]) / 100.0, (hst2[4] - hst2[0]) / 100.0, (hst2[5] - hst2[0]) / 100.0, (hst2[6] - hst2[0]) / 100.0, (hst2[7] - hst2[0]) / 100.0);
+#endif
+        }
+    }
     return 0;
 }
