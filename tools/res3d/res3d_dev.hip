@@ -1,7 +1,7 @@
 // res3d_dev.hip -- development harness for the RESIDENT 3D rollouts (round 6, percnn_amd/csrc/pi_res3d.h): the one-launch forward
 // (and reverse sweep) against a naive launch-per-step kernel of the same operation order -- whole trajectory compared bit for bit,
 // interleaved timing, device timeline of a step (-DPI_R3D_STAMPS=<workgroup>).  Not part of the product; build here, run on the box:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tools/scratch/res3d_dev tools/res3d_dev.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tools/scratch/res3d_dev tools/res3d/res3d_dev.hip
 //   ./tools/scratch/res3d_dev [N=128] [T=500] [reps=5] [pause=0]
 #include <hip/hip_runtime.h>
 
@@ -12,7 +12,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "../percnn_amd/csrc/pi_res3d.h"
+#include "pi_res3d.h"
 #ifndef R3D_NT
 #define R3D_NT 512
 #endif
