@@ -129,14 +129,28 @@ hipError_t allow_lds(F* f, size_t bytes)
     return hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-// One side stream + a small event ring per device for sweep || reduction overlap (created lazily, never destroyed;
-// fork/join through events only -- no host synchronisation).
+// One side stream + a small event ring per host thread and device for sweep || reduction overlap (created lazily, released when
+// the thread ends: applications that churn worker threads do not accumulate streams; fork/join through events only -- no host
+// synchronisation).
 struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     hipEvent_t done = nullptr;
     int next = 0;
     bool ok = false;
+    SideStream() = default;
+    SideStream(const SideStream&) = delete;
+    SideStream& operator=(const SideStream&) = delete;
+    ~SideStream()
+    {
+        // (thread-local destructors of the main thread run inside exit() before the runtime's own teardown; errors are ignored --
+        // work still queued on the stream completes, hipStreamDestroy only releases the handle)
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
+        if (done) (void)hipEventDestroy(done);
+        if (stream) (void)hipStreamDestroy(stream);
+        (void)hipGetLastError();
+    }
 };
 SideStream* side_stream()
 {
@@ -666,7 +680,7 @@ int brick_nt_for(const Problem& p, int vec, bool adjoint = true)
     return (p.opt.brick_nt == 512 && p.hc == 0 && p.loss.mode == 0) ? 512 : 256;
 }
 
-pi::BrickGeom make_brick_geom(const Problem& p, int vec, int rz, int nt = pi::BRICK_NT, bool adjoint = true)
+pi::BrickGeom make_brick_geom(const Problem& p, int vec, int rz, int nt = pi::BRICK_NT, bool adjoint = true, bool faces_first = false)
 {
     const Geom g = make_geom(p);
     pi::BrickGeom b;
@@ -708,6 +722,10 @@ pi::BrickGeom make_brick_geom(const Problem& p, int vec, int rz, int nt = pi::BR
             if (p.opt.brick_xny > 1 && ny != p.opt.brick_xny) continue;
             const int nz = pi::NXCD / ny;
             if (npg % nz || b.nrg % ny) continue;
+            // a launch with a fused peer put attached sends BOTH faces: Brick::locate computes them first only when the planes are
+            // split between at least two regions (its upper half walks top-down); strips of 1/8 of the rows (nz = 1) would store the
+            // top face last and expose that put behind the whole launch
+            if (faces_first && nz < 2 && p.opt.brick_xny <= 1) continue;
             const double planes = (double)(npg / nz) * rz, rows = (double)(b.nrg / ny) * rows_per_brick;
             const double share = 4.0 / planes + 4.0 / rows;
             const bool fits = footprint(rows) <= L2_KEEP;
@@ -754,7 +772,7 @@ template <typename T, int HC, int RZ, int NT = pi::BRICK_NT>
 hipError_t launch_brick_fwd(const T* h, T* out, const T* P, const Problem& p, hipStream_t st, const FusedPut* fp = nullptr)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
-    pi::BrickGeom b = make_brick_geom(p, VEC, RZ, NT, false);
+    pi::BrickGeom b = make_brick_geom(p, VEC, RZ, NT, false, fp != nullptr);
     if (b.n0 <= 0) return hipSuccess;
     const size_t lds = (size_t)2 * RZ * pi::brick_wb(NT) + (size_t)p.opt.lds_pad;
     const pi::PeerPutFused put = fused_put_args<RZ>(fp, p, b);
@@ -820,7 +838,7 @@ hipError_t launch_brick_bwd(const T* h, const T* G, const T* inj, T* Gp, double*
                             hipStream_t st, const FusedPut* fp = nullptr)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
-    pi::BrickGeom b = make_brick_geom(p, VEC, RZ, NT);
+    pi::BrickGeom b = make_brick_geom(p, VEC, RZ, NT, true, fp != nullptr);
     if (b.n0 <= 0) return hipSuccess;
     const unsigned grid = brick_bwd_grid(p, VEC, RZ);
     const size_t head = (size_t)(NT / pi::WAVE) * 2 * sizeof(double);
@@ -1681,9 +1699,16 @@ hipError_t launch_fwd_persist_small_t(T* frame_t0, int ngroups, const T* P, cons
     auto* k = pi::pi_fwd2d_persist_small_kernel<T, K, TILE_B, BY, NT>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, NT, lds) != hipSuccess || nb < 1 ||
-            (int64_t)grid > (int64_t)device_cu_count() * nb) { (void)hipGetLastError(); return hipErrorCooperativeLaunchTooLarge; }
+        static int blocks_per_cu[16] = {};                  // per device (per tile height / value type: a template), asked once
+        int dv = 0;
+        if (hipGetDevice(&dv) != hipSuccess || dv < 0 || dv >= 16) { (void)hipGetLastError(); return hipErrorCooperativeLaunchTooLarge; }
+        if (!blocks_per_cu[dv]) {
+            int q = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k, NT, lds) != hipSuccess || q < 1) { (void)hipGetLastError(); q = -1; }
+            blocks_per_cu[dv] = q;
+        }
+        const int nb = blocks_per_cu[dv];
+        if (nb < 1 || (int64_t)grid > (int64_t)device_cu_count() * nb) return hipErrorCooperativeLaunchTooLarge;
     }
     // per-device scratch (shared with the 32 x 32 resident forward): 256 B of sync words | granule outbox: 2 parities x tiles x 2 x 32 x BY
     const size_t outbox_bytes = (size_t)2 * grid * (2 * TILE_B * BY) * sizeof(unsigned long long);
@@ -3045,7 +3070,6 @@ hipError_t resident_begin(void* stream, size_t outbox_bytes, Resident& r)
         r.scratch = static_cast<unsigned char*>(g_persist.fwd_scratch[r.dev]);
         r.slot = g_persist.next_slot++ % PERSIST_SLOTS;
         g_persist.watch[r.slot] = false;
-        ++g_persist.launches;
     }
     if (hipError_t e = hipMemsetAsync(r.scratch, 0, need, st)) return e;
     r.hs = g_persist.host->slot[r.slot];
@@ -3063,6 +3087,7 @@ hipError_t resident_launched(void* stream, Resident& r, unsigned grid, const cha
     {
         std::lock_guard<std::mutex> lk(g_persist.mu);
         g_persist.watch[r.slot] = true;
+        ++g_persist.launches;                               // (counted here: the caller's launch has been enqueued without error)
     }
     hipError_t e = hipSuccess;
     if (handshake) e = persist_wait_roll_call(r.hs, r.slot, r.dev, grid, what);

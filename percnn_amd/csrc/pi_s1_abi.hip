@@ -57,11 +57,21 @@ bool resident_fits(const Geom& g, int T, K* kernel, unsigned& gx)
 {
     if (!g_s1.persist || T < g_s1.persist_min_steps || T >= 4096 || g.H % 4 || g.W % 4) return false;
     gx = (unsigned)((g.npatch + pi::s1::WAVES - 1) / pi::s1::WAVES);
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 64 * pi::s1::WAVES, 0) != hipSuccess || nb < 1) {
-        (void)hipGetLastError();
-        return false;
+    // workgroups of this kernel one CU holds: asked once per device and kernel (a template instance per kernel; benign race, same
+    // value) -- these calls exist to take microseconds of host time off a rollout
+    static int blocks_per_cu[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return false; }
+    if (!blocks_per_cu[dev]) {
+        int q = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kernel, 64 * pi::s1::WAVES, 0) != hipSuccess || q < 1) {
+            (void)hipGetLastError();
+            q = -1;
+        }
+        blocks_per_cu[dev] = q;
     }
+    const int nb = blocks_per_cu[dev];
+    if (nb < 1) return false;
     const int cus = pi_host::resident_cu_count();
     return cus > 0 && 2u * gx <= (unsigned)cus * (unsigned)(nb < 4 ? nb : 4);
 }

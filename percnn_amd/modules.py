@@ -10,6 +10,7 @@ from __future__ import annotations
 
 from typing import Optional, Sequence
 
+import os
 import numpy as np
 import torch
 import torch.nn as nn
@@ -771,10 +772,15 @@ class RCNN(nn.Module):
 
     def __init__(self, cell: RCNNCell, step: int = 1, effective_step: Sequence[int] = (1,),
                  init_state: Optional[torch.Tensor] = None, upscaler: Optional[nn.Module] = None,
-                 init_state_low: Optional[torch.Tensor] = None, cell_name: str = "crnn_cell"):
+                 init_state_low: Optional[torch.Tensor] = None, cell_name: str = "crnn_cell",
+                 cat_view: Optional[bool] = None):
         super().__init__()
         if (init_state is None) == (upscaler is None):
             raise ValueError("give either init_state or upscaler+init_state_low")
+        # cat_view: may ``torch.cat(tuple(outputs), dim=0)`` return the trajectory buffer itself (no copy; the SAME tensor on every
+        # call, an alias of every frame -- INTEGRATION.md 1)?  False / PERCNN_CAT_VIEW=0: the stock copying cat, for callers that
+        # edit the cat result in place.  ``outputs.stacked`` is there either way.
+        self.cat_view = (os.environ.get("PERCNN_CAT_VIEW", "1") not in ("0", "")) if cat_view is None else bool(cat_view)
         self.step = step
         self.effective_step = list(effective_step)
         self.cell_name = cell_name
@@ -880,7 +886,8 @@ class RCNN(nn.Module):
         else:
             outs = F_pi.pi_rollout_frames(self.init_state, self._block(), self.step, frames, with_stacked=True)
         outs, stacked = outs[:-1], outs[-1]
-        F_pi.link_frames(outs[:n_out], stacked)             # torch.cat(tuple(outputs), dim=0) -> a view of `stacked`, no copy
+        if self.cat_view:
+            F_pi.link_frames(outs[:n_out], stacked)         # torch.cat(tuple(outputs), dim=0) -> a view of `stacked`, no copy
         outputs = FrameList(outs[:n_out])
         if stacked is not None and n_out == self.step + 1:
             outputs.stacked = stacked                       # dense effective_step: == torch.cat(tuple(outputs), dim=0), no copy

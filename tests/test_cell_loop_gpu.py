@@ -222,6 +222,19 @@ def test_stacked_attribute_of_the_frame_list_equals_cat(kind, shape, T):
     sparse, _ = pa.RCNN(cell, step=T, effective_step=[0, 2, 5], init_state=h0)()
     gs_ref = flat(torch.autograd.grad((copying_cat(sparse) ** 2).mean(), params + [h0]))
     assert rel_l2(gs.cpu().numpy(), gs_ref.cpu().numpy()) < 1e-6
+    # the opt-out for callers that edit the cat result in place -- cat_view=False: the stock copying cat, a fresh tensor
+    # that may be written to while gradients are recorded (the linked view raises autograd's in-place error there)
+    plain = pa.RCNN(cell, step=T, effective_step=list(range(T)), init_state=h0, cat_view=False)
+    outs, _ = plain()
+    c1, c2 = torch.cat(tuple(outs), dim=0), torch.cat(tuple(outs), dim=0)
+    assert c1 is not outs.stacked and c1.data_ptr() != outs.stacked.data_ptr() and c1.data_ptr() != c2.data_ptr()
+    c1[0] = 0.0                                           # in place on the copy: fine
+    edited = flat(torch.autograd.grad((c1 ** 2).mean(), params + [h0]))
+    outs, _ = model()
+    z = copying_cat(outs)
+    z[0] = 0.0
+    edited_ref = flat(torch.autograd.grad((z ** 2).mean(), params + [h0]))
+    assert rel_l2(edited.cpu().numpy(), edited_ref.cpu().numpy()) < 1e-6
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
