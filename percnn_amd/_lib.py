@@ -18,7 +18,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 _INC = os.path.join("..", "..", "include")
 # translation unit -> headers it depends on (all under csrc/ unless a path is given)
 SOURCES = {
-    "pi_abi.hip": ["pi_kernels.h", "pi_tile2d.h", "pi_stream3d.h", "pi_brick3d.h", "pi_adv.h", "pi_contract.h", "pi_peer.h", "pi_device.h", "pi_host.h", os.path.join(_INC, "percnn_pi.h")],
+    "pi_abi.hip": ["pi_kernels.h", "pi_tile2d.h", "pi_stream3d.h", "pi_brick3d.h", "pi_res3d.h", "pi_adv.h", "pi_contract.h", "pi_peer.h", "pi_device.h", "pi_host.h", os.path.join(_INC, "percnn_pi.h")],
     "pi_s1_abi.hip": ["pi_s1.h", "pi_device.h", "pi_host.h", os.path.join(_INC, "percnn_pi.h"), os.path.join(_INC, "percnn_pi_stage1.h")],
     "pi_up3d_abi.hip": ["pi_up3d.h", "pi_device.h", os.path.join(_INC, "percnn_pi.h")],
 }

@@ -16,6 +16,7 @@
 #include "pi_tile2d.h"
 #include "pi_stream3d.h"
 #include "pi_brick3d.h"
+#include "pi_res3d.h"
 #include "pi_contract.h"
 #include "pi_peer.h"
 #include "pi_adv.h"
@@ -100,6 +101,10 @@ struct Options {
                             // -1 = the pre-round-2 rule (next power of two >= chunks per row)
     int brick3d = 1;        // 3D: brick kernels (pi_brick3d.h) for one-step launches where the shape allows: 0 never, 1 by
                             // size (brick_ok), 2 whenever eligible
+    int res3d = 1;          // 3D float32 pre-contracted blocks: the whole reverse sweep of a rollout as ONE launch of resident
+                            // workgroups with the adjoint state in LDS (pi_res3d.h; round 6): 0 never, 1 where it measured faster than
+                            // the brick sweep (whole 16 x 16 x 32 blocks, at least 3/4 of the CUs busy: 128^3 and its neighbours), 2 on
+                            // every grid of whole blocks that fits the device (tests)
     int brick_rz = 0;       // planes per brick (1, 2, 4; 0 = by size)
     int brick_xcd = 1;      // brick kernels: XCD regions split in y as well as in z where the counts divide (BrickGeom::xny):
                             // 0 never, 1 where it measured no worse (make_brick_geom), 2 always
@@ -1200,7 +1205,8 @@ int device_cu_count()
 
 bool persist_disabled_here();
 constexpr int PERSIST_BAND = 2 * (TILE_B * TILE_B - (TILE_B - 16) * (TILE_B - 16));     // granules per tile and parity (K = 4)
-size_t persist_outbox_bytes(const Problem& p, int elem = 4)     // 8-byte granules (float32), 16-byte ones (float64 forward)
+size_t persist_outbox_bytes(const Problem& p, int elem = 4)     // per band value: 8 bytes (float32: 16-byte granules of two values -- or the
+                                                                // 8-byte words of the unsplit sweep), 16 bytes (float64: one value per granule)
 {
     return (size_t)2 * (size_t)((p.n0 / TILE_B) * (p.W / TILE_B)) * PERSIST_BAND * (elem == 8 ? 16 : 8);
 }
@@ -1312,6 +1318,85 @@ void persist_leave(hipStream_t st, int dev)
     std::lock_guard<std::mutex> lk(g_persist.mu);
     if (!g_persist.ev[dev] && hipEventCreateWithFlags(&g_persist.ev[dev], hipEventDisableTiming) != hipSuccess) return;
     if (hipEventRecord(g_persist.ev[dev], st) == hipSuccess) { g_persist.st[dev] = st; g_persist.armed[dev] = true; }
+}
+
+// ---- RESIDENT 3D reverse sweep (pi_res3d.h, round 6) ------------------------------------------------------------------
+// The whole sweep of a float32 pre-contracted 3D rollout as one launch: one resident workgroup per 16 x 16 x 32 block keeps the
+// adjoint state in LDS, reads only h_{t-1} and the injected dL/dtraj_{t-1} per step, hands its two-deep faces to the six
+// neighbours as data-tagged granules and carries the 22 gradient sums; only dL/dh0 and one partial row per block are written.
+// Same-box A/B at 128^3 (profiles/r06_resident3d_ab.txt): 16.4 us per step against the brick sweep's 19.0; dL/dh0 bit-identical.
+struct Res3dPlan { int gz, gy, gx, rz, ry, rx, nblk; };
+bool res3d_plan(const Problem& p, int nsteps, size_t elem, Res3dPlan& pl)
+{
+    using namespace pi::r3d;
+    if (elem != 4 || p.ndim != 3 || p.hc != 0 || p.slab || p.loss.mode != 0 || !p.opt.res3d || !p.opt.tile_persist) return false;
+    if (nsteps < 16 || nsteps >= 4096) return false;                     // (the frame bitset of AdjArgs; short sweeps: bricks)
+    if (persist_disabled_here()) return false;                           // a resident launch aborted on this device (persist_reset re-arms)
+    if (p.n0 % BZ || p.n1 % BY || p.W % BX || p.n > (int64_t(1) << 28)) return false;
+    pl.gz = (int)(p.n0 / BZ); pl.gy = (int)(p.n1 / BY); pl.gx = (int)(p.W / BX);
+    pl.nblk = pl.gz * pl.gy * pl.gx;
+    if (pl.gz < 2 || pl.gy < 2 || pl.gx < 2) return false;              // (a block that is its own neighbour: never exercised)
+    const int cus = device_cu_count();
+    if (cus <= 0 || pl.nblk > cus) return false;
+    if (p.opt.res3d == 1 && pl.nblk * 4 < cus * 3) return false;         // too few CUs busy: the brick sweep wins
+    // XCD regions (workgroup b runs on XCD b % 8 and takes a block of region b % 8): the split of 8 = rz * ry * rx that divides
+    // the block counts with the fewest faces between regions; none divides: linear order, every face written through
+    pl.rz = pl.ry = pl.rx = 1;
+    long best = -1;
+    for (int rz : {1, 2, 4, 8})
+        for (int ry : {1, 2, 4, 8}) {
+            if (rz * ry > 8) continue;
+            const int rx = 8 / (rz * ry);
+            if (pl.gz % rz || pl.gy % ry || pl.gx % rx) continue;
+            const long dz = pl.gz / rz, dy = pl.gy / ry, dx = pl.gx / rx;
+            // face area (in points) a region exposes per axis it is cut along
+            const long cut = (rz > 1 ? dy * dx * BY * BX : 0) + (ry > 1 ? dz * dx * BZ * BX : 0) + (rx > 1 ? dz * dy * BZ * BY : 0);
+            if (best < 0 || cut < best) { best = cut; pl.rz = rz; pl.ry = ry; pl.rx = rx; }
+        }
+    return true;
+}
+
+// hipSuccess: the sweep t_top -> 0 has been enqueued (dL/dh0 and nblk partial rows); hipErrorLaunchFailure: it ran and aborted
+// (nothing it was asked for is valid: zero the partial rows and take the launch-per-step path); hipErrorLaunchTimeOut: fatal;
+// anything else: nothing was launched, take the launch-per-step path
+hipError_t launch_adj_res3d(const float* traj, const float* g_traj, const unsigned char* mask, const float* g_top, float* g_h0,
+                            int t_top, double* partials, const float* P, const Problem& p, const Res3dPlan& pl, hipStream_t st)
+{
+    using namespace pi::r3d;
+    constexpr int NT = 512;
+    auto* k = pi_adj3d_resident_kernel<NT>;
+    if (hipError_t e = allow_lds(k, (size_t)LDS_BYTES)) return e;
+    static int blocks_per_cu[16] = {};                      // per device, asked once
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return hipErrorNotSupported; }
+    if (!blocks_per_cu[dev]) {
+        int q = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k, NT, (size_t)LDS_BYTES) != hipSuccess || q < 1) { (void)hipGetLastError(); q = -1; }
+        blocks_per_cu[dev] = q;
+    }
+    if (blocks_per_cu[dev] < 1) return hipErrorCooperativeLaunchTooLarge;
+    pi_host::Resident r;
+    const size_t outbox_bytes = (size_t)2 * (size_t)pl.nblk * Shape<NT>::BOX_BYTES;
+    if (hipError_t e = pi_host::resident_begin(st, outbox_bytes, r)) return e == hipErrorLaunchFailure ? hipErrorNotSupported : e;
+    Args a{};
+    a.n0 = (int)p.n0; a.n1 = (int)p.n1; a.n2 = (int)p.W;
+    a.gz = pl.gz; a.gy = pl.gy; a.gx = pl.gx;
+    a.rz = pl.rz; a.ry = pl.ry; a.rx = pl.rx;
+    a.ss = (long)p.n; a.frame_stride = (long)(2 * p.n);
+    a.outbox = r.scratch + 256;
+    a.sync = reinterpret_cast<unsigned*>(r.scratch);
+    a.host = const_cast<int*>(r.hs);
+    a.nsteps = t_top;
+    a.skip = 0; a.pause = 0;
+    a.timeout_ticks = r.timeout_ticks; a.first_timeout_ticks = r.first_timeout_ticks;
+    AdjArgs aa{};
+    aa.traj = traj; aa.gtraj = g_traj; aa.gtop = g_top; aa.gout = g_h0; aa.partials = partials;
+    aa.np = pi::nparams(p.hc); aa.t_top = t_top;
+    for (int f = 0; f < t_top; ++f)
+        if (!mask || mask[f]) aa.frames[f >> 5] |= 1u << (f & 31);
+    hipLaunchKernelGGL(k, dim3((unsigned)pl.nblk), dim3(NT), (size_t)LDS_BYTES, st, P, a, aa, (unsigned long long*)nullptr);
+    if (hipError_t e = hipGetLastError()) return e;
+    return pi_host::resident_launched(st, r, (unsigned)pl.nblk, "the resident 3D adjoint sweep");
 }
 
 // groups of 4 steps from frame t_top down; g_h0 only if the last group ends at frame 0.  Returns hipErrorCooperativeLaunchTooLarge
@@ -2535,6 +2620,22 @@ int rollout_bwd_impl(const T* traj, const T* g_traj, const unsigned char* mask, 
             if (hipError_t e = hand_over(t_cur - K)) return (int)e;
         }
     }
+    // 3D float32 pre-contracted blocks on whole 16 x 16 x 32 blocks: the whole sweep as ONE resident launch (pi_res3d.h), the
+    // gradient sums carried along; aborted / not resident / not supported: the launch-per-step bricks below
+    if constexpr (sizeof(T) == 4) {
+        Res3dPlan rp;
+        if (t_cur == t_top && direct_sweep && fuse && !loss && res3d_plan(p, t_top, sizeof(T), rp)) {
+            const T* gin = top_in_place ? top_in_place : adj + (size_t)t_top * frame;
+            const hipError_t e = launch_adj_res3d(traj, g_traj, mask, gin, g_h0, t_top, w.partials, P, p, rp, st);
+            if (e == hipSuccess) { t_cur = 0; rows = (unsigned)rp.nblk; }
+            else if (e == hipErrorLaunchTimeOut) return (int)e;
+            else {
+                (void)hipGetLastError();
+                if (e == hipErrorLaunchFailure)             // it ran and gave up: blocks that were through may have added to their rows
+                    if (hipError_t e2 = hipMemsetAsync(w.partials, 0, w.partials_bytes, st)) return (int)e2;
+            }
+        }
+    }
     for (int t = t_cur; t >= 1; --t) {
         T* dst = (t == 1) ? g_h0 : adj + (size_t)(t - 1) * frame;
         const T* inj = has(t - 1) ? g_traj + (size_t)(t - 1) * frame : nullptr;
@@ -2853,6 +2954,11 @@ int apply_option(Options& o, const char* key, long value)
         o.brick3d = (int)value;
         return 0;
     }
+    if (!std::strcmp(key, "res3d")) {                            // 0 = never, 1 = where it measured faster, 2 = whenever eligible
+        if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
+        o.res3d = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "brick_wt")) { o.brick_wt = value != 0; return 0; }
     if (!std::strcmp(key, "brick_xcd")) {
         if (value < 0 || value > 2) return PERCNN_PI_EINVAL;
@@ -3022,6 +3128,10 @@ int debug_plan_impl(int hc, int ndim, const int64_t* shape, const char* options,
     else
         out[14] = ((out[1] == 1 && persist_ok<T>(p, nullptr, 1 << 20, 1 << 18, nullptr)) ? 1 : 0) |
                   ((out[0] == 1 && fwd_persist_ok<T>(p, 1 << 18, nullptr)) ? 2 : 0);
+    {                                                                      // 3D: the resident sweep (pi_res3d.h) where it applies
+        Res3dPlan rp;
+        if (out[1] == 3 && direct_sweep && fuse && res3d_plan(p, 1 << 10, sizeof(T), rp)) out[14] |= 1;
+    }
     for (int dir = 0; dir < 2; ++dir) {                                    // 2D tiles: width, height, lanes per workgroup
         if (out[dir] != 1) continue;
         const TileShape ts = tile_shape_for<T>(p, dir == 1);

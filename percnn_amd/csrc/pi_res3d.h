@@ -34,7 +34,7 @@
 // publish + request -- the hand-over's round trip sits under the interior strips of the NEXT step.
 // Arithmetic and its order are pi::star's / pi_fwd3d_brick_kernel's: every frame is bit-identical to the brick kernels'.
 #pragma once
-#include "../../percnn_amd/csrc/pi_device.h"
+#include "pi_device.h"
 
 namespace pi {
 namespace r3d {

@@ -1738,42 +1738,113 @@ __device__ __forceinline__ void persist_load_ops(StripOps<T>& o, const T* __rest
     o.jv[0] = c2.v[0]; o.jv[1] = c2.v[1]; o.jv[2] = d2.v[0]; o.jv[3] = d2.v[1];
 }
 
-// Data-tagged granules by value type.  float32: the 8-byte word {tag, value} of the sweeps (one agent-scope store / load).
-// float64 (round 5, configs[2]): a 16-byte granule {lo32, tag, hi32, tag} = two self-validating 8-byte words written by ONE
-// 16-byte write-through (sc1) store and read by ONE 16-byte sc1 load -- the request count of a hand-over stays that of the
-// float32 ring (requests are what it costs, not bytes); the reader accepts when BOTH tags match, so a torn pair is just "not yet".
+// Data-tagged granules by value type: ONE 16-byte write-through (sc1) store publishes a granule, ONE 16-byte sc1 load reads it
+// (requests are what a hand-over costs, not bytes).  float64 (round 5, configs[2]): {lo32, tag, hi32, tag} = one value as two
+// self-validating 8-byte words.  float32 (round 6): {value 0, tag, value 1, tag} = TWO x-adjacent values -- the 8-byte {tag, value}
+// words of rounds 3-5 cost a request per handed-over float (3 + 5 per lane and group; now 2 + 3), VERDICT r5 #2.  The reader
+// accepts when BOTH tags match, so a torn pair is just "not yet".  PI_GRANULE_PAIR=0 keeps the 8-byte float32 words (A/B builds of
+// the harnesses only; the library is built with pairs).
+#ifndef PI_GRANULE_PAIR
+#define PI_GRANULE_PAIR 1
+#endif
 typedef unsigned pi_v4u __attribute__((ext_vector_type(4)));
 template <typename T> struct GranuleIO;
+#if PI_GRANULE_PAIR
+template <> struct GranuleIO<float> {
+    using Raw = pi_v4u;
+    static constexpr int BYTES = 16, VALS = 2;
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ __forceinline__ GranuleIO(void* outbox, size_t bytes) : rs(__builtin_amdgcn_make_buffer_rsrc(outbox, 0, (int)bytes, 0x00020000)) {}
+    // src: the pair in LDS (8-byte aligned: even window column in either state buffer)
+    __device__ __forceinline__ void put(size_t idx, unsigned epoch, const float* src) const
+    {
+        const Pack<float, 2> v = ld<float, 2>(src);
+        const pi_v4u w = {__builtin_bit_cast(unsigned, v.v[0]), epoch, __builtin_bit_cast(unsigned, v.v[1]), epoch};
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)(idx * 16), 0, /*aux: sc1*/ 16);
+    }
+    __device__ __forceinline__ Raw get(size_t idx) const { return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(idx * 16), 0, 16); }
+    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return x.y == epoch && x.w == epoch; }
+    static __device__ __forceinline__ void land(Raw x, float* dst)
+    {
+        // (scalars first: __builtin_bit_cast applied to an element of an ext_vector read element 0 for every element -- hipcc 7.2)
+        const unsigned a = x.x, b = x.z;
+        st<float, 2>(dst, Pack<float, 2>{{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)}});
+    }
+};
+#else
 template <> struct GranuleIO<float> {
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     using Raw = unsigned long long;
-    static constexpr int BYTES = 8;
+    static constexpr int BYTES = 8, VALS = 1;
     gu64* base;
     __device__ __forceinline__ GranuleIO(void* outbox, size_t) : base((gu64*)outbox) {}
-    __device__ __forceinline__ void put(size_t idx, unsigned epoch, float v) const
+    __device__ __forceinline__ void put(size_t idx, unsigned epoch, const float* src) const
     {
-        __hip_atomic_store(base + idx, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+        __hip_atomic_store(base + idx, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, *src), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
     __device__ __forceinline__ Raw get(size_t idx) const { return __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return (unsigned)(x >> 32) == epoch; }
-    static __device__ __forceinline__ float value(Raw x) { return __builtin_bit_cast(float, (unsigned)x); }
+    static __device__ __forceinline__ void land(Raw x, float* dst) { *dst = __builtin_bit_cast(float, (unsigned)x); }
 };
+#endif
 template <> struct GranuleIO<double> {
     using Raw = pi_v4u;
-    static constexpr int BYTES = 16;
+    static constexpr int BYTES = 16, VALS = 1;
     __amdgpu_buffer_rsrc_t rs;
     // (the descriptor is built from kernel arguments only: wave-uniform by construction)
     __device__ __forceinline__ GranuleIO(void* outbox, size_t bytes) : rs(__builtin_amdgcn_make_buffer_rsrc(outbox, 0, (int)bytes, 0x00020000)) {}
-    __device__ __forceinline__ void put(size_t idx, unsigned epoch, double v) const
+    __device__ __forceinline__ void put(size_t idx, unsigned epoch, const double* src) const
     {
-        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, *src);
         const pi_v4u w = {(unsigned)b, epoch, (unsigned)(b >> 32), epoch};
         __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)(idx * 16), 0, /*aux: sc1*/ 16);
     }
     __device__ __forceinline__ Raw get(size_t idx) const { return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(idx * 16), 0, 16); }
     static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return x.y == epoch && x.w == epoch; }
-    static __device__ __forceinline__ double value(Raw x) { return __builtin_bit_cast(double, ((unsigned long long)x.z << 32) | x.x); }
+    static __device__ __forceinline__ void land(Raw x, double* dst) { *dst = __builtin_bit_cast(double, ((unsigned long long)x.z << 32) | x.x); }
+};
+
+// The hand-over tables of the 32 x 32 resident kernels, in units of one granule (GV = values per granule, x-adjacent): a tile's
+// border band of width HW is numbered by band_index (rows of B, then rows of 2 HW values: even x <-> even index), the halo ring
+// row-major over the window (rows of LXW, then rows of 2 HW: even window column <-> even index); a tile origin is a multiple of
+// B, so a pair never straddles two owners.
+template <int K, int BX, int GV, int NT>
+struct HandOver {
+    using TL = Tile<K, BX, BX>;
+    static constexpr int HW = 2 * K, LXW = TL::LX;
+    static constexpr int BANDH = BX * BX - (BX - 2 * HW) * (BX - 2 * HW);      // border values per species
+    static constexpr int RINGH = LXW * LXW - BX * BX;                          // halo values per species
+    static_assert(BANDH % GV == 0 && RINGH % GV == 0 && HW % GV == 0 && BX % GV == 0, "granules of x-adjacent values");
+    static constexpr int BANDU = BANDH / GV, RINGU = RINGH / GV;               // granules per species
+    static constexpr int NPUB = (2 * BANDU + NT - 1) / NT, NGAT = (2 * RINGU + NT - 1) / NT;
+    // LDS position (inside a state buffer) of the first value of band granule i (-1: none)
+    static __device__ __forceinline__ int pub_pos(int i)
+    {
+        if (i >= 2 * BANDU) return -1;
+        const int sp = i / BANDU, e = (i - sp * BANDU) * GV;
+        int y, x;                                          // inverse of band_index
+        if (e < HW * BX) { y = e / BX; x = e - y * BX; }
+        else if (e < 2 * HW * BX) { const int m = e - HW * BX; y = BX - HW + m / BX; x = m % BX; }
+        else { const int m = e - 2 * HW * BX; y = HW + m / (2 * HW); const int c = m % (2 * HW); x = c < HW ? c : BX - 2 * HW + c; }
+        return sp * TL::PLANE + (HW + y) * LXW + HW + x;
+    }
+    // ring granule r: gl = LDS position of its first value (-1: none), gs = granule index inside a parity half of the outbox
+    static __device__ __forceinline__ void gat_pos(int r, const TileGeom& g, int ty0, int tx0, int tiles_y, int& gl, int& gs)
+    {
+        gl = -1; gs = 0;
+        if (r >= 2 * RINGU) return;
+        const int sp = r / RINGU, e = (r - sp * RINGU) * GV;
+        int wy, wx;                                        // ring positions row-major over the window, skipping the centre
+        if (e < HW * LXW) { wy = e / LXW; wx = e - wy * LXW; }
+        else if (e < HW * LXW + BX * 2 * HW) { const int m = e - HW * LXW; wy = HW + m / (2 * HW); const int c = m % (2 * HW); wx = c < HW ? c : BX + c; }
+        else { const int m = e - HW * LXW - BX * 2 * HW; wy = HW + BX + m / LXW; wx = m % LXW; }
+        const int gy = ty0 + wy - HW, gx = tx0 + wx - HW;                       // global point (may wrap)
+        const int nty = ((gy + g.H) / BX) % tiles_y, ntx = ((gx + g.W) / BX) % g.tiles_x;
+        const int ly = (gy + g.H) % BX, lx = (gx + g.W) % BX;
+        gl = sp * TL::PLANE + wy * LXW + wx;
+        gs = (nty * g.tiles_x + ntx) * (2 * BANDU) + sp * BANDU + band_index<BX, HW>(ly, lx) / GV;
+    }
 };
 
 // int rows of NT the split sweep keeps in LDS behind the moments: 13 of hand-over tables + 6 of strip geometry (+ the abort word)
@@ -1877,10 +1948,8 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
 {
     static_assert(BX == BY && K == 4 && BX == 32 && NT == 512, "32 x 32 tiles, four sub-steps, 8 waves");
     using TL = Tile<K, BX, BY>;
-    constexpr int HW = 2 * K, LXW = TL::LX;
-    constexpr int BANDH = BX * BX - (BX - 2 * HW) * (BX - 2 * HW);      // border values per species
-    constexpr int RINGH = LXW * LXW - BX * BX;                          // halo values per species
-    constexpr int NPUB = (2 * BANDH + NT - 1) / NT, NGAT = (2 * RINGH + NT - 1) / NT;
+    using HO = HandOver<K, BX, GranuleIO<T>::VALS, NT>;                 // band / ring numbering in granules
+    constexpr int BANDU = HO::BANDU, NPUB = HO::NPUB, NGAT = HO::NGAT;
     static_assert(NPUB + 2 * NGAT <= 13, "tables fit the LDS the host reserves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* b0 = reinterpret_cast<T*>(smem_raw) + lds_pad0<T>::value;
@@ -1889,7 +1958,7 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
     const int tyi = tile / g.tiles_x, txi = tile % g.tiles_x, tiles_y = g.H / BY;
     const int ty0 = tyi * BY, tx0 = txi * BX;
     const int ntiles = g.tiles_x * tiles_y;
-    const GranuleIO<T> gio(pa.outbox, (size_t)2 * (size_t)ntiles * (2 * BANDH) * GranuleIO<T>::BYTES);
+    const GranuleIO<T> gio(pa.outbox, (size_t)2 * (size_t)ntiles * (2 * BANDU) * GranuleIO<T>::BYTES);
     constexpr int LACC = sizeof(T) == 8 ? NT / 2 : NT;     // float64: two lanes share a moment slot (LDS atomics), see persist_pass
     // which half of a mixed pass this wave works on (wave-uniform, kept in a scalar register)
     const int wave_id = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -1918,35 +1987,11 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
         for (int m = 0; m < 20; ++m) lacc[m * LACC + (int)threadIdx.x] = 0.0;
     }
 #pragma unroll
-    for (int q = 0; q < NPUB; ++q) {
-        const int i = (int)threadIdx.x + q * NT;
-        int pl = -1;
-        if (i < 2 * BANDH) {
-            const int sp = i / BANDH, e = i - sp * BANDH;
-            int y, x;                                      // inverse of band_index
-            if (e < HW * BX) { y = e / BX; x = e - y * BX; }
-            else if (e < 2 * HW * BX) { const int m = e - HW * BX; y = BX - HW + m / BX; x = m % BX; }
-            else { const int m = e - 2 * HW * BX; y = HW + m / (2 * HW); const int c = m % (2 * HW); x = c < HW ? c : BX - 2 * HW + c; }
-            pl = sp * TL::PLANE + (HW + y) * LXW + HW + x;
-        }
-        tab_pub[q * NT + (int)threadIdx.x] = pl;
-    }
+    for (int q = 0; q < NPUB; ++q) tab_pub[q * NT + (int)threadIdx.x] = HO::pub_pos((int)threadIdx.x + q * NT);
 #pragma unroll
     for (int q = 0; q < NGAT; ++q) {
-        const int r = (int)threadIdx.x + q * NT;
-        int gl = -1, gs = 0;
-        if (r < 2 * RINGH) {
-            const int sp = r / RINGH, e = r - sp * RINGH;
-            int wy, wx;                                    // ring positions row-major over the window, skipping the centre
-            if (e < HW * LXW) { wy = e / LXW; wx = e - wy * LXW; }
-            else if (e < HW * LXW + BX * 2 * HW) { const int m = e - HW * LXW; wy = HW + m / (2 * HW); const int c = m % (2 * HW); wx = c < HW ? c : BX + c; }
-            else { const int m = e - HW * LXW - BX * 2 * HW; wy = HW + BX + m / LXW; wx = m % LXW; }
-            const int gy = ty0 + wy - HW, gx = tx0 + wx - HW;                       // global point (may wrap)
-            const int nty = ((gy + g.H) / BY) % tiles_y, ntx = ((gx + g.W) / BX) % g.tiles_x;
-            const int ly = (gy + g.H) % BY, lx = (gx + g.W) % BX;
-            gl = sp * TL::PLANE + wy * LXW + wx;
-            gs = (nty * g.tiles_x + ntx) * (2 * BANDH) + sp * BANDH + band_index<BX, HW>(ly, lx);
-        }
+        int gl, gs;
+        HO::gat_pos((int)threadIdx.x + q * NT, g, ty0, tx0, tiles_y, gl, gs);
         tab_gl[q * NT + (int)threadIdx.x] = gl;
         tab_gs[q * NT + (int)threadIdx.x] = gs;
     }
@@ -1995,7 +2040,7 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
         // P0 / P1 alone, with the publish moved under P0 as well, the hand-over takes those waves 2 us and P0 waits for them --
         // both measured, tools/persist_dev.hip, profiles/r04_persistent_split_timelines.txt.) ----
         const unsigned epoch = (unsigned)grp;
-        const size_t half = (size_t)(epoch & 1u) * (size_t)ntiles * (2 * BANDH);          // granule index of this parity's half
+        const size_t half = (size_t)(epoch & 1u) * (size_t)ntiles * (2 * BANDU);          // granule index of this parity's half
         int gs[NGAT];
         typename GranuleIO<T>::Raw gx[NGAT];
         if (grp > 0) {
@@ -2036,7 +2081,7 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
             } else {
 #pragma unroll
                 for (int q = 0; q < NGAT; ++q)
-                    if (gl[q] >= 0) b0[gl[q]] = GranuleIO<T>::value(gx[q]);
+                    if (gl[q] >= 0) GranuleIO<T>::land(gx[q], b0 + gl[q]);
             }
             lds_barrier();
         }
@@ -2088,11 +2133,11 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
         gmask = gmask_next;
         // ---- publish my band (the border 2K points of the tile, complete since the barrier that ended P5) ----
         const unsigned ep1 = (unsigned)grp + 1u;
-        const size_t mine = (size_t)(ep1 & 1u) * (size_t)ntiles * (2 * BANDH) + (size_t)tile * (2 * BANDH);
+        const size_t mine = (size_t)(ep1 & 1u) * (size_t)ntiles * (2 * BANDU) + (size_t)tile * (2 * BANDU);
 #pragma unroll
         for (int q = 0; q < NPUB; ++q) {
             const int pl = tab_pub[q * NT + (int)threadIdx.x];
-            if (pl >= 0) gio.put(mine + (size_t)((int)threadIdx.x + q * NT), ep1, b0[pl]);
+            if (pl >= 0) gio.put(mine + (size_t)((int)threadIdx.x + q * NT), ep1, b0 + pl);
         }
         PI_PSTAMP(8);
         // (no barrier: the next pass, P0, reads b0 -- complete -- and writes b1's centre, which nobody reads any more)
@@ -2229,10 +2274,8 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
 {
     static_assert(BX == BY && K == 4 && BX == 32 && NT == 512, "32 x 32 tiles, four sub-steps, 8 waves");
     using TL = Tile<K, BX, BY>;
-    constexpr int HW = 2 * K, LXW = TL::LX;
-    constexpr int BANDH = BX * BX - (BX - 2 * HW) * (BX - 2 * HW);      // border values per species
-    constexpr int RINGH = LXW * LXW - BX * BX;                          // halo values per species
-    constexpr int NPUB = (2 * BANDH + NT - 1) / NT, NGAT = (2 * RINGH + NT - 1) / NT;
+    using HO = HandOver<K, BX, GranuleIO<T>::VALS, NT>;                 // band / ring numbering in granules
+    constexpr int BANDU = HO::BANDU, NPUB = HO::NPUB, NGAT = HO::NGAT;
     static_assert(NPUB + 2 * NGAT <= 13, "tables fit the LDS the host reserves");
     constexpr int IDLE = 4 * WAVE;                                      // waves 4..7 own no strip in P0, P1, P3, P4, P5
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -2242,7 +2285,7 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
     const int tyi = tile / g.tiles_x, txi = tile % g.tiles_x, tiles_y = g.H / BY;
     const int ty0 = tyi * BY, tx0 = txi * BX;
     const int ntiles = g.tiles_x * tiles_y;
-    const GranuleIO<T> gio(pa.outbox, (size_t)2 * (size_t)ntiles * (2 * BANDH) * GranuleIO<T>::BYTES);
+    const GranuleIO<T> gio(pa.outbox, (size_t)2 * (size_t)ntiles * (2 * BANDU) * GranuleIO<T>::BYTES);
 
     // LDS: state buffers | int tables (publish, gather, geometry) | abort word
     int* tab_pub = reinterpret_cast<int*>(smem_raw + tile_state_bytes<T, K, BX, BY>());     // [NPUB][NT]: LDS position of a border value
@@ -2262,35 +2305,11 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
     tab_geo[4 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 4>(g, ty0, tx0);
     tab_geo[5 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 5>(g, ty0, tx0);
 #pragma unroll
-    for (int q = 0; q < NPUB; ++q) {                       // (the tables of pi_adj2d_persist_split_kernel)
-        const int i = (int)threadIdx.x + q * NT;
-        int pl = -1;
-        if (i < 2 * BANDH) {
-            const int sp = i / BANDH, e = i - sp * BANDH;
-            int y, x;                                      // inverse of band_index
-            if (e < HW * BX) { y = e / BX; x = e - y * BX; }
-            else if (e < 2 * HW * BX) { const int m = e - HW * BX; y = BX - HW + m / BX; x = m % BX; }
-            else { const int m = e - 2 * HW * BX; y = HW + m / (2 * HW); const int c = m % (2 * HW); x = c < HW ? c : BX - 2 * HW + c; }
-            pl = sp * TL::PLANE + (HW + y) * LXW + HW + x;
-        }
-        tab_pub[q * NT + (int)threadIdx.x] = pl;
-    }
+    for (int q = 0; q < NPUB; ++q) tab_pub[q * NT + (int)threadIdx.x] = HO::pub_pos((int)threadIdx.x + q * NT);
 #pragma unroll
     for (int q = 0; q < NGAT; ++q) {
-        const int r = (int)threadIdx.x + q * NT;
-        int gl = -1, gs = 0;
-        if (r < 2 * RINGH) {
-            const int sp = r / RINGH, e = r - sp * RINGH;
-            int wy, wx;                                    // ring positions row-major over the window, skipping the centre
-            if (e < HW * LXW) { wy = e / LXW; wx = e - wy * LXW; }
-            else if (e < HW * LXW + BX * 2 * HW) { const int m = e - HW * LXW; wy = HW + m / (2 * HW); const int c = m % (2 * HW); wx = c < HW ? c : BX + c; }
-            else { const int m = e - HW * LXW - BX * 2 * HW; wy = HW + BX + m / LXW; wx = m % LXW; }
-            const int gy = ty0 + wy - HW, gx = tx0 + wx - HW;                       // global point (may wrap)
-            const int nty = ((gy + g.H) / BY) % tiles_y, ntx = ((gx + g.W) / BX) % g.tiles_x;
-            const int ly = (gy + g.H) % BY, lx = (gx + g.W) % BX;
-            gl = sp * TL::PLANE + wy * LXW + wx;
-            gs = (nty * g.tiles_x + ntx) * (2 * BANDH) + sp * BANDH + band_index<BX, HW>(ly, lx);
-        }
+        int gl, gs;
+        HO::gat_pos((int)threadIdx.x + q * NT, g, ty0, tx0, tiles_y, gl, gs);
         tab_gl[q * NT + (int)threadIdx.x] = gl;
         tab_gs[q * NT + (int)threadIdx.x] = gs;
     }
@@ -2307,7 +2326,7 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
         lds_barrier();
         PI_PSTAMP(1);
         const unsigned epoch = (unsigned)grp;
-        const size_t half = (size_t)(epoch & 1u) * (size_t)ntiles * (2 * BANDH);          // granule index of this parity's half
+        const size_t half = (size_t)(epoch & 1u) * (size_t)ntiles * (2 * BANDU);          // granule index of this parity's half
         int gs[NGAT];
         typename GranuleIO<T>::Raw gx[NGAT];
         auto request = [&]() {
@@ -2354,7 +2373,7 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
                 // (the ring of b0 -- level 0 -- is read by A_0 only; I_1 above wrote b0's centre)
 #pragma unroll
                 for (int q = 0; q < NGAT; ++q)
-                    if (gl[q] >= 0) b0[gl[q]] = GranuleIO<T>::value(gx[q]);
+                    if (gl[q] >= 0) GranuleIO<T>::land(gx[q], b0 + gl[q]);
             }
         }
         lds_barrier();
@@ -2395,11 +2414,11 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
         }
         // ---- publish my band of level 4 (complete since the barrier) ----
         const unsigned ep1 = (unsigned)grp + 1u;
-        const size_t mine = (size_t)(ep1 & 1u) * (size_t)ntiles * (2 * BANDH) + (size_t)tile * (2 * BANDH);
+        const size_t mine = (size_t)(ep1 & 1u) * (size_t)ntiles * (2 * BANDU) + (size_t)tile * (2 * BANDU);
 #pragma unroll
         for (int q = 0; q < NPUB; ++q) {
             const int pl = tab_pub[q * NT + tid];
-            if (pl >= 0) gio.put(mine + (size_t)(tid + q * NT), ep1, b0[pl]);
+            if (pl >= 0) gio.put(mine + (size_t)(tid + q * NT), ep1, b0 + pl);
         }
         PI_PSTAMP(8);
         // (no barrier: P0 reads b0 -- complete -- and writes b1 inside I_0's square; the store of level 3 from b1 was issued before

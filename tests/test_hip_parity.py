@@ -1091,6 +1091,65 @@ def test_small_tile_persistent_sweep_equals_launch_per_group(shape, T, hip_devic
         assert rel_l2(outs["persist"].cpu().numpy(), outs["per_group"].cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("shape,T", [((32, 32, 64), 19), ((48, 32, 64), 17), ((32, 64, 96), 18), ((64, 32, 128), 21)])
+def test_resident_3d_sweep_equals_brick_sweep(shape, T, hip_device):
+    """Round 6 (pi_res3d.h): the reverse sweep of a 3D float32 pre-contracted rollout as ONE launch of resident workgroups --
+    adjoint state of a 16 x 16 x 32 block in LDS, two-deep faces handed over as one-bit-tagged granules, XCD regions where the
+    block counts divide (8 / 12 / 24 / 32 blocks here: region maps 2x2x2, none, 2x4x1 ..., forced with res3d=2; the default takes
+    it from 3/4 of the CUs on: 128^3): dL/dh0 bit for bit the launch-per-step brick sweep's and the C oracle's, the 22 gradient
+    sums to float32 summation round-off; dense dL/dtraj and frame masks; res3d=0 is the old path."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    rs = np.random.RandomState(17)
+    Pn = random_block(0, 3, np.float32, 29, scale=0.1)
+    P = dev_t(Pn, hip_device)
+    h0 = rs.uniform(0, 1, (2,) + shape).astype(np.float32)
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=hip_device)
+    traj[0] = dev_t(h0, hip_device)
+    pa.rollout_fwd_(traj, P)
+    g = torch.randn(traj.shape, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(3)) / traj[0].numel()
+    assert not _lib.rollout_plan(0, shape, 4)["bwd_persistent"] and _lib.rollout_plan(0, shape, 4, "res3d=2")["bwd_persistent"]
+    n0 = _lib.persist_status()["launches"]
+    for mask in (None, [t % 3 != 1 for t in range(T + 1)], [t == T or t % 5 == 0 for t in range(T + 1)]):
+        a0, ag = pa.rollout_bwd(traj, g, P, frame_mask=mask, options={"res3d": 2})
+        b0, bg = pa.rollout_bwd(traj, g, P, frame_mask=mask, options={"res3d": 0})
+        assert torch.equal(a0, b0)
+        assert rel_l2(ag.cpu().numpy(), bg.cpu().numpy()) < 2e-6
+    assert _lib.persist_status()["launches"] == n0 + 3 and _lib.persist_status()["aborts"] == 0
+    if shape == (32, 32, 64):
+        g0_ref, pg_ref = o_rollout_bwd(traj.cpu().numpy(), g.cpu().numpy(), Pn)
+        a0, ag = pa.rollout_bwd(traj, g, P, options={"res3d": 2})
+        assert np.array_equal(a0.cpu().numpy(), g0_ref) and rel_l2(ag.cpu().numpy(), pg_ref) < 2e-5
+    # short sweeps, factored blocks and grids that are not whole blocks keep the bricks whatever the option says
+    assert not _lib.rollout_plan(2, shape, 4, "res3d=2")["bwd_persistent"]
+    assert not _lib.rollout_plan(0, (shape[0] + 8,) + shape[1:], 4, "res3d=2")["bwd_persistent"]
+    c0, cg = pa.rollout_bwd(traj[:9], g[:9], P, options={"res3d": 2})
+    d0, dg = pa.rollout_bwd(traj[:9], g[:9], P, options={"res3d": 0})
+    assert torch.equal(c0, d0) and _lib.persist_status()["launches"] == n0 + (4 if shape == (32, 32, 64) else 3)
+
+
+def test_resident_3d_sweep_is_the_default_at_128_cubed(hip_device):
+    """configs[3]'s grid: 256 blocks = one per CU, XCD regions 2 x 2 x 2; the default backward takes the resident sweep and its
+    dL/dh0 is the brick sweep's bit for bit (which the C oracle pins at this size in test_full_size_step_bitwise...)."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    shape, T = (128, 128, 128), 24
+    assert _lib.rollout_plan(0, shape, 4)["bwd_persistent"] and not _lib.rollout_plan(0, shape, 4, "res3d=0")["bwd_persistent"]
+    assert not _lib.rollout_plan(0, (144, 144, 144), 4)["bwd_persistent"] and not _lib.rollout_plan(0, (64, 64, 64), 4)["bwd_persistent"]
+    rs = np.random.RandomState(23)
+    P = dev_t(random_block(0, 3, np.float32, 31, scale=0.1), hip_device)
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=hip_device)
+    traj[0] = dev_t(rs.uniform(0, 1, (2,) + shape).astype(np.float32), hip_device)
+    pa.rollout_fwd_(traj, P)
+    g = torch.randn(traj.shape, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(5)) / traj[0].numel()
+    n0 = _lib.persist_status()["launches"]
+    for mask in (None, [t % 4 != 2 for t in range(T + 1)]):
+        a0, ag = pa.rollout_bwd(traj, g, P, frame_mask=mask)
+        b0, bg = pa.rollout_bwd(traj, g, P, frame_mask=mask, options={"res3d": 0})
+        assert torch.equal(a0, b0) and rel_l2(ag.cpu().numpy(), bg.cpu().numpy()) < 2e-6
+    assert _lib.persist_status()["launches"] == n0 + 2 and _lib.persist_status()["aborts"] == 0
+
+
 @pytest.mark.parametrize("shape,tile", [((544, 544), (32, 40, 640)), ((640, 640), (40, 40, 768)), ((560, 600), (40, 40, 768)),
                                         ((520, 536), (32, 40, 640))])
 def test_wide_tiles_past_512_bitwise(shape, tile, hip_device):

@@ -95,6 +95,45 @@ def test_persistent_sweep_aborts_cleanly_and_falls_back(hip_device):
     assert _lib.persist_status()["launches"] == s2["launches"] + 1 and torch.equal(d0, ref0)
 
 
+def test_resident_3d_sweep_aborts_cleanly_and_falls_back(hip_device):
+    """Round 6: the resident 3D sweep (256 workgroups at 128^3, 159 KB of LDS each) under the same stress: with 16 CUs held it
+    gives up at its first hand-over without writing dL/dh0 or a partial row, the same rollout_bwd call runs the brick sweep --
+    bit-identical to res3d=0 -- and the device keeps the launch-per-step path until persist_reset."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    pa.set_option("persist_reset", 1)
+    shape, T = (128, 128, 128), 18
+    rs = np.random.RandomState(6)
+    P = dev_t(random_block(0, 3, np.float32, 21, scale=0.1), hip_device)
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=hip_device)
+    traj[0] = dev_t(rs.uniform(0, 1, (2,) + shape).astype(np.float32), hip_device)
+    pa.rollout_fwd_(traj, P)
+    g = torch.randn(traj.shape, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(1)) / traj[0].numel()
+    ref0, refg = pa.rollout_bwd(traj, g, P, options={"res3d": 0})
+    s0 = _lib.persist_status()
+    a0, ag = pa.rollout_bwd(traj, g, P)
+    s1 = _lib.persist_status()
+    assert s1["launches"] == s0["launches"] + 1 and s1["aborts"] == s0["aborts"] and torch.equal(a0, ref0)
+    torch.cuda.synchronize()
+    try:
+        _hog(16, 150 * 1024, 1500, hip_device)
+        b0, bg = pa.rollout_bwd(traj, g, P, options={"persist_first_timeout_ms": 20})
+        s2 = _lib.persist_status()
+        torch.cuda.synchronize()
+        assert s2["launches"] == s1["launches"] + 1 and s2["aborts"] == s1["aborts"] + 1 and s2["disabled_on_current_device"]
+        assert torch.isfinite(b0).all() and torch.isfinite(bg).all() and torch.equal(b0, ref0)
+        assert rel_l2(bg.cpu().numpy(), refg.cpu().numpy()) < 2e-6
+        c0, cg = pa.rollout_bwd(traj, g, P)
+        assert _lib.persist_status()["launches"] == s2["launches"] and torch.equal(c0, ref0)
+        assert not _lib.rollout_plan(0, shape, 4)["bwd_persistent"]
+    finally:
+        torch.cuda.synchronize()
+        pa.set_option("persist_reset", 1)
+    assert _lib.rollout_plan(0, shape, 4)["bwd_persistent"]
+    d0, dg = pa.rollout_bwd(traj, g, P)
+    assert _lib.persist_status()["launches"] == s2["launches"] + 1 and torch.equal(d0, ref0)
+
+
 def test_persistent_forward_aborts_cleanly_and_falls_back(hip_device):
     """The resident forward under the same stress (CUs held by another kernel): the launch gives up at its first hand-over, the
     same rollout_fwd_ call recomputes the trajectory launch by launch -- bit-identical to fwd_persist=0, no NaNs -- and the

@@ -17,12 +17,14 @@ for wl in gs2d_512 gs3d_128 lo2d_512 gs2d_100; do
   grep "^{" /tmp/kt.log | tail -1 > $O/${ROUND}_final_bench_under_rocprof_$wl.json
 done
 (timeout 900 python $R/bench.py --workload gs2d_512 --reaction factored --no-cpu-baseline --no-also 2>&1 | tail -1) > $O/${ROUND}_final_bench_gs2d_512_factored.json
+# counters at the workloads' own horizons (round 6: the committed traffic figures are no longer T = 100 runs scaled up)
+declare -A TDEF=([gs2d_512]=1000 [gs3d_128]=500 [lo2d_512]=400 [gs2d_100]=200)
 : > $O/${ROUND}_final_pmc_fetch_write_summary.txt
 for wl in gs2d_512 gs3d_128 lo2d_512 gs2d_100; do
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcout
-  timeout 900 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmcout -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-also --workload $wl --T 100 > /tmp/pmc.log 2>&1
-  python $R/tools/pmc_summary.py $(find /tmp/pmcout -name "*.db" | head -1) "$wl T=100" | grep "pi::" >> $O/${ROUND}_final_pmc_fetch_write_summary.txt 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmcout -o pmc -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-also --workload $wl > /tmp/pmc.log 2>&1
+  python $R/tools/pmc_summary.py $(find /tmp/pmcout -name "*.db" | head -1) "$wl T=${TDEF[$wl]}" | grep "pi::" >> $O/${ROUND}_final_pmc_fetch_write_summary.txt 2>&1
 done
 done
 cd $R

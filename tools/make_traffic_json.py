@@ -18,15 +18,19 @@ for line in open(src):
         rows.setdefault(wl, {}).setdefault(kern, {})[ctr] = float(avg) * 1024.0
         rows[wl]["_T"] = int(T)
 for wl, kernels in rows.items():
-    out = {"_source": f"{src} (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --workload {wl} --T 100)",
+    out = {"_source": f"{src} (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --workload {wl} --T {kernels.get('_T', 100)})",
            "_note": "bytes per launch. FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane coalesced reads "
                     "(verified on pi_moments_kernel: raw FETCH = 0.49 x the 16 B/point-step it streams)", "detail": {}}
     T_run = kernels.pop("_T", 100)
+    out["_T"] = T_run
+    out["_date"] = __import__("datetime").date.fromtimestamp(os.path.getmtime(src)).isoformat()
     for k, v in kernels.items():
         f, w = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
         if k in ("pi_adj2d_persist_kernel", "pi_adj2d_persist_split_kernel", "pi_adj2d_persist_small_kernel"):
             # ONE launch per rollout (T // 4 groups of 4 steps inside): bench.py scales the per-group bytes to its own T
             out["pi_adj2d_persist_kernel_per_group"] = (2 * f + w) / max(1, T_run // 4)
+        if k == "pi_adj3d_resident_kernel":
+            out["pi_adj3d_resident_kernel_per_step"] = (2 * f + w) / max(1, T_run)        # ONE launch per rollout: T steps inside
         if k in ("pi_fwd2d_persist_kernel", "pi_fwd2d_persist_small_kernel"):
             out["pi_fwd2d_persist_kernel_per_group"] = (2 * f + w) / max(1, T_run // 4)
         out["detail"][k] = {"fetch_raw_bytes": f, "fetch_corrected_bytes": 2 * f, "write_bytes": w, "hbm_bytes_per_launch": 2 * f + w}

@@ -12,7 +12,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "pi_res3d.h"
+#include "../../percnn_amd/csrc/pi_res3d.h"
 #ifndef R3D_NT
 #define R3D_NT 512
 #endif
