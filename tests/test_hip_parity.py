@@ -422,6 +422,57 @@ def test_full_size_gradients_vs_reference(fam, shape, reaction, hip_device):
             assert rel_l2(gh[sub].cpu().numpy(), z[f"grad64_{lname}_h0_sub"]) < tol_g
 
 
+@pytest.mark.parametrize("reaction", ["factored", "poly"])
+def test_long_horizon_gradients_vs_reference(reaction, hip_device):
+    """the reference's own autograd over a LONG horizon at the headline grid -- train_2drd.py:407 on 512^2 x 300
+    steps (tools/make_golden.py --longgrad: a ~25 GB tape on the build container's host; both losses, all 164 parameter
+    gradients, dL/dh0 as every 8th point + norm).  The T = 1000 backward is pinned bit for bit to the C oracle
+    (test_headline_backward_512x512x1000_vs_c_oracle); this pins the long-horizon backward to the reference itself.  Yardstick
+    for the float32 reference's own summation error (262 144 terms per step and bias, 300 steps): the same cell in float64 on
+    this package's float64 kernels (which the T = 100 case checks against the reference's float64 twin)."""
+    import copy
+    import percnn_amd as pa
+    from oracle import restatement as R
+    fn = os.path.join(GOLDEN, "gs2d_longgrad300_512x512.npz")
+    if not os.path.exists(fn):
+        pytest.skip("longgrad golden absent")
+    z = np.load(fn)
+    tol_g = TOL_GRAD[np.dtype("float32")]
+    shape, steps, stride_t = (512, 512), int(z["steps"]), int(z["stride_t"])
+    assert steps == 300
+    sd = {k[6:]: torch.tensor(z[k]) for k in z.files if k.startswith("param/")}
+    cell = pa.gs2d_cell(reaction=reaction)
+    cell.load_state_dict(sd)
+    cell.to(hip_device)
+    cell64 = copy.deepcopy(cell).double()
+    sub = (slice(None), slice(None), slice(None, None, 8), slice(None, None, 8))
+    names = [n for n, p in cell.named_parameters() if p.requires_grad]
+
+    def run(c, dtype, lname):
+        h0 = R.gs_initial_state(shape, seed=0).to(hip_device).to(dtype).requires_grad_(True)
+        outs, _ = pa.RCNN(c, step=steps, effective_step=list(range(steps)), init_state=h0)()
+        traj = torch.cat(tuple(outs), dim=0)
+        loss = (traj ** 2).mean() if lname == "meansq" else data_loss(traj, stride_t, 2)
+        grads = torch.autograd.grad(loss, [p for n, p in c.named_parameters() if p.requires_grad] + [h0])
+        return traj[-1:].detach(), loss.item(), np.concatenate([g.double().cpu().numpy().ravel() for g in grads[:-1]]), grads[-1]
+
+    for lname in ("meansq", "data"):
+        last, loss, allm, gh = run(cell, torch.float32, lname)
+        _, _, all64, gh64 = run(cell64, torch.float64, lname)
+        assert rel_l2(last[sub].cpu().numpy(), z["sub_last"]) < 1e-5
+        ref_loss = float(z[f"loss_{lname}"])
+        assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss)
+        allr = np.concatenate([z[f"grad_{lname}/{n}"].ravel() for n in names])
+        assert allm.size == 164
+        e_ref = rel_l2(allr, all64)                          # the float32 reference's own distance from the exact gradients
+        assert rel_l2(allm, all64) < tol_g, (lname, rel_l2(allm, all64), e_ref)
+        assert rel_l2(allm, allr) < max(tol_g, 2 * e_ref), (lname, rel_l2(allm, allr), e_ref)
+        assert rel_l2(gh[sub].cpu().numpy(), z[f"grad_{lname}_h0_sub"]) < tol_g
+        l2 = float(z[f"grad_{lname}_h0_l2"])
+        assert abs(float(torch.linalg.vector_norm(gh.double())) - l2) < tol_g * l2
+        assert rel_l2(gh[sub].cpu().numpy(), gh64[sub].cpu().numpy()) < tol_g
+
+
 @pytest.mark.parametrize("a", [0.0, 2.0, 10.0, 50.0])
 def test_poly_conditioning_rule_on_the_kernels(a, hip_device):
     """The rule of RCNNCell's docstring on the HIP kernels themselves: poly vs factored kernel after 100 steps on the

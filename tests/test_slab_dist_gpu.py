@@ -342,3 +342,36 @@ def test_native_slab_loops_hand_back_a_failing_ring_call(fail_at, hip_device):
     out, errs, exs, fabric, _ = _fake_ring_run(2, (16, 16, 32), 4, 5, False, True, fail_at=fail_at)
     assert isinstance(errs[0], RuntimeError) and "slab_rollout" in str(errs[0]), errs
     assert errs[1] is None or isinstance(errs[1], (RuntimeError, Exception))
+
+
+def test_overlap_schedule_hides_an_injected_wire(hip_device, tmp_path):
+    """to self every message arrives as fast as a device copy, so the faces-first / side-stream schedule of the
+    native slab loops had only ever shown its own cost.  examples/slab_delay_ring.cpp drives percnn_pi_slab_rollout_fwd / _bwd
+    on the per-rank shape of configs[4] (32 x 256^2, halo 4) through a percnn_pi_halo_ring of C++ callbacks with RCCL's group
+    semantics and an INJECTED wire -- a link stream per direction that holds each message for 30 us (2 MiB forward faces) /
+    16 us (1 MiB adjoint faces), DESIGN.md 6's xGMI budget.  Asserted: (i) the plain schedule pays the wire in full (it is
+    ~ its own no-wire time + the wire), (ii) the overlap schedule hides most of it (its time grows by less than 40 % of the wire),
+    (iii) with a wire the overlap schedule beats the plain one, (iv) same bits from all four runs."""
+    import re
+    import subprocess
+    import percnn_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "slab_delay_ring")
+    csrc = os.path.dirname(percnn_amd.LIB_PATH)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "slab_delay_ring.cpp"), "-L" + csrc, "-lpercnn_pi", "-Wl,-rpath," + csrc, "-o", exe])
+    out = subprocess.run([exe, "40", "5", "30", "16", "4"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "bitwise: identical" in out.stdout and "slab_delay_ring ok" in out.stdout
+    rows = {}
+    for m in re.finditer(r"RESULT (.+?)\s+fwd_wire_us\s+([\d.]+) bwd_wire_us\s+([\d.]+) \| fwd\s+([\d.]+) bwd\s+([\d.]+) total\s+([\d.]+)", out.stdout):
+        rows[m.group(1).strip()] = tuple(float(m.group(i)) for i in range(2, 7))
+    assert set(rows) == {"plain, no wire", "overlap, no wire", "plain, wire", "overlap, wire"}, out.stdout
+    # the wire per time step: one forward exchange per two steps (halo 4) of 30 us, one adjoint exchange per step of 16 us;
+    # the two directions of an exchange travel on separate links
+    wire = 30.0 / 2 + 16.0
+    p0, o0, p1, o1 = (rows[k][4] for k in ("plain, no wire", "overlap, no wire", "plain, wire", "overlap, wire"))
+    print(out.stdout)
+    assert p1 - p0 > 0.8 * wire, (p0, p1, wire)                 # (i) nothing hidden
+    assert o1 - o0 < 0.4 * wire, (o0, o1, wire)                 # (ii) most of it hidden
+    assert o1 < p1, (o1, p1)                                    # (iii)

@@ -239,7 +239,7 @@ def big_case(case, mod, shape, checkpoints):
     print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
 
 
-def biggrad_case(case, mod, shape, steps, stride_t):
+def biggrad_case(case, mod, shape, steps, stride_t, twin=True, tag="biggrad"):
     """Reference forward + autograd backward at the BASELINE grid size (shorter horizon: the reference's tape is
     ~80 MB per 512^2 step): both losses, every parameter gradient, an every-8th-point subsample of dL/dh0 and of the
     last frame.  This is the backward the reference triggers at 2dgs:407 / 3dgs:408 / lo:373, at full spatial size."""
@@ -268,7 +268,7 @@ def biggrad_case(case, mod, shape, steps, stride_t):
         rec[f"grad_{lname}_h0_l2"] = float(torch.linalg.vector_norm(gh.double()))
         print(f"   loss {lname} = {loss.item():.9g}, backward done ({time.time()-t0:.0f}s)")
     del tr, loss, g, gh
-    if h0.dtype == torch.float32:
+    if h0.dtype == torch.float32 and twin:
         # float64 twin of the same cell (same float32-rounded weights and stencil taps, upcast): the yardstick that says
         # how far the float32 reference's OWN gradients are from the exact ones (its per-step bias / weight reductions
         # sum 262 144+ terms in float32)
@@ -288,7 +288,7 @@ def biggrad_case(case, mod, shape, steps, stride_t):
             rec[f"grad64_{lname}_h0_sub"] = gh64[sub].numpy()
             print(f"   float64 twin, loss {lname}: worst per-tensor rel-L2 of the float32 reference's parameter "
                   f"gradients = {worst:.2e} ({time.time()-t0:.0f}s)")
-    fn = os.path.join(OUT, f"{case}_biggrad_{'x'.join(map(str, shape))}.npz")
+    fn = os.path.join(OUT, f"{case}_{tag}_{'x'.join(map(str, shape))}.npz")
     np.savez_compressed(fn, **rec)
     print(f"  wrote {os.path.relpath(fn, ROOT)}  ({os.path.getsize(fn)/1024:.0f} KiB)")
 
@@ -537,9 +537,16 @@ def train_iter_case(case, mod):
           f"data={rec['loss_data']:.6g} ic={rec['loss_ic']:.6g} phy={rec['loss_phy']:.6g}; {len(gr)} gradient tensors")
 
 
-def run_case(case, big, biggrad=False):
+def run_case(case, big, biggrad=False, longgrad=False):
     mod = import_reference(case)
     torch.set_num_threads(8)
+    if longgrad:
+        # the reference's own autograd over a LONG horizon at the headline grid (512^2 x 300 steps: a ~25 GB tape,
+        # what this container holds; the float64 twin would need twice that and is left to the T = 100 case) -- pins the
+        # long-horizon backward to the reference itself, not only to the C oracle
+        if case == "gs2d":
+            biggrad_case(case, mod, (512, 512), 300, 20, twin=False, tag="longgrad300")
+        return
     if biggrad:
         if case == "gs2d":
             biggrad_case(case, mod, (512, 512), 100, 20)
@@ -593,6 +600,7 @@ if __name__ == "__main__":
     ap.add_argument("--case", choices=list(SCRIPTS))
     ap.add_argument("--big", action="store_true")
     ap.add_argument("--train-iter", action="store_true", help="only the training-iteration fixtures (gs2d, gs3d)")
+    ap.add_argument("--longgrad", action="store_true", help="reference gradients at 512^2 x 300 steps (gs2d; ~25 GB of autograd tape)")
     ap.add_argument("--biggrad", action="store_true", help="full-size reference gradients (512^2 x100, 128^3 x20, lo 512^2 x100)")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
@@ -602,6 +610,8 @@ if __name__ == "__main__":
         else:
             for c in ("gs2d", "gs3d"):
                 subprocess.check_call([sys.executable, os.path.abspath(__file__), "--case", c, "--train-iter"])
+    elif a.longgrad:
+        run_case("gs2d", False, longgrad=True)
     elif a.case:
         run_case(a.case, a.big, a.biggrad)
     else:
