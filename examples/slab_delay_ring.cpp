@@ -4,19 +4,18 @@
 // hide, so the faces-first / side-stream schedule has only ever shown its own cost.  This host drives the NATIVE slab loops
 // (percnn_pi_slab_rollout_fwd / _bwd: the per-rank code of the 8-GPU decomposition of BASELINE configs[4]) on ONE rank of the
 // configs[4] slab shape (32 x 256 x 256 float32, halo 4) through a percnn_pi_halo_ring whose four function pointers are C++
-// callbacks with RCCL's group semantics and an INJECTED WIRE: a send copies the face into a staging buffer on the caller's stream,
-// a "link" stream per direction then spins `delay` microseconds (one small kernel: it occupies one workgroup slot, like a DMA
-// engine would none) and records the arrival event; the matching receive makes the caller's stream wait for that event and
-// copies the face into the halo planes.  prev == next == this rank (a ring of one): sends and receives pair up in issue order,
-// RCCL's rule for two operations on the same peer.  Nothing synchronises with the host inside a rollout.
+// callbacks with RCCL's group semantics and an INJECTED WIRE (see Fabric below): the sends copy the faces into staging buffers on
+// the stream the loop hands in, group_end holds that stream for `delay` microseconds (one small spinning kernel: a workgroup slot,
+// no bandwidth) and then copies the faces into the halo planes.  prev == next == this rank (a ring of one): sends and receives pair
+// up in issue order, RCCL's rule for two operations on the same peer.  Nothing synchronises with the host inside a rollout.
 //
-// It prints, for delay = 0 and for the budgeted link times of DESIGN.md 6 (2 MiB face pair at ~64 GB/s per direction: 30 us per
-// forward message; 1 MiB: 16 us per adjoint message), the time per fwd+bwd step of the PLAIN schedule (exchange between
+// It prints, for delay = 0 and for the budgeted link times of DESIGN.md 6 (2 MiB faces at ~64 GB/s per direction: 30 us per
+// forward exchange; 1 MiB: 16 us per adjoint exchange), the time per fwd+bwd step of the PLAIN schedule (exchange between
 // steps) and of the OVERLAP schedule (faces first, exchange on a side stream under the interior), and checks that both
 // schedules produce the same bits.  tests/test_slab_dist_gpu.py asserts what the numbers must show.
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude examples/slab_delay_ring.cpp -Lpercnn_amd/csrc -lpercnn_pi \
-//         -Wl,-rpath,$PWD/percnn_amd/csrc -o slab_delay_ring && ./slab_delay_ring [T=40] [reps=5] [fwd_us=30] [bwd_us=16] [halo=4]
+//         -Wl,-rpath,$PWD/percnn_amd/csrc -o slab_delay_ring && ./slab_delay_ring [T=40] [reps=5] [fwd_us=30] [bwd_us=16] [halo=4] [ring|peer]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -39,54 +38,63 @@ __global__ void wire_kernel(unsigned long long ticks)          // 100 MHz wall c
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
-struct Message { void* stage; size_t bytes; hipEvent_t arrived; };
+struct Message { void* stage; size_t bytes; };
+struct PendingRecv { void* buf; size_t bytes; hipStream_t st; };
 
+// The wire model: every operation of a group runs on the stream the caller hands in (RCCL's send / receive kernels do too).  A send
+// copies the face into a staging buffer; the receives are held back until group_end, which first holds the stream for `delay`
+// microseconds -- ONE interval per exchange: the two directions of a ring exchange use two links and travel concurrently -- and
+// then copies the faces into the halo planes.  No other stream, no event: what the caller's schedule does not overlap itself is
+// exposed in full, what it puts on a side stream runs beside its compute stream.
 struct Fabric {
     std::deque<Message> fifo;                                    // the ordered pair (me -> me)
+    std::vector<PendingRecv> pending;
     std::vector<void*> stages;                                   // staging buffers, reused round-robin
-    std::vector<hipEvent_t> events;
     size_t stage_bytes = 0;
     size_t next = 0;
-    hipStream_t link[2] = {nullptr, nullptr};                    // one "wire" per direction: the two faces of an exchange travel concurrently
-    int dir = 0;
     bool in_group = false;
-    double delay_us = 0.0;                                       // per message
+    double delay_us = 0.0;                                       // per exchange
     long sends = 0, recvs = 0, groups = 0, errors = 0;
 } fab;
 
 int g_start() { if (fab.in_group) { ++fab.errors; return 4; } fab.in_group = true; return 0; }
-int g_end() { if (!fab.in_group) { ++fab.errors; return 4; } fab.in_group = false; ++fab.groups; return 0; }
 
 int ring_send(const void* buf, size_t count, int dtype, int peer, void* comm, void* stream)
 {
     if (!fab.in_group || peer != 0 || comm != (void*)0xC0FFEE || dtype != 7) { ++fab.errors; return 4; }
     const size_t bytes = count * 4;
     if (bytes > fab.stage_bytes) { ++fab.errors; return 4; }
-    auto st = static_cast<hipStream_t>(stream);
-    const size_t slot = fab.next++ % fab.stages.size();
-    void* stage = fab.stages[slot];
-    hipEvent_t copied = fab.events[2 * slot], arrived = fab.events[2 * slot + 1];
-    if (hipMemcpyAsync(stage, buf, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
-    if (hipEventRecord(copied, st) != hipSuccess) return 1;
-    hipStream_t wire = fab.link[fab.dir++ & 1];
-    if (hipStreamWaitEvent(wire, copied, 0) != hipSuccess) return 1;
-    if (fab.delay_us > 0.0) hipLaunchKernelGGL(wire_kernel, dim3(1), dim3(64), 0, wire, (unsigned long long)(fab.delay_us * 100.0));
-    if (hipEventRecord(arrived, wire) != hipSuccess) return 1;
-    fab.fifo.push_back(Message{stage, bytes, arrived});
+    void* stage = fab.stages[fab.next++ % fab.stages.size()];
+    if (hipMemcpyAsync(stage, buf, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)) != hipSuccess) return 1;
+    fab.fifo.push_back(Message{stage, bytes});
     ++fab.sends;
     return 0;
 }
 
 int ring_recv(void* buf, size_t count, int dtype, int peer, void* comm, void* stream)
 {
-    if (!fab.in_group || peer != 0 || comm != (void*)0xC0FFEE || dtype != 7 || fab.fifo.empty()) { ++fab.errors; return 4; }
-    const Message m = fab.fifo.front();
-    fab.fifo.pop_front();
-    if (m.bytes != count * 4) { ++fab.errors; return 4; }
-    auto st = static_cast<hipStream_t>(stream);
-    if (hipStreamWaitEvent(st, m.arrived, 0) != hipSuccess) return 1;
-    if (hipMemcpyAsync(buf, m.stage, m.bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
-    ++fab.recvs;
+    if (!fab.in_group || peer != 0 || comm != (void*)0xC0FFEE || dtype != 7) { ++fab.errors; return 4; }
+    fab.pending.push_back(PendingRecv{buf, count * 4, static_cast<hipStream_t>(stream)});
+    return 0;
+}
+
+int g_end()
+{
+    if (!fab.in_group) { ++fab.errors; return 4; }
+    fab.in_group = false;
+    ++fab.groups;
+    if (fab.pending.empty()) return 0;
+    hipStream_t st = fab.pending.front().st;
+    if (fab.delay_us > 0.0) hipLaunchKernelGGL(wire_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)(fab.delay_us * 100.0));
+    for (const PendingRecv& r : fab.pending) {                   // receives pair up with the sends in issue order
+        if (fab.fifo.empty() || r.st != st) { ++fab.errors; return 4; }
+        const Message m = fab.fifo.front();
+        fab.fifo.pop_front();
+        if (m.bytes != r.bytes) { ++fab.errors; return 4; }
+        if (hipMemcpyAsync(r.buf, m.stage, m.bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
+        ++fab.recvs;
+    }
+    fab.pending.clear();
     return 0;
 }
 
@@ -103,6 +111,9 @@ int main(int argc, char** argv)
     const int reps = argc > 2 ? std::atoi(argv[2]) : 5;
     const double fwd_us = argc > 3 ? std::atof(argv[3]) : 30.0, bwd_us = argc > 4 ? std::atof(argv[4]) : 16.0;
     const int halo = argc > 5 ? std::atoi(argv[5]) : 4;             // forward: 2 MiB faces every two steps; adjoint: 1 MiB every step
+    // transport: "ring" = the RCCL-shaped callbacks above; "peer" = the peer mailboxes (pi_peer.h) through this device's own
+    // mailbox, the wire injected by the library's measurement option peer_wire_us (the put holds its arrival flag back)
+    const bool peer = argc > 6 && !std::strcmp(argv[6], "peer");
     const int64_t shape[3] = {32, 256, 256};                     // one rank's interior of 256^3 / 8
     const size_t plane = (size_t)shape[1] * shape[2], padded = (size_t)(shape[0] + 2 * halo) * plane, frame = 2 * padded;
     const int np = (int)percnn_pi_param_count(0);
@@ -138,13 +149,9 @@ int main(int argc, char** argv)
     }
     hipStream_t st;
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    CK(hipStreamCreateWithFlags(&fab.link[0], hipStreamNonBlocking));
-    CK(hipStreamCreateWithFlags(&fab.link[1], hipStreamNonBlocking));
     fab.stage_bytes = (size_t)8 * halo * plane * sizeof(float);   // both species of a face of `halo` planes, with room to spare
     fab.stages.resize(16);
-    fab.events.resize(32);
     for (auto& s : fab.stages) CK(hipMalloc(&s, fab.stage_bytes));
-    for (auto& e : fab.events) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     void* pack_stage;
     CK(hipMalloc(&pack_stage, fab.stage_bytes));
 
@@ -154,28 +161,47 @@ int main(int argc, char** argv)
     ring.comm = (void*)0xC0FFEE; ring.prev = 0; ring.next = 0; ring.dtype_f32 = 7; ring.dtype_f64 = 8;
     ring.group_start = g_start; ring.group_end = g_end; ring.send = ring_send; ring.recv = ring_recv;
     ring.peer = nullptr; ring.stage = pack_stage; ring.stage_bytes = fab.stage_bytes;
+    percnn_pi_peer_ring pr;
+    std::memset(&pr, 0, sizeof pr);
+    if (peer) {
+        void* box = nullptr;
+        const size_t slot = (size_t)2 * halo * plane * sizeof(float);
+        PK(percnn_pi_peer_box_alloc(&box, slot));
+        pr.my_box = pr.prev_box = pr.next_box = box;
+        pr.slot_bytes = slot;
+        ring.peer = &pr;
+    }
 
     hipEvent_t e0, e1, e2;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
     std::vector<float> ref_last(frame), ref_g0(frame), got(frame);
     bool have_ref = false;
     int mismatches = 0;
-    struct Row { const char* name; int overlap; double f_us, b_us; double fwd, bwd; };
-    std::vector<Row> rows = {{"plain, no wire", 0, 0.0, 0.0, 0, 0}, {"overlap, no wire", 1, 0.0, 0.0, 0, 0},
-                             {"plain, wire", 0, fwd_us, bwd_us, 0, 0}, {"overlap, wire", 1, fwd_us, bwd_us, 0, 0}};
+    struct Row { const char* name; int overlap; double f_us, b_us; double fwd, bwd; int fused; };
+    std::vector<Row> rows = {{"plain, no wire", 0, 0.0, 0.0, 0, 0, 0}, {"overlap, no wire", 1, 0.0, 0.0, 0, 0, 0},
+                             {"plain, wire", 0, fwd_us, bwd_us, 0, 0, 0}, {"overlap, wire", 1, fwd_us, bwd_us, 0, 0, 0}};
+    if (peer) {                                                  // the puts fused into the step / sweep launches (no side stream)
+        rows.push_back({"fused put, no wire", 0, 0.0, 0.0, 0, 0, 1});
+        rows.push_back({"fused put, wire", 0, fwd_us, bwd_us, 0, 0, 1});
+    }
     for (auto& row : rows) {
         std::vector<double> tf, tb;
         for (int rep = 0; rep < reps + 1; ++rep) {
             CK(hipMemsetAsync(pg, 0, np * sizeof(double), st));
             fab.delay_us = row.f_us;
+            if (peer) {
+                PK(percnn_pi_set_option("slab_fused_put", row.fused));
+                PK(percnn_pi_set_option("slab_fused_put_adj", row.fused));
+                PK(percnn_pi_set_option("peer_wire_us", (long)row.f_us));
+            }
             CK(hipEventRecord(e0, st));
             PK(percnn_pi_slab_rollout_fwd_f32(traj, dP, 0, 3, shape, halo, T, &ring, row.overlap, st));
             CK(hipEventRecord(e1, st));
             fab.delay_us = row.b_us;
+            if (peer) PK(percnn_pi_set_option("peer_wire_us", (long)row.b_us));
             PK(percnn_pi_slab_rollout_bwd_f32(traj, gtraj, adj, pg, ws, ws_bytes, dP, 0, 3, shape, halo, T, &ring, row.overlap, st));
             CK(hipEventRecord(e2, st));
             CK(hipStreamSynchronize(st));
-            CK(hipStreamSynchronize(fab.link[0])); CK(hipStreamSynchronize(fab.link[1]));
             float a, b;
             CK(hipEventElapsedTime(&a, e0, e1)); CK(hipEventElapsedTime(&b, e1, e2));
             if (rep) { tf.push_back(a * 1e3 / T); tb.push_back(b * 1e3 / T); }
@@ -193,10 +219,16 @@ int main(int argc, char** argv)
         have_ref = true;
     }
     if (fab.errors || !fab.fifo.empty()) { std::printf("ring protocol errors: %ld, unmatched sends: %zu\n", fab.errors, fab.fifo.size()); return 1; }
-    const double runs = 4.0 * (reps + 1);
+    if (peer) {
+        unsigned long long bad = 0;
+        PK(percnn_pi_peer_box_status(pr.my_box, (uint64_t*)&bad, st));
+        if (bad) { std::printf("a take timed out at exchange %llu\n", bad); return 1; }
+        PK(percnn_pi_set_option("peer_wire_us", 0));
+    }
+    const double runs = (double)rows.size() * (reps + 1);
     const double ex_f = fab.groups ? (double)fab.sends / 2.0 / runs / T : 0.0;   // exchanges per time step (fwd + bwd), two sends each
-    std::printf("slab 32x256x256 f32, halo %d, T = %d, ring of one; messages per fwd+bwd step: %.2f sends (%ld groups)\n", halo, T,
-                (double)fab.sends / runs / T, fab.groups);
+    std::printf("slab 32x256x256 f32, halo %d, T = %d, ring of one, transport %s; messages per fwd+bwd step: %.2f sends (%ld groups)\n", halo, T,
+                peer ? "peer mailboxes" : "ring callbacks", (double)fab.sends / runs / T, fab.groups);
     (void)ex_f;
     for (const auto& row : rows)
         std::printf("RESULT %-18s fwd_wire_us %5.1f bwd_wire_us %5.1f | fwd %7.2f bwd %7.2f total %7.2f us per time step\n", row.name, row.f_us, row.b_us,

@@ -84,6 +84,8 @@ struct Options {
     int l2_tile_kb = 128;   // direct 3D kernels: y-tile of a plane (both species, KiB) whose five stencil planes stay in the L2
                             // (0 = whole planes, the pre-round-2 order): see set_blockmap
     int l2_tile_min_kb = 1536;  // ... applied once four neighbour planes x two species exceed this many KiB (0: always; tests)
+    int peer_wire_us = 0;   // MEASUREMENT AID: every put over the peer mailboxes holds its arrival flag back this many microseconds
+                            // (pi_peer.h PeerXfer::wire_ticks): a stand-in for the link time of an xGMI hop when the ring runs to self
     int slab_put_blocks = 16; // ... workgroups per direction of that fused put (a multiple of 4)
     int slab_fused_put = 1; // native slab rollouts over the peer mailboxes: the step kernel that writes a frame about to be exchanged
                             // also carries its faces into the neighbours' mailboxes (pi_peer.h "put fused into the step kernel")
@@ -2060,6 +2062,7 @@ int peer_prepare(T* slab, const Problem& p, int width, percnn_pi_peer_ring* pr, 
     put.epoch = take.epoch = epoch;
     put.blocks_per_dir = bpd;
     take.blocks_per_dir = bpt;
+    put.wire_ticks = (unsigned)p.opt.peer_wire_us * 100u;
     put.mine = take.mine = static_cast<pi::PeerBox*>(pr->my_box);
     put.signal[0] = static_cast<pi::PeerBox*>(pr->next_box);
     put.signal[1] = static_cast<pi::PeerBox*>(pr->prev_box);
@@ -2924,6 +2927,11 @@ int apply_option(Options& o, const char* key, long value)
     if (!std::strcmp(key, "fwd_small_pause")) { if (value < 0 || value > 200) return PERCNN_PI_EINVAL; o.fwd_small_pause = (int)value; return 0; }
     if (!std::strcmp(key, "brick_xny")) { if (value < -1 || value > 8 || value == 3 || (value > 4 && value < 8)) return PERCNN_PI_EINVAL; o.brick_xny = (int)value; return 0; }
     if (!std::strcmp(key, "slab_fused_put")) { o.slab_fused_put = value != 0; return 0; }
+    if (!std::strcmp(key, "peer_wire_us")) {
+        if (value < 0 || value > 100000) return PERCNN_PI_EINVAL;
+        o.peer_wire_us = (int)value;
+        return 0;
+    }
     if (!std::strcmp(key, "slab_put_blocks")) {
         if (value < 4 || value > 256 || value % 4) return PERCNN_PI_EINVAL;
         o.slab_put_blocks = (int)value;

@@ -65,7 +65,18 @@ struct PeerXfer {
     PeerBox* mine;               // my mailbox (put: block counters; take: arrival flags, error word)
     unsigned long long epoch;
     int blocks_per_dir;
+    unsigned wire_ticks;         // MEASUREMENT AID (option peer_wire_us, default 0): the put holds the arrival flag back this many
+                                 // 10 ns ticks after its stores have left -- a stand-in for the link time of a real xGMI hop when
+                                 // the ring runs through one device's own mailbox (examples/slab_delay_ring.cpp)
 };
+
+// the last put workgroup of a direction, just before it announces the slot
+__device__ __forceinline__ void peer_wire_delay(unsigned ticks)
+{
+    if (ticks == 0u) return;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(8);
+}
 
 template <bool VEC>
 __global__ void __launch_bounds__(256) peer_put_kernel(PeerXfer x)
@@ -78,6 +89,7 @@ __global__ void __launch_bounds__(256) peer_put_kernel(PeerXfer x)
         const unsigned done = __hip_atomic_fetch_add(&x.mine->count[dir][0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (done == (unsigned)x.blocks_per_dir - 1) {
             __hip_atomic_store(&x.mine->count[dir][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            peer_wire_delay(x.wire_ticks);
             __hip_atomic_store(&x.signal[dir]->flag[dir][0], x.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -156,6 +168,7 @@ __device__ __forceinline__ void peer_put_block(const PeerPutFused& f, int b)
             __hip_atomic_store(&x.mine->face[dir][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // (a put that gave up does not announce the slot: the neighbour's take times out and poisons its halo)
             const bool clean = __hip_atomic_load(&x.mine->error[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+            peer_wire_delay(x.wire_ticks);
             if (ready && clean) __hip_atomic_store(&x.signal[dir]->flag[dir][0], x.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
