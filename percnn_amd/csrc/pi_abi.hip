@@ -684,6 +684,11 @@ int brick_nt_for(const Problem& p, int vec, bool adjoint = true)
     // (while at least one 512-lane workgroup per CU remains: thinner slabs need the workgroups more than the shorter halo)
     if (!adjoint && p.opt.brick_nt == 0 && p.hc == 0 && p.loss.mode == 0 && p.W / std::max(1, vec) == pi::BRICK_CPR_MAX &&
         p.n1 % 8 == 0 && p.n / (4 * 512) >= 256) return 512;
+    // Round 6: rows of 32 chunks (W = 128 float32) whose 512-lane two-plane bricks fill whole resident rounds (128^3: 512 bricks =
+    // two per CU): forward 8.24 -> 8.03 us per step (same box, interleaved rounds; profiles/r06_forward_128_options.txt).  The
+    // adjoint of that class is the resident sweep (pi_res3d.h) and, where that does not run, stays on 256 lanes (round 5: 17.8 -> 18.3)
+    if (!adjoint && p.opt.brick_nt == 0 && p.hc == 0 && p.loss.mode == 0 && p.W / std::max(1, vec) == 32 && p.n1 % 16 == 0 &&
+        p.n0 % 2 == 0 && p.n >= (int64_t(1) << 21) && ((p.n1 * 32 / 512) * (p.n0 / 2)) % 256 == 0) return 512;
     return (p.opt.brick_nt == 512 && p.hc == 0 && p.loss.mode == 0) ? 512 : 256;
 }
 

@@ -21,6 +21,7 @@
 //                            double accumulator `acc` of the packed block (percnn_pi_step_bwd_* accumulates) and returns no
 //                            gradient for P at all: the block's own node (functional.PackBlockFunction) delivers `acc` once
 //                            per backward pass -- T-1 cast / add launches and T allocations less than one gradient per node.
+#include <cstdlib>
 #include <torch/extension.h>
 #include <torch/library.h>
 #include <c10/hip/HIPStream.h>
@@ -397,6 +398,9 @@ struct BlockState : torch::CustomClassHolder {
     int64_t valid = -1;         // frames[0 .. valid] hold enqueued results
     int64_t next = -1;          // frame a hit returns
     int depth = 0;              // steps of the last speculative launch (0: none yet)
+    int64_t chain_len = 0;      // frames handed out since the current chain of steps began (a call that matched nothing begins one)
+    int64_t last_chain_len = 0; // ... of the chain before it: a training loop runs the same number of steps every iteration, so the
+                                // groups of this chain are cut to end where the last one ended (round 6)
     bool recorded = false;      // the frames beyond `next` belong to an autograd node
     c10::TensorImpl* last_out = nullptr;
     uint32_t last_version = 0;
@@ -414,7 +418,7 @@ struct BlockState : torch::CustomClassHolder {
     void forget()
     {
         frames.clear(); chunk = Tensor();
-        valid = next = -1; depth = 0; last_out = nullptr; p_impl = nullptr;
+        valid = next = -1; depth = 0; last_out = nullptr; p_impl = nullptr; chain_len = last_chain_len = 0;
     }
     Tensor frame_tensor(int64_t i) const                   // a NON-view tensor on the chunk's storage: own version counter
     {
@@ -433,6 +437,7 @@ struct BlockState : torch::CustomClassHolder {
         p_version = P._version();
         stream = st;
         next = i + 1;
+        ++chain_len;
         return out;
     }
     // frames of one allocation.  Every frame a caller keeps pins its whole chunk, so chunks stay small: 32 MiB at most, and TWO
@@ -500,7 +505,12 @@ struct BlockState : torch::CustomClassHolder {
         if (hit && next > valid) {
             // the input is the newest frame we hold: the loop pattern.  Compute the next `want` steps in one fused call.
             const int64_t L = chunk.size(0);
+            // 4, 8, 16, 16, ... steps per launch.  Deeper groups (32 / 64 steps, with or without the resident kernels behind them)
+            // were measured in round 6 and LOSE: the loop is bound by the 200 Python -> dispatcher calls, not by the 13 group
+            // launches, and longer sweeps made the backward slower (profiles/r06_step_loop_speculation_depth.txt).
+            // A chain as long as the previous one is not speculated past its end.
             int64_t want = depth == 0 ? 4 : (depth < 16 ? 2 * depth : 16);
+            if (last_chain_len > chain_len && want > last_chain_len - chain_len) want = last_chain_len - chain_len;
             int64_t from = next - 1;                         // frame index of h
             if (from + 1 >= L) {                             // chunk exhausted: its last frame becomes frame 0 of a new one
                 const Tensor keep = h;
@@ -521,6 +531,8 @@ struct BlockState : torch::CustomClassHolder {
         }
         // anything else: a plain single step, written into frame 1 of a fresh chunk so that the next call can recognise its output
         depth = 0;
+        if (chain_len > 1) last_chain_len = chain_len;      // (single calls that never chain leave the estimate alone)
+        chain_len = 0;
         Tensor out = record ? single_step_recorded(h, P, sink, this) : single_step(h, P);
         frames[1] = out;
         valid = 1;
@@ -638,17 +650,18 @@ struct GroupStepFn : public torch::autograd::Function<GroupStepFn> {
             pg = at::zeros({P.numel()}, h.options().dtype(at::kDouble));
         }
         // (short sweeps: the launch-per-group tile sweep; the persistent flavour pays a host handshake per call)
+        const char* sweep_opts = "tile_persist=0";
         int rc;
         if (h.scalar_type() == at::kFloat)
             rc = percnn_pi_rollout_bwd_top_f32(base.const_data_ptr<float>(), reinterpret_cast<const float*>(gptr),
                                                g_top.const_data_ptr<float>(), mask.data(), g_h.mutable_data_ptr<float>(),
                                                pg.mutable_data_ptr<double>(), ws.mutable_data_ptr(), nbytes, P.const_data_ptr<float>(), hc,
-                                               sh.ndim, sh.s, (int)T, "tile_persist=0", st);
+                                               sh.ndim, sh.s, (int)T, sweep_opts, st);
         else
             rc = percnn_pi_rollout_bwd_top_f64(base.const_data_ptr<double>(), reinterpret_cast<const double*>(gptr),
                                                g_top.const_data_ptr<double>(), mask.data(), g_h.mutable_data_ptr<double>(),
                                                pg.mutable_data_ptr<double>(), ws.mutable_data_ptr(), nbytes, P.const_data_ptr<double>(), hc,
-                                               sh.ndim, sh.s, (int)T, "tile_persist=0", st);
+                                               sh.ndim, sh.s, (int)T, sweep_opts, st);
         check(rc, "rollout_bwd");
         return {g_h, Tensor(), Tensor(), Tensor(), Tensor()};
     }
