@@ -7,7 +7,7 @@ import json, re, sys, os
 src = sys.argv[1] if len(sys.argv) > 1 else sorted(f for f in __import__("glob").glob("profiles/r*_final_pmc_fetch_write_summary.txt"))[-1]   # newest round
 rows = {}
 for line in open(src):
-    m = re.match(r"(\S+) T=(\d+) \| (\w+) \| n=(\d+) avg=([\d.]+).*\| (?:void )?pi::(\w+)(<[^(]*>)?", line)
+    m = re.match(r"(\S+) T=(\d+) \| (\w+) \| n=(\d+) avg=([\d.]+).*\| (?:void )?pi::(?:r3d::|s1::)?(\w+)(<[^(]*>)?", line)
     if m:
         wl, T, ctr, n, avg, kern, targs = m.groups()
         # the tile sweep exists in two flavours (last template argument): the default run launches the fused one
