@@ -2395,7 +2395,9 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
         PI_PSTAMP(4);
         // ---- P3: A_1 (b1 -> b0); level 1 is complete in b1 outside the block stored in P1 ----
         persist_fwd_store<T, K, BX, BY, NT, IDLE, false, 2>(b1, fr + frame_stride, g, ty0, tx0);
+        PI_PSTAMP(9);                                      // (debug builds: what a pass is made of -- tools/fwd_dev.hip)
         fwd_strip_geo<T, K, BX, BY>(b1, b0, P, tab_geo[3 * NT + tid]);
+        PI_PSTAMP(10);
         lds_barrier();
         PI_PSTAMP(5);
         // ---- P4: A_2 (b0 -> b1); level 2 is complete in b0 ----

@@ -138,6 +138,18 @@ int main(int argc, char** argv)
             }
             std::printf("\n");
         }
+        // what pass P3 (A_1: one strip on waves 0-3, the rest of level 1 stored by waves 4-7) is made of, per wave: us since the
+        // barrier that ended P2 -- frame stores issued | strip computed and stored to LDS | through the barrier
+        for (int w = 0; w < 8; ++w) {
+            std::printf("P3 wave %d:", w);
+            for (int i : {9, 10, 5}) {
+                std::vector<double> v;
+                for (int b = 0; b < 256; ++b) v.push_back((hs[(b * 8 + w) * 16 + i] - hs[(b * 8 + w) * 16 + 4]) * 0.01);
+                std::sort(v.begin(), v.end());
+                std::printf("  %s %.2f", i == 9 ? "stores issued" : i == 10 ? "strip done" : "barrier passed", v[128]);
+            }
+            std::printf("\n");
+        }
     }
 #endif
     // the same 250 launches as ONE graph launch (does a captured chain shorten the dependent-kernel boundary?)
