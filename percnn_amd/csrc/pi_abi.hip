@@ -1534,14 +1534,17 @@ hipError_t launch_fwd_persist(T* frame_t0, int ngroups, const T* P, const Proble
     const unsigned grid = (unsigned)((p.n0 / TILE_B) * g.tiles_x);
     // state buffers | publish / gather tables and 6 rows of strip geometry | abort word
     const size_t lds = pi::tile_state_bytes<T, K, TILE_B, TILE_B>() + (size_t)pi::PERSIST_SPLIT_TABLE_ROWS * NT * sizeof(int) + 16;
-    auto* k = pi::pi_fwd2d_persist_kernel<T, K, TILE_B, TILE_B, NT>;
+    // one workgroup per CU: the flavour that holds the parameter block in vector registers (142 of them); a grid that needs two
+    // per CU (option fwd_persist_per_cu = 2): the one that holds it in scalar registers (83 vector registers)
+    const int two = (int64_t)grid > (int64_t)device_cu_count() ? 1 : 0;
+    auto* k = two ? pi::pi_fwd2d_persist_kernel<T, K, TILE_B, TILE_B, NT, 2> : pi::pi_fwd2d_persist_kernel<T, K, TILE_B, TILE_B, NT, 1>;
     if (hipError_t e = allow_lds(k, lds)) return e;
-    static int resident[16] = {};                           // per device: workgroups that fit a CU (asked once; -1: none)
-    if (!resident[dev]) {
+    static int resident[16][2] = {};                        // per device and flavour: workgroups that fit a CU (asked once; -1: none)
+    if (!resident[dev][two]) {
         int nb = 0;
-        resident[dev] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, NT, lds) == hipSuccess && nb >= 1) ? nb : -1;
+        resident[dev][two] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, NT, lds) == hipSuccess && nb >= 1) ? nb : -1;
     }
-    if (resident[dev] < 0 || (int64_t)grid > (int64_t)device_cu_count() * resident[dev]) return hipErrorCooperativeLaunchTooLarge;
+    if (resident[dev][two] < 0 || (int64_t)grid > (int64_t)device_cu_count() * resident[dev][two]) return hipErrorCooperativeLaunchTooLarge;
     // per-device scratch: 256 B of sync words | granule outbox (allocated once, sized for this grid or larger)
     const size_t need = 256 + persist_outbox_bytes(p, (int)sizeof(T));
     unsigned char* scratch;

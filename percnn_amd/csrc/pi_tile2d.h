@@ -2221,6 +2221,76 @@ __device__ __forceinline__ void fwd_strip_geo(const T* cur, T* nxt, const T* __r
     }
 }
 
+// The same strip with ALL its LDS reads issued first (float32; round 6).  hipcc schedules the second species' stencil rows behind
+// the first species' arithmetic and store -- three load -> wait -> compute phases in a strip that is alone on its SIMD; with the
+// 14 reads of both species in flight at once the strip waits once.  Same operations in the same order per value as lds_star4 /
+// fwd_strip_geo: bit-identical.
+template <typename T, int LX>
+struct StarRows {
+    Pack<T, 2> l, r;         // x = -2, -1 | +4, +5 of the centre row
+    Pack<T, 4> m, n[4];      // the centre row's own four points; rows -2, -1, +1, +2
+    __device__ __forceinline__ void load(const T* c)
+    {
+        l = ld<T, 2>(c - 2); m = ld<T, 4>(c); r = ld<T, 2>(c + 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) n[t] = ld<T, 4>(c + (t < 2 ? t - 2 : t - 1) * LX);
+    }
+    __device__ __forceinline__ void star(const T* __restrict__ P, T (&ctr)[4], T (&lap)[4]) const
+    {
+        const T win[8] = {l.v[0], l.v[1], m.v[0], m.v[1], m.v[2], m.v[3], r.v[0], r.v[1]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ctr[i] = win[2 + i]; lap[i] = P[P_C0] * win[2 + i]; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const T w = P[P_TAPS + t];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lap[i] = fma_(w, n[t].v[i], lap[i]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = t < 2 ? t - 2 : t - 1;
+            const T w = P[P_TAPS + 4 + t];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lap[i] = fma_(w, win[2 + i + k], lap[i]);
+        }
+    }
+};
+
+template <typename T, int K, int BX, int BY>
+__device__ __forceinline__ void fwd_strip_geo_loads_first(const T* cur, T* nxt, const T* __restrict__ P, unsigned w)
+{
+    static_assert(sizeof(T) == 4, "float32 (lds_star4's 16-byte reads)");
+    using TL = Tile<K, BX, BY>;
+    if (__builtin_amdgcn_ballot_w64(((w >> 16) & 1u) != 0u) == 0ull) return;
+    const int off = (int)(w & 0xFFFFu);
+    StarRows<T, TL::LX> ru, rv;
+    ru.load(cur + off);
+    rv.load(cur + TL::PLANE + off);
+    __builtin_amdgcn_sched_barrier(0);                     // nothing is scheduled across: every read is issued before the arithmetic
+    const T dt = P[P_DT];
+    T u[4], v[4], lap[2][4];
+    ru.star(P, u, lap[0]);
+    rv.star(P, v, lap[1]);
+    T o[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        T rr[4];
+        const T* c = P + P_W + 10 * s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rr[i] = poly_r(c, u[i], v[i]);
+        const T coef = P[P_COEF + s];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const T lp = s == 0 ? lap[0][i] : lap[1][i];
+            const T res = coef * lp + rr[i];
+            const T inc = res * dt;
+            o[s][i] = (s == 0 ? u[i] : v[i]) + inc;
+        }
+    }
+    lds_store4(nxt + off, o[0]);
+    lds_store4(nxt + TL::PLANE + off, o[1]);
+}
+
 // the owned BX x BY region of a level buffer -> its frame, by the lanes [FIRST, NT).  WHICH 0: all of it; 1: the block of rows /
 // 16-byte chunks that covers what I_2 overwrites (level 1 only); 2: everything but that block
 template <typename T, int K, int BX, int BY, int NT, int FIRST, bool PADDED, int WHICH>
@@ -2263,14 +2333,74 @@ __device__ __forceinline__ void persist_fwd_store(const T* buf, T* __restrict__ 
 #define PI_FWD_PERSIST_WT 0             // frame stores of the resident forward: 0 = plain (write-back) stores.  Nobody reads a frame from
 #endif                                  // memory before the launch ends (the state lives in LDS, halos travel as granules), and write-through
                                         // stores compete with the latency-critical granule loads: 5.8 -> 5.45 us per group (tools/fwd_dev.hip)
+// The same with the lane's chunks located ONCE per rollout (round 6): which chunks a lane stores never changes, but the loop
+// above re-derived species / row / column, the early-block test and both addresses for every chunk of every level of every group
+// -- ~40 VALU instructions per chunk on the SIMD that a computing wave shares.  Here: LDS element offset + frame element offset per
+// chunk in registers, a store is a read, a 32-bit offset next to the frame's wave-uniform base, and the write.
+template <typename T, int K, int BX, int BY, int NT, int FIRST>
+struct FwdStoreMap {
+    using TL = Tile<K, BX, BY>;
+    static constexpr int VEC = vec_width<T>::value, BXV = BX / VEC, N = 2 * BY * BXV, LANES = NT - FIRST, CH = (N + LANES - 1) / LANES;
+    unsigned lds[CH], glb[CH];
+    unsigned flags;                                        // bit j: chunk j exists; bit 8 + j: it lies in the early block
+    __device__ __forceinline__ void init(const TileGeom& g, int ty0, int tx0)
+    {
+        constexpr int SIDE = BX - 4 * (K - 1), O2 = (BX - SIDE) / 2;
+        constexpr int R0 = O2, R1 = O2 + SIDE, C0 = O2 / VEC, C1 = (O2 + SIDE + VEC - 1) / VEC;
+        flags = 0u;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int i = (int)threadIdx.x - FIRST + j * LANES;
+            const bool have = (int)threadIdx.x >= FIRST && i < N;
+            const int ii = have ? i : 0;
+            const int sp = ii / (BY * BXV), r = ii - sp * (BY * BXV), y = r / BXV, c = r - y * BXV;
+            const bool early = y >= R0 && y < R1 && c >= C0 && c < C1;
+            lds[j] = (unsigned)(sp * TL::PLANE + (2 * K + y) * TL::LX + 2 * K + c * VEC);
+            glb[j] = (unsigned)((long)sp * g.ss + (long)(ty0 + y) * g.W + tx0 + c * VEC);
+            flags |= (have ? 1u : 0u) << j | (early ? 1u : 0u) << (8 + j);
+            asm volatile("" : "+v"(lds[j]), "+v"(glb[j]));
+        }
+        asm volatile("" : "+v"(flags));
+    }
+    template <bool PADDED, int WHICH>
+    __device__ __forceinline__ void store(const T* buf, T* __restrict__ dst) const
+    {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const bool early = (flags >> (8 + j)) & 1u;
+            if (!((flags >> j) & 1u) || (WHICH == 1 && !early) || (WHICH == 2 && early)) continue;
+            const T* src = buf + lds[j];
+            Pack<T, VEC> p;
+            if constexpr (PADDED && lds_pad0<T>::value != 0) {
+                const Pack<T, 2> a = ld<T, 2>(src), b = ld<T, 2>(src + 2);
+                p.v[0] = a.v[0]; p.v[1] = a.v[1]; p.v[2] = b.v[0]; p.v[3] = b.v[1];
+            } else {
+                p = ld<T, VEC>(src);
+            }
+#if PI_FWD_PERSIST_WT
+            st_frame_wt<T, VEC>(dst + glb[j], p);
+#else
+            *reinterpret_cast<Pack<T, VEC>*>(dst + glb[j]) = p;
+#endif
+        }
+    }
+};
+
+#ifndef PI_FWD_HOLD_P
+#define PI_FWD_HOLD_P 1                 // float32 resident forward: parameter block (1: vector, 2: scalar registers), strip geometry and
+                                        // frame-store map held in registers for the whole rollout; 0: round 5's body
+#endif
+#ifndef PI_FWD_LOADS_FIRST
+#define PI_FWD_LOADS_FIRST 0            // 1: fwd_strip_geo_loads_first (float32 only)
+#endif
 #ifndef PI_FWD_PERSIST_PAUSE
 #define PI_FWD_PERSIST_PAUSE 0          // s_sleep units before the request
 #endif
 
-template <typename T, int K, int BX, int BY, int NT>
+template <typename T, int K, int BX, int BY, int NT, int HOLDP = PI_FWD_HOLD_P>
 __global__ void __launch_bounds__(NT)
 pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngroups are written */, long frame_stride,
-                        const T* __restrict__ P, TileGeom g, PersistArgs pa)
+                        const T* __restrict__ P_in, TileGeom g, PersistArgs pa)
 {
     static_assert(BX == BY && K == 4 && BX == 32 && NT == 512, "32 x 32 tiles, four sub-steps, 8 waves");
     using TL = Tile<K, BX, BY>;
@@ -2317,12 +2447,52 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
     tile_load<T, K, BX, BY, NT>(frames, g, ty0, tx0, b0);
     __syncthreads();
     const int tid = (int)threadIdx.x;
+    // Round 6 (float32; the float64 instantiation keeps the round-5 body -- its registers are spoken for): what never changes
+    // during a rollout is held in registers instead of being re-derived / re-read in every pass.
+    //  * the 36 entries of the parameter block: behind the barriers' memory clobbers the compiler re-read them with scalar loads in
+    //    EVERY pass -- after the strip's table word had arrived, and once more in the middle of the strip: two scalar-memory
+    //    round trips on the critical path of a 154-instruction strip;
+    //  * the lane's six strip-geometry words (the sweep, at 251 registers, keeps its LDS table; the forward uses 78 of 256);
+    //  * where the lane's frame chunks lie (FwdStoreMap).
+    // 512^2 x 1000, tools/fwd_dev.hip, same box: 1.335 -> 1.283 (block) -> 1.260 (+ geometry) -> 1.248 us per step (+ store map);
+    // trajectory bit-identical.  Reading all of a strip's LDS rows before its arithmetic (fwd_strip_geo_loads_first) measured no
+    // gain on top (1.26 either way) and is not used.
+    // HOLDP 1: the block in vector registers (142 registers: one workgroup per CU); 2: in scalar registers (83 vector registers: the
+    // two-workgroups-per-CU mode of option fwd_persist_per_cu still fits; 1.29 instead of 1.26 us per step); 0: round 5's body
+    constexpr bool HOLD = HOLDP != 0 && sizeof(T) == 4;
+    T Ph[HOLD ? NPOLY : 1];
+    unsigned gw[HOLD ? 6 : 1];
+    FwdStoreMap<T, K, BX, BY, NT, IDLE> smap;
+    if constexpr (HOLD) {
+#pragma unroll
+        for (int i = 0; i < NPOLY; ++i) {
+            T x = P_in[i];
+            if constexpr (HOLDP == 2) asm volatile("" : "+s"(x));
+            else asm volatile("" : "+v"(x));
+            Ph[i] = x;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { gw[i] = tab_geo[i * NT + tid]; asm volatile("" : "+v"(gw[i])); }
+        smap.init(g, ty0, tx0);
+    }
+    const T* P = HOLD ? Ph : P_in;
+    auto geo = [&](int i) -> unsigned { if constexpr (HOLD) return gw[i]; else return tab_geo[i * NT + tid]; };
+#define PI_FWD_GEO(i) geo(i)
+#define PI_FWD_STORE(PADDED, WHICH, buf, dst)                                                                      \
+    do {                                                                                                           \
+        if constexpr (HOLD) smap.template store<PADDED, WHICH>(buf, dst);                                          \
+        else persist_fwd_store<T, K, BX, BY, NT, IDLE, PADDED, WHICH>(buf, dst, g, ty0, tx0);                       \
+    } while (0)
+    auto PI_FWD_STRIP = [&](const T* cur, T* nxt, const T* pp, unsigned w) {
+        if constexpr (PI_FWD_LOADS_FIRST != 0 && sizeof(T) == 4) fwd_strip_geo_loads_first<T, K, BX, BY>(cur, nxt, pp, w);
+        else fwd_strip_geo<T, K, BX, BY>(cur, nxt, pp, w);
+    };
     for (int grp = 0; grp < pa.ngroups; ++grp) {
         T* fr = frames + (long)grp * K * frame_stride;                    // this group's frame t: fr + m * frame_stride = level m
         PI_PSTAMP(0);
         // ---- P0: I_0 (b0 -> b1); the idle waves store level 4 of the previous group (= this group's level 0, complete in b0) ----
-        if (grp > 0) persist_fwd_store<T, K, BX, BY, NT, IDLE, true, 0>(b0, fr, g, ty0, tx0);
-        fwd_strip_geo<T, K, BX, BY>(b0, b1, P, tab_geo[0 * NT + tid]);
+        if (grp > 0) PI_FWD_STORE(true, 0, b0, fr);
+        PI_FWD_STRIP(b0, b1, P, PI_FWD_GEO(0));
         lds_barrier();
         PI_PSTAMP(1);
         const unsigned epoch = (unsigned)grp;
@@ -2343,8 +2513,8 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
         };
         if constexpr (PI_FWD_PERSIST_REQ_AFTER == 0) request();
         // ---- P1: I_1 (b1 -> b0 centre); the idle waves store the block of level 1 that I_2 will overwrite ----
-        persist_fwd_store<T, K, BX, BY, NT, IDLE, false, 1>(b1, fr + frame_stride, g, ty0, tx0);
-        fwd_strip_geo<T, K, BX, BY>(b1, b0, P, tab_geo[1 * NT + tid]);
+        PI_FWD_STORE(false, 1, b1, fr + frame_stride);
+        PI_FWD_STRIP(b1, b0, P, PI_FWD_GEO(1));
         PI_PSTAMP(2);
         if constexpr (PI_FWD_PERSIST_REQ_AFTER == 1) request();
         if (grp > 0) {
@@ -2390,24 +2560,24 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
         }
         PI_PSTAMP(3);
         // ---- P2: I_2 (b0 centre -> b1 centre) next to A_0 (b0 with its ring -> b1 outside I_0's square) ----
-        fwd_strip_geo<T, K, BX, BY>(b0, b1, P, tab_geo[2 * NT + tid]);
+        PI_FWD_STRIP(b0, b1, P, PI_FWD_GEO(2));
         lds_barrier();
         PI_PSTAMP(4);
         // ---- P3: A_1 (b1 -> b0); level 1 is complete in b1 outside the block stored in P1 ----
-        persist_fwd_store<T, K, BX, BY, NT, IDLE, false, 2>(b1, fr + frame_stride, g, ty0, tx0);
+        PI_FWD_STORE(false, 2, b1, fr + frame_stride);
         PI_PSTAMP(9);                                      // (debug builds: what a pass is made of -- tools/fwd_dev.hip)
-        fwd_strip_geo<T, K, BX, BY>(b1, b0, P, tab_geo[3 * NT + tid]);
+        PI_FWD_STRIP(b1, b0, P, PI_FWD_GEO(3));
         PI_PSTAMP(10);
         lds_barrier();
         PI_PSTAMP(5);
         // ---- P4: A_2 (b0 -> b1); level 2 is complete in b0 ----
-        persist_fwd_store<T, K, BX, BY, NT, IDLE, true, 0>(b0, fr + 2 * frame_stride, g, ty0, tx0);
-        fwd_strip_geo<T, K, BX, BY>(b0, b1, P, tab_geo[4 * NT + tid]);
+        PI_FWD_STORE(true, 0, b0, fr + 2 * frame_stride);
+        PI_FWD_STRIP(b0, b1, P, PI_FWD_GEO(4));
         lds_barrier();
         PI_PSTAMP(6);
         // ---- P5: I_3 + A_3 (b1 -> b0); level 3 is complete in b1 ----
-        persist_fwd_store<T, K, BX, BY, NT, IDLE, false, 0>(b1, fr + 3 * frame_stride, g, ty0, tx0);
-        fwd_strip_geo<T, K, BX, BY>(b1, b0, P, tab_geo[5 * NT + tid]);
+        PI_FWD_STORE(false, 0, b1, fr + 3 * frame_stride);
+        PI_FWD_STRIP(b1, b0, P, PI_FWD_GEO(5));
         lds_barrier();
         PI_PSTAMP(7);
         if (grp + 1 == pa.ngroups) {                       // the last level 4: stored by everybody
@@ -2429,6 +2599,9 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
 }
 
 // ------------------------------------------------------------------------------------------------
+#undef PI_FWD_GEO
+#undef PI_FWD_STORE
+
 // PERSISTENT FORWARD for the SMALL-TILE regime and ragged grids (round 5): grids that are not whole 32 x 32
 // tiles or have fewer than 16 of them -- the reference's own 100^2 x 200 rollout (train_2drd.py:162-190, :597-636) among them --
 // paid one launch per four steps: 5.0 us for sub-steps that take under two.  Here the T-step rollout is ONE launch of resident
