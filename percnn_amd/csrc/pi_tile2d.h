@@ -573,6 +573,8 @@ pi_fwd2d_tile_kernel(T* __restrict__ frames /* frame t; t+1..t+K are written */,
     PI_STAMP_PREV();
     PI_STAMP(0);
     tile_load<T, K, BX, BY, NT>(frames, g, ty0, tx0, b0);
+    // (holding the 36-entry block in registers across the sub-steps, which pays in the resident kernels, LOSES here: 6.68 -> 7.7 us
+    // per launch of four steps -- a short launch waits for the 36 scalar loads before its first sub-step instead of under it; round 6)
     __syncthreads();
     PI_STAMP(1);
     fwd_substeps<T, HC, K, BX, BY, NT, 0>(b0, b1, frames, frame_stride, g, ty0, tx0, P);
@@ -1519,7 +1521,7 @@ template <typename T, int K, int BX, int BY, int NT>
 __global__ void __launch_bounds__(NT)
 pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gframe_t, T* __restrict__ aframe_t,
                               long frame_stride, T* __restrict__ g_h0, double* __restrict__ partials, int np,
-                              const T* __restrict__ P, TileGeom g, PersistArgs pa)
+                              const T* __restrict__ P_in, TileGeom g, PersistArgs pa)
 {
     static_assert(sizeof(T) == 4 && K % 2 == 0, "float32; an even number of sub-steps leaves the state in buffer 0");
     using TL = Tile<K, BX, BY>;
@@ -1589,6 +1591,16 @@ pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restric
     double acc_c[2] = {0.0, 0.0};
     bool failed = false;
     TileMoments<T, false> mom;
+    // (round 6, as in the resident forwards: the parameter block held in registers -- behind the barriers' memory clobbers every
+    // sub-step re-read what JacPairs does not hold with scalar loads on its critical path; 191 -> ~230 of 256 registers)
+    T Ph[NPOLY];
+#pragma unroll
+    for (int i = 0; i < NPOLY; ++i) {
+        T x = P_in[i];
+        asm volatile("" : "+v"(x));
+        Ph[i] = x;
+    }
+    const T* P = Ph;
     JacPairs<T> jp;
     jac_pairs_load<T>(jp, P);
     for (int grp = 0; grp < pa.ngroups; ++grp) {
@@ -2447,8 +2459,7 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
     tile_load<T, K, BX, BY, NT>(frames, g, ty0, tx0, b0);
     __syncthreads();
     const int tid = (int)threadIdx.x;
-    // Round 6 (float32; the float64 instantiation keeps the round-5 body -- its registers are spoken for): what never changes
-    // during a rollout is held in registers instead of being re-derived / re-read in every pass.
+    // Round 6: what never changes during a rollout is held in registers instead of being re-derived / re-read in every pass.
     //  * the 36 entries of the parameter block: behind the barriers' memory clobbers the compiler re-read them with scalar loads in
     //    EVERY pass -- after the strip's table word had arrived, and once more in the middle of the strip: two scalar-memory
     //    round trips on the critical path of a 154-instruction strip;
@@ -2459,7 +2470,7 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
     // gain on top (1.26 either way) and is not used.
     // HOLDP 1: the block in vector registers (142 registers: one workgroup per CU); 2: in scalar registers (83 vector registers: the
     // two-workgroups-per-CU mode of option fwd_persist_per_cu still fits; 1.29 instead of 1.26 us per step); 0: round 5's body
-    constexpr bool HOLD = HOLDP != 0 && sizeof(T) == 4;
+    constexpr bool HOLD = HOLDP != 0;                       // (float64: 101 -> ~190 of 256 registers)
     T Ph[HOLD ? NPOLY : 1];
     unsigned gw[HOLD ? 6 : 1];
     FwdStoreMap<T, K, BX, BY, NT, IDLE> smap;
@@ -2615,7 +2626,7 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
 template <typename T, int K, int BX, int BY, int NT>
 __global__ void __launch_bounds__(NT)
 pi_fwd2d_persist_small_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngroups are written */, long frame_stride,
-                              const T* __restrict__ P, TileGeom g, PersistArgs pa)
+                              const T* __restrict__ P_in, TileGeom g, PersistArgs pa)
 {
     static_assert(sizeof(T) == 4 && K % 2 == 0, "float32; an even number of sub-steps leaves the state in buffer 0");
     using TL = Tile<K, BX, BY>;
@@ -2679,6 +2690,16 @@ pi_fwd2d_persist_small_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K
     tile_load<T, K, BX, BY, NT>(frames, g, ty0, tx0, b0);
     __syncthreads();
     const int tid = (int)threadIdx.x;
+    // (round 6, as in pi_fwd2d_persist_kernel: the parameter block held in registers -- behind the barriers' memory clobbers every
+    // sub-step re-read it with scalar loads on its critical path; 85 -> ~125 of this kernel's 256 registers)
+    T Ph[NPOLY];
+#pragma unroll
+    for (int i = 0; i < NPOLY; ++i) {
+        T x = P_in[i];
+        asm volatile("" : "+v"(x));
+        Ph[i] = x;
+    }
+    const T* P = Ph;
     for (int grp = 0; grp < pa.ngroups; ++grp) {
         T* fr = frames + (long)grp * K * frame_stride;                    // this group's frame t
         const bool last = grp + 1 == pa.ngroups;
