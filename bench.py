@@ -47,11 +47,13 @@ HBM_COPY_CEILING_GBS = 6290.0    # the same table's measured float4-copy ceiling
 # what the SQ / TCP / TCC counters say limits each kernel (shares of a resident wave's life: issuing / stalled at issue / parked at
 # barriers, polls and waitcnts).  The roofline the path is priced against stays HBM; this is the honest "why not".
 LIMITERS = {
-    "pi_adj2d_persist_split_kernel": "instruction issue of one wave per SIMD + hand-over waits: issue 0.29 / stall 0.28 / parked 0.44, "
-                                     "VALU active 18 % (profiles/r05_counters_summary.txt)",
+    "pi_adj2d_persist_split_kernel": "VALU instruction issue: 22.9 wave-strips x ~600 instructions on 4 SIMDs = 7.0 of a group's 7.9 us, 245 VGPRs / "
+                                     "106 SGPRs; round-5 counters: issue 0.29 / stall 0.28 / parked 0.44 (profiles/r06_granule_pairs.txt, "
+                                     "r05_counters_summary.txt)",
     "pi_adj2d_persist_kernel": "hand-over waits (profiles/r04_persistent_split_timelines.txt)",
-    "pi_fwd2d_persist_kernel": "waiting, not issuing: parked 0.64 (six barrier intervals + a granule round trip per 4 steps), issue 0.25, "
-                               "VALU active 15 % (profiles/r05_counters_summary.txt)",
+    "pi_fwd2d_persist_kernel": "latency: a pass is ONE 154-instruction strip per wave taking ~0.65 us (LDS round trips, a SIMD shared with the "
+                               "frame-storing wave); six passes + a 0.4 us ring wait per 4 steps; round-5 counters: parked 0.64, issue 0.25 "
+                               "(profiles/r06_granule_pairs.txt, r05_counters_summary.txt)",
     "pi_fwd2d_persist_small_kernel": "the un-hidden hand-over: 1.6 us round trip per 4 steps (profiles/r05_small_tile_resident_forward.txt)",
     "pi_adj2d_persist_small_kernel": "hand-over + one wave per SIMD (profiles/r05_counters_summary.txt)",
     "pi_fwd2d_tile_kernel": "launch boundary 2.0 us + cold window 1.4 us per 4 steps: parked 0.60 (profiles/r05_counters_summary.txt)",
