@@ -51,9 +51,9 @@ LIMITERS = {
                                      "106 SGPRs; round-5 counters: issue 0.29 / stall 0.28 / parked 0.44 (profiles/r06_granule_pairs.txt, "
                                      "r05_counters_summary.txt)",
     "pi_adj2d_persist_kernel": "hand-over waits (profiles/r04_persistent_split_timelines.txt)",
-    "pi_fwd2d_persist_kernel": "latency: a pass is ONE 154-instruction strip per wave taking ~0.65 us (LDS round trips, a SIMD shared with the "
-                               "frame-storing wave); six passes + a 0.4 us ring wait per 4 steps; round-5 counters: parked 0.64, issue 0.25 "
-                               "(profiles/r06_granule_pairs.txt, r05_counters_summary.txt)",
+    "pi_fwd2d_persist_kernel": "LDS latency at low occupancy: a pass is ONE 128-instruction strip per wave (0.19 us of VALU issue) that takes "
+                               "0.45 us alone on its CU and 0.8 us next to three others (VALU active 22 %, waiting 67 %); six passes + a 0.4 us "
+                               "ring wait per 4 steps (profiles/r06_granule_pairs.txt)",
     "pi_fwd2d_persist_small_kernel": "the un-hidden hand-over: 1.6 us round trip per 4 steps (profiles/r05_small_tile_resident_forward.txt)",
     "pi_adj2d_persist_small_kernel": "hand-over + one wave per SIMD (profiles/r05_counters_summary.txt)",
     "pi_fwd2d_tile_kernel": "launch boundary 2.0 us + cold window 1.4 us per 4 steps: parked 0.60 (profiles/r05_counters_summary.txt)",
