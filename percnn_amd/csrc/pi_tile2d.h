@@ -2345,6 +2345,75 @@ __device__ __forceinline__ void persist_fwd_store(const T* buf, T* __restrict__ 
 #define PI_FWD_PERSIST_WT 0             // frame stores of the resident forward: 0 = plain (write-back) stores.  Nobody reads a frame from
 #endif                                  // memory before the launch ends (the state lives in LDS, halos travel as granules), and write-through
                                         // stores compete with the latency-critical granule loads: 5.8 -> 5.45 us per group (tools/fwd_dev.hip)
+// HALF STRIPS (float32, round 6).  The annulus passes A_0 .. A_3 of a group are the loop ring -> A_0 .. A_3 -> publish -> flight that
+// sets the resident forward's pace, and each of them is ONE four-point strip per wave on four to six of the eight waves: 128
+// instructions (0.19 us of VALU issue) that take 0.56 us because the wave waits for its own LDS round trips with nobody to
+// overlap them (tools/ubench/strip_ubench.hip, profiles/r06_granule_pairs.txt).  Cut in two, a pass's strips occupy all eight
+// waves -- both waves of a SIMD -- with half the dependent work each.  Same operations in the same order per point: bit-identical.
+// Geometry word of half-strip h (strip h / 2 of the pass's annulus, points 2 (h % 2) .. + 1): bits 0-15 LDS offset, 16 live.
+template <int K, int BX, int BY, int M>
+__device__ __forceinline__ unsigned fwd_half_word(int h)
+{
+    using TL = Tile<K, BX, BY>;
+    using SM = StripMap<K, BX, BY, M, PART_ANN>;
+    constexpr int O = 2 * (M + 1);
+    const bool live = h >= 0 && (h >> 1) < SM::N;
+    int idx = live ? (h >> 1) : 0;
+    int ry, rc;
+    SM::locate(idx, ry, rc);
+    const int ly = ry + O, lx = 4 * rc + O + 2 * (h & 1);
+    return (unsigned)(ly * TL::LX + lx) | (live ? 1u << 16 : 0u);
+}
+
+template <typename T, int K, int BX, int BY>
+__device__ __forceinline__ void fwd_half_strip_geo(const T* cur, T* nxt, const T* __restrict__ P, unsigned w)
+{
+    static_assert(sizeof(T) == 4, "float32");
+    using TL = Tile<K, BX, BY>;
+    constexpr int LX = TL::LX;
+    if (__builtin_amdgcn_ballot_w64(((w >> 16) & 1u) != 0u) == 0ull) return;       // whole waves without a half-strip in this pass
+    const int off = (int)(w & 0xFFFFu);
+    const T dt = P[P_DT];
+    T ctr[2][2], lap[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const T* c = cur + s * TL::PLANE + off;
+        const Pack<T, 2> a = ld<T, 2>(c - 2), m = ld<T, 2>(c), b = ld<T, 2>(c + 2);
+        const T win[6] = {a.v[0], a.v[1], m.v[0], m.v[1], b.v[0], b.v[1]};         // x = -2 .. +3 of the centre row
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { ctr[s][i] = win[2 + i]; lap[s][i] = P[P_C0] * win[2 + i]; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = t < 2 ? t - 2 : t - 1;
+            const Pack<T, 2> n = ld<T, 2>(c + k * LX);
+            const T wt = P[P_TAPS + t];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lap[s][i] = fma_(wt, n.v[i], lap[s][i]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = t < 2 ? t - 2 : t - 1;
+            const T wt = P[P_TAPS + 4 + t];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lap[s][i] = fma_(wt, win[2 + i + k], lap[s][i]);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const T* cf = P + P_W + 10 * s;
+        const T coef = P[P_COEF + s];
+        Pack<T, 2> o;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const T rr = poly_r(cf, ctr[0][i], ctr[1][i]);
+            const T res = coef * lap[s][i] + rr;
+            const T inc = res * dt;
+            o.v[i] = ctr[s][i] + inc;
+        }
+        st<T, 2>(nxt + s * TL::PLANE + off, o);
+    }
+}
+
 // The same with the lane's chunks located ONCE per rollout (round 6): which chunks a lane stores never changes, but the loop
 // above re-derived species / row / column, the early-block test and both addresses for every chunk of every level of every group
 // -- ~40 VALU instructions per chunk on the SIMD that a computing wave shares.  Here: LDS element offset + frame element offset per
@@ -2398,6 +2467,11 @@ struct FwdStoreMap {
     }
 };
 
+#ifndef PI_FWD_HALF_STRIPS
+#define PI_FWD_HALF_STRIPS 0            // float32 resident forward: the annulus passes on two-point half-strips (all eight waves).
+                                        // Measured (round 6): bit-identical, 1.26 -> 1.24 us per step -- a half-strip takes as long as a strip
+                                        // (0.52-0.56 us: the pass is LDS round trips, not arithmetic).  Off.
+#endif
 #ifndef PI_FWD_HOLD_P
 #define PI_FWD_HOLD_P 1                 // float32 resident forward: parameter block (1: vector, 2: scalar registers), strip geometry and
                                         // frame-store map held in registers for the whole rollout; 0: round 5's body
@@ -2472,8 +2546,11 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
     // two-workgroups-per-CU mode of option fwd_persist_per_cu still fits; 1.29 instead of 1.26 us per step); 0: round 5's body
     constexpr bool HOLD = HOLDP != 0;                       // (float64: 101 -> ~190 of 256 registers)
     T Ph[HOLD ? NPOLY : 1];
-    unsigned gw[HOLD ? 6 : 1];
+    constexpr bool HALF = HOLD && PI_FWD_HALF_STRIPS != 0 && sizeof(T) == 4;
+    unsigned gw[HOLD ? 7 : 1];
     FwdStoreMap<T, K, BX, BY, NT, IDLE> smap;
+    FwdStoreMap<T, K, BX, BY, NT, 0> smap_all;              // (half-strip passes: every wave computes, every lane stores one chunk)
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     if constexpr (HOLD) {
 #pragma unroll
         for (int i = 0; i < NPOLY; ++i) {
@@ -2483,7 +2560,19 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
             Ph[i] = x;
         }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { gw[i] = tab_geo[i * NT + tid]; asm volatile("" : "+v"(gw[i])); }
+        for (int i = 0; i < 6; ++i) gw[i] = tab_geo[i * NT + tid];
+        gw[6] = 0u;
+        if constexpr (HALF) {
+            // P2: I_2 on waves 0-1 (four-point strips), A_0 = 576 half-strips on the 384 lanes of waves 2-7 in two rounds (gw[2], gw[6]);
+            // P3: A_1 = 512 half-strips; P4: A_2 = 448; P5: I_3 on wave 0, A_3 = 384 half-strips on waves 1-6
+            if (tid >= 128) { gw[2] = fwd_half_word<K, BX, BY, 0>(tid - 128); gw[6] = fwd_half_word<K, BX, BY, 0>(tid - 128 + 384); }
+            gw[3] = fwd_half_word<K, BX, BY, 1>(tid);
+            gw[4] = fwd_half_word<K, BX, BY, 2>(tid);
+            if (tid >= 64) gw[5] = fwd_half_word<K, BX, BY, 3>(tid - 64);
+            smap_all.init(g, ty0, tx0);
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(gw[i]));
         smap.init(g, ty0, tx0);
     }
     const T* P = HOLD ? Ph : P_in;
@@ -2497,6 +2586,9 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
     auto PI_FWD_STRIP = [&](const T* cur, T* nxt, const T* pp, unsigned w) {
         if constexpr (PI_FWD_LOADS_FIRST != 0 && sizeof(T) == 4) fwd_strip_geo_loads_first<T, K, BX, BY>(cur, nxt, pp, w);
         else fwd_strip_geo<T, K, BX, BY>(cur, nxt, pp, w);
+    };
+    auto half_strip = [&](const T* cur, T* nxt, unsigned w) {
+        if constexpr (HALF) fwd_half_strip_geo<T, K, BX, BY>(cur, nxt, P, w);
     };
     for (int grp = 0; grp < pa.ngroups; ++grp) {
         T* fr = frames + (long)grp * K * frame_stride;                    // this group's frame t: fr + m * frame_stride = level m
@@ -2571,24 +2663,37 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
         }
         PI_PSTAMP(3);
         // ---- P2: I_2 (b0 centre -> b1 centre) next to A_0 (b0 with its ring -> b1 outside I_0's square) ----
-        PI_FWD_STRIP(b0, b1, P, PI_FWD_GEO(2));
+        if constexpr (HALF) {
+            if (wave_id < 2) PI_FWD_STRIP(b0, b1, P, gw[2]);
+            else { half_strip(b0, b1, gw[2]); half_strip(b0, b1, gw[6]); }
+        } else {
+            PI_FWD_STRIP(b0, b1, P, PI_FWD_GEO(2));
+        }
         lds_barrier();
         PI_PSTAMP(4);
         // ---- P3: A_1 (b1 -> b0); level 1 is complete in b1 outside the block stored in P1 ----
-        PI_FWD_STORE(false, 2, b1, fr + frame_stride);
+        if constexpr (HALF) smap_all.template store<false, 2>(b1, fr + frame_stride);
+        else PI_FWD_STORE(false, 2, b1, fr + frame_stride);
         PI_PSTAMP(9);                                      // (debug builds: what a pass is made of -- tools/fwd_dev.hip)
-        PI_FWD_STRIP(b1, b0, P, PI_FWD_GEO(3));
+        if constexpr (HALF) half_strip(b1, b0, gw[3]);
+        else PI_FWD_STRIP(b1, b0, P, PI_FWD_GEO(3));
         PI_PSTAMP(10);
         lds_barrier();
         PI_PSTAMP(5);
         // ---- P4: A_2 (b0 -> b1); level 2 is complete in b0 ----
-        PI_FWD_STORE(true, 0, b0, fr + 2 * frame_stride);
-        PI_FWD_STRIP(b0, b1, P, PI_FWD_GEO(4));
+        if constexpr (HALF) { smap_all.template store<true, 0>(b0, fr + 2 * frame_stride); half_strip(b0, b1, gw[4]); }
+        else { PI_FWD_STORE(true, 0, b0, fr + 2 * frame_stride); PI_FWD_STRIP(b0, b1, P, PI_FWD_GEO(4)); }
         lds_barrier();
         PI_PSTAMP(6);
         // ---- P5: I_3 + A_3 (b1 -> b0); level 3 is complete in b1 ----
-        PI_FWD_STORE(false, 0, b1, fr + 3 * frame_stride);
-        PI_FWD_STRIP(b1, b0, P, PI_FWD_GEO(5));
+        if constexpr (HALF) {
+            smap_all.template store<false, 0>(b1, fr + 3 * frame_stride);
+            if (wave_id < 1) PI_FWD_STRIP(b1, b0, P, gw[5]);
+            else half_strip(b1, b0, gw[5]);
+        } else {
+            PI_FWD_STORE(false, 0, b1, fr + 3 * frame_stride);
+            PI_FWD_STRIP(b1, b0, P, PI_FWD_GEO(5));
+        }
         lds_barrier();
         PI_PSTAMP(7);
         if (grp + 1 == pa.ngroups) {                       // the last level 4: stored by everybody
