@@ -681,6 +681,13 @@ def main():
             out["slab_3d"] = slab_extra_isolated(a, dev, dist, rank, world, local_rank)
         except Exception as e:                       # keep the headline number whatever happens here
             out["slab_3d"] = {"error": repr(e)[:300]}
+    # what the schedules do against a wire: measured once with an injected link time, committed, quoted here
+    wf = os.path.join(ROOT, "profiles", "slab_injected_wire.json")
+    if isinstance(out.get("slab_3d"), dict) and os.path.exists(wf):
+        try:
+            out["slab_3d"]["injected_wire"] = json.load(open(wf))
+        except Exception:
+            pass
     if world > 1:
         promote_sharded_headline(out, world)
     if dist is not None:
