@@ -2467,6 +2467,10 @@ struct FwdStoreMap {
     }
 };
 
+#ifndef PI_FWD_I2_EARLY
+#define PI_FWD_I2_EARLY 0               // resident forward: the pyramid's third level under the ring's flight instead of next to A_0
+                                        // (round 6: bit-identical, 1.26 -> 1.27-1.32 us per step: the extra barrier costs what P2 gains).  Off.
+#endif
 #ifndef PI_FWD_HALF_STRIPS
 #define PI_FWD_HALF_STRIPS 0            // float32 resident forward: the annulus passes on two-point half-strips (all eight waves).
                                         // Measured (round 6): bit-identical, 1.26 -> 1.24 us per step -- a half-strip takes as long as a strip
@@ -2620,6 +2624,12 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
         PI_FWD_STRIP(b1, b0, P, PI_FWD_GEO(1));
         PI_PSTAMP(2);
         if constexpr (PI_FWD_PERSIST_REQ_AFTER == 1) request();
+        if constexpr (PI_FWD_I2_EARLY != 0) {
+            // I_2 (waves 0-1; it needs I_1 only) while the ring is still in flight, instead of next to A_0 behind it: P2 is then the
+            // annulus alone.  One more barrier; b1's centre is free (its early block of level 1 was stored during P1).
+            lds_barrier();
+            if (wave_id < 2) PI_FWD_STRIP(b0, b1, P, PI_FWD_GEO(2));
+        }
         if (grp > 0) {
             int gl[NGAT];
 #pragma unroll
@@ -2666,6 +2676,8 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
         if constexpr (HALF) {
             if (wave_id < 2) PI_FWD_STRIP(b0, b1, P, gw[2]);
             else { half_strip(b0, b1, gw[2]); half_strip(b0, b1, gw[6]); }
+        } else if constexpr (PI_FWD_I2_EARLY != 0) {
+            if (wave_id >= 2) PI_FWD_STRIP(b0, b1, P, PI_FWD_GEO(2));
         } else {
             PI_FWD_STRIP(b0, b1, P, PI_FWD_GEO(2));
         }
