@@ -1179,6 +1179,29 @@ def test_resident_3d_sweep_equals_brick_sweep(shape, T, hip_device):
     assert torch.equal(c0, d0) and _lib.persist_status()["launches"] == n0 + (4 if shape == (32, 32, 64) else 3)
 
 
+@pytest.mark.parametrize("shape", [(112, 128, 128), (96, 128, 128), (128, 128, 96), (128, 112, 128)])
+def test_resident_3d_sweep_on_the_neighbours_of_128_cubed(shape, hip_device):
+    """The default takes the resident sweep from 3/4 of the CUs on (192 .. 256 blocks of 16 x 16 x 32): block counts that are not
+    powers of two pick other XCD region maps (7 x 8 x 4 -> 1 x 2 x 4, 8 x 8 x 3 -> 2 x 4 x 1, ...) or none; dL/dh0 bit for bit the
+    brick sweep's, gradient sums to float32 summation round-off, with and without a frame mask."""
+    import percnn_amd as pa
+    from percnn_amd import _lib
+    T = 17
+    assert _lib.rollout_plan(0, shape, 4)["bwd_persistent"]
+    rs = np.random.RandomState(29)
+    P = dev_t(random_block(0, 3, np.float32, 37, scale=0.1), hip_device)
+    traj = torch.empty((T + 1, 2) + shape, dtype=torch.float32, device=hip_device)
+    traj[0] = dev_t(rs.uniform(0, 1, (2,) + shape).astype(np.float32), hip_device)
+    pa.rollout_fwd_(traj, P)
+    g = torch.randn(traj.shape, device=hip_device, generator=torch.Generator(device=hip_device).manual_seed(7)) / traj[0].numel()
+    n0 = _lib.persist_status()["launches"]
+    for mask in (None, [t % 3 != 2 for t in range(T + 1)]):
+        a0, ag = pa.rollout_bwd(traj, g, P, frame_mask=mask)
+        b0, bg = pa.rollout_bwd(traj, g, P, frame_mask=mask, options={"res3d": 0})
+        assert torch.equal(a0, b0) and rel_l2(ag.cpu().numpy(), bg.cpu().numpy()) < 2e-6
+    assert _lib.persist_status()["launches"] == n0 + 2 and _lib.persist_status()["aborts"] == 0
+
+
 def test_resident_3d_sweep_is_the_default_at_128_cubed(hip_device):
     """configs[3]'s grid: 256 blocks = one per CU, XCD regions 2 x 2 x 2; the default backward takes the resident sweep and its
     dL/dh0 is the brick sweep's bit for bit (which the C oracle pins at this size in test_full_size_step_bitwise...)."""
