@@ -235,8 +235,8 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *                  touched <= 2.5 MiB; among the maps that fit, the smallest halo share), 1 = contiguous plane ranges, 2 / 4 / 8 =
  *                  force that many row strips, -1 = round 4's rule for forward steps of >= 8 M points.  Pure placement.
  *   "brick_wide"   1 (default): 3D rows of 65 .. 128 sixteen-byte chunks on 512-lane bricks where they win; 0: direct kernels
- *   "res3d"        1 (default): 3D float32 pre-contracted blocks on grids of whole 16 x 16 x 32 blocks with at least 3/4 of the CUs
- *                  busy and at most one block per CU (128^3 = 256 blocks and its neighbours), T >= 16: the whole reverse sweep of a
+ *   "res3d"        1 (default): 3D float32 pre-contracted blocks on grids of whole 16 x 16 x 32 blocks with at least 7/8 of the CUs
+ *                  busy and at most one block per CU (224 .. 256 blocks: 128^3, 112 x 128^2), T >= 16: the whole reverse sweep of a
  *                  rollout backward (train_3drd.py:408) as ONE launch of resident workgroups with the adjoint state in LDS
  *                  (pi_adj3d_resident_kernel, round 6; dL/dh0 is the brick sweep's bit for bit; residency check, abort -> the
  *                  launch-per-step bricks and "persist_reset" as "tile_persist", which also gates it; 21 MB of the per-device

@@ -105,7 +105,7 @@ struct Options {
                             // size (brick_ok), 2 whenever eligible
     int res3d = 1;          // 3D float32 pre-contracted blocks: the whole reverse sweep of a rollout as ONE launch of resident
                             // workgroups with the adjoint state in LDS (pi_res3d.h; round 6): 0 never, 1 where it measured faster than
-                            // the brick sweep (whole 16 x 16 x 32 blocks, at least 3/4 of the CUs busy: 128^3 and its neighbours), 2 on
+                            // the brick sweep (whole 16 x 16 x 32 blocks, at least 7/8 of the CUs busy: 128^3, 112 x 128^2), 2 on
                             // every grid of whole blocks that fits the device (tests)
     int brick_rz = 0;       // planes per brick (1, 2, 4; 0 = by size)
     int brick_xcd = 1;      // brick kernels: XCD regions split in y as well as in z where the counts divide (BrickGeom::xny):
@@ -1345,7 +1345,9 @@ bool res3d_plan(const Problem& p, int nsteps, size_t elem, Res3dPlan& pl)
     if (pl.gz < 2 || pl.gy < 2 || pl.gx < 2) return false;              // (a block that is its own neighbour: never exercised)
     const int cus = device_cu_count();
     if (cus <= 0 || pl.nblk > cus) return false;
-    if (p.opt.res3d == 1 && pl.nblk * 4 < cus * 3) return false;         // too few CUs busy: the brick sweep wins
+    // the resident sweep takes ~15 us per step whatever the block count (a block's step + one hand-over); the bricks scale with the
+    // points: 192 blocks 14.5 (bricks) vs 14.9, 224 blocks 16.9 vs 15.2, 256 blocks 17.3 vs 14.8 (profiles/r06_forward_128_options.txt)
+    if (p.opt.res3d == 1 && pl.nblk * 8 < cus * 7) return false;         // fewer than 7/8 of the CUs busy: the brick sweep wins
     // XCD regions (workgroup b runs on XCD b % 8 and takes a block of region b % 8): the split of 8 = rz * ry * rx that divides
     // the block counts with the fewest faces between regions; none divides: linear order, every face written through
     pl.rz = pl.ry = pl.rx = 1;
