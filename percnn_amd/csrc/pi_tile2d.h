@@ -15,6 +15,7 @@
 // from HBM (they need no neighbours); diffusion-coefficient gradients are accumulated in registers
 // across the K sub-steps and reduced once per launch.
 #pragma once
+#include <type_traits>
 #include "pi_device.h"
 
 namespace pi {
@@ -326,6 +327,29 @@ template <typename T, int LX, int FLIP>
 __device__ __forceinline__ void lds_star4v_at(const T* c, const T* __restrict__ P, V2<T> (&ctr)[2], V2<T> (&lap)[2])
 {
     lds_star4v_cf<T, LX, FLIP>(c, [P](int i) { return vs(P[i]); }, ctr, lap);
+}
+
+// the same for the two points at c (a HALF-strip: c is 8-byte aligned); operations and their order per point as lds_star4v_cf
+template <typename T> __device__ __forceinline__ V2<T> win_pair3(const V2<T> (&W)[3], int idx)
+{
+    return (idx & 1) ? V2<T>{W[idx / 2].y, W[idx / 2 + 1].x} : W[idx / 2];
+}
+template <typename T, int LX, int FLIP, typename CF>
+__device__ __forceinline__ void lds_star2v_cf(const T* c, CF cf, V2<T>& ctr, V2<T>& lap)
+{
+    const V2<T> W[3] = {ldv2(c - 2), ldv2(c), ldv2(c + 2)};
+    ctr = W[1];
+    lap = cf(P_C0) * ctr;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = FLIP * (t < 2 ? t - 2 : t - 1);
+        lap = vfma(cf(P_TAPS + t), ldv2(c + k * LX), lap);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = FLIP * (t < 2 ? t - 2 : t - 1);
+        lap = vfma(cf(P_TAPS + 4 + t), win_pair3(W, 2 + k), lap);
+    }
 }
 
 // pi::poly_r on 2-vectors (same operations in the same order)
@@ -846,14 +870,35 @@ __device__ __forceinline__ unsigned persist_geo_word(const TileGeom& g, int ty0,
     for (int i = 0; i < 4; ++i) w |= (rowin && (unsigned)(lx + i - 2 * K) < own_nx) ? (1u << (17 + i)) : 0u;
     return w;
 }
+// ... of a HALF-strip: lane index hh = tid - TID0 -> strip hh / 2 of the part, points 2 (hh % 2) .. + 1 (bits 17, 18: their ownership)
+template <int K, int BX, int BY, int NT, int M, int PART, int TID0>
+__device__ __forceinline__ unsigned persist_half_geo_word(const TileGeom& g, int ty0, int tx0)
+{
+    using TL = Tile<K, BX, BY>;
+    using SM = StripMap<K, BX, BY, M, PART>;
+    constexpr int RN4 = SM::N, O = 2 * (M + 1);
+    const int hh = (int)threadIdx.x - TID0;
+    const bool live = hh >= 0 && hh < 2 * RN4;
+    int ry, rc;
+    SM::locate(live ? (hh >> 1) : 0, ry, rc);
+    const int ly = ry + O, lx = 4 * rc + O + 2 * (hh & 1);
+    const unsigned own_ny = (unsigned)min(BY, g.H - ty0), own_nx = (unsigned)min(BX, g.W - tx0);
+    const bool rowin = live && (unsigned)(ly - 2 * K) < own_ny;
+    unsigned w = (unsigned)(ly * TL::LX + lx) | (live ? 1u << 16 : 0u);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w |= (rowin && (unsigned)(lx + i - 2 * K) < own_nx) ? (1u << (17 + i)) : 0u;
+    return w;
+}
 // GEO: the lane's strip geometry of this pass -- LDS offset, liveness, ownership of its four points -- comes packed in one word
 // of an LDS table built once per launch (persistent split sweep: persist_geo_word) instead of being derived from the lane id in
 // every pass of every group: the derivation (strip map with its divisions, clamps, four ownership compares and selects) was
 // ~60 of the ~300 VALU instructions of an issue-bound pass, and hoisting it into registers for all passes at once spills.
 // LACC: lanes per row of the float64 moment accumulators in LDS (`lacc`[20][LACC]; lanes tid and tid + LACC share a slot -- the
 // adds are LDS atomics)
+// HALFS (round 6, geometry words only): the lane works on a HALF-strip -- the two points at the word's offset; `pre` holds their
+// operands in elements 0, 1 and bits 17, 18 of the word their ownership.  Same operations per point.
 template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE, bool MOM, int PART = PART_FULL, int TID0 = 0,
-          bool GEO = false, int LACC = NT>
+          bool GEO = false, int LACC = NT, bool HALFS = false>
 __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict__ hfr, const T* __restrict__ gfr,
                                             const TileGeom& g, int ty0, int tx0, const T* __restrict__ P,
                                             double (&acc_c)[2], const StripOps<T>& pre, TileMoments<T, MOM>& mom,
@@ -870,6 +915,8 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
     constexpr int RN4 = SM::N, O = 2 * (M + 1);
     constexpr int PT = (RN4 + NT - 1) / NT;
     static_assert(!PRE || PT == 1, "prefetched operands cover one strip per lane");
+    static_assert(!HALFS || (GEO && PRE && HC == POLY), "half-strips: resident sweep passes with geometry words and prefetched operands");
+    constexpr int NH = HALFS ? 1 : 2;                       // point pairs per lane
     int tid = (int)threadIdx.x;
 #if PI_PERSIST_OPAQUE_TID
     // split persistent sweep: eight passes inlined into one loop.  Everything derived from the lane's strip position (LDS
@@ -920,13 +967,18 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
         const T (&jv)[4] = op.jv;
         const V2<T> U[2] = {V2<T>{u[0], u[1]}, V2<T>{u[2], u[3]}}, V[2] = {V2<T>{v[0], v[1]}, V2<T>{v[2], v[3]}};
         V2<T> gc[2][2], dl[2][2];                          // [species][half of the strip]
-        lds_star4v_cf<T, TL::LX, -1>(cur + off, cf, gc[0], dl[0]);
-        lds_star4v_cf<T, TL::LX, -1>(cur + TL::PLANE + off, cf, gc[1], dl[1]);
+        if constexpr (HALFS) {
+            lds_star2v_cf<T, TL::LX, -1>(cur + off, cf, gc[0][0], dl[0][0]);
+            lds_star2v_cf<T, TL::LX, -1>(cur + TL::PLANE + off, cf, gc[1][0], dl[1][0]);
+        } else {
+            lds_star4v_cf<T, TL::LX, -1>(cur + off, cf, gc[0], dl[0]);
+            lds_star4v_cf<T, TL::LX, -1>(cur + TL::PLANE + off, cf, gc[1], dl[1]);
+        }
         const V2<T> dtv = cf(P_DT);
         V2<T> own[2];                                      // 1 for owned, in-grid points, else 0 (MOM only)
         V2<T> cs[2] = {vs(T(0)), vs(T(0))};                 // this strip's owned part of sum_x dt*LapT(a)*h, per species
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             dl[0][h] *= dtv;
             dl[1][h] *= dtv;
 #pragma unroll
@@ -948,7 +1000,7 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
             for (int s = 0; s < 2; ++s) {
                 const T* c = P + P_W + 10 * s;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < NH; ++h) {
                     const V2<T> gr = gc[s][h] * dtv;
                     V2<T> ru, rv;
                     if constexpr (GEO && held_masks<T>::jac != 0) poly_dr_v_j(c, jp->m[s], U[h], V[h], ru, rv);
@@ -979,7 +1031,7 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
                     const W10<T> c = nx;
                     if (j + 1 < HC) nx = load_w10(W + 10 * (j + 1));
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < NH; ++h) {
                         const V2<T> a1 = vfma(vs(c.w[0]), U[h], vfma(vs(c.w[1]), V[h], vs(c.w[2])));
                         const V2<T> a2 = vfma(vs(c.w[3]), U[h], vfma(vs(c.w[4]), V[h], vs(c.w[5])));
                         const V2<T> a3 = vfma(vs(c.w[6]), U[h], vfma(vs(c.w[7]), V[h], vs(c.w[8])));
@@ -994,7 +1046,7 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
         }
         const V2<T> cu = cf(P_COEF + 0), cv = cf(P_COEF + 1);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             const V2<T> tu = cu * dl[0][h] + du[h];
             const V2<T> tv = cv * dl[1][h] + dv[h];
             V2<T> ou = gc[0][h] + tu, ov = gc[1][h] + tv;
@@ -1020,7 +1072,7 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
             // at a time: the stencil / Jacobian temporaries are dead by now.
             double* slot = lacc + (LACC == NT ? (int)threadIdx.x : (int)threadIdx.x % LACC);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < NH; ++h) {
                 const V2<T> uu = U[h], vv = V[h];
                 const V2<T> u2 = uu * uu, uv = uu * vv, v2 = vv * vv;
 #pragma unroll
@@ -1750,6 +1802,34 @@ __device__ __forceinline__ void persist_load_ops(StripOps<T>& o, const T* __rest
     o.jv[0] = c2.v[0]; o.jv[1] = c2.v[1]; o.jv[2] = d2.v[0]; o.jv[3] = d2.v[1];
 }
 
+// HALF-strips (round 6): byte offset of the lane's two points inside a species plane, and their pointwise operands
+template <typename T, int K, int BX, int BY, int NT, int M, int PART, int TID0>
+__device__ __forceinline__ unsigned persist_half_off(const TileGeom& g, int ty0, int tx0)
+{
+    using SM = StripMap<K, BX, BY, M, PART>;
+    constexpr int RN4 = SM::N, O = 2 * (M + 1);
+    int hh = (int)threadIdx.x - TID0;
+    if (hh < 0) hh = 0;
+    if (hh >= 2 * RN4) hh = 2 * RN4 - 1;
+    int ry, rc;
+    SM::locate(hh >> 1, ry, rc);
+    const int ly = ry + O, lx = 4 * rc + O + 2 * (hh & 1);
+    const int gy = wrap1(ty0 - 2 * K + ly, g.H), gx = wrap1(tx0 - 2 * K + lx, g.W);      // (two points never straddle the wrap: W is even)
+    return (unsigned)((long)gy * g.W + gx) * (unsigned)sizeof(T);
+}
+template <typename T>
+__device__ __forceinline__ void persist_load_ops_half(StripOps<T>& o, const T* __restrict__ hfr, const T* __restrict__ gfr,
+                                                      const TileGeom& g, unsigned off)
+{
+    const T* gsrc = gfr ? gfr : hfr;
+    const Pack<T, 2> a = *reinterpret_cast<const Pack<T, 2>*>(reinterpret_cast<const char*>(hfr) + off);
+    const Pack<T, 2> c = *reinterpret_cast<const Pack<T, 2>*>(reinterpret_cast<const char*>(hfr + g.ss) + off);
+    const Pack<T, 2> a2 = *reinterpret_cast<const Pack<T, 2>*>(reinterpret_cast<const char*>(gsrc) + off);
+    const Pack<T, 2> c2 = *reinterpret_cast<const Pack<T, 2>*>(reinterpret_cast<const char*>(gsrc + g.ss) + off);
+    o.u[0] = a.v[0]; o.u[1] = a.v[1]; o.v[0] = c.v[0]; o.v[1] = c.v[1];
+    o.ju[0] = a2.v[0]; o.ju[1] = a2.v[1]; o.jv[0] = c2.v[0]; o.jv[1] = c2.v[1];
+}
+
 // Data-tagged granules by value type: ONE 16-byte write-through (sc1) store publishes a granule, ONE 16-byte sc1 load reads it
 // (requests are what a hand-over costs, not bytes).  float64 (round 5, configs[2]): {lo32, tag, hi32, tag} = one value as two
 // self-validating 8-byte words.  float32 (round 6): {value 0, tag, value 1, tag} = TWO x-adjacent values -- the 8-byte {tag, value}
@@ -1862,6 +1942,16 @@ struct HandOver {
 // int rows of NT the split sweep keeps in LDS behind the moments: 13 of hand-over tables + 6 of strip geometry (+ the abort word)
 constexpr int PERSIST_SPLIT_TABLE_ROWS = 19;
 
+// HALF-STRIP passes of the split sweep (float32, round 6).  P3, P4, P5 -- A_1 | A_2 | I_3 + A_3 -- have 4, 3.5 and 4 wave-strips for
+// eight waves: one wave per SIMD issues a 450-instruction strip at the single-wave rate (1.04 us per pass) while the other wave of the
+// SIMD idles; P2, where two strips share a SIMD, does them in 0.8 us each.  On half-strips these passes occupy all eight waves
+// (512 / 448 / 128 + 384 lanes) with half the points per lane.  P0 .. P2 keep whole strips.
+#ifndef PI_SWEEP_HALF
+#define PI_SWEEP_HALF 1
+#endif
+template <typename T, int PASS> struct sweep_half_pass { static constexpr bool value = PI_SWEEP_HALF != 0 && sizeof(T) == 4 && PASS >= 3; };
+constexpr int SWEEP_HALF_P5_SPLIT = 128;                   // P5 on half-strips: I_3 = 64 strips on lanes 0 .. 127, A_3 = 192 from lane 128 on
+
 // The six passes of a group: which sub-step / part the waves below SPLIT work on (M1, PART1; strips indexed from lane 0) and
 // which the waves from SPLIT on (M2, PART2; strips indexed from lane SPLIT); SPLIT == NT: one part only.
 template <int PASS> struct PersistPass;
@@ -1898,6 +1988,36 @@ __device__ __forceinline__ StripOff persist_pass_off(const TileGeom& g, int ty0,
 
 // ... of pass PASS for this lane (lanes from SPLIT on: the second part)
 template <int K, int BX, int BY, int NT, int PASS>
+__device__ __forceinline__ unsigned persist_pass_half_geo(const TileGeom& g, int ty0, int tx0)
+{
+    using PP = PersistPass<PASS>;
+    static_assert(PASS >= 3, "half-strip passes");
+    if constexpr (PASS == 5) {
+        const unsigned lo = persist_half_geo_word<K, BX, BY, NT, PP::M1, PP::P1, 0>(g, ty0, tx0);
+        const unsigned hi = persist_half_geo_word<K, BX, BY, NT, PP::M2, PP::P2, SWEEP_HALF_P5_SPLIT>(g, ty0, tx0);
+        return (int)threadIdx.x >= SWEEP_HALF_P5_SPLIT ? hi : lo;
+    } else {
+        return persist_half_geo_word<K, BX, BY, NT, PP::M1, PP::P1, 0>(g, ty0, tx0);
+    }
+}
+template <typename T, int K, int BX, int BY, int NT, int PASS>
+__device__ __forceinline__ StripOff persist_pass_half_off(const TileGeom& g, int ty0, int tx0)
+{
+    using PP = PersistPass<PASS>;
+    StripOff so;
+    if constexpr (PASS == 5) {
+        const unsigned lo = persist_half_off<T, K, BX, BY, NT, PP::M1, PP::P1, 0>(g, ty0, tx0);
+        const unsigned hi = persist_half_off<T, K, BX, BY, NT, PP::M2, PP::P2, SWEEP_HALF_P5_SPLIT>(g, ty0, tx0);
+        so.o0 = (int)threadIdx.x >= SWEEP_HALF_P5_SPLIT ? hi : lo;
+    } else {
+        so.o0 = persist_half_off<T, K, BX, BY, NT, PP::M1, PP::P1, 0>(g, ty0, tx0);
+    }
+    so.o1 = so.o0;
+    asm volatile("" : "+v"(so.o0));
+    return so;
+}
+
+template <int K, int BX, int BY, int NT, int PASS>
 __device__ __forceinline__ unsigned persist_pass_geo(const TileGeom& g, int ty0, int tx0)
 {
     using PP = PersistPass<PASS>;
@@ -1920,10 +2040,18 @@ __device__ __forceinline__ void persist_pass(T* b0, T* b1, const T* const (&hf)[
                                              const unsigned* geo, const JacPairs<T>& jp, double* lacc = nullptr)
 {
     using PP = PersistPass<PASS>;
-    persist_load_ops<T>(ahead, hn, gn, g, so_next);
     constexpr bool GEO = PI_PERSIST_GEO != 0;
+    constexpr bool HALF_HERE = GEO && sweep_half_pass<T, PASS>::value, HALF_NEXT = GEO && sweep_half_pass<T, (PASS + 1) % 6>::value;
+    if constexpr (HALF_NEXT) persist_load_ops_half<T>(ahead, hn, gn, g, so_next.o0);
+    else persist_load_ops<T>(ahead, hn, gn, g, so_next);
     constexpr int LACC = sizeof(T) == 8 ? NT / 2 : NT;     // float64: moments straight into the shared LDS rows (adj_substep)
-    if constexpr (PP::SPLIT >= NT || GEO) {
+    if constexpr (HALF_HERE) {
+        // every lane a half-strip of sub-step M (P5: both parts are sub-step 3 and share the injection frame)
+        static_assert(PP::M1 == PP::M2 || PP::SPLIT >= NT, "half-strip passes: one sub-step");
+        constexpr int M = PP::M1;
+        adj_substep<T, POLY, K, BX, BY, NT, M, true, true, PP::P1, 0, GEO, LACC, true>((M & 1) ? b1 : b0, (M & 1) ? b0 : b1, hf[M], gf[M], g, ty0,
+                                                                                       tx0, P, acc_c, ops, mom, lacc, geo, &jp);
+    } else if constexpr (PP::SPLIT >= NT || GEO) {
         // With the geometry in a table the sub-step's body no longer depends on WHICH strips a wave works on: the two parts of a
         // mixed pass (same parity of M: same buffers) run the same instructions with their own table words and their own
         // injection frame -- one body instead of two behind a branch (the moments' 20 register pairs were copied at every merge).
@@ -1991,9 +2119,12 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
     tab_geo[0 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 0>(g, ty0, tx0);
     tab_geo[1 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 1>(g, ty0, tx0);
     tab_geo[2 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 2>(g, ty0, tx0);
-    tab_geo[3 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 3>(g, ty0, tx0);
-    tab_geo[4 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 4>(g, ty0, tx0);
-    tab_geo[5 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 5>(g, ty0, tx0);
+    if constexpr (sweep_half_pass<T, 3>::value) tab_geo[3 * NT + (int)threadIdx.x] = persist_pass_half_geo<K, BX, BY, NT, 3>(g, ty0, tx0);
+    else tab_geo[3 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 3>(g, ty0, tx0);
+    if constexpr (sweep_half_pass<T, 4>::value) tab_geo[4 * NT + (int)threadIdx.x] = persist_pass_half_geo<K, BX, BY, NT, 4>(g, ty0, tx0);
+    else tab_geo[4 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 4>(g, ty0, tx0);
+    if constexpr (sweep_half_pass<T, 5>::value) tab_geo[5 * NT + (int)threadIdx.x] = persist_pass_half_geo<K, BX, BY, NT, 5>(g, ty0, tx0);
+    else tab_geo[5 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 5>(g, ty0, tx0);
     if ((int)threadIdx.x < LACC) {
 #pragma unroll
         for (int m = 0; m < 20; ++m) lacc[m * LACC + (int)threadIdx.x] = 0.0;
@@ -2015,9 +2146,14 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
     const StripOff so0 = persist_pass_off<T, K, BX, BY, NT, 0>(g, ty0, tx0, false);
     const StripOff so1 = persist_pass_off<T, K, BX, BY, NT, 1>(g, ty0, tx0, false);
     const StripOff so2 = persist_pass_off<T, K, BX, BY, NT, 2>(g, ty0, tx0, up2);
-    const StripOff so3 = persist_pass_off<T, K, BX, BY, NT, 3>(g, ty0, tx0, false);
-    const StripOff so4 = persist_pass_off<T, K, BX, BY, NT, 4>(g, ty0, tx0, false);
-    const StripOff so5 = persist_pass_off<T, K, BX, BY, NT, 5>(g, ty0, tx0, up5);
+    auto pass_off = [&](auto pass_c, bool upper) {
+        constexpr int PASS = decltype(pass_c)::value;
+        if constexpr (sweep_half_pass<T, PASS>::value) return persist_pass_half_off<T, K, BX, BY, NT, PASS>(g, ty0, tx0);
+        else return persist_pass_off<T, K, BX, BY, NT, PASS>(g, ty0, tx0, upper);
+    };
+    const StripOff so3 = pass_off(std::integral_constant<int, 3>{}, false);
+    const StripOff so4 = pass_off(std::integral_constant<int, 4>{}, false);
+    const StripOff so5 = pass_off(std::integral_constant<int, 5>{}, up5);
     unsigned gmask = persist_mask<K>(pa, pa.t_top);
     StripOps<T> ops, ops2;                                  // operands of the pass at hand / of the next one, alternating
     persist_load_ops<T>(ops, hframe_t - frame_stride, gmask & 1u ? gframe_t - frame_stride : nullptr, g, so0);
