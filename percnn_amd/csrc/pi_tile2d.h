@@ -877,10 +877,14 @@ __device__ __forceinline__ unsigned persist_half_geo_word(const TileGeom& g, int
     using TL = Tile<K, BX, BY>;
     using SM = StripMap<K, BX, BY, M, PART>;
     constexpr int RN4 = SM::N, O = 2 * (M + 1);
-    const int hh = (int)threadIdx.x - TID0;
+    int hh = (int)threadIdx.x - TID0;
     const bool live = hh >= 0 && hh < 2 * RN4;
+    // (idle lanes of a partly live wave shadow the part's first / last half-strip -- the one persist_half_off gives them the operands
+    // of: they compute and store that half-strip's own values once more, like the idle lanes of the whole-strip passes)
+    if (hh < 0) hh = 0;
+    if (hh >= 2 * RN4) hh = 2 * RN4 - 1;
     int ry, rc;
-    SM::locate(live ? (hh >> 1) : 0, ry, rc);
+    SM::locate(hh >> 1, ry, rc);
     const int ly = ry + O, lx = 4 * rc + O + 2 * (hh & 1);
     const unsigned own_ny = (unsigned)min(BY, g.H - ty0), own_nx = (unsigned)min(BX, g.W - tx0);
     const bool rowin = live && (unsigned)(ly - 2 * K) < own_ny;
@@ -1949,7 +1953,13 @@ constexpr int PERSIST_SPLIT_TABLE_ROWS = 19;
 #ifndef PI_SWEEP_HALF
 #define PI_SWEEP_HALF 1
 #endif
-template <typename T, int PASS> struct sweep_half_pass { static constexpr bool value = PI_SWEEP_HALF != 0 && sizeof(T) == 4 && PASS >= 3; };
+#ifndef PI_SWEEP_HALF_MASK
+#define PI_SWEEP_HALF_MASK 0x39         // bit p: pass p runs on half-strips: P0, P3, P4, P5 (P2 mixes two sub-steps and keeps whole strips;
+                                        // P1 on half-strips measured slower: 1.79 -> 1.81 us per step)
+#endif
+template <typename T, int PASS> struct sweep_half_pass {
+    static constexpr bool value = PI_SWEEP_HALF != 0 && sizeof(T) == 4 && PASS != 2 && (((PI_SWEEP_HALF_MASK) >> PASS) & 1) != 0;
+};
 constexpr int SWEEP_HALF_P5_SPLIT = 128;                   // P5 on half-strips: I_3 = 64 strips on lanes 0 .. 127, A_3 = 192 from lane 128 on
 
 // The six passes of a group: which sub-step / part the waves below SPLIT work on (M1, PART1; strips indexed from lane 0) and
@@ -1991,7 +2001,7 @@ template <int K, int BX, int BY, int NT, int PASS>
 __device__ __forceinline__ unsigned persist_pass_half_geo(const TileGeom& g, int ty0, int tx0)
 {
     using PP = PersistPass<PASS>;
-    static_assert(PASS >= 3, "half-strip passes");
+    static_assert(PASS != 2, "half-strip passes");
     if constexpr (PASS == 5) {
         const unsigned lo = persist_half_geo_word<K, BX, BY, NT, PP::M1, PP::P1, 0>(g, ty0, tx0);
         const unsigned hi = persist_half_geo_word<K, BX, BY, NT, PP::M2, PP::P2, SWEEP_HALF_P5_SPLIT>(g, ty0, tx0);
@@ -2116,8 +2126,10 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
         const unsigned n = __hip_atomic_fetch_add(pa.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         if (n == (unsigned)ntiles && pa.host) __hip_atomic_store(pa.host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    tab_geo[0 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 0>(g, ty0, tx0);
-    tab_geo[1 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 1>(g, ty0, tx0);
+    if constexpr (sweep_half_pass<T, 0>::value) tab_geo[0 * NT + (int)threadIdx.x] = persist_pass_half_geo<K, BX, BY, NT, 0>(g, ty0, tx0);
+    else tab_geo[0 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 0>(g, ty0, tx0);
+    if constexpr (sweep_half_pass<T, 1>::value) tab_geo[1 * NT + (int)threadIdx.x] = persist_pass_half_geo<K, BX, BY, NT, 1>(g, ty0, tx0);
+    else tab_geo[1 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 1>(g, ty0, tx0);
     tab_geo[2 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 2>(g, ty0, tx0);
     if constexpr (sweep_half_pass<T, 3>::value) tab_geo[3 * NT + (int)threadIdx.x] = persist_pass_half_geo<K, BX, BY, NT, 3>(g, ty0, tx0);
     else tab_geo[3 * NT + (int)threadIdx.x] = persist_pass_geo<K, BX, BY, NT, 3>(g, ty0, tx0);
@@ -2143,20 +2155,22 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
     WindowLoader<T, K, BX, BY, NT> wl;
     wl.issue(aframe_t, g, ty0, tx0);
     // the lane's strip in each of the six passes (byte offsets of its pointwise operands)
-    const StripOff so0 = persist_pass_off<T, K, BX, BY, NT, 0>(g, ty0, tx0, false);
-    const StripOff so1 = persist_pass_off<T, K, BX, BY, NT, 1>(g, ty0, tx0, false);
+
     const StripOff so2 = persist_pass_off<T, K, BX, BY, NT, 2>(g, ty0, tx0, up2);
     auto pass_off = [&](auto pass_c, bool upper) {
         constexpr int PASS = decltype(pass_c)::value;
         if constexpr (sweep_half_pass<T, PASS>::value) return persist_pass_half_off<T, K, BX, BY, NT, PASS>(g, ty0, tx0);
         else return persist_pass_off<T, K, BX, BY, NT, PASS>(g, ty0, tx0, upper);
     };
+    const StripOff so0 = pass_off(std::integral_constant<int, 0>{}, false);
+    const StripOff so1 = pass_off(std::integral_constant<int, 1>{}, false);
     const StripOff so3 = pass_off(std::integral_constant<int, 3>{}, false);
     const StripOff so4 = pass_off(std::integral_constant<int, 4>{}, false);
     const StripOff so5 = pass_off(std::integral_constant<int, 5>{}, up5);
     unsigned gmask = persist_mask<K>(pa, pa.t_top);
     StripOps<T> ops, ops2;                                  // operands of the pass at hand / of the next one, alternating
-    persist_load_ops<T>(ops, hframe_t - frame_stride, gmask & 1u ? gframe_t - frame_stride : nullptr, g, so0);
+    if constexpr (sweep_half_pass<T, 0>::value) persist_load_ops_half<T>(ops, hframe_t - frame_stride, gmask & 1u ? gframe_t - frame_stride : nullptr, g, so0.o0);
+    else persist_load_ops<T>(ops, hframe_t - frame_stride, gmask & 1u ? gframe_t - frame_stride : nullptr, g, so0);
     wl.commit(b0);
     lds_barrier();
     double acc_c[2] = {0.0, 0.0};
