@@ -1958,7 +1958,10 @@ constexpr int PERSIST_SPLIT_TABLE_ROWS = 19;
                                         // P1 on half-strips measured slower: 1.79 -> 1.81 us per step)
 #endif
 template <typename T, int PASS> struct sweep_half_pass {
-    static constexpr bool value = PI_SWEEP_HALF != 0 && sizeof(T) == 4 && PASS != 2 && (((PI_SWEEP_HALF_MASK) >> PASS) & 1) != 0;
+#ifndef PI_SWEEP_HALF_F64
+#define PI_SWEEP_HALF_F64 1
+#endif
+    static constexpr bool value = PI_SWEEP_HALF != 0 && (sizeof(T) == 4 || PI_SWEEP_HALF_F64 != 0) && PASS != 2 && (((PI_SWEEP_HALF_MASK) >> PASS) & 1) != 0;
 };
 constexpr int SWEEP_HALF_P5_SPLIT = 128;                   // P5 on half-strips: I_3 = 64 strips on lanes 0 .. 127, A_3 = 192 from lane 128 on
 
