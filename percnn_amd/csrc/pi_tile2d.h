@@ -1950,6 +1950,9 @@ constexpr int PERSIST_SPLIT_TABLE_ROWS = 19;
 // eight waves: one wave per SIMD issues a 450-instruction strip at the single-wave rate (1.04 us per pass) while the other wave of the
 // SIMD idles; P2, where two strips share a SIMD, does them in 0.8 us each.  On half-strips these passes occupy all eight waves
 // (512 / 448 / 128 + 384 lanes) with half the points per lane.  P0 .. P2 keep whole strips.
+#ifndef PI_ADJ_PERSIST_PAUSE
+#define PI_ADJ_PERSIST_PAUSE 0          // split sweep: s_sleep units before the ring request (round 6: 0 / 8 / 32 measured, see profiles)
+#endif
 #ifndef PI_SWEEP_HALF
 #define PI_SWEEP_HALF 1
 #endif
@@ -2209,6 +2212,9 @@ pi_adj2d_persist_split_kernel(const T* __restrict__ hframe_t, const T* __restric
         int gs[NGAT];
         typename GranuleIO<T>::Raw gx[NGAT];
         if (grp > 0) {
+#if PI_ADJ_PERSIST_PAUSE
+            __builtin_amdgcn_s_sleep(PI_ADJ_PERSIST_PAUSE);
+#endif
 #pragma unroll
             for (int q = 0; q < NGAT; ++q) {
                 gs[q] = tab_gs[q * NT + (int)threadIdx.x];
