@@ -47,9 +47,9 @@ HBM_COPY_CEILING_GBS = 6290.0    # the same table's measured float4-copy ceiling
 # what the SQ / TCP / TCC counters say limits each kernel (shares of a resident wave's life: issuing / stalled at issue / parked at
 # barriers, polls and waitcnts).  The roofline the path is priced against stays HBM; this is the honest "why not".
 LIMITERS = {
-    "pi_adj2d_persist_split_kernel": "VALU instruction issue: 22.9 wave-strips x ~600 instructions on 4 SIMDs = 7.0 of a group's 7.9 us, 245 VGPRs / "
-                                     "106 SGPRs; round-5 counters: issue 0.29 / stall 0.28 / parked 0.44 (profiles/r06_granule_pairs.txt, "
-                                     "r05_counters_summary.txt)",
+    "pi_adj2d_persist_split_kernel": "VALU instruction issue: a strip is ~450 VALU instructions at the single-wave rate; since round 6 the thin passes "
+                                     "(P0, P3-P5) run on two-point half-strips so both waves of every SIMD issue (7.9 -> 7.1 us per group of 4 steps); "
+                                     "237 / 253 VGPRs (profiles/r06_granule_pairs.txt; round-5 counters: issue 0.29 / stall 0.28 / parked 0.44)",
     "pi_adj2d_persist_kernel": "hand-over waits (profiles/r04_persistent_split_timelines.txt)",
     "pi_fwd2d_persist_kernel": "LDS latency at low occupancy: a pass is ONE 128-instruction strip per wave (0.19 us of VALU issue) that takes "
                                "0.45 us alone on its CU and 0.8 us next to three others (VALU active 22 %, waiting 67 %); six passes + a 0.4 us "
