@@ -62,6 +62,7 @@ struct Options {
                             // launch-per-group sweep is enqueued in the same call and the persistent path is switched off for
                             // this device (percnn_pi_persist_status).  0: no wait; an aborted launch is reported by the NEXT
                             // entry point (PERCNN_PI_EASYNC) instead
+    int adj_small_half = 1;     // small-tile resident sweep (32 x 8 tiles) on half-strips: 512 lanes, two waves per SIMD
     int adj_small_pause = 24;   // ... of the small-tile resident SWEEP (100^2 1.53 -> 1.45 us per step, 256^2 1.93 -> 1.70: profiles/r05_small_tile_resident_forward.txt)
     int fwd_small_pause = 12;   // small-tile resident forward: 64-clock units between publish and the first ring request (PersistArgs::pause)
     int persist_small = 1;      // the 32 x 8-tile regime (grids below ~300^2, split schedule) as one persistent launch too
@@ -1654,7 +1655,7 @@ bool persist_small_ok(const Problem& p, const unsigned char* mask, int t_top, in
 }
 
 // as launch_adj_persist; every adjoint frame of the groups it runs is written
-template <typename T, int BY, int NT>
+template <typename T, int BY, int NT, bool HALFS = false>
 hipError_t launch_adj_persist_small_t(const T* hframe_t, const T* gframe_t, T* aframe_t, T* g_h0, int t_top, const unsigned char* mask,
                                     int ngroups, double* partials, unsigned long long* outbox, unsigned* sync, const T* P,
                                     const Problem& p, int dev, hipStream_t st)
@@ -1666,7 +1667,7 @@ hipError_t launch_adj_persist_small_t(const T* hframe_t, const T* gframe_t, T* a
     constexpr int RINGH = TL::LX * TL::LY - TILE_B * BY, NGAT = (2 * RINGH + NT - 1) / NT;
     // state buffers | gather tables | K rows of strip geometry | abort word
     const size_t lds = pi::tile_state_bytes<T, K, TILE_B, BY>() + (size_t)(2 * NGAT + K) * NT * sizeof(int) + 16;
-    auto* k = pi::pi_adj2d_persist_small_kernel<T, K, TILE_B, BY, NT>;
+    auto* k = pi::pi_adj2d_persist_small_kernel<T, K, TILE_B, BY, NT, HALFS>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     if (hipError_t e = hipMemsetAsync(outbox, 0, persist_small_outbox_bytes(p, (int)sizeof(T)), st)) return e;
     long frame_stride = (long)(2 * p.n);
@@ -1870,6 +1871,9 @@ hipError_t launch_adj_persist_small(const T* hframe_t, const T* gframe_t, T* afr
 {
     if (tile_by_for(p) == 16)
         return launch_adj_persist_small_t<T, 16, 320>(hframe_t, gframe_t, aframe_t, g_h0, t_top, mask, ngroups, partials, outbox, sync, P, p, dev, st);
+    // (round 6: half-strips on 512 lanes -- two waves per SIMD; adj_small_half=0: whole strips on 256 lanes)
+    if (p.opt.adj_small_half)
+        return launch_adj_persist_small_t<T, 8, 512, true>(hframe_t, gframe_t, aframe_t, g_h0, t_top, mask, ngroups, partials, outbox, sync, P, p, dev, st);
     return launch_adj_persist_small_t<T, 8, 256>(hframe_t, gframe_t, aframe_t, g_h0, t_top, mask, ngroups, partials, outbox, sync, P, p, dev, st);
 }
 
@@ -2933,6 +2937,7 @@ int apply_option(Options& o, const char* key, long value)
     if (!std::strcmp(key, "block_small")) { o.block_small = value != 0; return 0; }
     if (!std::strcmp(key, "slab_wide_adjoint")) { o.slab_wide_adjoint = value != 0; return 0; }
     if (!std::strcmp(key, "slab_local_index")) { o.slab_local_index = value != 0; return 0; }
+    if (!std::strcmp(key, "adj_small_half")) { if (value < 0 || value > 1) return PERCNN_PI_EINVAL; o.adj_small_half = (int)value; return 0; }
     if (!std::strcmp(key, "adj_small_pause")) { if (value < 0 || value > 200) return PERCNN_PI_EINVAL; o.adj_small_pause = (int)value; return 0; }
     if (!std::strcmp(key, "fwd_small_pause")) { if (value < 0 || value > 200) return PERCNN_PI_EINVAL; o.fwd_small_pause = (int)value; return 0; }
     if (!std::strcmp(key, "brick_xny")) { if (value < -1 || value > 8 || value == 3 || (value > 4 && value < 8)) return PERCNN_PI_EINVAL; o.brick_xny = (int)value; return 0; }

@@ -1095,16 +1095,46 @@ __device__ __forceinline__ void adj_substep(T* cur, T* nxt, const T* __restrict_
     }
 }
 
+// HALF-strips (round 6): byte offset of the lane's two points inside a species plane, and their pointwise operands
+template <typename T, int K, int BX, int BY, int NT, int M, int PART, int TID0>
+__device__ __forceinline__ unsigned persist_half_off(const TileGeom& g, int ty0, int tx0)
+{
+    using SM = StripMap<K, BX, BY, M, PART>;
+    constexpr int RN4 = SM::N, O = 2 * (M + 1);
+    int hh = (int)threadIdx.x - TID0;
+    if (hh < 0) hh = 0;
+    if (hh >= 2 * RN4) hh = 2 * RN4 - 1;
+    int ry, rc;
+    SM::locate(hh >> 1, ry, rc);
+    const int ly = ry + O, lx = 4 * rc + O + 2 * (hh & 1);
+    const int gy = wrap1(ty0 - 2 * K + ly, g.H), gx = wrap1(tx0 - 2 * K + lx, g.W);      // (two points never straddle the wrap: W is even)
+    return (unsigned)((long)gy * g.W + gx) * (unsigned)sizeof(T);
+}
+template <typename T>
+__device__ __forceinline__ void persist_load_ops_half(StripOps<T>& o, const T* __restrict__ hfr, const T* __restrict__ gfr,
+                                                      const TileGeom& g, unsigned off)
+{
+    const T* gsrc = gfr ? gfr : hfr;
+    const Pack<T, 2> a = *reinterpret_cast<const Pack<T, 2>*>(reinterpret_cast<const char*>(hfr) + off);
+    const Pack<T, 2> c = *reinterpret_cast<const Pack<T, 2>*>(reinterpret_cast<const char*>(hfr + g.ss) + off);
+    const Pack<T, 2> a2 = *reinterpret_cast<const Pack<T, 2>*>(reinterpret_cast<const char*>(gsrc) + off);
+    const Pack<T, 2> c2 = *reinterpret_cast<const Pack<T, 2>*>(reinterpret_cast<const char*>(gsrc + g.ss) + off);
+    o.u[0] = a.v[0]; o.u[1] = a.v[1]; o.v[0] = c.v[0]; o.v[1] = c.v[1];
+    o.ju[0] = a2.v[0]; o.ju[1] = a2.v[1]; o.jv[0] = c2.v[0]; o.jv[1] = c2.v[1];
+}
+
 // PRE: the pointwise operands of sub-step M+1 are requested before sub-step M is computed and stay in flight across
 // its LDS barrier (one strip per lane only); `ops` holds the operands of sub-step M, requested one sub-step earlier.
-template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE, bool MOM, bool GEO = false>
+// HALFS (round 6, resident small-tile sweep): the lanes work on half-strips -- `geo` rows from persist_half_geo_word, operand byte
+// offsets per sub-step in `hoff`[K] (persist_half_off) instead of `sa`.
+template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool PRE, bool MOM, bool GEO = false, bool HALFS = false>
 __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__ hbase, const T* __restrict__ gbase,
                                              T* __restrict__ abase, long frame_stride, unsigned inj_mask,
                                              T* __restrict__ g_h0, int steps_to_zero, const TileGeom& g, int ty0,
                                              int tx0, const T* __restrict__ P, double (&acc_c)[2],
                                              const StripOps<T>& ops, TileMoments<T, MOM>& mom, const StripAddr (&sa)[K],
                                              double* lacc = nullptr, bool store_handover = true, const unsigned* geo = nullptr,
-                                             const JacPairs<T>* jp = nullptr)
+                                             const JacPairs<T>* jp = nullptr, const unsigned* hoff = nullptr)
 {
     T* cur = (M & 1) ? b1 : b0;
     T* nxt = (M & 1) ? b0 : b1;
@@ -1112,12 +1142,15 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
     StripOps<T> ahead;
     if constexpr (PRE && M + 1 < K) {
         const long fn = -(long)(M + 2) * frame_stride;
-        adj_load_ops<T, K, BX, BY, NT, M + 1>(ahead, 0, hbase + fn, (inj_mask >> (M + 1)) & 1u ? gbase + fn : nullptr, g,
-                                              ty0, tx0, &sa[M + 1]);
+        if constexpr (HALFS)
+            persist_load_ops_half<T>(ahead, hbase + fn, (inj_mask >> (M + 1)) & 1u ? gbase + fn : nullptr, g, hoff[M + 1]);
+        else
+            adj_load_ops<T, K, BX, BY, NT, M + 1>(ahead, 0, hbase + fn, (inj_mask >> (M + 1)) & 1u ? gbase + fn : nullptr, g,
+                                                  ty0, tx0, &sa[M + 1]);
     }
     // (GEO: row M of the caller's [K][NT] table of geometry words + its held coefficient pairs -- resident sweeps only)
-    adj_substep<T, HC, K, BX, BY, NT, M, PRE, MOM, PART_FULL, 0, GEO>(cur, nxt, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g,
-                                                                      ty0, tx0, P, acc_c, ops, mom, lacc, GEO ? geo + M * NT : nullptr, jp);
+    adj_substep<T, HC, K, BX, BY, NT, M, PRE, MOM, PART_FULL, 0, GEO, NT, HALFS>(cur, nxt, hbase + fo, (inj_mask >> M) & 1u ? gbase + fo : nullptr, g,
+                                                                                 ty0, tx0, P, acc_c, ops, mom, lacc, GEO ? geo + M * NT : nullptr, jp);
 #if PI_PIN_MOMENTS
     // Pin this sub-step's moment accumulation HERE.  Left alone, the scheduler sinks the moment FMAs of all four sub-steps
     // (they depend on no LDS traffic) behind the last barrier -- 350 VALU instructions in the tail of the launch, where all
@@ -1145,9 +1178,9 @@ __device__ __forceinline__ void adj_substeps(T* b0, T* b1, const T* __restrict__
     }
     PI_STAMP(4 + 3 * M);
     if constexpr (M + 1 < K)
-        adj_substeps<T, HC, K, BX, BY, NT, M + 1, PRE, MOM, GEO>(b0, b1, hbase, gbase, abase, frame_stride, inj_mask, g_h0,
-                                                                 steps_to_zero, g, ty0, tx0, P, acc_c, ahead, mom, sa, lacc,
-                                                                 store_handover, geo, jp);
+        adj_substeps<T, HC, K, BX, BY, NT, M + 1, PRE, MOM, GEO, HALFS>(b0, b1, hbase, gbase, abase, frame_stride, inj_mask, g_h0,
+                                                                        steps_to_zero, g, ty0, tx0, P, acc_c, ahead, mom, sa, lacc,
+                                                                        store_handover, geo, jp, hoff);
 }
 
 template <typename T, int HC, int K, int BX, int BY, int NT, bool MOM = false>
@@ -1573,7 +1606,9 @@ pi_adj2d_persist_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gf
 // are recomputed there like a halo and never published.  Sub-steps = the device functions of pi_adj2d_tile_kernel<MOM = false>:
 // adjoint frames and dL/dh0 bit-identical.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int K, int BX, int BY, int NT>
+// HALFS (round 6): half-strips, NT = twice the lanes -- 7 | 5 | 4 | 2 waves busy in the four sub-steps of a 32 x 8 tile instead of
+// 4 | 3 | 2 | 1 (one per SIMD, each alone with its LDS latency), and half the granule requests per lane in the hand-over.
+template <typename T, int K, int BX, int BY, int NT, bool HALFS = false>
 __global__ void __launch_bounds__(NT)
 pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gframe_t, T* __restrict__ aframe_t,
                               long frame_stride, T* __restrict__ g_h0, double* __restrict__ partials, int np,
@@ -1585,7 +1620,8 @@ pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restric
     constexpr int OWN = BX * BY;                                         // values per species a tile publishes
     constexpr int RINGH = LXW * LYW - OWN;                               // halo values per species
     constexpr int NPUB = (2 * OWN + NT - 1) / NT, NGAT = (2 * RINGH + NT - 1) / NT;
-    constexpr bool PRE = PI_TILE_ADJ_PIPE && TL::region_n(0) / 4 <= NT;
+    constexpr bool PRE = PI_TILE_ADJ_PIPE && TL::region_n(0) / (HALFS ? 2 : 4) <= NT;
+    static_assert(!HALFS || (PRE && PI_PERSIST_GEO != 0), "half-strips: prefetched operands, geometry words");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* b0 = reinterpret_cast<T*>(smem_raw) + lds_pad0<T>::value;
     T* b1 = reinterpret_cast<T*>(smem_raw) + 2 * TL::PLANE + lds_pad1<T>::value;
@@ -1602,10 +1638,24 @@ pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restric
     unsigned* tab_geo = reinterpret_cast<unsigned*>(tab_gs + NGAT * NT);                    // [K][NT]: the lane's strip in each sub-step
     int* wg_abort = reinterpret_cast<int*>(tab_geo + K * NT);
     static_assert(K == 4, "geometry rows below");
-    tab_geo[0 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 0, PART_FULL, 0>(g, ty0, tx0);
-    tab_geo[1 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 1, PART_FULL, 0>(g, ty0, tx0);
-    tab_geo[2 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 2, PART_FULL, 0>(g, ty0, tx0);
-    tab_geo[3 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 3, PART_FULL, 0>(g, ty0, tx0);
+    unsigned hoff[K] = {0u, 0u, 0u, 0u};                                                    // HALFS: operand byte offsets per sub-step
+    if constexpr (HALFS) {
+        tab_geo[0 * NT + (int)threadIdx.x] = persist_half_geo_word<K, BX, BY, NT, 0, PART_FULL, 0>(g, ty0, tx0);
+        tab_geo[1 * NT + (int)threadIdx.x] = persist_half_geo_word<K, BX, BY, NT, 1, PART_FULL, 0>(g, ty0, tx0);
+        tab_geo[2 * NT + (int)threadIdx.x] = persist_half_geo_word<K, BX, BY, NT, 2, PART_FULL, 0>(g, ty0, tx0);
+        tab_geo[3 * NT + (int)threadIdx.x] = persist_half_geo_word<K, BX, BY, NT, 3, PART_FULL, 0>(g, ty0, tx0);
+        hoff[0] = persist_half_off<T, K, BX, BY, NT, 0, PART_FULL, 0>(g, ty0, tx0);
+        hoff[1] = persist_half_off<T, K, BX, BY, NT, 1, PART_FULL, 0>(g, ty0, tx0);
+        hoff[2] = persist_half_off<T, K, BX, BY, NT, 2, PART_FULL, 0>(g, ty0, tx0);
+        hoff[3] = persist_half_off<T, K, BX, BY, NT, 3, PART_FULL, 0>(g, ty0, tx0);
+#pragma unroll
+        for (int m = 0; m < K; ++m) asm volatile("" : "+v"(hoff[m]));
+    } else {
+        tab_geo[0 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 0, PART_FULL, 0>(g, ty0, tx0);
+        tab_geo[1 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 1, PART_FULL, 0>(g, ty0, tx0);
+        tab_geo[2 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 2, PART_FULL, 0>(g, ty0, tx0);
+        tab_geo[3 * NT + (int)threadIdx.x] = persist_geo_word<K, BX, BY, NT, 3, PART_FULL, 0>(g, ty0, tx0);
+    }
     if (threadIdx.x == 0) {                                                                 // residency roll call (pi_adj2d_persist_kernel)
         *wg_abort = 0;
         const unsigned n = __hip_atomic_fetch_add(pa.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -1637,7 +1687,9 @@ pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restric
     StripOps<T> ops0;
     StripAddr sa[K];
     unsigned gmask = persist_mask<K>(pa, pa.t_top);
-    if constexpr (PRE) {
+    if constexpr (HALFS) {
+        persist_load_ops_half<T>(ops0, hframe_t - frame_stride, gmask & 1u ? gframe_t - frame_stride : nullptr, g, hoff[0]);
+    } else if constexpr (PRE) {
         strip_addr_table<K, BX, BY, NT, 0>(sa, g, ty0, tx0);
         adj_load_ops<T, K, BX, BY, NT, 0>(ops0, 0, hframe_t - frame_stride, gmask & 1u ? gframe_t - frame_stride : nullptr, g, ty0, tx0,
                                           &sa[0]);
@@ -1664,13 +1716,16 @@ pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restric
         const bool last = grp + 1 == pa.ngroups;
         // every adjoint frame goes to memory (the moments pass reads them); the last one of the sweep may be dL/dh0 itself.  The
         // frame a group ends on is stored AFTER the tile has been published: the neighbours wait for the granules, nobody for it
-        adj_substeps<T, POLY, K, BX, BY, NT, 0, PRE, false, PI_PERSIST_GEO != 0>(b0, b1, hframe_t + go, gframe_t + go, aframe_t + go,
-                                                                                 frame_stride, gmask, g_h0, g_h0 && last ? K : 0, g, ty0,
-                                                                                 tx0, P, acc_c, ops0, mom, sa, nullptr, last, tab_geo, &jp);
+        adj_substeps<T, POLY, K, BX, BY, NT, 0, PRE, false, PI_PERSIST_GEO != 0, HALFS>(b0, b1, hframe_t + go, gframe_t + go, aframe_t + go,
+                                                                                        frame_stride, gmask, g_h0, g_h0 && last ? K : 0, g, ty0,
+                                                                                        tx0, P, acc_c, ops0, mom, sa, nullptr, last, tab_geo, &jp,
+                                                                                        hoff);
         if (last) break;
         const long gn = go - (long)K * frame_stride;
         gmask = persist_mask<K>(pa, pa.t_top - K * (grp + 1));
-        if constexpr (PRE)
+        if constexpr (HALFS)
+            persist_load_ops_half<T>(ops0, hframe_t + gn - frame_stride, gmask & 1u ? gframe_t + gn - frame_stride : nullptr, g, hoff[0]);
+        else if constexpr (PRE)
             adj_load_ops<T, K, BX, BY, NT, 0>(ops0, 0, hframe_t + gn - frame_stride, gmask & 1u ? gframe_t + gn - frame_stride : nullptr, g,
                                               ty0, tx0, &sa[0]);
         // (sub-step K - 1 ended with a barrier: buffer 0 is complete)
@@ -1804,34 +1859,6 @@ __device__ __forceinline__ void persist_load_ops(StripOps<T>& o, const T* __rest
     o.v[0] = c.v[0]; o.v[1] = c.v[1]; o.v[2] = d.v[0]; o.v[3] = d.v[1];
     o.ju[0] = a2.v[0]; o.ju[1] = a2.v[1]; o.ju[2] = b2.v[0]; o.ju[3] = b2.v[1];
     o.jv[0] = c2.v[0]; o.jv[1] = c2.v[1]; o.jv[2] = d2.v[0]; o.jv[3] = d2.v[1];
-}
-
-// HALF-strips (round 6): byte offset of the lane's two points inside a species plane, and their pointwise operands
-template <typename T, int K, int BX, int BY, int NT, int M, int PART, int TID0>
-__device__ __forceinline__ unsigned persist_half_off(const TileGeom& g, int ty0, int tx0)
-{
-    using SM = StripMap<K, BX, BY, M, PART>;
-    constexpr int RN4 = SM::N, O = 2 * (M + 1);
-    int hh = (int)threadIdx.x - TID0;
-    if (hh < 0) hh = 0;
-    if (hh >= 2 * RN4) hh = 2 * RN4 - 1;
-    int ry, rc;
-    SM::locate(hh >> 1, ry, rc);
-    const int ly = ry + O, lx = 4 * rc + O + 2 * (hh & 1);
-    const int gy = wrap1(ty0 - 2 * K + ly, g.H), gx = wrap1(tx0 - 2 * K + lx, g.W);      // (two points never straddle the wrap: W is even)
-    return (unsigned)((long)gy * g.W + gx) * (unsigned)sizeof(T);
-}
-template <typename T>
-__device__ __forceinline__ void persist_load_ops_half(StripOps<T>& o, const T* __restrict__ hfr, const T* __restrict__ gfr,
-                                                      const TileGeom& g, unsigned off)
-{
-    const T* gsrc = gfr ? gfr : hfr;
-    const Pack<T, 2> a = *reinterpret_cast<const Pack<T, 2>*>(reinterpret_cast<const char*>(hfr) + off);
-    const Pack<T, 2> c = *reinterpret_cast<const Pack<T, 2>*>(reinterpret_cast<const char*>(hfr + g.ss) + off);
-    const Pack<T, 2> a2 = *reinterpret_cast<const Pack<T, 2>*>(reinterpret_cast<const char*>(gsrc) + off);
-    const Pack<T, 2> c2 = *reinterpret_cast<const Pack<T, 2>*>(reinterpret_cast<const char*>(gsrc + g.ss) + off);
-    o.u[0] = a.v[0]; o.u[1] = a.v[1]; o.v[0] = c.v[0]; o.v[1] = c.v[1];
-    o.ju[0] = a2.v[0]; o.ju[1] = a2.v[1]; o.jv[0] = c2.v[0]; o.jv[1] = c2.v[1];
 }
 
 // Data-tagged granules by value type: ONE 16-byte write-through (sc1) store publishes a granule, ONE 16-byte sc1 load reads it

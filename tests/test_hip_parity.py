@@ -1117,8 +1117,12 @@ def test_small_tile_persistent_sweep_equals_launch_per_group(shape, T, hip_devic
         a0, ag = pa.rollout_bwd(traj, g, P, frame_mask=mask)
         b0, bg = pa.rollout_bwd(traj, g, P, frame_mask=mask, options={"persist_small": 0})
         assert torch.equal(a0, b0)
-        assert rel_l2(ag.cpu().numpy(), bg.cpu().numpy()) < 1e-9
-    assert _lib.persist_status()["launches"] == n0 + 3 and _lib.persist_status()["aborts"] == 0
+        # (round 6: the 32 x 8 sweep works half-strips -- the diffusion-coefficient sums add two products in float32 before the
+        # float64 accumulator instead of four; with whole strips, `adj_small_half=0`, the two paths agree to 1e-9)
+        assert rel_l2(ag.cpu().numpy(), bg.cpu().numpy()) < 5e-7
+        c0, cg = pa.rollout_bwd(traj, g, P, frame_mask=mask, options={"adj_small_half": 0})
+        assert torch.equal(c0, b0) and rel_l2(cg.cpu().numpy(), bg.cpu().numpy()) < 1e-9
+    assert _lib.persist_status()["launches"] == n0 + 6 and _lib.persist_status()["aborts"] == 0
     if shape[0] * shape[1] <= 128 * 128:
         g0_ref, pg_ref = o_rollout_bwd(traj.cpu().numpy(), g.cpu().numpy(), Pn)
         a0, ag = pa.rollout_bwd(traj, g, P)
@@ -2300,7 +2304,9 @@ def test_rollouts_are_hipgraph_capturable(hip_device):
     traj[0] = h0
     pa.rollout_fwd_(traj, P)
     ws = pa.functional.rollout_workspace(0, shape, T, torch.float32, hip_device)
-    g0_ref, pg_ref = pa.rollout_bwd(traj, g, P, ws=ws)
+    # (a capture runs the launch-per-group sweep on whole strips; the eager reference on whole strips too, so that the parameter
+    # sums can be compared to the last bits -- the resident half-strip sweep adds them in another order)
+    g0_ref, pg_ref = pa.rollout_bwd(traj, g, P, ws=ws, options={"adj_small_half": 0})
     ref = traj.clone()
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
