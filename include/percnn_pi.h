@@ -216,6 +216,7 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *                  one launch per four steps: tests and experiments only)
  *   "fwd_small_pause"  0 .. 200, default 12: units of 64 clocks the small-tile resident forward waits between publishing its tile
  *                  and the first request of its ring (granules asked for too early come back stale)
+ *   "fwd_small_half"   0 | 1, default 1: the small-tile resident forward works 32 x 8 tiles on half-strips (512 lanes)
  *   "adj_small_half"   0 | 1, default 1: the small-tile resident sweep works 32 x 8 tiles on half-strips (512 lanes)
  *   "adj_small_pause"  0 .. 200, default 24: the same for the small-tile resident sweep
  *   "fwd_persist"  1 (default): the FORWARD rollout of a grid the persistent sweep takes (float32 pre-contracted block, whole

@@ -62,6 +62,7 @@ struct Options {
                             // launch-per-group sweep is enqueued in the same call and the persistent path is switched off for
                             // this device (percnn_pi_persist_status).  0: no wait; an aborted launch is reported by the NEXT
                             // entry point (PERCNN_PI_EASYNC) instead
+    int fwd_small_half = 1;     // small-tile resident forward (32 x 8 tiles) on half-strips: 512 lanes, two waves per SIMD
     int adj_small_half = 1;     // small-tile resident sweep (32 x 8 tiles) on half-strips: 512 lanes, two waves per SIMD
     int adj_small_pause = 24;   // ... of the small-tile resident SWEEP (100^2 1.53 -> 1.45 us per step, 256^2 1.93 -> 1.70: profiles/r05_small_tile_resident_forward.txt)
     int fwd_small_pause = 12;   // small-tile resident forward: 64-clock units between publish and the first ring request (PersistArgs::pause)
@@ -1742,7 +1743,11 @@ int fwd_persist_small_by(const Problem& p, int ngroups, hipStream_t st)
     // 100^2 1.23 -> 1.08, 256^2 1.22 -> 1.14; 32 x 16 tiles (300 x 320) 1.46 -> 1.63 and ragged 32 x 32 tiles (500^2) 1.92 -> 2.28:
     // whole-tile granules and an un-overlapped hand-over only pay where the sub-steps are short -> the 8-row regime by default,
     // persist_small = 2 takes the others too (tests)
-    if (by != 8 && p.opt.persist_small < 2) return 0;
+    // Round 6, half-strips (twice the lanes, both waves of a SIMD busy): 32 x 8 tiles 100^2 1.05 -> 0.93, 256^2 1.08 -> 1.01; 32 x 16
+    // tiles 288^2 1.53 -> 1.12, 300 x 320 1.47 -> 1.22, 260^2 1.43 -> 1.12 -> the 16-row regime joins the default; ragged 32 x 32
+    // tiles (500^2: 1.90 -> 2.49) stay on the launch-per-group kernel
+    const bool by_default = by == 8 || (by == 16 && p.opt.fwd_small_half);
+    if (!by_default && p.opt.persist_small < 2) return 0;
     const int64_t tiles = ((p.n0 + by - 1) / by) * ((p.W + TILE_B - 1) / TILE_B);
     const int cus = device_cu_count();
     // one workgroup per CU at most: resident for sure (persist_small = 2, experiments: up to fwd_persist_per_cu x 2 per CU --
@@ -1784,7 +1789,7 @@ hipError_t persist_wait_roll_call(volatile int* hs, int slot, int dev, unsigned 
 }
 
 // frames t0 + 1 .. t0 + 4 * ngroups from frame t0; return values as launch_fwd_persist
-template <typename T, int BY, int NT>
+template <typename T, int BY, int NT, bool HALFS = false>
 hipError_t launch_fwd_persist_small_t(T* frame_t0, int ngroups, const T* P, const Problem& p, int dev, hipStream_t st)
 {
     constexpr int K = 4;
@@ -1794,7 +1799,7 @@ hipError_t launch_fwd_persist_small_t(T* frame_t0, int ngroups, const T* P, cons
     constexpr int RINGH = TL::LX * TL::LY - TILE_B * BY, NGAT = (2 * RINGH + NT - 1) / NT;
     // state buffers | gather tables | K rows of strip geometry | abort word
     const size_t lds = pi::tile_state_bytes<T, K, TILE_B, BY>() + (size_t)(2 * NGAT + K) * NT * sizeof(int) + 16;
-    auto* k = pi::pi_fwd2d_persist_small_kernel<T, K, TILE_B, BY, NT>;
+    auto* k = pi::pi_fwd2d_persist_small_kernel<T, K, TILE_B, BY, NT, HALFS>;
     if (hipError_t e = allow_lds(k, lds)) return e;
     {
         static int blocks_per_cu[16] = {};                  // per device (per tile height / value type: a template), asked once
@@ -1859,7 +1864,10 @@ hipError_t launch_fwd_persist_small_t(T* frame_t0, int ngroups, const T* P, cons
 template <typename T>
 hipError_t launch_fwd_persist_small(int by, T* frame_t0, int ngroups, const T* P, const Problem& p, int dev, hipStream_t st)
 {
+    // (round 6: 32 x 8 tiles on half-strips, 512 lanes; fwd_small_half=0: whole strips on 256 lanes)
+    if (by == 8 && p.opt.fwd_small_half) return launch_fwd_persist_small_t<T, 8, 512, true>(frame_t0, ngroups, P, p, dev, st);
     if (by == 8) return launch_fwd_persist_small_t<T, 8, 256>(frame_t0, ngroups, P, p, dev, st);
+    if (by == 16 && p.opt.fwd_small_half) return launch_fwd_persist_small_t<T, 16, 640, true>(frame_t0, ngroups, P, p, dev, st);
     if (by == 16) return launch_fwd_persist_small_t<T, 16, 320>(frame_t0, ngroups, P, p, dev, st);
     return launch_fwd_persist_small_t<T, TILE_B, 512>(frame_t0, ngroups, P, p, dev, st);
 }
@@ -1869,6 +1877,8 @@ hipError_t launch_adj_persist_small(const T* hframe_t, const T* gframe_t, T* afr
                                     int ngroups, double* partials, unsigned long long* outbox, unsigned* sync, const T* P,
                                     const Problem& p, int dev, hipStream_t st)
 {
+    if (tile_by_for(p) == 16 && p.opt.adj_small_half)
+        return launch_adj_persist_small_t<T, 16, 640, true>(hframe_t, gframe_t, aframe_t, g_h0, t_top, mask, ngroups, partials, outbox, sync, P, p, dev, st);
     if (tile_by_for(p) == 16)
         return launch_adj_persist_small_t<T, 16, 320>(hframe_t, gframe_t, aframe_t, g_h0, t_top, mask, ngroups, partials, outbox, sync, P, p, dev, st);
     // (round 6: half-strips on 512 lanes -- two waves per SIMD; adj_small_half=0: whole strips on 256 lanes)
@@ -2937,6 +2947,7 @@ int apply_option(Options& o, const char* key, long value)
     if (!std::strcmp(key, "block_small")) { o.block_small = value != 0; return 0; }
     if (!std::strcmp(key, "slab_wide_adjoint")) { o.slab_wide_adjoint = value != 0; return 0; }
     if (!std::strcmp(key, "slab_local_index")) { o.slab_local_index = value != 0; return 0; }
+    if (!std::strcmp(key, "fwd_small_half")) { if (value < 0 || value > 1) return PERCNN_PI_EINVAL; o.fwd_small_half = (int)value; return 0; }
     if (!std::strcmp(key, "adj_small_half")) { if (value < 0 || value > 1) return PERCNN_PI_EINVAL; o.adj_small_half = (int)value; return 0; }
     if (!std::strcmp(key, "adj_small_pause")) { if (value < 0 || value > 200) return PERCNN_PI_EINVAL; o.adj_small_pause = (int)value; return 0; }
     if (!std::strcmp(key, "fwd_small_pause")) { if (value < 0 || value > 200) return PERCNN_PI_EINVAL; o.fwd_small_pause = (int)value; return 0; }

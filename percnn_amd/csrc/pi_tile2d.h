@@ -503,10 +503,10 @@ __device__ __forceinline__ void fwd_substep(T* cur, T* nxt, const T* __restrict_
 }
 
 // first lane of the waves that own no strip in sub-step M (NT: every wave works)
-template <int K, int BX, int BY, int NT, int M, int CHUNKS>
+template <int K, int BX, int BY, int NT, int M, int CHUNKS, int PTS = 4>      // PTS: points per lane (2: half-strips)
 constexpr int fwd_first_idle_lane()
 {
-    constexpr int rn4 = Tile<K, BX, BY>::region_n(M) / 4;
+    constexpr int rn4 = Tile<K, BX, BY>::region_n(M) / PTS;
     constexpr int busy = (rn4 + WAVE - 1) / WAVE * WAVE;
     // only where the idle waves get away with <= PI_FWD_IDLE_MAX chunks per lane: ONE idle wave storing a whole frame (8 chunks
     // per lane, 16 in float64) takes longer than the sub-step it hides behind and becomes the critical path (measured: 512^2
@@ -550,23 +550,32 @@ __device__ __forceinline__ void tile_store_by_idle(const T* buf, T* __restrict__
 // `STORE_AHEAD`: sub-step M has idle waves (compile time; otherwise the all-waves store after the barrier stays).
 template <typename T, int K, int BX, int BY>
 __device__ __forceinline__ void fwd_strip_geo(const T* cur, T* nxt, const T* __restrict__ P, unsigned w);
+template <typename T, int K, int BX, int BY>
+__device__ __forceinline__ void fwd_half_strip_geo(const T* cur, T* nxt, const T* __restrict__ P, unsigned w);
+// HALFS (round 6, resident small-tile forward; float32): the lanes work on half-strips, `geo`[K] = the lane's own geometry words
+// (fwd_half_word<PART_FULL>, held in registers by the caller).
 // LAST_STORE = false: frame K stays in LDS (the resident small-tile forward stores it after its hand-over has been started);
 // GEO: the lane's strip of each sub-step comes as a geometry word from an LDS table ([K][NT], persist_geo_word; one strip per
 // lane) instead of being derived from the lane id in every sub-step of every group; WT = false: plain frame stores
-template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool LAST_STORE = true, bool GEO = false, bool WT = true>
+template <typename T, int HC, int K, int BX, int BY, int NT, int M, bool LAST_STORE = true, bool GEO = false, bool WT = true,
+          bool HALFS = false>
 __device__ __forceinline__ void fwd_substeps(T* b0, T* b1, T* __restrict__ frames, long frame_stride, const TileGeom& g,
                                              int ty0, int tx0, const T* __restrict__ P, const unsigned* geo = nullptr)
 {
     T* cur = (M & 1) ? b1 : b0;
     T* nxt = (M & 1) ? b0 : b1;
     constexpr int CHUNKS = 2 * BY * BX / vec_width<T>::value;
-    constexpr int IDLE = fwd_first_idle_lane<K, BX, BY, NT, M, CHUNKS>();
+    constexpr int PTS = HALFS ? 2 : 4;
+    constexpr int IDLE = fwd_first_idle_lane<K, BX, BY, NT, M, CHUNKS, PTS>();
     constexpr bool STORE_HERE = PI_FWD_IDLE_STORE && M >= 1 && IDLE < NT;       // frame M: by this sub-step's idle waves
     if constexpr (STORE_HERE) {
         if ((int)threadIdx.x >= IDLE)
             tile_store_by_idle<T, K, BX, BY, NT, IDLE, ((M - 1) & 1) != 0, WT>(cur, frames + (long)M * frame_stride, g, ty0, tx0);
     }
-    if constexpr (GEO) {
+    if constexpr (HALFS) {
+        static_assert(HC == POLY && Tile<K, BX, BY>::region_n(0) / 2 <= NT, "one half-strip per lane, pre-contracted block");
+        fwd_half_strip_geo<T, K, BX, BY>(cur, nxt, P, geo[M]);
+    } else if constexpr (GEO) {
         static_assert(HC == POLY && Tile<K, BX, BY>::region_n(0) / 4 <= NT, "one strip per lane, pre-contracted block");
         fwd_strip_geo<T, K, BX, BY>(cur, nxt, P, geo[M * NT + (int)threadIdx.x]);
     } else {
@@ -575,12 +584,12 @@ __device__ __forceinline__ void fwd_substeps(T* b0, T* b1, T* __restrict__ frame
     PI_STAMP(2 + 2 * M);
     lds_barrier();                                         // do not drain the previous frame's global stores
     // frame M + 1: left to the idle waves of the next sub-step if it has any, else stored now by everybody
-    constexpr bool NEXT_STORES = PI_FWD_IDLE_STORE && M + 1 < K && fwd_first_idle_lane<K, BX, BY, NT, (M + 1 < K ? M + 1 : M), CHUNKS>() < NT;
+    constexpr bool NEXT_STORES = PI_FWD_IDLE_STORE && M + 1 < K && fwd_first_idle_lane<K, BX, BY, NT, (M + 1 < K ? M + 1 : M), CHUNKS, PTS>() < NT;
     if constexpr (!NEXT_STORES && (M + 1 < K || LAST_STORE))
         tile_store<T, K, BX, BY, NT, (M & 1) != 0, WT>(nxt, frames + (long)(M + 1) * frame_stride, g, ty0, tx0);
     PI_STAMP(3 + 2 * M);
     if constexpr (M + 1 < K)
-        fwd_substeps<T, HC, K, BX, BY, NT, M + 1, LAST_STORE, GEO, WT>(b0, b1, frames, frame_stride, g, ty0, tx0, P, geo);
+        fwd_substeps<T, HC, K, BX, BY, NT, M + 1, LAST_STORE, GEO, WT, HALFS>(b0, b1, frames, frame_stride, g, ty0, tx0, P, geo);
 }
 
 template <typename T, int HC, int K, int BX, int BY, int NT>
@@ -2537,11 +2546,11 @@ __device__ __forceinline__ void persist_fwd_store(const T* buf, T* __restrict__ 
 // overlap them (tools/ubench/strip_ubench.hip, profiles/r06_granule_pairs.txt).  Cut in two, a pass's strips occupy all eight
 // waves -- both waves of a SIMD -- with half the dependent work each.  Same operations in the same order per point: bit-identical.
 // Geometry word of half-strip h (strip h / 2 of the pass's annulus, points 2 (h % 2) .. + 1): bits 0-15 LDS offset, 16 live.
-template <int K, int BX, int BY, int M>
+template <int K, int BX, int BY, int M, int PART = PART_ANN>
 __device__ __forceinline__ unsigned fwd_half_word(int h)
 {
     using TL = Tile<K, BX, BY>;
-    using SM = StripMap<K, BX, BY, M, PART_ANN>;
+    using SM = StripMap<K, BX, BY, M, PART>;
     constexpr int O = 2 * (M + 1);
     const bool live = h >= 0 && (h >> 1) < SM::N;
     int idx = live ? (h >> 1) : 0;
@@ -2926,7 +2935,9 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
 // pi_fwd2d_tile_kernel's own device functions (fwd_substeps): the trajectory is that kernel's bit for bit.  The frame a group ends
 // on is stored AFTER the tile has been published and the ring requested: the neighbours wait for the granules, nobody for it.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int K, int BX, int BY, int NT>
+// HALFS (round 6): half-strips on twice the lanes -- both waves of a SIMD work in every sub-step (7 | 5 | 4 | 2 waves of a 32 x 8 tile
+// instead of 4 | 3 | 2 | 1), half the granule requests per lane in the hand-over.  Same operations per point: bit-identical.
+template <typename T, int K, int BX, int BY, int NT, bool HALFS = false>
 __global__ void __launch_bounds__(NT)
 pi_fwd2d_persist_small_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngroups are written */, long frame_stride,
                               const T* __restrict__ P_in, TileGeom g, PersistArgs pa)
@@ -3003,12 +3014,21 @@ pi_fwd2d_persist_small_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K
         Ph[i] = x;
     }
     const T* P = Ph;
+    unsigned gw[K] = {0u, 0u, 0u, 0u};                                     // HALFS: the lane's half-strip in each sub-step
+    if constexpr (HALFS) {
+        gw[0] = fwd_half_word<K, BX, BY, 0, PART_FULL>(tid);
+        gw[1] = fwd_half_word<K, BX, BY, 1, PART_FULL>(tid);
+        gw[2] = fwd_half_word<K, BX, BY, 2, PART_FULL>(tid);
+        gw[3] = fwd_half_word<K, BX, BY, 3, PART_FULL>(tid);
+#pragma unroll
+        for (int m = 0; m < K; ++m) asm volatile("" : "+v"(gw[m]));
+    }
     for (int grp = 0; grp < pa.ngroups; ++grp) {
         T* fr = frames + (long)grp * K * frame_stride;                    // this group's frame t
         const bool last = grp + 1 == pa.ngroups;
         // frames t + 1 .. t + K - 1 go to memory as in the launch-per-group kernel (idle-wave stores included); frame t + K is
         // complete in buffer 0 after the barrier that ends sub-step K - 1
-        fwd_substeps<T, POLY, K, BX, BY, NT, 0, false, GEO, WT>(b0, b1, fr, frame_stride, g, ty0, tx0, P, tab_geo);
+        fwd_substeps<T, POLY, K, BX, BY, NT, 0, false, GEO, WT, HALFS>(b0, b1, fr, frame_stride, g, ty0, tx0, P, HALFS ? gw : tab_geo);
         if (last) {
             tile_store<T, K, BX, BY, NT, true, WT>(b0, fr + (long)K * frame_stride, g, ty0, tx0);
             break;

@@ -1035,8 +1035,9 @@ def test_small_tile_persistent_forward_equals_launch_per_group(shape, T, hip_dev
     stay on launches, `fwd_persist=0` is the old path, no aborts."""
     import percnn_amd as pa
     from percnn_amd import _lib
-    # by default the 8-row regime only (the others measured slower than one launch per group); persist_small = 2 takes them all
-    small8 = _lib.rollout_plan(0, shape, 4)["tile_fwd"] == (32, 8, 256)
+    # by default the 8- and (round 6, on half-strips) 16-row regimes (ragged 32 x 32 tiles measured slower than one launch per
+    # group); persist_small = 2 takes them all
+    small8 = _lib.rollout_plan(0, shape, 4)["tile_fwd"] in ((32, 8, 256), (32, 16, 320))
     opt = {} if small8 else {"persist_small": 2}
     ostr = "" if small8 else "persist_small=2"
     assert _lib.rollout_plan(0, shape, 4, ostr or None)["fwd_persistent"] and _lib.rollout_plan(0, shape, 4)["fwd_persistent"] == small8
@@ -1064,6 +1065,12 @@ def test_small_tile_persistent_forward_equals_launch_per_group(shape, T, hip_dev
     assert torch.equal(a[:29], short)
     if shape[0] * shape[1] <= 128 * 128:
         assert np.array_equal(a[:13].cpu().numpy(), o_rollout_fwd(h0, Pn, 12))
+    if small8:                                              # the whole-strip resident kernels (256 / 320 lanes) behind fwd_small_half=0
+        w = torch.full_like(a, float("nan"))
+        w[0] = a[0]
+        pa.rollout_fwd_(w, P, options={"fwd_small_half": 0, "persist_small": 2})
+        assert torch.equal(w, a) and _lib.persist_status()["launches"] == n1["launches"] + 1
+        n1 = _lib.persist_status()
     # twice, back to back on the same stream (the per-device granule scratch is reused: epochs start over), then on another stream
     c = torch.full_like(a, float("nan"))
     c[0] = a[0]
