@@ -2563,7 +2563,6 @@ __device__ __forceinline__ unsigned fwd_half_word(int h)
 template <typename T, int K, int BX, int BY>
 __device__ __forceinline__ void fwd_half_strip_geo(const T* cur, T* nxt, const T* __restrict__ P, unsigned w)
 {
-    static_assert(sizeof(T) == 4, "float32");
     using TL = Tile<K, BX, BY>;
     constexpr int LX = TL::LX;
     if (__builtin_amdgcn_ballot_w64(((w >> 16) & 1u) != 0u) == 0ull) return;       // whole waves without a half-strip in this pass
@@ -2666,6 +2665,9 @@ struct FwdStoreMap {
 #define PI_FWD_I2_EARLY 0               // resident forward: the pyramid's third level under the ring's flight instead of next to A_0
                                         // (round 6: bit-identical, 1.26 -> 1.27-1.32 us per step: the extra barrier costs what P2 gains).  Off.
 #endif
+#ifndef PI_FWD_HALF_STRIPS_F64
+#define PI_FWD_HALF_STRIPS_F64 1        // ... of the float64 forward (a strip is twice the instructions there)
+#endif
 #ifndef PI_FWD_HALF_STRIPS
 #define PI_FWD_HALF_STRIPS 0            // float32 resident forward: the annulus passes on two-point half-strips (all eight waves).
                                         // Measured (round 6): bit-identical, 1.26 -> 1.24 us per step -- a half-strip takes as long as a strip
@@ -2745,7 +2747,7 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
     // two-workgroups-per-CU mode of option fwd_persist_per_cu still fits; 1.29 instead of 1.26 us per step); 0: round 5's body
     constexpr bool HOLD = HOLDP != 0;                       // (float64: 101 -> ~190 of 256 registers)
     T Ph[HOLD ? NPOLY : 1];
-    constexpr bool HALF = HOLD && PI_FWD_HALF_STRIPS != 0 && sizeof(T) == 4;
+    constexpr bool HALF = HOLD && ((PI_FWD_HALF_STRIPS != 0 && sizeof(T) == 4) || (PI_FWD_HALF_STRIPS_F64 != 0 && sizeof(T) == 8));
     unsigned gw[HOLD ? 7 : 1];
     FwdStoreMap<T, K, BX, BY, NT, IDLE> smap;
     FwdStoreMap<T, K, BX, BY, NT, 0> smap_all;              // (half-strip passes: every wave computes, every lane stores one chunk)
