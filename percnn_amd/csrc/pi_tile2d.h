@@ -2000,7 +2000,11 @@ template <typename T, int PASS> struct sweep_half_pass {
 #ifndef PI_SWEEP_HALF_F64
 #define PI_SWEEP_HALF_F64 1
 #endif
-    static constexpr bool value = PI_SWEEP_HALF != 0 && (sizeof(T) == 4 || PI_SWEEP_HALF_F64 != 0) && PASS != 2 && (((PI_SWEEP_HALF_MASK) >> PASS) & 1) != 0;
+#ifndef PI_SWEEP_HALF_MASK_F64
+#define PI_SWEEP_HALF_MASK_F64 0x39         // (P1 too, 0x3B: 3.29 -> 3.29 us per step, no change)
+#endif
+    static constexpr bool value = PI_SWEEP_HALF != 0 && (sizeof(T) == 4 || PI_SWEEP_HALF_F64 != 0) && PASS != 2 &&
+                                  ((((sizeof(T) == 8 ? (PI_SWEEP_HALF_MASK_F64) : (PI_SWEEP_HALF_MASK))) >> PASS) & 1) != 0;
 };
 constexpr int SWEEP_HALF_P5_SPLIT = 128;                   // P5 on half-strips: I_3 = 64 strips on lanes 0 .. 127, A_3 = 192 from lane 128 on
 
@@ -2668,10 +2672,18 @@ struct FwdStoreMap {
 #ifndef PI_FWD_HALF_STRIPS_F64
 #define PI_FWD_HALF_STRIPS_F64 1        // ... of the float64 forward (a strip is twice the instructions there)
 #endif
+#ifndef PI_FWD_HALF_PYR_F64
+#define PI_FWD_HALF_PYR_F64 0           // ... and its pyramid passes P0 / P1 (I_0 on seven waves instead of four, I_1 on five instead of three):
+                                        // bit-identical, lambda-omega forward 1.807 -> 1.838 us per step (they run under the ring's flight).  Off.
+#endif
+#ifndef PI_FWD_HALF_PYR
+#define PI_FWD_HALF_PYR 0
+#endif
 #ifndef PI_FWD_HALF_STRIPS
 #define PI_FWD_HALF_STRIPS 0            // float32 resident forward: the annulus passes on two-point half-strips (all eight waves).
                                         // Measured (round 6): bit-identical, 1.26 -> 1.24 us per step -- a half-strip takes as long as a strip
-                                        // (0.52-0.56 us: the pass is LDS round trips, not arithmetic).  Off.
+                                        // (0.52-0.56 us: the pass is LDS round trips, not arithmetic); again after the small-tile work:
+                                        // 1.27 -> 1.258, headline 325.9 -> 326.3 k.  Off (float64, twice the arithmetic per strip, takes it).
 #endif
 #ifndef PI_FWD_HOLD_P
 #define PI_FWD_HOLD_P 1                 // float32 resident forward: parameter block (1: vector, 2: scalar registers), strip geometry and
@@ -2748,6 +2760,7 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
     constexpr bool HOLD = HOLDP != 0;                       // (float64: 101 -> ~190 of 256 registers)
     T Ph[HOLD ? NPOLY : 1];
     constexpr bool HALF = HOLD && ((PI_FWD_HALF_STRIPS != 0 && sizeof(T) == 4) || (PI_FWD_HALF_STRIPS_F64 != 0 && sizeof(T) == 8));
+    constexpr bool HALF_PYR = HALF && ((PI_FWD_HALF_PYR != 0 && sizeof(T) == 4) || (PI_FWD_HALF_PYR_F64 != 0 && sizeof(T) == 8));
     unsigned gw[HOLD ? 7 : 1];
     FwdStoreMap<T, K, BX, BY, NT, IDLE> smap;
     FwdStoreMap<T, K, BX, BY, NT, 0> smap_all;              // (half-strip passes: every wave computes, every lane stores one chunk)
@@ -2770,6 +2783,10 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
             gw[3] = fwd_half_word<K, BX, BY, 1>(tid);
             gw[4] = fwd_half_word<K, BX, BY, 2>(tid);
             if (tid >= 64) gw[5] = fwd_half_word<K, BX, BY, 3>(tid - 64);
+            if constexpr (HALF_PYR) {
+                gw[0] = fwd_half_word<K, BX, BY, 0, PART_PYR>(tid);
+                gw[1] = fwd_half_word<K, BX, BY, 1, PART_PYR>(tid);
+            }
             smap_all.init(g, ty0, tx0);
         }
 #pragma unroll
@@ -2795,8 +2812,13 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
         T* fr = frames + (long)grp * K * frame_stride;                    // this group's frame t: fr + m * frame_stride = level m
         PI_PSTAMP(0);
         // ---- P0: I_0 (b0 -> b1); the idle waves store level 4 of the previous group (= this group's level 0, complete in b0) ----
-        if (grp > 0) PI_FWD_STORE(true, 0, b0, fr);
-        PI_FWD_STRIP(b0, b1, P, PI_FWD_GEO(0));
+        if constexpr (HALF_PYR) {
+            if (grp > 0) smap_all.template store<true, 0>(b0, fr);
+            half_strip(b0, b1, gw[0]);
+        } else {
+            if (grp > 0) PI_FWD_STORE(true, 0, b0, fr);
+            PI_FWD_STRIP(b0, b1, P, PI_FWD_GEO(0));
+        }
         lds_barrier();
         PI_PSTAMP(1);
         const unsigned epoch = (unsigned)grp;
@@ -2817,8 +2839,13 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
         };
         if constexpr (PI_FWD_PERSIST_REQ_AFTER == 0) request();
         // ---- P1: I_1 (b1 -> b0 centre); the idle waves store the block of level 1 that I_2 will overwrite ----
-        PI_FWD_STORE(false, 1, b1, fr + frame_stride);
-        PI_FWD_STRIP(b1, b0, P, PI_FWD_GEO(1));
+        if constexpr (HALF_PYR) {
+            smap_all.template store<false, 1>(b1, fr + frame_stride);
+            half_strip(b1, b0, gw[1]);
+        } else {
+            PI_FWD_STORE(false, 1, b1, fr + frame_stride);
+            PI_FWD_STRIP(b1, b0, P, PI_FWD_GEO(1));
+        }
         PI_PSTAMP(2);
         if constexpr (PI_FWD_PERSIST_REQ_AFTER == 1) request();
         if constexpr (PI_FWD_I2_EARLY != 0) {
