@@ -2672,6 +2672,9 @@ struct FwdStoreMap {
 #ifndef PI_FWD_HALF_STRIPS_F64
 #define PI_FWD_HALF_STRIPS_F64 1        // ... of the float64 forward (a strip is twice the instructions there)
 #endif
+#ifndef PI_FWD_HALF_I3
+#define PI_FWD_HALF_I3 1                // half-strip builds: I_3 (P5) on half-strips too, on waves 0 and 7, instead of whole strips on wave 0
+#endif
 #ifndef PI_FWD_HALF_PYR_F64
 #define PI_FWD_HALF_PYR_F64 0           // ... and its pyramid passes P0 / P1 (I_0 on seven waves instead of four, I_1 on five instead of three):
                                         // bit-identical, lambda-omega forward 1.807 -> 1.838 us per step (they run under the ring's flight).  Off.
@@ -2783,6 +2786,10 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
             gw[3] = fwd_half_word<K, BX, BY, 1>(tid);
             gw[4] = fwd_half_word<K, BX, BY, 2>(tid);
             if (tid >= 64) gw[5] = fwd_half_word<K, BX, BY, 3>(tid - 64);
+            if constexpr (PI_FWD_HALF_I3 != 0) {            // I_3 = 128 half-strips on wave 0 and on wave 7 (idle in P5 otherwise)
+                if (tid < 64) gw[5] = fwd_half_word<K, BX, BY, 3, PART_PYR>(tid);
+                if (tid >= 448) gw[5] = fwd_half_word<K, BX, BY, 3, PART_PYR>(tid - 448 + 64);
+            }
             if constexpr (HALF_PYR) {
                 gw[0] = fwd_half_word<K, BX, BY, 0, PART_PYR>(tid);
                 gw[1] = fwd_half_word<K, BX, BY, 1, PART_PYR>(tid);
@@ -2924,7 +2931,7 @@ pi_fwd2d_persist_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K * ngr
         // ---- P5: I_3 + A_3 (b1 -> b0); level 3 is complete in b1 ----
         if constexpr (HALF) {
             smap_all.template store<false, 0>(b1, fr + 3 * frame_stride);
-            if (wave_id < 1) PI_FWD_STRIP(b1, b0, P, gw[5]);
+            if (PI_FWD_HALF_I3 == 0 && wave_id < 1) PI_FWD_STRIP(b1, b0, P, gw[5]);
             else half_strip(b1, b0, gw[5]);
         } else {
             PI_FWD_STORE(false, 0, b1, fr + 3 * frame_stride);
