@@ -2683,10 +2683,11 @@ struct FwdStoreMap {
 #define PI_FWD_HALF_PYR 0
 #endif
 #ifndef PI_FWD_HALF_STRIPS
-#define PI_FWD_HALF_STRIPS 0            // float32 resident forward: the annulus passes on two-point half-strips (all eight waves).
+#define PI_FWD_HALF_STRIPS 1            // float32 resident forward: the annulus passes on two-point half-strips (all eight waves).
                                         // Measured (round 6): bit-identical, 1.26 -> 1.24 us per step -- a half-strip takes as long as a strip
                                         // (0.52-0.56 us: the pass is LDS round trips, not arithmetic); again after the small-tile work:
-                                        // 1.27 -> 1.258, headline 325.9 -> 326.3 k.  Off (float64, twice the arithmetic per strip, takes it).
+                                        // 1.27 -> 1.258; with I_3 on half-strips as well (PI_FWD_HALF_I3) 1.27 -> 1.239, headline 325.9 ->
+                                        // 328.4 k: ON since then (float64, twice the arithmetic per strip, gains 12 % from the same passes).
 #endif
 #ifndef PI_FWD_HOLD_P
 #define PI_FWD_HOLD_P 1                 // float32 resident forward: parameter block (1: vector, 2: scalar registers), strip geometry and
