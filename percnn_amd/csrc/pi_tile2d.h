@@ -2544,11 +2544,13 @@ __device__ __forceinline__ void persist_fwd_store(const T* buf, T* __restrict__ 
 #define PI_FWD_PERSIST_WT 0             // frame stores of the resident forward: 0 = plain (write-back) stores.  Nobody reads a frame from
 #endif                                  // memory before the launch ends (the state lives in LDS, halos travel as granules), and write-through
                                         // stores compete with the latency-critical granule loads: 5.8 -> 5.45 us per group (tools/fwd_dev.hip)
-// HALF STRIPS (float32, round 6).  The annulus passes A_0 .. A_3 of a group are the loop ring -> A_0 .. A_3 -> publish -> flight that
+// HALF STRIPS (round 6; float32 and float64).  The annulus passes A_0 .. A_3 of a group are the loop ring -> A_0 .. A_3 -> publish -> flight that
 // sets the resident forward's pace, and each of them is ONE four-point strip per wave on four to six of the eight waves: 128
 // instructions (0.19 us of VALU issue) that take 0.56 us because the wave waits for its own LDS round trips with nobody to
 // overlap them (tools/ubench/strip_ubench.hip, profiles/r06_granule_pairs.txt).  Cut in two, a pass's strips occupy all eight
 // waves -- both waves of a SIMD -- with half the dependent work each.  Same operations in the same order per point: bit-identical.
+// float64, whose strips are twice the instructions, gains 12 % of its forward from it (with I_3 of pass P5 on half-strips too),
+// float32 2.4 %.  PART_FULL / PART_PYR words: the small-tile resident forward's sub-steps and I_3.
 // Geometry word of half-strip h (strip h / 2 of the pass's annulus, points 2 (h % 2) .. + 1): bits 0-15 LDS offset, 16 live.
 template <int K, int BX, int BY, int M, int PART = PART_ANN>
 __device__ __forceinline__ unsigned fwd_half_word(int h)
