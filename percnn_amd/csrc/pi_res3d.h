@@ -553,7 +553,7 @@ __device__ __forceinline__ void adj_load(AdjOps& o, const float* hfr, long ss, u
 
 // one strip of one adjoint step: Gp = G + coef * (dt * LapT(G)) + dt * J_react(h)^T G (+ inj); pi_adj3d_brick_kernel's order
 // `jfr` (nullable, wave-uniform): the frame of dL/dtraj this step injects; its strip is requested at the top and used at the bottom
-__device__ __forceinline__ void adj_strip(const unsigned char* smem, unsigned lo, const float* __restrict__ P, const AdjOps& o,
+__device__ __forceinline__ void adj_strip_whole(const unsigned char* smem, unsigned lo, const float* __restrict__ P, const AdjOps& o,
                                           const float* jfr, long ss, unsigned go, v4f& ou, v4f& ov, float (&mom)[2][10], double (&lane_c)[2])
 {
     v4f ju, jv;
@@ -645,6 +645,159 @@ __device__ __forceinline__ void adj_strip(const unsigned char* smem, unsigned lo
     }
 }
 
+// ---- the strip as TWO HALF-STRIPS on explicit pairs (round 6, late) ----
+// The four-point strip above (kept below as adj_strip_whole, R3D_ADJ_HALVES = 0) is scalar source that hipcc's SLP vectoriser packs
+// by itself: 418 vector instructions per strip where ~200 packed ones would do (118 v_mov building operand pairs), 256 registers and
+// 128 bytes of scratch.  Written as two halves of two x-adjacent points each on 2-vectors -- every LDS read is an 8-byte pair that
+// IS the operand of a v_pk_fma_f32 -- the same IEEE operations in the same order per point (adjoint state bit-identical) need no
+// pair building, and a half's temporaries are half a strip's.  R3D_MOM_PAIRS: the 20 moment sums as pairs (40 registers, one
+// packed FMA per moment and half) or as scalars (20 registers, two FMAs).
+// MEASURED AND NOT ADOPTED (tools/res3d, 128^3, dense injection, us per step): whole strips 16.3 | halves 21.9 (pairs) / 22.3
+// (scalar sums) | halves without the scheduling barrier between them 20.0 | whole strips with the parameter block re-read per strip
+// (R3D_P_RELOAD) 24.1.  All bit-identical.  The halves do drop ~50 v_mov per strip (264 v_mov_b32 against 590 + 100 v_pk_mov in the
+// kernel) but the allocator answers with MORE spills (216 bytes of scratch against 128, 136 scalar registers spilled to lanes
+// against 122): the kernel's wall is the 32 held outputs + 20 sums + operand ring next to ~50 live constants, not the strip's shape.
+#ifndef R3D_ADJ_HALVES
+#define R3D_ADJ_HALVES 0
+#endif
+#ifndef R3D_MOM_PAIRS
+#define R3D_MOM_PAIRS 1
+#endif
+#ifndef R3D_HALF_BARRIER
+#define R3D_HALF_BARRIER 1
+#endif
+#if R3D_ADJ_HALVES && R3D_MOM_PAIRS
+typedef v2f MomSum;
+__device__ __forceinline__ float mom_total(v2f a) { return a.x + a.y; }
+__device__ __forceinline__ v2f mom_zero() { return v2f{0.f, 0.f}; }
+#else
+typedef float MomSum;
+__device__ __forceinline__ float mom_total(float a) { return a; }
+__device__ __forceinline__ float mom_zero() { return 0.f; }
+#endif
+__device__ __forceinline__ v2f bc2(float x) { return v2f{x, x}; }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void mom_add(v2f& acc, v2f gr, v2f phi) { acc = fma2(gr, phi, acc); }
+__device__ __forceinline__ void mom_add(float& acc, v2f gr, v2f phi) { acc = fma_(gr.x, phi.x, acc); acc = fma_(gr.y, phi.y, acc); }
+__device__ __forceinline__ void mom_add1(v2f& acc, v2f gr) { acc += gr; }
+__device__ __forceinline__ void mom_add1(float& acc, v2f gr) { acc += gr.x; acc += gr.y; }
+// pi::poly_dr on pairs (same operations in the same order)
+__device__ __forceinline__ void poly_dr2(const float* __restrict__ c, v2f u, v2f v, v2f& ru, v2f& rv)
+{
+    const v2f A1 = fma2(v, fma2(v, bc2(c[8]), bc2(c[4])), bc2(c[1]));
+    const v2f A2x2 = fma2(v, bc2(2.f * c[7]), bc2(2.f * c[3]));
+    ru = fma2(u, fma2(u, bc2(3.f * c[6]), A2x2), A1);
+    const v2f B0 = fma2(v, fma2(v, bc2(3.f * c[9]), bc2(2.f * c[5])), bc2(c[2]));
+    const v2f B1 = fma2(v, bc2(2.f * c[8]), bc2(c[4]));
+    rv = fma2(u, fma2(u, bc2(c[7]), B1), B0);
+}
+// the two points at window byte offset `lo` (8-byte aligned); hu / hv: their state operands
+template <typename MOM>
+__device__ __forceinline__ void adj_half(const unsigned char* smem, unsigned lo, const float* __restrict__ P, v2f hu, v2f hv,
+                                         v2f& ou, v2f& ov, MOM (&mom)[2][10], double (&lane_c)[2])
+{
+    v2f gc[2], dl[2];
+    const v2f dt = bc2(P[P_DT]);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const unsigned char* b = smem + s * SP + lo;
+        const v2f W[3] = {lds2(b - 8), lds2(b), lds2(b + 8)};
+        gc[s] = W[1];
+        v2f l = bc2(P[P_C0]) * W[1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = -(t < 2 ? t - 2 : t - 1);                      // the transposed stencil: taps at mirrored offsets
+            l = fma2(bc2(P[P_TAPS + t]), lds2(b + k * ZS), l);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = -(t < 2 ? t - 2 : t - 1);
+            l = fma2(bc2(P[P_TAPS + 4 + t]), lds2(b + k * YS), l);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = -(t < 2 ? t - 2 : t - 1);
+            const int idx = 2 + k;                                       // element of the six-point row window W
+            const v2f nb = (idx & 1) ? v2f{W[idx / 2].y, W[idx / 2 + 1].x} : W[idx / 2];
+            l = fma2(bc2(P[P_TAPS + 8 + t]), nb, l);
+        }
+        dl[s] = l * dt;
+    }
+    v2f du = {0.f, 0.f}, dv = {0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float* c = P + P_W + 10 * s;
+        const v2f gr = gc[s] * dt;
+        const v2f ch = dl[s] * (s == 0 ? hu : hv);
+        double acc_c = 0.0;
+        acc_c += (double)ch.x;
+        acc_c += (double)ch.y;
+        lane_c[s] += acc_c;
+        v2f ru, rv;
+        poly_dr2(c, hu, hv, ru, rv);
+        du = fma2(gr, ru, du);
+        dv = fma2(gr, rv, dv);
+    }
+    {
+        const v2f u2 = hu * hu, uv = hu * hv, v2 = hv * hv;
+        const v2f u3 = u2 * hu, u2v = u2 * hv, uv2 = hu * v2, v3 = v2 * hv;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const v2f gr = gc[s] * dt;
+            MOM (&acc)[10] = mom[s];
+            mom_add1(acc[0], gr);
+            mom_add(acc[1], gr, hu); mom_add(acc[2], gr, hv);
+            mom_add(acc[3], gr, u2); mom_add(acc[4], gr, uv); mom_add(acc[5], gr, v2);
+            mom_add(acc[6], gr, u3); mom_add(acc[7], gr, u2v); mom_add(acc[8], gr, uv2); mom_add(acc[9], gr, v3);
+        }
+    }
+    const v2f tu = bc2(P[P_COEF + 0]) * dl[0] + du;
+    const v2f tv = bc2(P[P_COEF + 1]) * dl[1] + dv;
+    ou = gc[0] + tu;
+    ov = gc[1] + tv;
+}
+
+// one strip of one adjoint step: Gp = G + coef * (dt * LapT(G)) + dt * J_react(h)^T G (+ inj); pi_adj3d_brick_kernel's order
+// `jfr` (nullable, wave-uniform): the frame of dL/dtraj this step injects; its strip is requested at the top and used at the bottom
+template <typename MOM>
+__device__ __forceinline__ void adj_strip(const unsigned char* smem, unsigned lo, const float* __restrict__ P, const AdjOps& o,
+                                          const float* jfr, long ss, unsigned go, v4f& ou, v4f& ov, MOM (&mom)[2][10], double (&lane_c)[2])
+{
+    v4f ju, jv;
+    if (jfr) {
+        ju = *(const gv4f*)((const gchar*)jfr + go);
+        jv = *(const gv4f*)((const gchar*)(jfr + ss) + go);
+    }
+    v2f au, av, bu, bv;
+    adj_half(smem, lo, P, v2f{o.u[0], o.u[1]}, v2f{o.v[0], o.v[1]}, au, av, mom, lane_c);
+#if R3D_HALF_BARRIER
+    __builtin_amdgcn_sched_barrier(0);                                  // one half at a time (interleaved, their temporaries add up)
+#endif
+    adj_half(smem, lo + 8, P, v2f{o.u[2], o.u[3]}, v2f{o.v[2], o.v[3]}, bu, bv, mom, lane_c);
+    ou = v4f{au.x, au.y, bu.x, bu.y};
+    ov = v4f{av.x, av.y, bv.x, bv.y};
+    if (jfr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ou[i] += ju[i]; ov[i] += jv[i]; }
+    }
+}
+
+// R3D_P_RELOAD: the parameter block is read again for every strip (scalar loads from the constant cache) instead of living in ~50
+// scalar registers for the whole sweep, from where the allocator spilled it to vector lanes
+#ifndef R3D_P_RELOAD
+#define R3D_P_RELOAD 0
+#endif
+__device__ __forceinline__ const float* r3d_launder(const float* p) { asm volatile("" : "+s"(p)); return p; }
+#if R3D_P_RELOAD
+#define R3D_P(P) r3d_launder(P)
+#else
+#define R3D_P(P) (P)
+#endif
+#if R3D_ADJ_HALVES
+#define R3D_ADJ_STRIP adj_strip
+#else
+#define R3D_ADJ_STRIP adj_strip_whole
+#endif
 template <int NT>
 __global__ void __launch_bounds__(NT, 1)
 pi_adj3d_resident_kernel(const float* __restrict__ P, Args a, AdjArgs aa, unsigned long long* stamps)
@@ -710,20 +863,20 @@ pi_adj3d_resident_kernel(const float* __restrict__ P, Args a, AdjArgs aa, unsign
     }
     __syncthreads();
 
-    float mom[2][10];
+    MomSum mom[2][10];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int m = 0; m < 10; ++m) mom[s][m] = 0.f;
+        for (int m = 0; m < 10; ++m) mom[s][m] = mom_zero();
     double lane_c[2] = {0.0, 0.0};
     auto fold = [&]() {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int m = 0; m < 10; ++m) {
-                const float tot = wave_sum_to_last(mom[s][m]);
+                const float tot = wave_sum_to_last(mom_total(mom[s][m]));
                 if (lane == REDUCE_LANE) msum[wave * 20 + 10 * s + m] += (double)tot;
-                mom[s][m] = 0.f;
+                mom[s][m] = mom_zero();
             }
     };
 
@@ -747,7 +900,7 @@ pi_adj3d_resident_kernel(const float* __restrict__ P, Args a, AdjArgs aa, unsign
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s)
             if (s * NW + wave < WS) {
-                adj_strip(smem, lo_of(s), P, ops[s & 1], jcu, a.ss, go_of(s), ou[s], ov[s], mom, lane_c);
+                R3D_ADJ_STRIP(smem, lo_of(s), R3D_P(P), ops[s & 1], jcu, a.ss, go_of(s), ou[s], ov[s], mom, lane_c);
                 next_ops(s);
                 __builtin_amdgcn_sched_barrier(0);                      // one strip at a time: interleaved strips spill
                 stage_strip(smem, task(s), ou[s], ov[s]);
@@ -765,7 +918,7 @@ pi_adj3d_resident_kernel(const float* __restrict__ P, Args a, AdjArgs aa, unsign
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s)
             if (s * NW + wave >= WS) {
-                adj_strip(smem, lo_of(s), P, ops[s & 1], jcu, a.ss, go_of(s), ou[s], ov[s], mom, lane_c);
+                R3D_ADJ_STRIP(smem, lo_of(s), R3D_P(P), ops[s & 1], jcu, a.ss, go_of(s), ou[s], ov[s], mom, lane_c);
                 next_ops(s);
                 __builtin_amdgcn_sched_barrier(0);                      // one strip at a time: interleaved strips spill
             }
