@@ -2682,7 +2682,7 @@ struct FwdStoreMap {
                                         // bit-identical, lambda-omega forward 1.807 -> 1.838 us per step (they run under the ring's flight).  Off.
 #endif
 #ifndef PI_FWD_HALF_PYR
-#define PI_FWD_HALF_PYR 0
+#define PI_FWD_HALF_PYR 0                   // (float32: 1.239 -> 1.236 us per step, nothing)
 #endif
 #ifndef PI_FWD_HALF_STRIPS
 #define PI_FWD_HALF_STRIPS 1            // float32 resident forward: the annulus passes on two-point half-strips (all eight waves).
