@@ -407,7 +407,8 @@ int percnn_pi_debug_blockmap(int ndim, const int64_t* shape, int elem_size, cons
  * forward, bit 0: the tile sweep of a long rollout without frame mask runs as ONE launch of resident workgroups (option
  * tile_persist; asks the current device for its CU count -- 0 without a device), bit 1: so does its forward (fwd_persist)};
  * families: 0 direct step kernels,
- * 1 2D tile kernels, 2 3D plane streaming, 3 3D brick kernels, 4 advective block. */
+ * 1 2D tile kernels, 2 3D plane streaming, 3 3D brick kernels, 4 advective block.  (The lanes are those of the launch-per-group
+ * tile kernels; the resident launches of the 8- and 16-row regimes run twice as many on half-strips: fwd_small_half, adj_small_half.) */
 int percnn_pi_debug_plan(int hc, int ndim, const int64_t* shape, int elem_size, const char* options, int* out);
 
 size_t percnn_pi_peer_box_bytes(size_t slot_bytes);                 /* size of a mailbox allocation */
