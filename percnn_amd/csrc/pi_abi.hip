@@ -64,8 +64,12 @@ struct Options {
                             // entry point (PERCNN_PI_EASYNC) instead
     int fwd_small_half = 1;     // small-tile resident forward (32 x 8 tiles) on half-strips: 512 lanes, two waves per SIMD
     int adj_small_half = 1;     // small-tile resident sweep (32 x 8 tiles) on half-strips: 512 lanes, two waves per SIMD
-    int adj_small_pause = 24;   // ... of the small-tile resident SWEEP (100^2 1.53 -> 1.45 us per step, 256^2 1.93 -> 1.70: profiles/r05_small_tile_resident_forward.txt)
-    int fwd_small_pause = 12;   // small-tile resident forward: 64-clock units between publish and the first ring request (PersistArgs::pause)
+    // small-tile resident kernels: 64-clock units between publish and the first ring request (PersistArgs::pause); -1 = by tile count.
+    // Re-swept with the half-strip / pair-granule kernels of round 6 (us per step at pause 12 | 16 | 20 | 24 | 28 | 32):
+    //   forward  100^2 (52 tiles) .873 .867 .821 .819 .843 .871 | 160^2 .921 .916 .901 .886 .874 .874 | 256^2 .978 .941 .921 .865 .851 .878
+    //   sweep    100^2 1.159 1.145 1.123 1.130 1.155 1.182 | 160^2 1.216 1.206 1.201 1.183 1.179 1.206 | 256^2 1.539 1.517 1.480 1.432 1.373 1.377
+    int adj_small_pause = -1;   // -> 20 up to 64 tiles, 28 above
+    int fwd_small_pause = -1;   // -> 24 up to 64 tiles, 28 above
     int persist_small = 1;      // the 32 x 8-tile regime (grids below ~300^2, split schedule) as one persistent launch too
     int fwd_persist_per_cu = 1; // ... on grids of up to this many tiles per CU (1 or 2)
     int fwd_persist_f64 = 1;    // ... float64 too (lambda-omega; 16-byte granules)
@@ -1688,7 +1692,7 @@ hipError_t launch_adj_persist_small_t(const T* hframe_t, const T* gframe_t, T* a
     pa.timeout_ticks = (unsigned long long)p.opt.persist_timeout_ms * 100000ull;
     pa.first_timeout_ticks = (unsigned long long)p.opt.persist_first_timeout_ms * 100000ull;
     pa.t_top = t_top;
-    pa.pause = p.opt.adj_small_pause;
+    pa.pause = p.opt.adj_small_pause >= 0 ? p.opt.adj_small_pause : (grid <= 64 ? 20 : 28);
     pa.masked = mask ? 1 : 0;
     if (mask)
         for (int t = 0; t < t_top && t < 4096; ++t)
@@ -1850,7 +1854,7 @@ hipError_t launch_fwd_persist_small_t(T* frame_t0, int ngroups, const T* P, cons
     pa.host = const_cast<int*>(hs);
     pa.timeout_ticks = (unsigned long long)p.opt.persist_timeout_ms * 100000ull;             // 100 MHz clock
     pa.first_timeout_ticks = (unsigned long long)p.opt.persist_first_timeout_ms * 100000ull;
-    pa.pause = p.opt.fwd_small_pause;
+    pa.pause = p.opt.fwd_small_pause >= 0 ? p.opt.fwd_small_pause : (grid <= 64 ? 24 : 28);
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, frame_t0, frame_stride, P, g, pa);
     if (hipError_t e = hipGetLastError()) return e;
     {
@@ -2949,8 +2953,8 @@ int apply_option(Options& o, const char* key, long value)
     if (!std::strcmp(key, "slab_local_index")) { o.slab_local_index = value != 0; return 0; }
     if (!std::strcmp(key, "fwd_small_half")) { if (value < 0 || value > 1) return PERCNN_PI_EINVAL; o.fwd_small_half = (int)value; return 0; }
     if (!std::strcmp(key, "adj_small_half")) { if (value < 0 || value > 1) return PERCNN_PI_EINVAL; o.adj_small_half = (int)value; return 0; }
-    if (!std::strcmp(key, "adj_small_pause")) { if (value < 0 || value > 200) return PERCNN_PI_EINVAL; o.adj_small_pause = (int)value; return 0; }
-    if (!std::strcmp(key, "fwd_small_pause")) { if (value < 0 || value > 200) return PERCNN_PI_EINVAL; o.fwd_small_pause = (int)value; return 0; }
+    if (!std::strcmp(key, "adj_small_pause")) { if (value < -1 || value > 200) return PERCNN_PI_EINVAL; o.adj_small_pause = (int)value; return 0; }
+    if (!std::strcmp(key, "fwd_small_pause")) { if (value < -1 || value > 200) return PERCNN_PI_EINVAL; o.fwd_small_pause = (int)value; return 0; }
     if (!std::strcmp(key, "brick_xny")) { if (value < -1 || value > 8 || value == 3 || (value > 4 && value < 8)) return PERCNN_PI_EINVAL; o.brick_xny = (int)value; return 0; }
     if (!std::strcmp(key, "slab_fused_put")) { o.slab_fused_put = value != 0; return 0; }
     if (!std::strcmp(key, "peer_wire_us")) {

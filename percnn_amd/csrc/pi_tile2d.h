@@ -1615,6 +1615,84 @@ pi_adj2d_persist_kernel(const T* __restrict__ hframe_t, const T* __restrict__ gf
 // are recomputed there like a halo and never published.  Sub-steps = the device functions of pi_adj2d_tile_kernel<MOM = false>:
 // adjoint frames and dL/dh0 bit-identical.
 // ------------------------------------------------------------------------------------------------
+// Data-tagged granules by value type: ONE 16-byte write-through (sc1) store publishes a granule, ONE 16-byte sc1 load reads it
+// (requests are what a hand-over costs, not bytes).  float64 (round 5, configs[2]): {lo32, tag, hi32, tag} = one value as two
+// self-validating 8-byte words.  float32 (round 6): {value 0, tag, value 1, tag} = TWO x-adjacent values -- the 8-byte {tag, value}
+// words of rounds 3-5 cost a request per handed-over float (3 + 5 per lane and group; now 2 + 3), VERDICT r5 #2.  The reader
+// accepts when BOTH tags match, so a torn pair is just "not yet".  PI_GRANULE_PAIR=0 keeps the 8-byte float32 words (A/B builds of
+// the harnesses only; the library is built with pairs).
+#ifndef PI_GRANULE_PAIR
+#define PI_GRANULE_PAIR 1
+#endif
+typedef unsigned pi_v4u __attribute__((ext_vector_type(4)));
+template <typename T> struct GranuleIO;
+#if PI_GRANULE_PAIR
+template <> struct GranuleIO<float> {
+    using Raw = pi_v4u;
+    static constexpr int BYTES = 16, VALS = 2;
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ __forceinline__ GranuleIO(void* outbox, size_t bytes) : rs(__builtin_amdgcn_make_buffer_rsrc(outbox, 0, (int)bytes, 0x00020000)) {}
+    // src: the pair in LDS (8-byte aligned: even window column in either state buffer)
+    __device__ __forceinline__ void put(size_t idx, unsigned epoch, const float* src) const
+    {
+        const Pack<float, 2> v = ld<float, 2>(src);
+        const pi_v4u w = {__builtin_bit_cast(unsigned, v.v[0]), epoch, __builtin_bit_cast(unsigned, v.v[1]), epoch};
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)(idx * 16), 0, /*aux: sc1*/ 16);
+    }
+    __device__ __forceinline__ Raw get(size_t idx) const { return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(idx * 16), 0, 16); }
+    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return x.y == epoch && x.w == epoch; }
+    static __device__ __forceinline__ void land(Raw x, float* dst)
+    {
+        // (scalars first: __builtin_bit_cast applied to an element of an ext_vector read element 0 for every element -- hipcc 7.2)
+        const unsigned a = x.x, b = x.z;
+        st<float, 2>(dst, Pack<float, 2>{{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)}});
+    }
+};
+#else
+template <> struct GranuleIO<float> {
+    typedef __attribute__((address_space(1))) unsigned long long gu64;
+    using Raw = unsigned long long;
+    static constexpr int BYTES = 8, VALS = 1;
+    gu64* base;
+    __device__ __forceinline__ GranuleIO(void* outbox, size_t) : base((gu64*)outbox) {}
+    __device__ __forceinline__ void put(size_t idx, unsigned epoch, const float* src) const
+    {
+        __hip_atomic_store(base + idx, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, *src), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ Raw get(size_t idx) const { return __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return (unsigned)(x >> 32) == epoch; }
+    static __device__ __forceinline__ void land(Raw x, float* dst) { *dst = __builtin_bit_cast(float, (unsigned)x); }
+};
+#endif
+template <> struct GranuleIO<double> {
+    using Raw = pi_v4u;
+    static constexpr int BYTES = 16, VALS = 1;
+    __amdgpu_buffer_rsrc_t rs;
+    // (the descriptor is built from kernel arguments only: wave-uniform by construction)
+    __device__ __forceinline__ GranuleIO(void* outbox, size_t bytes) : rs(__builtin_amdgcn_make_buffer_rsrc(outbox, 0, (int)bytes, 0x00020000)) {}
+    __device__ __forceinline__ void put(size_t idx, unsigned epoch, const double* src) const
+    {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, *src);
+        const pi_v4u w = {(unsigned)b, epoch, (unsigned)(b >> 32), epoch};
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)(idx * 16), 0, /*aux: sc1*/ 16);
+    }
+    __device__ __forceinline__ Raw get(size_t idx) const { return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(idx * 16), 0, 16); }
+    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return x.y == epoch && x.w == epoch; }
+    static __device__ __forceinline__ void land(Raw x, double* dst) { *dst = __builtin_bit_cast(double, ((unsigned long long)x.z << 32) | x.x); }
+};
+
+// the granule of the small-tile resident kernels: pairs (GranuleIO<float>) or the 8-byte {tag, value} words of rounds 4-5
+template <typename T, bool PAIRS> struct SmallGranule {
+    using Raw = unsigned long long;
+    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return (unsigned)(x >> 32) == epoch; }
+    static __device__ __forceinline__ void land(Raw x, T* dst) { *dst = __builtin_bit_cast(T, (unsigned)x); }
+};
+template <typename T> struct SmallGranule<T, true> {
+    using Raw = typename GranuleIO<T>::Raw;
+    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return GranuleIO<T>::ok(x, epoch); }
+    static __device__ __forceinline__ void land(Raw x, T* dst) { GranuleIO<T>::land(x, dst); }
+};
 // HALFS (round 6): half-strips, NT = twice the lanes -- 7 | 5 | 4 | 2 waves busy in the four sub-steps of a 32 x 8 tile instead of
 // 4 | 3 | 2 | 1 (one per SIMD, each alone with its LDS latency), and half the granule requests per lane in the hand-over.
 template <typename T, int K, int BX, int BY, int NT, bool HALFS = false>
@@ -1628,7 +1706,12 @@ pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restric
     constexpr int HW = 2 * K, LXW = TL::LX, LYW = TL::LY;
     constexpr int OWN = BX * BY;                                         // values per species a tile publishes
     constexpr int RINGH = LXW * LYW - OWN;                               // halo values per species
-    constexpr int NPUB = (2 * OWN + NT - 1) / NT, NGAT = (2 * RINGH + NT - 1) / NT;
+    // PAIRS (round 6, with the half-strip kernels): the tile and its ring travel as 16-byte granules of two x-adjacent values
+    // (GranuleIO<float>) -- tile origins, the halo width and the grid width are even, so a pair never straddles two owners or the wrap
+    constexpr bool PAIRS = HALFS && GranuleIO<T>::VALS == 2;
+    constexpr int GV = PAIRS ? 2 : 1;
+    static_assert(OWN % (2 * GV) == 0 && RINGH % GV == 0 && BX % GV == 0 && HW % GV == 0, "granules of x-adjacent values");
+    constexpr int NPUB = (2 * OWN / GV + NT - 1) / NT, NGAT = (2 * RINGH / GV + NT - 1) / NT;
     constexpr bool PRE = PI_TILE_ADJ_PIPE && TL::region_n(0) / (HALFS ? 2 : 4) <= NT;
     static_assert(!HALFS || (PRE && PI_PERSIST_GEO != 0), "half-strips: prefetched operands, geometry words");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1641,6 +1724,7 @@ pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restric
     const int ntiles = g.tiles_x * tiles_y;
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     gu64* outbox = (gu64*)pa.outbox;
+    const GranuleIO<T> gio(pa.outbox, (size_t)2 * (size_t)ntiles * (2 * OWN) * 8);             // (PAIRS; same bytes either way)
     // LDS: state buffers | int tables | abort word
     int* tab_gl = reinterpret_cast<int*>(smem_raw + tile_state_bytes<T, K, BX, BY>());      // [NGAT][NT]: LDS position of a halo value
     int* tab_gs = tab_gl + NGAT * NT;                                                       // [NGAT][NT]: granule index inside a parity half
@@ -1674,8 +1758,8 @@ pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restric
     for (int q = 0; q < NGAT; ++q) {
         const int r = (int)threadIdx.x + q * NT;
         int gl = -1, gs = 0;
-        if (r < 2 * RINGH) {
-            const int sp = r / RINGH, e = r - sp * RINGH;
+        if (r < 2 * RINGH / GV) {
+            const int sp = r / (RINGH / GV), e = (r - sp * (RINGH / GV)) * GV;       // (e: first value of the granule)
             int wy, wx;                                    // ring positions row-major over the window, skipping the centre
             if (e < HW * LXW) { wy = e / LXW; wx = e - wy * LXW; }
             else if (e < HW * LXW + BY * 2 * HW) { const int m = e - HW * LXW; wy = HW + m / (2 * HW); const int c = m % (2 * HW); wx = c < HW ? c : BX + c; }
@@ -1685,7 +1769,7 @@ pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restric
             gx += gx < 0 ? g.W : 0;
             const int nty = gy / BY, ntx = gx / BX;
             gl = sp * TL::PLANE + wy * LXW + wx;
-            gs = (nty * g.tiles_x + ntx) * (2 * OWN) + sp * OWN + (gy - nty * BY) * BX + (gx - ntx * BX);
+            gs = ((nty * g.tiles_x + ntx) * (2 * OWN) + sp * OWN + (gy - nty * BY) * BX + (gx - ntx * BX)) / GV;
         }
         tab_gl[q * NT + (int)threadIdx.x] = gl;
         tab_gs[q * NT + (int)threadIdx.x] = gs;
@@ -1742,24 +1826,34 @@ pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restric
         const unsigned epoch = (unsigned)grp + 1u;
         gu64* half = outbox + (size_t)(epoch & 1u) * (size_t)ntiles * (2 * OWN);
         gu64* mine = half + (size_t)tile * (2 * OWN);
+        const size_t halfu = (size_t)(epoch & 1u) * (size_t)ntiles * (2 * OWN / GV);      // ... in granules (PAIRS)
 #pragma unroll
         for (int q = 0; q < NPUB; ++q) {
             const int i = (int)threadIdx.x + q * NT;
-            if (i < 2 * OWN) {
-                const int sp = i / OWN, e = i - sp * OWN, y = e / BX, x = e - y * BX;
-                const unsigned v = __builtin_bit_cast(unsigned, b0[sp * TL::PLANE + (HW + y) * LXW + HW + x]);
-                __hip_atomic_store(mine + i, ((unsigned long long)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i < 2 * OWN / GV) {
+                const int sp = i / (OWN / GV), e = (i - sp * (OWN / GV)) * GV, y = e / BX, x = e - y * BX;
+                const T* src = b0 + sp * TL::PLANE + (HW + y) * LXW + HW + x;
+                if constexpr (PAIRS) {
+                    gio.put(halfu + (size_t)tile * (2 * OWN / GV) + (size_t)i, epoch, src);
+                } else {
+                    const unsigned v = __builtin_bit_cast(unsigned, *src);
+                    __hip_atomic_store(mine + i, ((unsigned long long)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         tile_store<T, K, BX, BY, NT, true>(b0, aframe_t + gn, g, ty0, tx0);       // frame t - K of this group (buffer 0: K even)
         for (int w = 0; w < pa.pause; ++w) __builtin_amdgcn_s_sleep(1);            // (granules asked for too early come back stale)
         int gl[NGAT], gs[NGAT];
-        unsigned long long gx[NGAT];
+        typename SmallGranule<T, PAIRS>::Raw gx[NGAT];
+        auto fetch = [&](int idx) {
+            if constexpr (PAIRS) return gio.get(halfu + (size_t)idx);
+            else return __hip_atomic_load(half + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
 #pragma unroll
         for (int q = 0; q < NGAT; ++q) {
             gl[q] = tab_gl[q * NT + (int)threadIdx.x];
             gs[q] = tab_gs[q * NT + (int)threadIdx.x];
-            gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (lanes without: granule 0)
+            gx[q] = fetch(gs[q]);                                                                     // (lanes without: granule 0)
         }
         const unsigned long long t0 = wall_clock64();
         const unsigned long long bound = grp == 0 ? pa.first_timeout_ticks : pa.timeout_ticks;
@@ -1767,22 +1861,21 @@ pi_adj2d_persist_small_kernel(const T* __restrict__ hframe_t, const T* __restric
             bool ok = true;
 #pragma unroll
             for (int q = 0; q < NGAT; ++q)
-                if (gl[q] >= 0) ok &= (unsigned)(gx[q] >> 32) == epoch;
+                if (gl[q] >= 0) ok &= SmallGranule<T, PAIRS>::ok(gx[q], epoch);
             if (__all(ok)) break;
             if (wall_clock64() - t0 > bound ||
                 __hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { failed = true; break; }
             __builtin_amdgcn_s_sleep(1);
 #pragma unroll
             for (int q = 0; q < NGAT; ++q)                      // only what has not arrived yet is asked for again
-                if (gl[q] >= 0 && (unsigned)(gx[q] >> 32) != epoch)
-                    gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (gl[q] >= 0 && !SmallGranule<T, PAIRS>::ok(gx[q], epoch)) gx[q] = fetch(gs[q]);
         }
         if (failed) {
             if (threadIdx.x % WAVE == 0) *wg_abort = 1;
         } else {
 #pragma unroll
             for (int q = 0; q < NGAT; ++q)
-                if (gl[q] >= 0) b0[gl[q]] = __builtin_bit_cast(T, (unsigned)gx[q]);
+                if (gl[q] >= 0) SmallGranule<T, PAIRS>::land(gx[q], b0 + gl[q]);
         }
         lds_barrier();
         if (*wg_abort) {
@@ -1869,73 +1962,6 @@ __device__ __forceinline__ void persist_load_ops(StripOps<T>& o, const T* __rest
     o.ju[0] = a2.v[0]; o.ju[1] = a2.v[1]; o.ju[2] = b2.v[0]; o.ju[3] = b2.v[1];
     o.jv[0] = c2.v[0]; o.jv[1] = c2.v[1]; o.jv[2] = d2.v[0]; o.jv[3] = d2.v[1];
 }
-
-// Data-tagged granules by value type: ONE 16-byte write-through (sc1) store publishes a granule, ONE 16-byte sc1 load reads it
-// (requests are what a hand-over costs, not bytes).  float64 (round 5, configs[2]): {lo32, tag, hi32, tag} = one value as two
-// self-validating 8-byte words.  float32 (round 6): {value 0, tag, value 1, tag} = TWO x-adjacent values -- the 8-byte {tag, value}
-// words of rounds 3-5 cost a request per handed-over float (3 + 5 per lane and group; now 2 + 3), VERDICT r5 #2.  The reader
-// accepts when BOTH tags match, so a torn pair is just "not yet".  PI_GRANULE_PAIR=0 keeps the 8-byte float32 words (A/B builds of
-// the harnesses only; the library is built with pairs).
-#ifndef PI_GRANULE_PAIR
-#define PI_GRANULE_PAIR 1
-#endif
-typedef unsigned pi_v4u __attribute__((ext_vector_type(4)));
-template <typename T> struct GranuleIO;
-#if PI_GRANULE_PAIR
-template <> struct GranuleIO<float> {
-    using Raw = pi_v4u;
-    static constexpr int BYTES = 16, VALS = 2;
-    __amdgpu_buffer_rsrc_t rs;
-    __device__ __forceinline__ GranuleIO(void* outbox, size_t bytes) : rs(__builtin_amdgcn_make_buffer_rsrc(outbox, 0, (int)bytes, 0x00020000)) {}
-    // src: the pair in LDS (8-byte aligned: even window column in either state buffer)
-    __device__ __forceinline__ void put(size_t idx, unsigned epoch, const float* src) const
-    {
-        const Pack<float, 2> v = ld<float, 2>(src);
-        const pi_v4u w = {__builtin_bit_cast(unsigned, v.v[0]), epoch, __builtin_bit_cast(unsigned, v.v[1]), epoch};
-        __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)(idx * 16), 0, /*aux: sc1*/ 16);
-    }
-    __device__ __forceinline__ Raw get(size_t idx) const { return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(idx * 16), 0, 16); }
-    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return x.y == epoch && x.w == epoch; }
-    static __device__ __forceinline__ void land(Raw x, float* dst)
-    {
-        // (scalars first: __builtin_bit_cast applied to an element of an ext_vector read element 0 for every element -- hipcc 7.2)
-        const unsigned a = x.x, b = x.z;
-        st<float, 2>(dst, Pack<float, 2>{{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)}});
-    }
-};
-#else
-template <> struct GranuleIO<float> {
-    typedef __attribute__((address_space(1))) unsigned long long gu64;
-    using Raw = unsigned long long;
-    static constexpr int BYTES = 8, VALS = 1;
-    gu64* base;
-    __device__ __forceinline__ GranuleIO(void* outbox, size_t) : base((gu64*)outbox) {}
-    __device__ __forceinline__ void put(size_t idx, unsigned epoch, const float* src) const
-    {
-        __hip_atomic_store(base + idx, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, *src), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __device__ __forceinline__ Raw get(size_t idx) const { return __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return (unsigned)(x >> 32) == epoch; }
-    static __device__ __forceinline__ void land(Raw x, float* dst) { *dst = __builtin_bit_cast(float, (unsigned)x); }
-};
-#endif
-template <> struct GranuleIO<double> {
-    using Raw = pi_v4u;
-    static constexpr int BYTES = 16, VALS = 1;
-    __amdgpu_buffer_rsrc_t rs;
-    // (the descriptor is built from kernel arguments only: wave-uniform by construction)
-    __device__ __forceinline__ GranuleIO(void* outbox, size_t bytes) : rs(__builtin_amdgcn_make_buffer_rsrc(outbox, 0, (int)bytes, 0x00020000)) {}
-    __device__ __forceinline__ void put(size_t idx, unsigned epoch, const double* src) const
-    {
-        const unsigned long long b = __builtin_bit_cast(unsigned long long, *src);
-        const pi_v4u w = {(unsigned)b, epoch, (unsigned)(b >> 32), epoch};
-        __builtin_amdgcn_raw_buffer_store_b128(w, rs, (int)(idx * 16), 0, /*aux: sc1*/ 16);
-    }
-    __device__ __forceinline__ Raw get(size_t idx) const { return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(idx * 16), 0, 16); }
-    static __device__ __forceinline__ bool ok(Raw x, unsigned epoch) { return x.y == epoch && x.w == epoch; }
-    static __device__ __forceinline__ void land(Raw x, double* dst) { *dst = __builtin_bit_cast(double, ((unsigned long long)x.z << 32) | x.x); }
-};
 
 // The hand-over tables of the 32 x 32 resident kernels, in units of one granule (GV = values per granule, x-adjacent): a tile's
 // border band of width HW is numbered by band_index (rows of B, then rows of 2 HW values: even x <-> even index), the halo ring
@@ -2986,7 +3012,10 @@ pi_fwd2d_persist_small_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K
     constexpr int HW = 2 * K, LXW = TL::LX, LYW = TL::LY;
     constexpr int OWN = BX * BY;                                         // values per species a tile publishes
     constexpr int RINGH = LXW * LYW - OWN;                               // halo values per species
-    constexpr int NPUB = (2 * OWN + NT - 1) / NT, NGAT = (2 * RINGH + NT - 1) / NT;
+    constexpr bool PAIRS = HALFS && GranuleIO<T>::VALS == 2;            // (as in pi_adj2d_persist_small_kernel)
+    constexpr int GV = PAIRS ? 2 : 1;
+    static_assert(OWN % (2 * GV) == 0 && RINGH % GV == 0 && BX % GV == 0 && HW % GV == 0, "granules of x-adjacent values");
+    constexpr int NPUB = (2 * OWN / GV + NT - 1) / NT, NGAT = (2 * RINGH / GV + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* b0 = reinterpret_cast<T*>(smem_raw) + lds_pad0<T>::value;
     T* b1 = reinterpret_cast<T*>(smem_raw) + 2 * TL::PLANE + lds_pad1<T>::value;
@@ -2997,6 +3026,7 @@ pi_fwd2d_persist_small_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K
     const int ntiles = g.tiles_x * tiles_y;
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     gu64* outbox = (gu64*)pa.outbox;
+    const GranuleIO<T> gio(pa.outbox, (size_t)2 * (size_t)ntiles * (2 * OWN) * 8);             // (PAIRS; same bytes either way)
     // LDS: state buffers | gather tables | abort word
     int* tab_gl = reinterpret_cast<int*>(smem_raw + tile_state_bytes<T, K, BX, BY>());      // [NGAT][NT]: LDS position of a halo value
     int* tab_gs = tab_gl + NGAT * NT;                                                       // [NGAT][NT]: granule index inside a parity half
@@ -3023,8 +3053,8 @@ pi_fwd2d_persist_small_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K
     for (int q = 0; q < NGAT; ++q) {                       // (the tables of pi_adj2d_persist_small_kernel)
         const int r = (int)threadIdx.x + q * NT;
         int gl = -1, gs = 0;
-        if (r < 2 * RINGH) {
-            const int sp = r / RINGH, e = r - sp * RINGH;
+        if (r < 2 * RINGH / GV) {
+            const int sp = r / (RINGH / GV), e = (r - sp * (RINGH / GV)) * GV;       // (e: first value of the granule)
             int wy, wx;                                    // ring positions row-major over the window, skipping the centre
             if (e < HW * LXW) { wy = e / LXW; wx = e - wy * LXW; }
             else if (e < HW * LXW + BY * 2 * HW) { const int m = e - HW * LXW; wy = HW + m / (2 * HW); const int c = m % (2 * HW); wx = c < HW ? c : BX + c; }
@@ -3034,7 +3064,7 @@ pi_fwd2d_persist_small_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K
             gx += gx < 0 ? g.W : 0;
             const int nty = gy / BY, ntx = gx / BX;
             gl = sp * TL::PLANE + wy * LXW + wx;
-            gs = (nty * g.tiles_x + ntx) * (2 * OWN) + sp * OWN + (gy - nty * BY) * BX + (gx - ntx * BX);
+            gs = ((nty * g.tiles_x + ntx) * (2 * OWN) + sp * OWN + (gy - nty * BY) * BX + (gx - ntx * BX)) / GV;
         }
         tab_gl[q * NT + (int)threadIdx.x] = gl;
         tab_gs[q * NT + (int)threadIdx.x] = gs;
@@ -3076,24 +3106,34 @@ pi_fwd2d_persist_small_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K
         const unsigned epoch = (unsigned)grp + 1u;
         gu64* half = outbox + (size_t)(epoch & 1u) * (size_t)ntiles * (2 * OWN);
         gu64* mine = half + (size_t)tile * (2 * OWN);
+        const size_t halfu = (size_t)(epoch & 1u) * (size_t)ntiles * (2 * OWN / GV);      // ... in granules (PAIRS)
 #pragma unroll
         for (int q = 0; q < NPUB; ++q) {
             const int i = tid + q * NT;
-            if (i < 2 * OWN) {
-                const int sp = i / OWN, e = i - sp * OWN, y = e / BX, x = e - y * BX;
-                const unsigned v = __builtin_bit_cast(unsigned, b0[sp * TL::PLANE + (HW + y) * LXW + HW + x]);
-                __hip_atomic_store(mine + i, ((unsigned long long)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i < 2 * OWN / GV) {
+                const int sp = i / (OWN / GV), e = (i - sp * (OWN / GV)) * GV, y = e / BX, x = e - y * BX;
+                const T* src = b0 + sp * TL::PLANE + (HW + y) * LXW + HW + x;
+                if constexpr (PAIRS) {
+                    gio.put(halfu + (size_t)tile * (2 * OWN / GV) + (size_t)i, epoch, src);
+                } else {
+                    const unsigned v = __builtin_bit_cast(unsigned, *src);
+                    __hip_atomic_store(mine + i, ((unsigned long long)epoch << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         tile_store<T, K, BX, BY, NT, true, WT>(b0, fr + (long)K * frame_stride, g, ty0, tx0);
         for (int w = 0; w < pa.pause; ++w) __builtin_amdgcn_s_sleep(1);
         int gl[NGAT], gs[NGAT];
-        unsigned long long gx[NGAT];
+        typename SmallGranule<T, PAIRS>::Raw gx[NGAT];
+        auto fetch = [&](int idx) {
+            if constexpr (PAIRS) return gio.get(halfu + (size_t)idx);
+            else return __hip_atomic_load(half + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
 #pragma unroll
         for (int q = 0; q < NGAT; ++q) {
             gl[q] = tab_gl[q * NT + tid];
             gs[q] = tab_gs[q * NT + tid];
-            gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (lanes without: granule 0)
+            gx[q] = fetch(gs[q]);                                                                     // (lanes without: granule 0)
         }
         const unsigned long long t0 = wall_clock64();
         const unsigned long long bound = grp == 0 ? pa.first_timeout_ticks : pa.timeout_ticks;
@@ -3102,22 +3142,21 @@ pi_fwd2d_persist_small_kernel(T* __restrict__ frames /* frame t0; t0+1 .. t0 + K
             bool ok = true;
 #pragma unroll
             for (int q = 0; q < NGAT; ++q)
-                if (gl[q] >= 0) ok &= (unsigned)(gx[q] >> 32) == epoch;
+                if (gl[q] >= 0) ok &= SmallGranule<T, PAIRS>::ok(gx[q], epoch);
             if (__all(ok)) break;
             if (wall_clock64() - t0 > bound ||
                 __hip_atomic_load(pa.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { failed = true; break; }
             __builtin_amdgcn_s_sleep(1);
 #pragma unroll
             for (int q = 0; q < NGAT; ++q)                      // only what has not arrived yet is asked for again
-                if (gl[q] >= 0 && (unsigned)(gx[q] >> 32) != epoch)
-                    gx[q] = __hip_atomic_load(half + gs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (gl[q] >= 0 && !SmallGranule<T, PAIRS>::ok(gx[q], epoch)) gx[q] = fetch(gs[q]);
         }
         if (failed) {
             if (threadIdx.x % WAVE == 0) *wg_abort = 1;
         } else {
 #pragma unroll
             for (int q = 0; q < NGAT; ++q)
-                if (gl[q] >= 0) b0[gl[q]] = __builtin_bit_cast(T, (unsigned)gx[q]);
+                if (gl[q] >= 0) SmallGranule<T, PAIRS>::land(gx[q], b0 + gl[q]);
         }
         lds_barrier();
         if (*wg_abort) {
