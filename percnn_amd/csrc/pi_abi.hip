@@ -1734,6 +1734,20 @@ hipError_t launch_adj_persist_small_t(const T* hframe_t, const T* gframe_t, T* a
 // ---- small-tile / ragged resident FORWARD (pi_fwd2d_persist_small_kernel) ------------------------------------------------------
 // tile height the resident small forward runs on: what the launch-per-group forward would use (8 / 16 rows), or 32 rows for the
 // grids the 32 x 32 resident forward does not take (ragged, fewer than 16 tiles); 0 = not this path
+// Grids of 113 .. 128 whole 32 x 32 tiles, where round 5 moved the SWEEP from 16-row to 32-row tiles (tile_by_for): since the
+// 16-row resident forward works on half-strips and pair granules it beats the 32 x 32 resident forward there (us per step: 256 x 512
+// 1.20 -> 1.01, 384 x 320 1.20 -> 1.01, 352^2 1.33 -> 1.20) while the 32-row sweep still wins (1.93 vs 2.04): the forward alone
+// takes 16 rows.  Every kernel's trajectory is the same bit for bit.
+template <typename T>
+bool fwd_prefers_16_rows(const Problem& p)
+{
+    if (sizeof(T) != 4 || !p.opt.persist_small || !p.opt.fwd_small_half || p.opt.tile_by != 0 || p.hc != 0) return false;
+    if (p.n0 % TILE_B || p.W % TILE_B || tile_by_for(p) != TILE_B) return false;
+    const int64_t tiles32 = (p.n0 / TILE_B) * (p.W / TILE_B), tiles16 = (p.n0 / 16) * (p.W / TILE_B);
+    const int cus = device_cu_count();
+    return tiles32 > 112 && tiles32 <= 128 && cus > 0 && tiles16 <= std::min<int64_t>(cus, 256);
+}
+
 template <typename T>
 int fwd_persist_small_by(const Problem& p, int ngroups, hipStream_t st)
 {
@@ -2449,11 +2463,11 @@ int rollout_fwd_impl(T* traj, const T* P, int hc, int ndim, const int64_t* shape
             // ... and the grids the 32 x 32 flavour does not take -- small-tile regime, ragged grids, fewer than 16 tiles -- on
             // pi_fwd2d_persist_small_kernel (round 5; float32)
             int small_by = 0;
-            if constexpr (sizeof(T) == 4) small_by = big ? 0 : fwd_persist_small_by<T>(p, ngroups, st);
+            if constexpr (sizeof(T) == 4) small_by = big ? (fwd_prefers_16_rows<T>(p) ? 16 : 0) : fwd_persist_small_by<T>(p, ngroups, st);
             if ((big || small_by) && persist_enter(st, pdev)) {
                 hipError_t e;
                 if constexpr (sizeof(T) == 4)
-                    e = big ? launch_fwd_persist<T>(traj, ngroups, P, p, pdev, st)
+                    e = (big && !small_by) ? launch_fwd_persist<T>(traj, ngroups, P, p, pdev, st)
                             : launch_fwd_persist_small<T>(small_by, traj, ngroups, P, p, pdev, st);
                 else
                     e = launch_fwd_persist<T>(traj, ngroups, P, p, pdev, st);
