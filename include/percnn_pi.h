@@ -212,12 +212,12 @@ size_t percnn_pi_rollout_bwd_workspace_bytes(int hc, int ndim, const int64_t *sh
  *                  its granule outbox is part of percnn_pi_rollout_bwd_workspace_bytes); 0: one launch per four steps
  *                  Round 5: the FORWARD of that regime too (pi_fwd2d_persist_small_kernel, 32 x 8 tiles, T >= 32; gated by
  *                  "fwd_persist" as well; scratch from the per-device granule outbox of the resident forward); round 6: 32 x 16 tiles
- *                  too (with "fwd_small_half").  2: also ragged 32 x 32 grids and up to 2 x "fwd_persist_per_cu" workgroups per
- *                  CU (measured slower than one launch per four steps: tests and experiments only)
- *   "fwd_small_pause"  -1 .. 200, default -1 (24 up to 64 tiles, 28 above): units of 64 clocks the small-tile resident forward waits between publishing its tile
+ *                  too and ragged grids of 32 x 32 tiles too (with "fwd_small_half").  2: up to 2 x "fwd_persist_per_cu" workgroups per CU
+ *                  (tests and experiments only)
+ *   "fwd_small_pause"  -1 .. 200, default -1 (24 up to 64 tiles, 28 above, 52 for 32-row tiles): units of 64 clocks the small-tile resident forward waits between publishing its tile
  *                  and the first request of its ring (granules asked for too early come back stale)
  *   "fwd_small_half"   0 | 1, default 1: the small-tile resident forward works its tiles on two-point half-strips (512 lanes at
- *                  32 x 8, 640 at 32 x 16) and hands them over as 16-byte granules of two values; 0: round 5's kernels
+ *                  32 x 8, 640 at 32 x 16, 1024 at 32 x 32) and hands them over as 16-byte granules of two values; 0: round 5's kernels
  *   "adj_small_half"   0 | 1, default 1: the same for the small-tile resident sweep
  *   "adj_small_pause"  -1 .. 200, default -1 (20 up to 64 tiles, 28 above): the same for the small-tile resident sweep
  *   "fwd_persist"  1 (default): the FORWARD rollout of a grid the persistent sweep takes (float32 pre-contracted block, whole

@@ -1763,8 +1763,9 @@ int fwd_persist_small_by(const Problem& p, int ngroups, hipStream_t st)
     // persist_small = 2 takes the others too (tests)
     // Round 6, half-strips (twice the lanes, both waves of a SIMD busy): 32 x 8 tiles 100^2 1.05 -> 0.93, 256^2 1.08 -> 1.01; 32 x 16
     // tiles 288^2 1.53 -> 1.12, 300 x 320 1.47 -> 1.22, 260^2 1.43 -> 1.12 -> the 16-row regime joins the default; ragged 32 x 32
-    // tiles (500^2: 1.90 -> 2.49) stay on the launch-per-group kernel
-    const bool by_default = by == 8 || (by == 16 && p.opt.fwd_small_half);
+    // tiles (500^2: 1.90 -> 2.49) stay on the launch-per-group kernel -- until the same kernel on 1024 lanes (half-strips, pair granules,
+    // a longer pause): 500^2 1.93 -> 1.60: default as well.  (512^2 on it: 1.40 against the 32 x 32 pyramid kernel's 1.35.)
+    const bool by_default = by == 8 || ((by == 16 || by == TILE_B) && p.opt.fwd_small_half);
     if (!by_default && p.opt.persist_small < 2) return 0;
     const int64_t tiles = ((p.n0 + by - 1) / by) * ((p.W + TILE_B - 1) / TILE_B);
     const int cus = device_cu_count();
@@ -1868,7 +1869,8 @@ hipError_t launch_fwd_persist_small_t(T* frame_t0, int ngroups, const T* P, cons
     pa.host = const_cast<int*>(hs);
     pa.timeout_ticks = (unsigned long long)p.opt.persist_timeout_ms * 100000ull;             // 100 MHz clock
     pa.first_timeout_ticks = (unsigned long long)p.opt.persist_first_timeout_ms * 100000ull;
-    pa.pause = p.opt.fwd_small_pause >= 0 ? p.opt.fwd_small_pause : (grid <= 64 ? 24 : 28);
+    // (32-row tiles -- ragged grids -- at pause 28 | 40 | 48 | 56 | 64 | 80: 500^2 1.77 1.66 1.60 1.57 1.61 1.73, 400^2 1.54 1.51 1.49 1.49 1.56 1.71)
+    pa.pause = p.opt.fwd_small_pause >= 0 ? p.opt.fwd_small_pause : (BY == TILE_B ? 52 : (grid <= 64 ? 24 : 28));
     hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, frame_t0, frame_stride, P, g, pa);
     if (hipError_t e = hipGetLastError()) return e;
     {
@@ -1887,6 +1889,7 @@ hipError_t launch_fwd_persist_small(int by, T* frame_t0, int ngroups, const T* P
     if (by == 8) return launch_fwd_persist_small_t<T, 8, 256>(frame_t0, ngroups, P, p, dev, st);
     if (by == 16 && p.opt.fwd_small_half) return launch_fwd_persist_small_t<T, 16, 640, true>(frame_t0, ngroups, P, p, dev, st);
     if (by == 16) return launch_fwd_persist_small_t<T, 16, 320>(frame_t0, ngroups, P, p, dev, st);
+    if (p.opt.fwd_small_half) return launch_fwd_persist_small_t<T, TILE_B, 1024, true>(frame_t0, ngroups, P, p, dev, st);
     return launch_fwd_persist_small_t<T, TILE_B, 512>(frame_t0, ngroups, P, p, dev, st);
 }
 

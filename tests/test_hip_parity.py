@@ -1035,9 +1035,8 @@ def test_small_tile_persistent_forward_equals_launch_per_group(shape, T, hip_dev
     stay on launches, `fwd_persist=0` is the old path, no aborts."""
     import percnn_amd as pa
     from percnn_amd import _lib
-    # by default the 8- and (round 6, on half-strips) 16-row regimes (ragged 32 x 32 tiles measured slower than one launch per
-    # group); persist_small = 2 takes them all
-    small8 = _lib.rollout_plan(0, shape, 4)["tile_fwd"] in ((32, 8, 256), (32, 16, 320))
+    # by default the 8-row regime and (round 6, on half-strips: 640 / 1024 lanes) the 16-row one and ragged grids of 32 x 32 tiles
+    small8 = _lib.rollout_plan(0, shape, 4)["tile_fwd"] in ((32, 8, 256), (32, 16, 320), (32, 32, 512))
     opt = {} if small8 else {"persist_small": 2}
     ostr = "" if small8 else "persist_small=2"
     assert _lib.rollout_plan(0, shape, 4, ostr or None)["fwd_persistent"] and _lib.rollout_plan(0, shape, 4)["fwd_persistent"] == small8
